@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REFERENCE = "/root/reference/node_classification_clean"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` tests are skipped (not failed) on a box without a GPU when selected by accident."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return load
+
+
+@pytest.fixture(scope="session")
+def reference_modules():
+    """The live reference layers (only in the build container); tests using it auto-skip elsewhere."""
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("/root/reference not present")
+    sys.path.insert(0, REFERENCE)
+    try:
+        import ekan as ref_ekan
+        import fastkan as ref_fastkan
+    finally:
+        sys.path.remove(REFERENCE)
+    return ref_ekan, ref_fastkan

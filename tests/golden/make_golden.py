@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (``/root/reference`` present):
+
+    python tests/golden/make_golden.py
+
+The reference's pure-torch layers ``node_classification_clean/ekan.py`` and ``fastkan.py``
+are imported read-only and driven on seeded inputs; inputs, parameters, outputs and all
+gradients are stored as ``.npz`` (data only -- no reference source travels).  The message
+passing around them (GIN / GCN / GINE / pool) is third-party torch_geometric, absent here, so
+those fixtures combine ``oracle.kan_oracle``'s restated aggregation with the reference's KAN
+modules -- they pin the *composition*, and are flagged
+"parity unpinned" for the aggregation semantics themselves.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/node_classification_clean"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+import ekan as ref_ekan          # noqa: E402  (reference, read-only)
+import fastkan as ref_fastkan    # noqa: E402
+from oracle import kan_oracle as orc  # noqa: E402
+
+torch.set_num_threads(1)  # deterministic reduction order in the fixtures
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def special_points(knots_row: torch.Tensor) -> torch.Tensor:
+    """every knot, knot +- 1ulp, midpoints, just outside the range, 0, NaN, +-Inf."""
+    k = knots_row.to(torch.float32)
+    up = torch.nextafter(k, torch.full_like(k, float("inf")))
+    dn = torch.nextafter(k, torch.full_like(k, float("-inf")))
+    mid = (k[:-1] + k[1:]) / 2
+    extra = torch.tensor([k[0] - 0.1, k[-1] + 0.1, 0.0, 0.123456, -0.987654,
+                          float("nan"), float("inf"), float("-inf")])
+    return torch.cat([k, up, dn, mid, extra])
+
+
+def mixed_inputs(n, f, knots_row, gen):
+    """N(0, 0.8^2) body with exact knots and out-of-range values sprinkled in."""
+    x = torch.randn(n, f, generator=gen) * 0.8
+    flat = x.view(-1)
+    idx = torch.randperm(flat.numel(), generator=gen)[: max(4, flat.numel() // 50)]
+    pool = torch.cat([knots_row, torch.tensor([knots_row[0] - 0.5, knots_row[-1] + 0.7, 0.0])])
+    flat[idx] = pool[torch.randint(0, pool.numel(), (idx.numel(),), generator=gen)]
+    return x
+
+
+# ---------------------------------------------------------------- G1: b_splines table
+def g1():
+    out = {}
+    for (G, k) in [(5, 3), (4, 3), (8, 3), (1, 1), (2, 1), (8, 4), (32, 4), (3, 2)]:
+        layer = ref_ekan.KANLinear(2, 1, grid_size=G, spline_order=k)
+        pts = special_points(layer.grid[0])
+        x = torch.stack([pts, pts.flip(0)], dim=1)
+        with torch.no_grad():
+            b = layer.b_splines(x)
+        out[f"x_G{G}_k{k}"] = npy(x)
+        out[f"grid_G{G}_k{k}"] = npy(layer.grid)
+        out[f"bases_G{G}_k{k}"] = npy(b)
+    save("g1_bsplines", **out)
+
+
+# ---------------------------------------------------------------- G2: KANLinear fwd+bwd
+def g2():
+    out = {}
+    shapes = [(64, 64, 5, 3), (128, 32, 5, 3), (48, 40, 8, 3), (7, 5, 1, 1), (3, 2, 2, 1),
+              (16, 16, 8, 4), (33, 17, 4, 3), (40, 24, 3, 2)]
+    for i, (fi, fo, G, k) in enumerate(shapes):
+        torch.manual_seed(100 + i)
+        layer = ref_ekan.KANLinear(fi, fo, grid_size=G, spline_order=k)
+        gen = torch.Generator().manual_seed(200 + i)
+        x = mixed_inputs(257, fi, layer.grid[0], gen).requires_grad_(True)
+        gy = torch.randn(257, fo, generator=gen)
+        y = layer(x)
+        y.backward(gy)
+        tag = f"{fi}_{fo}_{G}_{k}"
+        out[f"shape_{i}"] = np.array([fi, fo, G, k])
+        for kname, v in layer.state_dict().items():
+            out[f"{tag}.{kname}"] = npy(v)
+        out[f"{tag}.x"] = npy(x)
+        out[f"{tag}.gy"] = npy(gy)
+        out[f"{tag}.y"] = npy(y)
+        out[f"{tag}.gx"] = npy(x.grad)
+        out[f"{tag}.g_base_weight"] = npy(layer.base_weight.grad)
+        out[f"{tag}.g_spline_weight"] = npy(layer.spline_weight.grad)
+        out[f"{tag}.g_spline_scaler"] = npy(layer.spline_scaler.grad)
+    save("g2_kanlinear", **out)
+
+
+# ---------------------------------------------------------------- G3: KAN chains
+def g3():
+    out = {}
+    for i, (sizes, G, k) in enumerate([([128, 32, 32], 5, 3), ([64, 64, 64], 5, 3), ([10, 6, 3], 4, 3)]):
+        torch.manual_seed(300 + i)
+        net = ref_ekan.KAN(sizes, grid_size=G, spline_order=k)
+        gen = torch.Generator().manual_seed(310 + i)
+        x = (torch.randn(193, sizes[0], generator=gen) * 0.6).requires_grad_(True)
+        gy = torch.randn(193, sizes[-1], generator=gen)
+        y = net(x)
+        y.backward(gy)
+        tag = "kan_" + "_".join(map(str, sizes))
+        out[f"cfg_{i}"] = np.array(sizes + [G, k])
+        for kname, v in net.state_dict().items():
+            out[f"{tag}.{kname}"] = npy(v)
+        for pname, p in net.named_parameters():
+            out[f"{tag}.grad.{pname}"] = npy(p.grad)
+        out[f"{tag}.x"] = npy(x)
+        out[f"{tag}.gy"] = npy(gy)
+        out[f"{tag}.y"] = npy(y)
+        out[f"{tag}.gx"] = npy(x.grad)
+    save("g3_kan_chain", **out)
+
+
+# ---------------------------------------------------------------- G4: FastKAN
+def g4():
+    out = {}
+    for i, (fi, fo, ng) in enumerate([(64, 64, 8), (128, 48, 4), (5, 3, 2), (200, 40, 4), (64, 32, 5)]):
+        torch.manual_seed(400 + i)
+        layer = ref_fastkan.FastKANLayer(fi, fo, num_grids=ng)
+        with torch.no_grad():  # non-trivial affine so the LN grads are exercised
+            layer.layernorm.weight.uniform_(0.5, 1.5)
+            layer.layernorm.bias.uniform_(-0.3, 0.3)
+        gen = torch.Generator().manual_seed(410 + i)
+        x = (torch.randn(131, fi, generator=gen) * 1.3 + 0.2).requires_grad_(True)
+        gy = torch.randn(131, fo, generator=gen)
+        y = layer(x)
+        y.backward(gy)
+        tag = f"fk_{fi}_{fo}_{ng}"
+        out[f"shape_{i}"] = np.array([fi, fo, ng])
+        for kname, v in layer.state_dict().items():
+            out[f"{tag}.{kname}"] = npy(v)
+        for pname, p in layer.named_parameters():
+            if p.grad is not None:
+                out[f"{tag}.grad.{pname}"] = npy(p.grad)
+        out[f"{tag}.x"] = npy(x)
+        out[f"{tag}.gy"] = npy(gy)
+        out[f"{tag}.y"] = npy(y)
+        out[f"{tag}.gx"] = npy(x.grad)
+    torch.manual_seed(450)
+    net = ref_fastkan.FastKAN([48, 72, 24], num_grids=4)
+    gen = torch.Generator().manual_seed(451)
+    x = torch.randn(97, 48, generator=gen).requires_grad_(True)
+    gy = torch.randn(97, 24, generator=gen)
+    y = net(x)
+    y.backward(gy)
+    tag = "fastkan_48_72_24"
+    for kname, v in net.state_dict().items():
+        out[f"{tag}.{kname}"] = npy(v)
+    for pname, p in net.named_parameters():
+        if p.grad is not None:
+            out[f"{tag}.grad.{pname}"] = npy(p.grad)
+    out[f"{tag}.x"], out[f"{tag}.gy"], out[f"{tag}.y"], out[f"{tag}.gx"] = npy(x), npy(gy), npy(y), npy(x.grad)
+    save("g4_fastkan", **out)
+
+
+# ---------------------------------------------------------------- graphs for G5-G8
+def small_graph(gen, n=300, e=2000):
+    """isolated nodes, self-loops, duplicate edges and one hub."""
+    src = torch.randint(0, n - 20, (e,), generator=gen)     # last 20 nodes never send
+    dst = torch.randint(10, n - 10, (e,), generator=gen)    # first/last 10 never receive
+    dst[:400] = 42                                          # hub
+    src[400:420] = dst[400:420]                             # self loops
+    src[420:440], dst[420:440] = src[440:460], dst[440:460]  # duplicates
+    p = torch.randperm(e, generator=gen)
+    return torch.stack([src[p], dst[p]])
+
+
+def g5_g6_g7():
+    out5, out6, out7 = {}, {}, {}
+    gen = torch.Generator().manual_seed(500)
+    graphs = {"small": (small_graph(gen), 300), "plaw": (orc.powerlaw_graph(1000, 10000, seed=0), 1000)}
+    for gname, (ei, n) in graphs.items():
+        rp, col, perm = orc.csr_by_key(ei[1], ei[0], n)
+        rpt, colt, permt = orc.csr_by_key(ei[0], ei[1], n)
+        out7[f"{gname}.edge_index"] = npy(ei)
+        out7[f"{gname}.num_nodes"] = np.array([n])
+        for nm, v in [("rowptr", rp), ("col", col), ("perm", perm),
+                      ("rowptr_t", rpt), ("col_t", colt), ("perm_t", permt)]:
+            out7[f"{gname}.{nm}"] = npy(v)
+
+        # ---- G5: GIN(KAN) and GIN(FastKAN) on the reference's own modules
+        F_ = 16
+        torch.manual_seed(510)
+        kan = ref_ekan.KAN([F_, 24, 24], grid_size=5, spline_order=3)
+        fk = ref_fastkan.FastKAN([F_, 24, 24], num_grids=4)
+        x0 = torch.randn(n, F_, generator=gen) * 0.25
+        for tag, net in [("kan", kan), ("fastkan", fk)]:
+            net.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            gy = torch.randn(n, 24, generator=gen)
+            y = orc.gin_conv(x, ei, net, eps=0.0)
+            y.backward(gy)
+            pre = f"{gname}.{tag}"
+            for kname, v in net.state_dict().items():
+                out5[f"{pre}.{kname}"] = npy(v)
+            for pname, p in net.named_parameters():
+                if p.grad is not None:
+                    out5[f"{pre}.grad.{pname}"] = npy(p.grad)
+            out5[f"{pre}.x"], out5[f"{pre}.gy"] = npy(x), npy(gy)
+            out5[f"{pre}.y"], out5[f"{pre}.gx"] = npy(y), npy(x.grad)
+            out5[f"{pre}.agg"] = npy(orc.sum_aggregate(x0, ei) + x0)
+
+        # ---- G6: GCN(KANLinear): restated gcn_norm + reference KANLinear + bias
+        torch.manual_seed(520)
+        lin = ref_ekan.KANLinear(F_, 24, grid_size=4, spline_order=3)
+        bias = (torch.randn(24, generator=gen) * 0.1).requires_grad_(True)
+        x = (x0 * 2.0).clone().requires_grad_(True)
+        gy = torch.randn(n, 24, generator=gen)
+        y = orc.gcn_conv(x, ei, lin, bias)
+        y.backward(gy)
+        ei2, w2 = orc.gcn_norm(ei, n)
+        pre = f"{gname}.gcn"
+        for kname, v in lin.state_dict().items():
+            out6[f"{pre}.lin.{kname}"] = npy(v)
+        for pname, p in lin.named_parameters():
+            out6[f"{pre}.grad.lin.{pname}"] = npy(p.grad)
+        out6[f"{pre}.bias"], out6[f"{pre}.grad.bias"] = npy(bias), npy(bias.grad)
+        out6[f"{pre}.x"], out6[f"{pre}.gy"] = npy(x), npy(gy)
+        out6[f"{pre}.y"], out6[f"{pre}.gx"] = npy(y), npy(x.grad)
+        out6[f"{pre}.norm_edge_index"], out6[f"{pre}.norm_weight"] = npy(ei2), npy(w2)
+    save("g5_gin", **out5)
+    save("g6_gcn", **out6)
+    save("g7_csr", **out7)
+
+
+def g8():
+    """16 small graphs batched: GINE message relu(x_j + e_ij), sum, KAN, then global_add_pool."""
+    gen = torch.Generator().manual_seed(800)
+    H = 16
+    xs, eis, eas, batch = [], [], [], []
+    off = 0
+    for g in range(16):
+        n = int(torch.randint(12, 35, (1,), generator=gen))
+        e = int(torch.randint(20, 80, (1,), generator=gen))
+        xs.append(torch.randn(n, H, generator=gen) * 0.5)
+        eis.append(torch.randint(0, n, (2, e), generator=gen) + off)
+        eas.append(torch.randn(e, H, generator=gen) * 0.5)
+        batch.append(torch.full((n,), g, dtype=torch.int64))
+        off += n
+    x0, ei, ea, batch = torch.cat(xs), torch.cat(eis, 1), torch.cat(eas), torch.cat(batch)
+    torch.manual_seed(810)
+    kan = ref_ekan.KAN([H, H, H], grid_size=4, spline_order=3)
+    x = x0.clone().requires_grad_(True)
+    ea_ = ea.clone().requires_grad_(True)
+    h = orc.gine_conv(x, ei, ea_, kan)
+    pooled = orc.global_add_pool(h, batch, 16)
+    gp = torch.randn(16, H, generator=gen)
+    pooled.backward(gp)
+    out = {"x": npy(x), "edge_index": npy(ei), "edge_attr": npy(ea), "batch": npy(batch),
+           "h": npy(h), "pooled": npy(pooled), "g_pooled": npy(gp),
+           "gx": npy(x.grad), "g_edge_attr": npy(ea_.grad)}
+    for kname, v in kan.state_dict().items():
+        out[f"kan.{kname}"] = npy(v)
+    for pname, p in kan.named_parameters():
+        out[f"grad.{pname}"] = npy(p.grad)
+    save("g8_gine_pool", **out)
+
+
+if __name__ == "__main__":
+    g1(); g2(); g3(); g4(); g5_g6_g7(); g8()
