@@ -1,0 +1,203 @@
+/*
+ * kagnn_hip.h -- C ABI of libkagnn_hip.so, the MI355X (gfx950) implementation of the
+ * KAN-GNN layer hot path of RomanBresson/KAGNN.
+ *
+ * The reference has NO native boundary (it is 100 % Python on torch / torch_geometric); the
+ * entry points below are what a ctypes binding inside the reference's layers would call in
+ * place of the aten-op sequences cited on each function (paths relative to the reference
+ * repository root).  INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host;
+ *  - matrices are row-major fp32 with an explicit leading dimension (elements) so column
+ *    slices of a wider activation can be passed without a copy;
+ *  - index arrays produced by this library are int32 (validated: N, E < 2^31); the edge list
+ *    handed in is the reference's int64 `edge_index`;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); no call synchronises
+ *    the device except kagnn_csr_build (documented there);
+ *  - return value 0 = success, negative = error; kagnn_last_error() returns a message for the
+ *    calling thread's most recent failure.  Nothing falls back to a CPU path.
+ */
+#ifndef KAGNN_HIP_H
+#define KAGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KAGNN_OK 0
+#define KAGNN_ERR_ARG (-1)      /* bad argument (shape / range / null)            */
+#define KAGNN_ERR_HIP (-2)      /* a HIP runtime call or kernel launch failed      */
+#define KAGNN_ERR_UNSUPPORTED (-3)
+
+/* precision of the dense contraction (the `mode` argument of the KAN entry points) */
+#define KAGNN_PREC_FP32 0       /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate    */
+#define KAGNN_PREC_SPLIT 1      /* fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate */
+
+int kagnn_version(void);
+const char* kagnn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph structure.  Replaces the per-call `index_select` / `scatter_add_` bookkeeping of
+ * torch_geometric's MessagePassing.propagate (called from node_classification_clean/
+ * models.py:48-56 via GINConv and :31-37 via GCNConv) by a CSR built once per edge_index.
+ *
+ * kagnn_csr_build: stable sort of the E edges by `key` (values 0..N-1).
+ *   rowptr[N+1]  = exclusive prefix sum of the key histogram
+ *   perm[E]      = argsort(key, stable)                (bit-exact contract)
+ *   col[E]       = val[perm]
+ * (key=dst,val=src) gives the forward structure, (key=src,val=dst) its transpose for backward.
+ * Rows whose degree exceeds `hub_threshold` are split into segments of at most
+ * `hub_threshold` edges, listed in hub_seg[3*i+{0,1,2}] = {row, e_begin, e_end};
+ * *num_hub_seg_host receives their count (never more than 2*E/hub_threshold + 1, so size
+ * hub_seg for 3x that many int32).  This call synchronises `stream` once (to return the count).
+ * ------------------------------------------------------------------------------------------ */
+int kagnn_csr_workspace_bytes(int64_t num_edges, int64_t num_nodes, size_t* bytes_host);
+int kagnn_csr_build(const int64_t* key, const int64_t* val, int64_t num_edges, int64_t num_nodes,
+                    int32_t* rowptr, int32_t* col, int32_t* perm,
+                    int32_t hub_threshold, int32_t* hub_seg, int64_t hub_seg_capacity,
+                    int64_t* num_hub_seg_host,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* in-degree normalisation of GCN (torch_geometric gcn_norm as used by KAGCNConv,
+ * node_classification_clean/models.py:31-37): dis[i] = (1 + #non-loop in-edges of i)^-1/2.
+ * `rowptr/col` must be the by-destination CSR of the ORIGINAL edge list. */
+int kagnn_gcn_deg_inv_sqrt(const int32_t* rowptr, const int32_t* col, int64_t num_nodes,
+                           float* dis, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Neighbour aggregation (sum).  Replaces x.index_select(0,row) -> scatter_add_(0,col) of
+ * MessagePassing.propagate:
+ *
+ *   out[i,:] = out_scale[i] * ( self_scale * s(i) * x[i,:] + sum_{e in row i} w(e) * s(col[e]) * x[col[e],:] ) + bias[:]
+ *
+ * with s(j) = in_scale[j] (or 1 when NULL), w(e) = edge_weight[e] in CSR order (or 1 when NULL),
+ * out_scale NULL = 1, bias NULL = 0.  `skip_self_loops` != 0 drops edges with col[e]==i (GCN's
+ * add_remaining_self_loops).  GIN: self_scale = 1+eps, everything else NULL.  GCN: in_scale =
+ * out_scale = dis, self_scale = 1, skip_self_loops = 1, bias = conv bias.  The backward of an
+ * aggregation is the same call on the transposed CSR.
+ * Deterministic except for rows listed in hub_seg (fp32 atomics across segments).
+ * ------------------------------------------------------------------------------------------ */
+int kagnn_aggregate_sum(const float* x, int64_t ldx, float* out, int64_t ldo,
+                        const int32_t* rowptr, const int32_t* col, const float* edge_weight,
+                        int64_t num_nodes, int32_t num_feat, float self_scale,
+                        const float* in_scale, const float* out_scale, const float* bias,
+                        int32_t skip_self_loops,
+                        const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
+                        void* stream);
+
+/* GINE message: out[i,:] = self_scale*x[i,:] + sum_e relu(x[col[e],:] + edge_attr[perm[e],:])
+ * (torch_geometric GINEConv as used by graph_regression/models.py:98,113).              */
+int kagnn_aggregate_gine(const float* x, int64_t ldx, const float* edge_attr, int64_t lde,
+                         float* out, int64_t ldo, const int32_t* rowptr, const int32_t* col,
+                         const int32_t* perm, int64_t num_nodes, int32_t num_feat,
+                         float self_scale, void* stream);
+/* backward of the GINE message, run on the TRANSPOSED structure (rows = source nodes j, built
+ * with key=src,val=dst): for e in row j with target i = col_t[e] and original edge id
+ * pe = perm_t[e]:  g = gout[i,:] * (x[j,:] + edge_attr[pe,:] > 0);  g_edge_attr[pe,:] = g;
+ * gx[j,:] = self_scale*gout[j,:] + sum_e g.  Deterministic (no atomics); g_edge_attr may be NULL. */
+int kagnn_aggregate_gine_bwd(const float* x, int64_t ldx, const float* edge_attr, int64_t lde,
+                             const float* gout, int64_t ldg, float* gx, int64_t ldgx,
+                             float* g_edge_attr, int64_t ldge,
+                             const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t,
+                             int64_t num_nodes, int32_t num_feat, float self_scale, void* stream);
+
+/* segmented sum over a SORTED batch vector given as segment offsets (global_add_pool,
+ * graph_regression/models.py:117): out[b,:] = sum_{i in [seg[b],seg[b+1])} x[i,:];
+ * `mean` != 0 divides by max(count,1) (global_mean_pool).  Backward = kagnn_segment_broadcast. */
+int kagnn_segment_pool(const float* x, int64_t ldx, float* out, int64_t ldo,
+                       const int32_t* seg_ptr, int64_t num_segments, int32_t num_feat,
+                       int32_t mean, void* stream);
+int kagnn_segment_broadcast(const float* gout, int64_t ldg, float* gx, int64_t ldgx,
+                            const int32_t* seg_ptr, int64_t num_segments, int32_t num_feat,
+                            int32_t mean, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * efficient-KAN layer.  Replaces KANLinear.forward (node_classification_clean/ekan.py:154-162:
+ * b_splines :79-112 + scaled_spline_weight :146-152 + two F.linear) and its autograd backward.
+ * The [N, in, G+k] basis tensor is never materialised.
+ *
+ *  knots        : ONE row of the module's `grid` buffer, G+2k+1 fp32 values (uniform grid;
+ *                 the host side verifies all rows equal and uniform, else refuses)
+ *  base_weight  [out,in], spline_weight [out,in,G+k], spline_scaler [out,in] or NULL
+ *
+ * kagnn_kan_pack rearranges (base_weight | spline_weight*scaler) into the MFMA fragment order
+ * used by fwd (`pack_fwd`) and by the input-gradient kernel (`pack_dx`); call it whenever the
+ * parameters change.  Sizes from kagnn_kan_pack_bytes.
+ * ------------------------------------------------------------------------------------------ */
+int kagnn_kan_pack_bytes(int32_t in_features, int32_t out_features, int32_t grid_size,
+                         int32_t spline_order, int32_t mode, size_t* fwd_bytes_host,
+                         size_t* dx_bytes_host);
+int kagnn_kan_pack(const float* base_weight, const float* spline_weight,
+                   const float* spline_scaler, int32_t in_features, int32_t out_features,
+                   int32_t grid_size, int32_t spline_order, int32_t mode,
+                   void* pack_fwd, void* pack_dx, void* stream);
+
+/* y[N,out] = silu(x) @ base_weight^T + bases(x) @ (spline_weight*scaler)^T                */
+int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t num_rows, const float* knots,
+                         int32_t in_features, int32_t out_features, int32_t grid_size,
+                         int32_t spline_order, int32_t mode, const void* pack_fwd,
+                         float* y, int64_t ldy, void* stream);
+
+/* gx[N,in] = d loss / d x given gy[N,out] (x is the saved layer input; bases' derivatives are
+ * recomputed, nothing but x was saved).                                                   */
+int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int64_t ldgy,
+                               int64_t num_rows, const float* knots, int32_t in_features,
+                               int32_t out_features, int32_t grid_size, int32_t spline_order,
+                               int32_t mode, const void* pack_dx, float* gx, int64_t ldgx,
+                               void* stream);
+
+/* parameter gradients: g_base_weight[out,in], g_spline_weight[out,in,G+k],
+ * g_spline_scaler[out,in] (NULL when the layer has no scaler).  `workspace` holds the per-wave
+ * partial sums (size from kagnn_kan_bwd_weight_workspace_bytes); deterministic reduction.   */
+int kagnn_kan_bwd_weight_workspace_bytes(int64_t num_rows, int32_t in_features,
+                                         int32_t out_features, int32_t grid_size,
+                                         int32_t spline_order, int32_t mode, size_t* bytes_host);
+int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, int64_t ldgy,
+                                int64_t num_rows, const float* knots, int32_t in_features,
+                                int32_t out_features, int32_t grid_size, int32_t spline_order,
+                                int32_t mode, const float* spline_weight,
+                                const float* spline_scaler, float* g_base_weight,
+                                float* g_spline_weight, float* g_spline_scaler,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FastKAN layer.  Replaces FastKANLayer.forward (node_classification_clean/fastkan.py:76-85:
+ * LayerNorm :77-78, RadialBasisFunction :46-47, SplineLinear :81, base_linear(silu(x)) :82-84)
+ * and its autograd backward.  centers = the module's `rbf.grid` parameter (num_grids fp32
+ * values, device pointer), denominator as in fastkan.py:44.  ln_weight/ln_bias NULL = no layernorm; base_weight NULL = no base branch.
+ *   spline_weight [out, in*num_grids]  (in major, grid minor), base_weight [out,in], base_bias [out]
+ * ------------------------------------------------------------------------------------------ */
+int kagnn_fastkan_fwd_workspace_bytes(int64_t num_rows, int32_t in_features,
+                                      int32_t out_features, int32_t num_grids,
+                                      size_t* bytes_host);
+int kagnn_fastkan_fwd(const float* x, int64_t ldx, int64_t num_rows, int32_t in_features,
+                      int32_t out_features, int32_t num_grids, const float* centers,
+                      float denominator, const float* ln_weight, const float* ln_bias,
+                      float ln_eps, const float* spline_weight, const float* base_weight,
+                      const float* base_bias, float* y, int64_t ldy,
+                      float* row_stats /* [N,2] = mean, rstd; required when ln_weight != NULL */,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int kagnn_fastkan_bwd_workspace_bytes(int64_t num_rows, int32_t in_features,
+                                      int32_t out_features, int32_t num_grids,
+                                      size_t* bytes_host);
+/* all gradients of one layer: gx[N,in], g_ln_weight[in], g_ln_bias[in],
+ * g_spline_weight[out,in*num_grids], g_base_weight[out,in], g_base_bias[out]; `row_stats` is the
+ * array kagnn_fastkan_fwd wrote.  No gradient is produced for `centers` (rbf.grid has
+ * requires_grad=False, fastkan.py:43).                                                      */
+int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy,
+                      int64_t num_rows, int32_t in_features, int32_t out_features,
+                      int32_t num_grids, const float* centers, float denominator,
+                      const float* ln_weight, const float* ln_bias, float ln_eps,
+                      const float* spline_weight, const float* base_weight,
+                      const float* row_stats, float* gx, int64_t ldgx, float* g_ln_weight,
+                      float* g_ln_bias, float* g_spline_weight, float* g_base_weight,
+                      float* g_base_bias, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAGNN_HIP_H */

@@ -1,0 +1,13 @@
+"""kagnn_amd -- MI355X-native KAN-GNN layer hot path (drop-in for RomanBresson/KAGNN's layers).
+
+Host side: Python mirrors of the reference's ``nn.Module`` surface (``ekan``, ``fastkan``,
+``models``, ``graph_models``).  Compute: ``libkagnn_hip.so`` (hand-written HIP for gfx950) behind the
+C ABI of ``include/kagnn_hip.h``, reached through ``kagnn_amd.ops``.
+"""
+from . import _lib, ops                                                          # noqa: F401
+from .ekan import KAN, KANLinear                                                 # noqa: F401
+from .fastkan import FastKAN, FastKANLayer, RadialBasisFunction, SplineLinear    # noqa: F401
+from .models import (FASTKAGCNConv, FKANLayer, GFASTKAN_Nodes, GIFASTKANLayer,   # noqa: F401
+                     GIKANLayer, GKAN_Nodes, KAGCNConv, KANLayer)
+
+__version__ = "0.1.0"

@@ -1,0 +1,85 @@
+"""ctypes binding of libkagnn_hip.so (C ABI: include/kagnn_hip.h).
+
+The library is the product; there is no fallback.  If it is missing or a call fails, the
+caller gets a RuntimeError -- nothing in ``kagnn_amd`` silently computes on the CPU or through
+stock torch ops instead.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkagnn_hip.so")
+
+PREC_FP32 = 0
+PREC_SPLIT = 1
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "kagnn_version": (c_int32, []),
+    "kagnn_last_error": (ctypes.c_char_p, []),
+    "kagnn_csr_workspace_bytes": (c_int32, [c_int64, c_int64, POINTER(c_size_t)]),
+    "kagnn_csr_build": (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int32, _P, c_int64,
+                                  POINTER(c_int64), _P, c_size_t, _P]),
+    "kagnn_gcn_deg_inv_sqrt": (c_int32, [_P, _P, c_int64, _P, _P]),
+    "kagnn_aggregate_sum": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int32, c_float,
+                                      _P, _P, _P, c_int32, _P, c_int64, c_int32, _P]),
+    "kagnn_aggregate_gine": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64,
+                                       c_int32, c_float, _P]),
+    "kagnn_aggregate_gine_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P,
+                                           c_int64, _P, _P, _P, c_int64, c_int32, c_float, _P]),
+    "kagnn_segment_pool": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
+    "kagnn_segment_broadcast": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
+    "kagnn_kan_pack_bytes": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32,
+                                       POINTER(c_size_t), POINTER(c_size_t)]),
+    "kagnn_kan_pack": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "kagnn_kan_linear_fwd": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, c_int32,
+                                       c_int32, _P, _P, c_int64, _P]),
+    "kagnn_kan_linear_bwd_input": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, c_int32, c_int32,
+                                             c_int32, c_int32, c_int32, _P, _P, c_int64, _P]),
+    "kagnn_kan_bwd_weight_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32,
+                                                       c_int32, POINTER(c_size_t)]),
+    "kagnn_kan_linear_bwd_weight": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, c_int32, c_int32,
+                                              c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P,
+                                              c_size_t, _P]),
+    "kagnn_fastkan_fwd_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+    "kagnn_fastkan_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, c_int32, _P, c_float, _P, _P,
+                                    c_float, _P, _P, _P, _P, c_int64, _P, _P, c_size_t, _P]),
+    "kagnn_fastkan_bwd_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+    "kagnn_fastkan_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, _P,
+                                    c_float, _P, _P, c_float, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
+                                    _P, _P, c_size_t, _P]),
+}
+
+EXPORTED = tuple(_SIGNATURES)
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m kagnn_amd._build` (needs hipcc). "
+                "kagnn_amd has no CPU or eager-torch fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().kagnn_last_error()
+        raise RuntimeError(f"libkagnn_hip {what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

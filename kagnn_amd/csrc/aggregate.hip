@@ -1,0 +1,271 @@
+// Neighbour aggregation over a CSR (sum), the MI355X replacement for the
+// index_select -> scatter_add_ pair inside torch_geometric's MessagePassing.propagate
+// (reached from node_classification_clean/models.py:48-56 GIKANLayer/GINConv and :31-37
+// KAGCNConv/GCNConv).  HBM-bound: a destination row is owned by a group of
+// LPR lanes that each keep one float4 of the row in registers, walk the row's neighbour list
+// with four independent 16-byte gathers in flight, and write the row once -- no [E,F] message
+// tensor, no atomics.  Rows above `hub_threshold` edges are split into segments handled by one
+// workgroup each (agg_hub_kernel) so a 10^4-degree hub does not serialise a single lane group.
+#include "common.h"
+
+namespace kagnn {
+
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void fma4(float4& a, float w, const float4& v) {
+    a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
+}
+
+// weight of edge e into row i (0 drops it)
+__device__ __forceinline__ float edge_w(const AggArgs& a, int e, int j, long i) {
+    float w = a.ew ? a.ew[e] : 1.0f;
+    if (a.in_scale) w *= a.in_scale[j];
+    if (a.skip_self && j == (int)i) w = 0.0f;
+    return w;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void agg_rows_v4_kernel(AggArgs a) {
+    const long gid = (blockIdx.x * 256L + threadIdx.x) / LPR;
+    const int c4 = (threadIdx.x % LPR) * 4;
+    if (gid >= a.N || c4 >= a.F) return;
+    const int s = a.rowptr[gid], t = a.rowptr[gid + 1];
+    const bool hub = (t - s) > a.hub_threshold;
+    float4 acc = ld4(a.x + gid * a.ldx + c4);
+    const float sw = a.self_scale * (a.in_scale ? a.in_scale[gid] : 1.0f);
+    acc.x *= sw; acc.y *= sw; acc.z *= sw; acc.w *= sw;
+    if (!hub) {
+        int e = s;
+        for (; e + 4 <= t; e += 4) {
+            const int j0 = a.col[e], j1 = a.col[e + 1], j2 = a.col[e + 2], j3 = a.col[e + 3];
+            const float4 v0 = ld4(a.x + (long)j0 * a.ldx + c4);
+            const float4 v1 = ld4(a.x + (long)j1 * a.ldx + c4);
+            const float4 v2 = ld4(a.x + (long)j2 * a.ldx + c4);
+            const float4 v3 = ld4(a.x + (long)j3 * a.ldx + c4);
+            fma4(acc, edge_w(a, e, j0, gid), v0);
+            fma4(acc, edge_w(a, e + 1, j1, gid), v1);
+            fma4(acc, edge_w(a, e + 2, j2, gid), v2);
+            fma4(acc, edge_w(a, e + 3, j3, gid), v3);
+        }
+        for (; e < t; ++e) {
+            const int j = a.col[e];
+            fma4(acc, edge_w(a, e, j, gid), ld4(a.x + (long)j * a.ldx + c4));
+        }
+    }
+    const float os = a.out_scale ? a.out_scale[gid] : 1.0f;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) b = ld4(a.bias + c4);
+    float4 o = make_float4(fmaf(os, acc.x, b.x), fmaf(os, acc.y, b.y), fmaf(os, acc.z, b.z), fmaf(os, acc.w, b.w));
+    *reinterpret_cast<float4*>(a.out + gid * a.ldo + c4) = o;
+}
+
+// one workgroup per hub segment {row, e0, e1}; adds its partial sum onto out[row] (which the row
+// kernel initialised with the self term and bias) with fp32 atomics.
+template <int LPR>
+__global__ __launch_bounds__(256) void agg_hub_v4_kernel(AggArgs a, const int* __restrict__ seg) {
+    __shared__ float4 s_part[256];
+    const int row = seg[3 * blockIdx.x], e0 = seg[3 * blockIdx.x + 1], e1 = seg[3 * blockIdx.x + 2];
+    constexpr int G = 256 / LPR;
+    const int g = threadIdx.x / LPR, lg = threadIdx.x % LPR, c4 = lg * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < a.F) {
+        for (int e = e0 + g; e < e1; e += G) {
+            const int j = a.col[e];
+            fma4(acc, edge_w(a, e, j, row), ld4(a.x + (long)j * a.ldx + c4));
+        }
+    }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && c4 < a.F) {
+        for (int k = 1; k < G; ++k) {          // fixed order inside the segment
+            const float4 p = s_part[k * LPR + lg];
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        const float os = a.out_scale ? a.out_scale[row] : 1.0f;
+        float* o = a.out + (long)row * a.ldo + c4;
+        atomicAdd(o + 0, os * acc.x); atomicAdd(o + 1, os * acc.y);
+        atomicAdd(o + 2, os * acc.z); atomicAdd(o + 3, os * acc.w);
+    }
+}
+
+// any F / any alignment: grid (N, ceil(F/256)), one thread per feature, edges walked in order.
+__global__ __launch_bounds__(256) void agg_rows_generic_kernel(AggArgs a) {
+    const long i = blockIdx.x;
+    const int f = blockIdx.y * 256 + threadIdx.x;
+    if (f >= a.F) return;
+    const int s = a.rowptr[i], t = a.rowptr[i + 1];
+    float acc = a.self_scale * (a.in_scale ? a.in_scale[i] : 1.0f) * a.x[i * a.ldx + f];
+    for (int e = s; e < t; ++e) {
+        const int j = a.col[e];
+        acc = fmaf(edge_w(a, e, j, i), a.x[(long)j * a.ldx + f], acc);
+    }
+    const float os = a.out_scale ? a.out_scale[i] : 1.0f;
+    a.out[i * a.ldo + f] = fmaf(os, acc, a.bias ? a.bias[f] : 0.0f);
+}
+
+__global__ void gcn_deg_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, long N,
+                               float* __restrict__ dis) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int d = 1;                                    // the one self loop gcn_norm guarantees
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) d += (col[e] != (int)i);
+    dis[i] = rsqrtf((float)d);
+}
+
+// ------------------------------------------------------------------ GINE message + pooling
+// out[i,:] = self_scale*x[i,:] + sum_e relu(x[col[e],:] + edge_attr[perm[e],:]); wave per row.
+__global__ __launch_bounds__(256) void gine_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                       const float* __restrict__ ea, long lde,
+                                                       float* __restrict__ out, long ldo,
+                                                       const int* __restrict__ rowptr,
+                                                       const int* __restrict__ col,
+                                                       const int* __restrict__ perm, long N, int F,
+                                                       float self_scale) {
+    const long i = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int s = rowptr[i], t = rowptr[i + 1];
+    for (int f = lane; f < F; f += 64) {
+        float acc = self_scale * x[i * ldx + f];
+        for (int e = s; e < t; ++e)
+            acc += fmaxf(x[(long)col[e] * ldx + f] + ea[(long)perm[e] * lde + f], 0.0f);
+        out[i * ldo + f] = acc;
+    }
+}
+
+// on the TRANSPOSED structure (rows = source nodes j): for e in row j with target i = col[e],
+// original edge id pe = perm[e]:  g = gout[i,:] * (x[j,:] + ea[pe,:] > 0);
+// g_ea[pe,:] = g ; gx[j,:] = self_scale*gout[j,:] + sum_e g.   Deterministic, no atomics.
+__global__ __launch_bounds__(256) void gine_bwd_kernel(const float* __restrict__ x, long ldx,
+                                                       const float* __restrict__ ea, long lde,
+                                                       const float* __restrict__ gout, long ldg,
+                                                       float* __restrict__ gx, long ldgx,
+                                                       float* __restrict__ gea, long ldge,
+                                                       const int* __restrict__ rowptr,
+                                                       const int* __restrict__ col,
+                                                       const int* __restrict__ perm, long N, int F,
+                                                       float self_scale) {
+    const long j = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (j >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int s = rowptr[j], t = rowptr[j + 1];
+    for (int f = lane; f < F; f += 64) {
+        const float xj = x[j * ldx + f];
+        float acc = self_scale * gout[j * ldg + f];
+        for (int e = s; e < t; ++e) {
+            const long pe = perm[e];
+            const float g = (xj + ea[pe * lde + f] > 0.0f) ? gout[(long)col[e] * ldg + f] : 0.0f;
+            if (gea) gea[pe * ldge + f] = g;
+            acc += g;
+        }
+        gx[j * ldgx + f] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restrict__ x, long ldx,
+                                                           float* __restrict__ out, long ldo,
+                                                           const int* __restrict__ seg, long B, int F,
+                                                           int mean) {
+    const long b = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int s = seg[b], t = seg[b + 1];
+    const float inv = mean ? 1.0f / (float)max(t - s, 1) : 1.0f;
+    for (int f = lane; f < F; f += 64) {
+        float acc = 0.0f;
+        for (int i = s; i < t; ++i) acc += x[(long)i * ldx + f];
+        out[b * ldo + f] = acc * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void segment_bcast_kernel(const float* __restrict__ g, long ldg,
+                                                            float* __restrict__ gx, long ldgx,
+                                                            const int* __restrict__ seg, long B, int F,
+                                                            int mean) {
+    const long b = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int s = seg[b], t = seg[b + 1];
+    const float inv = mean ? 1.0f / (float)max(t - s, 1) : 1.0f;
+    for (int f = lane; f < F; f += 64) {
+        const float v = g[b * ldg + f] * inv;
+        for (int i = s; i < t; ++i) gx[(long)i * ldgx + f] = v;
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+static bool vec4_ok(const AggArgs& a) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return a.F % 4 == 0 && a.F <= 256 && a.ldx % 4 == 0 && a.ldo % 4 == 0 && al(a.x) && al(a.out) &&
+           (!a.bias || al(a.bias));
+}
+
+int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, hipStream_t st) {
+    if (a.N == 0) return KAGNN_OK;
+    if (!vec4_ok(a)) {
+        AggArgs b = a;
+        b.hub_threshold = 0x7fffffff;
+        dim3 grid((unsigned)a.N, cdiv(a.F, 256));
+        agg_rows_generic_kernel<<<grid, 256, 0, st>>>(b);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
+    AggArgs b = a;
+    if (num_hub_seg == 0 || hub_seg == nullptr) b.hub_threshold = 0x7fffffff;
+#define ROWS(LPR)                                                                     \
+    {                                                                                 \
+        agg_rows_v4_kernel<LPR><<<cdiv(a.N * LPR, 256), 256, 0, st>>>(b);             \
+        KAGNN_LAUNCH_CHECK();                                                         \
+        if (b.hub_threshold != 0x7fffffff) {                                          \
+            agg_hub_v4_kernel<LPR><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg); \
+            KAGNN_LAUNCH_CHECK();                                                     \
+        }                                                                             \
+    }
+    if (a.F <= 16) ROWS(4) else if (a.F <= 32) ROWS(8) else if (a.F <= 64) ROWS(16)
+    else if (a.F <= 128) ROWS(32) else ROWS(64)
+#undef ROWS
+    return KAGNN_OK;
+}
+
+int gcn_deg_inv_sqrt(const int* rowptr, const int* col, long N, float* dis, hipStream_t st) {
+    if (N == 0) return KAGNN_OK;
+    gcn_deg_kernel<<<cdiv(N, 256), 256, 0, st>>>(rowptr, col, N, dis);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int gine_fwd(const float* x, long ldx, const float* ea, long lde, float* out, long ldo,
+             const int* rowptr, const int* col, const int* perm, long N, int F, float self_scale,
+             hipStream_t st) {
+    if (N == 0) return KAGNN_OK;
+    gine_fwd_kernel<<<cdiv(N, 4), 256, 0, st>>>(x, ldx, ea, lde, out, ldo, rowptr, col, perm, N, F, self_scale);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int gine_bwd(const float* x, long ldx, const float* ea, long lde, const float* gout, long ldg,
+             float* gx, long ldgx, float* gea, long ldge, const int* rowptr, const int* col,
+             const int* perm, long N, int F, float self_scale, hipStream_t st) {
+    if (N == 0) return KAGNN_OK;
+    gine_bwd_kernel<<<cdiv(N, 4), 256, 0, st>>>(x, ldx, ea, lde, gout, ldg, gx, ldgx, gea, ldge, rowptr, col, perm, N, F, self_scale);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int segment_pool(const float* x, long ldx, float* out, long ldo, const int* seg, long B, int F,
+                 int mean, hipStream_t st) {
+    if (B == 0) return KAGNN_OK;
+    segment_pool_kernel<<<cdiv(B, 4), 256, 0, st>>>(x, ldx, out, ldo, seg, B, F, mean);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int segment_bcast(const float* g, long ldg, float* gx, long ldgx, const int* seg, long B, int F,
+                  int mean, hipStream_t st) {
+    if (B == 0) return KAGNN_OK;
+    segment_bcast_kernel<<<cdiv(B, 4), 256, 0, st>>>(g, ldg, gx, ldgx, seg, B, F, mean);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+}  // namespace kagnn

@@ -1,0 +1,260 @@
+// extern "C" surface of libkagnn_hip.so (declared in include/kagnn_hip.h): argument validation
+// and dispatch only -- the kernels live in the sibling .hip files.
+#include "common.h"
+
+namespace kagnn {
+thread_local char g_err[512] = "";
+
+int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, hipStream_t st);
+int gcn_deg_inv_sqrt(const int* rowptr, const int* col, long N, float* dis, hipStream_t st);
+int gine_fwd(const float*, long, const float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
+int gine_bwd(const float*, long, const float*, long, const float*, long, float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
+int segment_pool(const float*, long, float*, long, const int*, long, int, int, hipStream_t);
+int segment_bcast(const float*, long, float*, long, const int*, long, int, int, hipStream_t);
+int csr_workspace_bytes(long E, long N, size_t* bytes);
+int csr_build(const int64_t*, const int64_t*, long, long, int*, int*, int*, int, int*, long, int64_t*, void*, size_t, hipStream_t);
+
+size_t kan_f32_pack_fwd_bytes(int in, int out, int C);
+size_t kan_f32_pack_dx_bytes(int in, int out, int C);
+int kan_f32_pack(const float*, const float*, const float*, int, int, int, float*, float*, hipStream_t);
+int kan_f32_fwd(const float*, long, long, const float*, int, int, int, int, const float*, float*, long, hipStream_t);
+int kan_f32_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, float*, long, hipStream_t);
+size_t kan_f32_dw_ws_bytes(long N, int in, int out, int C);
+int kan_f32_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t);
+
+size_t kan_split_pack_fwd_bytes(int in, int out, int C);
+size_t kan_split_pack_dx_bytes(int in, int out, int C);
+int kan_split_pack(const float*, const float*, const float*, int, int, int, void*, void*, hipStream_t);
+int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t);
+int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t);
+size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
+int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t);
+bool kan_split_supported(int in, int out, int G, int K);
+
+int fastkan_fwd(const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, void*, size_t, hipStream_t);
+size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng);
+size_t fastkan_bwd_ws_bytes(long N, int in, int out, int ng);
+int fastkan_bwd(const float*, long, const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, float*, float*, float*, float*, void*, size_t, hipStream_t);
+}  // namespace kagnn
+
+using namespace kagnn;
+
+static int check_kan_dims(const char* fn, int in, int out, int G, int K, int mode) {
+    if (in < 1 || out < 1) return fail(KAGNN_ERR_ARG, "%s: in_features/out_features must be >= 1", fn);
+    if (K < 1 || K > kMaxOrder) return fail(KAGNN_ERR_UNSUPPORTED, "%s: spline_order must be 1..4", fn);
+    if (G < 1 || G + 2 * K + 1 > kMaxKnots) return fail(KAGNN_ERR_UNSUPPORTED, "%s: grid_size out of range", fn);
+    if (mode != KAGNN_PREC_FP32 && mode != KAGNN_PREC_SPLIT) return fail(KAGNN_ERR_ARG, "%s: unknown precision mode", fn);
+    return KAGNN_OK;
+}
+// the split path covers the hot shapes; everything else runs the exact-fp32 kernels
+static int eff_mode(int in, int out, int G, int K, int mode) {
+    return (mode == KAGNN_PREC_SPLIT && kan_split_supported(in, out, G, K)) ? KAGNN_PREC_SPLIT : KAGNN_PREC_FP32;
+}
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int kagnn_version(void) { return 100; }
+const char* kagnn_last_error(void) { return g_err; }
+
+int kagnn_csr_workspace_bytes(int64_t E, int64_t N, size_t* bytes) {
+    KAGNN_CHECK_ARG(bytes != nullptr && E >= 0 && N >= 0, "null output or negative size");
+    KAGNN_CHECK_ARG(E < 2147483647LL && N < 2147483647LL, "N and E must fit int32");
+    return csr_workspace_bytes(E, N, bytes);
+}
+
+int kagnn_csr_build(const int64_t* key, const int64_t* val, int64_t E, int64_t N, int32_t* rowptr,
+                    int32_t* col, int32_t* perm, int32_t hub_threshold, int32_t* hub_seg,
+                    int64_t hub_seg_capacity, int64_t* num_hub_seg_host, void* ws, size_t ws_bytes,
+                    void* stream) {
+    KAGNN_CHECK_ARG(E >= 0 && N >= 0 && E < 2147483647LL && N < 2147483647LL, "N and E must fit int32");
+    KAGNN_CHECK_ARG(rowptr != nullptr, "rowptr is null");
+    KAGNN_CHECK_ARG(E == 0 || (key && val && col && perm && ws), "null array");
+    return csr_build(key, val, E, N, rowptr, col, perm, hub_threshold, hub_seg, hub_seg_capacity,
+                     num_hub_seg_host, ws, ws_bytes, as_stream(stream));
+}
+
+int kagnn_gcn_deg_inv_sqrt(const int32_t* rowptr, const int32_t* col, int64_t N, float* dis, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && rowptr && dis, "null array");
+    return gcn_deg_inv_sqrt(rowptr, col, N, dis, as_stream(stream));
+}
+
+int kagnn_aggregate_sum(const float* x, int64_t ldx, float* out, int64_t ldo, const int32_t* rowptr,
+                        const int32_t* col, const float* edge_weight, int64_t N, int32_t F,
+                        float self_scale, const float* in_scale, const float* out_scale,
+                        const float* bias, int32_t skip_self_loops, const int32_t* hub_seg,
+                        int64_t num_hub_seg, int32_t hub_threshold, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && F >= 1, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (x && out && rowptr), "null array");
+    KAGNN_CHECK_ARG(ldx >= F && ldo >= F, "leading dimension smaller than num_feat");
+    KAGNN_CHECK_ARG(x != out, "in-place aggregation is not supported");
+    AggArgs a{x, ldx, out, ldo, rowptr, col, edge_weight, N, F, self_scale, in_scale, out_scale, bias,
+              skip_self_loops, hub_threshold > 0 ? hub_threshold : 0x7fffffff};
+    return aggregate_sum(a, hub_seg, num_hub_seg, as_stream(stream));
+}
+
+int kagnn_aggregate_gine(const float* x, int64_t ldx, const float* ea, int64_t lde, float* out,
+                         int64_t ldo, const int32_t* rowptr, const int32_t* col, const int32_t* perm,
+                         int64_t N, int32_t F, float self_scale, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && F >= 1, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (x && out && rowptr), "null array");
+    return gine_fwd(x, ldx, ea, lde, out, ldo, rowptr, col, perm, N, F, self_scale, as_stream(stream));
+}
+
+int kagnn_aggregate_gine_bwd(const float* x, int64_t ldx, const float* ea, int64_t lde,
+                             const float* gout, int64_t ldg, float* gx, int64_t ldgx, float* gea,
+                             int64_t ldge, const int32_t* rowptr_t, const int32_t* col_t,
+                             const int32_t* perm_t, int64_t N, int32_t F, float self_scale, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && F >= 1, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (x && gout && gx && rowptr_t), "null array");
+    return gine_bwd(x, ldx, ea, lde, gout, ldg, gx, ldgx, gea, ldge, rowptr_t, col_t, perm_t, N, F,
+                    self_scale, as_stream(stream));
+}
+
+int kagnn_segment_pool(const float* x, int64_t ldx, float* out, int64_t ldo, const int32_t* seg,
+                       int64_t B, int32_t F, int32_t mean, void* stream) {
+    KAGNN_CHECK_ARG(B >= 0 && F >= 1 && (B == 0 || (x && out && seg)), "bad argument");
+    return segment_pool(x, ldx, out, ldo, seg, B, F, mean, as_stream(stream));
+}
+
+int kagnn_segment_broadcast(const float* g, int64_t ldg, float* gx, int64_t ldgx, const int32_t* seg,
+                            int64_t B, int32_t F, int32_t mean, void* stream) {
+    KAGNN_CHECK_ARG(B >= 0 && F >= 1 && (B == 0 || (g && gx && seg)), "bad argument");
+    return segment_bcast(g, ldg, gx, ldgx, seg, B, F, mean, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- efficient-KAN
+int kagnn_kan_pack_bytes(int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
+                         size_t* fwd_bytes, size_t* dx_bytes) {
+    int rc = check_kan_dims(__func__, in, out, G, K, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(fwd_bytes && dx_bytes, "null output");
+    if (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT) {
+        *fwd_bytes = kan_split_pack_fwd_bytes(in, out, G + K);
+        *dx_bytes = kan_split_pack_dx_bytes(in, out, G + K);
+    } else {
+        *fwd_bytes = kan_f32_pack_fwd_bytes(in, out, G + K);
+        *dx_bytes = kan_f32_pack_dx_bytes(in, out, G + K);
+    }
+    return KAGNN_OK;
+}
+
+int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in, int32_t out,
+                   int32_t G, int32_t K, int32_t mode, void* pack_fwd, void* pack_dx, void* stream) {
+    int rc = check_kan_dims(__func__, in, out, G, K, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(bw && sw && pack_fwd && pack_dx, "null array");
+    if (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT)
+        return kan_split_pack(bw, sw, sc, in, out, G + K, pack_fwd, pack_dx, as_stream(stream));
+    return kan_f32_pack(bw, sw, sc, in, out, G + K, (float*)pack_fwd, (float*)pack_dx, as_stream(stream));
+}
+
+int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* knots, int32_t in,
+                         int32_t out, int32_t G, int32_t K, int32_t mode, const void* pack_fwd,
+                         float* y, int64_t ldy, void* stream) {
+    int rc = check_kan_dims(__func__, in, out, G, K, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldy >= out, "bad shape");
+    if (N == 0) return KAGNN_OK;
+    KAGNN_CHECK_ARG(x && knots && pack_fwd && y, "null array");
+    if (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT)
+        return kan_split_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, as_stream(stream));
+    return kan_f32_fwd(x, ldx, N, knots, in, out, G, K, (const float*)pack_fwd, y, ldy, as_stream(stream));
+}
+
+int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N,
+                               const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
+                               int32_t mode, const void* pack_dx, float* gx, int64_t ldgx, void* stream) {
+    int rc = check_kan_dims(__func__, in, out, G, K, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
+    if (N == 0) return KAGNN_OK;
+    KAGNN_CHECK_ARG(x && gy && knots && pack_dx && gx, "null array");
+    if (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT)
+        return kan_split_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack_dx, gx, ldgx, as_stream(stream));
+    return kan_f32_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, (const float*)pack_dx, gx, ldgx, as_stream(stream));
+}
+
+int kagnn_kan_bwd_weight_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K,
+                                         int32_t mode, size_t* bytes) {
+    int rc = check_kan_dims(__func__, in, out, G, K, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
+    *bytes = (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT) ? kan_split_dw_ws_bytes(N, in, out, G + K)
+                                                                   : kan_f32_dw_ws_bytes(N, in, out, G + K);
+    return KAGNN_OK;
+}
+
+int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N,
+                                const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
+                                int32_t mode, const float* sw, const float* sc, float* g_bw,
+                                float* g_sw, float* g_sc, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_kan_dims(__func__, in, out, G, K, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out, "bad shape");
+    KAGNN_CHECK_ARG(knots && sw && g_bw && g_sw && ws, "null array");
+    KAGNN_CHECK_ARG(N == 0 || (x && gy), "null array");
+    KAGNN_CHECK_ARG((sc == nullptr) == (g_sc == nullptr), "spline_scaler and its gradient must both be given or both be null");
+    if (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT)
+        return kan_split_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream));
+    return kan_f32_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- FastKAN
+static int check_fk(const char* fn, int in, int out, int ng) {
+    if (in < 1 || out < 1) return fail(KAGNN_ERR_ARG, "%s: input_dim/output_dim must be >= 1", fn);
+    if (ng < 1 || ng > kMaxKnots) return fail(KAGNN_ERR_UNSUPPORTED, "%s: num_grids out of range", fn);
+    return KAGNN_OK;
+}
+
+int kagnn_fastkan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t ng, size_t* bytes) {
+    int rc = check_fk(__func__, in, out, ng);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
+    *bytes = fastkan_fwd_ws_bytes(N, in, out, ng);
+    return KAGNN_OK;
+}
+
+int kagnn_fastkan_fwd(const float* x, int64_t ldx, int64_t N, int32_t in, int32_t out, int32_t ng,
+                      const float* centers, float denominator, const float* ln_w, const float* ln_b,
+                      float ln_eps, const float* spline_w, const float* base_w, const float* base_b,
+                      float* y, int64_t ldy, float* row_stats, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_fk(__func__, in, out, ng);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldy >= out, "bad shape");
+    if (N == 0) return KAGNN_OK;
+    KAGNN_CHECK_ARG(x && centers && spline_w && y && ws, "null array");
+    KAGNN_CHECK_ARG(denominator != 0.0f, "denominator is zero");
+    KAGNN_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "layernorm weight and bias must both be given or both be null");
+    return fastkan_fwd(x, ldx, N, in, out, ng, centers, denominator, ln_w, ln_b, ln_eps, spline_w, base_w,
+                       base_b, y, ldy, row_stats, ws, ws_bytes, as_stream(stream));
+}
+
+int kagnn_fastkan_bwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t ng, size_t* bytes) {
+    int rc = check_fk(__func__, in, out, ng);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
+    *bytes = fastkan_bwd_ws_bytes(N, in, out, ng);
+    return KAGNN_OK;
+}
+
+int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N, int32_t in,
+                      int32_t out, int32_t ng, const float* centers, float denominator,
+                      const float* ln_w, const float* ln_b, float ln_eps, const float* spline_w,
+                      const float* base_w, const float* row_stats, float* gx, int64_t ldgx,
+                      float* g_ln_w, float* g_ln_b, float* g_spline_w, float* g_base_w,
+                      float* g_base_b, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_fk(__func__, in, out, ng);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
+    KAGNN_CHECK_ARG(centers && spline_w && g_spline_w && ws, "null array");
+    KAGNN_CHECK_ARG(N == 0 || (x && gy && gx), "null array");
+    KAGNN_CHECK_ARG(ln_w == nullptr || (ln_b && row_stats && g_ln_w && g_ln_b), "layernorm needs bias, row_stats and both gradient outputs");
+    KAGNN_CHECK_ARG(base_w == nullptr || (g_base_w && g_base_b), "base branch needs both gradient outputs");
+    return fastkan_bwd(x, ldx, gy, ldgy, N, in, out, ng, centers, denominator, ln_w, ln_b, ln_eps, spline_w,
+                       base_w, row_stats, gx, ldgx, g_ln_w, g_ln_b, g_spline_w, g_base_w, g_base_b, ws,
+                       ws_bytes, as_stream(stream));
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

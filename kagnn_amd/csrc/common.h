@@ -1,0 +1,154 @@
+// Shared device/host helpers for libkagnn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/kagnn_hip.h"
+
+namespace kagnn {
+
+// ---------------------------------------------------------------- error plumbing
+extern thread_local char g_err[512];
+inline int fail(int code, const char* fmt, const char* a = "", long b = 0, long c = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+    return code;
+}
+#define KAGNN_CHECK_ARG(cond, msg)                                                       \
+    do {                                                                                 \
+        if (!(cond)) return kagnn::fail(KAGNN_ERR_ARG, "%s: argument check failed: " msg, __func__); \
+    } while (0)
+#define KAGNN_HIP(...)                                                                   \
+    do {                                                                                 \
+        hipError_t e_ = (__VA_ARGS__);                                                   \
+        if (e_ != hipSuccess) {                                                          \
+            snprintf(kagnn::g_err, sizeof(kagnn::g_err), "%s: HIP error at line %d -> %s", __func__, __LINE__, \
+                     hipGetErrorString(e_));                                             \
+            return KAGNN_ERR_HIP;                                                        \
+        }                                                                                \
+    } while (0)
+#define KAGNN_LAUNCH_CHECK() KAGNN_HIP(hipGetLastError())
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxKnots = 48;   // G + 2k + 1 <= 32 + 8 + 1
+constexpr int kMaxOrder = 4;
+
+__host__ __device__ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// D-fragment row of v_mfma_f32_32x32x*: reg r (0..15), lane-half hi -> row in the 32x32 tile
+__device__ __forceinline__ int mfma32_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }
+
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float siluf(float x) { return x * sigmoidf_fast(x); }
+__device__ __forceinline__ float silu_gradf(float x) {
+    float s = sigmoidf_fast(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+
+// ---------------------------------------------------------------- local uniform B-spline
+// For x in knot span m (knots[m] <= x < knots[m+1], the half-open test of ekan.py:95) the only
+// non-zero order-K bases are j = m-K .. m; N[r] = B_{m-K+r,K}(x), r = 0..K, via the Cox-de Boor
+// recursion (ekan.py:96-105) restricted to that span: with u = (x-knots[m])/h,
+//   N^p_r = ((u+p-r)/p) N^{p-1}_{r-1} + ((r+1-u)/p) N^{p-1}_r .
+// dN[r] = d/dx of the same = (N^{K-1}_{r-1} - N^{K-1}_r) / h.
+// Outside [knots[0], knots[last]) everything is 0; non-finite x gives NaN like the reference.
+struct SplineGeom {
+    int nknots;     // G + 2K + 1
+    float g0;       // knots[0]
+    float inv_h;    // 1 / knot spacing
+};
+
+// geometry from the knot table itself (no host scalars, no device->host read-back)
+__device__ __forceinline__ SplineGeom geom_from_knots(const float* knots /* LDS */, int nknots) {
+    SplineGeom g;
+    g.nknots = nknots;
+    g.g0 = knots[0];
+    g.inv_h = (float)(nknots - 1) / (knots[nknots - 1] - knots[0]);
+    return g;
+}
+
+template <int K, bool DERIV>
+__device__ __forceinline__ int bspline_local(float x, const float* __restrict__ knots /* LDS */,
+                                             const SplineGeom& g, float (&N)[K + 1],
+                                             float (&dN)[K + 1]) {
+    const int last = g.nknots - 2;                 // last valid span index
+    float t = (x - g.g0) * g.inv_h;
+    float tc = fminf(fmaxf(t, 0.0f), (float)last);  // NaN -> 0
+    int m = (int)tc;
+    float tl = knots[m], tr = knots[m + 1];
+    // the arithmetic guess can be one span off right at a knot: settle it with the reference's
+    // own comparisons against the stored fp32 knots
+    if (x >= tr && m < last) {
+        ++m; tl = tr; tr = knots[m + 1];
+    } else if (x < tl && m > 0) {
+        --m; tr = tl; tl = knots[m];
+    }
+    const bool inside = (x >= tl) && (x < tr);
+    const float u = (x - tl) * g.inv_h;
+    float n[K + 1];
+    float prev[K + 1];
+    n[0] = 1.0f;
+#pragma unroll
+    for (int r = 1; r <= K; ++r) n[r] = 0.0f;
+#pragma unroll
+    for (int p = 1; p <= K; ++p) {
+#pragma unroll
+        for (int r = 0; r <= K; ++r) prev[r] = n[r];
+        const float ip = 1.0f / (float)p;
+#pragma unroll
+        for (int r = 0; r <= p; ++r) {
+            float a = (r >= 1) ? (u + (float)(p - r)) * ip * prev[r - 1] : 0.0f;
+            float b = (r <= p - 1) ? ((float)(r + 1) - u) * ip * prev[r] : 0.0f;
+            n[r] = a + b;
+        }
+        if (DERIV && p == K) {
+#pragma unroll
+            for (int r = 0; r <= K; ++r) {
+                float lo = (r >= 1) ? prev[r - 1] : 0.0f;
+                float hi = (r <= K - 1) ? prev[r] : 0.0f;
+                dN[r] = (lo - hi) * g.inv_h;
+            }
+        }
+    }
+    const bool finite = fabsf(x) <= 3.4028234e38f;   // false for NaN and +-Inf
+    const float nanv = __builtin_nanf("");
+#pragma unroll
+    for (int r = 0; r <= K; ++r) {
+        N[r] = finite ? (inside ? n[r] : 0.0f) : nanv;
+        if (DERIV) dN[r] = finite ? (inside ? dN[r] : 0.0f) : nanv;
+    }
+    return m;
+}
+
+// value of basis index c given the local set: N[c - (m-K)] if 0 <= c-(m-K) <= K else 0
+template <int K>
+__device__ __forceinline__ float pick_basis(const float (&N)[K + 1], int m, int c) {
+    const int d = c - (m - K);
+    float a = 0.0f;
+#pragma unroll
+    for (int r = 0; r <= K; ++r) a = (d == r) ? N[r] : a;
+    return a;
+}
+
+// arguments of the sum-aggregation kernels (aggregate.hip)
+struct AggArgs {
+    const float* x; long ldx;
+    float* out; long ldo;
+    const int* rowptr; const int* col; const float* ew;
+    long N; int F;
+    float self_scale;
+    const float* in_scale; const float* out_scale; const float* bias;
+    int skip_self; int hub_threshold;
+};
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace kagnn

@@ -1,0 +1,424 @@
+// FastKAN layer on gfx950: LayerNorm row statistics + Gaussian RBF expansion evaluated in
+// registers and fed straight into v_mfma_f32_32x32x2_f32 -- the [N, in, num_grids] basis tensor
+// of the reference never exists.
+//
+// Reference behaviour replaced: node_classification_clean/fastkan.py:76-85 (FastKANLayer.forward:
+// LayerNorm :77-78, RadialBasisFunction.forward :46-47, SplineLinear :81, base_linear(silu(x))
+// :82-84) and the autograd backward of those.  Fragment mapping is the one of kan_fp32.hip:
+// the two k-lanes of an MFMA are two input features, one MFMA per grid point g (plus one for
+// the SiLU base branch).
+#include "common.h"
+
+namespace kagnn {
+
+int kan_f32_pack(const float*, const float*, const float*, int, int, int, float*, float*, hipStream_t);
+size_t kan_f32_pack_fwd_bytes(int in, int out, int C);
+size_t kan_f32_pack_dx_bytes(int in, int out, int C);
+int kan_dw_reduce(const float* slab, long NS, long per_slab, float* gcat, hipStream_t st);
+void dw_plan(long N, int in, int out, int* NBx, long* rpw);
+
+struct LnArgs {
+    const float* w; const float* b; float eps;   // w == nullptr: no layernorm
+};
+
+__device__ __forceinline__ float rbf_val(float z, float c, float inv_den) {
+    const float d = (z - c) * inv_den;
+    return __expf(-d * d);
+}
+
+// ------------------------------------------------------------------ forward
+template <int OT>
+__global__ __launch_bounds__(256) void fastkan_fwd_kernel(
+    const float* __restrict__ x, long ldx, long N, int in, int ng, const float* __restrict__ centers,
+    float inv_den, LnArgs ln, const float* __restrict__ pack, int ot0, int OT_total,
+    const float* __restrict__ base_bias, float* __restrict__ y, long ldy, int out,
+    float* __restrict__ stats) {
+    __shared__ float s_c[kMaxKnots];
+    if (threadIdx.x < ng) s_c[threadIdx.x] = centers[threadIdx.x];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (row0 >= N) return;
+    const int r = lane & 31, kh = lane >> 5;
+    const long row = row0 + r;
+    const bool rv = row < N;
+    const int P = (in + 1) / 2, CT = ng + 1;
+    const float* xr = x + (rv ? row : 0) * ldx;
+
+    float mean = 0.0f, rstd = 1.0f;
+    if (ln.w) {                                   // two-pass mean / biased variance, eps inside the sqrt
+        float s = 0.0f;
+        for (int p = 0; p < P; ++p) { const int f = p + kh * P; if (rv && f < in) s += xr[f]; }
+        s += __shfl_xor(s, 32);
+        mean = s / (float)in;
+        float v = 0.0f;
+        for (int p = 0; p < P; ++p) {
+            const int f = p + kh * P;
+            if (rv && f < in) { const float d = xr[f] - mean; v = fmaf(d, d, v); }
+        }
+        v += __shfl_xor(v, 32);
+        rstd = rsqrtf(v / (float)in + ln.eps);
+        if (stats && kh == 0 && rv && ot0 == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    }
+
+    f32x16 acc[OT];
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    for (int p = 0; p < P; ++p) {
+        const int f = p + kh * P;
+        const bool fv = rv && f < in;
+        const float xv = fv ? xr[f] : 0.0f;
+        const float z = (ln.w && fv) ? fmaf((xv - mean) * rstd, ln.w[f], ln.b[f]) : xv;
+        const float sl = fv ? siluf(xv) : 0.0f;
+        const float* wp = pack + ((long)p * CT * OT_total + ot0) * 64 + lane;
+        for (int g = 0; g < ng; ++g) {
+            const float a = fv ? rbf_val(z, s_c[g], inv_den) : 0.0f;
+#pragma unroll
+            for (int t = 0; t < OT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wp[((long)g * OT_total + t) * 64], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sl, wp[((long)ng * OT_total + t) * 64], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+        const int col = 32 * (ot0 + t) + r;
+        const float bb = (base_bias && col < out) ? base_bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long rr = row0 + mfma32_row(i, kh);
+            if (rr < N && col < out) y[rr * ldy + col] = acc[t][i] + bb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ input gradient, stage 1
+// D_g[n][f] = sum_o gy[n][o] * W[o][f][g];  gz[n][f] = sum_g D_g * d phi_g / dz  (gradient w.r.t.
+// the layer-normed value), gb[n][f] = D_base * silu'(x).  Without layernorm gx = gz + gb directly.
+constexpr int kFkGroup = 9;
+
+__global__ __launch_bounds__(256) void fastkan_dx_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
+    int out, int ng, const float* __restrict__ centers, float inv_den, LnArgs ln,
+    const float* __restrict__ stats, const float* __restrict__ pack, int OT_total,
+    float* __restrict__ gx, long ldgx, float* __restrict__ gz_tmp /* [N,in] when layernorm */) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_c = smem;
+    const int Q = 16 * OT_total, outP = 2 * Q, ldt = outP + 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* s_gy = smem + kMaxKnots + (long)wave * 32 * ldt;
+    if (threadIdx.x < ng) s_c[threadIdx.x] = centers[threadIdx.x];
+    const long row0 = ((long)blockIdx.x * 4 + wave) * 32;
+    for (int i = lane; i < 32 * outP; i += 64) {
+        const int rr = i / outP, o = i - rr * outP;
+        const long row = row0 + rr;
+        s_gy[rr * ldt + o] = (row < N && o < out) ? gy[row * ldgy + o] : 0.0f;
+    }
+    __syncthreads();
+    if (row0 >= N) return;
+    const int r = lane & 31, kh = lane >> 5;
+    const int CT = ng + 1, FT = cdiv(in, 32);
+    const float* arow = s_gy + r * ldt + kh * Q;
+
+    for (int ft = 0; ft < FT; ++ft) {
+        const int f = 32 * ft + r;
+        float gzacc[16], gbacc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { gzacc[i] = 0.0f; gbacc[i] = 0.0f; }
+        for (int c0 = 0; c0 < CT; c0 += kFkGroup) {
+            f32x16 D[kFkGroup];
+#pragma unroll
+            for (int j = 0; j < kFkGroup; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) D[j][i] = 0.0f;
+            const float* wp = pack + ((long)ft * CT + c0) * Q * 64 + lane;
+            for (int q = 0; q < Q; ++q) {
+                const float a = arow[q];
+#pragma unroll
+                for (int j = 0; j < kFkGroup; ++j)
+                    if (c0 + j < CT)
+                        D[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wp[((long)j * Q + q) * 64], D[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long rr = row0 + mfma32_row(i, kh);
+                const bool ok = rr < N && f < in;
+                const float xv = ok ? x[rr * ldx + f] : 0.0f;
+                float z = xv;
+                if (ln.w && ok) z = fmaf((xv - stats[2 * rr]) * stats[2 * rr + 1], ln.w[f], ln.b[f]);
+                const float sg = silu_gradf(xv);
+#pragma unroll
+                for (int j = 0; j < kFkGroup; ++j) {
+                    const int c = c0 + j;
+                    if (c < ng) {
+                        const float d = (z - s_c[c]) * inv_den;
+                        gzacc[i] = fmaf(D[j][i], __expf(-d * d) * (-2.0f * d * inv_den), gzacc[i]);
+                    } else if (c == ng) {
+                        gbacc[i] = D[j][i] * sg;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long rr = row0 + mfma32_row(i, kh);
+            if (rr < N && f < in) {
+                if (ln.w) { gz_tmp[rr * (long)in + f] = gzacc[i]; gx[rr * ldgx + f] = gbacc[i]; }
+                else gx[rr * ldgx + f] = gzacc[i] + gbacc[i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ input gradient, stage 2
+// LayerNorm backward, one wave per row (persistent, so the per-feature sums for g_ln_weight /
+// g_ln_bias stay in registers):  gh = gz*gamma;  gx += rstd * (gh - mean(gh) - zhat*mean(gh*zhat)).
+constexpr int kLnMaxT = 16;     // features per lane: in <= 64*16
+
+__global__ __launch_bounds__(256) void fastkan_ln_bwd_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ gz, long N, int in, LnArgs ln,
+    const float* __restrict__ stats, float* __restrict__ gx, long ldgx,
+    float* __restrict__ partial /* [waves][2][in] */) {
+    const int lane = threadIdx.x & 63;
+    const long wid = blockIdx.x * 4L + (threadIdx.x >> 6), nw = gridDim.x * 4L;
+    float cw[kLnMaxT], cb[kLnMaxT];
+#pragma unroll
+    for (int t = 0; t < kLnMaxT; ++t) { cw[t] = 0.0f; cb[t] = 0.0f; }
+    const float inv_n = 1.0f / (float)in;
+    for (long row = wid; row < N; row += nw) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        float zh[kLnMaxT], gh[kLnMaxT];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int t = 0; t < kLnMaxT; ++t) {
+            const int f = lane + 64 * t;
+            zh[t] = 0.0f; gh[t] = 0.0f;
+            if (f < in) {
+                const float g = gz[row * (long)in + f];
+                zh[t] = (x[row * ldx + f] - mean) * rstd;
+                gh[t] = g * ln.w[f];
+                cw[t] = fmaf(g, zh[t], cw[t]);
+                cb[t] += g;
+                s1 += gh[t];
+                s2 = fmaf(gh[t], zh[t], s2);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 *= inv_n; s2 *= inv_n;
+#pragma unroll
+        for (int t = 0; t < kLnMaxT; ++t) {
+            const int f = lane + 64 * t;
+            if (f < in) gx[row * ldgx + f] += rstd * (gh[t] - s1 - zh[t] * s2);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kLnMaxT; ++t) {
+        const int f = lane + 64 * t;
+        if (f < in) { partial[(wid * 2 + 0) * in + f] = cw[t]; partial[(wid * 2 + 1) * in + f] = cb[t]; }
+    }
+}
+
+// out[j] = sum_w partial[w*stride + j], j < n  (fixed order)
+__global__ void sum_partials_kernel(const float* __restrict__ partial, long W, long stride, long n,
+                                    float* __restrict__ out0, float* __restrict__ out1, long split) {
+    const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float a = 0.0f;
+    for (long w = 0; w < W; ++w) a += partial[w * stride + j];
+    if (j < split) out0[j] = a; else out1[j - split] = a;
+}
+
+// column sums of gy (g_base_bias): block b sums rows [b*rpb, ...) for all columns
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, long lda,
+                                                             long N, int F, long rpb,
+                                                             float* __restrict__ partial) {
+    const long r0 = blockIdx.x * rpb, r1 = min(N, r0 + rpb);
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float s = 0.0f;
+        for (long r = r0; r < r1; ++r) s += a[r * lda + f];
+        partial[blockIdx.x * (long)F + f] = s;
+    }
+}
+
+// ------------------------------------------------------------------ weight gradient
+__global__ __launch_bounds__(256) void fastkan_dw_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
+    int out, int ng, const float* __restrict__ centers, float inv_den, LnArgs ln,
+    const float* __restrict__ stats, int OT, long rows_per_wave, float* __restrict__ slab) {
+    __shared__ float s_c[kMaxKnots];
+    if (threadIdx.x < ng) s_c[threadIdx.x] = centers[threadIdx.x];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, kh = lane >> 5;
+    const int ft = blockIdx.y / OT, ot = blockIdx.y % OT;
+    const int FT = gridDim.y / OT;
+    const long s = (long)blockIdx.x * 4 + wave;
+    const long rbeg = s * rows_per_wave;
+    const long rend = min(N, rbeg + rows_per_wave);
+    const int CT = ng + 1;
+    const int f = 32 * ft + r, o = 32 * ot + r;
+    const bool fv = f < in, ov = o < out;
+    const long inP = 32L * FT, outP = 32L * OT;
+    const float gam = (ln.w && fv) ? ln.w[f] : 1.0f, bet = (ln.w && fv) ? ln.b[f] : 0.0f;
+
+    for (int c0 = 0; c0 < CT; c0 += kFkGroup) {
+        f32x16 D[kFkGroup];
+#pragma unroll
+        for (int j = 0; j < kFkGroup; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) D[j][i] = 0.0f;
+        for (long n = rbeg + kh; n < rend + kh; n += 2) {
+            const bool nv = n < rend;
+            const bool live = nv && fv;
+            const float xv = live ? x[n * ldx + f] : 0.0f;
+            const float b = (nv && ov) ? gy[n * ldgy + o] : 0.0f;
+            float z = xv;
+            if (ln.w && live) z = fmaf((xv - stats[2 * n]) * stats[2 * n + 1], gam, bet);
+            const float sl = siluf(xv);
+#pragma unroll
+            for (int j = 0; j < kFkGroup; ++j) {
+                const int c = c0 + j;
+                if (c < CT) {
+                    float a = (c == ng) ? sl : rbf_val(z, s_c[min(c, ng - 1)], inv_den);
+                    a = live ? a : 0.0f;
+                    D[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, D[j], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kFkGroup; ++j) {
+            const int c = c0 + j;
+            if (c < CT) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int fl = 32 * ft + mfma32_row(i, kh);
+                    slab[((s * CT + c) * inP + fl) * outP + o] = D[j][i];
+                }
+            }
+        }
+    }
+}
+
+// g_spline_weight[o][f*ng+g] = gcat[g][f][o] ; g_base_weight[o][f] = gcat[ng][f][o]
+__global__ void fastkan_dw_unpack_kernel(const float* __restrict__ gcat, int in, int out, int ng,
+                                         long inP, long outP, float* __restrict__ g_sw,
+                                         float* __restrict__ g_bw) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)in * out) return;
+    const int o = i % out, f = i / out;
+    for (int g = 0; g < ng; ++g)
+        g_sw[((long)o * in + f) * ng + g] = gcat[((long)g * inP + f) * outP + o];
+    if (g_bw) g_bw[(long)o * in + f] = gcat[((long)ng * inP + f) * outP + o];
+}
+
+// ------------------------------------------------------------------ host launchers
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng) {
+    return al256(kan_f32_pack_fwd_bytes(in, out, ng)) + al256(kan_f32_pack_dx_bytes(in, out, ng));
+}
+
+int fastkan_fwd(const float* x, long ldx, long N, int in, int out, int ng, const float* centers,
+                float den, const float* lnw, const float* lnb, float eps, const float* sw,
+                const float* bw, const float* bb, float* y, long ldy, float* stats, void* ws,
+                size_t ws_bytes, hipStream_t st) {
+    if (ws_bytes < fastkan_fwd_ws_bytes(N, in, out, ng)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "fastkan_fwd");
+    if (lnw && !stats) return fail(KAGNN_ERR_ARG, "%s: row_stats is required with layernorm", "fastkan_fwd");
+    float* pf = (float*)ws;
+    float* pd = (float*)((char*)ws + al256(kan_f32_pack_fwd_bytes(in, out, ng)));
+    { int rc = kan_f32_pack(bw, sw, nullptr, in, out, ng, pf, pd, st); if (rc) return rc; }
+    LnArgs ln{lnw, lnb, eps};
+    const int OTt = cdiv(out, 32);
+    dim3 grid(cdiv(N, 128));
+    for (int ot0 = 0; ot0 < OTt; ot0 += 4) {
+        const int n = min(4, OTt - ot0);
+#define L(OTN) fastkan_fwd_kernel<OTN><<<grid, 256, 0, st>>>(x, ldx, N, in, ng, centers, 1.0f / den, ln, pf, ot0, OTt, bb, y, ldy, out, stats)
+        if (n == 1) L(1); else if (n == 2) L(2); else if (n == 3) L(3); else L(4);
+#undef L
+        KAGNN_LAUNCH_CHECK();
+    }
+    return KAGNN_OK;
+}
+
+struct FkBwdPlan {
+    size_t pack_f, pack_d, gz, gcat, slab, lnpart, colpart, total;
+    int nb; long rpw; long NS; long per; int ln_blocks; int col_blocks; long col_rpb;
+};
+
+static FkBwdPlan fk_plan(long N, int in, int out, int ng) {
+    FkBwdPlan p;
+    p.pack_f = al256(kan_f32_pack_fwd_bytes(in, out, ng));
+    p.pack_d = al256(kan_f32_pack_dx_bytes(in, out, ng));
+    p.gz = al256((size_t)N * in * 4);
+    dw_plan(N, in, out, &p.nb, &p.rpw);
+    p.NS = (long)p.nb * 4;
+    p.per = (long)(ng + 1) * 32 * cdiv(in, 32) * 32 * cdiv(out, 32);
+    p.gcat = al256((size_t)p.per * 4);
+    p.slab = al256((size_t)p.NS * p.per * 4);
+    p.ln_blocks = (int)min(256L, (N + 3) / 4 > 0 ? (N + 3) / 4 : 1);
+    p.lnpart = al256((size_t)p.ln_blocks * 4 * 2 * in * 4);
+    p.col_blocks = (int)max(1L, min(1024L, N / 64 + 1));
+    p.col_rpb = (N + p.col_blocks - 1) / p.col_blocks;
+    p.colpart = al256((size_t)p.col_blocks * out * 4);
+    p.total = p.pack_f + p.pack_d + p.gz + p.gcat + p.slab + p.lnpart + p.colpart;
+    return p;
+}
+
+size_t fastkan_bwd_ws_bytes(long N, int in, int out, int ng) { return fk_plan(N, in, out, ng).total; }
+
+int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int ng,
+                const float* centers, float den, const float* lnw, const float* lnb, float eps,
+                const float* sw, const float* bw, const float* stats, float* gx, long ldgx,
+                float* g_lnw, float* g_lnb, float* g_sw, float* g_bw, float* g_bb, void* ws,
+                size_t ws_bytes, hipStream_t st) {
+    const FkBwdPlan p = fk_plan(N, in, out, ng);
+    if (ws_bytes < p.total) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "fastkan_bwd");
+    if (lnw && in > 64 * kLnMaxT) return fail(KAGNN_ERR_UNSUPPORTED, "%s: layernorm backward supports input_dim <= 1024", "fastkan_bwd");
+    char* q = (char*)ws;
+    float* pf = (float*)q; q += p.pack_f;
+    float* pd = (float*)q; q += p.pack_d;
+    float* gz = (float*)q; q += p.gz;
+    float* gcat = (float*)q; q += p.gcat;
+    float* slab = (float*)q; q += p.slab;
+    float* lnpart = (float*)q; q += p.lnpart;
+    float* colpart = (float*)q;
+    const float inv_den = 1.0f / den;
+    LnArgs ln{lnw, lnb, eps};
+    const int OTt = cdiv(out, 32), FT = cdiv(in, 32);
+    if (N > 0) {
+        int rc = kan_f32_pack(bw, sw, nullptr, in, out, ng, pf, pd, st);
+        if (rc) return rc;
+        const size_t lds = (kMaxKnots + 4L * 32 * (32 * OTt + 1)) * sizeof(float);
+        if (lds > 160 * 1024) return fail(KAGNN_ERR_UNSUPPORTED, "%s: output_dim too large", "fastkan_bwd");
+        if (lds > 64 * 1024)
+            KAGNN_HIP(hipFuncSetAttribute((const void*)fastkan_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        fastkan_dx_kernel<<<cdiv(N, 128), 256, lds, st>>>(x, ldx, gy, ldgy, N, in, out, ng, centers, inv_den, ln, stats, pd, OTt, gx, ldgx, gz);
+        KAGNN_LAUNCH_CHECK();
+    }
+    if (lnw) {
+        fastkan_ln_bwd_kernel<<<p.ln_blocks, 256, 0, st>>>(x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart);
+        KAGNN_LAUNCH_CHECK();
+        sum_partials_kernel<<<cdiv(2L * in, 256), 256, 0, st>>>(lnpart, p.ln_blocks * 4L, 2L * in, 2L * in, g_lnw, g_lnb, in);
+        KAGNN_LAUNCH_CHECK();
+    }
+    dim3 grid(p.nb, FT * OTt);
+    fastkan_dw_kernel<<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, ng, centers, inv_den, ln, stats, OTt, p.rpw, slab);
+    KAGNN_LAUNCH_CHECK();
+    { int rc = kan_dw_reduce(slab, p.NS, p.per, gcat, st); if (rc) return rc; }
+    fastkan_dw_unpack_kernel<<<cdiv((long)in * out, 256), 256, 0, st>>>(gcat, in, out, ng, 32L * FT, 32L * OTt, g_sw, g_bw);
+    KAGNN_LAUNCH_CHECK();
+    if (g_bb) {
+        colsum_partial_kernel<<<p.col_blocks, 256, 0, st>>>(gy, ldgy, N, out, p.col_rpb, colpart);
+        KAGNN_LAUNCH_CHECK();
+        sum_partials_kernel<<<cdiv(out, 256), 256, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
+        KAGNN_LAUNCH_CHECK();
+    }
+    return KAGNN_OK;
+}
+
+}  // namespace kagnn

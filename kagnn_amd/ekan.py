@@ -1,0 +1,162 @@
+"""efficient-KAN layers with the reference's module surface, computed by libkagnn_hip.so.
+
+Drop-in for ``node_classification_clean/ekan.py`` (``KANLinear`` :7-233, ``KAN`` :236-281 of
+the reference): same constructor signatures, same parameter / buffer names and shapes
+(``base_weight, spline_weight, spline_scaler, grid``), so ``state_dict()`` round-trips with the
+reference.  ``forward`` does not run torch ops: it calls ``kagnn_kan_linear_fwd`` (and the two
+backward entry points through autograd) -- see ``kagnn_amd.ops``.
+
+Only parameter *initialisation* runs host-side torch code (a one-off least-squares fit, like the
+reference's ``reset_parameters`` :57-77); it is not on the hot path.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+def _init_bases(points: torch.Tensor, knots: torch.Tensor, order: int) -> torch.Tensor:
+    """Dense B-spline collocation matrix for the init-time fit only (G+1 sample points).
+    points [M, in], knots [in, G+2k+1] -> [M, in, G+k]."""
+    p = points.unsqueeze(-1)
+    b = ((p >= knots[:, :-1]) & (p < knots[:, 1:])).to(points.dtype)
+    for d in range(1, order + 1):
+        left = (p - knots[:, : -(d + 1)]) / (knots[:, d:-1] - knots[:, : -(d + 1)])
+        right = (knots[:, d + 1:] - p) / (knots[:, d + 1:] - knots[:, 1:-d])
+        b = left * b[..., :-1] + right * b[..., 1:]
+    return b
+
+
+class KANLinear(nn.Module):
+    """``y = silu(x) @ base_weight.T + B(x) @ (spline_weight * spline_scaler[..., None]).T``
+
+    ``B(x)`` are the ``grid_size + spline_order`` uniform B-spline bases per input feature; they
+    are evaluated in registers inside the HIP kernel and never stored.
+    """
+
+    def __init__(self, in_features, out_features, grid_size=5, spline_order=3, scale_noise=0.1,
+                 scale_base=1.0, scale_spline=1.0, enable_standalone_scale_spline=True,
+                 base_activation=torch.nn.SiLU, grid_eps=0.02, grid_range=[-1, 1]):
+        super().__init__()
+        if base_activation is not torch.nn.SiLU:
+            raise NotImplementedError("the fused kernel implements the SiLU base branch only "
+                                      "(the only activation KAGNN uses)")
+        if not 1 <= spline_order <= 4:
+            raise NotImplementedError("spline_order must be in 1..4 (KAGNN's search space)")
+        self.in_features = in_features
+        self.out_features = out_features
+        self.grid_size = grid_size
+        self.spline_order = spline_order
+        self.scale_noise = scale_noise
+        self.scale_base = scale_base
+        self.scale_spline = scale_spline
+        self.enable_standalone_scale_spline = enable_standalone_scale_spline
+        self.base_activation = base_activation()
+        self.grid_eps = grid_eps
+        self.precision: Optional[int] = None      # None -> ops.default_precision()
+
+        step = (grid_range[1] - grid_range[0]) / grid_size
+        row = torch.arange(-spline_order, grid_size + spline_order + 1) * step + grid_range[0]
+        self.register_buffer("grid", row.expand(in_features, -1).contiguous())
+
+        coeffs = grid_size + spline_order
+        self.base_weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.spline_weight = nn.Parameter(torch.empty(out_features, in_features, coeffs))
+        if enable_standalone_scale_spline:
+            self.spline_scaler = nn.Parameter(torch.empty(out_features, in_features))
+        self._knots_key = None
+        self._knots_row = None
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ init (host side)
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.base_weight, a=math.sqrt(5) * self.scale_base)
+        with torch.no_grad():
+            k = self.spline_order
+            noise = (torch.rand(self.grid_size + 1, self.in_features, self.out_features) - 0.5)
+            noise = noise * self.scale_noise / self.grid_size
+            fit = self.curve2coeff(self.grid.T[k:-k], noise)
+            if not self.enable_standalone_scale_spline:
+                fit = fit * self.scale_spline
+            self.spline_weight.copy_(fit)
+            if self.enable_standalone_scale_spline:
+                nn.init.kaiming_uniform_(self.spline_scaler, a=math.sqrt(5) * self.scale_spline)
+
+    def curve2coeff(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """Least-squares spline coefficients through samples ``y[M,in,out]`` at ``x[M,in]``."""
+        assert x.dim() == 2 and x.size(1) == self.in_features
+        assert y.size() == (x.size(0), self.in_features, self.out_features)
+        lhs = _init_bases(x, self.grid, self.spline_order).permute(1, 0, 2)   # [in, M, C]
+        sol = torch.linalg.lstsq(lhs, y.permute(1, 0, 2)).solution            # [in, C, out]
+        return sol.permute(2, 0, 1).contiguous()
+
+    @property
+    def scaled_spline_weight(self):
+        if self.enable_standalone_scale_spline:
+            return self.spline_weight * self.spline_scaler.unsqueeze(-1)
+        return self.spline_weight
+
+    # ------------------------------------------------------------------ hot path
+    def _knots(self) -> torch.Tensor:
+        g = self.grid
+        key = (g.data_ptr(), g._version, str(g.device))
+        if key != self._knots_key:
+            row = g[0].detach().to(torch.float32)
+            steps = row[1:] - row[:-1]
+            h = float(steps.mean())
+            same = bool((g == row).all()) and bool(((steps - h).abs() <= 1e-4 * abs(h)).all()) and h > 0
+            if not same:
+                raise NotImplementedError(
+                    "KANLinear.grid is not one uniform knot vector shared by all features; adaptive "
+                    "grids (update_grid) are outside the KAGNN hot path and not implemented")
+            self._knots_row = row.contiguous().clone()
+            self._knots_key = key
+        return self._knots_row
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.dim() == 2 and x.size(1) == self.in_features
+        scaler = self.spline_scaler if self.enable_standalone_scale_spline else None
+        return ops.kan_linear(x, self.base_weight, self.spline_weight, scaler, self._knots(),
+                              self.grid_size, self.spline_order, self.precision)
+
+    # ------------------------------------------------------------------ not on the KAGNN path
+    def update_grid(self, x: torch.Tensor, margin=0.01):
+        raise NotImplementedError("update_grid is never called by KAGNN (SURVEY.md 2, row 1); "
+                                  "adaptive grids are out of scope of this implementation")
+
+    def regularization_loss(self, regularize_activation=1.0, regularize_entropy=1.0):
+        mag = self.spline_weight.abs().mean(-1)
+        total = mag.sum()
+        share = mag / total
+        return regularize_activation * total - regularize_entropy * torch.sum(share * share.log())
+
+
+class KAN(nn.Module):
+    """A bare chain of KANLinear layers (no activation or norm in between), ``ekan.py:236-281``."""
+
+    def __init__(self, layers_hidden: Sequence[int], grid_size=5, spline_order=3, scale_noise=0.1,
+                 scale_base=1.0, scale_spline=1.0, base_activation=torch.nn.SiLU, grid_eps=0.02,
+                 grid_range=[-1, 1]):
+        super().__init__()
+        self.grid_size = grid_size
+        self.spline_order = spline_order
+        self.layers = nn.ModuleList(
+            KANLinear(a, b, grid_size=grid_size, spline_order=spline_order, scale_noise=scale_noise,
+                      scale_base=scale_base, scale_spline=scale_spline, base_activation=base_activation,
+                      grid_eps=grid_eps, grid_range=grid_range)
+            for a, b in zip(layers_hidden[:-1], layers_hidden[1:]))
+
+    def forward(self, x: torch.Tensor, update_grid=False) -> torch.Tensor:
+        if update_grid:
+            raise NotImplementedError("update_grid=True is not used by KAGNN and not implemented")
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+    def regularization_loss(self, regularize_activation=1.0, regularize_entropy=1.0):
+        return sum(l.regularization_loss(regularize_activation, regularize_entropy) for l in self.layers)

@@ -1,0 +1,178 @@
+"""KAN-GNN convolutions and node-level models with the reference's class surface.
+
+Mirrors ``node_classification_clean/models.py`` of the reference: ``KANLayer`` :27-29,
+``KAGCNConv`` :31-37, ``GIKANLayer`` :48-56, ``FKANLayer`` :58-66, ``FASTKAGCNConv`` :68-74,
+``GIFASTKANLayer`` :85-92, ``GKAN_Nodes`` :150-203, ``GFASTKAN_Nodes`` :205-257 -- same constructor
+arguments, attribute names (``nn``/``eps`` for the GIN flavour, ``lin``/``bias`` for the GCN
+flavour, ``convs``/``bns``/``lay_out`` for the models) and therefore the same state_dict keys.
+
+The reference subclasses torch_geometric's ``GINConv`` / ``GCNConv``; torch_geometric is a
+third-party dependency that is not available here, so the two message-passing schemes are
+restated on top of ``kagnn_amd.ops`` (CSR built once per ``edge_index``, HIP aggregation kernel):
+
+* GIN  (``GINConv(nn, eps=0, train_eps=False)``):  ``nn((1+eps) * x_i + sum_{j->i} x_j)``
+* GCN  (``GCNConv(in, out)`` defaults: self loops added, symmetric normalisation, bias, not
+  cached):  ``bias + sum_{j->i or j=i} d_i^-1/2 d_j^-1/2 * lin(x)_j``,  ``d`` = in-degree incl. the loop.
+
+The GAT variants (``KAGATConv`` / ``FASTKAGATConv``) are outside the hot path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ekan import KAN as eKAN, KANLinear
+from .fastkan import FastKAN, FastKANLayer
+
+
+def make_kan(num_features, hidden_dim, out_dim, hidden_layers, grid_size, spline_order):
+    sizes = [num_features] + [hidden_dim] * (hidden_layers - 1) + [out_dim]
+    return eKAN(layers_hidden=sizes, grid_size=grid_size, spline_order=spline_order)
+
+
+def make_fastkan(num_features, hidden_dim, out_dim, hidden_layers, grid_size):
+    sizes = [num_features] + [hidden_dim] * (hidden_layers - 1) + [out_dim]
+    return FastKAN(layers_hidden=sizes, num_grids=grid_size)
+
+
+class KANLayer(KANLinear):
+    def __init__(self, input_dim, output_dim, grid_size=4, spline_order=3):
+        super().__init__(in_features=input_dim, out_features=output_dim, grid_size=grid_size,
+                         spline_order=spline_order)
+
+
+class FKANLayer(FastKANLayer):
+    def __init__(self, input_dim, output_dim, num_grids=4):
+        super().__init__(input_dim=input_dim, output_dim=output_dim, num_grids=num_grids)
+        self.num_grids = num_grids
+
+    def reset_parameters(self):
+        self.__init__(self.input_dim, self.output_dim, self.num_grids)
+
+
+# ---------------------------------------------------------------------------------- conv bases
+class _SumAggregateConv(nn.Module):
+    """GIN message passing: ``nn((1 + eps) * x_i + sum_{j -> i} x_j)`` with a fixed eps buffer."""
+
+    def __init__(self, net: nn.Module, eps: float = 0.0):
+        super().__init__()
+        self.nn = net
+        self.register_buffer("eps", torch.full((1,), float(eps)))
+        self._eps_key = None
+        self._eps_val = float(eps)
+
+    def _eps(self) -> float:
+        key = (self.eps.data_ptr(), self.eps._version)
+        if key != self._eps_key:              # one host read per change of the buffer, not per call
+            self._eps_val = float(self.eps)
+            self._eps_key = key
+        return self._eps_val
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+        g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
+        return self.nn(ops.aggregate_sum(x, g, self_scale=1.0 + self._eps()))
+
+
+class _NormalisedConv(nn.Module):
+    """GCN message passing around a KAN transform ``lin`` (transform first, then aggregate)."""
+
+    def __init__(self, lin: nn.Module, out_channels: int):
+        super().__init__()
+        self.lin = lin
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor,
+                edge_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if edge_weight is not None or (isinstance(edge_index, torch.Tensor) and edge_index.is_sparse):
+            raise NotImplementedError("weighted / sparse-matrix adjacency for the GCN flavour is not "
+                                      "implemented yet (SURVEY.md 8(f) rank 3)")
+        g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
+        dis = g.gcn_dis
+        return ops.aggregate_sum(self.lin(x), g, self_scale=1.0, in_scale=dis, out_scale=dis,
+                                 bias=self.bias, skip_self_loops=True)
+
+
+class KAGCNConv(_NormalisedConv):
+    def __init__(self, in_feat: int, out_feat: int, grid_size: int = 4, spline_order: int = 3):
+        super().__init__(KANLayer(in_feat, out_feat, grid_size, spline_order), out_feat)
+
+
+class GIKANLayer(_SumAggregateConv):
+    def __init__(self, in_feat: int, out_feat: int, grid_size: int = 4, spline_order: int = 3,
+                 hidden_dim: int = 16, nb_layers: int = 2):
+        super().__init__(make_kan(in_feat, hidden_dim, out_feat, nb_layers, grid_size, spline_order))
+
+
+class FASTKAGCNConv(_NormalisedConv):
+    def __init__(self, in_feat: int, out_feat: int, grid_size: int = 4):
+        super().__init__(FKANLayer(in_feat, out_feat, num_grids=grid_size), out_feat)
+        self.grid_size = grid_size
+
+
+class GIFASTKANLayer(_SumAggregateConv):
+    def __init__(self, in_feat: int, out_feat: int, grid_size: int = 4, hidden_dim: int = 16,
+                 nb_layers: int = 2):
+        super().__init__(make_fastkan(in_feat, hidden_dim, out_feat, nb_layers, grid_size))
+
+
+# ---------------------------------------------------------------------------------- node models
+class _NodeModel(nn.Module):
+    """mp_layers x {conv -> BatchNorm1d -> dropout}, skip-concat of the input and every layer
+    output, then a KAN / FastKAN read-out (reference ``models.py:192-203,246-257``)."""
+
+    def _build(self, conv_type, mp_layers, num_features, hidden_channels, skip, dropout, make_conv):
+        if conv_type == "gat":
+            raise NotImplementedError("the GAT flavour is outside the KAGNN hot path (SURVEY.md 2 row 5)")
+        if conv_type not in ("gcn", "gin"):
+            raise ValueError("unknown conv_type")
+        self.convs = nn.ModuleList()
+        self.bns = nn.ModuleList()
+        for i in range(mp_layers):
+            self.convs.append(make_conv(num_features if i == 0 else hidden_channels))
+            self.bns.append(nn.BatchNorm1d(hidden_channels))
+        self.skip = skip
+        self.dropout = nn.Dropout(dropout)
+        return num_features + mp_layers * hidden_channels if skip else hidden_channels
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+        g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
+        outs = [x]
+        for conv, bn in zip(self.convs, self.bns):
+            x = self.dropout(bn(conv(x, g)))
+            outs.append(x)
+        if self.skip:
+            x = torch.cat(outs, dim=1)
+        return self.lay_out(x)
+
+
+class GKAN_Nodes(_NodeModel):
+    def __init__(self, conv_type: str, mp_layers: int, num_features: int, hidden_channels: int,
+                 num_classes: int, skip: bool = True, grid_size: int = 4, spline_order: int = 3,
+                 hidden_layers: int = 2, dropout: float = 0., heads=4):
+        super().__init__()
+
+        def make_conv(width):
+            if conv_type == "gcn":
+                return KAGCNConv(width, hidden_channels, grid_size, spline_order)
+            return GIKANLayer(width, hidden_channels, grid_size, spline_order, hidden_channels, hidden_layers)
+
+        dim = self._build(conv_type, mp_layers, num_features, hidden_channels, skip, dropout, make_conv)
+        self.lay_out = KANLinear(dim, num_classes, grid_size=grid_size, spline_order=spline_order)
+
+
+class GFASTKAN_Nodes(_NodeModel):
+    def __init__(self, conv_type: str, mp_layers: int, num_features: int, hidden_channels: int,
+                 num_classes: int, skip: bool = True, grid_size: int = 4, hidden_layers: int = 2,
+                 dropout: float = 0., heads=4):
+        super().__init__()
+
+        def make_conv(width):
+            if conv_type == "gcn":
+                return FASTKAGCNConv(width, hidden_channels, grid_size)
+            return GIFASTKANLayer(width, hidden_channels, grid_size, hidden_channels, hidden_layers)
+
+        dim = self._build(conv_type, mp_layers, num_features, hidden_channels, skip, dropout, make_conv)
+        self.lay_out = FastKANLayer(dim, num_classes, num_grids=grid_size)

@@ -1,0 +1,414 @@
+"""Autograd-aware Python front of the C ABI (include/kagnn_hip.h).
+
+torch is plumbing here: it owns device memory, the current stream and the autograd tape.  Every
+arithmetic step of the hot path is a call into libkagnn_hip.so through ctypes.  CPU tensors are
+refused -- there is no CPU implementation in this package (the CPU restatement lives in
+``oracle/`` and is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import weakref
+from ctypes import byref, c_int64, c_size_t
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import PREC_FP32, PREC_SPLIT
+
+HUB_THRESHOLD = 512
+
+
+def default_precision() -> int:
+    """`KAGNN_PRECISION=fp32|split` (default split: fp16 hi/lo operands, fp32 accumulate)."""
+    v = os.environ.get("KAGNN_PRECISION", "split").lower()
+    if v in ("fp32", "exact", "0"):
+        return PREC_FP32
+    if v in ("split", "1"):
+        return PREC_SPLIT
+    raise ValueError(f"KAGNN_PRECISION={v!r}: expected 'fp32' or 'split'")
+
+
+class EntryPointTimer:
+    """Optional per-entry-point device timing (HIP events on the launch stream), used by bench.py
+    to report the dominant kernel's duration live.  Off by default: zero overhead."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.records:
+            d = out.setdefault(name, [0, 0.0])
+            d[0] += 1
+            d[1] += a.elapsed_time(b)
+        return {k: {"launches": v[0], "total_ms": v[1], "avg_ms": v[1] / v[0]} for k, v in out.items()}
+
+
+_timer: Optional[EntryPointTimer] = None
+
+
+def set_timer(t: Optional[EntryPointTimer]) -> None:
+    global _timer
+    _timer = t
+
+
+def _call(name: str, *args) -> None:
+    if _timer is None:
+        _lib.call(name, *args)
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _lib.call(name, *args)
+    b.record()
+    _timer.records.append((name, a, b))
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "kagnn_amd ops run only on MI355X device tensors (libkagnn_hip.so); got a CPU tensor. "
+                "There is no CPU fallback in this package.")
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """2-D fp32 with unit column stride (row stride is passed to the kernels as ld)."""
+    if t.dim() != 2:
+        raise AssertionError(f"expected a 2-D tensor, got shape {tuple(t.shape)}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"kagnn_amd kernels are fp32; got {t.dtype}")
+    if t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1)):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.size(0) > 1 else max(t.size(1), t.stride(0))
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ======================================================================== graph structure
+class GraphIndex:
+    """CSR (by destination) and its transpose (by source) of one ``edge_index``, int32, on device.
+
+    Built once per edge list by ``kagnn_csr_build`` (stable radix sort => ``perm`` equals
+    ``argsort(dst, stable=True)`` bit for bit) and cached; replaces the index bookkeeping
+    torch_geometric redoes on every ``propagate`` call.
+    """
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, hub_threshold: int = HUB_THRESHOLD):
+        _need_cuda(edge_index)
+        if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.int64:
+            raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(edge_index.size(1))
+        self.hub_threshold = int(hub_threshold)
+        self.device = edge_index.device
+        src = edge_index[0].contiguous()
+        dst = edge_index[1].contiguous()
+        self.rowptr, self.col, self.perm, self.hub_seg, self.num_hub_seg = self._build(dst, src)
+        self.rowptr_t, self.col_t, self.perm_t, self.hub_seg_t, self.num_hub_seg_t = self._build(src, dst)
+        self._dis = None
+
+    def _build(self, key, val):
+        n, e, dev = self.num_nodes, self.num_edges, self.device
+        nbytes = c_size_t(0)
+        _call("kagnn_csr_workspace_bytes", e, n, byref(nbytes))
+        ws = _ws(nbytes.value, dev)
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(e, dtype=torch.int32, device=dev)
+        perm = torch.empty(e, dtype=torch.int32, device=dev)
+        cap = 2 * e // self.hub_threshold + 1
+        hub = torch.empty(3 * cap, dtype=torch.int32, device=dev)
+        nseg = c_int64(0)
+        _call("kagnn_csr_build", _ptr(key), _ptr(val), e, n, _ptr(rowptr), _ptr(col), _ptr(perm),
+                  self.hub_threshold, _ptr(hub), cap, byref(nseg), _ptr(ws), ws.numel(), _stream())
+        return rowptr, col, perm, hub, int(nseg.value)
+
+    @property
+    def gcn_dis(self) -> torch.Tensor:
+        """deg^-1/2 with one self loop per node (gcn_norm, add_remaining_self_loops)."""
+        if self._dis is None:
+            dis = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
+            _call("kagnn_gcn_deg_inv_sqrt", _ptr(self.rowptr), _ptr(self.col), self.num_nodes,
+                      _ptr(dis), _stream())
+            self._dis = dis
+        return self._dis
+
+    def side(self, transposed: bool):
+        if transposed:
+            return self.rowptr_t, self.col_t, self.perm_t, self.hub_seg_t, self.num_hub_seg_t
+        return self.rowptr, self.col, self.perm, self.hub_seg, self.num_hub_seg
+
+
+_graph_cache: "dict[tuple, GraphIndex]" = {}
+_GRAPH_CACHE_MAX = 8
+
+
+def graph_index(edge_index: torch.Tensor, num_nodes: int) -> GraphIndex:
+    """Cached GraphIndex keyed on the identity and version of ``edge_index`` (SURVEY 8(b) ownership)."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
+           edge_index.device.index)
+    g = _graph_cache.get(key)
+    if g is None:
+        if len(_graph_cache) >= _GRAPH_CACHE_MAX:
+            _graph_cache.pop(next(iter(_graph_cache)))
+        g = GraphIndex(edge_index, num_nodes)
+        g._keepalive = edge_index     # the key holds a raw pointer: pin the tensor it names
+        _graph_cache[key] = g
+    return g
+
+
+def clear_graph_cache() -> None:
+    _graph_cache.clear()
+
+
+# ======================================================================== aggregation
+def _aggregate_raw(x, g: GraphIndex, transposed, self_scale, edge_weight, in_scale, out_scale, bias,
+                   skip_self) -> torch.Tensor:
+    x = _rows(x)
+    n, f = x.shape
+    if n != g.num_nodes:
+        raise ValueError(f"x has {n} rows but the graph has {g.num_nodes} nodes")
+    rowptr, col, _, hub, nhub = g.side(transposed)
+    out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    _call("kagnn_aggregate_sum", _ptr(x), _ld(x), _ptr(out), f, _ptr(rowptr), _ptr(col),
+              _ptr(edge_weight), n, f, float(self_scale), _ptr(in_scale), _ptr(out_scale), _ptr(bias),
+              int(skip_self), _ptr(hub) if nhub else None, nhub, g.hub_threshold, _stream())
+    return out
+
+
+class _AggregateFn(Function):
+    """out = out_scale * (self_scale*s*x_i + sum_e w_e * s_j * x_j) + bias over the by-dst CSR;
+    backward is the same kernel on the transposed CSR with in/out scales swapped."""
+
+    @staticmethod
+    def forward(ctx, x, bias, g, self_scale, edge_weight, in_scale, out_scale, skip_self):
+        _need_cuda(x)
+        ctx.g, ctx.self_scale, ctx.skip_self = g, self_scale, skip_self
+        ctx.in_scale, ctx.out_scale = in_scale, out_scale
+        ctx.edge_weight_t = None
+        if edge_weight is not None:
+            w = edge_weight.to(torch.float32)
+            ctx.edge_weight_t = w[g.perm_t.long()].contiguous()
+            edge_weight = w[g.perm.long()].contiguous()
+        return _aggregate_raw(x, g, False, self_scale, edge_weight, in_scale, out_scale, bias, skip_self)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        gx = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _aggregate_raw(gout, ctx.g, True, ctx.self_scale, ctx.edge_weight_t, ctx.out_scale,
+                                ctx.in_scale, None, ctx.skip_self)
+        if ctx.needs_input_grad[1]:
+            gb = gout.sum(0)
+        return gx, gb, None, None, None, None, None, None
+
+
+def aggregate_sum(x, g: GraphIndex, self_scale: float = 1.0, edge_weight=None, in_scale=None,
+                  out_scale=None, bias=None, skip_self_loops: bool = False) -> torch.Tensor:
+    return _AggregateFn.apply(x, bias, g, float(self_scale), edge_weight, in_scale, out_scale,
+                              bool(skip_self_loops))
+
+
+class _GineFn(Function):
+    @staticmethod
+    def forward(ctx, x, edge_attr, g, self_scale):
+        _need_cuda(x, edge_attr)
+        x, ea = _rows(x), _rows(edge_attr)
+        n, f = x.shape
+        if ea.shape != (g.num_edges, f):
+            raise ValueError("edge_attr must be [E, F] with F == x.size(1)")
+        out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+        _call("kagnn_aggregate_gine", _ptr(x), _ld(x), _ptr(ea), _ld(ea), _ptr(out), f,
+                  _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm), n, f, float(self_scale), _stream())
+        ctx.save_for_backward(x, ea)
+        ctx.g, ctx.self_scale = g, self_scale
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, ea = ctx.saved_tensors
+        g = ctx.g
+        gout = _rows(gout)
+        n, f = x.shape
+        gx = torch.empty((n, f), dtype=torch.float32, device=x.device)
+        gea = torch.empty((g.num_edges, f), dtype=torch.float32, device=x.device) \
+            if ctx.needs_input_grad[1] else None
+        _call("kagnn_aggregate_gine_bwd", _ptr(x), _ld(x), _ptr(ea), _ld(ea), _ptr(gout), _ld(gout),
+                  _ptr(gx), f, _ptr(gea), f, _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(g.perm_t), n, f,
+                  float(ctx.self_scale), _stream())
+        return gx, gea, None, None
+
+
+def aggregate_gine(x, edge_attr, g: GraphIndex, self_scale: float = 1.0) -> torch.Tensor:
+    return _GineFn.apply(x, edge_attr, g, float(self_scale))
+
+
+# ======================================================================== pooling
+def segment_ptr(batch: torch.Tensor, num_graphs: int) -> torch.Tensor:
+    """Offsets of a SORTED batch vector (torch_geometric's DataLoader emits it sorted)."""
+    counts = torch.bincount(batch, minlength=num_graphs)
+    ptr = torch.zeros(num_graphs + 1, dtype=torch.int32, device=batch.device)
+    ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return ptr
+
+
+class _SegmentPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, seg, mean):
+        _need_cuda(x, seg)
+        x = _rows(x)
+        b, f = seg.numel() - 1, x.size(1)
+        out = torch.empty((b, f), dtype=torch.float32, device=x.device)
+        _call("kagnn_segment_pool", _ptr(x), _ld(x), _ptr(out), f, _ptr(seg), b, f, int(mean), _stream())
+        ctx.seg, ctx.mean, ctx.n = seg, mean, x.size(0)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        gout = _rows(gout)
+        b, f = gout.shape
+        gx = torch.empty((ctx.n, f), dtype=torch.float32, device=gout.device)
+        _call("kagnn_segment_broadcast", _ptr(gout), _ld(gout), _ptr(gx), f, _ptr(ctx.seg), b, f,
+                  int(ctx.mean), _stream())
+        return gx, None, None
+
+
+def segment_pool(x, seg_ptr, mean: bool = False) -> torch.Tensor:
+    return _SegmentPoolFn.apply(x, seg_ptr, bool(mean))
+
+
+# ======================================================================== efficient-KAN layer
+class _KANLinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode):
+        _need_cuda(x, base_weight, spline_weight, spline_scaler, knots)
+        x = _rows(x)
+        n, fin = x.shape
+        fout = base_weight.size(0)
+        bw, sw = base_weight.contiguous(), spline_weight.contiguous()
+        sc = None if spline_scaler is None else spline_scaler.contiguous()
+        fb, db = c_size_t(0), c_size_t(0)
+        _call("kagnn_kan_pack_bytes", fin, fout, grid_size, spline_order, mode, byref(fb), byref(db))
+        pack_f, pack_d = _ws(fb.value, x.device), _ws(db.value, x.device)
+        _call("kagnn_kan_pack", _ptr(bw), _ptr(sw), _ptr(sc), fin, fout, grid_size, spline_order, mode,
+                  _ptr(pack_f), _ptr(pack_d), _stream())
+        y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
+        _call("kagnn_kan_linear_fwd", _ptr(x), _ld(x), n, _ptr(knots), fin, fout, grid_size,
+                  spline_order, mode, _ptr(pack_f), _ptr(y), fout, _stream())
+        ctx.save_for_backward(x, sw, sc, knots, pack_d)
+        ctx.dims = (fin, fout, grid_size, spline_order, mode)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, sw, sc, knots, pack_d = ctx.saved_tensors
+        fin, fout, G, K, mode = ctx.dims
+        gy = _rows(gy)
+        n = x.size(0)
+        gx = gbw = gsw = gsc = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((n, fin), dtype=torch.float32, device=x.device)
+            _call("kagnn_kan_linear_bwd_input", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
+                      fout, G, K, mode, _ptr(pack_d), _ptr(gx), fin, _stream())
+        if any(ctx.needs_input_grad[1:4]):
+            nb = c_size_t(0)
+            _call("kagnn_kan_bwd_weight_workspace_bytes", n, fin, fout, G, K, mode, byref(nb))
+            ws = _ws(nb.value, x.device)
+            gbw = torch.empty((fout, fin), dtype=torch.float32, device=x.device)
+            gsw = torch.empty((fout, fin, G + K), dtype=torch.float32, device=x.device)
+            gsc = None if sc is None else torch.empty((fout, fin), dtype=torch.float32, device=x.device)
+            _call("kagnn_kan_linear_bwd_weight", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
+                      fout, G, K, mode, _ptr(sw), _ptr(sc), _ptr(gbw), _ptr(gsw), _ptr(gsc), _ptr(ws),
+                      ws.numel(), _stream())
+        return gx, gbw, gsw, gsc, None, None, None, None
+
+
+def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
+               mode: Optional[int] = None) -> torch.Tensor:
+    """y = silu(x) @ base_weight.T + bases(x) @ (spline_weight*scaler).T  (ekan.py:154-162).
+    ``knots`` is ONE row of the layer's grid buffer (uniform), fp32 [G+2k+1] on the device."""
+    if mode is None:
+        mode = default_precision()
+    return _KANLinearFn.apply(x, base_weight, spline_weight, spline_scaler, knots, int(grid_size),
+                              int(spline_order), int(mode))
+
+
+# ======================================================================== FastKAN layer
+class _FastKANFn(Function):
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, spline_w, base_w, base_b, centers, denominator, ln_eps):
+        _need_cuda(x, spline_w, centers)
+        x = _rows(x)
+        n, fin = x.shape
+        fout = spline_w.size(0)
+        ng = centers.numel()
+        if spline_w.size(1) != fin * ng:
+            raise AssertionError("spline_linear.weight must be [out, in*num_grids]")
+        sw = spline_w.contiguous()
+        lw = None if ln_w is None else ln_w.contiguous()
+        lb = None if ln_b is None else ln_b.contiguous()
+        bw = None if base_w is None else base_w.contiguous()
+        bb = None if base_b is None else base_b.contiguous()
+        nb = c_size_t(0)
+        _call("kagnn_fastkan_fwd_workspace_bytes", n, fin, fout, ng, byref(nb))
+        ws = _ws(nb.value, x.device)
+        stats = torch.empty((n, 2), dtype=torch.float32, device=x.device) if lw is not None else None
+        y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
+        _call("kagnn_fastkan_fwd", _ptr(x), _ld(x), n, fin, fout, ng, _ptr(centers), float(denominator),
+                  _ptr(lw), _ptr(lb), float(ln_eps), _ptr(sw), _ptr(bw), _ptr(bb), _ptr(y), fout,
+                  _ptr(stats), _ptr(ws), ws.numel(), _stream())
+        ctx.save_for_backward(x, lw, lb, sw, bw, centers, stats)
+        ctx.meta = (fin, fout, ng, float(denominator), float(ln_eps), bb is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, lw, lb, sw, bw, centers, stats = ctx.saved_tensors
+        fin, fout, ng, den, eps, has_bb = ctx.meta
+        gy = _rows(gy)
+        n, dev = x.size(0), x.device
+        nb = c_size_t(0)
+        _call("kagnn_fastkan_bwd_workspace_bytes", n, fin, fout, ng, byref(nb))
+        ws = _ws(nb.value, dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        gx = torch.empty((n, fin), **f32)
+        glw = torch.empty(fin, **f32) if lw is not None else None
+        glb = torch.empty(fin, **f32) if lw is not None else None
+        gsw = torch.empty((fout, fin * ng), **f32)
+        gbw = torch.empty((fout, fin), **f32) if bw is not None else None
+        gbb = torch.empty(fout, **f32) if bw is not None else None
+        _call("kagnn_fastkan_bwd", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, fin, fout, ng, _ptr(centers), den,
+                  _ptr(lw), _ptr(lb), eps, _ptr(sw), _ptr(bw), _ptr(stats), _ptr(gx), fin, _ptr(glw),
+                  _ptr(glb), _ptr(gsw), _ptr(gbw), _ptr(gbb), _ptr(ws), ws.numel(), _stream())
+        return gx, glw, glb, gsw, gbw, (gbb if has_bb else None), None, None, None
+
+
+def fastkan_layer(x, ln_weight, ln_bias, spline_weight, base_weight, base_bias, centers,
+                  denominator: float, ln_eps: float = 1e-5) -> torch.Tensor:
+    """FastKANLayer.forward (fastkan.py:76-85) on 2-D input."""
+    return _FastKANFn.apply(x, ln_weight, ln_bias, spline_weight, base_weight, base_bias, centers,
+                            float(denominator), float(ln_eps))

@@ -1,0 +1,333 @@
+"""GPU parity tests: the HIP path (through the C ABI, via kagnn_amd.ops / modules) against the
+golden vectors generated from the reference's own layers and against the CPU oracle on seeded
+inputs.  Tolerance: 1e-4 relative to max(1, max|reference|) for fp32 results (north_star);
+bit-exact for indices."""
+import numpy as np
+import pytest
+import torch
+
+import kagnn_amd
+from kagnn_amd import ops
+from oracle import kan_oracle as orc
+from helpers import FK_KEYS, KAN_KEYS, T, TOL, assert_close, oracle_kan_linear_fwd_bwd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MODES = [ops.PREC_FP32, ops.PREC_SPLIT]
+MODE_IDS = ["fp32", "split"]
+
+
+# ------------------------------------------------------------------ integer work: bit-exact
+def test_csr_golden_bit_exact(golden):
+    z = golden("g7_csr")
+    for g in ("small", "plaw"):
+        ei, n = T(z[f"{g}.edge_index"], DEV), int(z[f"{g}.num_nodes"][0])
+        gi = ops.GraphIndex(ei, n)
+        for name, t in [("rowptr", gi.rowptr), ("col", gi.col), ("perm", gi.perm),
+                        ("rowptr_t", gi.rowptr_t), ("col_t", gi.col_t), ("perm_t", gi.perm_t)]:
+            np.testing.assert_array_equal(t.cpu().numpy().astype(np.int64), z[f"{g}.{name}"], err_msg=f"{g}.{name}")
+
+
+@pytest.mark.parametrize("n,e,seed", [(1, 0, 0), (5, 0, 1), (1, 7, 2), (1000, 30000, 3), (50000, 400000, 4)])
+def test_csr_random_vs_oracle(n, e, seed):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    gi = ops.GraphIndex(ei.to(DEV), n)
+    rp, col, perm = orc.csr_by_key(ei[1], ei[0], n)
+    assert torch.equal(gi.rowptr.cpu().long(), rp)
+    assert torch.equal(gi.col.cpu().long(), col)
+    assert torch.equal(gi.perm.cpu().long(), perm)
+    rp, col, perm = orc.csr_by_key(ei[0], ei[1], n)
+    assert torch.equal(gi.rowptr_t.cpu().long(), rp) and torch.equal(gi.col_t.cpu().long(), col)
+
+
+def test_csr_rejects_out_of_range_ids():
+    ei = torch.tensor([[0, 1, 5], [1, 2, 0]], device=DEV)
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.GraphIndex(ei, 3)
+
+
+# ------------------------------------------------------------------ aggregation
+def test_gin_aggregation_golden(golden):
+    z, g7 = golden("g5_gin"), golden("g7_csr")
+    for g in ("small", "plaw"):
+        ei = T(g7[f"{g}.edge_index"], DEV)
+        x = T(z[f"{g}.kan.x"], DEV)
+        gi = ops.GraphIndex(ei, x.size(0))
+        assert_close(ops.aggregate_sum(x, gi, self_scale=1.0), z[f"{g}.kan.agg"], what=f"{g}.agg")
+
+
+@pytest.mark.parametrize("f", [64, 128, 16, 4, 7, 33, 300])
+def test_aggregate_vs_oracle_with_hub_fwd_bwd(f):
+    """power-law graph whose top hub exceeds the hub threshold; forward and backward."""
+    n, e = 20000, 200000
+    ei = orc.powerlaw_graph(n, e, seed=1)
+    deg = torch.bincount(ei[1], minlength=n)
+    assert int(deg.max()) > ops.HUB_THRESHOLD and int((deg == 0).sum()) > 0
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, f, generator=gen)
+    gy = torch.randn(n, f, generator=gen)
+    xr = x.double().requires_grad_(True)
+    want = orc.sum_aggregate(xr, ei) + 1.5 * xr
+    want.backward(gy.double())
+    xd = x.to(DEV).requires_grad_(True)
+    gi = ops.GraphIndex(ei.to(DEV), n)
+    assert gi.num_hub_seg > 0
+    got = ops.aggregate_sum(xd, gi, self_scale=1.5)
+    got.backward(gy.to(DEV))
+    assert_close(got, want.detach(), what="agg fwd")
+    assert_close(xd.grad, xr.grad, what="agg bwd")
+
+
+def test_aggregate_strided_input_columns():
+    n, e = 3000, 20000
+    ei = orc.powerlaw_graph(n, e, seed=2)
+    wide = torch.randn(n, 96)
+    gi = ops.GraphIndex(ei.to(DEV), n)
+    got = ops.aggregate_sum(wide.to(DEV)[:, 32:96], gi, self_scale=1.0)
+    want = orc.sum_aggregate(wide[:, 32:96].double(), ei) + wide[:, 32:96].double()
+    assert_close(got, want, what="strided agg")
+
+
+def test_gcn_conv_golden(golden):
+    z, g7 = golden("g6_gcn"), golden("g7_csr")
+    for g in ("small", "plaw"):
+        pre = f"{g}.gcn"
+        ei = T(g7[f"{g}.edge_index"], DEV)
+        fi, fo = z[f"{pre}.lin.base_weight"].shape[1], z[f"{pre}.lin.base_weight"].shape[0]
+        conv = kagnn_amd.KAGCNConv(fi, fo, grid_size=4, spline_order=3)
+        conv.lin.load_state_dict({k: T(z[f"{pre}.lin.{k}"]) for k in KAN_KEYS})
+        conv.bias.data.copy_(T(z[f"{pre}.bias"]))
+        conv = conv.to(DEV)
+        x = T(z[f"{pre}.x"], DEV).requires_grad_(True)
+        y = conv(x, ei)
+        y.backward(T(z[f"{pre}.gy"], DEV))
+        assert_close(y, z[f"{pre}.y"], what=pre + ".y")
+        assert_close(x.grad, z[f"{pre}.gx"], what=pre + ".gx")
+        assert_close(conv.bias.grad, z[f"{pre}.grad.bias"], what=pre + ".g_bias")
+        for k in ("base_weight", "spline_weight", "spline_scaler"):
+            assert_close(getattr(conv.lin, k).grad, z[f"{pre}.grad.lin.{k}"], what=f"{pre}.g_{k}")
+        # normalisation itself: dis == deg^-1/2 of the restated gcn_norm
+        ei2 = T(z[f"{pre}.norm_edge_index"])
+        deg = torch.zeros(x.size(0)).scatter_add_(0, ei2[1], torch.ones(ei2.size(1)))
+        assert_close(ops.graph_index(ei, x.size(0)).gcn_dis, deg.pow(-0.5), 1e-6, what="gcn dis")
+
+
+# ------------------------------------------------------------------ efficient-KAN
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_bspline_table_golden(golden, mode):
+    """G1: every knot, knot +- 1ulp, midpoints, out of range, NaN, +-Inf.  A one-hot spline weight
+    turns the layer output into the basis table itself."""
+    z = golden("g1_bsplines")
+    for (G, k) in [(5, 3), (4, 3), (8, 3), (1, 1), (2, 1), (8, 4), (32, 4), (3, 2)]:
+        x = T(z[f"x_G{G}_k{k}"], DEV)
+        want = z[f"bases_G{G}_k{k}"]                      # [P, 2, C]
+        C = G + k
+        layer = kagnn_amd.KANLinear(2, 2 * C, grid_size=G, spline_order=k)
+        with torch.no_grad():
+            layer.base_weight.zero_()
+            layer.spline_scaler.fill_(1.0)
+            layer.spline_weight.zero_()
+            for f in range(2):
+                for c in range(C):
+                    layer.spline_weight[f * C + c, f, c] = 1.0
+        layer = layer.to(DEV)
+        layer.precision = mode
+        got = layer(x).view(-1, 2, C)
+        assert_close(got, want, 2e-6, what=f"bases G={G} k={k}")
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_kanlinear_golden_fwd_bwd(golden, mode):
+    z = golden("g2_kanlinear")
+    i = 0
+    while f"shape_{i}" in z:
+        fi, fo, G, k = [int(v) for v in z[f"shape_{i}"]]
+        tag = f"{fi}_{fo}_{G}_{k}"
+        layer = kagnn_amd.KANLinear(fi, fo, grid_size=G, spline_order=k)
+        layer.load_state_dict({n: T(z[f"{tag}.{n}"]) for n in KAN_KEYS})
+        layer = layer.to(DEV)
+        layer.precision = mode
+        x = T(z[f"{tag}.x"], DEV).requires_grad_(True)
+        y = layer(x)
+        y.backward(T(z[f"{tag}.gy"], DEV))
+        assert_close(y, z[f"{tag}.y"], what=tag + ".y")
+        assert_close(x.grad, z[f"{tag}.gx"], what=tag + ".gx")
+        assert_close(layer.base_weight.grad, z[f"{tag}.g_base_weight"], what=tag + ".g_base_weight")
+        assert_close(layer.spline_weight.grad, z[f"{tag}.g_spline_weight"], what=tag + ".g_spline_weight")
+        assert_close(layer.spline_scaler.grad, z[f"{tag}.g_spline_scaler"], what=tag + ".g_spline_scaler")
+        i += 1
+    assert i == 8
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_kan_chain_golden(golden, mode):
+    z = golden("g3_kan_chain")
+    i = 0
+    while f"cfg_{i}" in z:
+        cfg = [int(v) for v in z[f"cfg_{i}"]]
+        sizes, G, k = cfg[:-2], cfg[-2], cfg[-1]
+        tag = "kan_" + "_".join(map(str, sizes))
+        net = kagnn_amd.KAN(sizes, grid_size=G, spline_order=k)
+        net.load_state_dict({n[len(tag) + 1:]: T(z[n]) for n in z.files
+                             if n.startswith(tag + ".layers.")})
+        net = net.to(DEV)
+        for l in net.layers:
+            l.precision = mode
+        x = T(z[f"{tag}.x"], DEV).requires_grad_(True)
+        y = net(x)
+        y.backward(T(z[f"{tag}.gy"], DEV))
+        assert_close(y, z[f"{tag}.y"], what=tag + ".y")
+        assert_close(x.grad, z[f"{tag}.gx"], what=tag + ".gx")
+        for name, p in net.named_parameters():
+            assert_close(p.grad, z[f"{tag}.grad.{name}"], what=f"{tag}.grad.{name}")
+        i += 1
+    assert i == 3
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+@pytest.mark.parametrize("shape", [(1, 64, 64, 5, 3), (31, 64, 64, 5, 3), (129, 64, 64, 5, 3),
+                                   (1000, 65, 33, 5, 3), (513, 1433, 32, 4, 3), (300, 200, 7, 4, 3),
+                                   (700, 128, 128, 8, 3), (257, 2, 2, 1, 1), (400, 40, 160, 3, 2),
+                                   (64, 16, 16, 32, 4)])
+def test_kanlinear_ragged_shapes_vs_oracle(shape, mode):
+    """ragged / edge shapes (N not a tile multiple, odd widths, Cora-sized input, out > 128) against
+    the oracle in fp64; also reports how the HIP error compares with the reference's own fp32 error."""
+    n, fi, fo, G, k = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    p = orc.init_kan_linear(fi, fo, G, k, gen)
+    x = torch.randn(n, fi, generator=gen) * 0.7
+    gy = torch.randn(n, fo, generator=gen)
+    y64, gx64, g64 = oracle_kan_linear_fwd_bwd(x, gy, p, k)
+    layer = kagnn_amd.KANLinear(fi, fo, grid_size=G, spline_order=k)
+    layer.load_state_dict(p)
+    layer = layer.to(DEV)
+    layer.precision = mode
+    xd = x.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    y.backward(gy.to(DEV))
+    assert_close(y, y64, what="y")
+    assert_close(xd.grad, gx64, what="gx")
+    for nme in ("base_weight", "spline_weight", "spline_scaler"):
+        assert_close(getattr(layer, nme).grad, g64[nme], what="g_" + nme)
+
+
+def test_empty_batch():
+    layer = kagnn_amd.KANLinear(8, 4).to(DEV)
+    y = layer(torch.empty(0, 8, device=DEV))
+    assert y.shape == (0, 4)
+
+
+def test_kanlinear_refuses_nonuniform_grid_and_cpu():
+    layer = kagnn_amd.KANLinear(4, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(torch.randn(3, 4))
+    layer = layer.to(DEV)
+    with torch.no_grad():
+        layer.grid[1, 3] += 0.05
+    with pytest.raises(NotImplementedError):
+        layer(torch.randn(3, 4, device=DEV))
+    with pytest.raises(AssertionError):
+        kagnn_amd.KANLinear(4, 4).to(DEV)(torch.randn(3, 5, device=DEV))
+
+
+# ------------------------------------------------------------------ GIN layer (the metric's unit of work)
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_gin_kan_layer_golden(golden, mode):
+    z, g7 = golden("g5_gin"), golden("g7_csr")
+    for g in ("small", "plaw"):
+        pre = f"{g}.kan"
+        ei = T(g7[f"{g}.edge_index"], DEV)
+        fi = z[f"{pre}.layers.0.base_weight"].shape[1]
+        hid = z[f"{pre}.layers.0.base_weight"].shape[0]
+        fo = z[f"{pre}.layers.1.base_weight"].shape[0]
+        conv = kagnn_amd.GIKANLayer(fi, fo, grid_size=5, spline_order=3, hidden_dim=hid, nb_layers=2)
+        conv.nn.load_state_dict({n[len(pre) + 1:]: T(z[n]) for n in z.files if n.startswith(pre + ".layers.")})
+        conv = conv.to(DEV)
+        for l in conv.nn.layers:
+            l.precision = mode
+        x = T(z[f"{pre}.x"], DEV).requires_grad_(True)
+        y = conv(x, ei)
+        y.backward(T(z[f"{pre}.gy"], DEV))
+        assert_close(y, z[f"{pre}.y"], what=pre + ".y")
+        assert_close(x.grad, z[f"{pre}.gx"], what=pre + ".gx")
+        for name, p in conv.nn.named_parameters():
+            assert_close(p.grad, z[f"{pre}.grad.{name}"], what=f"{pre}.grad.{name}")
+
+
+# ------------------------------------------------------------------ FastKAN
+def test_fastkan_layer_golden(golden):
+    z = golden("g4_fastkan")
+    i = 0
+    while f"shape_{i}" in z:
+        fi, fo, ng = [int(v) for v in z[f"shape_{i}"]]
+        tag = f"fk_{fi}_{fo}_{ng}"
+        layer = kagnn_amd.FastKANLayer(fi, fo, num_grids=ng)
+        layer.load_state_dict({n: T(z[f"{tag}.{n}"]) for n in FK_KEYS})
+        layer = layer.to(DEV)
+        x = T(z[f"{tag}.x"], DEV).requires_grad_(True)
+        y = layer(x)
+        y.backward(T(z[f"{tag}.gy"], DEV))
+        assert_close(y, z[f"{tag}.y"], what=tag + ".y")
+        assert_close(x.grad, z[f"{tag}.gx"], what=tag + ".gx")
+        for name, p in layer.named_parameters():
+            if p.requires_grad:
+                assert_close(p.grad, z[f"{tag}.grad.{name}"], what=f"{tag}.grad.{name}")
+        i += 1
+    assert i == 5
+    tag = "fastkan_48_72_24"
+    net = kagnn_amd.FastKAN([48, 72, 24], num_grids=4)
+    net.load_state_dict({n[len(tag) + 1:]: T(z[n]) for n in z.files if n.startswith(tag + ".layers.")})
+    net = net.to(DEV)
+    x = T(z[f"{tag}.x"], DEV).requires_grad_(True)
+    y = net(x)
+    y.backward(T(z[f"{tag}.gy"], DEV))
+    assert_close(y, z[f"{tag}.y"], what=tag + ".y")
+    assert_close(x.grad, z[f"{tag}.gx"], what=tag + ".gx")
+    for name, p in net.named_parameters():
+        if p.requires_grad:
+            assert_close(p.grad, z[f"{tag}.grad.{name}"], what=f"{tag}.grad.{name}")
+
+
+def test_gin_fastkan_layer_golden(golden):
+    z, g7 = golden("g5_gin"), golden("g7_csr")
+    for g in ("small", "plaw"):
+        pre = f"{g}.fastkan"
+        ei = T(g7[f"{g}.edge_index"], DEV)
+        fi = z[f"{pre}.layers.0.base_linear.weight"].shape[1]
+        hid = z[f"{pre}.layers.0.base_linear.weight"].shape[0]
+        fo = z[f"{pre}.layers.1.base_linear.weight"].shape[0]
+        conv = kagnn_amd.GIFASTKANLayer(fi, fo, grid_size=4, hidden_dim=hid, nb_layers=2)
+        conv.nn.load_state_dict({n[len(pre) + 1:]: T(z[n]) for n in z.files if n.startswith(pre + ".layers.")})
+        conv = conv.to(DEV)
+        x = T(z[f"{pre}.x"], DEV).requires_grad_(True)
+        y = conv(x, ei)
+        y.backward(T(z[f"{pre}.gy"], DEV))
+        assert_close(y, z[f"{pre}.y"], what=pre + ".y")
+        assert_close(x.grad, z[f"{pre}.gx"], what=pre + ".gx")
+        for name, p in conv.nn.named_parameters():
+            if p.requires_grad:
+                assert_close(p.grad, z[f"{pre}.grad.{name}"], what=f"{pre}.grad.{name}")
+
+
+# ------------------------------------------------------------------ GINE + pooling (config 4 callers)
+def test_gine_pool_golden(golden):
+    z = golden("g8_gine_pool")
+    ei = T(z["edge_index"], DEV)
+    x = T(z["x"], DEV).requires_grad_(True)
+    ea = T(z["edge_attr"], DEV).requires_grad_(True)
+    batch = T(z["batch"], DEV)
+    H = x.size(1)
+    kan = kagnn_amd.KAN([H, H, H], grid_size=4, spline_order=3)
+    kan.load_state_dict({n[4:]: T(z[n]) for n in z.files if n.startswith("kan.")})
+    kan = kan.to(DEV)
+    gi = ops.GraphIndex(ei, x.size(0))
+    h = kan(ops.aggregate_gine(x, ea, gi, self_scale=1.0))
+    pooled = ops.segment_pool(h, ops.segment_ptr(batch, 16))
+    pooled.backward(T(z["g_pooled"], DEV))
+    assert_close(h, z["h"], what="gine h")
+    assert_close(pooled, z["pooled"], what="pooled")
+    assert_close(x.grad, z["gx"], what="gine gx")
+    assert_close(ea.grad, z["g_edge_attr"], what="gine g_edge_attr")
+    for name, p in kan.named_parameters():
+        assert_close(p.grad, z[f"grad.{name}"], what=f"gine grad.{name}")
