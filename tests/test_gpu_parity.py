@@ -121,7 +121,10 @@ def test_bspline_table_golden(golden, mode):
     z = golden("g1_bsplines")
     for (G, k) in [(5, 3), (4, 3), (8, 3), (1, 1), (2, 1), (8, 4), (32, 4), (3, 2)]:
         x = T(z[f"x_G{G}_k{k}"], DEV)
-        want = z[f"bases_G{G}_k{k}"]                      # [P, 2, C]
+        want = z[f"bases_G{G}_k{k}"].copy()               # [P, 2, C]
+        # the table goes through the layer's matmul: a non-finite basis row poisons the whole output
+        # row (NaN * 0 = NaN), exactly as the reference's F.linear would
+        want[np.isnan(want).any(axis=(1, 2))] = np.nan
         C = G + k
         layer = kagnn_amd.KANLinear(2, 2 * C, grid_size=G, spline_order=k)
         with torch.no_grad():
