@@ -24,12 +24,15 @@ int kan_f32_dw(const float*, long, const float*, long, long, const float*, int, 
 
 size_t kan_split_pack_fwd_bytes(int in, int out, int C);
 size_t kan_split_pack_dx_bytes(int in, int out, int C);
-int kan_split_pack(const float*, const float*, const float*, int, int, int, void*, void*, hipStream_t);
+int kan_split_pack_fwd(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
+int kan_split_pack_dx(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t);
 int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t);
 size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
 int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t);
-bool kan_split_supported(int in, int out, int G, int K);
+bool kan_split_fwd_ok(int in, int out, int G, int K);
+bool kan_split_dx_ok(int in, int out, int G, int K);
+bool kan_split_dw_ok(int in, int out, int G, int K);
 
 int fastkan_fwd(const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, void*, size_t, hipStream_t);
 size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng);
@@ -46,10 +49,10 @@ static int check_kan_dims(const char* fn, int in, int out, int G, int K, int mod
     if (mode != KAGNN_PREC_FP32 && mode != KAGNN_PREC_SPLIT) return fail(KAGNN_ERR_ARG, "%s: unknown precision mode", fn);
     return KAGNN_OK;
 }
-// the split path covers the hot shapes; everything else runs the exact-fp32 kernels
-static int eff_mode(int in, int out, int G, int K, int mode) {
-    return (mode == KAGNN_PREC_SPLIT && kan_split_supported(in, out, G, K)) ? KAGNN_PREC_SPLIT : KAGNN_PREC_FP32;
-}
+// the split path covers the hot shapes; everything else runs the exact-fp32 kernels (still HIP)
+static bool use_split_fwd(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_fwd_ok(in, out, G, K); }
+static bool use_split_dx(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_dx_ok(in, out, G, K); }
+static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_dw_ok(in, out, G, K); }
 
 #pragma GCC visibility push(default)
 extern "C" {
@@ -129,13 +132,8 @@ int kagnn_kan_pack_bytes(int32_t in, int32_t out, int32_t G, int32_t K, int32_t 
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(fwd_bytes && dx_bytes, "null output");
-    if (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT) {
-        *fwd_bytes = kan_split_pack_fwd_bytes(in, out, G + K);
-        *dx_bytes = kan_split_pack_dx_bytes(in, out, G + K);
-    } else {
-        *fwd_bytes = kan_f32_pack_fwd_bytes(in, out, G + K);
-        *dx_bytes = kan_f32_pack_dx_bytes(in, out, G + K);
-    }
+    *fwd_bytes = use_split_fwd(in, out, G, K, mode) ? kan_split_pack_fwd_bytes(in, out, G + K) : kan_f32_pack_fwd_bytes(in, out, G + K);
+    *dx_bytes = use_split_dx(in, out, G, K, mode) ? kan_split_pack_dx_bytes(in, out, G + K) : kan_f32_pack_dx_bytes(in, out, G + K);
     return KAGNN_OK;
 }
 
@@ -144,9 +142,12 @@ int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bw && sw && pack_fwd && pack_dx, "null array");
-    if (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT)
-        return kan_split_pack(bw, sw, sc, in, out, G + K, pack_fwd, pack_dx, as_stream(stream));
-    return kan_f32_pack(bw, sw, sc, in, out, G + K, (float*)pack_fwd, (float*)pack_dx, as_stream(stream));
+    const bool sf = use_split_fwd(in, out, G, K, mode), sd = use_split_dx(in, out, G, K, mode);
+    if (sf) { rc = kan_split_pack_fwd(bw, sw, sc, in, out, G + K, pack_fwd, as_stream(stream)); if (rc) return rc; }
+    if (sd) { rc = kan_split_pack_dx(bw, sw, sc, in, out, G + K, pack_dx, as_stream(stream)); if (rc) return rc; }
+    if (!sf || !sd)
+        return kan_f32_pack(bw, sw, sc, in, out, G + K, sf ? nullptr : (float*)pack_fwd, sd ? nullptr : (float*)pack_dx, as_stream(stream));
+    return KAGNN_OK;
 }
 
 int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* knots, int32_t in,
@@ -157,7 +158,7 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* kn
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldy >= out, "bad shape");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && knots && pack_fwd && y, "null array");
-    if (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT)
+    if (use_split_fwd(in, out, G, K, mode))
         return kan_split_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, as_stream(stream));
     return kan_f32_fwd(x, ldx, N, knots, in, out, G, K, (const float*)pack_fwd, y, ldy, as_stream(stream));
 }
@@ -170,7 +171,7 @@ int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && gy && knots && pack_dx && gx, "null array");
-    if (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT)
+    if (use_split_dx(in, out, G, K, mode))
         return kan_split_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack_dx, gx, ldgx, as_stream(stream));
     return kan_f32_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, (const float*)pack_dx, gx, ldgx, as_stream(stream));
 }
@@ -180,7 +181,7 @@ int kagnn_kan_bwd_weight_workspace_bytes(int64_t N, int32_t in, int32_t out, int
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
-    *bytes = (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT) ? kan_split_dw_ws_bytes(N, in, out, G + K)
+    *bytes = use_split_dw(in, out, G, K, mode) ? kan_split_dw_ws_bytes(N, in, out, G + K)
                                                                    : kan_f32_dw_ws_bytes(N, in, out, G + K);
     return KAGNN_OK;
 }
@@ -195,7 +196,7 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
     KAGNN_CHECK_ARG(knots && sw && g_bw && g_sw && ws, "null array");
     KAGNN_CHECK_ARG(N == 0 || (x && gy), "null array");
     KAGNN_CHECK_ARG((sc == nullptr) == (g_sc == nullptr), "spline_scaler and its gradient must both be given or both be null");
-    if (eff_mode(in, out, G, K, mode) == KAGNN_PREC_SPLIT)
+    if (use_split_dw(in, out, G, K, mode))
         return kan_split_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream));
     return kan_f32_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream));
 }

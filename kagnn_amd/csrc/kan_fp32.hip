@@ -38,13 +38,13 @@ __global__ void kan_pack_f32_kernel(const float* __restrict__ bw, const float* _
             int lane = i & 63; long r = i >> 6;
             int ot = r % OT; r /= OT;
             int c = r % CT; int p = r / CT;
-            pf[i] = wcat(bw, sw, sc, in, out, C, 32 * ot + (lane & 31), p + (lane >> 5) * P, c);
+            if (pf) pf[i] = wcat(bw, sw, sc, in, out, C, 32 * ot + (lane & 31), p + (lane >> 5) * P, c);
         } else {
             long j = i - nf;
             int lane = j & 63; long r = j >> 6;
             int q = r % Q; r /= Q;
             int c = r % CT; int ft = r / CT;
-            pd[j] = wcat(bw, sw, sc, in, out, C, q + (lane >> 5) * Q, 32 * ft + (lane & 31), c);
+            if (pd) pd[j] = wcat(bw, sw, sc, in, out, C, q + (lane >> 5) * Q, 32 * ft + (lane & 31), c);
         }
     }
 }

@@ -1,14 +1,367 @@
-// efficient-KAN layer, split-precision mode (KAGNN_PREC_SPLIT) -- placeholder translation unit
-// during bring-up: kan_split_supported() answers "no", so api.hip routes every shape to the
-// exact-fp32 MFMA kernels in kan_fp32.hip.
+// efficient-KAN layer, split-precision mode (KAGNN_PREC_SPLIT): the dense contraction runs on
+// the 16-bit matrix cores at fp32-equivalent accuracy.
+//
+//   a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi          (a_hi = fp16(a), a_lo = fp16(a - a_hi))
+//
+// three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator.  Both operands are pre-scaled by exact
+// powers of two (bases by 2^10, weights so that max|W| lands in [2^9, 2^10)) so hi and lo stay in
+// fp16's normal range; the dropped a_lo*w_lo term is ~2^-22 relative -- the same class as fp32
+// rounding (measured against an fp64 oracle in tests/test_gpu_parity.py).  That is 3/16 of the
+// cost of v_mfma_f32_32x32x2_f32 (kan_fp32.hip), which is what lets the layer approach the HBM
+// roofline instead of the fp32 matrix peak.  The SiLU base branch has unbounded
+// inputs, so it uses a 3-way bf16 split (6 v_mfma_f32_32x32x16_bf16, ~2^-24) in the same
+// accumulator.
+//
+// Fragment mapping (fwd): lane l of a wave owns row (l&31) of a 32-row tile and, per MFMA, the 8
+// consecutive k-slots 8*(l>>5)..+7 -- we make those 8 slots the (up to) 8 spline coefficients of
+// ONE input feature, so a lane evaluates the K+1 non-zero B-spline bases of one scalar x[row,f]
+// in registers, splits them, drops them into place with v_perm_b32 and feeds the matrix core.
+// The packed weights live in LDS for the whole (persistent) workgroup when they fit (152 KB at
+// in=out=64, G+k=8), otherwise they stream through LDS per 64-feature chunk.
+//
+// Reference behaviour replaced: node_classification_clean/ekan.py:79-112,146-162.
 #include "common.h"
+
 namespace kagnn {
-bool kan_split_supported(int, int, int, int) { return false; }
-size_t kan_split_pack_fwd_bytes(int, int, int) { return 0; }
-size_t kan_split_pack_dx_bytes(int, int, int) { return 0; }
-size_t kan_split_dw_ws_bytes(long, int, int, int) { return 0; }
-int kan_split_pack(const float*, const float*, const float*, int, int, int, void*, void*, hipStream_t) { return fail(KAGNN_ERR_UNSUPPORTED, "%s: split mode not built", "kan_split_pack"); }
-int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t) { return fail(KAGNN_ERR_UNSUPPORTED, "%s: split mode not built", "kan_split_fwd"); }
-int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t) { return fail(KAGNN_ERR_UNSUPPORTED, "%s: split mode not built", "kan_split_dx"); }
-int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t) { return fail(KAGNN_ERR_UNSUPPORTED, "%s: split mode not built", "kan_split_dw"); }
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kHdrBytes = 256;           // pack header: [0] float post_scale, [1] int exponent
+constexpr int kLdsHdr = 512;             // LDS: knots (48 f32) @0, perm table (16 x 16 B) @256
+constexpr float kAScale = 1024.0f;       // bases / silu pre-scale (2^10)
+constexpr int kLdsBudget = 160 * 1024 - kLdsHdr;
+
+__host__ __device__ inline int split_cf(int OT) { return OT <= 2 ? 64 : 32; }   // features per chunk
+__host__ __device__ inline size_t split_fwd_chunk_bytes(int OT) {
+    const int CF = split_cf(OT);
+    return (size_t)(CF / 2) * OT * 2 * 1024 + (size_t)(CF / 16) * OT * 3 * 1024;
+}
+
+bool kan_split_fwd_ok(int in, int out, int G, int K) {
+    return K >= 1 && K <= 3 && G + K <= 8 && out <= 128;
+}
+bool kan_split_dx_ok(int, int, int, int) { return false; }
+bool kan_split_dw_ok(int, int, int, int) { return false; }
+
+size_t kan_split_pack_fwd_bytes(int in, int out, int C) {
+    const int OT = cdiv(out, 32), CF = split_cf(OT);
+    return kHdrBytes + (size_t)cdiv(in, CF) * split_fwd_chunk_bytes(OT);
+}
+
+// ------------------------------------------------------------------ packing
+__device__ __forceinline__ float wcat_s(const float* bw, const float* sw, const float* sc, int in,
+                                        int out, int C, int o, int f, int c) {
+    if (o >= out || f >= in || c > C) return 0.0f;
+    if (c == C) return bw[(long)o * in + f];
+    float w = sw[((long)o * in + f) * C + c];
+    return sc ? w * sc[(long)o * in + f] : w;
+}
+
+// absmax over Wcat -> hdr[2] (uint bits of a non-negative float; atomicMax works on the bits)
+__global__ void split_absmax_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
+                                    const float* __restrict__ sc, int in, int out, int C,
+                                    unsigned* __restrict__ hdr) {
+    float m = 0.0f;
+    const long n = (long)out * in * (C + 1);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % (C + 1); const long of = i / (C + 1);
+        const float v = fabsf(wcat_s(bw, sw, sc, in, out, C, (int)(of / in), (int)(of % in), c));
+        m = fmaxf(m, (v <= 3.0e38f) ? v : 0.0f);        // ignore inf/nan for the scale choice
+    }
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(hdr + 2, __float_as_uint(m));
+}
+
+// exponent e with max|W| * 2^-e in [2^9, 2^10);  hdr[0] = 2^(e-10-10)... see below
+__device__ __forceinline__ int scale_exp_from_max(float m) {
+    if (!(m > 0.0f)) return 0;
+    int ex;
+    frexpf(m, &ex);                 // m = frac * 2^ex, frac in [0.5,1)  =>  m < 2^ex
+    return ex - 10;                 // m * 2^-(ex-10) < 2^10
+}
+
+__global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
+                                      const float* __restrict__ sc, int in, int out, int C,
+                                      unsigned char* __restrict__ pack) {
+    const int OT = cdiv(out, 32), CF = split_cf(OT), HF = CF / 2;
+    const int SPC = CF / 2, BPC = CF / 16;
+    unsigned* hdr = reinterpret_cast<unsigned*>(pack);
+    const int e = scale_exp_from_max(__uint_as_float(hdr[2]));
+    const float wscale = ldexpf(1.0f, -e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        reinterpret_cast<float*>(pack)[0] = ldexpf(1.0f, e - 10);   // post scale: undo 2^10 and 2^-e
+        reinterpret_cast<int*>(pack)[1] = e;
+    }
+    const size_t chunk_bytes = split_fwd_chunk_bytes(OT);
+    const long spl_per_chunk = (long)SPC * OT * 64, base_per_chunk = (long)BPC * OT * 64;
+    const long per_chunk = spl_per_chunk + base_per_chunk;
+    const long total = (long)cdiv(in, CF) * per_chunk;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = i / per_chunk; long r = i % per_chunk;
+        unsigned char* cbase = pack + kHdrBytes + (size_t)ch * chunk_bytes;
+        if (r < spl_per_chunk) {
+            const int lane = r & 63; r >>= 6;
+            const int ot = r % OT; const int s = r / OT;
+            const int o = 32 * ot + (lane & 31), f = ch * CF + (lane >> 5) * HF + s;
+            _Float16 hi[8], lo[8];
+            for (int j = 0; j < 8; ++j) {
+                const float w = wcat_s(bw, sw, sc, in, out, C, o, f, j < C ? j : C + 1) * wscale;
+                hi[j] = (_Float16)w;
+                lo[j] = (_Float16)(w - (float)hi[j]);
+            }
+            _Float16* dh = reinterpret_cast<_Float16*>(cbase + ((size_t)(s * OT + ot) * 2 + 0) * 1024 + lane * 16);
+            _Float16* dl = reinterpret_cast<_Float16*>(cbase + ((size_t)(s * OT + ot) * 2 + 1) * 1024 + lane * 16);
+            for (int j = 0; j < 8; ++j) { dh[j] = hi[j]; dl[j] = lo[j]; }
+        } else {
+            r -= spl_per_chunk;
+            const int lane = r & 63; r >>= 6;
+            const int ot = r % OT; const int sb = r / OT;
+            const int o = 32 * ot + (lane & 31);
+            unsigned char* bb = cbase + (size_t)SPC * OT * 2 * 1024 + (size_t)(sb * OT + ot) * 3 * 1024 + lane * 16;
+            for (int j = 0; j < 8; ++j) {
+                const int f = ch * CF + (lane >> 5) * HF + 8 * sb + j;
+                float w = wcat_s(bw, sw, sc, in, out, C, o, f, C) * wscale;
+                for (int p = 0; p < 3; ++p) {              // truncating bf16 split: w = w1 + w2 + w3 (+2^-24)
+                    const unsigned bits = __float_as_uint(w) & 0xffff0000u;
+                    reinterpret_cast<unsigned short*>(bb + p * 1024)[j] = (unsigned short)(bits >> 16);
+                    w -= __uint_as_float(bits);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ device helpers
+// selector table for v_perm_b32: entry t (shift sh = t-4 halfs) holds 4 selectors; output half s of
+// the 8-slot window takes payload half s-sh (payload = 4 halfs in {p1:p0}), zero when out of range.
+__device__ __forceinline__ void build_perm_table(unsigned* tbl /* LDS, 16*4 */, int tid) {
+    if (tid < 64) {
+        const int t = tid >> 2, q = tid & 3, sh = t - 4;
+        unsigned sel = 0;
+        for (int hh = 0; hh < 2; ++hh) {
+            const int r = 2 * q + hh - sh;
+            const unsigned b = (r >= 0 && r <= 3) ? (unsigned)((2 * r) | ((2 * r + 1) << 8)) : 0x0c0cu;
+            sel |= b << (16 * hh);
+        }
+        tbl[tid] = sel;
+    }
+}
+
+__device__ __forceinline__ unsigned pk_f16_rtz(float a, float b) {
+    auto v = __builtin_amdgcn_cvt_pkrtz(a, b);     // two fp16, round toward zero
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float f16lo_to_f32(unsigned p) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu));
+}
+__device__ __forceinline__ float f16hi_to_f32(unsigned p) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16));
+}
+
+// bases (already scaled by 2^10) of one scalar -> hi / lo A fragments (8 fp16 each) for window
+// slots 0..7 of its feature.  Returns via references.
+template <int K>
+__device__ __forceinline__ void make_spline_frag(float x, const float* __restrict__ knots,
+                                                 const unsigned* __restrict__ tbl,
+                                                 const SplineGeom& g, u32x4& ahi, u32x4& alo) {
+    float N[K + 1], dummy[K + 1];
+    const int m = bspline_local<K, false>(x, knots, g, N, dummy);
+    float n0 = N[0] * kAScale, n1 = N[1] * kAScale;
+    float n2 = (K >= 2) ? N[K >= 2 ? 2 : 0] * kAScale : 0.0f;
+    float n3 = (K >= 3) ? N[K >= 3 ? 3 : 0] * kAScale : 0.0f;
+    const unsigned h0 = pk_f16_rtz(n0, n1), h1 = pk_f16_rtz(n2, n3);
+    const unsigned l0 = pk_f16_rtz(n0 - f16lo_to_f32(h0), n1 - f16hi_to_f32(h0));
+    const unsigned l1 = pk_f16_rtz(n2 - f16lo_to_f32(h1), n3 - f16hi_to_f32(h1));
+    int t = m - K + 4;
+    t = t < 0 ? 0 : (t > 15 ? 15 : t);
+    const u32x4 sel = *reinterpret_cast<const u32x4*>(tbl + 4 * t);
+    ahi[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
+    ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
+    alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);
+    alo[2] = __builtin_amdgcn_perm(l1, l0, sel[2]); alo[3] = __builtin_amdgcn_perm(l1, l0, sel[3]);
+}
+
+// 8 fp32 values -> three truncated-bf16 fragments (v = v1 + v2 + v3 up to 2^-24)
+__device__ __forceinline__ void split_bf16x3(const float (&v)[8], u32x4& p1, u32x4& p2, u32x4& p3) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a = v[2 * q], b = v[2 * q + 1];
+        p1[q] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+        a -= __uint_as_float(__float_as_uint(a) & 0xffff0000u);
+        b -= __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+        p2[q] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+        a -= __uint_as_float(__float_as_uint(a) & 0xffff0000u);
+        b -= __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+        p3[q] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ forward
+template <int K, int OT>
+__global__ __launch_bounds__(512) void kan_split_fwd_kernel(
+    const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g,
+    int nknots, const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy,
+    int out) {
+    constexpr int CF = (OT <= 2) ? 64 : 32, HF = CF / 2, SPC = CF / 2, BPC = CF / 16;
+    constexpr int CHUNK_BYTES = SPC * OT * 2 * 1024 + BPC * OT * 3 * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* s_knots = reinterpret_cast<float*>(smem);
+    unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
+    unsigned char* s_w = smem + kLdsHdr;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < nknots) s_knots[tid] = knots_g[tid];
+    build_perm_table(s_tbl, tid);
+    const float post = reinterpret_cast<const float*>(pack)[0];
+    const unsigned char* gw = pack + kHdrBytes;
+    auto stage_chunk = [&](int ch) {
+        const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)ch * CHUNK_BYTES);
+        uint4* dst = reinterpret_cast<uint4*>(s_w);
+        for (int i = tid; i < CHUNK_BYTES / 16; i += 512) dst[i] = src[i];
+    };
+    if (nchunks == 1) stage_chunk(0);
+    __syncthreads();
+    const SplineGeom geom = geom_from_knots(s_knots, nknots);
+    const int r = lane & 31, kg = lane >> 5;
+    const bool al4 = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+
+    for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
+        const long row0 = tile * 256 + wave * 32;
+        const long row = row0 + r;
+        const bool rv = row < N;
+        const float* xr = x + (rv ? row : 0) * ldx;
+        f32x16 acc[OT];
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (nchunks > 1) {
+                __syncthreads();
+                stage_chunk(ch);
+                __syncthreads();
+            }
+            // this lane's HF consecutive features of the chunk; invalid -> a value outside every span
+            const int f0 = ch * CF + kg * HF;
+            float xv[HF];
+            const float kOut = s_knots[nknots - 1] + 1.0f;        // finite, outside the grid: all bases 0
+            if (al4 && rv && f0 + HF <= in) {
+#pragma unroll
+                for (int j = 0; j < HF; j += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(xr + f0 + j);
+                    xv[j] = v.x; xv[j + 1] = v.y; xv[j + 2] = v.z; xv[j + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < HF; ++j) xv[j] = (rv && f0 + j < in) ? xr[f0 + j] : kOut;
+            }
+            // ---- spline part: one MFMA step per feature
+#pragma unroll
+            for (int s = 0; s < SPC; ++s) {
+                u32x4 ahi, alo;
+                make_spline_frag<K>(xv[s], s_knots, s_tbl, geom, ahi, alo);
+                const unsigned char* wp = s_w + (size_t)(s * OT) * 2 * 1024 + lane * 16;
+#pragma unroll
+                for (int t = 0; t < OT; ++t) {
+                    const u32x4 bhi = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 0) * 1024);
+                    const u32x4 blo = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 1) * 1024);
+                    acc[t] = mfma_f16(ahi, bhi, acc[t]);
+                    acc[t] = mfma_f16(ahi, blo, acc[t]);
+                    acc[t] = mfma_f16(alo, bhi, acc[t]);
+                }
+            }
+            // ---- SiLU base branch: 8 features per lane per step, 3-way bf16 split
+#pragma unroll
+            for (int sb = 0; sb < BPC; ++sb) {
+                float sv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xx = xv[8 * sb + j];
+                    const bool ok = rv && (f0 + 8 * sb + j < in);
+                    sv[j] = ok ? siluf(xx) * kAScale : 0.0f;
+                }
+                u32x4 a1, a2, a3;
+                split_bf16x3(sv, a1, a2, a3);
+                const unsigned char* wp = s_w + (size_t)SPC * OT * 2 * 1024 + (size_t)(sb * OT) * 3 * 1024 + lane * 16;
+#pragma unroll
+                for (int t = 0; t < OT; ++t) {
+                    const u32x4 w1 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 0) * 1024);
+                    const u32x4 w2 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 1) * 1024);
+                    const u32x4 w3 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 2) * 1024);
+                    acc[t] = mfma_bf16(a3, w1, acc[t]);
+                    acc[t] = mfma_bf16(a2, w2, acc[t]);
+                    acc[t] = mfma_bf16(a1, w3, acc[t]);
+                    acc[t] = mfma_bf16(a2, w1, acc[t]);
+                    acc[t] = mfma_bf16(a1, w2, acc[t]);
+                    acc[t] = mfma_bf16(a1, w1, acc[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < OT; ++t) {
+            const int col = 32 * t + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long rr = row0 + mfma32_row(i, kg);
+                if (rr < N && col < out) y[rr * ldy + col] = acc[t][i] * post;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+int kan_split_pack_fwd(const float* bw, const float* sw, const float* sc, int in, int out, int C,
+                       void* pack_fwd, hipStream_t st) {
+    unsigned char* pf = static_cast<unsigned char*>(pack_fwd);
+    KAGNN_HIP(hipMemsetAsync(pf, 0, kHdrBytes, st));
+    const long n = (long)out * in * (C + 1);
+    split_absmax_kernel<<<(int)min((n + 255) / 256, 1024L), 256, 0, st>>>(bw, sw, sc, in, out, C, reinterpret_cast<unsigned*>(pf));
+    KAGNN_LAUNCH_CHECK();
+    const long items = (long)(kan_split_pack_fwd_bytes(in, out, C) - kHdrBytes) / 16;
+    split_pack_fwd_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, pf);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+template <int K, int OT>
+static int launch_fwd(const float* x, long ldx, long N, int in, const float* knots, int nknots,
+                      const unsigned char* pack, int nchunks, float* y, long ldy, int out, hipStream_t st) {
+    const size_t lds = kLdsHdr + split_fwd_chunk_bytes(OT);
+    static bool configured = false;
+    if (!configured) {
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const int grid = (int)min((long)cdiv(N, 256), 256L);
+    kan_split_fwd_kernel<K, OT><<<grid, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int kan_split_fwd(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
+                  const void* pack, float* y, long ldy, hipStream_t st) {
+    const int OT = cdiv(out, 32), nk = G + 2 * K + 1, nch = cdiv(in, split_cf(OT));
+    const unsigned char* p = static_cast<const unsigned char*>(pack);
+#define GO(KK, TT) return launch_fwd<KK, TT>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, st)
+#define BYOT(KK) switch (OT) { case 1: GO(KK, 1); case 2: GO(KK, 2); case 3: GO(KK, 3); case 4: GO(KK, 4); }
+    switch (K) {
+        case 1: BYOT(1) break;
+        case 2: BYOT(2) break;
+        case 3: BYOT(3) break;
+    }
+#undef BYOT
+#undef GO
+    return fail(KAGNN_ERR_UNSUPPORTED, "%s: shape not covered by the split path", "kan_split_fwd");
+}
+
+
+// ---- input-gradient / weight-gradient split kernels: see kan_split_bwd.hip
 }  // namespace kagnn
