@@ -295,6 +295,13 @@ __global__ void kan_dw_unpack_kernel(const float* __restrict__ gcat, int in, int
     g_bw[of] = gcat[((long)C * inP + f) * outP + o];
 }
 
+int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP, const float* sw,
+                  const float* sc, float* g_bw, float* g_sw, float* g_sc, hipStream_t st) {
+    kan_dw_unpack_kernel<<<cdiv((long)in * out, 256), 256, 0, st>>>(gcat, in, out, C, inP, outP, sw, sc, g_bw, g_sw, g_sc);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 // ------------------------------------------------------------------ host launchers
 
 size_t kan_f32_pack_fwd_bytes(int in, int out, int C) {

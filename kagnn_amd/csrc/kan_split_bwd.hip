@@ -1,10 +1,427 @@
-// split-precision backward kernels of the efficient-KAN layer (bring-up: not enabled yet; api.hip
-// asks kan_split_dx_ok / kan_split_dw_ok and routes to the exact-fp32 kernels when they say no).
-#include "common.h"
+// Split-precision backward of the efficient-KAN layer (see kan_split.hip for the numeric scheme).
+//
+// Input gradient (kan_split_dx_kernel):  D_c[n][f] = sum_o gy[n][o] * W[o][f][c]  as 32x32x16 fp16
+// MFMAs (3 per product), one accumulator per coefficient c and one for the base weight; the lane that
+// owns D[.][f] then contracts over c in registers with the K+1 non-zero basis derivatives of x[n][f]
+// (recomputed -- only the layer input was saved).  gy rows are scaled per row by an exact power of two
+// into fp16 range; the packed W^T fragments stay resident in LDS.
+//
+// Weight gradient (kan_split_dw_kernel):  D_c[f][o] += sum_n B_c(x[n][f]) * gy[n][o]  as 16x16x32 fp16
+// MFMAs over 32-row chunks; a lane evaluates the bases of 8 consecutive rows of ONE feature, the 8x8
+// (row, coefficient) block is transposed in registers with v_perm_b32.  gy is scaled per wave with a
+// running power-of-two maximum (accumulators are rescaled, exactly, when it grows).  The SiLU branch
+// (unbounded inputs) uses v_mfma_f32_16x16x4_f32.  Partial sums go to per-wave slabs reduced in a
+// fixed order (deterministic).
+//
+// Reference behaviour replaced: the autograd backward of node_classification_clean/ekan.py:154-162.
+#include "split_common.h"
+
 namespace kagnn {
-size_t kan_split_pack_dx_bytes(int, int, int) { return 0; }
-size_t kan_split_dw_ws_bytes(long, int, int, int) { return 0; }
-int kan_split_pack_dx(const float*, const float*, const float*, int, int, int, void*, hipStream_t) { return fail(KAGNN_ERR_UNSUPPORTED, "%s: not built", "kan_split_pack_dx"); }
-int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t) { return fail(KAGNN_ERR_UNSUPPORTED, "%s: not built", "kan_split_dx"); }
-int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t) { return fail(KAGNN_ERR_UNSUPPORTED, "%s: not built", "kan_split_dw"); }
+
+int split_absmax(const float*, const float*, const float*, int, int, int, unsigned*, hipStream_t);
+int kan_dw_reduce(const float* slab, long NS, long per_slab, float* gcat, hipStream_t st);
+int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP, const float* sw,
+                  const float* sc, float* g_bw, float* g_sw, float* g_sc, hipStream_t st);
+
+// ====================================================================== input gradient
+static inline int dx_q(int out) { return out <= 32 ? 2 : (out <= 64 ? 4 : 8); }
+
+bool kan_split_dx_ok(int in, int out, int G, int K) { return K >= 1 && K <= 3 && G + K <= 8 && out <= 128; }
+
+size_t kan_split_pack_dx_bytes(int in, int out, int C) {
+    return kHdrBytes + (size_t)cdiv(in, 32) * (C + 1) * dx_q(out) * 2 * 1024;
+}
+
+// pack_dx[ft][c][q][part][lane][8] : lane (f = lane&31, kg = lane>>5), j -> W'[o = 16q+8kg+j][32ft+f][c]
+__global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
+                                     const float* __restrict__ sc, int in, int out, int C, int Q,
+                                     unsigned char* __restrict__ pack) {
+    unsigned* hdr = reinterpret_cast<unsigned*>(pack);
+    const int e = scale_exp_from_max(__uint_as_float(hdr[2]));
+    const float wscale = ldexpf(1.0f, -e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        reinterpret_cast<float*>(pack)[0] = ldexpf(1.0f, e - 10);
+        reinterpret_cast<int*>(pack)[1] = e;
+    }
+    const int CT = C + 1;
+    const long total = (long)cdiv(in, 32) * CT * Q * 64;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = i & 63; long r = i >> 6;
+        const int q = r % Q; r /= Q;
+        const int c = r % CT; const int ft = r / CT;
+        const int f = 32 * ft + (lane & 31);
+        _Float16* dh = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q + q) * 2 + 0) * 1024 + lane * 16);
+        _Float16* dl = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q + q) * 2 + 1) * 1024 + lane * 16);
+        for (int j = 0; j < 8; ++j) {
+            const int o = 16 * q + 8 * (lane >> 5) + j;
+            const float w = wcat_s(bw, sw, sc, in, out, C, o, f, c) * wscale;
+            const _Float16 h = (_Float16)w;
+            dh[j] = h;
+            dl[j] = (_Float16)(w - (float)h);
+        }
+    }
+}
+
+int kan_split_pack_dx(const float* bw, const float* sw, const float* sc, int in, int out, int C,
+                      void* pack_dx, hipStream_t st) {
+    unsigned char* p = static_cast<unsigned char*>(pack_dx);
+    KAGNN_HIP(hipMemsetAsync(p, 0, kHdrBytes, st));
+    { int rc = split_absmax(bw, sw, sc, in, out, C, reinterpret_cast<unsigned*>(p), st); if (rc) return rc; }
+    const int Q = dx_q(out);
+    const long items = (long)cdiv(in, 32) * (C + 1) * Q * 64;
+    split_pack_dx_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, Q, p);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+constexpr int kCTmax = 9;     // C + 1 <= 9
+
+template <int K, int Q, int NT /* threads */>
+__global__ __launch_bounds__(NT) void kan_split_dx_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
+    int out, int C, const float* __restrict__ knots_g, int nknots,
+    const unsigned char* __restrict__ pack, int ft_per_load, float* __restrict__ gx, long ldgx) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* s_knots = reinterpret_cast<float*>(smem);
+    unsigned char* s_w = smem + kLdsHdr;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < nknots) s_knots[tid] = knots_g[tid];
+    const int CT = C + 1, FT = cdiv(in, 32);
+    const int FT_BYTES = CT * Q * 2 * 1024;
+    const int e_w = reinterpret_cast<const int*>(pack)[1];
+    const unsigned char* gw = pack + kHdrBytes;
+    auto stage = [&](int ft0, int nft) {
+        const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)ft0 * FT_BYTES);
+        uint4* dst = reinterpret_cast<uint4*>(s_w);
+        const int n16 = nft * FT_BYTES / 16;
+        for (int i = tid; i < n16; i += NT) dst[i] = src[i];
+    };
+    const bool resident = ft_per_load >= FT;
+    if (resident) stage(0, FT);
+    __syncthreads();
+    const SplineGeom geom = geom_from_knots(s_knots, nknots);
+    const int r = lane & 31, kg = lane >> 5;
+    const bool al4 = ((ldgy & 3) == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+    constexpr int ROWS = NW * 32;
+
+    for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
+        const long row0 = tile * ROWS + wave * 32;
+        const long row = row0 + r;
+        const bool rv = row < N;
+        // ---- A operand: this lane's 8 consecutive gy values per k-step, scaled per row, split
+        u32x4 ahi[Q], alo[Q];
+        int rexp;
+        {
+            float raw[Q][8];
+            const float* gr = gy + (rv ? row : 0) * ldgy;
+            float mx = 0.0f;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int o0 = 16 * q + 8 * kg;
+                if (al4 && rv && o0 + 8 <= out) {
+                    const float4 a = *reinterpret_cast<const float4*>(gr + o0);
+                    const float4 b = *reinterpret_cast<const float4*>(gr + o0 + 4);
+                    raw[q][0] = a.x; raw[q][1] = a.y; raw[q][2] = a.z; raw[q][3] = a.w;
+                    raw[q][4] = b.x; raw[q][5] = b.y; raw[q][6] = b.z; raw[q][7] = b.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) raw[q][j] = (rv && o0 + j < out) ? gr[o0 + j] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(raw[q][j]));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            rexp = exp_for_max(mx);
+            const float sc = ldexpf(1.0f, 10 - rexp);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = raw[q][j] * sc;
+                split_f16x2(v, ahi[q], alo[q]);
+            }
+        }
+        // undo factors for the 16 rows this lane holds in its D registers: 2^(e_w + rexp_row - 10)
+        float rinv[16];
+        {
+            const float mine = ldexpf(1.0f, e_w + rexp - 10);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rinv[i] = __shfl(mine, mfma32_row(i, kg));
+        }
+
+        for (int ft = 0; ft < FT; ++ft) {
+            if (!resident) {
+                __syncthreads();
+                stage(ft, 1);
+                __syncthreads();
+            }
+            const unsigned char* wft = s_w + (size_t)(resident ? ft : 0) * FT_BYTES + lane * 16;
+            f32x16 D[kCTmax];
+#pragma unroll
+            for (int c = 0; c < kCTmax; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) D[c][i] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+#pragma unroll
+                for (int c = 0; c < kCTmax; ++c) {
+                    if (c < CT) {
+                        const u32x4 bhi = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q + q) * 2 + 0) * 1024);
+                        const u32x4 blo = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q + q) * 2 + 1) * 1024);
+                        D[c] = mfma_f16(ahi[q], bhi, D[c]);
+                        D[c] = mfma_f16(ahi[q], blo, D[c]);
+                        D[c] = mfma_f16(alo[q], bhi, D[c]);
+                    }
+                }
+            }
+            // ---- contraction over c with the local basis derivatives (barrel shift by the span index)
+            const int f = 32 * ft + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long rr = row0 + mfma32_row(i, kg);
+                const bool ok = rr < N && f < in;
+                const float xv = ok ? x[rr * ldx + f] : 0.0f;
+                float Nv[K + 1], dN[K + 1];
+                const int m = bspline_local<K, true>(xv, s_knots, geom, Nv, dN);
+                // Dp[j] = D[j-K] (0 outside 0..C-1); E[r] = Dp[m + r]
+                constexpr int W8 = K + 8, W4 = K + 4, W2 = K + 2;
+                float T8[W8], T4[W4], T2[W2], E[K + 1];
+                const bool b8 = (m & 8) != 0, b4 = (m & 4) != 0, b2 = (m & 2) != 0, b1 = (m & 1) != 0;
+                auto Dp = [&](int j) -> float {           // j is a constant after unrolling
+                    const int c = j - K;
+                    if (c < 0 || c >= kCTmax - 1) return 0.0f;
+                    return (c < C) ? D[c][i] : 0.0f;
+                };
+#pragma unroll
+                for (int j = 0; j < W8; ++j) T8[j] = b8 ? Dp(j + 8) : Dp(j);
+#pragma unroll
+                for (int j = 0; j < W4; ++j) T4[j] = b4 ? T8[j + 4] : T8[j];
+#pragma unroll
+                for (int j = 0; j < W2; ++j) T2[j] = b2 ? T4[j + 2] : T4[j];
+#pragma unroll
+                for (int j = 0; j <= K; ++j) E[j] = b1 ? T2[j + 1] : T2[j];
+                // base-weight accumulator sits at index C (runtime): pick it with a uniform select chain
+                float db = 0.0f;
+#pragma unroll
+                for (int c = 0; c < kCTmax; ++c) db = (c == C) ? D[c][i] : db;
+                float s = db * silu_gradf(xv);
+#pragma unroll
+                for (int j = 0; j <= K; ++j) s = fmaf(E[j], dN[j], s);
+                if (ok) gx[rr * ldgx + f] = s * rinv[i];
+            }
+        }
+    }
+}
+
+template <int K, int Q>
+static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
+                     const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
+                     hipStream_t st) {
+    constexpr int NT = 256;   // 1 wave per SIMD: the 9 accumulators + fragments need > 256 registers
+    const int FT = cdiv(in, 32);
+    const size_t ft_bytes = (size_t)(C + 1) * Q * 2 * 1024;
+    const size_t budget = 160 * 1024 - kLdsHdr;
+    if (ft_bytes > budget) return fail(KAGNN_ERR_UNSUPPORTED, "%s: f-tile does not fit LDS", "kan_split_dx");
+    const int fpl = (int)min((size_t)FT, budget / ft_bytes);
+    const bool resident = fpl >= FT;
+    const size_t lds = kLdsHdr + (resident ? FT : 1) * ft_bytes;
+    static size_t configured = 0;
+    if (lds > configured) {
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q, NT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        configured = 160 * 1024;
+    }
+    const int rows = NT / 2;
+    const int grid = (int)min((long)cdiv(N, rows), 256L);
+    kan_split_dx_kernel<K, Q, NT><<<grid, NT, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
+                                                         resident ? FT : 1, gx, ldgx);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
+                 int out, int G, int K, const void* pack, float* gx, long ldgx, hipStream_t st) {
+    const int C = G + K, nk = G + 2 * K + 1, Q = dx_q(out);
+    const unsigned char* p = static_cast<const unsigned char*>(pack);
+#define GO(KK, QQ) return launch_dx<KK, QQ>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, st)
+#define BYQ(KK) switch (Q) { case 2: GO(KK, 2); case 4: GO(KK, 4); case 8: GO(KK, 8); }
+    switch (K) {
+        case 1: BYQ(1) break;
+        case 2: BYQ(2) break;
+        case 3: BYQ(3) break;
+    }
+#undef BYQ
+#undef GO
+    return fail(KAGNN_ERR_UNSUPPORTED, "%s: shape not covered by the split path", "kan_split_dx");
+}
+
+// ====================================================================== weight gradient
+bool kan_split_dw_ok(int in, int out, int G, int K) { return K >= 1 && K <= 3 && G + K <= 8; }
+
+struct DwPlan { int nbx; long rpw; long NS; long per; int FG, OC; long inP, outP; };
+
+static DwPlan split_dw_plan(long N, int in, int out, int C) {
+    DwPlan p;
+    p.FG = cdiv(in, 64); p.OC = cdiv(out, 64);
+    const int roles = p.FG * p.OC;
+    int nb = max(1, 256 / roles);                      // ~1 workgroup per CU
+    long r = (N + nb - 1) / nb;
+    r = max(32L, (r + 31) & ~31L);                     // whole 32-row chunks
+    nb = (int)max(1L, (long)cdiv(N, r));
+    p.nbx = nb; p.rpw = r; p.NS = nb;
+    p.inP = 32L * cdiv(in, 32); p.outP = 32L * cdiv(out, 32);
+    p.per = (long)(C + 1) * p.inP * p.outP;
+    return p;
+}
+
+size_t kan_split_dw_ws_bytes(long N, int in, int out, int C) {
+    const DwPlan p = split_dw_plan(N, in, out, C);
+    return (size_t)(p.NS + 1) * p.per * sizeof(float);
+}
+
+// one workgroup = 4 waves = 64 features x 64 outputs over rows [rbeg, rend); wave w owns features
+// 64*fg + 16*w .. +15.  slab[s][c][f][o].
+template <int K>
+__global__ __launch_bounds__(256) void kan_split_dw_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
+    int out, int C, const float* __restrict__ knots_g, int nknots, int OC, long rows_per_block,
+    long inP, long outP, float* __restrict__ slab) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsHdr];
+    float* s_knots = reinterpret_cast<float*>(smem);
+    unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < nknots) s_knots[tid] = knots_g[tid];
+    build_perm_table(s_tbl, tid);
+    __syncthreads();
+    const SplineGeom geom = geom_from_knots(s_knots, nknots);
+    const int fg = blockIdx.y / OC, oc = blockIdx.y % OC;
+    const int li = lane & 15, kg = lane >> 4;
+    const int f = 64 * fg + 16 * wave + li;            // A side: this lane's feature
+    const bool fv = f < in;
+    const long s = blockIdx.x;
+    const long rbeg = s * rows_per_block, rend = min(N, rbeg + rows_per_block);
+    const float kOut = s_knots[nknots - 1] + 1.0f;
+
+    f32x4 D[kCTmax - 1][4];        // spline coefficients x 4 o-tiles (scaled by 2^(10 + 10 - T))
+    f32x4 Db[4];                   // base weight (plain fp32)
+#pragma unroll
+    for (int c = 0; c < kCTmax - 1; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) D[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Db[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int T = -1000;                 // running exponent: gy is fed as gy * 2^(10 - T)
+
+    for (long n0 = rbeg; n0 < rend; n0 += 32) {
+        // ---- loads: 8 rows x (1 feature | 4 x 1 output column) per lane
+        float xv[8], g[4][8];
+        float mx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long n = n0 + 8 * kg + j;
+            const bool nv = n < rend;
+            xv[j] = (nv && fv) ? x[n * ldx + f] : kOut;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int o = 64 * oc + 16 * t + li;
+                g[t][j] = (nv && o < out) ? gy[n * ldgy + o] : 0.0f;
+                mx = fmaxf(mx, fabsf(g[t][j]));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const int ex = exp_for_max(mx);
+        if (ex > T) {                                   // wave-uniform: rescale what was accumulated so far
+            if (T > -1000) {
+                const float dn = ldexpf(1.0f, T - ex);
+#pragma unroll
+                for (int c = 0; c < kCTmax - 1; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) D[c][t] *= dn;
+            }
+            T = ex;
+        }
+        const float gs = ldexpf(1.0f, 10 - T);
+        u32x4 bhi[4], blo[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = g[t][j] * gs;
+            split_f16x2(v, bhi[t], blo[t]);
+        }
+        // ---- A: bases of 8 rows of one feature, placed per row then transposed to per-coefficient
+        u32x4 rh[8], rl[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) make_spline_frag<K>(xv[j], s_knots, s_tbl, geom, rh[j], rl[j]);
+#pragma unroll
+        for (int c = 0; c < kCTmax - 1; ++c) {
+            if (c < C) {
+                const int q = c >> 1;
+                const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
+                u32x4 ah, al;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    ah[p] = __builtin_amdgcn_perm(rh[2 * p + 1][q], rh[2 * p][q], sel);
+                    al[p] = __builtin_amdgcn_perm(rl[2 * p + 1][q], rl[2 * p][q], sel);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    D[c][t] = mfma16_f16(ah, bhi[t], D[c][t]);
+                    D[c][t] = mfma16_f16(ah, blo[t], D[c][t]);
+                    D[c][t] = mfma16_f16(al, bhi[t], D[c][t]);
+                }
+            }
+        }
+        // ---- SiLU base branch: exact fp32 MFMA, 4 rows per instruction (k-lane kg <-> row 8*kg + j)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long n = n0 + 8 * kg + j;
+            const float a = (n < rend && fv) ? siluf(xv[j]) : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                Db[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, g[t][j], Db[t], 0, 0, 0);
+        }
+    }
+    // ---- slab write: D rows <-> features 4*kg + reg, cols <-> outputs li
+    const float undo = (T > -1000) ? ldexpf(1.0f, T - 20) : 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const long o = 64 * oc + 16 * t + li;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const long fl = 64 * fg + 16 * wave + 4 * kg + reg;
+            if (fl < inP && o < outP) {
+#pragma unroll
+                for (int c = 0; c < kCTmax - 1; ++c)
+                    if (c < C) slab[((s * (C + 1) + c) * inP + fl) * outP + o] = D[c][t][reg] * undo;
+                slab[((s * (C + 1) + C) * inP + fl) * outP + o] = Db[t][reg];
+            }
+        }
+    }
+}
+
+int kan_split_dw(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
+                 int out, int G, int K, const float* sw, const float* sc, float* g_bw, float* g_sw,
+                 float* g_sc, float* ws, size_t ws_bytes, hipStream_t st) {
+    const int C = G + K, nk = G + 2 * K + 1;
+    const DwPlan p = split_dw_plan(N, in, out, C);
+    if (ws_bytes < (size_t)(p.NS + 1) * p.per * sizeof(float)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "kan_split_dw");
+    float* gcat = ws;
+    float* slab = ws + p.per;
+    dim3 grid(p.nbx, p.FG * p.OC);
+#define L(KK) kan_split_dw_kernel<KK><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab)
+    switch (K) {
+        case 1: L(1); break;
+        case 2: L(2); break;
+        case 3: L(3); break;
+        default: return fail(KAGNN_ERR_UNSUPPORTED, "%s: spline_order must be 1..3", "kan_split_dw");
+    }
+#undef L
+    KAGNN_LAUNCH_CHECK();
+    { int rc = kan_dw_reduce(slab, p.NS, p.per, gcat, st); if (rc) return rc; }
+    return kan_dw_unpack(gcat, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, st);
+}
+
 }  // namespace kagnn

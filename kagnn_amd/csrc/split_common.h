@@ -1,0 +1,120 @@
+// helpers shared by the split-precision KAN kernels (kan_split.hip, kan_split_bwd.hip)
+#pragma once
+#include "common.h"
+
+namespace kagnn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kHdrBytes = 256;           // pack header: [0] float 2^(e-10), [1] int e, [2] absmax bits
+constexpr int kLdsHdr = 512;             // LDS: knots (48 f32) @0, perm table (16 x 16 B) @256
+constexpr float kAScale = 1024.0f;       // bases / silu pre-scale (2^10)
+
+__device__ __forceinline__ float wcat_s(const float* bw, const float* sw, const float* sc, int in,
+                                        int out, int C, int o, int f, int c) {
+    if (o >= out || f >= in || c > C) return 0.0f;
+    if (c == C) return bw[(long)o * in + f];
+    float w = sw[((long)o * in + f) * C + c];
+    return sc ? w * sc[(long)o * in + f] : w;
+}
+
+// exponent e with max|W| * 2^-e in [2^9, 2^10)
+__device__ __forceinline__ int scale_exp_from_max(float m) {
+    if (!(m > 0.0f)) return 0;
+    int ex;
+    frexpf(m, &ex);                 // m = frac * 2^ex, frac in [0.5,1)  =>  m < 2^ex
+    return ex - 10;
+}
+
+// selector table for v_perm_b32: entry t (shift sh = t-4 halfs) holds 4 selectors; output half s of
+// the 8-slot window takes payload half s-sh (payload = 4 halfs in {p1:p0}), zero when out of range.
+__device__ __forceinline__ void build_perm_table(unsigned* tbl /* LDS, 16*4 */, int tid) {
+    if (tid < 64) {
+        const int t = tid >> 2, q = tid & 3, sh = t - 4;
+        unsigned sel = 0;
+        for (int hh = 0; hh < 2; ++hh) {
+            const int r = 2 * q + hh - sh;
+            const unsigned b = (r >= 0 && r <= 3) ? (unsigned)((2 * r) | ((2 * r + 1) << 8)) : 0x0c0cu;
+            sel |= b << (16 * hh);
+        }
+        tbl[tid] = sel;
+    }
+}
+
+__device__ __forceinline__ unsigned pk_f16_rtz(float a, float b) {
+    auto v = __builtin_amdgcn_cvt_pkrtz(a, b);     // two fp16, round toward zero
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float f16lo_to_f32(unsigned p) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu));
+}
+__device__ __forceinline__ float f16hi_to_f32(unsigned p) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16));
+}
+
+// 8 fp32 values (already scaled into fp16 range) -> hi and lo fp16 fragments
+__device__ __forceinline__ void split_f16x2(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned h = pk_f16_rtz(v[2 * q], v[2 * q + 1]);
+        hi[q] = h;
+        lo[q] = pk_f16_rtz(v[2 * q] - f16lo_to_f32(h), v[2 * q + 1] - f16hi_to_f32(h));
+    }
+}
+
+// bases (scaled by 2^10) of one scalar -> hi / lo A fragments (8 fp16 each) for window slots 0..7
+template <int K>
+__device__ __forceinline__ void make_spline_frag(float x, const float* __restrict__ knots,
+                                                 const unsigned* __restrict__ tbl,
+                                                 const SplineGeom& g, u32x4& ahi, u32x4& alo) {
+    float N[K + 1], dummy[K + 1];
+    const int m = bspline_local<K, false>(x, knots, g, N, dummy);
+    float n0 = N[0] * kAScale, n1 = N[1] * kAScale;
+    float n2 = (K >= 2) ? N[K >= 2 ? 2 : 0] * kAScale : 0.0f;
+    float n3 = (K >= 3) ? N[K >= 3 ? 3 : 0] * kAScale : 0.0f;
+    const unsigned h0 = pk_f16_rtz(n0, n1), h1 = pk_f16_rtz(n2, n3);
+    const unsigned l0 = pk_f16_rtz(n0 - f16lo_to_f32(h0), n1 - f16hi_to_f32(h0));
+    const unsigned l1 = pk_f16_rtz(n2 - f16lo_to_f32(h1), n3 - f16hi_to_f32(h1));
+    int t = m - K + 4;
+    t = t < 0 ? 0 : (t > 15 ? 15 : t);
+    const u32x4 sel = *reinterpret_cast<const u32x4*>(tbl + 4 * t);
+    ahi[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
+    ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
+    alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);
+    alo[2] = __builtin_amdgcn_perm(l1, l0, sel[2]); alo[3] = __builtin_amdgcn_perm(l1, l0, sel[3]);
+}
+
+// 8 fp32 values -> three truncated-bf16 fragments (v = v1 + v2 + v3 up to 2^-24)
+__device__ __forceinline__ void split_bf16x3(const float (&v)[8], u32x4& p1, u32x4& p2, u32x4& p3) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a = v[2 * q], b = v[2 * q + 1];
+        p1[q] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+        a -= __uint_as_float(__float_as_uint(a) & 0xffff0000u);
+        b -= __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+        p2[q] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+        a -= __uint_as_float(__float_as_uint(a) & 0xffff0000u);
+        b -= __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+        p3[q] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16_f16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// power-of-two scale that brings |v| <= m below 2^10 (exact); 1 for m == 0 / non-finite
+__device__ __forceinline__ int exp_for_max(float m) {
+    if (!(m > 0.0f) || !(m <= 3.0e38f)) return 10;
+    int ex;
+    frexpf(m, &ex);
+    return ex;                      // m < 2^ex ; scale = 2^(10-ex)
+}
+
+}  // namespace kagnn
