@@ -131,6 +131,7 @@ __global__ __launch_bounds__(512) void kan_split_fwd_kernel(
     if (nchunks == 1) stage_chunk(0);
     __syncthreads();
     const SplineGeom geom = geom_from_knots(s_knots, nknots);
+    const FastGeom fgeo = fast_geom(s_knots, nknots);
     const int r = lane & 31, kg = lane >> 5;
     const bool al4 = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(512) void kan_split_fwd_kernel(
 #pragma unroll
             for (int s = 0; s < SPC; ++s) {
                 u32x4 ahi, alo;
-                make_spline_frag<K>(xv[s], s_knots, s_tbl, geom, ahi, alo);
+                spline_frag<K>(xv[s], s_knots, s_tbl, geom, fgeo, ahi, alo);
                 const unsigned char* wp = s_w + (size_t)(s * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
                 for (int t = 0; t < OT; ++t) {

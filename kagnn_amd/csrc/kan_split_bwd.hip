@@ -24,17 +24,17 @@ int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP
                   const float* sc, float* g_bw, float* g_sw, float* g_sc, hipStream_t st);
 
 // ====================================================================== input gradient
-static inline int dx_q(int out) { return out <= 32 ? 2 : (out <= 64 ? 4 : 8); }
+static inline int dx_q2(int out) { return out <= 32 ? 1 : (out <= 64 ? 2 : 4); }   // 32-wide k-steps
 
 bool kan_split_dx_ok(int in, int out, int G, int K) { return K >= 1 && K <= 3 && G + K <= 8 && out <= 128; }
 
 size_t kan_split_pack_dx_bytes(int in, int out, int C) {
-    return kHdrBytes + (size_t)cdiv(in, 32) * (C + 1) * dx_q(out) * 2 * 1024;
+    return kHdrBytes + (size_t)cdiv(in, 16) * (C + 1) * dx_q2(out) * 2 * 1024;
 }
 
-// pack_dx[ft][c][q][part][lane][8] : lane (f = lane&31, kg = lane>>5), j -> W'[o = 16q+8kg+j][32ft+f][c]
+// pack_dx[ft16][c][q2][part][lane][8] : lane (f = lane&15, kg = lane>>4), j -> W'[o = 32*q2+8*kg+j][16*ft16+f][c]
 __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
-                                     const float* __restrict__ sc, int in, int out, int C, int Q,
+                                     const float* __restrict__ sc, int in, int out, int C, int Q2,
                                      unsigned char* __restrict__ pack) {
     unsigned* hdr = reinterpret_cast<unsigned*>(pack);
     const int e = scale_exp_from_max(__uint_as_float(hdr[2]));
@@ -44,16 +44,16 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
         reinterpret_cast<int*>(pack)[1] = e;
     }
     const int CT = C + 1;
-    const long total = (long)cdiv(in, 32) * CT * Q * 64;
+    const long total = (long)cdiv(in, 16) * CT * Q2 * 64;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int lane = i & 63; long r = i >> 6;
-        const int q = r % Q; r /= Q;
+        const int q = r % Q2; r /= Q2;
         const int c = r % CT; const int ft = r / CT;
-        const int f = 32 * ft + (lane & 31);
-        _Float16* dh = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q + q) * 2 + 0) * 1024 + lane * 16);
-        _Float16* dl = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q + q) * 2 + 1) * 1024 + lane * 16);
+        const int f = 16 * ft + (lane & 15);
+        _Float16* dh = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q2 + q) * 2 + 0) * 1024 + lane * 16);
+        _Float16* dl = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q2 + q) * 2 + 1) * 1024 + lane * 16);
         for (int j = 0; j < 8; ++j) {
-            const int o = 16 * q + 8 * (lane >> 5) + j;
+            const int o = 32 * q + 8 * (lane >> 4) + j;
             const float w = wcat_s(bw, sw, sc, in, out, C, o, f, c) * wscale;
             const _Float16 h = (_Float16)w;
             dh[j] = h;
@@ -67,58 +67,88 @@ int kan_split_pack_dx(const float* bw, const float* sw, const float* sc, int in,
     unsigned char* p = static_cast<unsigned char*>(pack_dx);
     KAGNN_HIP(hipMemsetAsync(p, 0, kHdrBytes, st));
     { int rc = split_absmax(bw, sw, sc, in, out, C, reinterpret_cast<unsigned*>(p), st); if (rc) return rc; }
-    const int Q = dx_q(out);
-    const long items = (long)cdiv(in, 32) * (C + 1) * Q * 64;
-    split_pack_dx_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, Q, p);
+    const int Q2 = dx_q2(out);
+    const long items = (long)cdiv(in, 16) * (C + 1) * Q2 * 64;
+    split_pack_dx_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, Q2, p);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
 
+// sum_r dN[r] * d[m - K + r]  (d[.] = 0 outside 0..7).  Two select stages over the register array:
+// by m>>2 (window of K+4 consecutive entries), then by m&3.  Written as select CHAINS on purpose:
+// `cond ? a[i] : a[j]` on one array gets folded into a dynamically indexed (scratch) access.
+template <int K>
+__device__ __forceinline__ float barrel_dot(const float (&d)[8], int m, const float (&dN)[K + 1]) {
+    const int a = m >> 2, b = m & 3;
+    float U[K + 4];
+#pragma unroll
+    for (int j = 0; j < K + 4; ++j) {
+        float v = 0.0f;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            const int c = 4 * aa + j - K;          // a constant after unrolling
+            if (c >= 0 && c < 8) v = (a == aa) ? d[c] : v;
+        }
+        U[j] = v;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r <= K; ++r) {
+        float e = U[r];
+#pragma unroll
+        for (int bb = 1; bb < 4; ++bb) e = (b == bb) ? U[r + bb] : e;
+        s = fmaf(e, dN[r], s);
+    }
+    return s;
+}
+
 constexpr int kCTmax = 9;     // C + 1 <= 9
 
-template <int K, int Q, int NT /* threads */>
-__global__ __launch_bounds__(NT) void kan_split_dx_kernel(
+// One wave = 32 rows (two 16-row MFMA tiles) x one 16-feature tile at a time.  v_mfma_f32_16x16x32_f16:
+// A lane (row = l&15, kg = l>>4) holds gy[row][32*q2 + 8*kg + j]; B lane (f = l&15, kg) holds W^T;
+// D lane (f = l&15) holds rows 4*kg + reg.
+template <int K, int Q2>
+__global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
-    const unsigned char* __restrict__ pack, int ft_per_load, float* __restrict__ gx, long ldgx) {
-    constexpr int NW = NT / 64;
+    const unsigned char* __restrict__ pack, int resident, float* __restrict__ gx, long ldgx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* s_knots = reinterpret_cast<float*>(smem);
     unsigned char* s_w = smem + kLdsHdr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < nknots) s_knots[tid] = knots_g[tid];
-    const int CT = C + 1, FT = cdiv(in, 32);
-    const int FT_BYTES = CT * Q * 2 * 1024;
+    const int CT = C + 1, FT = cdiv(in, 16);
+    const int FT_BYTES = CT * Q2 * 2 * 1024;
     const int e_w = reinterpret_cast<const int*>(pack)[1];
     const unsigned char* gw = pack + kHdrBytes;
     auto stage = [&](int ft0, int nft) {
         const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)ft0 * FT_BYTES);
         uint4* dst = reinterpret_cast<uint4*>(s_w);
         const int n16 = nft * FT_BYTES / 16;
-        for (int i = tid; i < n16; i += NT) dst[i] = src[i];
+        for (int i = tid; i < n16; i += 512) dst[i] = src[i];
     };
-    const bool resident = ft_per_load >= FT;
     if (resident) stage(0, FT);
     __syncthreads();
     const SplineGeom geom = geom_from_knots(s_knots, nknots);
-    const int r = lane & 31, kg = lane >> 5;
+    const FastGeom fgeo = fast_geom(s_knots, nknots);
+    const int li = lane & 15, kg = lane >> 4;
     const bool al4 = ((ldgy & 3) == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
-    constexpr int ROWS = NW * 32;
 
-    for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
-        const long row0 = tile * ROWS + wave * 32;
-        const long row = row0 + r;
-        const bool rv = row < N;
-        // ---- A operand: this lane's 8 consecutive gy values per k-step, scaled per row, split
-        u32x4 ahi[Q], alo[Q];
-        int rexp;
-        {
-            float raw[Q][8];
+    for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
+        const long row0 = tile * 256 + wave * 32;
+        // ---- A operand: gy rows scaled per row by 2^(10 - rexp), split into fp16 hi / lo
+        u32x4 ahi[2][Q2], alo[2][Q2];
+        float rinv[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const long row = row0 + 16 * rt + li;
+            const bool rv = row < N;
             const float* gr = gy + (rv ? row : 0) * ldgy;
+            float raw[Q2][8];
             float mx = 0.0f;
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int o0 = 16 * q + 8 * kg;
+            for (int q = 0; q < Q2; ++q) {
+                const int o0 = 32 * q + 8 * kg;
                 if (al4 && rv && o0 + 8 <= out) {
                     const float4 a = *reinterpret_cast<const float4*>(gr + o0);
                     const float4 b = *reinterpret_cast<const float4*>(gr + o0 + 4);
@@ -131,23 +161,20 @@ __global__ __launch_bounds__(NT) void kan_split_dx_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(raw[q][j]));
             }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            rexp = exp_for_max(mx);
+            const int rexp = exp_for_max(mx);
             const float sc = ldexpf(1.0f, 10 - rexp);
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
+            for (int q = 0; q < Q2; ++q) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = raw[q][j] * sc;
-                split_f16x2(v, ahi[q], alo[q]);
+                split_f16x2(v, ahi[rt][q], alo[rt][q]);
             }
-        }
-        // undo factors for the 16 rows this lane holds in its D registers: 2^(e_w + rexp_row - 10)
-        float rinv[16];
-        {
-            const float mine = ldexpf(1.0f, e_w + rexp - 10);
+            const float mine = ldexpf(1.0f, e_w + rexp - 10);      // undo factor of this lane's row
 #pragma unroll
-            for (int i = 0; i < 16; ++i) rinv[i] = __shfl(mine, mfma32_row(i, kg));
+            for (int reg = 0; reg < 4; ++reg) rinv[rt][reg] = __shfl(mine, 4 * kg + reg);
         }
 
         for (int ft = 0; ft < FT; ++ft) {
@@ -157,95 +184,86 @@ __global__ __launch_bounds__(NT) void kan_split_dx_kernel(
                 __syncthreads();
             }
             const unsigned char* wft = s_w + (size_t)(resident ? ft : 0) * FT_BYTES + lane * 16;
-            f32x16 D[kCTmax];
+            f32x4 D[kCTmax][2];
 #pragma unroll
-            for (int c = 0; c < kCTmax; ++c)
+            for (int c = 0; c < kCTmax; ++c) { D[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) D[c][i] = 0.0f;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
+            for (int q = 0; q < Q2; ++q) {
 #pragma unroll
                 for (int c = 0; c < kCTmax; ++c) {
                     if (c < CT) {
-                        const u32x4 bhi = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q + q) * 2 + 0) * 1024);
-                        const u32x4 blo = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q + q) * 2 + 1) * 1024);
-                        D[c] = mfma_f16(ahi[q], bhi, D[c]);
-                        D[c] = mfma_f16(ahi[q], blo, D[c]);
-                        D[c] = mfma_f16(alo[q], bhi, D[c]);
+                        const u32x4 bhi = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q2 + q) * 2 + 0) * 1024);
+                        const u32x4 blo = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q2 + q) * 2 + 1) * 1024);
+                        D[c][0] = mfma16_f16(ahi[0][q], bhi, D[c][0]);
+                        D[c][1] = mfma16_f16(ahi[1][q], bhi, D[c][1]);
+                        D[c][0] = mfma16_f16(ahi[0][q], blo, D[c][0]);
+                        D[c][1] = mfma16_f16(ahi[1][q], blo, D[c][1]);
+                        D[c][0] = mfma16_f16(alo[0][q], bhi, D[c][0]);
+                        D[c][1] = mfma16_f16(alo[1][q], bhi, D[c][1]);
                     }
                 }
             }
             // ---- contraction over c with the local basis derivatives (barrel shift by the span index)
-            const int f = 32 * ft + r;
+            const int f = 16 * ft + li;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const long rr = row0 + mfma32_row(i, kg);
-                const bool ok = rr < N && f < in;
-                const float xv = ok ? x[rr * ldx + f] : 0.0f;
-                float Nv[K + 1], dN[K + 1];
-                const int m = bspline_local<K, true>(xv, s_knots, geom, Nv, dN);
-                // Dp[j] = D[j-K] (0 outside 0..C-1); E[r] = Dp[m + r]
-                constexpr int W8 = K + 8, W4 = K + 4, W2 = K + 2;
-                float T8[W8], T4[W4], T2[W2], E[K + 1];
-                const bool b8 = (m & 8) != 0, b4 = (m & 4) != 0, b2 = (m & 2) != 0, b1 = (m & 1) != 0;
-                auto Dp = [&](int j) -> float {           // j is a constant after unrolling
-                    const int c = j - K;
-                    if (c < 0 || c >= kCTmax - 1) return 0.0f;
-                    return (c < C) ? D[c][i] : 0.0f;
-                };
+            for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
-                for (int j = 0; j < W8; ++j) T8[j] = b8 ? Dp(j + 8) : Dp(j);
+                for (int reg = 0; reg < 4; ++reg) {
+                    const long rr = row0 + 16 * rt + 4 * kg + reg;
+                    const bool ok = rr < N && f < in;
+                    const float xv = ok ? x[rr * ldx + f] : 0.0f;
+                    float dN[K + 1];
+                    int m;
+                    if constexpr (K == 3) {
+                        float u; bool inside;
+                        fast_span(xv, fgeo, m, u, inside);
+                        cubic_dbases(u, inside ? 0.5f * fgeo.inv_h : 0.0f, dN);
+                    } else {
+                        float Nv[K + 1];
+                        m = bspline_local<K, true>(xv, s_knots, geom, Nv, dN);
+                    }
+                    float d[kCTmax - 1];                       // this element's per-coefficient sums
 #pragma unroll
-                for (int j = 0; j < W4; ++j) T4[j] = b4 ? T8[j + 4] : T8[j];
+                    for (int c = 0; c < kCTmax - 1; ++c) d[c] = (c < C) ? D[c][rt][reg] : 0.0f;
+                    float db = 0.0f;                          // base-weight accumulator sits at index C
 #pragma unroll
-                for (int j = 0; j < W2; ++j) T2[j] = b2 ? T4[j + 2] : T4[j];
-#pragma unroll
-                for (int j = 0; j <= K; ++j) E[j] = b1 ? T2[j + 1] : T2[j];
-                // base-weight accumulator sits at index C (runtime): pick it with a uniform select chain
-                float db = 0.0f;
-#pragma unroll
-                for (int c = 0; c < kCTmax; ++c) db = (c == C) ? D[c][i] : db;
-                float s = db * silu_gradf(xv);
-#pragma unroll
-                for (int j = 0; j <= K; ++j) s = fmaf(E[j], dN[j], s);
-                if (ok) gx[rr * ldgx + f] = s * rinv[i];
+                    for (int c = 0; c < kCTmax; ++c) db = (c == C) ? D[c][rt][reg] : db;
+                    const float s = fmaf(db, silu_gradf(xv), barrel_dot<K>(d, m, dN));
+                    if (ok) gx[rr * ldgx + f] = s * rinv[rt][reg];
+                }
             }
         }
     }
 }
 
-template <int K, int Q>
+template <int K, int Q2>
 static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                      const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
                      hipStream_t st) {
-    constexpr int NT = 256;   // 1 wave per SIMD: the 9 accumulators + fragments need > 256 registers
-    const int FT = cdiv(in, 32);
-    const size_t ft_bytes = (size_t)(C + 1) * Q * 2 * 1024;
+    const int FT = cdiv(in, 16);
+    const size_t ft_bytes = (size_t)(C + 1) * Q2 * 2 * 1024;
     const size_t budget = 160 * 1024 - kLdsHdr;
-    if (ft_bytes > budget) return fail(KAGNN_ERR_UNSUPPORTED, "%s: f-tile does not fit LDS", "kan_split_dx");
-    const int fpl = (int)min((size_t)FT, budget / ft_bytes);
-    const bool resident = fpl >= FT;
+    const bool resident = (size_t)FT * ft_bytes <= budget;
     const size_t lds = kLdsHdr + (resident ? FT : 1) * ft_bytes;
-    static size_t configured = 0;
-    if (lds > configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q, NT>,
+    static bool configured = false;
+    if (!configured) {
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        configured = 160 * 1024;
+        configured = true;
     }
-    const int rows = NT / 2;
-    const int grid = (int)min((long)cdiv(N, rows), 256L);
-    kan_split_dx_kernel<K, Q, NT><<<grid, NT, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
-                                                         resident ? FT : 1, gx, ldgx);
+    const int grid = (int)min((long)cdiv(N, 256), 256L);
+    kan_split_dx_kernel<K, Q2><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
+                                                       resident ? 1 : 0, gx, ldgx);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
 
 int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
                  int out, int G, int K, const void* pack, float* gx, long ldgx, hipStream_t st) {
-    const int C = G + K, nk = G + 2 * K + 1, Q = dx_q(out);
+    const int C = G + K, nk = G + 2 * K + 1, Q2 = dx_q2(out);
     const unsigned char* p = static_cast<const unsigned char*>(pack);
 #define GO(KK, QQ) return launch_dx<KK, QQ>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, st)
-#define BYQ(KK) switch (Q) { case 2: GO(KK, 2); case 4: GO(KK, 4); case 8: GO(KK, 8); }
+#define BYQ(KK) switch (Q2) { case 1: GO(KK, 1); case 2: GO(KK, 2); case 4: GO(KK, 4); }
     switch (K) {
         case 1: BYQ(1) break;
         case 2: BYQ(2) break;
@@ -295,6 +313,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     build_perm_table(s_tbl, tid);
     __syncthreads();
     const SplineGeom geom = geom_from_knots(s_knots, nknots);
+    const FastGeom fgeo = fast_geom(s_knots, nknots);
     const int fg = blockIdx.y / OC, oc = blockIdx.y % OC;
     const int li = lane & 15, kg = lane >> 4;
     const int f = 64 * fg + 16 * wave + li;            // A side: this lane's feature
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
         // ---- A: bases of 8 rows of one feature, placed per row then transposed to per-coefficient
         u32x4 rh[8], rl[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) make_spline_frag<K>(xv[j], s_knots, s_tbl, geom, rh[j], rl[j]);
+        for (int j = 0; j < 8; ++j) spline_frag<K>(xv[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j]);
 #pragma unroll
         for (int c = 0; c < kCTmax - 1; ++c) {
             if (c < C) {

@@ -62,6 +62,50 @@ __device__ __forceinline__ void split_f16x2(const float (&v)[8], u32x4& hi, u32x
     }
 }
 
+// ---- uniform-grid fast path (K == 3, the order every KAGNN config uses) -------------------------
+// span index from arithmetic only: m = clamp(floor((x-g0)/h)), u = (x-g0)/h - m.  Right at a knot
+// the arithmetic may pick the neighbouring span with u ~ 1 or ~ 0; cubic pieces join C2 so values
+// and first derivatives agree to rounding.  `inside` uses the stored first/last knots, i.e. the
+// reference's half-open support [knots[0], knots[last]).  Non-finite x gives u = NaN/Inf and the
+// polynomials below turn that into NaN (0 * Inf = NaN), matching the reference.
+struct FastGeom {
+    float inv_h, c0;          // t = x*inv_h + c0
+    float k_first, k_last;
+    float last_span;          // (float)(nknots-2)
+};
+__device__ __forceinline__ FastGeom fast_geom(const float* knots, int nknots) {
+    FastGeom g;
+    g.inv_h = (float)(nknots - 1) / (knots[nknots - 1] - knots[0]);
+    g.c0 = -knots[0] * g.inv_h;
+    g.k_first = knots[0];
+    g.k_last = knots[nknots - 1];
+    g.last_span = (float)(nknots - 2);
+    return g;
+}
+__device__ __forceinline__ void fast_span(float x, const FastGeom& g, int& m, float& u, bool& inside) {
+    const float t = fmaf(x, g.inv_h, g.c0);
+    const float tf = fminf(fmaxf(floorf(t), 0.0f), g.last_span);
+    m = (int)tf;
+    u = t - tf;
+    inside = (x >= g.k_first) && (x < g.k_last);
+}
+// cubic pieces times w6 (= scale/6 inside the support, 0 outside): N[r] = B_{m-3+r}(x) * scale
+__device__ __forceinline__ void cubic_bases(float u, float w6, float (&N)[4]) {
+    const float u2 = u * u, u3 = u2 * u, om = 1.0f - u;
+    N[0] = om * om * om * w6;
+    N[3] = u3 * w6;
+    N[1] = fmaf(u3, 3.0f, fmaf(u2, -6.0f, 4.0f)) * w6;
+    N[2] = fmaf(fmaf(fmaf(u, -3.0f, 3.0f), u, 3.0f), u, 1.0f) * w6;
+}
+// d/dx of the same pieces times wd (= inv_h/2 inside, 0 outside)
+__device__ __forceinline__ void cubic_dbases(float u, float wd, float (&dN)[4]) {
+    const float om = 1.0f - u, u2 = u * u;
+    dN[0] = -(om * om) * wd;
+    dN[3] = u2 * wd;
+    dN[1] = fmaf(u2, 3.0f, u * -4.0f) * wd;
+    dN[2] = fmaf(u2, -3.0f, fmaf(u, 2.0f, 1.0f)) * wd;
+}
+
 // bases (scaled by 2^10) of one scalar -> hi / lo A fragments (8 fp16 each) for window slots 0..7
 template <int K>
 __device__ __forceinline__ void make_spline_frag(float x, const float* __restrict__ knots,
@@ -82,6 +126,31 @@ __device__ __forceinline__ void make_spline_frag(float x, const float* __restric
     ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
     alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);
     alo[2] = __builtin_amdgcn_perm(l1, l0, sel[2]); alo[3] = __builtin_amdgcn_perm(l1, l0, sel[3]);
+}
+
+// K == 3 fast path: arithmetic span, closed-form cubic pieces, no knot lookups
+__device__ __forceinline__ void make_spline_frag3(float x, const unsigned* __restrict__ tbl,
+                                                  const FastGeom& g, u32x4& ahi, u32x4& alo) {
+    int m; float u; bool inside;
+    fast_span(x, g, m, u, inside);
+    float N[4];
+    cubic_bases(u, inside ? (kAScale / 6.0f) : 0.0f, N);
+    const unsigned h0 = pk_f16_rtz(N[0], N[1]), h1 = pk_f16_rtz(N[2], N[3]);
+    const unsigned l0 = pk_f16_rtz(N[0] - f16lo_to_f32(h0), N[1] - f16hi_to_f32(h0));
+    const unsigned l1 = pk_f16_rtz(N[2] - f16lo_to_f32(h1), N[3] - f16hi_to_f32(h1));
+    const u32x4 sel = *reinterpret_cast<const u32x4*>(tbl + 4 * (m + 1));     // m - 3 + 4, m in [0, 14]
+    ahi[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
+    ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
+    alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);
+    alo[2] = __builtin_amdgcn_perm(l1, l0, sel[2]); alo[3] = __builtin_amdgcn_perm(l1, l0, sel[3]);
+}
+
+template <int K>
+__device__ __forceinline__ void spline_frag(float x, const float* __restrict__ knots,
+                                            const unsigned* __restrict__ tbl, const SplineGeom& g,
+                                            const FastGeom& fg, u32x4& ahi, u32x4& alo) {
+    if constexpr (K == 3) make_spline_frag3(x, tbl, fg, ahi, alo);
+    else make_spline_frag<K>(x, knots, tbl, g, ahi, alo);
 }
 
 // 8 fp32 values -> three truncated-bf16 fragments (v = v1 + v2 + v3 up to 2^-24)
