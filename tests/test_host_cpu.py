@@ -1,0 +1,110 @@
+"""CPU-side checks (no GPU, no compute calls): the C-ABI library loads and exports every symbol that
+include/kagnn_hip.h declares; the module surface mirrors the reference's names, constructor
+signatures and state_dict keys; the product refuses CPU tensors instead of falling back."""
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+import kagnn_amd
+from kagnn_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "kagnn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kagnn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/kagnn_hip.h but not exported"
+    assert sorted(_lib.EXPORTED) == declared, "ctypes signature table and header disagree"
+    assert lib.kagnn_version() >= 100
+
+
+def test_state_dict_surface_matches_reference_names():
+    m = kagnn_amd.GKAN_Nodes("gin", 2, 10, 8, 3, grid_size=5, spline_order=3)
+    keys = set(m.state_dict())
+    for k in ("convs.0.eps", "convs.0.nn.layers.0.base_weight", "convs.0.nn.layers.1.spline_scaler",
+              "convs.1.nn.layers.0.grid", "bns.0.running_mean", "lay_out.spline_weight"):
+        assert k in keys, k
+    assert m.lay_out.in_features == 10 + 2 * 8
+    m = kagnn_amd.GKAN_Nodes("gcn", 2, 10, 8, 3)
+    keys = set(m.state_dict())
+    for k in ("convs.0.bias", "convs.0.lin.base_weight", "convs.1.lin.grid"):
+        assert k in keys, k
+    assert m.convs[0].lin.grid_size == 4                      # the reference's default grid_size=4
+    f = kagnn_amd.GFASTKAN_Nodes("gin", 3, 6, 4, 2)
+    keys = set(f.state_dict())
+    for k in ("convs.0.nn.layers.0.layernorm.weight", "convs.0.nn.layers.0.rbf.grid",
+              "convs.2.nn.layers.1.spline_linear.weight", "lay_out.base_linear.bias"):
+        assert k in keys, k
+    assert not f.convs[0].nn.layers[0].rbf.grid.requires_grad
+    with pytest.raises(ValueError, match="unknown conv_type"):
+        kagnn_amd.GKAN_Nodes("sage", 1, 4, 4, 2)
+
+
+def test_constructor_signatures_match_reference():
+    sig = inspect.signature(kagnn_amd.KANLinear.__init__)
+    assert list(sig.parameters)[1:] == ["in_features", "out_features", "grid_size", "spline_order", "scale_noise",
+                                        "scale_base", "scale_spline", "enable_standalone_scale_spline",
+                                        "base_activation", "grid_eps", "grid_range"]
+    assert sig.parameters["grid_size"].default == 5 and sig.parameters["spline_order"].default == 3
+    sig = inspect.signature(kagnn_amd.GIKANLayer.__init__)
+    assert list(sig.parameters)[1:] == ["in_feat", "out_feat", "grid_size", "spline_order", "hidden_dim", "nb_layers"]
+    assert sig.parameters["hidden_dim"].default == 16
+    sig = inspect.signature(kagnn_amd.FastKANLayer.__init__)
+    assert list(sig.parameters)[1:] == ["input_dim", "output_dim", "grid_min", "grid_max", "num_grids",
+                                        "use_base_update", "use_layernorm", "base_activation",
+                                        "spline_weight_init_scale"]
+
+
+def test_reference_state_dict_loads(reference_modules):
+    """a state_dict produced by the reference's own KAN loads into ours unchanged (and back)."""
+    ref_ekan, ref_fastkan = reference_modules
+    torch.manual_seed(0)
+    ref = ref_ekan.KAN([6, 5, 4], grid_size=4, spline_order=2)
+    ours = kagnn_amd.KAN([6, 5, 4], grid_size=4, spline_order=2)
+    ours.load_state_dict(ref.state_dict())
+    ref.load_state_dict(ours.state_dict())
+    rf = ref_fastkan.FastKAN([6, 5, 4], num_grids=3)
+    of = kagnn_amd.FastKAN([6, 5, 4], num_grids=3)
+    of.load_state_dict(rf.state_dict())
+    assert [n for n, _ in of.named_parameters()] == [n for n, _ in rf.named_parameters()]
+
+
+def test_init_distributions_match_reference(reference_modules):
+    """same init *distributions* (not RNG streams): compare moments of many draws."""
+    ref_ekan, _ = reference_modules
+    torch.manual_seed(1)
+    a = ref_ekan.KANLinear(64, 64)
+    torch.manual_seed(2)
+    b = kagnn_amd.KANLinear(64, 64)
+    for name in ("base_weight", "spline_weight", "spline_scaler"):
+        x, y = getattr(a, name).detach(), getattr(b, name).detach()
+        assert abs(float(x.std()) - float(y.std())) < 0.1 * float(x.std()), name
+        assert abs(float(x.mean()) - float(y.mean())) < 0.05 * float(x.std()) + 1e-4, name
+    assert torch.equal(a.grid, b.grid)
+
+
+def test_cpu_tensors_are_refused_not_emulated():
+    layer = kagnn_amd.KANLinear(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(torch.randn(2, 4))
+    fk = kagnn_amd.FastKANLayer(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fk(torch.randn(2, 4))
+    conv = kagnn_amd.GIKANLayer(4, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        conv(torch.randn(5, 4), torch.zeros(2, 3, dtype=torch.long))
