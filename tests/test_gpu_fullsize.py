@@ -1,0 +1,158 @@
+"""Full-size (BASELINE.json metric: N=1M, E=10M, F=64) checks of the HIP path through
+size-independent properties plus oracle comparisons on row samples, and the feature-sharded layer on
+one GPU."""
+import pytest
+import torch
+
+import kagnn_amd
+from kagnn_amd import ops
+from kagnn_amd.sharded import ShardedKANLinear
+from oracle import kan_oracle as orc
+from helpers import assert_close, oracle_kan_linear_fwd_bwd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N, E, F = 1_000_000, 10_000_000, 64
+
+
+@pytest.fixture(scope="module")
+def big():
+    ei = orc.powerlaw_graph(N, E, seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, F, generator=g) * 0.25
+    return ei, x, ops.GraphIndex(ei.to(DEV), N)
+
+
+def test_fullsize_csr_properties(big):
+    ei, _, gi = big
+    rp = gi.rowptr.long()
+    assert int(rp[0]) == 0 and int(rp[-1]) == E and bool((rp[1:] >= rp[:-1]).all())
+    assert torch.equal(rp[1:] - rp[:-1], torch.bincount(ei[1].to(DEV), minlength=N))      # histogram
+    perm = gi.perm.long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(E, device=DEV))                # a permutation
+    dst_sorted = ei[1].to(DEV)[perm]
+    assert bool((dst_sorted[1:] >= dst_sorted[:-1]).all())                                  # sortedness
+    same = dst_sorted[1:] == dst_sorted[:-1]
+    assert bool((perm[1:][same] > perm[:-1][same]).all())                                   # stability
+    assert torch.equal(gi.col.long(), ei[0].to(DEV)[perm])
+    assert gi.num_hub_seg > 0                                                               # top hub ~1e4 in-edges
+
+
+def test_fullsize_aggregation_checksum_and_samples(big):
+    ei, x, gi = big
+    xd = x.to(DEV)
+    out = ops.aggregate_sum(xd, gi, self_scale=1.0)
+    # checksum of checksums: column sums of the output == column sums of all messages + self term (fp64)
+    want = xd.double().sum(0) + xd.double().index_select(0, ei[0].to(DEV)).sum(0)
+    assert_close(out.double().sum(0), want, 1e-6, what="column checksum")   # fp32 row rounding, random walk over 1M rows
+    # sampled destination rows (incl. the biggest hub and an isolated node) against the CPU oracle
+    deg = torch.bincount(ei[1], minlength=N)
+    rows = torch.cat([torch.randint(0, N, (3000,), generator=torch.Generator().manual_seed(1)),
+                      deg.argmax().view(1), (deg == 0).nonzero()[:3].view(-1)])
+    mask = torch.zeros(N, dtype=torch.bool); mask[rows] = True
+    keep = mask[ei[1]]
+    sub = orc.sum_aggregate(x.double(), ei[:, keep], N) + x.double()
+    assert_close(out.cpu()[rows], sub[rows], what="sampled rows")
+    # transpose consistency: <A x, y> == <x, A^T y>
+    y = torch.randn(N, F, generator=torch.Generator().manual_seed(2)).to(DEV)
+    aty = ops._aggregate_raw(y, gi, True, 1.0, None, None, None, None, False)
+    lhs = float((out.double() * y.double()).sum()); rhs = float((xd.double() * aty.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("mode", [ops.PREC_SPLIT, ops.PREC_FP32], ids=["split", "fp32"])
+def test_fullsize_kanlinear_samples_and_linearity(big, mode):
+    _, x, _ = big
+    gen = torch.Generator().manual_seed(3)
+    p = orc.init_kan_linear(F, F, 5, 3, gen)
+    layer = kagnn_amd.KANLinear(F, F, grid_size=5, spline_order=3)
+    layer.load_state_dict(p)
+    layer = layer.to(DEV)
+    layer.precision = mode
+    xs = (x * 3.0).to(DEV).requires_grad_(True)          # std 0.75: most values inside the spline support
+    rows = torch.randint(0, N, (4096,), generator=gen)
+    gy = torch.zeros(N, F)
+    gy[rows] = torch.randn(rows.numel(), F, generator=gen)
+    y = layer(xs)
+    y.backward(gy.to(DEV))
+    ur = torch.unique(rows)
+    y64, gx64, g64 = oracle_kan_linear_fwd_bwd((x * 3.0)[ur], gy[ur], p, 3)
+    assert_close(y.detach().cpu()[ur], y64, what="y rows")
+    assert_close(xs.grad.cpu()[ur], gx64, what="gx rows")
+    for k in ("base_weight", "spline_weight", "spline_scaler"):
+        assert_close(getattr(layer, k).grad, g64[k], what="g_" + k)    # gy is zero outside the sample
+    off = torch.ones(N, dtype=torch.bool); off[ur] = False
+    assert float(xs.grad[off.to(DEV)].abs().max()) == 0.0             # no gradient leaks to other rows
+    # linearity of the weight gradient in gy / additivity over a row partition (full size)
+    g2 = torch.randn(N, F, generator=gen).to(DEV)
+    half = N // 2 + 17
+    def wgrad(gmat):
+        for q in layer.parameters():
+            q.grad = None
+        layer(xs.detach()).backward(gmat)
+        return layer.spline_weight.grad.clone(), layer.base_weight.grad.clone()
+    full_s, full_b = wgrad(g2)
+    ga = g2.clone(); ga[half:] = 0
+    gb = g2.clone(); gb[:half] = 0
+    a_s, a_b = wgrad(ga)
+    b_s, b_b = wgrad(gb)
+    assert_close(a_s + b_s, full_s, 2e-5, what="dW additivity")
+    assert_close(a_b + b_b, full_b, 2e-5, what="dWb additivity")
+
+
+def test_two_feature_shards_sum_to_the_full_layer():
+    """the per-rank pieces of kagnn_amd.sharded on ONE GPU: partial sums over input-feature shards
+    (strided column views, narrow in_features) add up to the unsharded layer, fwd and bwd."""
+    n = 5000
+    gen = torch.Generator().manual_seed(4)
+    full = kagnn_amd.KANLinear(64, 64, grid_size=5, spline_order=3).to(DEV)
+    x = (torch.randn(n, 64, generator=gen) * 0.6).to(DEV)
+    gy = torch.randn(n, 64, generator=gen).to(DEV)
+    xr = x.clone().requires_grad_(True)
+    yf = full(xr)
+    yf.backward(gy)
+    for world in (2, 8):
+        total = torch.zeros_like(yf)
+        gx = torch.zeros_like(x)
+        for r in range(world):
+            sh = ShardedKANLinear(full, r, world).to(DEV)
+            xs = x[:, sh.lo:sh.hi].detach().requires_grad_(True)        # strided view, ld = 64
+            part = sh(xs, ops)
+            part.backward(gy)
+            total += part.detach()
+            gx[:, sh.lo:sh.hi] = xs.grad
+            assert_close(sh.base_weight.grad, full.base_weight.grad[:, sh.lo:sh.hi], what="g_base shard")
+            assert_close(sh.spline_weight.grad, full.spline_weight.grad[:, sh.lo:sh.hi], what="g_spline shard")
+            assert_close(sh.spline_scaler.grad, full.spline_scaler.grad[:, sh.lo:sh.hi], what="g_scaler shard")
+        assert_close(total, yf.detach(), what=f"sum of {world} partials")
+        assert_close(gx, xr.grad, what=f"gx from {world} shards")
+
+
+def test_sharded_layer_world1_nccl():
+    """ShardedGIKANLayer end to end through RCCL with a 1-rank group (the 8-GPU run is the driver's)."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        from kagnn_amd.sharded import ShardedGIKANLayer
+        n, e, f = 20000, 200000, 64
+        ei = orc.powerlaw_graph(n, e, seed=5)
+        gen = torch.Generator().manual_seed(5)
+        x = torch.randn(n, f, generator=gen) * 0.25
+        gy = torch.randn(n, f, generator=gen)
+        conv = kagnn_amd.GIKANLayer(f, f, grid_size=5, spline_order=3, hidden_dim=f, nb_layers=2)
+        layers = [{k: v.detach().clone() for k, v in l.state_dict().items()} for l in conv.nn.layers]
+        y_ref, gx_ref, _ = orc.kan_gin_layer_fwd_bwd(x, ei, layers, 3, gy)
+        s = ShardedGIKANLayer(conv, None).to(DEV)
+        xs = x.to(DEV).requires_grad_(True)
+        y = s(xs, ops.GraphIndex(ei.to(DEV), n))
+        y.backward(gy.to(DEV))
+        assert_close(y, y_ref, what="sharded y")
+        assert_close(xs.grad, gx_ref, what="sharded gx")
+    finally:
+        if created:
+            dist.destroy_process_group()
