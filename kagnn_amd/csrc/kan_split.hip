@@ -135,11 +135,33 @@ __global__ __launch_bounds__(512) void kan_split_fwd_kernel(
     const int r = lane & 31, kg = lane >> 5;
     const bool al4 = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 
+    // this lane's HF consecutive features of chunk `ch` of the tile starting at row0t.  Loads are
+    // unconditional on clamped addresses and never masked (a per-lane `cond ? load : const` makes hipcc
+    // branch around every load): rows >= N are never stored, features >= in meet zero weights in the pack.
+    auto load_x = [&](long row0t, int ch, float (&xv)[HF]) {
+        const long row = row0t + r;
+        const bool rv = row < N;
+        // unconditional loads on clamped addresses, masked afterwards (no per-lane branch around a load)
+        const float* xr = x + (rv ? row : N - 1) * ldx;
+        const int f0 = ch * CF + kg * HF;
+        if (al4 && ch * CF + CF <= in) {                  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < HF; j += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + f0 + j);
+                xv[j] = v.x; xv[j + 1] = v.y; xv[j + 2] = v.z; xv[j + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < HF; ++j) xv[j] = xr[min(f0 + j, in - 1)];
+        }
+    };
+    float xnext[HF];
+    if (nchunks == 1) load_x((long)blockIdx.x * 256 + wave * 32, 0, xnext);
+
     for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
         const long row0 = tile * 256 + wave * 32;
         const long row = row0 + r;
         const bool rv = row < N;
-        const float* xr = x + (rv ? row : 0) * ldx;
         f32x16 acc[OT];
 #pragma unroll
         for (int t = 0; t < OT; ++t)
@@ -152,19 +174,14 @@ __global__ __launch_bounds__(512) void kan_split_fwd_kernel(
                 stage_chunk(ch);
                 __syncthreads();
             }
-            // this lane's HF consecutive features of the chunk; invalid -> a value outside every span
             const int f0 = ch * CF + kg * HF;
             float xv[HF];
-            const float kOut = s_knots[nknots - 1] + 1.0f;        // finite, outside the grid: all bases 0
-            if (al4 && rv && f0 + HF <= in) {
+            if (nchunks == 1) {
 #pragma unroll
-                for (int j = 0; j < HF; j += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(xr + f0 + j);
-                    xv[j] = v.x; xv[j + 1] = v.y; xv[j + 2] = v.z; xv[j + 3] = v.w;
-                }
+                for (int j = 0; j < HF; ++j) xv[j] = xnext[j];
+                load_x((tile + gridDim.x) * 256 + wave * 32, 0, xnext);     // next tile's rows, in flight during this one
             } else {
-#pragma unroll
-                for (int j = 0; j < HF; ++j) xv[j] = (rv && f0 + j < in) ? xr[f0 + j] : kOut;
+                load_x(row0, ch, xv);
             }
             // ---- spline part: one MFMA step per feature
 #pragma unroll
@@ -187,9 +204,7 @@ __global__ __launch_bounds__(512) void kan_split_fwd_kernel(
                 float sv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float xx = xv[8 * sb + j];
-                    const bool ok = rv && (f0 + 8 * sb + j < in);
-                    sv[j] = ok ? siluf(xx) * kAScale : 0.0f;
+                    sv[j] = siluf(xv[8 * sb + j]) * kAScale;
                 }
                 u32x4 a1, a2, a3;
                 split_bf16x3(sv, a1, a2, a3);

@@ -24,12 +24,13 @@ int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP
                   const float* sc, float* g_bw, float* g_sw, float* g_sc, hipStream_t st);
 
 // ====================================================================== input gradient
+constexpr int kCTmax = 9;     // C + 1 <= 9 accumulators (8 spline coefficients + base); unused slots carry zero weights
 static inline int dx_q2(int out) { return out <= 32 ? 1 : (out <= 64 ? 2 : 4); }   // 32-wide k-steps
 
 bool kan_split_dx_ok(int in, int out, int G, int K) { return K >= 1 && K <= 3 && G + K <= 8 && out <= 128; }
 
 size_t kan_split_pack_dx_bytes(int in, int out, int C) {
-    return kHdrBytes + (size_t)cdiv(in, 16) * (C + 1) * dx_q2(out) * 2 * 1024;
+    return kHdrBytes + (size_t)cdiv(in, 16) * kCTmax * dx_q2(out) * 2 * 1024;   // always 9 slots: branch-free MFMA loop
 }
 
 // pack_dx[ft16][c][q2][part][lane][8] : lane (f = lane&15, kg = lane>>4), j -> W'[o = 32*q2+8*kg+j][16*ft16+f][c]
@@ -43,7 +44,7 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
         reinterpret_cast<float*>(pack)[0] = ldexpf(1.0f, e - 10);
         reinterpret_cast<int*>(pack)[1] = e;
     }
-    const int CT = C + 1;
+    const int CT = kCTmax;
     const long total = (long)cdiv(in, 16) * CT * Q2 * 64;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int lane = i & 63; long r = i >> 6;
@@ -68,7 +69,7 @@ int kan_split_pack_dx(const float* bw, const float* sw, const float* sc, int in,
     KAGNN_HIP(hipMemsetAsync(p, 0, kHdrBytes, st));
     { int rc = split_absmax(bw, sw, sc, in, out, C, reinterpret_cast<unsigned*>(p), st); if (rc) return rc; }
     const int Q2 = dx_q2(out);
-    const long items = (long)cdiv(in, 16) * (C + 1) * Q2 * 64;
+    const long items = (long)cdiv(in, 16) * kCTmax * Q2 * 64;
     split_pack_dx_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, Q2, p);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
@@ -102,7 +103,6 @@ __device__ __forceinline__ float barrel_dot(const float (&d)[8], int m, const fl
     return s;
 }
 
-constexpr int kCTmax = 9;     // C + 1 <= 9
 
 // One wave = 32 rows (two 16-row MFMA tiles) x one 16-feature tile at a time.  v_mfma_f32_16x16x32_f16:
 // A lane (row = l&15, kg = l>>4) holds gy[row][32*q2 + 8*kg + j]; B lane (f = l&15, kg) holds W^T;
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     unsigned char* s_w = smem + kLdsHdr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < nknots) s_knots[tid] = knots_g[tid];
-    const int CT = C + 1, FT = cdiv(in, 16);
-    const int FT_BYTES = CT * Q2 * 2 * 1024;
+    const int FT = cdiv(in, 16);
+    constexpr int FT_BYTES = kCTmax * Q2 * 2 * 1024;
     const int e_w = reinterpret_cast<const int*>(pack)[1];
     const unsigned char* gw = pack + kHdrBytes;
     auto stage = [&](int ft0, int nft) {
@@ -143,20 +143,23 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
         for (int rt = 0; rt < 2; ++rt) {
             const long row = row0 + 16 * rt + li;
             const bool rv = row < N;
-            const float* gr = gy + (rv ? row : 0) * ldgy;
+            // loads are UNCONDITIONAL on clamped addresses and never masked: a per-lane `cond ? load : const`
+            // makes hipcc branch around every load and drain vmcnt each time.  Rows >= N are computed on a
+            // duplicate of the last row and never stored; columns >= out meet zero weights in the pack.
+            const float* gr = gy + (rv ? row : N - 1) * ldgy;
             float raw[Q2][8];
             float mx = 0.0f;
 #pragma unroll
             for (int q = 0; q < Q2; ++q) {
                 const int o0 = 32 * q + 8 * kg;
-                if (al4 && rv && o0 + 8 <= out) {
+                if (al4 && 32 * Q2 == out) {              // wave-uniform
                     const float4 a = *reinterpret_cast<const float4*>(gr + o0);
                     const float4 b = *reinterpret_cast<const float4*>(gr + o0 + 4);
                     raw[q][0] = a.x; raw[q][1] = a.y; raw[q][2] = a.z; raw[q][3] = a.w;
                     raw[q][4] = b.x; raw[q][5] = b.y; raw[q][6] = b.z; raw[q][7] = b.w;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) raw[q][j] = (rv && o0 + j < out) ? gr[o0 + j] : 0.0f;
+                    for (int j = 0; j < 8; ++j) raw[q][j] = gr[min(o0 + j, out - 1)];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(raw[q][j]));
@@ -184,34 +187,41 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                 __syncthreads();
             }
             const unsigned char* wft = s_w + (size_t)(resident ? ft : 0) * FT_BYTES + lane * 16;
+            // this lane's 8 x values of the tile: issue the loads now, they land under the MFMAs
+            const int f = 16 * ft + li;
+            float xq[2][4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const long rr = row0 + 16 * rt + 4 * kg + reg;
+                    xq[rt][reg] = x[min(rr, N - 1) * ldx + min(f, in - 1)];        // unconditional, clamped; unused lanes never store
+                }
             f32x4 D[kCTmax][2];
 #pragma unroll
             for (int c = 0; c < kCTmax; ++c) { D[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int q = 0; q < Q2; ++q) {
 #pragma unroll
-                for (int c = 0; c < kCTmax; ++c) {
-                    if (c < CT) {
-                        const u32x4 bhi = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q2 + q) * 2 + 0) * 1024);
-                        const u32x4 blo = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q2 + q) * 2 + 1) * 1024);
-                        D[c][0] = mfma16_f16(ahi[0][q], bhi, D[c][0]);
-                        D[c][1] = mfma16_f16(ahi[1][q], bhi, D[c][1]);
-                        D[c][0] = mfma16_f16(ahi[0][q], blo, D[c][0]);
-                        D[c][1] = mfma16_f16(ahi[1][q], blo, D[c][1]);
-                        D[c][0] = mfma16_f16(alo[0][q], bhi, D[c][0]);
-                        D[c][1] = mfma16_f16(alo[1][q], bhi, D[c][1]);
-                    }
+                for (int c = 0; c < kCTmax; ++c) {          // all 9 slots, no branch: unused ones hold zero weights
+                    const u32x4 bhi = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q2 + q) * 2 + 0) * 1024);
+                    const u32x4 blo = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q2 + q) * 2 + 1) * 1024);
+                    D[c][0] = mfma16_f16(ahi[0][q], bhi, D[c][0]);
+                    D[c][1] = mfma16_f16(ahi[1][q], bhi, D[c][1]);
+                    D[c][0] = mfma16_f16(ahi[0][q], blo, D[c][0]);
+                    D[c][1] = mfma16_f16(ahi[1][q], blo, D[c][1]);
+                    D[c][0] = mfma16_f16(alo[0][q], bhi, D[c][0]);
+                    D[c][1] = mfma16_f16(alo[1][q], bhi, D[c][1]);
                 }
             }
             // ---- contraction over c with the local basis derivatives (barrel shift by the span index)
-            const int f = 16 * ft + li;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const long rr = row0 + 16 * rt + 4 * kg + reg;
                     const bool ok = rr < N && f < in;
-                    const float xv = ok ? x[rr * ldx + f] : 0.0f;
+                    const float xv = xq[rt][reg];
                     float dN[K + 1];
                     int m;
                     if constexpr (K == 3) {
@@ -241,7 +251,7 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
                      const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
                      hipStream_t st) {
     const int FT = cdiv(in, 16);
-    const size_t ft_bytes = (size_t)(C + 1) * Q2 * 2 * 1024;
+    const size_t ft_bytes = (size_t)kCTmax * Q2 * 2 * 1024;
     const size_t budget = 160 * 1024 - kLdsHdr;
     const bool resident = (size_t)FT * ft_bytes <= budget;
     const size_t lds = kLdsHdr + (resident ? FT : 1) * ft_bytes;
@@ -300,6 +310,17 @@ size_t kan_split_dw_ws_bytes(long N, int in, int out, int C) {
 
 // one workgroup = 4 waves = 64 features x 64 outputs over rows [rbeg, rend); wave w owns features
 // 64*fg + 16*w .. +15.  slab[s][c][f][o].
+//
+// Software pipeline (1 wave per SIMD: the 160 accumulator registers leave no room for a second wave,
+// and a lone wave issues at most one instruction per ~4 cycles): the MFMAs of chunk i are interleaved
+// at source level with the VALU work that prepares chunk i+1, and the global loads of chunk i+2 are
+// already in flight.
+struct DwRaw { float x[8]; float g[4][8]; };
+struct DwFrag {
+    u32x4 rh[8], rl[8];          // per row: 8-slot windows (hi / lo) of this lane's feature
+    u32x4 bhi[4], blo[4];        // gy * 2^(10-T), per 16-wide output tile
+};
+
 template <int K>
 __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
@@ -317,12 +338,10 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     const int fg = blockIdx.y / OC, oc = blockIdx.y % OC;
     const int li = lane & 15, kg = lane >> 4;
     const int f = 64 * fg + 16 * wave + li;            // A side: this lane's feature
-    const bool fv = f < in;
     const long s = blockIdx.x;
     const long rbeg = s * rows_per_block, rend = min(N, rbeg + rows_per_block);
-    const float kOut = s_knots[nknots - 1] + 1.0f;
 
-    f32x4 D[kCTmax - 1][4];        // spline coefficients x 4 o-tiles (scaled by 2^(10 + 10 - T))
+    f32x4 D[kCTmax - 1][4];        // spline coefficients x 4 o-tiles (scaled by 2^(20 - T))
     f32x4 Db[4];                   // base weight (plain fp32)
 #pragma unroll
     for (int c = 0; c < kCTmax - 1; ++c)
@@ -330,81 +349,106 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
         for (int t = 0; t < 4; ++t) D[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t) Db[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int T = -1000;                 // running exponent: gy is fed as gy * 2^(10 - T)
 
-    for (long n0 = rbeg; n0 < rend; n0 += 32) {
-        // ---- loads: 8 rows x (1 feature | 4 x 1 output column) per lane
-        float xv[8], g[4][8];
-        float mx = 0.0f;
+    auto load_raw = [&](long n0, DwRaw& r) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            // unconditional loads on clamped addresses.  Rows past the end are neutralised by a 0/1 factor on
+            // gy (every product carries a gy factor); features >= in and outputs >= out only reach slab
+            // entries nobody reads.  (A `cond ? load : const` would put a branch + vmcnt drain on every load.)
             const long n = n0 + 8 * kg + j;
-            const bool nv = n < rend;
-            xv[j] = (nv && fv) ? x[n * ldx + f] : kOut;
+            const long nc = min(n, N - 1);
+            const float live = (n < rend) ? 1.0f : 0.0f;
+            r.x[j] = x[nc * ldx + min(f, in - 1)];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int o = 64 * oc + 16 * t + li;
-                g[t][j] = (nv && o < out) ? gy[n * ldgy + o] : 0.0f;
-                mx = fmaxf(mx, fabsf(g[t][j]));
+                r.g[t][j] = gy[nc * ldgy + min(o, out - 1)] * live;
             }
         }
+    };
+    // wave-uniform exponent of the chunk's largest |gy|
+    auto chunk_exp = [&](const DwRaw& r) -> int {
+        float mx = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(r.g[t][j]));
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        const int ex = exp_for_max(mx);
-        if (ex > T) {                                   // wave-uniform: rescale what was accumulated so far
-            if (T > -1000) {
-                const float dn = ldexpf(1.0f, T - ex);
+        return exp_for_max(mx);
+    };
+    auto make_b = [&](const DwRaw& r, int t, float gs, DwFrag& fr) {
+        float v[8];
 #pragma unroll
-                for (int c = 0; c < kCTmax - 1; ++c)
+        for (int j = 0; j < 8; ++j) v[j] = r.g[t][j] * gs;
+        split_f16x2(v, fr.bhi[t], fr.blo[t]);
+    };
+    auto make_row = [&](const DwRaw& r, int j, DwFrag& fr) {
+        spline_frag<K>(r.x[j], s_knots, s_tbl, geom, fgeo, fr.rh[j], fr.rl[j]);
+    };
+    // SiLU base branch of one chunk straight from the raw values: exact fp32 MFMA, 4 rows per
+    // instruction (k-lane kg <-> row 8*kg + j); rows past the end have gy == 0
+    auto base_row = [&](const DwRaw& r, int j) {
+        const float a = siluf(r.x[j]);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) D[c][t] *= dn;
-            }
-            T = ex;
-        }
+        for (int t = 0; t < 4; ++t) Db[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, r.g[t][j], Db[t], 0, 0, 0);
+    };
+
+    int T = -1000;                 // running exponent: gy is fed as gy * 2^(10 - T)
+    DwRaw r1, r2;
+    DwFrag cur, nxt;
+    load_raw(rbeg, r1);
+    T = chunk_exp(r1);
+    {
         const float gs = ldexpf(1.0f, 10 - T);
-        u32x4 bhi[4], blo[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v[8];
+        for (int t = 0; t < 4; ++t) make_b(r1, t, gs, cur);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = g[t][j] * gs;
-            split_f16x2(v, bhi[t], blo[t]);
-        }
-        // ---- A: bases of 8 rows of one feature, placed per row then transposed to per-coefficient
-        u32x4 rh[8], rl[8];
+        for (int j = 0; j < 8; ++j) { make_row(r1, j, cur); base_row(r1, j); }
+    }
+    load_raw(rbeg + 32, r1);
+
+    for (long n0 = rbeg; n0 < rend; n0 += 32) {
+        load_raw(n0 + 64, r2);                           // two chunks ahead, lands during this iteration
+        const int Tn = max(T, chunk_exp(r1));            // exponent the NEXT chunk's gy is scaled with
+        const float gsn = ldexpf(1.0f, 10 - Tn);
+        // ---- MFMAs of the current chunk, interleaved with the preparation of the next one
 #pragma unroll
-        for (int j = 0; j < 8; ++j) spline_frag<K>(xv[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j]);
-#pragma unroll
-        for (int c = 0; c < kCTmax - 1; ++c) {
-            if (c < C) {
+        for (int c = 0; c < kCTmax - 1; ++c) {              // all 8 slots, no branch: slots >= C are always zero
+            {
                 const int q = c >> 1;
                 const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
                 u32x4 ah, al;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    ah[p] = __builtin_amdgcn_perm(rh[2 * p + 1][q], rh[2 * p][q], sel);
-                    al[p] = __builtin_amdgcn_perm(rl[2 * p + 1][q], rl[2 * p][q], sel);
+                    ah[p] = __builtin_amdgcn_perm(cur.rh[2 * p + 1][q], cur.rh[2 * p][q], sel);
+                    al[p] = __builtin_amdgcn_perm(cur.rl[2 * p + 1][q], cur.rl[2 * p][q], sel);
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    D[c][t] = mfma16_f16(ah, bhi[t], D[c][t]);
-                    D[c][t] = mfma16_f16(ah, blo[t], D[c][t]);
-                    D[c][t] = mfma16_f16(al, bhi[t], D[c][t]);
-                }
+                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(ah, cur.bhi[t], D[c][t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(ah, cur.blo[t], D[c][t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(al, cur.bhi[t], D[c][t]);
             }
+            make_row(r1, c, nxt);                        // independent VALU work: row c of the next chunk
+            base_row(r1, c);                             // ... and its base-branch MFMAs (fp32, unscaled)
+            if (c < 4) make_b(r1, c, gsn, nxt);
         }
-        // ---- SiLU base branch: exact fp32 MFMA, 4 rows per instruction (k-lane kg <-> row 8*kg + j)
+        if (Tn > T) {                                    // wave-uniform: rescale what was accumulated so far
+            const float dn = ldexpf(1.0f, T - Tn);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long n = n0 + 8 * kg + j;
-            const float a = (n < rend && fv) ? siluf(xv[j]) : 0.0f;
+            for (int c = 0; c < kCTmax - 1; ++c)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                Db[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, g[t][j], Db[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) D[c][t] *= dn;
+            T = Tn;
         }
+        cur = nxt;
+        r1 = r2;
     }
     // ---- slab write: D rows <-> features 4*kg + reg, cols <-> outputs li
-    const float undo = (T > -1000) ? ldexpf(1.0f, T - 20) : 0.0f;
+    const float undo = ldexpf(1.0f, T - 20);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const long o = 64 * oc + 16 * t + li;
