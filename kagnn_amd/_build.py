@@ -36,7 +36,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "kagnn_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(PKG), "include", "kagnn_hip.h"))
 
     def compile_one(src):
         s = os.path.join(CSRC, src)

@@ -50,6 +50,8 @@ static int check_kan_dims(const char* fn, int in, int out, int G, int K, int mod
     return KAGNN_OK;
 }
 // the split path covers the hot shapes; everything else runs the exact-fp32 kernels (still HIP)
+// the split kernels address activations through buffer descriptors with 32-bit byte offsets
+static bool fits32(long N, long ld) { return (N + (1L << 18)) * ld * 4 < 0xF0000000L; }
 static bool use_split_fwd(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_fwd_ok(in, out, G, K); }
 static bool use_split_dx(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_dx_ok(in, out, G, K); }
 static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_dw_ok(in, out, G, K); }
@@ -158,8 +160,10 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* kn
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldy >= out, "bad shape");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && knots && pack_fwd && y, "null array");
-    if (use_split_fwd(in, out, G, K, mode))
+    if (use_split_fwd(in, out, G, K, mode)) {
+        if (!(fits32(N, ldx) && fits32(N, ldy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
         return kan_split_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, as_stream(stream));
+    }
     return kan_f32_fwd(x, ldx, N, knots, in, out, G, K, (const float*)pack_fwd, y, ldy, as_stream(stream));
 }
 
@@ -171,8 +175,10 @@ int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && gy && knots && pack_dx && gx, "null array");
-    if (use_split_dx(in, out, G, K, mode))
+    if (use_split_dx(in, out, G, K, mode)) {
+        if (!(fits32(N, ldx) && fits32(N, ldgy) && fits32(N, ldgx))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
         return kan_split_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack_dx, gx, ldgx, as_stream(stream));
+    }
     return kan_f32_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, (const float*)pack_dx, gx, ldgx, as_stream(stream));
 }
 
@@ -196,8 +202,10 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
     KAGNN_CHECK_ARG(knots && sw && g_bw && g_sw && ws, "null array");
     KAGNN_CHECK_ARG(N == 0 || (x && gy), "null array");
     KAGNN_CHECK_ARG((sc == nullptr) == (g_sc == nullptr), "spline_scaler and its gradient must both be given or both be null");
-    if (use_split_dw(in, out, G, K, mode))
+    if (use_split_dw(in, out, G, K, mode)) {
+        if (!(fits32(N, ldx) && fits32(N, ldgy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
         return kan_split_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream));
+    }
     return kan_f32_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream));
 }
 

@@ -107,61 +107,60 @@ __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float*
 }
 
 // ------------------------------------------------------------------ forward
-template <int K, int OT>
-__global__ __launch_bounds__(512) void kan_split_fwd_kernel(
+// Workgroup = 1024 threads = 16 waves (4 per SIMD, <= 128 VGPRs each) so that LDS / VALU latencies of
+// one wave hide under the other three; one wave = 32 rows.  x is consumed in groups of 8 features per
+// lane (two float4), the next group is prefetched while the current one is expanded.
+template <int K, int OT, int NT>
+__global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g,
     int nknots, const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy,
     int out) {
     constexpr int CF = (OT <= 2) ? 64 : 32, HF = CF / 2, SPC = CF / 2, BPC = CF / 16;
     constexpr int CHUNK_BYTES = SPC * OT * 2 * 1024 + BPC * OT * 3 * 1024;
+    constexpr int NG = HF / 8;                       // groups of 8 features per lane-half and chunk
+    constexpr int ROWS = (NT / 64) * 32;             // rows per workgroup iteration
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* s_knots = reinterpret_cast<float*>(smem);
     unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
     unsigned char* s_w = smem + kLdsHdr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < nknots) s_knots[tid] = knots_g[tid];
-    build_perm_table(s_tbl, tid);
+    if (K == 3) build_perm_table3(s_tbl, tid, nknots); else build_perm_table(s_tbl, tid);
     const float post = reinterpret_cast<const float*>(pack)[0];
     const unsigned char* gw = pack + kHdrBytes;
     auto stage_chunk = [&](int ch) {
         const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)ch * CHUNK_BYTES);
         uint4* dst = reinterpret_cast<uint4*>(s_w);
-        for (int i = tid; i < CHUNK_BYTES / 16; i += 512) dst[i] = src[i];
+        for (int i = tid; i < CHUNK_BYTES / 16; i += NT) dst[i] = src[i];
     };
     if (nchunks == 1) stage_chunk(0);
     __syncthreads();
     const SplineGeom geom = geom_from_knots(s_knots, nknots);
-    const FastGeom fgeo = fast_geom(s_knots, nknots);
+    const Frag3Geom f3geo = frag3_geom(s_knots, nknots);
     const int r = lane & 31, kg = lane >> 5;
     const bool al4 = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 
-    // this lane's HF consecutive features of chunk `ch` of the tile starting at row0t.  Loads are
-    // unconditional on clamped addresses and never masked (a per-lane `cond ? load : const` makes hipcc
-    // branch around every load): rows >= N are never stored, features >= in meet zero weights in the pack.
-    auto load_x = [&](long row0t, int ch, float (&xv)[HF]) {
-        const long row = row0t + r;
-        const bool rv = row < N;
-        // unconditional loads on clamped addresses, masked afterwards (no per-lane branch around a load)
-        const float* xr = x + (rv ? row : N - 1) * ldx;
-        const int f0 = ch * CF + kg * HF;
+    // 8 consecutive features (group g of chunk ch) of this lane's row.  Unconditional loads on clamped
+    // addresses, never masked (a per-lane `cond ? load : const` makes hipcc branch around every load):
+    // rows >= N are never stored, features >= in meet zero weights in the pack.
+    const GBuf xb = gbuf(x, N, ldx, in), yb = gbuf(y, N, ldy, out);
+    const unsigned ldx4 = (unsigned)ldx * 4u, ldy4 = (unsigned)ldy * 4u;
+    auto load8 = [&](long row0t, int ch, int g, float (&v)[8]) {
+        const unsigned ro = (unsigned)(row0t + r) * ldx4;   // rows >= N: past the descriptor -> zeros
+        const int f0 = ch * CF + kg * HF + 8 * g;
         if (al4 && ch * CF + CF <= in) {                  // wave-uniform
-#pragma unroll
-            for (int j = 0; j < HF; j += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(xr + f0 + j);
-                xv[j] = v.x; xv[j + 1] = v.y; xv[j + 2] = v.z; xv[j + 3] = v.w;
-            }
+            gld4(xb, ro + f0 * 4, v);
+            gld4(xb, ro + f0 * 4 + 16, v + 4);
         } else {
 #pragma unroll
-            for (int j = 0; j < HF; ++j) xv[j] = xr[min(f0 + j, in - 1)];
+            for (int j = 0; j < 8; ++j) v[j] = gld(xb, ro + min(f0 + j, in - 1) * 4);
         }
     };
-    float xnext[HF];
-    if (nchunks == 1) load_x((long)blockIdx.x * 256 + wave * 32, 0, xnext);
 
-    for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
-        const long row0 = tile * 256 + wave * 32;
-        const long row = row0 + r;
-        const bool rv = row < N;
+    float xn[8];
+    load8((long)blockIdx.x * ROWS + wave * 32, 0, 0, xn);
+    for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
+        const long row0 = tile * ROWS + wave * 32;
         f32x16 acc[OT];
 #pragma unroll
         for (int t = 0; t < OT; ++t)
@@ -174,62 +173,126 @@ __global__ __launch_bounds__(512) void kan_split_fwd_kernel(
                 stage_chunk(ch);
                 __syncthreads();
             }
-            const int f0 = ch * CF + kg * HF;
-            float xv[HF];
-            if (nchunks == 1) {
 #pragma unroll
-                for (int j = 0; j < HF; ++j) xv[j] = xnext[j];
-                load_x((tile + gridDim.x) * 256 + wave * 32, 0, xnext);     // next tile's rows, in flight during this one
-            } else {
-                load_x(row0, ch, xv);
-            }
-            // ---- spline part: one MFMA step per feature
+            for (int g = 0; g < NG; ++g) {
+                float xv[8];
 #pragma unroll
-            for (int s = 0; s < SPC; ++s) {
-                u32x4 ahi, alo;
-                spline_frag<K>(xv[s], s_knots, s_tbl, geom, fgeo, ahi, alo);
-                const unsigned char* wp = s_w + (size_t)(s * OT) * 2 * 1024 + lane * 16;
+                for (int j = 0; j < 8; ++j) xv[j] = xn[j];
+                // prefetch the next group: same chunk, next chunk, or the first group of this wave's next tile
+                if (g + 1 < NG) load8(row0, ch, g + 1, xn);
+                else if (ch + 1 < nchunks) load8(row0, ch + 1, 0, xn);
+                else load8(row0 + (long)gridDim.x * ROWS, 0, 0, xn);
+
+                if constexpr (K == 3) {
+                    // ---- software pipeline inside the group: while the 6*OT/2 MFMAs of feature j execute, the
+                    // VALU expands feature j+1 (or prepares the SiLU fragments after the last feature) and the
+                    // LDS reads of its weights / selectors are already in flight.
+                    u32x4 ahi, alo, bw[2 * OT];
+                    {
+                        float u; unsigned off, h0, h1, l0, l1;
+                        frag3_index<false>(xv[0], f3geo, u, off);
+                        const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + off);
+                        const unsigned char* wp = s_w + (size_t)((8 * g) * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
-                for (int t = 0; t < OT; ++t) {
-                    const u32x4 bhi = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 0) * 1024);
-                    const u32x4 blo = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 1) * 1024);
-                    acc[t] = mfma_f16(ahi, bhi, acc[t]);
-                    acc[t] = mfma_f16(ahi, blo, acc[t]);
-                    acc[t] = mfma_f16(alo, bhi, acc[t]);
-                }
-            }
-            // ---- SiLU base branch: 8 features per lane per step, 3-way bf16 split
+                        for (int i = 0; i < 2 * OT; ++i) bw[i] = *reinterpret_cast<const u32x4*>(wp + i * 1024);
+                        frag3_payload(u, h0, h1, l0, l1);
+                        frag3_place(sel, h0, h1, l0, l1, ahi, alo);
+                    }
+                    u32x4 a1, a2, a3;                      // SiLU fragments, prepared under the last feature's MFMAs
 #pragma unroll
-            for (int sb = 0; sb < BPC; ++sb) {
-                float sv[8];
+                    for (int j = 0; j < 8; ++j) {
+                        u32x4 nhi, nlo, nbw[2 * OT], sel;
+                        float u; unsigned h0, h1, l0, l1;
+                        if (j < 7) {                      // issue the next feature's LDS reads first
+                            unsigned off;
+                            frag3_index<false>(xv[j + 1], f3geo, u, off);
+                            sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + off);
+                            const unsigned char* wp = s_w + (size_t)((8 * g + j + 1) * OT) * 2 * 1024 + lane * 16;
+#pragma unroll
+                            for (int i = 0; i < 2 * OT; ++i) nbw[i] = *reinterpret_cast<const u32x4*>(wp + i * 1024);
+                        }
+#pragma unroll
+                        for (int t = 0; t < OT; ++t) acc[t] = mfma_f16(ahi, bw[2 * t], acc[t]);
+#pragma unroll
+                        for (int t = 0; t < OT; ++t) acc[t] = mfma_f16(ahi, bw[2 * t + 1], acc[t]);
+#pragma unroll
+                        for (int t = 0; t < OT; ++t) acc[t] = mfma_f16(alo, bw[2 * t], acc[t]);
+                        if (j < 7) {
+                            frag3_payload(u, h0, h1, l0, l1);
+                            frag3_place(sel, h0, h1, l0, l1, nhi, nlo);
+                            ahi = nhi; alo = nlo;
+#pragma unroll
+                            for (int i = 0; i < 2 * OT; ++i) bw[i] = nbw[i];
+                        } else {
+                            float sv[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) sv[i] = (siluf(xv[i]) + (xv[i] - xv[i])) * kAScale;   // +-Inf -> NaN like the reference
+                            split_bf16x3(sv, a1, a2, a3);
+                        }
+                    }
+                    {
+                        const unsigned char* wp = s_w + (size_t)SPC * OT * 2 * 1024 + (size_t)(g * OT) * 3 * 1024 + lane * 16;
+#pragma unroll
+                        for (int t = 0; t < OT; ++t) {
+                            const u32x4 w1 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 0) * 1024);
+                            const u32x4 w2 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 1) * 1024);
+                            const u32x4 w3 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 2) * 1024);
+                            acc[t] = mfma_bf16(a3, w1, acc[t]);
+                            acc[t] = mfma_bf16(a2, w2, acc[t]);
+                            acc[t] = mfma_bf16(a1, w3, acc[t]);
+                            acc[t] = mfma_bf16(a2, w1, acc[t]);
+                            acc[t] = mfma_bf16(a1, w2, acc[t]);
+                            acc[t] = mfma_bf16(a1, w1, acc[t]);
+                        }
+                    }
+                } else {
+                // ---- generic orders (K = 1, 2): one MFMA step per feature, exact knot comparisons
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    sv[j] = siluf(xv[8 * sb + j]) * kAScale;
-                }
-                u32x4 a1, a2, a3;
-                split_bf16x3(sv, a1, a2, a3);
-                const unsigned char* wp = s_w + (size_t)SPC * OT * 2 * 1024 + (size_t)(sb * OT) * 3 * 1024 + lane * 16;
+                    const int s = 8 * g + j;
+                    u32x4 ahi, alo;
+                    make_spline_frag<K>(xv[j], s_knots, s_tbl, geom, ahi, alo);
+                    const unsigned char* wp = s_w + (size_t)(s * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
-                for (int t = 0; t < OT; ++t) {
-                    const u32x4 w1 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 0) * 1024);
-                    const u32x4 w2 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 1) * 1024);
-                    const u32x4 w3 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 2) * 1024);
-                    acc[t] = mfma_bf16(a3, w1, acc[t]);
-                    acc[t] = mfma_bf16(a2, w2, acc[t]);
-                    acc[t] = mfma_bf16(a1, w3, acc[t]);
-                    acc[t] = mfma_bf16(a2, w1, acc[t]);
-                    acc[t] = mfma_bf16(a1, w2, acc[t]);
-                    acc[t] = mfma_bf16(a1, w1, acc[t]);
+                    for (int t = 0; t < OT; ++t) {
+                        const u32x4 bhi = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 0) * 1024);
+                        const u32x4 blo = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 1) * 1024);
+                        acc[t] = mfma_f16(ahi, bhi, acc[t]);
+                        acc[t] = mfma_f16(ahi, blo, acc[t]);
+                        acc[t] = mfma_f16(alo, bhi, acc[t]);
+                    }
+                }
+                {
+                    float sv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sv[j] = (siluf(xv[j]) + (xv[j] - xv[j])) * kAScale;
+                    u32x4 a1, a2, a3;
+                    split_bf16x3(sv, a1, a2, a3);
+                    const unsigned char* wp = s_w + (size_t)SPC * OT * 2 * 1024 + (size_t)(g * OT) * 3 * 1024 + lane * 16;
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) {
+                        const u32x4 w1 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 0) * 1024);
+                        const u32x4 w2 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 1) * 1024);
+                        const u32x4 w3 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 2) * 1024);
+                        acc[t] = mfma_bf16(a3, w1, acc[t]);
+                        acc[t] = mfma_bf16(a2, w2, acc[t]);
+                        acc[t] = mfma_bf16(a1, w3, acc[t]);
+                        acc[t] = mfma_bf16(a2, w1, acc[t]);
+                        acc[t] = mfma_bf16(a1, w2, acc[t]);
+                        acc[t] = mfma_bf16(a1, w1, acc[t]);
+                    }
+                }
                 }
             }
         }
 #pragma unroll
         for (int t = 0; t < OT; ++t) {
             const int col = 32 * t + r;
+            const unsigned base = (unsigned)(row0 + 4 * kg) * ldy4 + col * 4;
+            if (col < out) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const long rr = row0 + mfma32_row(i, kg);
-                if (rr < N && col < out) y[rr * ldy + col] = acc[t][i] * post;
+                for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped
+                    gst(yb, base + (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, acc[t][i] * post);
             }
         }
     }
@@ -259,15 +322,16 @@ int kan_split_pack_fwd(const float* bw, const float* sw, const float* sc, int in
 template <int K, int OT>
 static int launch_fwd(const float* x, long ldx, long N, int in, const float* knots, int nknots,
                       const unsigned char* pack, int nchunks, float* y, long ldy, int out, hipStream_t st) {
+    constexpr int NT = (OT <= 2) ? 1024 : 512;       // 4 waves per SIMD when the accumulators leave room (<= 128 VGPRs)
     const size_t lds = kLdsHdr + split_fwd_chunk_bytes(OT);
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT>,
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT, NT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    const int grid = (int)min((long)cdiv(N, 256), 256L);
-    kan_split_fwd_kernel<K, OT><<<grid, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out);
+    const int grid = (int)min((long)cdiv(N, NT / 2), 256L);
+    kan_split_fwd_kernel<K, OT, NT><<<grid, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }

@@ -133,6 +133,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const FastGeom fgeo = fast_geom(s_knots, nknots);
     const int li = lane & 15, kg = lane >> 4;
     const bool al4 = ((ldgy & 3) == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+    const GBuf xb = gbuf(x, N, ldx, in), gyb = gbuf(gy, N, ldgy, out), gxb = gbuf(gx, N, ldgx, in);
+    const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u, ldgx4 = (unsigned)ldgx * 4u;
 
     for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
         const long row0 = tile * 256 + wave * 32;
@@ -141,25 +143,20 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
         float rinv[2][4];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            const long row = row0 + 16 * rt + li;
-            const bool rv = row < N;
-            // loads are UNCONDITIONAL on clamped addresses and never masked: a per-lane `cond ? load : const`
-            // makes hipcc branch around every load and drain vmcnt each time.  Rows >= N are computed on a
-            // duplicate of the last row and never stored; columns >= out meet zero weights in the pack.
-            const float* gr = gy + (rv ? row : N - 1) * ldgy;
+            // buffer loads with 32-bit offsets: rows >= N read as 0 (never stored anyway); columns >= out are
+            // clamped to the row's last value and meet zero weights in the pack
+            const unsigned ro = (unsigned)(row0 + 16 * rt + li) * ldgy4;
             float raw[Q2][8];
             float mx = 0.0f;
 #pragma unroll
             for (int q = 0; q < Q2; ++q) {
                 const int o0 = 32 * q + 8 * kg;
                 if (al4 && 32 * Q2 == out) {              // wave-uniform
-                    const float4 a = *reinterpret_cast<const float4*>(gr + o0);
-                    const float4 b = *reinterpret_cast<const float4*>(gr + o0 + 4);
-                    raw[q][0] = a.x; raw[q][1] = a.y; raw[q][2] = a.z; raw[q][3] = a.w;
-                    raw[q][4] = b.x; raw[q][5] = b.y; raw[q][6] = b.z; raw[q][7] = b.w;
+                    gld4(gyb, ro + o0 * 4, raw[q]);
+                    gld4(gyb, ro + o0 * 4 + 16, raw[q] + 4);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) raw[q][j] = gr[min(o0 + j, out - 1)];
+                    for (int j = 0; j < 8; ++j) raw[q][j] = gld(gyb, ro + min(o0 + j, out - 1) * 4);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(raw[q][j]));
@@ -195,7 +192,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const long rr = row0 + 16 * rt + 4 * kg + reg;
-                    xq[rt][reg] = x[min(rr, N - 1) * ldx + min(f, in - 1)];        // unconditional, clamped; unused lanes never store
+                    xq[rt][reg] = gld(xb, (unsigned)rr * ldx4 + min(f, in - 1) * 4);   // rows >= N -> 0, never stored
                 }
             f32x4 D[kCTmax][2];
 #pragma unroll
@@ -220,7 +217,6 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const long rr = row0 + 16 * rt + 4 * kg + reg;
-                    const bool ok = rr < N && f < in;
                     const float xv = xq[rt][reg];
                     float dN[K + 1];
                     int m;
@@ -239,7 +235,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
 #pragma unroll
                     for (int c = 0; c < kCTmax; ++c) db = (c == C) ? D[c][rt][reg] : db;
                     const float s = fmaf(db, silu_gradf(xv), barrel_dot<K>(d, m, dN));
-                    if (ok) gx[rr * ldgx + f] = s * rinv[rt][reg];
+                    if (f < in) gst(gxb, (unsigned)rr * ldgx4 + f * 4, s * rinv[rt][reg]);   // rows >= N: dropped by the descriptor
                 }
             }
         }
@@ -350,21 +346,22 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t) Db[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const GBuf xb = gbuf(x, N, ldx, in), gyb = gbuf(gy, N, ldgy, out);
+    const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u;
+    const unsigned fo = (unsigned)min(f, in - 1) * 4u;
+    unsigned go[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) go[t] = (unsigned)min(64 * oc + 16 * t + li, out - 1) * 4u;
     auto load_raw = [&](long n0, DwRaw& r) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            // unconditional loads on clamped addresses.  Rows past the end are neutralised by a 0/1 factor on
-            // gy (every product carries a gy factor); features >= in and outputs >= out only reach slab
-            // entries nobody reads.  (A `cond ? load : const` would put a branch + vmcnt drain on every load.)
-            const long n = n0 + 8 * kg + j;
-            const long nc = min(n, N - 1);
-            const float live = (n < rend) ? 1.0f : 0.0f;
-            r.x[j] = x[nc * ldx + min(f, in - 1)];
+            // unconditional buffer loads, 32-bit offsets.  Rows >= N read as 0 through the descriptor; the chunk
+            // prefetched past this block's range is never multiplied (spline) or is masked (base, `live`);
+            // features >= in / outputs >= out are clamped and only reach slab entries nobody reads.
+            const unsigned n = (unsigned)(n0 + 8 * kg + j);
+            r.x[j] = gld(xb, n * ldx4 + fo);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int o = 64 * oc + 16 * t + li;
-                r.g[t][j] = gy[nc * ldgy + min(o, out - 1)] * live;
-            }
+            for (int t = 0; t < 4; ++t) r.g[t][j] = gld(gyb, n * ldgy4 + go[t]);
         }
     };
     // wave-uniform exponent of the chunk's largest |gy|
@@ -389,8 +386,8 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     };
     // SiLU base branch of one chunk straight from the raw values: exact fp32 MFMA, 4 rows per
     // instruction (k-lane kg <-> row 8*kg + j); rows past the end have gy == 0
-    auto base_row = [&](const DwRaw& r, int j) {
-        const float a = siluf(r.x[j]);
+    auto base_row = [&](const DwRaw& r, int j, float live) {
+        const float a = siluf(r.x[j]) * live;
 #pragma unroll
         for (int t = 0; t < 4; ++t) Db[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, r.g[t][j], Db[t], 0, 0, 0);
     };
@@ -405,12 +402,13 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) make_b(r1, t, gs, cur);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { make_row(r1, j, cur); base_row(r1, j); }
+        for (int j = 0; j < 8; ++j) { make_row(r1, j, cur); base_row(r1, j, 1.0f); }
     }
     load_raw(rbeg + 32, r1);
 
     for (long n0 = rbeg; n0 < rend; n0 += 32) {
         load_raw(n0 + 64, r2);                           // two chunks ahead, lands during this iteration
+        const float live_next = (n0 + 32 < rend) ? 1.0f : 0.0f;   // the next chunk may belong to another workgroup
         const int Tn = max(T, chunk_exp(r1));            // exponent the NEXT chunk's gy is scaled with
         const float gsn = ldexpf(1.0f, 10 - Tn);
         // ---- MFMAs of the current chunk, interleaved with the preparation of the next one
@@ -433,7 +431,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
                 for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(al, cur.bhi[t], D[c][t]);
             }
             make_row(r1, c, nxt);                        // independent VALU work: row c of the next chunk
-            base_row(r1, c);                             // ... and its base-branch MFMAs (fp32, unscaled)
+            base_row(r1, c, live_next);                  // ... and its base-branch MFMAs (fp32, unscaled)
             if (c < 4) make_b(r1, c, gsn, nxt);
         }
         if (Tn > T) {                                    // wave-uniform: rescale what was accumulated so far

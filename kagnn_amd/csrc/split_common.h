@@ -18,6 +18,30 @@ __device__ __forceinline__ float wcat_s(const float* bw, const float* sw, const 
     return sc ? w * sc[(long)o * in + f] : w;
 }
 
+// ---- global memory through buffer descriptors: 32-bit byte offsets (no 64-bit VALU address math) and
+// hardware bounds checking -- a load past `bytes` returns 0, a store past it is dropped, so rows >= N
+// need neither clamping nor predication.  The host side only takes this path when the tensor (plus the
+// prefetch margin) spans < 4 GiB.
+struct GBuf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ GBuf gbuf(const void* p, long rows, long ld, int width) {
+    const long bytes = rows > 0 ? ((rows - 1) * ld + width) * 4 : 0;
+    GBuf b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (unsigned)bytes, 0x00020000);
+    return b;
+}
+__device__ __forceinline__ float gld(const GBuf& b, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, off, 0, 0));
+}
+__device__ __forceinline__ void gld4(const GBuf& b, unsigned off, float* v) {
+    // NB: __builtin_bit_cast(float, t[i]) on the vector elements silently reads element 0 for every i
+    // (hipcc 7.2); go through the named components instead.
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 0);
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+}
+__device__ __forceinline__ void gst(const GBuf& b, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, off, 0, 0);
+}
+
 // exponent e with max|W| * 2^-e in [2^9, 2^10)
 __device__ __forceinline__ int scale_exp_from_max(float m) {
     if (!(m > 0.0f)) return 0;
@@ -91,11 +115,11 @@ __device__ __forceinline__ void fast_span(float x, const FastGeom& g, int& m, fl
 }
 // cubic pieces times w6 (= scale/6 inside the support, 0 outside): N[r] = B_{m-3+r}(x) * scale
 __device__ __forceinline__ void cubic_bases(float u, float w6, float (&N)[4]) {
-    const float u2 = u * u, u3 = u2 * u, om = 1.0f - u;
-    N[0] = om * om * om * w6;
-    N[3] = u3 * w6;
-    N[1] = fmaf(u3, 3.0f, fmaf(u2, -6.0f, 4.0f)) * w6;
-    N[2] = fmaf(fmaf(fmaf(u, -3.0f, 3.0f), u, 3.0f), u, 1.0f) * w6;
+    const float u2 = u * u, om = 1.0f - u, uw = u * w6, ow = om * w6;
+    N[0] = ow * (om * om);
+    N[3] = uw * u2;
+    N[1] = fmaf(uw, fmaf(u, 3.0f, -6.0f) * u, 4.0f * w6);              // (3u^3 - 6u^2 + 4) w6
+    N[2] = fmaf(uw, fmaf(fmaf(u, -3.0f, 3.0f), u, 3.0f), w6);          // (-3u^3 + 3u^2 + 3u + 1) w6
 }
 // d/dx of the same pieces times wd (= inv_h/2 inside, 0 outside)
 __device__ __forceinline__ void cubic_dbases(float u, float wd, float (&dN)[4]) {
@@ -139,6 +163,66 @@ __device__ __forceinline__ void make_spline_frag3(float x, const unsigned* __res
     const unsigned l0 = pk_f16_rtz(N[0] - f16lo_to_f32(h0), N[1] - f16hi_to_f32(h0));
     const unsigned l1 = pk_f16_rtz(N[2] - f16lo_to_f32(h1), N[3] - f16hi_to_f32(h1));
     const u32x4 sel = *reinterpret_cast<const u32x4*>(tbl + 4 * (m + 1));     // m - 3 + 4, m in [0, 14]
+    ahi[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
+    ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
+    alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);
+    alo[2] = __builtin_amdgcn_perm(l1, l0, sel[2]); alo[3] = __builtin_amdgcn_perm(l1, l0, sel[3]);
+}
+
+// ---- the same K == 3 expansion in three pieces, so a caller can software-pipeline it under MFMAs:
+//   frag3_index   : table index of the span (needs only t)           -> issue the LDS table read early
+//   frag3_payload : cubic pieces, fp16 hi/lo payloads (pure VALU)     -> overlaps the MFMAs in flight
+//   frag3_place   : 8 x v_perm_b32 with the selectors read from LDS
+// Span / support handling is folded into the table: idx = floor(t) + 1 clamped to [0, 15]; entries
+// outside [1, nspans] hold all-zero selectors (x outside [knots[0], knots[last]) -> all bases 0; at the
+// two boundary knots every existing basis is 0 anyway, so an ulp of disagreement with the reference's
+// half-open test is harmless).  NaN -> idx 1 with NaN payload -> NaN, +-Inf -> Inf*0 = NaN payload
+// guarded below.
+struct Frag3Geom { float inv_h, c1; };            // t' = x*inv_h + c1  with c1 = 1 - knots[0]*inv_h
+__device__ __forceinline__ Frag3Geom frag3_geom(const float* knots, int nknots) {
+    Frag3Geom g;
+    g.inv_h = (float)(nknots - 1) / (knots[nknots - 1] - knots[0]);
+    g.c1 = 1.0f - knots[0] * g.inv_h;
+    return g;
+}
+// table with support folded in: entry i (1 <= i <= nspans) = shift (i-1) - 3; everything else zero
+__device__ __forceinline__ void build_perm_table3(unsigned* tbl /* LDS, 16*4 */, int tid, int nknots) {
+    if (tid < 64) {
+        const int t = tid >> 2, q = tid & 3, sh = t - 4;
+        unsigned sel = 0;
+        for (int hh = 0; hh < 2; ++hh) {
+            const int r = 2 * q + hh - sh;
+            const bool live = (t >= 1) && (t <= nknots - 1) && (r >= 0) && (r <= 3);
+            const unsigned b = live ? (unsigned)((2 * r) | ((2 * r + 1) << 8)) : 0x0c0cu;
+            sel |= b << (16 * hh);
+        }
+        tbl[tid] = sel;
+    }
+}
+// NANSAFE: non-finite x selects a live table entry and a NaN payload (the reference's bases are NaN
+// there).  The forward kernel does not need it: its SiLU branch already turns such rows into NaN.
+template <bool NANSAFE>
+__device__ __forceinline__ void frag3_index(float x, const Frag3Geom& g, float& u, unsigned& byte_off) {
+    const float t = fmaf(x, g.inv_h, g.c1);
+    u = __builtin_amdgcn_fractf(t);
+    const int i = (int)floorf(t);                  // v_cvt_flr_i32_f32; NaN -> 0
+    byte_off = min((unsigned)i, 15u) << 4;         // negative -> huge unsigned -> 15 (a zero entry)
+    if (NANSAFE) {
+        const bool fin = fabsf(x) < __builtin_inff();
+        byte_off = fin ? byte_off : 16u;
+        u = fin ? u : __builtin_nanf("");
+    }
+}
+__device__ __forceinline__ void frag3_payload(float u, unsigned& h0, unsigned& h1, unsigned& l0,
+                                              unsigned& l1) {
+    float N[4];
+    cubic_bases(u, kAScale / 6.0f, N);
+    h0 = pk_f16_rtz(N[0], N[1]); h1 = pk_f16_rtz(N[2], N[3]);
+    l0 = pk_f16_rtz(N[0] - f16lo_to_f32(h0), N[1] - f16hi_to_f32(h0));
+    l1 = pk_f16_rtz(N[2] - f16lo_to_f32(h1), N[3] - f16hi_to_f32(h1));
+}
+__device__ __forceinline__ void frag3_place(const u32x4& sel, unsigned h0, unsigned h1, unsigned l0,
+                                            unsigned l1, u32x4& ahi, u32x4& alo) {
     ahi[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
     ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
     alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);

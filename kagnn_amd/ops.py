@@ -352,6 +352,8 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
     ``knots`` is ONE row of the layer's grid buffer (uniform), fp32 [G+2k+1] on the device."""
     if mode is None:
         mode = default_precision()
+    if mode == PREC_SPLIT and (x.size(0) + (1 << 18)) * max(x.stride(0), base_weight.size(0), 1) * 4 >= 0xF0000000:
+        mode = PREC_FP32      # the split kernels use 32-bit buffer offsets; >= 3.75 GiB activations go fp32
     return _KANLinearFn.apply(x, base_weight, spline_weight, spline_scaler, knots, int(grid_size),
                               int(spline_order), int(mode))
 
