@@ -47,26 +47,29 @@ def kan_flops(n, fin, fout, c):
 
 def cpu_baseline(n_sample, e_sample, f, grid, order, seed=0):
     """The reference's algorithm (oracle/kan_oracle.py: dense bases, F.linear, index_select +
-    scatter_add_, stock autograd) on the host cores, bounded sample of the same workload."""
+    scatter_add_, stock autograd) on the host cores, bounded sample of the same workload.  torch's CPU
+    elementwise kernels stop scaling (and then regress badly) beyond a few dozen threads, so a few thread
+    counts are tried and the best one is reported -- `cores` is the thread count actually used."""
     from oracle import kan_oracle as orc
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     ei = orc.powerlaw_graph(n_sample, e_sample, seed=seed)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n_sample, f, generator=g) * 0.25
     layers = [orc.init_kan_linear(f, f, grid, order, g) for _ in range(2)]
-    best = float("inf")
-    for it in range(3):
+    host = os.cpu_count() or 1
+    best, best_threads, tried = float("inf"), 1, []
+    for th in sorted({min(8, host), min(32, host)}):
+        torch.set_num_threads(th)
+        if not tried:
+            orc.kan_gin_layer_fwd_bwd(x, ei, layers, order)          # warm-up (allocator, thread pool)
         t0 = time.perf_counter()
         orc.kan_gin_layer_fwd_bwd(x, ei, layers, order)
         dt = time.perf_counter() - t0
-        if it > 0:
-            best = min(best, dt)
-        if dt > 25.0 and it > 0:
-            break
-    return {"value": e_sample / best, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": f"same recipe at N={n_sample}, E={e_sample}, F={f}, grid={grid}, order={order}: "
-                      f"1 warm-up + best of <=2, {best:.2f} s per fwd+bwd"}
+        tried.append((th, round(dt, 2)))
+        if dt < best:
+            best, best_threads = dt, th
+    return {"value": e_sample / best, "unit": "edges/s", "cores": best_threads, "kind": "port",
+            "sample": f"same recipe at N={n_sample}, E={e_sample}, F={f}, grid={grid}, order={order}; 1 warm-up, then one "
+                      f"timed fwd+bwd per thread count {tried} (threads, s) on a {host}-thread host; best reported"}
 
 
 def main():
@@ -81,7 +84,7 @@ def main():
     ap.add_argument("--order", type=int, default=3)
     ap.add_argument("--precision", default=os.environ.get("KAGNN_PRECISION", "split"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=200_000, help="nodes in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=100_000, help="nodes in the CPU-baseline sample")
     args = ap.parse_args()
     os.environ["KAGNN_PRECISION"] = args.precision
 

@@ -1,0 +1,121 @@
+"""Graph-level KAN-GNN models with the reference's class surface (mini-batches of many small graphs).
+
+Mirrors ``graph_classification/models.py`` (``KAGIN`` :95-119, ``FASTKAGIN`` :125-151) and
+``graph_regression/models.py`` (``KAGIN`` :86-119 with GINE messages and node/edge encoders): same
+constructor arguments, attribute names (``conv``, ``bn``, ``kan``, ``atom_encoder``, ``bond_encoder``)
+and state_dict keys (``conv.{i}.eps``, ``conv.{i}.nn.layers.{j}.*``, ``bn.{i}.*``, ``kan.layers.{j}.*``).
+``forward(data)`` takes anything with ``x, edge_index, batch`` (and ``edge_attr`` for the regression
+model) -- e.g. a torch_geometric ``Batch`` -- and runs message passing + pooling on the HIP kernels:
+the whole mini-batch is one CSR (the disjoint union torch_geometric's DataLoader already builds), the
+read-out is a segmented sum over the sorted ``batch`` vector (``kagnn_segment_pool``).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .models import GIFASTKANLayer, GIKANLayer, make_fastkan, make_kan
+
+
+def _num_graphs(data) -> int:
+    n = getattr(data, "num_graphs", None)
+    return int(n) if n is not None else int(data.batch.max()) + 1
+
+
+class _GraphLevel(nn.Module):
+    def _message_passing(self, x, g, edge_attr=None):
+        for conv, bn in zip(self.conv, self.bn):
+            x = conv(x, g) if edge_attr is None else conv(x, g, edge_attr)
+            x = self.dropout(bn(x))
+        return x
+
+    def _pool(self, x, data):
+        return ops.segment_pool(x, ops.segment_ptr(data.batch, _num_graphs(data)))
+
+
+class KAGIN(_GraphLevel):
+    """graph classification: GIN(KAN) stack -> global_add_pool -> KAN read-out -> log_softmax."""
+
+    def __init__(self, gnn_layers, num_features, hidden_dim, num_classes, hidden_layers, grid_size,
+                 spline_order, dropout):
+        super().__init__()
+        self.n_layers = gnn_layers
+        self.conv = nn.ModuleList(
+            GIKANLayer(num_features if i == 0 else hidden_dim, hidden_dim, grid_size, spline_order, hidden_dim,
+                       hidden_layers) for i in range(gnn_layers))
+        self.bn = nn.ModuleList(nn.BatchNorm1d(hidden_dim) for _ in range(gnn_layers))
+        self.kan = make_kan(hidden_dim, hidden_dim, num_classes, hidden_layers, grid_size, spline_order)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, data):
+        g = ops.graph_index(data.edge_index, data.x.size(0))
+        x = self._message_passing(data.x, g)
+        return F.log_softmax(self.kan(self._pool(x, data)), dim=1)
+
+
+class FASTKAGIN(_GraphLevel):
+    def __init__(self, gnn_layers, num_features, hidden_dim, num_classes, hidden_layers, grid_size, dropout):
+        super().__init__()
+        self.n_layers = gnn_layers
+        self.conv = nn.ModuleList(
+            GIFASTKANLayer(num_features if i == 0 else hidden_dim, hidden_dim, grid_size, hidden_dim, hidden_layers)
+            for i in range(gnn_layers))
+        self.bn = nn.ModuleList(nn.BatchNorm1d(hidden_dim) for _ in range(gnn_layers))
+        self.kan = make_fastkan(hidden_dim, hidden_dim, num_classes, hidden_layers, grid_size)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, data):
+        g = ops.graph_index(data.edge_index, data.x.size(0))
+        x = self._message_passing(data.x, g)
+        return F.log_softmax(self.kan(self._pool(x, data)), dim=1)
+
+
+class GINEKANLayer(nn.Module):
+    """GINE message passing around a KAN: ``nn((1+eps) x_i + sum_{j->i} relu(x_j + e_ij))``."""
+
+    def __init__(self, net: nn.Module, eps: float = 0.0):
+        super().__init__()
+        self.nn = net
+        self.register_buffer("eps", torch.full((1,), float(eps)))
+        self._eps_key, self._eps_val = None, float(eps)
+
+    def forward(self, x, edge_index, edge_attr):
+        key = (self.eps.data_ptr(), self.eps._version)
+        if key != self._eps_key:
+            self._eps_val, self._eps_key = float(self.eps), key
+        g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
+        return self.nn(ops.aggregate_gine(x, edge_attr, g, self_scale=1.0 + self._eps_val))
+
+
+class KAGINRegression(_GraphLevel):
+    """graph regression (ZINC / QM9 flavour of the reference, ``graph_regression/models.py:86-119``):
+    linear (or caller-supplied) node / edge encoders -> GINE(KAN) stack -> global_add_pool -> KAN.
+    ``ogb_encoders=True`` (OGB Atom/BondEncoder embedding tables) is out of the hot path: pass already
+    embedded ``x`` / ``edge_attr`` or use the linear encoders."""
+
+    def __init__(self, num_node_features, num_edge_features, gnn_layers, hidden_dim, hidden_layers, grid_size,
+                 spline_order, num_classes, dropout, ogb_encoders=False):
+        super().__init__()
+        if ogb_encoders:
+            raise NotImplementedError("OGB embedding encoders are outside the hot path; embed upstream")
+        self.n_layers = gnn_layers
+        self.atom_encoder = nn.Linear(num_node_features, hidden_dim)
+        self.bond_encoder = nn.Linear(num_edge_features, hidden_dim)
+        self.conv = nn.ModuleList(
+            GINEKANLayer(make_kan(hidden_dim, hidden_dim, hidden_dim, hidden_layers, grid_size, spline_order))
+            for _ in range(gnn_layers))
+        self.bn = nn.ModuleList(nn.BatchNorm1d(hidden_dim) for _ in range(gnn_layers))
+        self.kan = make_kan(hidden_dim, hidden_dim, num_classes, hidden_layers, grid_size, spline_order)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, data):
+        x, edge_attr = data.x, data.edge_attr
+        if edge_attr.dim() == 1:
+            edge_attr = edge_attr.unsqueeze(1)
+        x = self.atom_encoder(x)
+        edge_attr = self.bond_encoder(edge_attr)
+        g = ops.graph_index(data.edge_index, x.size(0))
+        x = self._message_passing(x, g, edge_attr)
+        return self.kan(self._pool(x, data))

@@ -275,5 +275,82 @@ def g8():
     save("g8_gine_pool", **out)
 
 
+# ---------------------------------------------------------------- G9: harness step (2 Adam steps)
+class _RefConv(torch.nn.Module):
+    """reference KAN modules inside the restated GIN / GCN message passing, with the attribute names of
+    node_classification_clean/models.py (nn + eps | lin + bias) so the state_dict keys coincide."""
+
+    def __init__(self, kind, fi, fo, hidden, G, k):
+        super().__init__()
+        self.kind = kind
+        if kind == "gin":
+            self.nn = ref_ekan.KAN([fi, hidden, fo], grid_size=G, spline_order=k)
+            self.register_buffer("eps", torch.zeros(1))
+        else:
+            self.lin = ref_ekan.KANLinear(fi, fo, grid_size=G, spline_order=k)
+            self.bias = torch.nn.Parameter(torch.zeros(fo))
+
+    def forward(self, x, ei):
+        if self.kind == "gin":
+            return orc.gin_conv(x, ei, self.nn, eps=0.0)
+        return orc.gcn_conv(x, ei, self.lin, self.bias)
+
+
+class _RefGKAN(torch.nn.Module):
+    """GKAN_Nodes.forward (models.py:192-203): conv -> BatchNorm1d -> dropout(0) -> skip concat -> KANLinear."""
+
+    def __init__(self, kind, L, fin, hid, classes, G, k):
+        super().__init__()
+        self.convs = torch.nn.ModuleList(_RefConv(kind, fin if i == 0 else hid, hid, hid, G, k) for i in range(L))
+        self.bns = torch.nn.ModuleList(torch.nn.BatchNorm1d(hid) for _ in range(L))
+        self.lay_out = ref_ekan.KANLinear(fin + L * hid, classes, grid_size=G, spline_order=k)
+
+    def forward(self, x, ei):
+        outs = [x]
+        for conv, bn in zip(self.convs, self.bns):
+            x = bn(conv(x, ei))
+            outs.append(x)
+        return self.lay_out(torch.cat(outs, dim=1))
+
+
+def g9():
+    out = {}
+    gen = torch.Generator().manual_seed(900)
+    n, e, fin, hid, classes, G, k = 500, 3000, 16, 8, 4, 4, 3
+    ei = orc.powerlaw_graph(n, e, seed=9)
+    x = torch.randn(n, fin, generator=gen) * 0.4
+    y = torch.randint(0, classes, (n,), generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.5
+    out["x"], out["edge_index"], out["y"], out["mask"] = npy(x), npy(ei), npy(y), npy(mask)
+    out["cfg"] = np.array([n, e, fin, hid, classes, G, k])
+    for kind in ("gin", "gcn"):
+        torch.manual_seed(910)
+        model = _RefGKAN(kind, 2, fin, hid, classes, G, k)
+        for kname, v in model.state_dict().items():
+            out[f"{kind}.init.{kname}"] = npy(v).copy()      # copy: Adam updates the tensors in place below
+        opt = torch.optim.Adam(model.parameters(), lr=0.001)
+        crit = torch.nn.CrossEntropyLoss()
+        losses = []
+        for step in range(2):
+            opt.zero_grad()
+            logits = model(x, ei)
+            if step == 0:
+                out[f"{kind}.logits0"] = npy(logits)
+            loss = crit(torch.softmax(logits, dim=1)[mask], y[mask])     # time_model.py:43-44 (softmax, then CE)
+            loss.backward()
+            if step == 0:
+                for pname, p in model.named_parameters():
+                    out[f"{kind}.grad0.{pname}"] = npy(p.grad)
+            opt.step()
+            losses.append(float(loss))
+        out[f"{kind}.losses"] = np.array(losses)
+        with torch.no_grad():
+            out[f"{kind}.logits2"] = npy(model(x, ei))
+    save("g9_harness", **out)
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g4(); g5_g6_g7(); g8()
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g567", "g8", "g9"]
+    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g567": g5_g6_g7, "g8": g8, "g9": g9}
+    for w in which:
+        fns[w]()
