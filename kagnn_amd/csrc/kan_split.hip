@@ -146,14 +146,16 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     const GBuf xb = gbuf(x, N, ldx, in), yb = gbuf(y, N, ldy, out);
     const unsigned ldx4 = (unsigned)ldx * 4u, ldy4 = (unsigned)ldy * 4u;
     auto load8 = [&](long row0t, int ch, int g, float (&v)[8]) {
-        const unsigned ro = (unsigned)(row0t + r) * ldx4;   // rows >= N: past the descriptor -> zeros
-        const int f0 = ch * CF + kg * HF + 8 * g;
+        const unsigned ro = (unsigned)(row0t + r) * ldx4 + kg * HF * 4;   // rows >= N: past the descriptor -> zeros
+        const unsigned so = (unsigned)(ch * CF + 8 * g) * 4u;              // wave-uniform part of the offset
         if (al4 && ch * CF + CF <= in) {                  // wave-uniform
-            gld4(xb, ro + f0 * 4, v);
-            gld4(xb, ro + f0 * 4 + 16, v + 4);
+            gld4_s(xb, ro, so, v);
+            gld4_s(xb, ro, so + 16, v + 4);
         } else {
+            const int f0 = ch * CF + kg * HF + 8 * g;
+            const unsigned rb = (unsigned)(row0t + r) * ldx4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = gld(xb, ro + min(f0 + j, in - 1) * 4);
+            for (int j = 0; j < 8; ++j) v[j] = gld(xb, rb + min(f0 + j, in - 1) * 4);
         }
     };
 
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
             if (col < out) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped
-                    gst(yb, base + (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, acc[t][i] * post);
+                    gst_s(yb, base, (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, acc[t][i] * post);
             }
         }
     }

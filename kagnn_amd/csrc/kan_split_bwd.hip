@@ -55,7 +55,9 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
         _Float16* dl = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q2 + q) * 2 + 1) * 1024 + lane * 16);
         for (int j = 0; j < 8; ++j) {
             const int o = 32 * q + 8 * (lane >> 4) + j;
-            const float w = wcat_s(bw, sw, sc, in, out, C, o, f, c) * wscale;
+            // slot 8 = base weight, slots 0..C-1 = spline coefficients, slots C..7 = 0
+            const int wc = (c == kCTmax - 1) ? C : (c < C ? c : C + 1);
+            const float w = wcat_s(bw, sw, sc, in, out, C, o, f, wc) * wscale;
             const _Float16 h = (_Float16)w;
             dh[j] = h;
             dl[j] = (_Float16)(w - (float)h);
@@ -138,6 +140,9 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
 
     for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
         const long row0 = tile * 256 + wave * 32;
+        const unsigned gy_ro = (unsigned)(row0 + li) * ldgy4;
+        const unsigned x_ro = (unsigned)(row0 + 4 * kg) * ldx4 + min(li, in - 1) * 4;    // + 64 B per 16-feature tile
+        const unsigned gx_ro = (unsigned)(row0 + 4 * kg) * ldgx4 + li * 4;
         // ---- A operand: gy rows scaled per row by 2^(10 - rexp), split into fp16 hi / lo
         u32x4 ahi[2][Q2], alo[2][Q2];
         float rinv[2][4];
@@ -145,18 +150,19 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
         for (int rt = 0; rt < 2; ++rt) {
             // buffer loads with 32-bit offsets: rows >= N read as 0 (never stored anyway); columns >= out are
             // clamped to the row's last value and meet zero weights in the pack
-            const unsigned ro = (unsigned)(row0 + 16 * rt + li) * ldgy4;
+            const unsigned ro = gy_ro + kg * 32;             // (row0 + li) * ldgy4 + 8*kg*4, tile-constant
+            const unsigned so = (unsigned)(16 * rt) * ldgy4; // wave-uniform
             float raw[Q2][8];
             float mx = 0.0f;
 #pragma unroll
             for (int q = 0; q < Q2; ++q) {
-                const int o0 = 32 * q + 8 * kg;
                 if (al4 && 32 * Q2 == out) {              // wave-uniform
-                    gld4(gyb, ro + o0 * 4, raw[q]);
-                    gld4(gyb, ro + o0 * 4 + 16, raw[q] + 4);
+                    gld4_s(gyb, ro, so + 128 * q, raw[q]);
+                    gld4_s(gyb, ro, so + 128 * q + 16, raw[q] + 4);
                 } else {
+                    const int o0 = 32 * q + 8 * kg;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) raw[q][j] = gld(gyb, ro + min(o0 + j, out - 1) * 4);
+                    for (int j = 0; j < 8; ++j) raw[q][j] = gld_s(gyb, gy_ro + min(o0 + j, out - 1) * 4, so);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(raw[q][j]));
@@ -191,8 +197,9 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const long rr = row0 + 16 * rt + 4 * kg + reg;
-                    xq[rt][reg] = gld(xb, (unsigned)rr * ldx4 + min(f, in - 1) * 4);   // rows >= N -> 0, never stored
+                    // rows >= N -> 0 (never stored); a partial last feature tile re-reads the clamped column
+                    const unsigned vo = (f < in) ? x_ro + ft * 64 : (unsigned)(row0 + 4 * kg) * ldx4 + (in - 1) * 4;
+                    xq[rt][reg] = gld_s(xb, vo, (unsigned)(16 * rt + reg) * ldx4);
                 }
             f32x4 D[kCTmax][2];
 #pragma unroll
@@ -216,7 +223,6 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const long rr = row0 + 16 * rt + 4 * kg + reg;
                     const float xv = xq[rt][reg];
                     float dN[K + 1];
                     int m;
@@ -228,14 +234,11 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                         float Nv[K + 1];
                         m = bspline_local<K, true>(xv, s_knots, geom, Nv, dN);
                     }
-                    float d[kCTmax - 1];                       // this element's per-coefficient sums
+                    float d[kCTmax - 1];                       // per-coefficient sums (slots >= C are exact zeros)
 #pragma unroll
-                    for (int c = 0; c < kCTmax - 1; ++c) d[c] = (c < C) ? D[c][rt][reg] : 0.0f;
-                    float db = 0.0f;                          // base-weight accumulator sits at index C
-#pragma unroll
-                    for (int c = 0; c < kCTmax; ++c) db = (c == C) ? D[c][rt][reg] : db;
-                    const float s = fmaf(db, silu_gradf(xv), barrel_dot<K>(d, m, dN));
-                    if (f < in) gst(gxb, (unsigned)rr * ldgx4 + f * 4, s * rinv[rt][reg]);   // rows >= N: dropped by the descriptor
+                    for (int c = 0; c < kCTmax - 1; ++c) d[c] = D[c][rt][reg];
+                    const float s = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot<K>(d, m, dN));
+                    if (f < in) gst_s(gxb, gx_ro + ft * 64, (unsigned)(16 * rt + reg) * ldgx4, s * rinv[rt][reg]);   // rows >= N: dropped
                 }
             }
         }
@@ -307,15 +310,12 @@ size_t kan_split_dw_ws_bytes(long N, int in, int out, int C) {
 // one workgroup = 4 waves = 64 features x 64 outputs over rows [rbeg, rend); wave w owns features
 // 64*fg + 16*w .. +15.  slab[s][c][f][o].
 //
-// Software pipeline (1 wave per SIMD: the 160 accumulator registers leave no room for a second wave,
-// and a lone wave issues at most one instruction per ~4 cycles): the MFMAs of chunk i are interleaved
-// at source level with the VALU work that prepares chunk i+1, and the global loads of chunk i+2 are
-// already in flight.
+// One wave per SIMD (160 accumulator registers).  Measured on MI355X these kernels cost
+// ~4 cycles per VALU instruction PLUS the MFMA cycles -- the two barely overlap -- so the loop is kept
+// minimal instead of deeply pipelined: loads of chunk i+1 are issued, the MFMAs of chunk i run (and
+// cover the load latency), then chunk i+1 is expanded in place.  Everything non-accumulator fits the
+// 256 architectural VGPRs, so nothing shuttles through AGPRs.
 struct DwRaw { float x[8]; float g[4][8]; };
-struct DwFrag {
-    u32x4 rh[8], rl[8];          // per row: 8-slot windows (hi / lo) of this lane's feature
-    u32x4 bhi[4], blo[4];        // gy * 2^(10-T), per 16-wide output tile
-};
 
 template <int K>
 __global__ __launch_bounds__(256) void kan_split_dw_kernel(
@@ -337,33 +337,44 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     const long s = blockIdx.x;
     const long rbeg = s * rows_per_block, rend = min(N, rbeg + rows_per_block);
 
-    f32x4 D[kCTmax - 1][4];        // spline coefficients x 4 o-tiles (scaled by 2^(20 - T))
-    f32x4 Db[4];                   // base weight (plain fp32)
+    f32x4 D[kCTmax - 1][4];        // spline coefficients x 4 o-tiles, scaled by 2^(20 - T)
+    f32x4 Dh[4];                   // base weight through the fp16 path, scaled by 2^(14 - T)
+    f32x4 Df[4];                   // base weight through the exact fp32 path (chunks whose silu overflows fp16)
 #pragma unroll
     for (int c = 0; c < kCTmax - 1; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) D[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) Db[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) { Dh[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Df[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const GBuf xb = gbuf(x, N, ldx, in), gyb = gbuf(gy, N, ldgy, out);
     const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u;
-    const unsigned fo = (unsigned)min(f, in - 1) * 4u;
-    unsigned go[4];
+    // per-lane byte offsets of the chunk being fetched; rows advance by 32 per call.  Unconditional buffer
+    // loads: rows >= N read as 0 through the descriptor (rows_per_block is a multiple of 32, so a chunk
+    // never straddles two workgroups); features >= in / outputs >= out are clamped and only reach slab
+    // entries nobody reads.
+    unsigned xo = (unsigned)(rbeg + 8 * kg) * ldx4 + (unsigned)min(f, in - 1) * 4u, gvo[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) go[t] = (unsigned)min(64 * oc + 16 * t + li, out - 1) * 4u;
-    auto load_raw = [&](long n0, DwRaw& r) {
+    for (int t = 0; t < 4; ++t) gvo[t] = (unsigned)(rbeg + 8 * kg) * ldgy4 + (unsigned)min(64 * oc + 16 * t + li, out - 1) * 4u;
+    auto load_raw = [&](DwRaw& r) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            // unconditional buffer loads, 32-bit offsets.  Rows >= N read as 0 through the descriptor; the chunk
-            // prefetched past this block's range is never multiplied (spline) or is masked (base, `live`);
-            // features >= in / outputs >= out are clamped and only reach slab entries nobody reads.
-            const unsigned n = (unsigned)(n0 + 8 * kg + j);
-            r.x[j] = gld(xb, n * ldx4 + fo);
+            r.x[j] = gld_s(xb, xo, (unsigned)j * ldx4);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) r.g[t][j] = gld(gyb, n * ldgy4 + go[t]);
+            for (int t = 0; t < 4; ++t) r.g[t][j] = gld_s(gyb, gvo[t], (unsigned)j * ldgy4);
         }
+        xo += 32u * ldx4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gvo[t] += 32u * ldgy4;
     };
+
+    // fragments of the current chunk
+    u32x4 rh[8], rl[8];            // per row: 8-slot windows (hi / lo) of this lane's feature
+    u32x4 bhi[4], blo[4];          // gy * 2^(10-T), per 16-wide output tile
+    u32x4 sah, sal;                // silu(x) * 2^4 over the 8 rows, hi / lo
+    int T;                         // running exponent: gy is fed as gy * 2^(10 - T)
+    bool base32 = false;           // this chunk's base branch already went through the fp32 path
+
     // wave-uniform exponent of the chunk's largest |gy|
     auto chunk_exp = [&](const DwRaw& r) -> int {
         float mx = 0.0f;
@@ -375,78 +386,90 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
         for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         return exp_for_max(mx);
     };
-    auto make_b = [&](const DwRaw& r, int t, float gs, DwFrag& fr) {
-        float v[8];
+    // raw chunk -> fragments, with gy scaled by 2^(10 - Tfix) (Tfix >= the chunk's exponent)
+    auto expand = [&](const DwRaw& r, int Tfix) {
+        const float gs = ldexpf(1.0f, 10 - Tfix);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = r.g[t][j] * gs;
-        split_f16x2(v, fr.bhi[t], fr.blo[t]);
-    };
-    auto make_row = [&](const DwRaw& r, int j, DwFrag& fr) {
-        spline_frag<K>(r.x[j], s_knots, s_tbl, geom, fgeo, fr.rh[j], fr.rl[j]);
-    };
-    // SiLU base branch of one chunk straight from the raw values: exact fp32 MFMA, 4 rows per
-    // instruction (k-lane kg <-> row 8*kg + j); rows past the end have gy == 0
-    auto base_row = [&](const DwRaw& r, int j, float live) {
-        const float a = siluf(r.x[j]) * live;
+        for (int t = 0; t < 4; ++t) {
+            float v[8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) Db[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, r.g[t][j], Db[t], 0, 0, 0);
+            for (int j = 0; j < 8; ++j) v[j] = r.g[t][j] * gs;
+            split_f16x2(v, bhi[t], blo[t]);
+        }
+        // ---- bases of 8 rows of this lane's feature
+#pragma unroll
+        for (int j = 0; j < 8; ++j) spline_frag<K>(r.x[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j]);
+        // ---- SiLU branch: fp16 hi/lo at scale 2^4 (|silu| < 4094); larger values take the fp32 MFMA
+        float sv[8];
+        float smx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sv[j] = siluf(r.x[j]) * 16.0f; smx = fmaxf(smx, fabsf(sv[j])); }
+        base32 = __any(!(smx < 60000.0f));              // wave-uniform; also catches NaN / Inf
+        split_f16x2(sv, sah, sal);
+        if (base32) {                                    // rare: do this chunk's base branch right here, in exact fp32
+#pragma unroll                                           // (4 rows per MFMA, k-lane kg <-> row 8*kg + j)
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    Df[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[j] * 0.0625f, r.g[t][j], Df[t], 0, 0, 0);
+        }
     };
 
-    int T = -1000;                 // running exponent: gy is fed as gy * 2^(10 - T)
-    DwRaw r1, r2;
-    DwFrag cur, nxt;
-    load_raw(rbeg, r1);
-    T = chunk_exp(r1);
-    {
-        const float gs = ldexpf(1.0f, 10 - T);
+    DwRaw raw;
+    load_raw(raw);
+    T = chunk_exp(raw);
+    expand(raw, T);
+    long n0 = rbeg;
+    while (n0 < rend) {
+        // ---- hot loop: the scale exponent T is FIXED in here, so the 160 accumulators are only ever touched by
+        // MFMAs (a conditional rescale inside the loop makes the compiler copy them around every iteration)
+        bool grow = false;
+        for (; n0 < rend; n0 += 32) {
+            load_raw(raw);                               // next chunk: lands under the MFMAs below
 #pragma unroll
-        for (int t = 0; t < 4; ++t) make_b(r1, t, gs, cur);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { make_row(r1, j, cur); base_row(r1, j, 1.0f); }
-    }
-    load_raw(rbeg + 32, r1);
-
-    for (long n0 = rbeg; n0 < rend; n0 += 32) {
-        load_raw(n0 + 64, r2);                           // two chunks ahead, lands during this iteration
-        const float live_next = (n0 + 32 < rend) ? 1.0f : 0.0f;   // the next chunk may belong to another workgroup
-        const int Tn = max(T, chunk_exp(r1));            // exponent the NEXT chunk's gy is scaled with
-        const float gsn = ldexpf(1.0f, 10 - Tn);
-        // ---- MFMAs of the current chunk, interleaved with the preparation of the next one
-#pragma unroll
-        for (int c = 0; c < kCTmax - 1; ++c) {              // all 8 slots, no branch: slots >= C are always zero
-            {
+            for (int c = 0; c < kCTmax - 1; ++c) {       // all 8 slots, no branch: slots >= C are always zero
                 const int q = c >> 1;
                 const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
-                u32x4 ah, al;
+                u32x4 ah, al;                            // transpose (row, coefficient) 8x8 blocks on the fly
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    ah[p] = __builtin_amdgcn_perm(cur.rh[2 * p + 1][q], cur.rh[2 * p][q], sel);
-                    al[p] = __builtin_amdgcn_perm(cur.rl[2 * p + 1][q], cur.rl[2 * p][q], sel);
+                    ah[p] = __builtin_amdgcn_perm(rh[2 * p + 1][q], rh[2 * p][q], sel);
+                    al[p] = __builtin_amdgcn_perm(rl[2 * p + 1][q], rl[2 * p][q], sel);
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(ah, cur.bhi[t], D[c][t]);
+                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(ah, bhi[t], D[c][t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(ah, cur.blo[t], D[c][t]);
+                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(ah, blo[t], D[c][t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(al, cur.bhi[t], D[c][t]);
+                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(al, bhi[t], D[c][t]);
             }
-            make_row(r1, c, nxt);                        // independent VALU work: row c of the next chunk
-            base_row(r1, c, live_next);                  // ... and its base-branch MFMAs (fp32, unscaled)
-            if (c < 4) make_b(r1, c, gsn, nxt);
+            if (!base32) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sah, bhi[t], Dh[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sah, blo[t], Dh[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sal, bhi[t], Dh[t]);
+            }
+            if (n0 + 32 >= rend) { n0 += 32; break; }    // that was the last chunk
+            if (chunk_exp(raw) > T) { grow = true; n0 += 32; break; }   // wave-uniform, rare
+            expand(raw, T);
         }
-        if (Tn > T) {                                    // wave-uniform: rescale what was accumulated so far
-            const float dn = ldexpf(1.0f, T - Tn);
+        if (grow) {                                      // the pending chunk needs a larger scale: rescale once, exactly
+            const int ex = chunk_exp(raw);
+            const float dn = ldexpf(1.0f, T - ex);
 #pragma unroll
             for (int c = 0; c < kCTmax - 1; ++c)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) D[c][t] *= dn;
-            T = Tn;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Dh[t] *= dn;
+            T = ex;
+            expand(raw, T);
         }
-        cur = nxt;
-        r1 = r2;
     }
     // ---- slab write: D rows <-> features 4*kg + reg, cols <-> outputs li
-    const float undo = ldexpf(1.0f, T - 20);
+    const float undo = ldexpf(1.0f, T - 20), undo_b = ldexpf(1.0f, T - 14);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const long o = 64 * oc + 16 * t + li;
@@ -457,7 +480,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
 #pragma unroll
                 for (int c = 0; c < kCTmax - 1; ++c)
                     if (c < C) slab[((s * (C + 1) + c) * inP + fl) * outP + o] = D[c][t][reg] * undo;
-                slab[((s * (C + 1) + C) * inP + fl) * outP + o] = Db[t][reg];
+                slab[((s * (C + 1) + C) * inP + fl) * outP + o] = fmaf(Dh[t][reg], undo_b, Df[t][reg]);
             }
         }
     }

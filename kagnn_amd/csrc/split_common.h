@@ -41,6 +41,18 @@ __device__ __forceinline__ void gld4(const GBuf& b, unsigned off, float* v) {
 __device__ __forceinline__ void gst(const GBuf& b, unsigned off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, off, 0, 0);
 }
+// variants with a wave-uniform (SGPR) byte offset on top of the per-lane one: row strides and tile steps
+// cost no VALU address arithmetic at all
+__device__ __forceinline__ float gld_s(const GBuf& b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
+}
+__device__ __forceinline__ void gld4_s(const GBuf& b, unsigned voff, unsigned soff, float* v) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, 0);
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+}
+__device__ __forceinline__ void gst_s(const GBuf& b, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, voff, soff, 0);
+}
 
 // exponent e with max|W| * 2^-e in [2^9, 2^10)
 __device__ __forceinline__ int scale_exp_from_max(float m) {
