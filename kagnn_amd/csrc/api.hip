@@ -26,6 +26,8 @@ size_t kan_split_pack_fwd_bytes(int in, int out, int C);
 size_t kan_split_pack_dx_bytes(int in, int out, int C);
 int kan_split_pack_fwd(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_pack_dx(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
+int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
+int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t);
 int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t);
 size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
@@ -145,8 +147,9 @@ int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in
     if (rc) return rc;
     KAGNN_CHECK_ARG(bw && sw && pack_fwd && pack_dx, "null array");
     const bool sf = use_split_fwd(in, out, G, K, mode), sd = use_split_dx(in, out, G, K, mode);
-    if (sf) { rc = kan_split_pack_fwd(bw, sw, sc, in, out, G + K, pack_fwd, as_stream(stream)); if (rc) return rc; }
-    if (sd) { rc = kan_split_pack_dx(bw, sw, sc, in, out, G + K, pack_dx, as_stream(stream)); if (rc) return rc; }
+    // one launch per layout; each workgroup derives the power-of-two weight scale itself
+    if (sf) { rc = kan_split_pack_fwd_noscale(bw, sw, sc, in, out, G + K, pack_fwd, as_stream(stream)); if (rc) return rc; }
+    if (sd) { rc = kan_split_pack_dx_noscale(bw, sw, sc, in, out, G + K, pack_dx, as_stream(stream)); if (rc) return rc; }
     if (!sf || !sd)
         return kan_f32_pack(bw, sw, sc, in, out, G + K, sf ? nullptr : (float*)pack_fwd, sd ? nullptr : (float*)pack_dx, as_stream(stream));
     return KAGNN_OK;

@@ -57,11 +57,13 @@ __global__ void split_absmax_kernel(const float* __restrict__ bw, const float* _
 
 __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
                                       const float* __restrict__ sc, int in, int out, int C,
-                                      unsigned char* __restrict__ pack) {
+                                      unsigned char* __restrict__ pack, int self_scale) {
     const int OT = cdiv(out, 32), CF = split_cf(OT), HF = CF / 2;
     const int SPC = CF / 2, BPC = CF / 16;
     unsigned* hdr = reinterpret_cast<unsigned*>(pack);
-    const int e = scale_exp_from_max(__uint_as_float(hdr[2]));
+    __shared__ float s_m[17];
+    const float wmax = self_scale ? block_absmax_w(bw, sw, sc, in, out, C, s_m) : __uint_as_float(hdr[2]);
+    const int e = scale_exp_from_max(wmax);
     const float wscale = ldexpf(1.0f, -e);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         reinterpret_cast<float*>(pack)[0] = ldexpf(1.0f, e - 10);   // post scale: undo 2^10 and 2^-e
@@ -308,6 +310,15 @@ int split_absmax(const float* bw, const float* sw, const float* sc, int in, int 
     return KAGNN_OK;
 }
 
+int kan_split_pack_fwd_noscale(const float* bw, const float* sw, const float* sc, int in, int out, int C,
+                               void* pack_fwd, hipStream_t st) {
+    unsigned char* pf = static_cast<unsigned char*>(pack_fwd);
+    const long items = (long)(kan_split_pack_fwd_bytes(in, out, C) - kHdrBytes) / 16;
+    split_pack_fwd_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(bw, sw, sc, in, out, C, pf, 1);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 int kan_split_pack_fwd(const float* bw, const float* sw, const float* sc, int in, int out, int C,
                        void* pack_fwd, hipStream_t st) {
     unsigned char* pf = static_cast<unsigned char*>(pack_fwd);
@@ -316,7 +327,7 @@ int kan_split_pack_fwd(const float* bw, const float* sw, const float* sc, int in
     split_absmax_kernel<<<(int)min((n + 255) / 256, 1024L), 256, 0, st>>>(bw, sw, sc, in, out, C, reinterpret_cast<unsigned*>(pf));
     KAGNN_LAUNCH_CHECK();
     const long items = (long)(kan_split_pack_fwd_bytes(in, out, C) - kHdrBytes) / 16;
-    split_pack_fwd_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, pf);
+    split_pack_fwd_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, pf, 0);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }

@@ -36,9 +36,11 @@ size_t kan_split_pack_dx_bytes(int in, int out, int C) {
 // pack_dx[ft16][c][q2][part][lane][8] : lane (f = lane&15, kg = lane>>4), j -> W'[o = 32*q2+8*kg+j][16*ft16+f][c]
 __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
                                      const float* __restrict__ sc, int in, int out, int C, int Q2,
-                                     unsigned char* __restrict__ pack) {
+                                     unsigned char* __restrict__ pack, int self_scale) {
     unsigned* hdr = reinterpret_cast<unsigned*>(pack);
-    const int e = scale_exp_from_max(__uint_as_float(hdr[2]));
+    __shared__ float s_m[17];
+    const float wmax = self_scale ? block_absmax_w(bw, sw, sc, in, out, C, s_m) : __uint_as_float(hdr[2]);
+    const int e = scale_exp_from_max(wmax);
     const float wscale = ldexpf(1.0f, -e);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         reinterpret_cast<float*>(pack)[0] = ldexpf(1.0f, e - 10);
@@ -65,6 +67,16 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
     }
 }
 
+int kan_split_pack_dx_noscale(const float* bw, const float* sw, const float* sc, int in, int out, int C,
+                              void* pack_dx, hipStream_t st) {
+    const int Q2 = dx_q2(out);
+    const long items = (long)cdiv(in, 16) * kCTmax * Q2 * 64;
+    split_pack_dx_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(bw, sw, sc, in, out, C, Q2,
+                                                                                static_cast<unsigned char*>(pack_dx), 1);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 int kan_split_pack_dx(const float* bw, const float* sw, const float* sc, int in, int out, int C,
                       void* pack_dx, hipStream_t st) {
     unsigned char* p = static_cast<unsigned char*>(pack_dx);
@@ -72,7 +84,7 @@ int kan_split_pack_dx(const float* bw, const float* sw, const float* sc, int in,
     { int rc = split_absmax(bw, sw, sc, in, out, C, reinterpret_cast<unsigned*>(p), st); if (rc) return rc; }
     const int Q2 = dx_q2(out);
     const long items = (long)cdiv(in, 16) * kCTmax * Q2 * 64;
-    split_pack_dx_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, Q2, p);
+    split_pack_dx_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, Q2, p, 0);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -204,18 +216,29 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             f32x4 D[kCTmax][2];
 #pragma unroll
             for (int c = 0; c < kCTmax; ++c) { D[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            // 9 slots x Q2 k-steps, no branch (unused slots hold zero weights).  The W fragments of group g+1 are
+            // read from LDS BEFORE the MFMAs of group g are issued, so the LDS latency hides under them.
+            {
+                constexpr int NGRP = kCTmax * Q2;
+                u32x4 bh[2], bl[2];
+                bh[0] = *reinterpret_cast<const u32x4*>(wft + 0 * 1024);
+                bl[0] = *reinterpret_cast<const u32x4*>(wft + 1 * 1024);
 #pragma unroll
-            for (int q = 0; q < Q2; ++q) {
-#pragma unroll
-                for (int c = 0; c < kCTmax; ++c) {          // all 9 slots, no branch: unused ones hold zero weights
-                    const u32x4 bhi = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q2 + q) * 2 + 0) * 1024);
-                    const u32x4 blo = *reinterpret_cast<const u32x4*>(wft + ((size_t)(c * Q2 + q) * 2 + 1) * 1024);
+                for (int g = 0; g < NGRP; ++g) {
+                    const int c = g / Q2, q = g % Q2;      // LDS order is [c][q][hi|lo], i.e. group g at 2g KiB
+                    if (g + 1 < NGRP) {
+                        bh[(g + 1) & 1] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * (g + 1) + 0) * 1024);
+                        bl[(g + 1) & 1] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * (g + 1) + 1) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // pin: hipcc otherwise sinks the reads back to their first use
+                    const u32x4 bhi = bh[g & 1], blo = bl[g & 1];
                     D[c][0] = mfma16_f16(ahi[0][q], bhi, D[c][0]);
                     D[c][1] = mfma16_f16(ahi[1][q], bhi, D[c][1]);
                     D[c][0] = mfma16_f16(ahi[0][q], blo, D[c][0]);
                     D[c][1] = mfma16_f16(ahi[1][q], blo, D[c][1]);
                     D[c][0] = mfma16_f16(alo[0][q], bhi, D[c][0]);
                     D[c][1] = mfma16_f16(alo[1][q], bhi, D[c][1]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // ---- contraction over c with the local basis derivatives (barrel shift by the span index)

@@ -62,6 +62,32 @@ __device__ __forceinline__ int scale_exp_from_max(float m) {
     return ex - 10;
 }
 
+// One launch packs BOTH layouts: every workgroup first computes max|Wcat| over the whole (small, L2-resident)
+// parameter set by itself -- cheaper than a separate reduction launch + memset -- then packs its share.
+__device__ __forceinline__ float block_absmax_w(const float* __restrict__ bw, const float* __restrict__ sw,
+                                const float* __restrict__ sc, int in, int out, int C, float* s_m /* LDS[17] */) {
+    float m = 0.0f;
+    const int nof = out * in;
+    for (int of = threadIdx.x; of < nof; of += blockDim.x) {
+        float v = fabsf(bw[of]);
+        m = fmaxf(m, (v <= 3.0e38f) ? v : 0.0f);
+        const float scale = sc ? sc[of] : 1.0f;
+        for (int c = 0; c < C; ++c) {
+            v = fabsf(sw[(long)of * C + c] * scale);
+            m = fmaxf(m, (v <= 3.0e38f) ? v : 0.0f);
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, s_m[i]);
+        s_m[16] = m;
+    }
+    __syncthreads();
+    return s_m[16];
+}
+
 // selector table for v_perm_b32: entry t (shift sh = t-4 halfs) holds 4 selectors; output half s of
 // the 8-slot window takes payload half s-sh (payload = 4 halfs in {p1:p0}), zero when out of range.
 __device__ __forceinline__ void build_perm_table(unsigned* tbl /* LDS, 16*4 */, int tid) {
