@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> <counter> [<counter> ...]  -- one rocprofv3 --pmc pass over a short bench run
+# usage: tools/pmc.sh <tag> <counter> [<counter> ...]  -- one rocprofv3 --pmc pass over a short bench run
 TAG=$1; shift
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT

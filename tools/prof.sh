@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag>   -- rocprofv3 passes over a short bench run (GPU box only)
+# usage: tools/prof.sh <tag>   -- rocprofv3 passes over a short bench run (GPU box only)
 set -u
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
