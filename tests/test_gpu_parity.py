@@ -388,3 +388,48 @@ def test_graph_level_models_run_and_match_composition(golden):
     pred = r(d)
     pred.abs().mean().backward()                     # L1-style loss as in optuna_zinc.py
     assert pred.shape == (16, 1) and all(p.grad is not None for p in r.parameters())
+
+
+# ------------------------------------------------------------------ range robustness of the split path
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_kanlinear_extreme_ranges_vs_oracle(mode):
+    """rows with huge activations (SiLU branch far beyond fp16 range -> fp32 MFMA fallback in dW, bf16 split
+    in fwd), upstream gradients spanning 40 decades across rows (per-row scaling in dX, running-max rescale
+    of the accumulators in dW), tiny and large weights (power-of-two weight scale)."""
+    n, fi, fo, G, k = 4099, 64, 64, 5, 3
+    gen = torch.Generator().manual_seed(77)
+    p = orc.init_kan_linear(fi, fo, G, k, gen)
+    p["base_weight"] = p["base_weight"] * 37.0
+    p["spline_weight"] = p["spline_weight"] * 1e-3
+    x = torch.randn(n, fi, generator=gen) * 0.7
+    x[5] *= 1e4; x[77, :8] = 3e5; x[1000:1040] *= 300.0; x[4000] = -2e4
+    gy = torch.randn(n, fo, generator=gen)
+    scale = torch.ones(n, 1)
+    scale[:500] = 1e-18; scale[500:900] = 1e-6; scale[2500:2600] = 1e9; scale[4090:] = 1e19
+    gy = gy * scale
+    y64, gx64, g64 = oracle_kan_linear_fwd_bwd(x, gy, p, k)
+    layer = kagnn_amd.KANLinear(fi, fo, grid_size=G, spline_order=k)
+    layer.load_state_dict(p)
+    layer = layer.to(DEV)
+    layer.precision = mode
+    xd = x.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    y.backward(gy.to(DEV))
+    assert_close(y, y64, what="y")
+    # the input gradient is checked ROW-wise relative to each row's own scale (40 decades across rows)
+    rs = gx64.abs().amax(1, keepdim=True).clamp(min=1e-300)
+    assert float(((xd.grad.cpu().double() - gx64) / rs).abs().max()) < 1e-4
+    for nme in ("base_weight", "spline_weight", "spline_scaler"):
+        assert_close(getattr(layer, nme).grad, g64[nme], what="g_" + nme)
+
+
+def test_kanlinear_degenerate_weights_and_gradients():
+    layer = kagnn_amd.KANLinear(16, 8).to(DEV)
+    with torch.no_grad():
+        for q in layer.parameters():
+            q.zero_()
+    x = torch.randn(100, 16, device=DEV, requires_grad=True)
+    y = layer(x)
+    assert float(y.abs().max()) == 0.0
+    y.backward(torch.zeros_like(y))
+    assert float(x.grad.abs().max()) == 0.0 and float(layer.spline_weight.grad.abs().max()) == 0.0
