@@ -48,13 +48,17 @@ __global__ __launch_bounds__(256) void fastkan_fwd_kernel(
     float mean = 0.0f, rstd = 1.0f;
     if (ln.w) {                                   // two-pass mean / biased variance, eps inside the sqrt
         float s = 0.0f;
-        for (int p = 0; p < P; ++p) { const int f = p + kh * P; if (rv && f < in) s += xr[f]; }
+        for (int p = 0; p < P; ++p) {               // unconditional clamped loads, masked by a 0/1 factor
+            const int f = p + kh * P;
+            s = fmaf(xr[min(f, in - 1)], (rv && f < in) ? 1.0f : 0.0f, s);
+        }
         s += __shfl_xor(s, 32);
         mean = s / (float)in;
         float v = 0.0f;
         for (int p = 0; p < P; ++p) {
             const int f = p + kh * P;
-            if (rv && f < in) { const float d = xr[f] - mean; v = fmaf(d, d, v); }
+            const float d = (xr[min(f, in - 1)] - mean) * ((rv && f < in) ? 1.0f : 0.0f);
+            v = fmaf(d, d, v);
         }
         v += __shfl_xor(v, 32);
         rstd = rsqrtf(v / (float)in + ln.eps);
@@ -70,8 +74,9 @@ __global__ __launch_bounds__(256) void fastkan_fwd_kernel(
     for (int p = 0; p < P; ++p) {
         const int f = p + kh * P;
         const bool fv = rv && f < in;
-        const float xv = fv ? xr[f] : 0.0f;
-        const float z = (ln.w && fv) ? fmaf((xv - mean) * rstd, ln.w[f], ln.b[f]) : xv;
+        const float xv = xr[min(f, in - 1)];          // unconditional clamped load (masked below)
+        const int fc = min(f, in - 1);
+        const float z = ln.w ? fmaf((xv - mean) * rstd, ln.w[fc], ln.b[fc]) : xv;   // ln.w is wave-uniform
         const float sl = fv ? siluf(xv) : 0.0f;
         const float* wp = pack + ((long)p * CT * OT_total + ot0) * 64 + lane;
         for (int g = 0; g < ng; ++g) {
@@ -116,7 +121,8 @@ __global__ __launch_bounds__(256) void fastkan_dx_kernel(
     for (int i = lane; i < 32 * outP; i += 64) {
         const int rr = i / outP, o = i - rr * outP;
         const long row = row0 + rr;
-        s_gy[rr * ldt + o] = (row < N && o < out) ? gy[row * ldgy + o] : 0.0f;
+        const float gv = gy[min(row, N - 1) * ldgy + min(o, out - 1)];      // unconditional clamped load
+        s_gy[rr * ldt + o] = (row < N && o < out) ? gv : 0.0f;
     }
     __syncthreads();
     if (row0 >= N) return;
@@ -147,9 +153,12 @@ __global__ __launch_bounds__(256) void fastkan_dx_kernel(
             for (int i = 0; i < 16; ++i) {
                 const long rr = row0 + mfma32_row(i, kh);
                 const bool ok = rr < N && f < in;
-                const float xv = ok ? x[rr * ldx + f] : 0.0f;
+                const float xv = x[min(rr, N - 1) * ldx + min(f, in - 1)];       // clamped; !ok lanes never store
                 float z = xv;
-                if (ln.w && ok) z = fmaf((xv - stats[2 * rr]) * stats[2 * rr + 1], ln.w[f], ln.b[f]);
+                if (ln.w) {                            // wave-uniform; clamped indices, no per-lane branch around loads
+                    const long rc = min(rr, N - 1); const int fc = min(f, in - 1);
+                    z = fmaf((xv - stats[2 * rc]) * stats[2 * rc + 1], ln.w[fc], ln.b[fc]);
+                }
                 const float sg = silu_gradf(xv);
 #pragma unroll
                 for (int j = 0; j < kFkGroup; ++j) {
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256) void fastkan_dw_kernel(
     const int f = 32 * ft + r, o = 32 * ot + r;
     const bool fv = f < in, ov = o < out;
     const long inP = 32L * FT, outP = 32L * OT;
-    const float gam = (ln.w && fv) ? ln.w[f] : 1.0f, bet = (ln.w && fv) ? ln.b[f] : 0.0f;
+    const float gam = ln.w ? ln.w[min(f, in - 1)] : 1.0f, bet = ln.w ? ln.b[min(f, in - 1)] : 0.0f;
 
     for (int c0 = 0; c0 < CT; c0 += kFkGroup) {
         f32x16 D[kFkGroup];
@@ -275,10 +284,11 @@ __global__ __launch_bounds__(256) void fastkan_dw_kernel(
         for (long n = rbeg + kh; n < rend + kh; n += 2) {
             const bool nv = n < rend;
             const bool live = nv && fv;
-            const float xv = live ? x[n * ldx + f] : 0.0f;
-            const float b = (nv && ov) ? gy[n * ldgy + o] : 0.0f;
+            const long nc = min(n, N - 1);                 // clamped unconditional loads; `live` masks the products
+            const float xv = x[nc * ldx + min(f, in - 1)];
+            const float b = gy[nc * ldgy + min(o, out - 1)];
             float z = xv;
-            if (ln.w && live) z = fmaf((xv - stats[2 * n]) * stats[2 * n + 1], gam, bet);
+            if (ln.w) z = fmaf((xv - stats[2 * nc]) * stats[2 * nc + 1], gam, bet);   // wave-uniform condition
             const float sl = siluf(xv);
 #pragma unroll
             for (int j = 0; j < kFkGroup; ++j) {

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void kan_fwd_f32_kernel(
     for (int p = 0; p < P; ++p) {
         const int f = p + kh * P;
         const bool fv = rv && f < in;
-        const float xv = fv ? xr[f] : 0.0f;
+        const float xv = xr[min(f, in - 1)];          // unconditional clamped load (masked below): no per-load branch
         float Nv[K + 1], dummy[K + 1];
         int m = bspline_local<K, false>(xv, s_knots, geom, Nv, dummy);
         float sl = siluf(xv);
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
     for (int i = lane; i < 32 * outP; i += 64) {
         const int rr = i / outP, o = i - rr * outP;
         const long row = row0 + rr;
-        s_gy[rr * ldt + o] = (row < N && o < out) ? gy[row * ldgy + o] : 0.0f;
+        const float gv = gy[min(row, N - 1) * ldgy + min(o, out - 1)];      // unconditional clamped load
+        s_gy[rr * ldt + o] = (row < N && o < out) ? gv : 0.0f;
     }
     __syncthreads();
     if (row0 >= N) return;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
             for (int i = 0; i < 16; ++i) {
                 const long rr = row0 + mfma32_row(i, kh);
                 const bool ok = rr < N && f < in;
-                const float xv = ok ? x[rr * ldx + f] : 0.0f;
+                const float xv = x[min(rr, N - 1) * ldx + min(f, in - 1)];       // clamped; !ok lanes never store
                 float Nv[K + 1], dN[K + 1];
                 const int m = bspline_local<K, true>(xv, s_knots, geom, Nv, dN);
                 const float sg = silu_gradf(xv);
@@ -221,8 +222,9 @@ __global__ __launch_bounds__(256) void kan_dw_f32_kernel(
             for (int i = 0; i < 16; ++i) D[j][i] = 0.0f;
         for (long n = rbeg + kh; n < rend + kh; n += 2) {   // both halves run the same trip count
             const bool nv = n < rend;
-            const float xv = (nv && fv) ? x[n * ldx + f] : 0.0f;
-            const float b = (nv && ov) ? gy[n * ldgy + o] : 0.0f;
+            const long nc = min(n, N - 1);                 // clamped unconditional loads; `live` masks the products
+            const float xv = x[nc * ldx + min(f, in - 1)];
+            const float b = gy[nc * ldgy + min(o, out - 1)];
             float Nv[K + 1], dummy[K + 1];
             const int m = bspline_local<K, false>(xv, s_knots, geom, Nv, dummy);
             const float sl = siluf(xv);
