@@ -168,22 +168,23 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
  * FastKAN layer.  Replaces FastKANLayer.forward (node_classification_clean/fastkan.py:76-85:
  * LayerNorm :77-78, RadialBasisFunction :46-47, SplineLinear :81, base_linear(silu(x)) :82-84)
  * and its autograd backward.  centers = the module's `rbf.grid` parameter (num_grids fp32
- * values, device pointer), denominator as in fastkan.py:44.  ln_weight/ln_bias NULL = no layernorm; base_weight NULL = no base branch.
+ * values, device pointer), denominator as in fastkan.py:44.  `precision` as for the KAN layer
+ * (KAGNN_PREC_SPLIT covers num_grids <= 8; other shapes run the exact-fp32 kernels either way).  ln_weight/ln_bias NULL = no layernorm; base_weight NULL = no base branch.
  *   spline_weight [out, in*num_grids]  (in major, grid minor), base_weight [out,in], base_bias [out]
  * ------------------------------------------------------------------------------------------ */
 int kagnn_fastkan_fwd_workspace_bytes(int64_t num_rows, int32_t in_features,
                                       int32_t out_features, int32_t num_grids,
-                                      size_t* bytes_host);
+                                      int32_t precision, size_t* bytes_host);
 int kagnn_fastkan_fwd(const float* x, int64_t ldx, int64_t num_rows, int32_t in_features,
                       int32_t out_features, int32_t num_grids, const float* centers,
                       float denominator, const float* ln_weight, const float* ln_bias,
                       float ln_eps, const float* spline_weight, const float* base_weight,
                       const float* base_bias, float* y, int64_t ldy,
                       float* row_stats /* [N,2] = mean, rstd; required when ln_weight != NULL */,
-                      void* workspace, size_t workspace_bytes, void* stream);
+                      int32_t precision, void* workspace, size_t workspace_bytes, void* stream);
 int kagnn_fastkan_bwd_workspace_bytes(int64_t num_rows, int32_t in_features,
                                       int32_t out_features, int32_t num_grids,
-                                      size_t* bytes_host);
+                                      int32_t precision, size_t* bytes_host);
 /* all gradients of one layer: gx[N,in], g_ln_weight[in], g_ln_bias[in],
  * g_spline_weight[out,in*num_grids], g_base_weight[out,in], g_base_bias[out]; `row_stats` is the
  * array kagnn_fastkan_fwd wrote.  No gradient is produced for `centers` (rbf.grid has
@@ -195,7 +196,8 @@ int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy
                       const float* spline_weight, const float* base_weight,
                       const float* row_stats, float* gx, int64_t ldgx, float* g_ln_weight,
                       float* g_ln_bias, float* g_spline_weight, float* g_base_weight,
-                      float* g_base_bias, void* workspace, size_t workspace_bytes, void* stream);
+                      float* g_base_bias, int32_t precision, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -45,13 +45,13 @@ _SIGNATURES = {
     "kagnn_kan_linear_bwd_weight": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, c_int32, c_int32,
                                               c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P,
                                               c_size_t, _P]),
-    "kagnn_fastkan_fwd_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+    "kagnn_fastkan_fwd_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "kagnn_fastkan_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, c_int32, _P, c_float, _P, _P,
-                                    c_float, _P, _P, _P, _P, c_int64, _P, _P, c_size_t, _P]),
-    "kagnn_fastkan_bwd_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+                                    c_float, _P, _P, _P, _P, c_int64, _P, c_int32, _P, c_size_t, _P]),
+    "kagnn_fastkan_bwd_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "kagnn_fastkan_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, _P,
                                     c_float, _P, _P, c_float, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
-                                    _P, _P, c_size_t, _P]),
+                                    _P, c_int32, _P, c_size_t, _P]),
 }
 
 EXPORTED = tuple(_SIGNATURES)

@@ -24,8 +24,6 @@ int kan_f32_dw(const float*, long, const float*, long, long, const float*, int, 
 
 size_t kan_split_pack_fwd_bytes(int in, int out, int C);
 size_t kan_split_pack_dx_bytes(int in, int out, int C);
-int kan_split_pack_fwd(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
-int kan_split_pack_dx(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t);
@@ -36,10 +34,10 @@ bool kan_split_fwd_ok(int in, int out, int G, int K);
 bool kan_split_dx_ok(int in, int out, int G, int K);
 bool kan_split_dw_ok(int in, int out, int G, int K);
 
-int fastkan_fwd(const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, void*, size_t, hipStream_t);
-size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng);
-size_t fastkan_bwd_ws_bytes(long N, int in, int out, int ng);
-int fastkan_bwd(const float*, long, const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, float*, float*, float*, float*, void*, size_t, hipStream_t);
+int fastkan_fwd(const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, void*, size_t, int, hipStream_t);
+size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng, int mode);
+size_t fastkan_bwd_ws_bytes(long N, int in, int out, int ng, int mode);
+int fastkan_bwd(const float*, long, const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, float*, float*, float*, float*, void*, size_t, int, hipStream_t);
 }  // namespace kagnn
 
 using namespace kagnn;
@@ -213,40 +211,43 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
 }
 
 // ---------------------------------------------------------------- FastKAN
-static int check_fk(const char* fn, int in, int out, int ng) {
+static int check_fk(const char* fn, int in, int out, int ng, int mode) {
     if (in < 1 || out < 1) return fail(KAGNN_ERR_ARG, "%s: input_dim/output_dim must be >= 1", fn);
     if (ng < 1 || ng > kMaxKnots) return fail(KAGNN_ERR_UNSUPPORTED, "%s: num_grids out of range", fn);
+    if (mode != KAGNN_PREC_FP32 && mode != KAGNN_PREC_SPLIT) return fail(KAGNN_ERR_ARG, "%s: unknown precision mode", fn);
     return KAGNN_OK;
 }
 
-int kagnn_fastkan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t ng, size_t* bytes) {
-    int rc = check_fk(__func__, in, out, ng);
+int kagnn_fastkan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t ng, int32_t mode, size_t* bytes) {
+    int rc = check_fk(__func__, in, out, ng, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
-    *bytes = fastkan_fwd_ws_bytes(N, in, out, ng);
+    *bytes = fastkan_fwd_ws_bytes(N, in, out, ng, mode);
     return KAGNN_OK;
 }
 
 int kagnn_fastkan_fwd(const float* x, int64_t ldx, int64_t N, int32_t in, int32_t out, int32_t ng,
                       const float* centers, float denominator, const float* ln_w, const float* ln_b,
                       float ln_eps, const float* spline_w, const float* base_w, const float* base_b,
-                      float* y, int64_t ldy, float* row_stats, void* ws, size_t ws_bytes, void* stream) {
-    int rc = check_fk(__func__, in, out, ng);
+                      float* y, int64_t ldy, float* row_stats, int32_t mode, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_fk(__func__, in, out, ng, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldy >= out, "bad shape");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && centers && spline_w && y && ws, "null array");
     KAGNN_CHECK_ARG(denominator != 0.0f, "denominator is zero");
     KAGNN_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "layernorm weight and bias must both be given or both be null");
+    if (mode == KAGNN_PREC_SPLIT && !(fits32(N, ldx) && fits32(N, ldy)))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
     return fastkan_fwd(x, ldx, N, in, out, ng, centers, denominator, ln_w, ln_b, ln_eps, spline_w, base_w,
-                       base_b, y, ldy, row_stats, ws, ws_bytes, as_stream(stream));
+                       base_b, y, ldy, row_stats, ws, ws_bytes, mode, as_stream(stream));
 }
 
-int kagnn_fastkan_bwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t ng, size_t* bytes) {
-    int rc = check_fk(__func__, in, out, ng);
+int kagnn_fastkan_bwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t ng, int32_t mode, size_t* bytes) {
+    int rc = check_fk(__func__, in, out, ng, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
-    *bytes = fastkan_bwd_ws_bytes(N, in, out, ng);
+    *bytes = fastkan_bwd_ws_bytes(N, in, out, ng, mode);
     return KAGNN_OK;
 }
 
@@ -255,17 +256,19 @@ int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy
                       const float* ln_w, const float* ln_b, float ln_eps, const float* spline_w,
                       const float* base_w, const float* row_stats, float* gx, int64_t ldgx,
                       float* g_ln_w, float* g_ln_b, float* g_spline_w, float* g_base_w,
-                      float* g_base_b, void* ws, size_t ws_bytes, void* stream) {
-    int rc = check_fk(__func__, in, out, ng);
+                      float* g_base_b, int32_t mode, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_fk(__func__, in, out, ng, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
     KAGNN_CHECK_ARG(centers && spline_w && g_spline_w && ws, "null array");
     KAGNN_CHECK_ARG(N == 0 || (x && gy && gx), "null array");
     KAGNN_CHECK_ARG(ln_w == nullptr || (ln_b && row_stats && g_ln_w && g_ln_b), "layernorm needs bias, row_stats and both gradient outputs");
     KAGNN_CHECK_ARG(base_w == nullptr || (g_base_w && g_base_b), "base branch needs both gradient outputs");
+    if (mode == KAGNN_PREC_SPLIT && !(fits32(N, ldx) && fits32(N, ldgy) && fits32(N, ldgx)))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
     return fastkan_bwd(x, ldx, gy, ldgy, N, in, out, ng, centers, denominator, ln_w, ln_b, ln_eps, spline_w,
                        base_w, row_stats, gx, ldgx, g_ln_w, g_ln_b, g_spline_w, g_base_w, g_base_b, ws,
-                       ws_bytes, as_stream(stream));
+                       ws_bytes, mode, as_stream(stream));
 }
 
 }  // extern "C"

@@ -7,9 +7,20 @@
 // :82-84) and the autograd backward of those.  Fragment mapping is the one of kan_fp32.hip:
 // the two k-lanes of an MFMA are two input features, one MFMA per grid point g (plus one for
 // the SiLU base branch).
-#include "common.h"
+#include "split_common.h"
 
 namespace kagnn {
+
+// split-precision kernels shared with the B-spline layer (K == 0 selects the RBF basis)
+bool kan_split_fwd_ok(int in, int out, int G, int K);
+size_t kan_split_pack_fwd_bytes(int in, int out, int C);
+size_t kan_split_pack_dx_bytes(int in, int out, int C);
+size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
+int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
+int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
+int kan_split_fwd_any(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, hipStream_t);
+int kan_split_dx_any(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, hipStream_t);
+int kan_split_dw_any(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, const RbfArgs&, hipStream_t);
 
 int kan_f32_pack(const float*, const float*, const float*, int, int, int, float*, float*, hipStream_t);
 size_t kan_f32_pack_fwd_bytes(int in, int out, int C);
@@ -24,6 +35,36 @@ struct LnArgs {
 __device__ __forceinline__ float rbf_val(float z, float c, float inv_den) {
     const float d = (z - c) * inv_den;
     return __expf(-d * d);
+}
+
+// LayerNorm row statistics (mean, 1/sqrt(biased var + eps)), two-pass like torch; 16 lanes per row
+__global__ __launch_bounds__(256) void fastkan_stats_kernel(const float* __restrict__ x, long ldx, long N,
+                                                            int in, float eps, float* __restrict__ stats) {
+    const long row = (blockIdx.x * 256L + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    const float* xr = x + min(row, N - 1) * ldx;
+    float s = 0.0f;
+    for (int f = l; f < in; f += 16) s += xr[f];
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)in;
+    float v = 0.0f;
+    for (int f = l; f < in; f += 16) { const float d = xr[f] - mean; v = fmaf(d, d, v); }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (l == 0 && row < N) { stats[2 * row] = mean; stats[2 * row + 1] = rsqrtf(v / (float)in + eps); }
+}
+
+static bool fk_split(int in, int out, int ng, int mode) { return mode == 1 && kan_split_fwd_ok(in, out, ng, 0); }
+
+static RbfArgs fk_rbf(const float* centers, int ng, float den, const float* lnw, const float* lnb,
+                      const float* stats, const float* bias, float* gz) {
+    RbfArgs rb{};
+    rb.centers = centers; rb.ng = ng;
+    rb.a = 1.2011224087864498f / den;                 // sqrt(log2 e) / denominator
+    rb.k2 = -2.0f * rb.a * 0.6931471805599453f;
+    rb.ln_w = lnw; rb.ln_b = lnb; rb.stats = stats; rb.bias = bias; rb.gz = gz;
+    return rb;
 }
 
 // ------------------------------------------------------------------ forward
@@ -117,7 +158,7 @@ __global__ __launch_bounds__(256) void fastkan_dx_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* s_gy = smem + kMaxKnots + (long)wave * 32 * ldt;
     if (threadIdx.x < ng) s_c[threadIdx.x] = centers[threadIdx.x];
-    const long row0 = ((long)blockIdx.x * 4 + wave) * 32;
+    const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 32;
     for (int i = lane; i < 32 * outP; i += 64) {
         const int rr = i / outP, o = i - rr * outP;
         const long row = row0 + rr;
@@ -186,50 +227,69 @@ __global__ __launch_bounds__(256) void fastkan_dx_kernel(
 // ------------------------------------------------------------------ input gradient, stage 2
 // LayerNorm backward, one wave per row (persistent, so the per-feature sums for g_ln_weight /
 // g_ln_bias stay in registers):  gh = gz*gamma;  gx += rstd * (gh - mean(gh) - zhat*mean(gh*zhat)).
-constexpr int kLnMaxT = 16;     // features per lane: in <= 64*16
+constexpr int kLnMaxT = 64;     // features per lane: in <= 64*64
 
+// T = features per lane.  T <= 16 keeps the row (zhat, gh) in registers between the two passes; wider rows
+// re-read it (L2-hot) so that only the per-feature sums occupy registers.
+template <int T>
 __global__ __launch_bounds__(256) void fastkan_ln_bwd_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gz, long N, int in, LnArgs ln,
     const float* __restrict__ stats, float* __restrict__ gx, long ldgx,
     float* __restrict__ partial /* [waves][2][in] */) {
+    constexpr bool CACHE = T <= 16;
     const int lane = threadIdx.x & 63;
     const long wid = blockIdx.x * 4L + (threadIdx.x >> 6), nw = gridDim.x * 4L;
-    float cw[kLnMaxT], cb[kLnMaxT];
+    float cw[T], cb[T];
 #pragma unroll
-    for (int t = 0; t < kLnMaxT; ++t) { cw[t] = 0.0f; cb[t] = 0.0f; }
+    for (int t = 0; t < T; ++t) { cw[t] = 0.0f; cb[t] = 0.0f; }
     const float inv_n = 1.0f / (float)in;
     for (long row = wid; row < N; row += nw) {
         const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-        float zh[kLnMaxT], gh[kLnMaxT];
+        float zh[CACHE ? T : 1], gh[CACHE ? T : 1];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int t = 0; t < kLnMaxT; ++t) {
+        for (int t = 0; t < T; ++t) {
             const int f = lane + 64 * t;
-            zh[t] = 0.0f; gh[t] = 0.0f;
             if (f < in) {
                 const float g = gz[row * (long)in + f];
-                zh[t] = (x[row * ldx + f] - mean) * rstd;
-                gh[t] = g * ln.w[f];
-                cw[t] = fmaf(g, zh[t], cw[t]);
+                const float z = (x[row * ldx + f] - mean) * rstd;
+                const float h = g * ln.w[f];
+                if constexpr (CACHE) { zh[t] = z; gh[t] = h; }
+                cw[t] = fmaf(g, z, cw[t]);
                 cb[t] += g;
-                s1 += gh[t];
-                s2 = fmaf(gh[t], zh[t], s2);
+                s1 += h;
+                s2 = fmaf(h, z, s2);
             }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
         s1 *= inv_n; s2 *= inv_n;
 #pragma unroll
-        for (int t = 0; t < kLnMaxT; ++t) {
+        for (int t = 0; t < T; ++t) {
             const int f = lane + 64 * t;
-            if (f < in) gx[row * ldgx + f] += rstd * (gh[t] - s1 - zh[t] * s2);
+            if (f < in) {
+                float z, h;
+                if constexpr (CACHE) { z = zh[t]; h = gh[t]; }
+                else { z = (x[row * ldx + f] - mean) * rstd; h = gz[row * (long)in + f] * ln.w[f]; }
+                gx[row * ldgx + f] += rstd * (h - s1 - z * s2);
+            }
         }
     }
 #pragma unroll
-    for (int t = 0; t < kLnMaxT; ++t) {
+    for (int t = 0; t < T; ++t) {
         const int f = lane + 64 * t;
         if (f < in) { partial[(wid * 2 + 0) * in + f] = cw[t]; partial[(wid * 2 + 1) * in + f] = cb[t]; }
     }
+}
+
+static int launch_ln_bwd(int blocks, const float* x, long ldx, const float* gz, long N, int in, LnArgs ln,
+                         const float* stats, float* gx, long ldgx, float* partial, hipStream_t st) {
+    const int T = cdiv(in, 64);
+#define L(TT) fastkan_ln_bwd_kernel<TT><<<blocks, 256, 0, st>>>(x, ldx, gz, N, in, ln, stats, gx, ldgx, partial)
+    if (T <= 2) L(2); else if (T <= 4) L(4); else if (T <= 16) L(16); else if (T <= 32) L(32); else L(64);
+#undef L
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
 }
 
 // out[j] = sum_w partial[w*stride + j], j < n  (fixed order)
@@ -329,16 +389,26 @@ __global__ void fastkan_dw_unpack_kernel(const float* __restrict__ gcat, int in,
 // ------------------------------------------------------------------ host launchers
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng) {
+size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng, int mode) {
+    if (fk_split(in, out, ng, mode)) return al256(kan_split_pack_fwd_bytes(in, out, ng));
     return al256(kan_f32_pack_fwd_bytes(in, out, ng)) + al256(kan_f32_pack_dx_bytes(in, out, ng));
 }
 
 int fastkan_fwd(const float* x, long ldx, long N, int in, int out, int ng, const float* centers,
                 float den, const float* lnw, const float* lnb, float eps, const float* sw,
                 const float* bw, const float* bb, float* y, long ldy, float* stats, void* ws,
-                size_t ws_bytes, hipStream_t st) {
-    if (ws_bytes < fastkan_fwd_ws_bytes(N, in, out, ng)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "fastkan_fwd");
+                size_t ws_bytes, int mode, hipStream_t st) {
+    if (ws_bytes < fastkan_fwd_ws_bytes(N, in, out, ng, mode)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "fastkan_fwd");
     if (lnw && !stats) return fail(KAGNN_ERR_ARG, "%s: row_stats is required with layernorm", "fastkan_fwd");
+    if (fk_split(in, out, ng, mode)) {
+        if (lnw) {
+            fastkan_stats_kernel<<<cdiv(N, 16), 256, 0, st>>>(x, ldx, N, in, eps, stats);
+            KAGNN_LAUNCH_CHECK();
+        }
+        { int rc = kan_split_pack_fwd_noscale(bw, sw, nullptr, in, out, ng, ws, st); if (rc) return rc; }
+        return kan_split_fwd_any(x, ldx, N, nullptr, in, out, ng, 0, ws, y, ldy,
+                                 fk_rbf(centers, ng, den, lnw, lnb, stats, bb, nullptr), st);
+    }
     float* pf = (float*)ws;
     float* pd = (float*)((char*)ws + al256(kan_f32_pack_fwd_bytes(in, out, ng)));
     { int rc = kan_f32_pack(bw, sw, nullptr, in, out, ng, pf, pd, st); if (rc) return rc; }
@@ -358,18 +428,28 @@ int fastkan_fwd(const float* x, long ldx, long N, int in, int out, int ng, const
 struct FkBwdPlan {
     size_t pack_f, pack_d, gz, gcat, slab, lnpart, colpart, total;
     int nb; long rpw; long NS; long per; int ln_blocks; int col_blocks; long col_rpb;
+    bool split;
 };
 
-static FkBwdPlan fk_plan(long N, int in, int out, int ng) {
+static FkBwdPlan fk_plan(long N, int in, int out, int ng, int mode) {
     FkBwdPlan p;
-    p.pack_f = al256(kan_f32_pack_fwd_bytes(in, out, ng));
-    p.pack_d = al256(kan_f32_pack_dx_bytes(in, out, ng));
+    p.split = fk_split(in, out, ng, mode);
     p.gz = al256((size_t)N * in * 4);
-    dw_plan(N, in, out, &p.nb, &p.rpw);
-    p.NS = (long)p.nb * 4;
-    p.per = (long)(ng + 1) * 32 * cdiv(in, 32) * 32 * cdiv(out, 32);
-    p.gcat = al256((size_t)p.per * 4);
-    p.slab = al256((size_t)p.NS * p.per * 4);
+    if (p.split) {
+        p.pack_f = 0;
+        p.pack_d = al256(kan_split_pack_dx_bytes(in, out, ng));
+        p.gcat = 0;                                   // gcat + slabs live inside the split kernel's own workspace
+        p.slab = al256(kan_split_dw_ws_bytes(N, in, out, ng));
+        p.nb = 0; p.rpw = 0; p.NS = 0; p.per = 0;
+    } else {
+        p.pack_f = al256(kan_f32_pack_fwd_bytes(in, out, ng));
+        p.pack_d = al256(kan_f32_pack_dx_bytes(in, out, ng));
+        dw_plan(N, in, out, &p.nb, &p.rpw);
+        p.NS = (long)p.nb * 4;
+        p.per = (long)(ng + 1) * 32 * cdiv(in, 32) * 32 * cdiv(out, 32);
+        p.gcat = al256((size_t)p.per * 4);
+        p.slab = al256((size_t)p.NS * p.per * 4);
+    }
     p.ln_blocks = (int)min(256L, (N + 3) / 4 > 0 ? (N + 3) / 4 : 1);
     p.lnpart = al256((size_t)p.ln_blocks * 4 * 2 * in * 4);
     p.col_blocks = (int)max(1L, min(1024L, N / 64 + 1));
@@ -379,16 +459,16 @@ static FkBwdPlan fk_plan(long N, int in, int out, int ng) {
     return p;
 }
 
-size_t fastkan_bwd_ws_bytes(long N, int in, int out, int ng) { return fk_plan(N, in, out, ng).total; }
+size_t fastkan_bwd_ws_bytes(long N, int in, int out, int ng, int mode) { return fk_plan(N, in, out, ng, mode).total; }
 
 int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int ng,
                 const float* centers, float den, const float* lnw, const float* lnb, float eps,
                 const float* sw, const float* bw, const float* stats, float* gx, long ldgx,
                 float* g_lnw, float* g_lnb, float* g_sw, float* g_bw, float* g_bb, void* ws,
-                size_t ws_bytes, hipStream_t st) {
-    const FkBwdPlan p = fk_plan(N, in, out, ng);
+                size_t ws_bytes, int mode, hipStream_t st) {
+    const FkBwdPlan p = fk_plan(N, in, out, ng, mode);
     if (ws_bytes < p.total) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "fastkan_bwd");
-    if (lnw && in > 64 * kLnMaxT) return fail(KAGNN_ERR_UNSUPPORTED, "%s: layernorm backward supports input_dim <= 1024", "fastkan_bwd");
+    if (lnw && in > 64 * kLnMaxT) return fail(KAGNN_ERR_UNSUPPORTED, "%s: layernorm backward supports input_dim <= 4096", "fastkan_bwd");
     char* q = (char*)ws;
     float* pf = (float*)q; q += p.pack_f;
     float* pd = (float*)q; q += p.pack_d;
@@ -397,22 +477,48 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
     float* slab = (float*)q; q += p.slab;
     float* lnpart = (float*)q; q += p.lnpart;
     float* colpart = (float*)q;
+    if (p.split) {
+        // same split-precision kernels as the B-spline layer, K == 0 selecting the RBF basis
+        const RbfArgs rb = fk_rbf(centers, ng, den, lnw, lnb, stats, nullptr, gz);
+        if (N > 0) {
+            int rc = kan_split_pack_dx_noscale(bw, sw, nullptr, in, out, ng, pd, st);
+            if (rc) return rc;
+            rc = kan_split_dx_any(x, ldx, gy, ldgy, N, nullptr, in, out, ng, 0, pd, gx, ldgx, rb, st);
+            if (rc) return rc;
+        }
+        if (lnw) {
+            LnArgs ln{lnw, lnb, eps};
+            { int rc = launch_ln_bwd(p.ln_blocks, x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart, st); if (rc) return rc; }
+            sum_partials_kernel<<<cdiv(2L * in, 256), 256, 0, st>>>(lnpart, p.ln_blocks * 4L, 2L * in, 2L * in, g_lnw, g_lnb, in);
+            KAGNN_LAUNCH_CHECK();
+        }
+        { int rc = kan_split_dw_any(x, ldx, gy, ldgy, N, nullptr, in, out, ng, 0, sw, nullptr, g_bw, g_sw, nullptr,
+                                    slab, p.slab, rb, st); if (rc) return rc; }
+        if (g_bb) {
+            colsum_partial_kernel<<<p.col_blocks, 256, 0, st>>>(gy, ldgy, N, out, p.col_rpb, colpart);
+            KAGNN_LAUNCH_CHECK();
+            sum_partials_kernel<<<cdiv(out, 256), 256, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
+            KAGNN_LAUNCH_CHECK();
+        }
+        return KAGNN_OK;
+    }
     const float inv_den = 1.0f / den;
     LnArgs ln{lnw, lnb, eps};
     const int OTt = cdiv(out, 32), FT = cdiv(in, 32);
     if (N > 0) {
         int rc = kan_f32_pack(bw, sw, nullptr, in, out, ng, pf, pd, st);
         if (rc) return rc;
-        const size_t lds = (kMaxKnots + 4L * 32 * (32 * OTt + 1)) * sizeof(float);
+        int W = 4;                                    // waves per workgroup: as many as the gy tiles leave LDS for
+        while (W > 1 && (kMaxKnots + (size_t)W * 32 * (32 * OTt + 1)) * sizeof(float) > 160 * 1024) W >>= 1;
+        const size_t lds = (kMaxKnots + (size_t)W * 32 * (32 * OTt + 1)) * sizeof(float);
         if (lds > 160 * 1024) return fail(KAGNN_ERR_UNSUPPORTED, "%s: output_dim too large", "fastkan_bwd");
         if (lds > 64 * 1024)
             KAGNN_HIP(hipFuncSetAttribute((const void*)fastkan_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        fastkan_dx_kernel<<<cdiv(N, 128), 256, lds, st>>>(x, ldx, gy, ldgy, N, in, out, ng, centers, inv_den, ln, stats, pd, OTt, gx, ldgx, gz);
+        fastkan_dx_kernel<<<cdiv(N, 32 * W), 64 * W, lds, st>>>(x, ldx, gy, ldgy, N, in, out, ng, centers, inv_den, ln, stats, pd, OTt, gx, ldgx, gz);
         KAGNN_LAUNCH_CHECK();
     }
     if (lnw) {
-        fastkan_ln_bwd_kernel<<<p.ln_blocks, 256, 0, st>>>(x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart);
-        KAGNN_LAUNCH_CHECK();
+        { int rc = launch_ln_bwd(p.ln_blocks, x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart, st); if (rc) return rc; }
         sum_partials_kernel<<<cdiv(2L * in, 256), 256, 0, st>>>(lnpart, p.ln_blocks * 4L, 2L * in, 2L * in, g_lnw, g_lnb, in);
         KAGNN_LAUNCH_CHECK();
     }

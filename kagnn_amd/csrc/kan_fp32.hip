@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* s_gy = smem + kMaxKnots + (long)wave * 32 * ldt;
     if (threadIdx.x < nknots) s_knots[threadIdx.x] = knots_g[threadIdx.x];
-    const long row0 = ((long)blockIdx.x * 4 + wave) * 32;
+    const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 32;
     // stage this wave's gy tile [32][outP] (zero padded)
     for (int i = lane; i < 32 * outP; i += 64) {
         const int rr = i / outP, o = i - rr * outP;
@@ -294,7 +294,7 @@ __global__ void kan_dw_unpack_kernel(const float* __restrict__ gcat, int in, int
         gs = fmaf(g, sw[of * C + c], gs);
     }
     if (g_sc) g_sc[of] = gs;
-    g_bw[of] = gcat[((long)C * inP + f) * outP + o];
+    if (g_bw) g_bw[of] = gcat[((long)C * inP + f) * outP + o];
 }
 
 int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP, const float* sw,
@@ -355,15 +355,17 @@ int kan_f32_dx(const float* x, long ldx, const float* gy, long ldgy, long N, con
                long ldgx, hipStream_t st) {
     const int g = G + 2 * K + 1;   // number of knots
     const int C = G + K, OTt = cdiv(out, 32);
-    const size_t lds = (kMaxKnots + 4L * 32 * (32 * OTt + 1)) * sizeof(float);
+    int W = 4;                                        // waves per workgroup: as many as the gy tiles leave LDS for
+    while (W > 1 && (kMaxKnots + (size_t)W * 32 * (32 * OTt + 1)) * sizeof(float) > 160 * 1024) W >>= 1;
+    const size_t lds = (kMaxKnots + (size_t)W * 32 * (32 * OTt + 1)) * sizeof(float);
     if (lds > 160 * 1024) return fail(KAGNN_ERR_UNSUPPORTED, "%s: out_features too large for the fp32 dx kernel", "kan_f32_dx");
-    dim3 grid(cdiv(N, 128));
+    dim3 grid(cdiv(N, 32 * W));
 #define L(KK)                                                                                     \
     {                                                                                             \
         if (lds > 64 * 1024)                                                                      \
             KAGNN_HIP(hipFuncSetAttribute((const void*)kan_dx_f32_kernel<KK>,                     \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kan_dx_f32_kernel<KK><<<grid, 256, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, g, pack, OTt, gx, ldgx); \
+        kan_dx_f32_kernel<KK><<<grid, 64 * W, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, g, pack, OTt, gx, ldgx); \
     }
     switch (K) {
         case 1: L(1) break;

@@ -30,31 +30,22 @@ __host__ __device__ inline size_t split_fwd_chunk_bytes(int OT) {
     return (size_t)(CF / 2) * OT * 2 * 1024 + (size_t)(CF / 16) * OT * 3 * 1024;
 }
 
+// K == 0 denotes the Gaussian RBF basis of FastKAN (G = num_grids slots)
 bool kan_split_fwd_ok(int in, int out, int G, int K) {
-    return K >= 1 && K <= 3 && G + K <= 8 && out <= 128;
+    return K >= 0 && K <= 3 && G + K <= 8;
 }
 
-size_t kan_split_pack_fwd_bytes(int in, int out, int C) {
-    const int OT = cdiv(out, 32), CF = split_cf(OT);
+// Outputs are processed in blocks of <= 128 columns (4 accumulator tiles per wave); every block has its
+// own pack (own power-of-two weight scale) at a fixed stride.
+static size_t fwd_blk_bytes(int in, int ob, int C) {
+    const int OT = cdiv(ob, 32), CF = split_cf(OT);
     return kHdrBytes + (size_t)cdiv(in, CF) * split_fwd_chunk_bytes(OT);
+}
+size_t kan_split_pack_fwd_bytes(int in, int out, int C) {
+    return (size_t)cdiv(out, kOutBlk) * fwd_blk_bytes(in, min(out, kOutBlk), C);
 }
 
 // ------------------------------------------------------------------ packing
-// absmax over Wcat -> hdr[2] (uint bits of a non-negative float; atomicMax works on the bits)
-__global__ void split_absmax_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
-                                    const float* __restrict__ sc, int in, int out, int C,
-                                    unsigned* __restrict__ hdr) {
-    float m = 0.0f;
-    const long n = (long)out * in * (C + 1);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int c = i % (C + 1); const long of = i / (C + 1);
-        const float v = fabsf(wcat_s(bw, sw, sc, in, out, C, (int)(of / in), (int)(of % in), c));
-        m = fmaxf(m, (v <= 3.0e38f) ? v : 0.0f);        // ignore inf/nan for the scale choice
-    }
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(hdr + 2, __float_as_uint(m));
-}
-
 __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
                                       const float* __restrict__ sc, int in, int out, int C,
                                       unsigned char* __restrict__ pack, int self_scale) {
@@ -116,7 +107,7 @@ template <int K, int OT, int NT>
 __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g,
     int nknots, const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy,
-    int out) {
+    int out, RbfArgs rb) {
     constexpr int CF = (OT <= 2) ? 64 : 32, HF = CF / 2, SPC = CF / 2, BPC = CF / 16;
     constexpr int CHUNK_BYTES = SPC * OT * 2 * 1024 + BPC * OT * 3 * 1024;
     constexpr int NG = HF / 8;                       // groups of 8 features per lane-half and chunk
@@ -126,8 +117,8 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
     unsigned char* s_w = smem + kLdsHdr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < nknots) s_knots[tid] = knots_g[tid];
-    if (K == 3) build_perm_table3(s_tbl, tid, nknots); else build_perm_table(s_tbl, tid);
+    if (K > 0 && tid < nknots) s_knots[tid] = knots_g[tid];
+    if (K == 3) build_perm_table3(s_tbl, tid, nknots); else if (K > 0) build_perm_table(s_tbl, tid);
     const float post = reinterpret_cast<const float*>(pack)[0];
     const unsigned char* gw = pack + kHdrBytes;
     auto stage_chunk = [&](int ch) {
@@ -137,8 +128,10 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     };
     if (nchunks == 1) stage_chunk(0);
     __syncthreads();
-    const SplineGeom geom = geom_from_knots(s_knots, nknots);
-    const Frag3Geom f3geo = frag3_geom(s_knots, nknots);
+    SplineGeom geom{}; Frag3Geom f3geo{};
+    float ca[8] = {};
+    if constexpr (K == 0) rbf_centers(rb, ca);
+    if constexpr (K > 0) { geom = geom_from_knots(s_knots, nknots); f3geo = frag3_geom(s_knots, nknots); }
     const int r = lane & 31, kg = lane >> 5;
     const bool al4 = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 
@@ -170,6 +163,11 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
         for (int t = 0; t < OT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+        float mean = 0.0f, rstd = 1.0f;                  // K == 0 with layernorm: this lane's row statistics
+        if (K == 0 && rb.ln_w) {
+            const long rc = min(row0 + r, N - 1);
+            mean = rb.stats[2 * rc]; rstd = rb.stats[2 * rc + 1];
+        }
 
         for (int ch = 0; ch < nchunks; ++ch) {
             if (nchunks > 1) {
@@ -250,12 +248,24 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                         }
                     }
                 } else {
-                // ---- generic orders (K = 1, 2): one MFMA step per feature, exact knot comparisons
+                // ---- generic orders (K = 1, 2: exact knot comparisons) and the RBF basis (K == 0): one MFMA
+                // step per feature
+                float gam[8] = {}, bet[8] = {};
+                if (K == 0 && rb.ln_w) {                   // wave-uniform
+                    const int f0 = ch * CF + kg * HF + 8 * g;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const int fc = min(f0 + j, in - 1); gam[j] = rb.ln_w[fc]; bet[j] = rb.ln_b[fc]; }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int s = 8 * g + j;
                     u32x4 ahi, alo;
-                    make_spline_frag<K>(xv[j], s_knots, s_tbl, geom, ahi, alo);
+                    if constexpr (K == 0) {
+                        const float z = rb.ln_w ? fmaf((xv[j] - mean) * rstd, gam[j], bet[j]) : xv[j];
+                        make_rbf_frag(z, rb.a, ca, ahi, alo);
+                    } else {
+                        make_spline_frag<K>(xv[j], s_knots, s_tbl, geom, ahi, alo);
+                    }
                     const unsigned char* wp = s_w + (size_t)(s * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
                     for (int t = 0; t < OT; ++t) {
@@ -294,47 +304,35 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
             const int col = 32 * t + r;
             const unsigned base = (unsigned)(row0 + 4 * kg) * ldy4 + col * 4;
             if (col < out) {
+                const float bb = (K == 0 && rb.bias) ? rb.bias[col] : 0.0f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped
-                    gst_s(yb, base, (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, acc[t][i] * post);
+                    gst_s(yb, base, (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, fmaf(acc[t][i], post, bb));
             }
         }
     }
 }
 
 // ------------------------------------------------------------------ host side
-int split_absmax(const float* bw, const float* sw, const float* sc, int in, int out, int C, unsigned* hdr, hipStream_t st) {
-    const long n = (long)out * in * (C + 1);
-    split_absmax_kernel<<<(int)min((n + 255) / 256, 1024L), 256, 0, st>>>(bw, sw, sc, in, out, C, hdr);
-    KAGNN_LAUNCH_CHECK();
-    return KAGNN_OK;
-}
-
 int kan_split_pack_fwd_noscale(const float* bw, const float* sw, const float* sc, int in, int out, int C,
                                void* pack_fwd, hipStream_t st) {
-    unsigned char* pf = static_cast<unsigned char*>(pack_fwd);
-    const long items = (long)(kan_split_pack_fwd_bytes(in, out, C) - kHdrBytes) / 16;
-    split_pack_fwd_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(bw, sw, sc, in, out, C, pf, 1);
-    KAGNN_LAUNCH_CHECK();
-    return KAGNN_OK;
-}
-
-int kan_split_pack_fwd(const float* bw, const float* sw, const float* sc, int in, int out, int C,
-                       void* pack_fwd, hipStream_t st) {
-    unsigned char* pf = static_cast<unsigned char*>(pack_fwd);
-    KAGNN_HIP(hipMemsetAsync(pf, 0, kHdrBytes, st));
-    const long n = (long)out * in * (C + 1);
-    split_absmax_kernel<<<(int)min((n + 255) / 256, 1024L), 256, 0, st>>>(bw, sw, sc, in, out, C, reinterpret_cast<unsigned*>(pf));
-    KAGNN_LAUNCH_CHECK();
-    const long items = (long)(kan_split_pack_fwd_bytes(in, out, C) - kHdrBytes) / 16;
-    split_pack_fwd_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, pf, 0);
-    KAGNN_LAUNCH_CHECK();
+    const size_t stride = fwd_blk_bytes(in, min(out, kOutBlk), C);
+    for (int b = 0; b * kOutBlk < out; ++b) {
+        const int ob = min(kOutBlk, out - b * kOutBlk);
+        const long o0 = (long)b * kOutBlk;
+        unsigned char* pf = static_cast<unsigned char*>(pack_fwd) + b * stride;
+        const long items = (long)(fwd_blk_bytes(in, ob, C) - kHdrBytes) / 16;
+        split_pack_fwd_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(
+            bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C, pf, 1);
+        KAGNN_LAUNCH_CHECK();
+    }
     return KAGNN_OK;
 }
 
 template <int K, int OT>
 static int launch_fwd(const float* x, long ldx, long N, int in, const float* knots, int nknots,
-                      const unsigned char* pack, int nchunks, float* y, long ldy, int out, hipStream_t st) {
+                      const unsigned char* pack, int nchunks, float* y, long ldy, int out, const RbfArgs& rb,
+                      hipStream_t st) {
     constexpr int NT = (OT <= 2) ? 1024 : 512;       // 4 waves per SIMD when the accumulators leave room (<= 128 VGPRs)
     const size_t lds = kLdsHdr + split_fwd_chunk_bytes(OT);
     static bool configured = false;
@@ -344,18 +342,19 @@ static int launch_fwd(const float* x, long ldx, long N, int in, const float* kno
         configured = true;
     }
     const int grid = (int)min((long)cdiv(N, NT / 2), 256L);
-    kan_split_fwd_kernel<K, OT, NT><<<grid, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out);
+    kan_split_fwd_kernel<K, OT, NT><<<grid, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, rb);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
 
-int kan_split_fwd(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
-                  const void* pack, float* y, long ldy, hipStream_t st) {
-    const int OT = cdiv(out, 32), nk = G + 2 * K + 1, nch = cdiv(in, split_cf(OT));
-    const unsigned char* p = static_cast<const unsigned char*>(pack);
-#define GO(KK, TT) return launch_fwd<KK, TT>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, st)
+// one <= 128-column output block
+static int fwd_block(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
+                     const unsigned char* p, float* y, long ldy, const RbfArgs& rb, hipStream_t st) {
+    const int OT = cdiv(out, 32), nk = K ? G + 2 * K + 1 : 0, nch = cdiv(in, split_cf(OT));
+#define GO(KK, TT) return launch_fwd<KK, TT>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, st)
 #define BYOT(KK) switch (OT) { case 1: GO(KK, 1); case 2: GO(KK, 2); case 3: GO(KK, 3); case 4: GO(KK, 4); }
     switch (K) {
+        case 0: BYOT(0) break;
         case 1: BYOT(1) break;
         case 2: BYOT(2) break;
         case 3: BYOT(3) break;
@@ -365,6 +364,24 @@ int kan_split_fwd(const float* x, long ldx, long N, const float* knots, int in, 
     return fail(KAGNN_ERR_UNSUPPORTED, "%s: shape not covered by the split path", "kan_split_fwd");
 }
 
+// K == 0: Gaussian RBF basis with G = num_grids (rb holds centres / layernorm / bias), else B-splines
+int kan_split_fwd_any(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
+                      const void* pack, float* y, long ldy, const RbfArgs& rb, hipStream_t st) {
+    const size_t stride = fwd_blk_bytes(in, min(out, kOutBlk), G + K);
+    for (int b = 0; b * kOutBlk < out; ++b) {
+        RbfArgs rbb = rb;
+        if (rbb.bias) rbb.bias += b * kOutBlk;
+        const int rc = fwd_block(x, ldx, N, knots, in, min(kOutBlk, out - b * kOutBlk), G, K,
+                                 static_cast<const unsigned char*>(pack) + b * stride, y + b * kOutBlk, ldy, rbb, st);
+        if (rc) return rc;
+    }
+    return KAGNN_OK;
+}
+
+int kan_split_fwd(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
+                  const void* pack, float* y, long ldy, hipStream_t st) {
+    return kan_split_fwd_any(x, ldx, N, knots, in, out, G, K, pack, y, ldy, RbfArgs{}, st);
+}
 
 // ---- input-gradient / weight-gradient split kernels: see kan_split_bwd.hip
 }  // namespace kagnn

@@ -18,7 +18,6 @@
 
 namespace kagnn {
 
-int split_absmax(const float*, const float*, const float*, int, int, int, unsigned*, hipStream_t);
 int kan_dw_reduce(const float* slab, long NS, long per_slab, float* gcat, hipStream_t st);
 int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP, const float* sw,
                   const float* sc, float* g_bw, float* g_sw, float* g_sc, hipStream_t st);
@@ -27,10 +26,14 @@ int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP
 constexpr int kCTmax = 9;     // C + 1 <= 9 accumulators (8 spline coefficients + base); unused slots carry zero weights
 static inline int dx_q2(int out) { return out <= 32 ? 1 : (out <= 64 ? 2 : 4); }   // 32-wide k-steps
 
-bool kan_split_dx_ok(int in, int out, int G, int K) { return K >= 1 && K <= 3 && G + K <= 8 && out <= 128; }
+bool kan_split_dx_ok(int in, int out, int G, int K) { return K >= 0 && K <= 3 && G + K <= 8; }   // K == 0: RBF basis
 
+// outputs (the contraction dimension here) go in blocks of <= 128, one pack / launch per block
+static size_t dx_blk_bytes(int in, int ob) {
+    return kHdrBytes + (size_t)cdiv(in, 16) * kCTmax * dx_q2(ob) * 2 * 1024;   // always 9 slots: branch-free MFMA loop
+}
 size_t kan_split_pack_dx_bytes(int in, int out, int C) {
-    return kHdrBytes + (size_t)cdiv(in, 16) * kCTmax * dx_q2(out) * 2 * 1024;   // always 9 slots: branch-free MFMA loop
+    return (size_t)cdiv(out, kOutBlk) * dx_blk_bytes(in, min(out, kOutBlk));
 }
 
 // pack_dx[ft16][c][q2][part][lane][8] : lane (f = lane&15, kg = lane>>4), j -> W'[o = 32*q2+8*kg+j][16*ft16+f][c]
@@ -69,23 +72,16 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
 
 int kan_split_pack_dx_noscale(const float* bw, const float* sw, const float* sc, int in, int out, int C,
                               void* pack_dx, hipStream_t st) {
-    const int Q2 = dx_q2(out);
-    const long items = (long)cdiv(in, 16) * kCTmax * Q2 * 64;
-    split_pack_dx_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(bw, sw, sc, in, out, C, Q2,
-                                                                                static_cast<unsigned char*>(pack_dx), 1);
-    KAGNN_LAUNCH_CHECK();
-    return KAGNN_OK;
-}
-
-int kan_split_pack_dx(const float* bw, const float* sw, const float* sc, int in, int out, int C,
-                      void* pack_dx, hipStream_t st) {
-    unsigned char* p = static_cast<unsigned char*>(pack_dx);
-    KAGNN_HIP(hipMemsetAsync(p, 0, kHdrBytes, st));
-    { int rc = split_absmax(bw, sw, sc, in, out, C, reinterpret_cast<unsigned*>(p), st); if (rc) return rc; }
-    const int Q2 = dx_q2(out);
-    const long items = (long)cdiv(in, 16) * kCTmax * Q2 * 64;
-    split_pack_dx_kernel<<<(int)min((items + 255) / 256, 2048L), 256, 0, st>>>(bw, sw, sc, in, out, C, Q2, p, 0);
-    KAGNN_LAUNCH_CHECK();
+    const size_t stride = dx_blk_bytes(in, min(out, kOutBlk));
+    for (int b = 0; b * kOutBlk < out; ++b) {
+        const int ob = min(kOutBlk, out - b * kOutBlk), Q2 = dx_q2(ob);
+        const long o0 = (long)b * kOutBlk;
+        const long items = (long)cdiv(in, 16) * kCTmax * Q2 * 64;
+        split_pack_dx_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(
+            bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C, Q2,
+            static_cast<unsigned char*>(pack_dx) + b * stride, 1);
+        KAGNN_LAUNCH_CHECK();
+    }
     return KAGNN_OK;
 }
 
@@ -125,12 +121,13 @@ template <int K, int Q2>
 __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
-    const unsigned char* __restrict__ pack, int resident, float* __restrict__ gx, long ldgx) {
+    const unsigned char* __restrict__ pack, int resident, float* __restrict__ gx, long ldgx,
+    RbfArgs rb, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* s_knots = reinterpret_cast<float*>(smem);
     unsigned char* s_w = smem + kLdsHdr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < nknots) s_knots[tid] = knots_g[tid];
+    if (K > 0 && tid < nknots) s_knots[tid] = knots_g[tid];
     const int FT = cdiv(in, 16);
     constexpr int FT_BYTES = kCTmax * Q2 * 2 * 1024;
     const int e_w = reinterpret_cast<const int*>(pack)[1];
@@ -143,8 +140,12 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     };
     if (resident) stage(0, FT);
     __syncthreads();
-    const SplineGeom geom = geom_from_knots(s_knots, nknots);
-    const FastGeom fgeo = fast_geom(s_knots, nknots);
+    SplineGeom geom{}; FastGeom fgeo{};
+    float ca[8] = {};
+    if constexpr (K == 0) rbf_centers(rb, ca);
+    if constexpr (K > 0) { geom = geom_from_knots(s_knots, nknots); fgeo = fast_geom(s_knots, nknots); }
+    const bool ln_on = (K == 0) && rb.ln_w != nullptr;           // wave-uniform
+    const GBuf gzb = gbuf(rb.gz, N, in, in);
     const int li = lane & 15, kg = lane >> 4;
     const bool al4 = ((ldgy & 3) == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
     const GBuf xb = gbuf(x, N, ldx, in), gyb = gbuf(gy, N, ldgy, out), gxb = gbuf(gx, N, ldgx, in);
@@ -155,6 +156,17 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
         const unsigned gy_ro = (unsigned)(row0 + li) * ldgy4;
         const unsigned x_ro = (unsigned)(row0 + 4 * kg) * ldx4 + min(li, in - 1) * 4;    // + 64 B per 16-feature tile
         const unsigned gx_ro = (unsigned)(row0 + 4 * kg) * ldgx4 + li * 4;
+        const unsigned gz_ro = (unsigned)(row0 + 4 * kg) * (unsigned)in * 4u + li * 4;
+        float mu[2][4], rs[2][4];                          // layernorm statistics of this lane's 8 rows
+        if (ln_on) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const long rc = min(row0 + 16 * rt + 4 * kg + reg, N - 1);
+                    mu[rt][reg] = rb.stats[2 * rc]; rs[rt][reg] = rb.stats[2 * rc + 1];
+                }
+        }
         // ---- A operand: gy rows scaled per row by 2^(10 - rexp), split into fp16 hi / lo
         u32x4 ahi[2][Q2], alo[2][Q2];
         float rinv[2][4];
@@ -204,6 +216,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             const unsigned char* wft = s_w + (size_t)(resident ? ft : 0) * FT_BYTES + lane * 16;
             // this lane's 8 x values of the tile: issue the loads now, they land under the MFMAs
             const int f = 16 * ft + li;
+            float gam = 1.0f, bet = 0.0f;
+            if (ln_on) { gam = rb.ln_w[min(f, in - 1)]; bet = rb.ln_b[min(f, in - 1)]; }
             float xq[2][4];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -247,6 +261,31 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const float xv = xq[rt][reg];
+                    if constexpr (K == 0) {
+                        // Gaussian RBF: gz = k2 * sum_g D_g * phi_g(z) * t_g   (gradient w.r.t. z), gb = D_base * silu'(x)
+                        const float z = ln_on ? fmaf((xv - mu[rt][reg]) * rs[rt][reg], gam, bet) : xv;
+                        const float t0 = z * rb.a;
+                        float sgz = 0.0f;
+#pragma unroll
+                        for (int g = 0; g < kCTmax - 1; ++g) {
+                            const float t = t0 - ca[g];
+                            sgz = fmaf(D[g][rt][reg], __builtin_amdgcn_exp2f(-t * t) * t, sgz);
+                        }
+                        float vz = sgz * rb.k2 * rinv[rt][reg];
+                        float vb = D[kCTmax - 1][rt][reg] * silu_gradf(xv) * rinv[rt][reg];
+                        const unsigned so_x = (unsigned)(16 * rt + reg) * ldgx4, so_z = (unsigned)(16 * rt + reg) * (unsigned)in * 4u;
+                        if (f < in) {
+                            if (ln_on) {
+                                if (accumulate) { vz += gld_s(gzb, gz_ro + ft * 64, so_z); vb += gld_s(gxb, gx_ro + ft * 64, so_x); }
+                                gst_s(gzb, gz_ro + ft * 64, so_z, vz);
+                                gst_s(gxb, gx_ro + ft * 64, so_x, vb);
+                            } else {
+                                float v = vz + vb;
+                                if (accumulate) v += gld_s(gxb, gx_ro + ft * 64, so_x);
+                                gst_s(gxb, gx_ro + ft * 64, so_x, v);
+                            }
+                        }
+                    } else {
                     float dN[K + 1];
                     int m;
                     if constexpr (K == 3) {
@@ -260,8 +299,13 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     float d[kCTmax - 1];                       // per-coefficient sums (slots >= C are exact zeros)
 #pragma unroll
                     for (int c = 0; c < kCTmax - 1; ++c) d[c] = D[c][rt][reg];
-                    const float s = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot<K>(d, m, dN));
-                    if (f < in) gst_s(gxb, gx_ro + ft * 64, (unsigned)(16 * rt + reg) * ldgx4, s * rinv[rt][reg]);   // rows >= N: dropped
+                    float s = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot<K>(d, m, dN)) * rinv[rt][reg];
+                    if (f < in) {
+                        const unsigned so_x = (unsigned)(16 * rt + reg) * ldgx4;
+                        if (accumulate) s += gld_s(gxb, gx_ro + ft * 64, so_x);         // second and later output blocks
+                        gst_s(gxb, gx_ro + ft * 64, so_x, s);                           // rows >= N: dropped
+                    }
+                    }
                 }
             }
         }
@@ -271,7 +315,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
 template <int K, int Q2>
 static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                      const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
-                     hipStream_t st) {
+                     const RbfArgs& rb, int accumulate, hipStream_t st) {
     const int FT = cdiv(in, 16);
     const size_t ft_bytes = (size_t)kCTmax * Q2 * 2 * 1024;
     const size_t budget = 160 * 1024 - kLdsHdr;
@@ -285,18 +329,19 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
     }
     const int grid = (int)min((long)cdiv(N, 256), 256L);
     kan_split_dx_kernel<K, Q2><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
-                                                       resident ? 1 : 0, gx, ldgx);
+                                                       resident ? 1 : 0, gx, ldgx, rb, accumulate);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
 
-int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
-                 int out, int G, int K, const void* pack, float* gx, long ldgx, hipStream_t st) {
-    const int C = G + K, nk = G + 2 * K + 1, Q2 = dx_q2(out);
-    const unsigned char* p = static_cast<const unsigned char*>(pack);
-#define GO(KK, QQ) return launch_dx<KK, QQ>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, st)
+static int dx_block(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
+                    int out, int G, int K, const unsigned char* p, float* gx, long ldgx, const RbfArgs& rb,
+                    int accumulate, hipStream_t st) {
+    const int C = G + K, nk = K ? G + 2 * K + 1 : 0, Q2 = dx_q2(out);
+#define GO(KK, QQ) return launch_dx<KK, QQ>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, rb, accumulate, st)
 #define BYQ(KK) switch (Q2) { case 1: GO(KK, 1); case 2: GO(KK, 2); case 4: GO(KK, 4); }
     switch (K) {
+        case 0: BYQ(0) break;
         case 1: BYQ(1) break;
         case 2: BYQ(2) break;
         case 3: BYQ(3) break;
@@ -306,8 +351,26 @@ int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, c
     return fail(KAGNN_ERR_UNSUPPORTED, "%s: shape not covered by the split path", "kan_split_dx");
 }
 
+// K == 0: Gaussian RBF basis (with layernorm: rb.gz receives dL/dz, gx the base-branch part only)
+int kan_split_dx_any(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
+                     int out, int G, int K, const void* pack, float* gx, long ldgx, const RbfArgs& rb,
+                     hipStream_t st) {
+    const size_t stride = dx_blk_bytes(in, min(out, kOutBlk));
+    for (int b = 0; b * kOutBlk < out; ++b) {
+        const int rc = dx_block(x, ldx, gy + b * kOutBlk, ldgy, N, knots, in, min(kOutBlk, out - b * kOutBlk), G, K,
+                                static_cast<const unsigned char*>(pack) + b * stride, gx, ldgx, rb, b > 0, st);
+        if (rc) return rc;
+    }
+    return KAGNN_OK;
+}
+
+int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
+                 int out, int G, int K, const void* pack, float* gx, long ldgx, hipStream_t st) {
+    return kan_split_dx_any(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack, gx, ldgx, RbfArgs{}, st);
+}
+
 // ====================================================================== weight gradient
-bool kan_split_dw_ok(int in, int out, int G, int K) { return K >= 1 && K <= 3 && G + K <= 8; }
+bool kan_split_dw_ok(int in, int out, int G, int K) { return K >= 0 && K <= 3 && G + K <= 8; }   // K == 0: RBF basis
 
 struct DwPlan { int nbx; long rpw; long NS; long per; int FG, OC; long inP, outP; };
 
@@ -338,22 +401,25 @@ size_t kan_split_dw_ws_bytes(long N, int in, int out, int C) {
 // minimal instead of deeply pipelined: loads of chunk i+1 are issued, the MFMAs of chunk i run (and
 // cover the load latency), then chunk i+1 is expanded in place.  Everything non-accumulator fits the
 // 256 architectural VGPRs, so nothing shuttles through AGPRs.
-struct DwRaw { float x[8]; float g[4][8]; };
+struct DwRaw { float x[8]; float g[4][8]; float mu[8], rs[8]; };   // mu / rs: layernorm statistics (RBF basis only)
 
 template <int K>
 __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots, int OC, long rows_per_block,
-    long inP, long outP, float* __restrict__ slab) {
+    long inP, long outP, float* __restrict__ slab, RbfArgs rb) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsHdr];
     float* s_knots = reinterpret_cast<float*>(smem);
     unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < nknots) s_knots[tid] = knots_g[tid];
-    build_perm_table(s_tbl, tid);
+    if (K > 0 && tid < nknots) s_knots[tid] = knots_g[tid];
+    if (K > 0) build_perm_table(s_tbl, tid);
     __syncthreads();
-    const SplineGeom geom = geom_from_knots(s_knots, nknots);
-    const FastGeom fgeo = fast_geom(s_knots, nknots);
+    SplineGeom geom{}; FastGeom fgeo{};
+    float ca[8] = {};
+    if constexpr (K == 0) rbf_centers(rb, ca);
+    if constexpr (K > 0) { geom = geom_from_knots(s_knots, nknots); fgeo = fast_geom(s_knots, nknots); }
+    const bool ln_on = (K == 0) && rb.ln_w != nullptr;           // wave-uniform
     const int fg = blockIdx.y / OC, oc = blockIdx.y % OC;
     const int li = lane & 15, kg = lane >> 4;
     const int f = 64 * fg + 16 * wave + li;            // A side: this lane's feature
@@ -371,6 +437,9 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     for (int t = 0; t < 4; ++t) { Dh[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Df[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const GBuf xb = gbuf(x, N, ldx, in), gyb = gbuf(gy, N, ldgy, out);
+    const GBuf stb = gbuf(rb.stats, ln_on ? N : 0, 2, 2);      // rows >= N: (0, 0) -> z = beta, finite; their gy is 0
+    const float gam = ln_on ? rb.ln_w[min(f, in - 1)] : 1.0f, bet = ln_on ? rb.ln_b[min(f, in - 1)] : 0.0f;
+    unsigned sto = (unsigned)(rbeg + 8 * kg) * 8u;
     const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u;
     // per-lane byte offsets of the chunk being fetched; rows advance by 32 per call.  Unconditional buffer
     // loads: rows >= N read as 0 through the descriptor (rows_per_block is a multiple of 32, so a chunk
@@ -385,6 +454,11 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
             r.x[j] = gld_s(xb, xo, (unsigned)j * ldx4);
 #pragma unroll
             for (int t = 0; t < 4; ++t) r.g[t][j] = gld_s(gyb, gvo[t], (unsigned)j * ldgy4);
+        }
+        if (ln_on) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { r.mu[j] = gld(stb, sto + 8u * j); r.rs[j] = gld(stb, sto + 8u * j + 4u); }
+            sto += 32u * 8u;
         }
         xo += 32u * ldx4;
 #pragma unroll
@@ -421,7 +495,14 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
         }
         // ---- bases of 8 rows of this lane's feature
 #pragma unroll
-        for (int j = 0; j < 8; ++j) spline_frag<K>(r.x[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j]);
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (K == 0) {
+                const float z = ln_on ? fmaf((r.x[j] - r.mu[j]) * r.rs[j], gam, bet) : r.x[j];
+                make_rbf_frag(z, rb.a, ca, rh[j], rl[j]);
+            } else {
+                spline_frag<K>(r.x[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j]);
+            }
+        }
         // ---- SiLU branch: fp16 hi/lo at scale 2^4 (|silu| < 4094); larger values take the fp32 MFMA
         float sv[8];
         float smx = 0.0f;
@@ -509,17 +590,19 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     }
 }
 
-int kan_split_dw(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
-                 int out, int G, int K, const float* sw, const float* sc, float* g_bw, float* g_sw,
-                 float* g_sc, float* ws, size_t ws_bytes, hipStream_t st) {
-    const int C = G + K, nk = G + 2 * K + 1;
+// K == 0: Gaussian RBF basis with G = num_grids; sc == nullptr and g_sw laid out [out][in][G] either way
+int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
+                     int out, int G, int K, const float* sw, const float* sc, float* g_bw, float* g_sw,
+                     float* g_sc, float* ws, size_t ws_bytes, const RbfArgs& rb, hipStream_t st) {
+    const int C = G + K, nk = K ? G + 2 * K + 1 : 0;
     const DwPlan p = split_dw_plan(N, in, out, C);
     if (ws_bytes < (size_t)(p.NS + 1) * p.per * sizeof(float)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "kan_split_dw");
     float* gcat = ws;
     float* slab = ws + p.per;
     dim3 grid(p.nbx, p.FG * p.OC);
-#define L(KK) kan_split_dw_kernel<KK><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab)
+#define L(KK) kan_split_dw_kernel<KK><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb)
     switch (K) {
+        case 0: L(0); break;
         case 1: L(1); break;
         case 2: L(2); break;
         case 3: L(3); break;
@@ -529,6 +612,12 @@ int kan_split_dw(const float* x, long ldx, const float* gy, long ldgy, long N, c
     KAGNN_LAUNCH_CHECK();
     { int rc = kan_dw_reduce(slab, p.NS, p.per, gcat, st); if (rc) return rc; }
     return kan_dw_unpack(gcat, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, st);
+}
+
+int kan_split_dw(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
+                 int out, int G, int K, const float* sw, const float* sc, float* g_bw, float* g_sw,
+                 float* g_sc, float* ws, size_t ws_bytes, hipStream_t st) {
+    return kan_split_dw_any(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, ws, ws_bytes, RbfArgs{}, st);
 }
 
 }  // namespace kagnn

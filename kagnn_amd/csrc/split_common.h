@@ -9,11 +9,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kHdrBytes = 256;           // pack header: [0] float 2^(e-10), [1] int e, [2] absmax bits
 constexpr int kLdsHdr = 512;             // LDS: knots (48 f32) @0, perm table (16 x 16 B) @256
 constexpr float kAScale = 1024.0f;       // bases / silu pre-scale (2^10)
+constexpr int kOutBlk = 128;             // output columns per launch of the fwd / input-gradient kernels
 
 __device__ __forceinline__ float wcat_s(const float* bw, const float* sw, const float* sc, int in,
                                         int out, int C, int o, int f, int c) {
     if (o >= out || f >= in || c > C) return 0.0f;
-    if (c == C) return bw[(long)o * in + f];
+    if (c == C) return bw ? bw[(long)o * in + f] : 0.0f;
     float w = sw[((long)o * in + f) * C + c];
     return sc ? w * sc[(long)o * in + f] : w;
 }
@@ -69,7 +70,7 @@ __device__ __forceinline__ float block_absmax_w(const float* __restrict__ bw, co
     float m = 0.0f;
     const int nof = out * in;
     for (int of = threadIdx.x; of < nof; of += blockDim.x) {
-        float v = fabsf(bw[of]);
+        float v = bw ? fabsf(bw[of]) : 0.0f;
         m = fmaxf(m, (v <= 3.0e38f) ? v : 0.0f);
         const float scale = sc ? sc[of] : 1.0f;
         for (int c = 0; c < C; ++c) {
@@ -298,6 +299,37 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 }
 __device__ __forceinline__ f32x4 mfma16_f16(const u32x4& a, const u32x4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// ---- Gaussian RBF basis (FastKAN, fastkan.py:46-47) for the K == 0 instantiations of the split kernels:
+// phi_g(z) = exp(-((z - c_g)/den)^2) = exp2(-t_g^2) with t_g = a*z - a*c_g, a = sqrt(log2 e)/den.
+// z is the layer-normed input (fastkan.py:77-78) when ln_w != nullptr, else x itself.
+struct RbfArgs {
+    const float* centers;     // rbf.grid, num_grids device floats
+    int ng;
+    float a;                  // sqrt(log2 e) / denominator
+    float k2;                 // d phi_g/dz = phi_g * t_g * k2,  k2 = -2 a ln 2
+    const float* ln_w; const float* ln_b; const float* stats;   // stats[n] = (mean, rstd)
+    const float* bias;        // forward: added to y (base_linear.bias), may be nullptr
+    float* gz;                // input gradient: [N, in] gradient w.r.t. z when layernorm is on
+};
+
+// ca[g] = a * c_g (wave-uniform; slots >= num_grids repeat the last centre -- their packed weights are zero)
+__device__ __forceinline__ void rbf_centers(const RbfArgs& rb, float (&ca)[8]) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) ca[g] = rb.centers[min(g, rb.ng - 1)] * rb.a;
+}
+
+// 8 RBF values of one scalar, scaled by 2^10, as fp16 hi / lo fragments
+__device__ __forceinline__ void make_rbf_frag(float z, float a, const float (&ca)[8], u32x4& hi, u32x4& lo) {
+    const float t0 = z * a;
+    float v[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const float t = t0 - ca[g];
+        v[g] = __builtin_amdgcn_exp2f(fmaf(-t, t, 10.0f));
+    }
+    split_f16x2(v, hi, lo);
 }
 
 // power-of-two scale that brings |v| <= m below 2^10 (exact); 1 for m == 0 / non-finite

@@ -10,7 +10,7 @@ part of the KAGNN path and are not provided.
 """
 from __future__ import annotations
 
-from typing import List
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
@@ -57,6 +57,7 @@ class FastKANLayer(nn.Module):
         self.rbf = RadialBasisFunction(grid_min, grid_max, num_grids)
         self.spline_linear = SplineLinear(input_dim * num_grids, output_dim, spline_weight_init_scale)
         self.use_base_update = use_base_update
+        self.precision = None                     # None -> ops.default_precision()
         if use_base_update:
             self.base_activation = base_activation
             self.base_linear = nn.Linear(input_dim, output_dim)
@@ -71,7 +72,7 @@ class FastKANLayer(nn.Module):
             self.spline_linear.weight,
             self.base_linear.weight if self.use_base_update else None,
             self.base_linear.bias if self.use_base_update else None,
-            self.rbf.grid, self.rbf.denominator, 1e-5 if ln is None else ln.eps)
+            self.rbf.grid, self.rbf.denominator, 1e-5 if ln is None else ln.eps, self.precision)
         return y.reshape(*lead, self.output_dim)
 
 

@@ -361,7 +361,7 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
 # ======================================================================== FastKAN layer
 class _FastKANFn(Function):
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, spline_w, base_w, base_b, centers, denominator, ln_eps):
+    def forward(ctx, x, ln_w, ln_b, spline_w, base_w, base_b, centers, denominator, ln_eps, mode):
         _need_cuda(x, spline_w, centers)
         x = _rows(x)
         n, fin = x.shape
@@ -375,26 +375,26 @@ class _FastKANFn(Function):
         bw = None if base_w is None else base_w.contiguous()
         bb = None if base_b is None else base_b.contiguous()
         nb = c_size_t(0)
-        _call("kagnn_fastkan_fwd_workspace_bytes", n, fin, fout, ng, byref(nb))
+        _call("kagnn_fastkan_fwd_workspace_bytes", n, fin, fout, ng, mode, byref(nb))
         ws = _ws(nb.value, x.device)
         stats = torch.empty((n, 2), dtype=torch.float32, device=x.device) if lw is not None else None
         y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
         _call("kagnn_fastkan_fwd", _ptr(x), _ld(x), n, fin, fout, ng, _ptr(centers), float(denominator),
                   _ptr(lw), _ptr(lb), float(ln_eps), _ptr(sw), _ptr(bw), _ptr(bb), _ptr(y), fout,
-                  _ptr(stats), _ptr(ws), ws.numel(), _stream())
+                  _ptr(stats), mode, _ptr(ws), ws.numel(), _stream())
         ctx.save_for_backward(x, lw, lb, sw, bw, centers, stats)
-        ctx.meta = (fin, fout, ng, float(denominator), float(ln_eps), bb is not None)
+        ctx.meta = (fin, fout, ng, float(denominator), float(ln_eps), bb is not None, mode)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
         x, lw, lb, sw, bw, centers, stats = ctx.saved_tensors
-        fin, fout, ng, den, eps, has_bb = ctx.meta
+        fin, fout, ng, den, eps, has_bb, mode = ctx.meta
         gy = _rows(gy)
         n, dev = x.size(0), x.device
         nb = c_size_t(0)
-        _call("kagnn_fastkan_bwd_workspace_bytes", n, fin, fout, ng, byref(nb))
+        _call("kagnn_fastkan_bwd_workspace_bytes", n, fin, fout, ng, mode, byref(nb))
         ws = _ws(nb.value, dev)
         f32 = dict(dtype=torch.float32, device=dev)
         gx = torch.empty((n, fin), **f32)
@@ -405,12 +405,21 @@ class _FastKANFn(Function):
         gbb = torch.empty(fout, **f32) if bw is not None else None
         _call("kagnn_fastkan_bwd", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, fin, fout, ng, _ptr(centers), den,
                   _ptr(lw), _ptr(lb), eps, _ptr(sw), _ptr(bw), _ptr(stats), _ptr(gx), fin, _ptr(glw),
-                  _ptr(glb), _ptr(gsw), _ptr(gbw), _ptr(gbb), _ptr(ws), ws.numel(), _stream())
-        return gx, glw, glb, gsw, gbw, (gbb if has_bb else None), None, None, None
+                  _ptr(glb), _ptr(gsw), _ptr(gbw), _ptr(gbb), mode, _ptr(ws), ws.numel(), _stream())
+        return gx, glw, glb, gsw, gbw, (gbb if has_bb else None), None, None, None, None
+
+
+def _fits32(x, width) -> bool:
+    """The split kernels address activations with 32-bit byte offsets (< 3.75 GiB incl. prefetch margin)."""
+    return (x.size(0) + (1 << 18)) * max(x.stride(0), width, 1) * 4 < 0xF0000000
 
 
 def fastkan_layer(x, ln_weight, ln_bias, spline_weight, base_weight, base_bias, centers,
-                  denominator: float, ln_eps: float = 1e-5) -> torch.Tensor:
+                  denominator: float, ln_eps: float = 1e-5, mode: Optional[int] = None) -> torch.Tensor:
     """FastKANLayer.forward (fastkan.py:76-85) on 2-D input."""
+    if mode is None:
+        mode = default_precision()
+    if mode == PREC_SPLIT and not _fits32(x, spline_weight.size(0)):
+        mode = PREC_FP32
     return _FastKANFn.apply(x, ln_weight, ln_bias, spline_weight, base_weight, base_bias, centers,
-                            float(denominator), float(ln_eps))
+                            float(denominator), float(ln_eps), int(mode))

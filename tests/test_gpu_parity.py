@@ -191,7 +191,7 @@ def test_kan_chain_golden(golden, mode):
 @pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
 @pytest.mark.parametrize("shape", [(1, 64, 64, 5, 3), (31, 64, 64, 5, 3), (129, 64, 64, 5, 3),
                                    (1000, 65, 33, 5, 3), (513, 1433, 32, 4, 3), (300, 200, 7, 4, 3),
-                                   (700, 128, 128, 8, 3), (257, 2, 2, 1, 1), (400, 40, 160, 3, 2),
+                                   (700, 128, 128, 8, 3), (257, 2, 2, 1, 1), (400, 40, 160, 3, 2), (300, 256, 256, 5, 3), (200, 70, 300, 4, 3),
                                    (64, 16, 16, 32, 4)])
 def test_kanlinear_ragged_shapes_vs_oracle(shape, mode):
     """ragged / edge shapes (N not a tile multiple, odd widths, Cora-sized input, out > 128) against
@@ -259,7 +259,8 @@ def test_gin_kan_layer_golden(golden, mode):
 
 
 # ------------------------------------------------------------------ FastKAN
-def test_fastkan_layer_golden(golden):
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_fastkan_layer_golden(golden, mode):
     z = golden("g4_fastkan")
     i = 0
     while f"shape_{i}" in z:
@@ -268,6 +269,7 @@ def test_fastkan_layer_golden(golden):
         layer = kagnn_amd.FastKANLayer(fi, fo, num_grids=ng)
         layer.load_state_dict({n: T(z[f"{tag}.{n}"]) for n in FK_KEYS})
         layer = layer.to(DEV)
+        layer.precision = mode
         x = T(z[f"{tag}.x"], DEV).requires_grad_(True)
         y = layer(x)
         y.backward(T(z[f"{tag}.gy"], DEV))
@@ -282,6 +284,8 @@ def test_fastkan_layer_golden(golden):
     net = kagnn_amd.FastKAN([48, 72, 24], num_grids=4)
     net.load_state_dict({n[len(tag) + 1:]: T(z[n]) for n in z.files if n.startswith(tag + ".layers.")})
     net = net.to(DEV)
+    for lay in net.layers:
+        lay.precision = mode
     x = T(z[f"{tag}.x"], DEV).requires_grad_(True)
     y = net(x)
     y.backward(T(z[f"{tag}.gy"], DEV))
@@ -290,6 +294,40 @@ def test_fastkan_layer_golden(golden):
     for name, p in net.named_parameters():
         if p.requires_grad:
             assert_close(p.grad, z[f"{tag}.grad.{name}"], what=f"{tag}.grad.{name}")
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+@pytest.mark.parametrize("shape", [(1, 64, 64, 8, True, True), (300, 256, 256, 8, True, True), (129, 40, 160, 5, True, True),
+                                   (1000, 65, 33, 8, False, True), (257, 33, 200, 3, True, False),
+                                   (500, 1433, 32, 4, True, True), (64, 16, 16, 12, True, True)])
+def test_fastkan_ragged_shapes_vs_oracle(shape, mode):
+    """ragged / wide shapes (out > 128, in > one LDS chunk, num_grids < 8 and > 8, no layernorm, no base
+    branch) against the oracle evaluated in fp64."""
+    n, fi, fo, ng, use_ln, use_base = shape
+    torch.manual_seed(sum(int(v) for v in shape))
+    layer = kagnn_amd.FastKANLayer(fi, fo, num_grids=ng, use_base_update=use_base, use_layernorm=use_ln)
+    if use_ln:
+        layer.layernorm.weight.data.uniform_(0.5, 1.5)
+        layer.layernorm.bias.data.uniform_(-0.3, 0.3)
+    x = torch.randn(n, fi) * 1.3 + 0.2
+    gy = torch.randn(n, fo)
+    p64 = {k: v.detach().double() for k, v in layer.state_dict().items()}
+    w64 = {k: v.clone().requires_grad_(True) for k, v in p64.items() if k != "rbf.grid"}
+    x64 = x.double().requires_grad_(True)
+    y64 = orc.fastkan_layer_forward(x64, w64.get("layernorm.weight"), w64.get("layernorm.bias"), p64["rbf.grid"],
+                                    layer.rbf.denominator, w64["spline_linear.weight"],
+                                    w64.get("base_linear.weight"), w64.get("base_linear.bias"))
+    y64.backward(gy.double())
+    layer = layer.to(DEV)
+    layer.precision = mode
+    xd = x.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    y.backward(gy.to(DEV))
+    assert_close(y, y64, what="y")
+    assert_close(xd.grad, x64.grad, what="gx")
+    for name, prm in layer.named_parameters():
+        if prm.requires_grad:
+            assert_close(prm.grad, w64[name].grad, what="g_" + name)
 
 
 def test_gin_fastkan_layer_golden(golden):

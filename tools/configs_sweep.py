@@ -1,6 +1,9 @@
-"""Sanity/perf sweep over the BASELINE.json configs (synthetic shapes)."""
+"""Sanity/perf sweep over the BASELINE.json configs (synthetic shapes).
+usage: python tools/configs_sweep.py [config numbers ...]   (default: all)"""
 import sys, time, torch
-sys.path.insert(0, '.')
+WANT = {int(a) for a in sys.argv[1:]} or {1, 2, 3, 4, 5}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kagnn_amd
 from kagnn_amd import ops
 from kagnn_amd.harness import time_model
@@ -14,53 +17,59 @@ def run(name, fn, iters=5):
     print(f"{name}: {(time.perf_counter()-t0)/iters*1e3:.2f} ms", flush=True)
 
 # config 2: ogbn-arxiv shape, KAN-GIN 3-layer hidden 64 grid 5 (full model step with Adam)
-n, e = 169343, 1166243
-ei = orc.powerlaw_graph(n, e, seed=1).to(dev)
-x = (torch.randn(n, 128) * 0.5).to(dev); y = torch.randint(0, 40, (n,)).to(dev); mask = (torch.rand(n) < 0.5).to(dev)
-m = kagnn_amd.GKAN_Nodes('gin', 3, 128, 64, 40, grid_size=5, spline_order=3, hidden_layers=2).to(dev)
-t, losses = time_model(m, x, ei, y, mask, nb_epochs=5, warmup=2)
-print("cfg2 GKAN_Nodes gin arxiv-shape: s/epoch", t, "edges/s (3 conv layers)", 3 * e / t, losses[-1], flush=True)
-m = kagnn_amd.GKAN_Nodes('gcn', 3, 128, 64, 40, grid_size=5, spline_order=3).to(dev)
-t, losses = time_model(m, x, ei, y, mask, nb_epochs=5, warmup=2)
-print("cfg2b GKAN_Nodes gcn arxiv-shape: s/epoch", t, losses[-1], flush=True)
+if WANT & {2, 5}:
+    n, e = 169343, 1166243
+    ei = orc.powerlaw_graph(n, e, seed=1).to(dev)
+    x = (torch.randn(n, 128) * 0.5).to(dev); y = torch.randint(0, 40, (n,)).to(dev); mask = (torch.rand(n) < 0.5).to(dev)
+if 2 in WANT:
+    m = kagnn_amd.GKAN_Nodes('gin', 3, 128, 64, 40, grid_size=5, spline_order=3, hidden_layers=2).to(dev)
+    t, losses = time_model(m, x, ei, y, mask, nb_epochs=5, warmup=2)
+    print("cfg2 GKAN_Nodes gin arxiv-shape: s/epoch", t, "edges/s (3 conv layers)", 3 * e / t, losses[-1], flush=True)
+    m = kagnn_amd.GKAN_Nodes('gcn', 3, 128, 64, 40, grid_size=5, spline_order=3).to(dev)
+    t, losses = time_model(m, x, ei, y, mask, nb_epochs=5, warmup=2)
+    print("cfg2b GKAN_Nodes gcn arxiv-shape: s/epoch", t, losses[-1], flush=True)
 # config 5: FastKAN hidden 256 on arxiv shape
-m = kagnn_amd.GFASTKAN_Nodes('gin', 3, 128, 256, 40, grid_size=8, hidden_layers=2).to(dev)
-t, losses = time_model(m, x, ei, y, mask, nb_epochs=3, warmup=1)
-print("cfg5 GFASTKAN_Nodes gin hidden 256: s/epoch", t, losses[-1], flush=True)
+if 5 in WANT:
+    m = kagnn_amd.GFASTKAN_Nodes('gin', 3, 128, 256, 40, grid_size=8, hidden_layers=2).to(dev)
+    t, losses = time_model(m, x, ei, y, mask, nb_epochs=3, warmup=1)
+    print("cfg5 GFASTKAN_Nodes gin hidden 256: s/epoch", t, losses[-1], flush=True)
 # config 3 (single GPU slice): 1M/10M hidden 128 grid 8 layer fwd+bwd
-n, e, f = 1_000_000, 10_000_000, 128
-ei = orc.powerlaw_graph(n, e, seed=0).to(dev)
-g = ops.GraphIndex(ei, n)
-conv = kagnn_amd.GIKANLayer(f, f, grid_size=8, spline_order=3, hidden_dim=f, nb_layers=2).to(dev)
-xx = (torch.randn(n, f) * 0.25).to(dev).requires_grad_(True); gy = torch.randn(n, f).to(dev)
-def step():
-    xx.grad = None
-    for p in conv.parameters(): p.grad = None
-    conv(xx, g).backward(gy)
-run("cfg3 KAN-GIN layer hidden 128 grid 8 (C=11 -> fp32 MFMA path), 1 GPU", step, 3)
+if 3 in WANT:
+    n, e, f = 1_000_000, 10_000_000, 128
+    ei = orc.powerlaw_graph(n, e, seed=0).to(dev)
+    g = ops.GraphIndex(ei, n)
+    conv = kagnn_amd.GIKANLayer(f, f, grid_size=8, spline_order=3, hidden_dim=f, nb_layers=2).to(dev)
+    xx = (torch.randn(n, f) * 0.25).to(dev).requires_grad_(True); gy = torch.randn(n, f).to(dev)
+    def step():
+        xx.grad = None
+        for p in conv.parameters(): p.grad = None
+        conv(xx, g).backward(gy)
+    run("cfg3 KAN-GIN layer hidden 128 grid 8 (C=11 -> fp32 MFMA path), 1 GPU", step, 3)
 # config 1: Cora shape (CPU in the reference; here GPU)
-n, e = 2708, 10556
-ei = torch.randint(0, n, (2, e)).to(dev)
-x = torch.rand(n, 1433).to(dev); x = x / x.sum(1, keepdim=True)
-y = torch.randint(0, 7, (n,)).to(dev); mask = (torch.rand(n) < 0.1).to(dev)
-m = kagnn_amd.GKAN_Nodes('gcn', 2, 1433, 32, 7, grid_size=5, spline_order=3).to(dev)
-t, losses = time_model(m, x, ei, y, mask, nb_epochs=20, warmup=2)
-print("cfg1 Cora-shape KAN-GCN 2-layer hidden 32: s/epoch", t, losses[-1], flush=True)
+if 1 in WANT:
+    n, e = 2708, 10556
+    ei = torch.randint(0, n, (2, e)).to(dev)
+    x = torch.rand(n, 1433).to(dev); x = x / x.sum(1, keepdim=True)
+    y = torch.randint(0, 7, (n,)).to(dev); mask = (torch.rand(n) < 0.1).to(dev)
+    m = kagnn_amd.GKAN_Nodes('gcn', 2, 1433, 32, 7, grid_size=5, spline_order=3).to(dev)
+    t, losses = time_model(m, x, ei, y, mask, nb_epochs=20, warmup=2)
+    print("cfg1 Cora-shape KAN-GCN 2-layer hidden 32: s/epoch", t, losses[-1], flush=True)
 # config 4: ZINC-like batches
-from types import SimpleNamespace
-B = 256
-sizes = torch.randint(18, 29, (B,))
-N = int(sizes.sum()); off = torch.cumsum(sizes, 0) - sizes
-src, dst, batch = [], [], []
-for b in range(B):
-    nb = int(sizes[b]); eb = 2 * nb + 4
-    src.append(torch.randint(0, nb, (eb,)) + off[b]); dst.append(torch.randint(0, nb, (eb,)) + off[b])
-    batch.append(torch.full((nb,), b))
-d = SimpleNamespace(x=torch.randn(N, 21).to(dev), edge_index=torch.stack([torch.cat(src), torch.cat(dst)]).to(dev),
-                    edge_attr=torch.randn(sum(len(s) for s in src), 4).to(dev), batch=torch.cat(batch).to(dev), num_graphs=B)
-m = kagnn_amd.KAGINRegression(21, 4, 4, 64, 2, 4, 3, 1, 0.0).to(dev)
-opt = torch.optim.Adam(m.parameters(), lr=1e-3)
-tgt = torch.randn(B, 1).to(dev)
-def zstep():
-    opt.zero_grad(); (m(d) - tgt).abs().mean().backward(); opt.step()
-run("cfg4 ZINC-like batch 256 graphs KAGIN(GINE) 4 layers hidden 64: step", zstep, 20)
+if 4 in WANT:
+    from types import SimpleNamespace
+    B = 256
+    sizes = torch.randint(18, 29, (B,))
+    N = int(sizes.sum()); off = torch.cumsum(sizes, 0) - sizes
+    src, dst, batch = [], [], []
+    for b in range(B):
+        nb = int(sizes[b]); eb = 2 * nb + 4
+        src.append(torch.randint(0, nb, (eb,)) + off[b]); dst.append(torch.randint(0, nb, (eb,)) + off[b])
+        batch.append(torch.full((nb,), b))
+    d = SimpleNamespace(x=torch.randn(N, 21).to(dev), edge_index=torch.stack([torch.cat(src), torch.cat(dst)]).to(dev),
+                        edge_attr=torch.randn(sum(len(s) for s in src), 4).to(dev), batch=torch.cat(batch).to(dev), num_graphs=B)
+    m = kagnn_amd.KAGINRegression(21, 4, 4, 64, 2, 4, 3, 1, 0.0).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    tgt = torch.randn(B, 1).to(dev)
+    def zstep():
+        opt.zero_grad(); (m(d) - tgt).abs().mean().backward(); opt.step()
+    run("cfg4 ZINC-like batch 256 graphs KAGIN(GINE) 4 layers hidden 64: step", zstep, 20)
