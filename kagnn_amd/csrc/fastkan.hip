@@ -229,77 +229,129 @@ __global__ __launch_bounds__(256) void fastkan_dx_kernel(
 // g_ln_bias stay in registers):  gh = gz*gamma;  gx += rstd * (gh - mean(gh) - zhat*mean(gh*zhat)).
 constexpr int kLnMaxT = 64;     // features per lane: in <= 64*64
 
-// T = features per lane.  T <= 16 keeps the row (zhat, gh) in registers between the two passes; wider rows
-// re-read it (L2-hot) so that only the per-feature sums occupy registers.
-template <int T>
+// T = features per lane, R = rows in flight per wave (more loads in flight for narrow rows).  T <= 16 keeps
+// the rows (zhat, gh) in registers between the two passes; wider rows re-read them (L2-hot) so that only the
+// per-feature sums occupy registers.  The four waves of a workgroup combine their sums through LDS in a
+// fixed order: one partial row per workgroup.
+template <int T, int R>
 __global__ __launch_bounds__(256) void fastkan_ln_bwd_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gz, long N, int in, LnArgs ln,
     const float* __restrict__ stats, float* __restrict__ gx, long ldgx,
-    float* __restrict__ partial /* [waves][2][in] */) {
+    float* __restrict__ partial /* [blocks][2][in] */) {
     constexpr bool CACHE = T <= 16;
-    const int lane = threadIdx.x & 63;
-    const long wid = blockIdx.x * 4L + (threadIdx.x >> 6), nw = gridDim.x * 4L;
-    float cw[T], cb[T];
+    extern __shared__ float s_part[];              // [2][in]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wid = blockIdx.x * 4L + wave, nw = gridDim.x * 4L;
+    float cw[T], cb[T], gam[CACHE ? T : 1];
 #pragma unroll
-    for (int t = 0; t < T; ++t) { cw[t] = 0.0f; cb[t] = 0.0f; }
+    for (int t = 0; t < T; ++t) {
+        cw[t] = 0.0f; cb[t] = 0.0f;
+        if constexpr (CACHE) gam[t] = ln.w[min(lane + 64 * t, in - 1)];
+    }
     const float inv_n = 1.0f / (float)in;
-    for (long row = wid; row < N; row += nw) {
-        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-        float zh[CACHE ? T : 1], gh[CACHE ? T : 1];
-        float s1 = 0.0f, s2 = 0.0f;
+    for (long row0 = wid * R; row0 < N; row0 += nw * R) {
+        float zh[R][CACHE ? T : 1], gh[R][CACHE ? T : 1];
+        float s1[R], s2[R], mean[R], rstd[R];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int f = lane + 64 * t;
-            if (f < in) {
-                const float g = gz[row * (long)in + f];
-                const float z = (x[row * ldx + f] - mean) * rstd;
-                const float h = g * ln.w[f];
-                if constexpr (CACHE) { zh[t] = z; gh[t] = h; }
-                cw[t] = fmaf(g, z, cw[t]);
-                cb[t] += g;
-                s1 += h;
-                s2 = fmaf(h, z, s2);
+        for (int r = 0; r < R; ++r) {
+            const long row = min(row0 + r, N - 1);
+            const float live = (row0 + r < N) ? 1.0f : 0.0f;         // rows past the end contribute zeros
+            mean[r] = stats[2 * row]; rstd[r] = stats[2 * row + 1];
+            s1[r] = 0.0f; s2[r] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int f = lane + 64 * t;
+                if (f < in) {
+                    const float g = gz[row * (long)in + f] * live;
+                    const float z = (x[row * ldx + f] - mean[r]) * rstd[r];
+                    const float h = g * (CACHE ? gam[t] : ln.w[f]);
+                    if constexpr (CACHE) { zh[r][t] = z; gh[r][t] = h; }
+                    cw[t] = fmaf(g, z, cw[t]);
+                    cb[t] += g;
+                    s1[r] += h;
+                    s2[r] = fmaf(h, z, s2[r]);
+                }
             }
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        s1 *= inv_n; s2 *= inv_n;
+        for (int o = 32; o >= 1; o >>= 1)
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int f = lane + 64 * t;
-            if (f < in) {
-                float z, h;
-                if constexpr (CACHE) { z = zh[t]; h = gh[t]; }
-                else { z = (x[row * ldx + f] - mean) * rstd; h = gz[row * (long)in + f] * ln.w[f]; }
-                gx[row * ldgx + f] += rstd * (h - s1 - z * s2);
+            for (int r = 0; r < R; ++r) { s1[r] += __shfl_xor(s1[r], o); s2[r] += __shfl_xor(s2[r], o); }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (row0 + r >= N) break;
+            const long row = row0 + r;
+            const float m1 = s1[r] * inv_n, m2 = s2[r] * inv_n;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int f = lane + 64 * t;
+                if (f < in) {
+                    float z, h;
+                    if constexpr (CACHE) { z = zh[r][t]; h = gh[r][t]; }
+                    else { z = (x[row * ldx + f] - mean[r]) * rstd[r]; h = gz[row * (long)in + f] * ln.w[f]; }
+                    gx[row * ldgx + f] += rstd[r] * (h - m1 - z * m2);
+                }
             }
         }
     }
+    for (int w = 1; w < 4; ++w) {                    // waves 1..3 hand their sums to wave 0, in order
+        __syncthreads();
+        if (wave == w) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int f = lane + 64 * t;
-        if (f < in) { partial[(wid * 2 + 0) * in + f] = cw[t]; partial[(wid * 2 + 1) * in + f] = cb[t]; }
+            for (int t = 0; t < T; ++t) {
+                const int f = lane + 64 * t;
+                if (f < in) { s_part[f] = cw[t]; s_part[in + f] = cb[t]; }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int f = lane + 64 * t;
+                if (f < in) { cw[t] += s_part[f]; cb[t] += s_part[in + f]; }
+            }
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int f = lane + 64 * t;
+            if (f < in) { partial[(blockIdx.x * 2L + 0) * in + f] = cw[t]; partial[(blockIdx.x * 2L + 1) * in + f] = cb[t]; }
+        }
     }
 }
 
 static int launch_ln_bwd(int blocks, const float* x, long ldx, const float* gz, long N, int in, LnArgs ln,
                          const float* stats, float* gx, long ldgx, float* partial, hipStream_t st) {
     const int T = cdiv(in, 64);
-#define L(TT) fastkan_ln_bwd_kernel<TT><<<blocks, 256, 0, st>>>(x, ldx, gz, N, in, ln, stats, gx, ldgx, partial)
-    if (T <= 2) L(2); else if (T <= 4) L(4); else if (T <= 16) L(16); else if (T <= 32) L(32); else L(64);
+    const size_t lds = 2 * (size_t)in * sizeof(float);
+#define L(TT, RR) fastkan_ln_bwd_kernel<TT, RR><<<blocks, 256, lds, st>>>(x, ldx, gz, N, in, ln, stats, gx, ldgx, partial)
+    // measured on MI355X: many single-row waves beat fewer multi-row ones (only very narrow rows take two)
+    if (T <= 1) L(1, 2); else if (T <= 2) L(2, 2); else if (T <= 4) L(4, 1); else if (T <= 8) L(8, 1);
+    else if (T <= 16) L(16, 1); else if (T <= 32) L(32, 1); else L(64, 1);
 #undef L
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
 
-// out[j] = sum_w partial[w*stride + j], j < n  (fixed order)
-__global__ void sum_partials_kernel(const float* __restrict__ partial, long W, long stride, long n,
-                                    float* __restrict__ out0, float* __restrict__ out1, long split) {
-    const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (j >= n) return;
+// out[j] = sum_w partial[w*stride + j], j < n  (fixed order).  One workgroup = 32 columns x 8 row groups;
+// the groups are combined through LDS in a fixed order, so the result is deterministic.
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, long W, long stride, long n,
+                                                           float* __restrict__ out0, float* __restrict__ out1, long split) {
+    __shared__ float s_p[8][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const long j = blockIdx.x * 32L + c;
     float a = 0.0f;
-    for (long w = 0; w < W; ++w) a += partial[w * stride + j];
-    if (j < split) out0[j] = a; else out1[j - split] = a;
+    if (j < n)
+        for (long w = rg; w < W; w += 8) a += partial[w * stride + j];
+    s_p[rg][c] = a;
+    __syncthreads();
+    if (rg == 0 && j < n) {
+        float t = s_p[0][c];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += s_p[g][c];
+        if (j < split) out0[j] = t; else out1[j - split] = t;
+    }
 }
 
 // column sums of gy (g_base_bias): block b sums rows [b*rpb, ...) for all columns
@@ -450,8 +502,8 @@ static FkBwdPlan fk_plan(long N, int in, int out, int ng, int mode) {
         p.gcat = al256((size_t)p.per * 4);
         p.slab = al256((size_t)p.NS * p.per * 4);
     }
-    p.ln_blocks = (int)min(256L, (N + 3) / 4 > 0 ? (N + 3) / 4 : 1);
-    p.lnpart = al256((size_t)p.ln_blocks * 4 * 2 * in * 4);
+    p.ln_blocks = (int)max(1L, min(2048L, (N + 15) / 16));       // >= 4 rows per wave, up to 8192 waves
+    p.lnpart = al256((size_t)p.ln_blocks * 2 * in * 4);
     p.col_blocks = (int)max(1L, min(1024L, N / 64 + 1));
     p.col_rpb = (N + p.col_blocks - 1) / p.col_blocks;
     p.colpart = al256((size_t)p.col_blocks * out * 4);
@@ -489,7 +541,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
         if (lnw) {
             LnArgs ln{lnw, lnb, eps};
             { int rc = launch_ln_bwd(p.ln_blocks, x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart, st); if (rc) return rc; }
-            sum_partials_kernel<<<cdiv(2L * in, 256), 256, 0, st>>>(lnpart, p.ln_blocks * 4L, 2L * in, 2L * in, g_lnw, g_lnb, in);
+            sum_partials_kernel<<<cdiv(2L * in, 32), 256, 0, st>>>(lnpart, p.ln_blocks, 2L * in, 2L * in, g_lnw, g_lnb, in);
             KAGNN_LAUNCH_CHECK();
         }
         { int rc = kan_split_dw_any(x, ldx, gy, ldgy, N, nullptr, in, out, ng, 0, sw, nullptr, g_bw, g_sw, nullptr,
@@ -497,7 +549,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
         if (g_bb) {
             colsum_partial_kernel<<<p.col_blocks, 256, 0, st>>>(gy, ldgy, N, out, p.col_rpb, colpart);
             KAGNN_LAUNCH_CHECK();
-            sum_partials_kernel<<<cdiv(out, 256), 256, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
+            sum_partials_kernel<<<cdiv(out, 32), 256, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
             KAGNN_LAUNCH_CHECK();
         }
         return KAGNN_OK;
@@ -519,7 +571,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
     }
     if (lnw) {
         { int rc = launch_ln_bwd(p.ln_blocks, x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart, st); if (rc) return rc; }
-        sum_partials_kernel<<<cdiv(2L * in, 256), 256, 0, st>>>(lnpart, p.ln_blocks * 4L, 2L * in, 2L * in, g_lnw, g_lnb, in);
+        sum_partials_kernel<<<cdiv(2L * in, 32), 256, 0, st>>>(lnpart, p.ln_blocks, 2L * in, 2L * in, g_lnw, g_lnb, in);
         KAGNN_LAUNCH_CHECK();
     }
     dim3 grid(p.nb, FT * OTt);
@@ -531,7 +583,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
     if (g_bb) {
         colsum_partial_kernel<<<p.col_blocks, 256, 0, st>>>(gy, ldgy, N, out, p.col_rpb, colpart);
         KAGNN_LAUNCH_CHECK();
-        sum_partials_kernel<<<cdiv(out, 256), 256, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
+        sum_partials_kernel<<<cdiv(out, 32), 256, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
         KAGNN_LAUNCH_CHECK();
     }
     return KAGNN_OK;

@@ -144,7 +144,7 @@ class _NodeModel(nn.Module):
             x = self.dropout(bn(conv(x, g)))
             outs.append(x)
         if self.skip:
-            x = torch.cat(outs, dim=1)
+            x = ops.concat_columns(outs)
         return self.lay_out(x)
 
 

@@ -409,6 +409,26 @@ class _FastKANFn(Function):
         return gx, glw, glb, gsw, gbw, (gbb if has_bb else None), None, None, None, None
 
 
+class _ConcatColumnsFn(Function):
+    """torch.cat(dim=1) whose backward hands every branch a CONTIGUOUS gradient (stock cat backward returns
+    strided column slices, which sends BatchNorm1d's backward down a ~15x slower non-contiguous kernel)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        ctx.widths = [p.size(1) for p in parts]
+        return torch.cat(parts, dim=1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return tuple(c.contiguous() for c in torch.split(g, ctx.widths, dim=1))
+
+
+def concat_columns(parts) -> torch.Tensor:
+    """Skip-concatenation of the node models (reference ``models.py:200-201``: ``torch.cat(outs, dim=1)``)."""
+    return _ConcatColumnsFn.apply(*parts)
+
+
 def _fits32(x, width) -> bool:
     """The split kernels address activations with 32-bit byte offsets (< 3.75 GiB incl. prefetch margin)."""
     return (x.size(0) + (1 << 18)) * max(x.stride(0), width, 1) * 4 < 0xF0000000
