@@ -32,14 +32,15 @@ __host__ __device__ inline size_t split_fwd_chunk_bytes(int OT) {
 
 // K == 0 denotes the Gaussian RBF basis of FastKAN (G = num_grids slots)
 bool kan_split_fwd_ok(int in, int out, int G, int K) {
-    return K >= 0 && K <= 3 && G + K <= 8;
+    return K >= 0 && K <= 3 && G + K <= 16;
 }
+static inline int vshift(int C) { return C > 8 ? 1 : 0; }     // 9..16 coefficients: two 8-slot windows per feature
 
 // Outputs are processed in blocks of <= 128 columns (4 accumulator tiles per wave); every block has its
 // own pack (own power-of-two weight scale) at a fixed stride.
 static size_t fwd_blk_bytes(int in, int ob, int C) {
     const int OT = cdiv(ob, 32), CF = split_cf(OT);
-    return kHdrBytes + (size_t)cdiv(in, CF) * split_fwd_chunk_bytes(OT);
+    return kHdrBytes + (size_t)cdiv(in << vshift(C), CF) * split_fwd_chunk_bytes(OT);
 }
 size_t kan_split_pack_fwd_bytes(int in, int out, int C) {
     return (size_t)cdiv(out, kOutBlk) * fwd_blk_bytes(in, min(out, kOutBlk), C);
@@ -49,6 +50,7 @@ size_t kan_split_pack_fwd_bytes(int in, int out, int C) {
 __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
                                       const float* __restrict__ sc, int in, int out, int C,
                                       unsigned char* __restrict__ pack, int self_scale) {
+    const int sh = C > 8 ? 1 : 0, inv = in << sh;          // virtual features (see wcat_v)
     const int OT = cdiv(out, 32), CF = split_cf(OT), HF = CF / 2;
     const int SPC = CF / 2, BPC = CF / 16;
     unsigned* hdr = reinterpret_cast<unsigned*>(pack);
@@ -63,7 +65,7 @@ __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float*
     const size_t chunk_bytes = split_fwd_chunk_bytes(OT);
     const long spl_per_chunk = (long)SPC * OT * 64, base_per_chunk = (long)BPC * OT * 64;
     const long per_chunk = spl_per_chunk + base_per_chunk;
-    const long total = (long)cdiv(in, CF) * per_chunk;
+    const long total = (long)cdiv(inv, CF) * per_chunk;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ch = i / per_chunk; long r = i % per_chunk;
         unsigned char* cbase = pack + kHdrBytes + (size_t)ch * chunk_bytes;
@@ -73,7 +75,7 @@ __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float*
             const int o = 32 * ot + (lane & 31), f = ch * CF + (lane >> 5) * HF + s;
             _Float16 hi[8], lo[8];
             for (int j = 0; j < 8; ++j) {
-                const float w = wcat_s(bw, sw, sc, in, out, C, o, f, j < C ? j : C + 1) * wscale;
+                const float w = wcat_v(bw, sw, sc, in, out, C, o, f, j, sh) * wscale;
                 hi[j] = (_Float16)w;
                 lo[j] = (_Float16)(w - (float)hi[j]);
             }
@@ -88,7 +90,7 @@ __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float*
             unsigned char* bb = cbase + (size_t)SPC * OT * 2 * 1024 + (size_t)(sb * OT + ot) * 3 * 1024 + lane * 16;
             for (int j = 0; j < 8; ++j) {
                 const int f = ch * CF + (lane >> 5) * HF + 8 * sb + j;
-                float w = wcat_s(bw, sw, sc, in, out, C, o, f, C) * wscale;
+                float w = wcat_v(bw, sw, sc, in, out, C, o, f, 8, sh) * wscale;
                 for (int p = 0; p < 3; ++p) {              // truncating bf16 split: w = w1 + w2 + w3 (+2^-24)
                     const unsigned bits = __float_as_uint(w) & 0xffff0000u;
                     reinterpret_cast<unsigned short*>(bb + p * 1024)[j] = (unsigned short)(bits >> 16);
@@ -107,7 +109,7 @@ template <int K, int OT, int NT>
 __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g,
     int nknots, const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy,
-    int out, RbfArgs rb) {
+    int out, RbfArgs rb, int sh /* 1: two 8-slot windows per input feature (virtual features, see wcat_v) */) {
     constexpr int CF = (OT <= 2) ? 64 : 32, HF = CF / 2, SPC = CF / 2, BPC = CF / 16;
     constexpr int CHUNK_BYTES = SPC * OT * 2 * 1024 + BPC * OT * 3 * 1024;
     constexpr int NG = HF / 8;                       // groups of 8 features per lane-half and chunk
@@ -129,9 +131,10 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     if (nchunks == 1) stage_chunk(0);
     __syncthreads();
     SplineGeom geom{}; Frag3Geom f3geo{};
-    float ca[8] = {};
-    if constexpr (K == 0) rbf_centers(rb, ca);
+    float ca[8] = {}, cao[8] = {};                       // RBF centres of the even / odd virtual features
+    if constexpr (K == 0) { rbf_centers(rb, ca, 0); rbf_centers(rb, cao, sh); }
     if constexpr (K > 0) { geom = geom_from_knots(s_knots, nknots); f3geo = frag3_geom(s_knots, nknots); }
+    const unsigned wodd = sh ? kWinBytes : 0u;           // selector-table offset of odd virtual features
     const int r = lane & 31, kg = lane >> 5;
     const bool al4 = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 
@@ -143,14 +146,14 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     auto load8 = [&](long row0t, int ch, int g, float (&v)[8]) {
         const unsigned ro = (unsigned)(row0t + r) * ldx4 + kg * HF * 4;   // rows >= N: past the descriptor -> zeros
         const unsigned so = (unsigned)(ch * CF + 8 * g) * 4u;              // wave-uniform part of the offset
-        if (al4 && ch * CF + CF <= in) {                  // wave-uniform
+        if (al4 && sh == 0 && ch * CF + CF <= in) {       // wave-uniform
             gld4_s(xb, ro, so, v);
             gld4_s(xb, ro, so + 16, v + 4);
         } else {
             const int f0 = ch * CF + kg * HF + 8 * g;
             const unsigned rb = (unsigned)(row0t + r) * ldx4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = gld(xb, rb + min(f0 + j, in - 1) * 4);
+            for (int j = 0; j < 8; ++j) v[j] = gld(xb, rb + min((f0 + j) >> sh, in - 1) * 4);
         }
     };
 
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                         float u; unsigned h0, h1, l0, l1;
                         if (j < 7) {                      // issue the next feature's LDS reads first
                             unsigned off;
-                            frag3_index<false>(xv[j + 1], f3geo, u, off);
+                            frag3_index<false>(xv[j + 1], f3geo, u, off, ((j + 1) & 1) ? wodd : 0u);
                             sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + off);
                             const unsigned char* wp = s_w + (size_t)((8 * g + j + 1) * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                 if (K == 0 && rb.ln_w) {                   // wave-uniform
                     const int f0 = ch * CF + kg * HF + 8 * g;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const int fc = min(f0 + j, in - 1); gam[j] = rb.ln_w[fc]; bet[j] = rb.ln_b[fc]; }
+                    for (int j = 0; j < 8; ++j) { const int fc = min((f0 + j) >> sh, in - 1); gam[j] = rb.ln_w[fc]; bet[j] = rb.ln_b[fc]; }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -262,9 +265,9 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                     u32x4 ahi, alo;
                     if constexpr (K == 0) {
                         const float z = rb.ln_w ? fmaf((xv[j] - mean) * rstd, gam[j], bet[j]) : xv[j];
-                        make_rbf_frag(z, rb.a, ca, ahi, alo);
+                        make_rbf_frag(z, rb.a, (j & 1) ? cao : ca, ahi, alo);
                     } else {
-                        make_spline_frag<K>(xv[j], s_knots, s_tbl, geom, ahi, alo);
+                        make_spline_frag<K>(xv[j], s_knots, s_tbl, geom, ahi, alo, (j & 1) ? wodd : 0u);
                     }
                     const unsigned char* wp = s_w + (size_t)(s * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
@@ -329,11 +332,10 @@ int kan_split_pack_fwd_noscale(const float* bw, const float* sw, const float* sc
     return KAGNN_OK;
 }
 
-template <int K, int OT>
+template <int K, int OT, int NT>
 static int launch_fwd(const float* x, long ldx, long N, int in, const float* knots, int nknots,
                       const unsigned char* pack, int nchunks, float* y, long ldy, int out, const RbfArgs& rb,
-                      hipStream_t st) {
-    constexpr int NT = (OT <= 2) ? 1024 : 512;       // 4 waves per SIMD when the accumulators leave room (<= 128 VGPRs)
+                      int sh, hipStream_t st) {
     const size_t lds = kLdsHdr + split_fwd_chunk_bytes(OT);
     static bool configured = false;
     if (!configured) {
@@ -342,7 +344,7 @@ static int launch_fwd(const float* x, long ldx, long N, int in, const float* kno
         configured = true;
     }
     const int grid = (int)min((long)cdiv(N, NT / 2), 256L);
-    kan_split_fwd_kernel<K, OT, NT><<<grid, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, rb);
+    kan_split_fwd_kernel<K, OT, NT><<<grid, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, rb, sh);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -350,9 +352,14 @@ static int launch_fwd(const float* x, long ldx, long N, int in, const float* kno
 // one <= 128-column output block
 static int fwd_block(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
                      const unsigned char* p, float* y, long ldy, const RbfArgs& rb, hipStream_t st) {
-    const int OT = cdiv(out, 32), nk = K ? G + 2 * K + 1 : 0, nch = cdiv(in, split_cf(OT));
-#define GO(KK, TT) return launch_fwd<KK, TT>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, st)
-#define BYOT(KK) switch (OT) { case 1: GO(KK, 1); case 2: GO(KK, 2); case 3: GO(KK, 3); case 4: GO(KK, 4); }
+    const int sh = vshift(G + K);
+    const int OT = cdiv(out, 32), nk = K ? G + 2 * K + 1 : 0, nch = cdiv(in << sh, split_cf(OT));
+    // 4 waves per SIMD (1024 threads) when the accumulators leave room (<= 128 VGPRs); `narrow` launches
+    // 2 waves per SIMD instead, which leaves half the register file to a co-resident memory-bound kernel
+    static const bool narrow = getenv("KAGNN_FWD_NARROW") != nullptr;
+#define GO(KK, TT) return launch_fwd<KK, TT, 512>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, sh, st)
+#define GOW(KK, TT) if (narrow) GO(KK, TT); return launch_fwd<KK, TT, 1024>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, sh, st)
+#define BYOT(KK) switch (OT) { case 1: GOW(KK, 1); case 2: GOW(KK, 2); case 3: GO(KK, 3); case 4: GO(KK, 4); }
     switch (K) {
         case 0: BYOT(0) break;
         case 1: BYOT(1) break;
@@ -360,6 +367,7 @@ static int fwd_block(const float* x, long ldx, long N, const float* knots, int i
         case 3: BYOT(3) break;
     }
 #undef BYOT
+#undef GOW
 #undef GO
     return fail(KAGNN_ERR_UNSUPPORTED, "%s: shape not covered by the split path", "kan_split_fwd");
 }

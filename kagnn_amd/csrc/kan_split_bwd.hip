@@ -26,14 +26,15 @@ int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP
 constexpr int kCTmax = 9;     // C + 1 <= 9 accumulators (8 spline coefficients + base); unused slots carry zero weights
 static inline int dx_q2(int out) { return out <= 32 ? 1 : (out <= 64 ? 2 : 4); }   // 32-wide k-steps
 
-bool kan_split_dx_ok(int in, int out, int G, int K) { return K >= 0 && K <= 3 && G + K <= 8; }   // K == 0: RBF basis
+bool kan_split_dx_ok(int in, int out, int G, int K) { return K >= 0 && K <= 3 && G + K <= 16; }   // K == 0: RBF basis
+static inline int vshift(int C) { return C > 8 ? 1 : 0; }     // 9..16 coefficients: two 8-slot windows per feature (wcat_v)
 
 // outputs (the contraction dimension here) go in blocks of <= 128, one pack / launch per block
-static size_t dx_blk_bytes(int in, int ob) {
-    return kHdrBytes + (size_t)cdiv(in, 16) * kCTmax * dx_q2(ob) * 2 * 1024;   // always 9 slots: branch-free MFMA loop
+static size_t dx_blk_bytes(int inv /* virtual features */, int ob) {
+    return kHdrBytes + (size_t)cdiv(inv, 16) * kCTmax * dx_q2(ob) * 2 * 1024;   // always 9 slots: branch-free MFMA loop
 }
 size_t kan_split_pack_dx_bytes(int in, int out, int C) {
-    return (size_t)cdiv(out, kOutBlk) * dx_blk_bytes(in, min(out, kOutBlk));
+    return (size_t)cdiv(out, kOutBlk) * dx_blk_bytes(in << vshift(C), min(out, kOutBlk));
 }
 
 // pack_dx[ft16][c][q2][part][lane][8] : lane (f = lane&15, kg = lane>>4), j -> W'[o = 32*q2+8*kg+j][16*ft16+f][c]
@@ -50,7 +51,8 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
         reinterpret_cast<int*>(pack)[1] = e;
     }
     const int CT = kCTmax;
-    const long total = (long)cdiv(in, 16) * CT * Q2 * 64;
+    const int sh = C > 8 ? 1 : 0, inv = in << sh;
+    const long total = (long)cdiv(inv, 16) * CT * Q2 * 64;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int lane = i & 63; long r = i >> 6;
         const int q = r % Q2; r /= Q2;
@@ -60,9 +62,8 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
         _Float16* dl = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q2 + q) * 2 + 1) * 1024 + lane * 16);
         for (int j = 0; j < 8; ++j) {
             const int o = 32 * q + 8 * (lane >> 4) + j;
-            // slot 8 = base weight, slots 0..C-1 = spline coefficients, slots C..7 = 0
-            const int wc = (c == kCTmax - 1) ? C : (c < C ? c : C + 1);
-            const float w = wcat_s(bw, sw, sc, in, out, C, o, f, wc) * wscale;
+            // slot 8 = base weight, slots 0..7 = spline coefficients of this (virtual) feature's window
+            const float w = wcat_v(bw, sw, sc, in, out, C, o, f, c, sh) * wscale;
             const _Float16 h = (_Float16)w;
             dh[j] = h;
             dl[j] = (_Float16)(w - (float)h);
@@ -72,11 +73,12 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
 
 int kan_split_pack_dx_noscale(const float* bw, const float* sw, const float* sc, int in, int out, int C,
                               void* pack_dx, hipStream_t st) {
-    const size_t stride = dx_blk_bytes(in, min(out, kOutBlk));
+    const int inv = in << vshift(C);
+    const size_t stride = dx_blk_bytes(inv, min(out, kOutBlk));
     for (int b = 0; b * kOutBlk < out; ++b) {
         const int ob = min(kOutBlk, out - b * kOutBlk), Q2 = dx_q2(ob);
         const long o0 = (long)b * kOutBlk;
-        const long items = (long)cdiv(in, 16) * kCTmax * Q2 * 64;
+        const long items = (long)cdiv(inv, 16) * kCTmax * Q2 * 64;
         split_pack_dx_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(
             bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C, Q2,
             static_cast<unsigned char*>(pack_dx) + b * stride, 1);
@@ -117,18 +119,22 @@ __device__ __forceinline__ float barrel_dot(const float (&d)[8], int m, const fl
 // One wave = 32 rows (two 16-row MFMA tiles) x one 16-feature tile at a time.  v_mfma_f32_16x16x32_f16:
 // A lane (row = l&15, kg = l>>4) holds gy[row][32*q2 + 8*kg + j]; B lane (f = l&15, kg) holds W^T;
 // D lane (f = l&15) holds rows 4*kg + reg.
-template <int K, int Q2>
+// GEN == false is the lean instantiation of the common case (one output block, <= 8 coefficients): no
+// accumulate / virtual-feature code at all.  GEN == true takes both as run-time (wave-uniform) flags.
+template <int K, int Q2, bool GEN>
 __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
     const unsigned char* __restrict__ pack, int resident, float* __restrict__ gx, long ldgx,
-    RbfArgs rb, int accumulate) {
+    RbfArgs rb, int sh_arg /* 1: virtual features, two 8-slot windows per input feature */, int acc_arg) {
+    const int sh = GEN ? sh_arg : 0;
+    const bool ACC = GEN && acc_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* s_knots = reinterpret_cast<float*>(smem);
     unsigned char* s_w = smem + kLdsHdr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (K > 0 && tid < nknots) s_knots[tid] = knots_g[tid];
-    const int FT = cdiv(in, 16);
+    const int inv = in << sh, FT = cdiv(inv, 16);
     constexpr int FT_BYTES = kCTmax * Q2 * 2 * 1024;
     const int e_w = reinterpret_cast<const int*>(pack)[1];
     const unsigned char* gw = pack + kHdrBytes;
@@ -141,12 +147,18 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     if (resident) stage(0, FT);
     __syncthreads();
     SplineGeom geom{}; FastGeom fgeo{};
+    const int li = lane & 15, kg = lane >> 4;
+    const int win = li & sh;                                     // this lane's slot window (virtual feature parity)
     float ca[8] = {};
-    if constexpr (K == 0) rbf_centers(rb, ca);
+    if constexpr (K == 0) {
+        float c0[8], c1[8];
+        rbf_centers(rb, c0, 0); rbf_centers(rb, c1, sh);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) ca[g] = win ? c1[g] : c0[g];
+    }
     if constexpr (K > 0) { geom = geom_from_knots(s_knots, nknots); fgeo = fast_geom(s_knots, nknots); }
     const bool ln_on = (K == 0) && rb.ln_w != nullptr;           // wave-uniform
     const GBuf gzb = gbuf(rb.gz, N, in, in);
-    const int li = lane & 15, kg = lane >> 4;
     const bool al4 = ((ldgy & 3) == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
     const GBuf xb = gbuf(x, N, ldx, in), gyb = gbuf(gy, N, ldgy, out), gxb = gbuf(gx, N, ldgx, in);
     const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u, ldgx4 = (unsigned)ldgx * 4u;
@@ -154,9 +166,9 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
         const long row0 = tile * 256 + wave * 32;
         const unsigned gy_ro = (unsigned)(row0 + li) * ldgy4;
-        const unsigned x_ro = (unsigned)(row0 + 4 * kg) * ldx4 + min(li, in - 1) * 4;    // + 64 B per 16-feature tile
-        const unsigned gx_ro = (unsigned)(row0 + 4 * kg) * ldgx4 + li * 4;
-        const unsigned gz_ro = (unsigned)(row0 + 4 * kg) * (unsigned)in * 4u + li * 4;
+        const unsigned x_rb = (unsigned)(row0 + 4 * kg) * ldx4;
+        const unsigned gx_rb = (unsigned)(row0 + 4 * kg) * ldgx4;
+        const unsigned gz_rb = (unsigned)(row0 + 4 * kg) * (unsigned)in * 4u;
         float mu[2][4], rs[2][4];                          // layernorm statistics of this lane's 8 rows
         if (ln_on) {
 #pragma unroll
@@ -215,17 +227,19 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             }
             const unsigned char* wft = s_w + (size_t)(resident ? ft : 0) * FT_BYTES + lane * 16;
             // this lane's 8 x values of the tile: issue the loads now, they land under the MFMAs
-            const int f = 16 * ft + li;
+            const int f = 16 * ft + li;                  // (virtual) feature of this lane; fr = the real one
+            const int fr = f >> sh;
+            const unsigned fcol = (unsigned)min(fr, in - 1) * 4u;
+            const unsigned gx_ro = gx_rb + fcol, gz_ro = gz_rb + fcol;
             float gam = 1.0f, bet = 0.0f;
-            if (ln_on) { gam = rb.ln_w[min(f, in - 1)]; bet = rb.ln_b[min(f, in - 1)]; }
+            if (ln_on) { gam = rb.ln_w[min(fr, in - 1)]; bet = rb.ln_b[min(fr, in - 1)]; }
             float xq[2][4];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     // rows >= N -> 0 (never stored); a partial last feature tile re-reads the clamped column
-                    const unsigned vo = (f < in) ? x_ro + ft * 64 : (unsigned)(row0 + 4 * kg) * ldx4 + (in - 1) * 4;
-                    xq[rt][reg] = gld_s(xb, vo, (unsigned)(16 * rt + reg) * ldx4);
+                    xq[rt][reg] = gld_s(xb, x_rb + fcol, (unsigned)(16 * rt + reg) * ldx4);
                 }
             f32x4 D[kCTmax][2];
 #pragma unroll
@@ -273,16 +287,17 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                         }
                         float vz = sgz * rb.k2 * rinv[rt][reg];
                         float vb = D[kCTmax - 1][rt][reg] * silu_gradf(xv) * rinv[rt][reg];
+                        if (sh) vz += __shfl_xor(vz, 1);                 // the two windows of one input feature (wave-uniform branch)
                         const unsigned so_x = (unsigned)(16 * rt + reg) * ldgx4, so_z = (unsigned)(16 * rt + reg) * (unsigned)in * 4u;
-                        if (f < in) {
+                        if (f < inv && win == 0) {
                             if (ln_on) {
-                                if (accumulate) { vz += gld_s(gzb, gz_ro + ft * 64, so_z); vb += gld_s(gxb, gx_ro + ft * 64, so_x); }
-                                gst_s(gzb, gz_ro + ft * 64, so_z, vz);
-                                gst_s(gxb, gx_ro + ft * 64, so_x, vb);
+                                if (ACC) { vz += gld_s(gzb, gz_ro, so_z); vb += gld_s(gxb, gx_ro, so_x); }
+                                gst_s(gzb, gz_ro, so_z, vz);
+                                gst_s(gxb, gx_ro, so_x, vb);
                             } else {
                                 float v = vz + vb;
-                                if (accumulate) v += gld_s(gxb, gx_ro + ft * 64, so_x);
-                                gst_s(gxb, gx_ro + ft * 64, so_x, v);
+                                if (ACC) v += gld_s(gxb, gx_ro, so_x);
+                                gst_s(gxb, gx_ro, so_x, v);
                             }
                         }
                     } else {
@@ -299,11 +314,12 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     float d[kCTmax - 1];                       // per-coefficient sums (slots >= C are exact zeros)
 #pragma unroll
                     for (int c = 0; c < kCTmax - 1; ++c) d[c] = D[c][rt][reg];
-                    float s = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot<K>(d, m, dN)) * rinv[rt][reg];
-                    if (f < in) {
+                    float s = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot<K>(d, m - 8 * win, dN)) * rinv[rt][reg];
+                    if (sh) s += __shfl_xor(s, 1);                       // the two windows of one input feature (wave-uniform branch)
+                    if (f < inv && win == 0) {
                         const unsigned so_x = (unsigned)(16 * rt + reg) * ldgx4;
-                        if (accumulate) s += gld_s(gxb, gx_ro + ft * 64, so_x);         // second and later output blocks
-                        gst_s(gxb, gx_ro + ft * 64, so_x, s);                           // rows >= N: dropped
+                        if (ACC) s += gld_s(gxb, gx_ro, so_x);                          // second and later output blocks
+                        gst_s(gxb, gx_ro, so_x, s);                                     // rows >= N: dropped
                     }
                     }
                 }
@@ -312,24 +328,24 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     }
 }
 
-template <int K, int Q2>
+template <int K, int Q2, bool GEN>
 static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                      const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
                      const RbfArgs& rb, int accumulate, hipStream_t st) {
-    const int FT = cdiv(in, 16);
+    const int sh = vshift(C), FT = cdiv(in << sh, 16);
     const size_t ft_bytes = (size_t)kCTmax * Q2 * 2 * 1024;
     const size_t budget = 160 * 1024 - kLdsHdr;
     const bool resident = (size_t)FT * ft_bytes <= budget;
     const size_t lds = kLdsHdr + (resident ? FT : 1) * ft_bytes;
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2>,
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
     }
     const int grid = (int)min((long)cdiv(N, 256), 256L);
-    kan_split_dx_kernel<K, Q2><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
-                                                       resident ? 1 : 0, gx, ldgx, rb, accumulate);
+    kan_split_dx_kernel<K, Q2, GEN><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
+                                                            resident ? 1 : 0, gx, ldgx, rb, sh, accumulate);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -338,7 +354,8 @@ static int dx_block(const float* x, long ldx, const float* gy, long ldgy, long N
                     int out, int G, int K, const unsigned char* p, float* gx, long ldgx, const RbfArgs& rb,
                     int accumulate, hipStream_t st) {
     const int C = G + K, nk = K ? G + 2 * K + 1 : 0, Q2 = dx_q2(out);
-#define GO(KK, QQ) return launch_dx<KK, QQ>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, rb, accumulate, st)
+#define GO(KK, QQ) return (accumulate || C > 8) ? launch_dx<KK, QQ, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, rb, accumulate, st) \
+                                                 : launch_dx<KK, QQ, false>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, rb, 0, st)
 #define BYQ(KK) switch (Q2) { case 1: GO(KK, 1); case 2: GO(KK, 2); case 4: GO(KK, 4); }
     switch (K) {
         case 0: BYQ(0) break;
@@ -355,7 +372,7 @@ static int dx_block(const float* x, long ldx, const float* gy, long ldgy, long N
 int kan_split_dx_any(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
                      int out, int G, int K, const void* pack, float* gx, long ldgx, const RbfArgs& rb,
                      hipStream_t st) {
-    const size_t stride = dx_blk_bytes(in, min(out, kOutBlk));
+    const size_t stride = dx_blk_bytes(in << vshift(G + K), min(out, kOutBlk));
     for (int b = 0; b * kOutBlk < out; ++b) {
         const int rc = dx_block(x, ldx, gy + b * kOutBlk, ldgy, N, knots, in, min(kOutBlk, out - b * kOutBlk), G, K,
                                 static_cast<const unsigned char*>(pack) + b * stride, gx, ldgx, rb, b > 0, st);
@@ -370,12 +387,13 @@ int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, c
 }
 
 // ====================================================================== weight gradient
-bool kan_split_dw_ok(int in, int out, int G, int K) { return K >= 0 && K <= 3 && G + K <= 8; }   // K == 0: RBF basis
+bool kan_split_dw_ok(int in, int out, int G, int K) { return K >= 0 && K <= 3 && G + K <= 16; }   // K == 0: RBF basis
 
 struct DwPlan { int nbx; long rpw; long NS; long per; int FG, OC; long inP, outP; };
 
 static DwPlan split_dw_plan(long N, int in, int out, int C) {
     DwPlan p;
+    if (C > 8) { in <<= 1; C = 8; }                    // virtual features: 2*in features of 8 slots (wcat_v)
     p.FG = cdiv(in, 64); p.OC = cdiv(out, 64);
     const int roles = p.FG * p.OC;
     int nb = max(1, 256 / roles);                      // ~1 workgroup per CU
@@ -403,11 +421,12 @@ size_t kan_split_dw_ws_bytes(long N, int in, int out, int C) {
 // 256 architectural VGPRs, so nothing shuttles through AGPRs.
 struct DwRaw { float x[8]; float g[4][8]; float mu[8], rs[8]; };   // mu / rs: layernorm statistics (RBF basis only)
 
-template <int K>
+template <int K, bool GEN>      // GEN == false: <= 8 coefficients, no virtual-feature code (see kan_split_dx_kernel)
 __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots, int OC, long rows_per_block,
-    long inP, long outP, float* __restrict__ slab, RbfArgs rb) {
+    long inP, long outP, float* __restrict__ slab, RbfArgs rb, int sh_arg /* 1: virtual features (wcat_v); then C == 8 */) {
+    const int sh = GEN ? sh_arg : 0;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsHdr];
     float* s_knots = reinterpret_cast<float*>(smem);
     unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
@@ -416,13 +435,20 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     if (K > 0) build_perm_table(s_tbl, tid);
     __syncthreads();
     SplineGeom geom{}; FastGeom fgeo{};
-    float ca[8] = {};
-    if constexpr (K == 0) rbf_centers(rb, ca);
-    if constexpr (K > 0) { geom = geom_from_knots(s_knots, nknots); fgeo = fast_geom(s_knots, nknots); }
-    const bool ln_on = (K == 0) && rb.ln_w != nullptr;           // wave-uniform
     const int fg = blockIdx.y / OC, oc = blockIdx.y % OC;
     const int li = lane & 15, kg = lane >> 4;
-    const int f = 64 * fg + 16 * wave + li;            // A side: this lane's feature
+    const int fv = 64 * fg + 16 * wave + li;           // A side: this lane's (virtual) feature
+    const int f = fv >> sh, win = fv & sh;             // input feature and slot window
+    const unsigned woff = win ? kWinBytes : 0u;
+    float ca[8] = {};
+    if constexpr (K == 0) {
+        float c0[8], c1[8];
+        rbf_centers(rb, c0, 0); rbf_centers(rb, c1, sh);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) ca[g] = win ? c1[g] : c0[g];
+    }
+    if constexpr (K > 0) { geom = geom_from_knots(s_knots, nknots); fgeo = fast_geom(s_knots, nknots); }
+    const bool ln_on = (K == 0) && rb.ln_w != nullptr;           // wave-uniform
     const long s = blockIdx.x;
     const long rbeg = s * rows_per_block, rend = min(N, rbeg + rows_per_block);
 
@@ -500,7 +526,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
                 const float z = ln_on ? fmaf((r.x[j] - r.mu[j]) * r.rs[j], gam, bet) : r.x[j];
                 make_rbf_frag(z, rb.a, ca, rh[j], rl[j]);
             } else {
-                spline_frag<K>(r.x[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j]);
+                spline_frag<K>(r.x[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j], woff);
             }
         }
         // ---- SiLU branch: fp16 hi/lo at scale 2^4 (|silu| < 4094); larger values take the fp32 MFMA
@@ -590,17 +616,40 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     }
 }
 
+// virtual-feature layout (sh == 1) back to the parameter layout, with the spline_scaler chain rule of
+// kan_dw_unpack: coefficient c of input feature f lives in plane c & 7 of virtual feature 2f + (c >> 3)
+__global__ void kan_dw_unpack_v_kernel(const float* __restrict__ gcat, int in, int out, int C, long inP,
+                                       long outP, const float* __restrict__ sw, const float* __restrict__ sc,
+                                       float* __restrict__ g_bw, float* __restrict__ g_sw,
+                                       float* __restrict__ g_sc) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)in * out) return;
+    const int o = i % out, f = i / out;
+    const long of = (long)o * in + f;
+    float gs = 0.0f;
+    const float scale = sc ? sc[of] : 1.0f;
+    for (int c = 0; c < C; ++c) {
+        const float g = gcat[((long)(c & 7) * inP + 2 * f + (c >> 3)) * outP + o];
+        g_sw[of * C + c] = g * scale;
+        gs = fmaf(g, sw[of * C + c], gs);
+    }
+    if (g_sc) g_sc[of] = gs;
+    if (g_bw) g_bw[of] = gcat[(8L * inP + 2 * f) * outP + o];
+}
+
 // K == 0: Gaussian RBF basis with G = num_grids; sc == nullptr and g_sw laid out [out][in][G] either way
 int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
                      int out, int G, int K, const float* sw, const float* sc, float* g_bw, float* g_sw,
                      float* g_sc, float* ws, size_t ws_bytes, const RbfArgs& rb, hipStream_t st) {
     const int C = G + K, nk = K ? G + 2 * K + 1 : 0;
+    const int sh = C > 8 ? 1 : 0, Ck = sh ? 8 : C;          // slots per (virtual) feature the kernel stores
     const DwPlan p = split_dw_plan(N, in, out, C);
     if (ws_bytes < (size_t)(p.NS + 1) * p.per * sizeof(float)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "kan_split_dw");
     float* gcat = ws;
     float* slab = ws + p.per;
     dim3 grid(p.nbx, p.FG * p.OC);
-#define L(KK) kan_split_dw_kernel<KK><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb)
+#define L(KK) if (sh) kan_split_dw_kernel<KK, true><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, Ck, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb, sh); \
+              else kan_split_dw_kernel<KK, false><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, Ck, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb, 0)
     switch (K) {
         case 0: L(0); break;
         case 1: L(1); break;
@@ -611,6 +660,11 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
 #undef L
     KAGNN_LAUNCH_CHECK();
     { int rc = kan_dw_reduce(slab, p.NS, p.per, gcat, st); if (rc) return rc; }
+    if (sh) {
+        kan_dw_unpack_v_kernel<<<cdiv((long)in * out, 256), 256, 0, st>>>(gcat, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
     return kan_dw_unpack(gcat, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, st);
 }
 

@@ -7,7 +7,8 @@ namespace kagnn {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kHdrBytes = 256;           // pack header: [0] float 2^(e-10), [1] int e, [2] absmax bits
-constexpr int kLdsHdr = 512;             // LDS: knots (48 f32) @0, perm table (16 x 16 B) @256
+constexpr int kLdsHdr = 1536;            // LDS: knots (48 f32) @0, perm tables (2 windows x 32 x 16 B) @256
+constexpr unsigned kWinBytes = 512;      // byte distance between the selector tables of window 0 and window 1
 constexpr float kAScale = 1024.0f;       // bases / silu pre-scale (2^10)
 constexpr int kOutBlk = 128;             // output columns per launch of the fwd / input-gradient kernels
 
@@ -17,6 +18,17 @@ __device__ __forceinline__ float wcat_s(const float* bw, const float* sw, const 
     if (c == C) return bw ? bw[(long)o * in + f] : 0.0f;
     float w = sw[((long)o * in + f) * C + c];
     return sc ? w * sc[(long)o * in + f] : w;
+}
+
+// Layers with 9..16 coefficients per input feature run as 2*in "virtual" features of 8 slots each (sh = 1):
+// virtual feature v = (input feature v >> 1, slot window v & 1); window 1 holds coefficients 8..15 and no
+// base weight.  slot 0..7 = coefficient inside the window, slot 8 = the base (SiLU) weight.
+__device__ __forceinline__ float wcat_v(const float* bw, const float* sw, const float* sc, int in,
+                                        int out, int C, int o, int v, int slot, int sh) {
+    const int f = v >> sh, w = v & sh;
+    if (slot == 8) return w == 0 ? wcat_s(bw, sw, sc, in, out, C, o, f, C) : 0.0f;
+    const int c = slot + 8 * w;
+    return c < C ? wcat_s(bw, sw, sc, in, out, C, o, f, c) : 0.0f;
 }
 
 // ---- global memory through buffer descriptors: 32-bit byte offsets (no 64-bit VALU address math) and
@@ -89,11 +101,12 @@ __device__ __forceinline__ float block_absmax_w(const float* __restrict__ bw, co
     return s_m[16];
 }
 
-// selector table for v_perm_b32: entry t (shift sh = t-4 halfs) holds 4 selectors; output half s of
-// the 8-slot window takes payload half s-sh (payload = 4 halfs in {p1:p0}), zero when out of range.
-__device__ __forceinline__ void build_perm_table(unsigned* tbl /* LDS, 16*4 */, int tid) {
-    if (tid < 64) {
-        const int t = tid >> 2, q = tid & 3, sh = t - 4;
+// selector tables for v_perm_b32: entry t of window w (shift sh = t - 4 - 8w halfs) holds 4 selectors; output
+// half s of the 8-slot window takes payload half s-sh (payload = 4 halfs in {p1:p0}), zero when out of range.
+// Layout: [window 2][t 32][q 4] dwords; all callers run >= 256 threads.
+__device__ __forceinline__ void build_perm_table(unsigned* tbl /* LDS, 2*32*4 */, int tid) {
+    if (tid < 256) {
+        const int w = tid >> 7, t = (tid >> 2) & 31, q = tid & 3, sh = t - 4 - 8 * w;
         unsigned sel = 0;
         for (int hh = 0; hh < 2; ++hh) {
             const int r = 2 * q + hh - sh;
@@ -173,7 +186,8 @@ __device__ __forceinline__ void cubic_dbases(float u, float wd, float (&dN)[4]) 
 template <int K>
 __device__ __forceinline__ void make_spline_frag(float x, const float* __restrict__ knots,
                                                  const unsigned* __restrict__ tbl,
-                                                 const SplineGeom& g, u32x4& ahi, u32x4& alo) {
+                                                 const SplineGeom& g, u32x4& ahi, u32x4& alo,
+                                                 unsigned woff = 0) {
     float N[K + 1], dummy[K + 1];
     const int m = bspline_local<K, false>(x, knots, g, N, dummy);
     float n0 = N[0] * kAScale, n1 = N[1] * kAScale;
@@ -183,8 +197,8 @@ __device__ __forceinline__ void make_spline_frag(float x, const float* __restric
     const unsigned l0 = pk_f16_rtz(n0 - f16lo_to_f32(h0), n1 - f16hi_to_f32(h0));
     const unsigned l1 = pk_f16_rtz(n2 - f16lo_to_f32(h1), n3 - f16hi_to_f32(h1));
     int t = m - K + 4;
-    t = t < 0 ? 0 : (t > 15 ? 15 : t);
-    const u32x4 sel = *reinterpret_cast<const u32x4*>(tbl + 4 * t);
+    t = t < 0 ? 0 : (t > 31 ? 31 : t);
+    const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + woff + 16 * t);
     ahi[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
     ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
     alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);
@@ -193,7 +207,8 @@ __device__ __forceinline__ void make_spline_frag(float x, const float* __restric
 
 // K == 3 fast path: arithmetic span, closed-form cubic pieces, no knot lookups
 __device__ __forceinline__ void make_spline_frag3(float x, const unsigned* __restrict__ tbl,
-                                                  const FastGeom& g, u32x4& ahi, u32x4& alo) {
+                                                  const FastGeom& g, u32x4& ahi, u32x4& alo,
+                                                  unsigned woff = 0) {
     int m; float u; bool inside;
     fast_span(x, g, m, u, inside);
     float N[4];
@@ -201,7 +216,7 @@ __device__ __forceinline__ void make_spline_frag3(float x, const unsigned* __res
     const unsigned h0 = pk_f16_rtz(N[0], N[1]), h1 = pk_f16_rtz(N[2], N[3]);
     const unsigned l0 = pk_f16_rtz(N[0] - f16lo_to_f32(h0), N[1] - f16hi_to_f32(h0));
     const unsigned l1 = pk_f16_rtz(N[2] - f16lo_to_f32(h1), N[3] - f16hi_to_f32(h1));
-    const u32x4 sel = *reinterpret_cast<const u32x4*>(tbl + 4 * (m + 1));     // m - 3 + 4, m in [0, 14]
+    const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + woff + 16 * (m + 1));   // m - 3 + 4, m in [0, 30]
     ahi[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
     ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
     alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);
@@ -212,7 +227,7 @@ __device__ __forceinline__ void make_spline_frag3(float x, const unsigned* __res
 //   frag3_index   : table index of the span (needs only t)           -> issue the LDS table read early
 //   frag3_payload : cubic pieces, fp16 hi/lo payloads (pure VALU)     -> overlaps the MFMAs in flight
 //   frag3_place   : 8 x v_perm_b32 with the selectors read from LDS
-// Span / support handling is folded into the table: idx = floor(t) + 1 clamped to [0, 15]; entries
+// Span / support handling is folded into the table: idx = floor(t) + 1 clamped to [0, 31]; entries
 // outside [1, nspans] hold all-zero selectors (x outside [knots[0], knots[last]) -> all bases 0; at the
 // two boundary knots every existing basis is 0 anyway, so an ulp of disagreement with the reference's
 // half-open test is harmless).  NaN -> idx 1 with NaN payload -> NaN, +-Inf -> Inf*0 = NaN payload
@@ -225,9 +240,9 @@ __device__ __forceinline__ Frag3Geom frag3_geom(const float* knots, int nknots) 
     return g;
 }
 // table with support folded in: entry i (1 <= i <= nspans) = shift (i-1) - 3; everything else zero
-__device__ __forceinline__ void build_perm_table3(unsigned* tbl /* LDS, 16*4 */, int tid, int nknots) {
-    if (tid < 64) {
-        const int t = tid >> 2, q = tid & 3, sh = t - 4;
+__device__ __forceinline__ void build_perm_table3(unsigned* tbl /* LDS, 2*32*4 */, int tid, int nknots) {
+    if (tid < 256) {
+        const int w = tid >> 7, t = (tid >> 2) & 31, q = tid & 3, sh = t - 4 - 8 * w;
         unsigned sel = 0;
         for (int hh = 0; hh < 2; ++hh) {
             const int r = 2 * q + hh - sh;
@@ -241,14 +256,15 @@ __device__ __forceinline__ void build_perm_table3(unsigned* tbl /* LDS, 16*4 */,
 // NANSAFE: non-finite x selects a live table entry and a NaN payload (the reference's bases are NaN
 // there).  The forward kernel does not need it: its SiLU branch already turns such rows into NaN.
 template <bool NANSAFE>
-__device__ __forceinline__ void frag3_index(float x, const Frag3Geom& g, float& u, unsigned& byte_off) {
+__device__ __forceinline__ void frag3_index(float x, const Frag3Geom& g, float& u, unsigned& byte_off,
+                                            unsigned woff = 0) {
     const float t = fmaf(x, g.inv_h, g.c1);
     u = __builtin_amdgcn_fractf(t);
     const int i = (int)floorf(t);                  // v_cvt_flr_i32_f32; NaN -> 0
-    byte_off = min((unsigned)i, 15u) << 4;         // negative -> huge unsigned -> 15 (a zero entry)
+    byte_off = (min((unsigned)i, 31u) << 4) + woff;   // negative -> huge unsigned -> 31 (a zero entry)
     if (NANSAFE) {
         const bool fin = fabsf(x) < __builtin_inff();
-        byte_off = fin ? byte_off : 16u;
+        byte_off = fin ? byte_off : 16u + woff;
         u = fin ? u : __builtin_nanf("");
     }
 }
@@ -271,9 +287,9 @@ __device__ __forceinline__ void frag3_place(const u32x4& sel, unsigned h0, unsig
 template <int K>
 __device__ __forceinline__ void spline_frag(float x, const float* __restrict__ knots,
                                             const unsigned* __restrict__ tbl, const SplineGeom& g,
-                                            const FastGeom& fg, u32x4& ahi, u32x4& alo) {
-    if constexpr (K == 3) make_spline_frag3(x, tbl, fg, ahi, alo);
-    else make_spline_frag<K>(x, knots, tbl, g, ahi, alo);
+                                            const FastGeom& fg, u32x4& ahi, u32x4& alo, unsigned woff = 0) {
+    if constexpr (K == 3) make_spline_frag3(x, tbl, fg, ahi, alo, woff);
+    else make_spline_frag<K>(x, knots, tbl, g, ahi, alo, woff);
 }
 
 // 8 fp32 values -> three truncated-bf16 fragments (v = v1 + v2 + v3 up to 2^-24)
@@ -314,10 +330,11 @@ struct RbfArgs {
     float* gz;                // input gradient: [N, in] gradient w.r.t. z when layernorm is on
 };
 
-// ca[g] = a * c_g (wave-uniform; slots >= num_grids repeat the last centre -- their packed weights are zero)
-__device__ __forceinline__ void rbf_centers(const RbfArgs& rb, float (&ca)[8]) {
+// ca[g] = a * c_{8*window+g} (wave-uniform; slots >= num_grids repeat the last centre -- their packed weights
+// are zero)
+__device__ __forceinline__ void rbf_centers(const RbfArgs& rb, float (&ca)[8], int window = 0) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) ca[g] = rb.centers[min(g, rb.ng - 1)] * rb.a;
+    for (int g = 0; g < 8; ++g) ca[g] = rb.centers[min(8 * window + g, rb.ng - 1)] * rb.a;
 }
 
 // 8 RBF values of one scalar, scaled by 2^10, as fp16 hi / lo fragments

@@ -191,7 +191,8 @@ def test_kan_chain_golden(golden, mode):
 @pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
 @pytest.mark.parametrize("shape", [(1, 64, 64, 5, 3), (31, 64, 64, 5, 3), (129, 64, 64, 5, 3),
                                    (1000, 65, 33, 5, 3), (513, 1433, 32, 4, 3), (300, 200, 7, 4, 3),
-                                   (700, 128, 128, 8, 3), (257, 2, 2, 1, 1), (400, 40, 160, 3, 2), (300, 256, 256, 5, 3), (200, 70, 300, 4, 3),
+                                   (700, 128, 128, 8, 3), (257, 2, 2, 1, 1), (400, 40, 160, 3, 2), (300, 256, 256, 5, 3), (200, 70, 300, 4, 3), (300, 64, 64, 13, 3), (257, 33, 40, 8, 1), (200, 20, 24, 7, 2),
+                                   (500, 128, 160, 8, 3),
                                    (64, 16, 16, 32, 4)])
 def test_kanlinear_ragged_shapes_vs_oracle(shape, mode):
     """ragged / edge shapes (N not a tile multiple, odd widths, Cora-sized input, out > 128) against
@@ -299,7 +300,8 @@ def test_fastkan_layer_golden(golden, mode):
 @pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
 @pytest.mark.parametrize("shape", [(1, 64, 64, 8, True, True), (300, 256, 256, 8, True, True), (129, 40, 160, 5, True, True),
                                    (1000, 65, 33, 8, False, True), (257, 33, 200, 3, True, False),
-                                   (500, 1433, 32, 4, True, True), (64, 16, 16, 12, True, True)])
+                                   (500, 1433, 32, 4, True, True), (64, 16, 16, 12, True, True), (200, 70, 150, 16, True, True),
+                                   (333, 24, 24, 9, False, True), (100, 8, 8, 20, True, True)])
 def test_fastkan_ragged_shapes_vs_oracle(shape, mode):
     """ragged / wide shapes (out > 128, in > one LDS chunk, num_grids < 8 and > 8, no layernorm, no base
     branch) against the oracle evaluated in fp64."""

@@ -44,7 +44,7 @@ if 3 in WANT:
         xx.grad = None
         for p in conv.parameters(): p.grad = None
         conv(xx, g).backward(gy)
-    run("cfg3 KAN-GIN layer hidden 128 grid 8 (C=11 -> fp32 MFMA path), 1 GPU", step, 3)
+    run("cfg3 KAN-GIN layer hidden 128 grid 8 (C=11 -> two 8-slot windows), 1 GPU", step, 3)
 # config 1: Cora shape (CPU in the reference; here GPU)
 if 1 in WANT:
     n, e = 2708, 10556
