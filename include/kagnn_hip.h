@@ -199,6 +199,30 @@ int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy
                       float* g_base_bias, int32_t precision, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm1d over node rows (the epilogue after every convolution of the node / graph models:
+ * node_classification_clean/models.py:195-202, torch.nn.BatchNorm1d semantics).  x, y, gy, gx are
+ * [num_rows, num_features] row-major with leading dimensions in elements; statistics per column.
+ *   training != 0: batch statistics (biased variance) normalise; running_mean / running_var (may be
+ *                  NULL) are updated with `momentum` (unbiased variance), save_mean / save_rstd
+ *                  receive the batch mean and 1/sqrt(var + eps) for the backward.
+ *   training == 0: running statistics normalise; save_mean / save_rstd receive running_mean and
+ *                  1/sqrt(running_var + eps).
+ * weight / bias may be NULL (affine=False).  The backward writes gx (may be NULL), g_weight and
+ * g_bias (either may be NULL) for the same `training` flag as the forward.  Deterministic.
+ * ------------------------------------------------------------------------------------------ */
+int kagnn_batchnorm_workspace_bytes(int64_t num_rows, int32_t num_features, size_t* bytes_host);
+int kagnn_batchnorm_fwd(const float* x, int64_t ldx, int64_t num_rows, int32_t num_features,
+                        const float* weight, const float* bias, float* running_mean,
+                        float* running_var, float momentum, float eps, int32_t training, float* y,
+                        int64_t ldy, float* save_mean, float* save_rstd, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int kagnn_batchnorm_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy,
+                        int64_t num_rows, int32_t num_features, const float* weight,
+                        const float* save_mean, const float* save_rstd, int32_t training, float* gx,
+                        int64_t ldgx, float* g_weight, float* g_bias, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@ from .fastkan import FastKAN, FastKANLayer, RadialBasisFunction, SplineLinear   
 from .models import (FASTKAGCNConv, FKANLayer, GFASTKAN_Nodes, GIFASTKANLayer,   # noqa: F401
                      GIKANLayer, GKAN_Nodes, KAGCNConv, KANLayer)
 
+from .norm import BatchNorm1d                                                    # noqa: F401
 from .graph_models import FASTKAGIN, KAGIN, GINEKANLayer, KAGINRegression               # noqa: F401
 
 __version__ = "0.1.0"

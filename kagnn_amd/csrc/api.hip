@@ -38,6 +38,9 @@ int fastkan_fwd(const float*, long, long, int, int, int, const float*, float, co
 size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng, int mode);
 size_t fastkan_bwd_ws_bytes(long N, int in, int out, int ng, int mode);
 int fastkan_bwd(const float*, long, const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, float*, float*, float*, float*, void*, size_t, int, hipStream_t);
+size_t bn_ws_bytes(long N, int F);
+int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, float*, long, float*, float*, void*, size_t, hipStream_t);
+int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float*, long, float*, float*, void*, size_t, hipStream_t);
 }  // namespace kagnn
 
 using namespace kagnn;
@@ -269,6 +272,37 @@ int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy
     return fastkan_bwd(x, ldx, gy, ldgy, N, in, out, ng, centers, denominator, ln_w, ln_b, ln_eps, spline_w,
                        base_w, row_stats, gx, ldgx, g_ln_w, g_ln_b, g_spline_w, g_base_w, g_base_b, ws,
                        ws_bytes, mode, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- BatchNorm1d
+int kagnn_batchnorm_workspace_bytes(int64_t N, int32_t F, size_t* bytes) {
+    KAGNN_CHECK_ARG(bytes && N >= 0 && F >= 1, "bad argument");
+    *bytes = bn_ws_bytes(N, F);
+    return KAGNN_OK;
+}
+
+int kagnn_batchnorm_fwd(const float* x, int64_t ldx, int64_t N, int32_t F, const float* weight, const float* bias,
+                        float* running_mean, float* running_var, float momentum, float eps, int32_t training,
+                        float* y, int64_t ldy, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes,
+                        void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && F >= 1 && ldx >= F && ldy >= F, "bad shape");
+    if (N == 0) return KAGNN_OK;
+    KAGNN_CHECK_ARG(x && y && save_mean && save_rstd && ws, "null array");
+    KAGNN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var must both be given or both be null");
+    KAGNN_CHECK_ARG(training || running_mean, "eval mode needs the running statistics");
+    return bn_fwd(x, ldx, N, F, weight, bias, running_mean, running_var, momentum, eps, training, y, ldy, save_mean,
+                  save_rstd, ws, ws_bytes, as_stream(stream));
+}
+
+int kagnn_batchnorm_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N, int32_t F,
+                        const float* weight, const float* save_mean, const float* save_rstd, int32_t training,
+                        float* gx, int64_t ldgx, float* g_weight, float* g_bias, void* ws, size_t ws_bytes,
+                        void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && F >= 1 && ldx >= F && ldgy >= F && (gx == nullptr || ldgx >= F), "bad shape");
+    if (N == 0) return KAGNN_OK;
+    KAGNN_CHECK_ARG(x && gy && save_mean && save_rstd && ws, "null array");
+    return bn_bwd(x, ldx, gy, ldgy, N, F, weight, save_mean, save_rstd, training, gx, ldgx, g_weight, g_bias, ws,
+                  ws_bytes, as_stream(stream));
 }
 
 }  // extern "C"

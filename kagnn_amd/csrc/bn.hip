@@ -1,0 +1,257 @@
+// BatchNorm1d over node rows ([N, F] activations, statistics per feature column) -- the epilogue that
+// follows every KAN convolution in the node models (reference node_classification_clean/models.py:195-202,
+// torch.nn.BatchNorm1d semantics: biased variance for the normalisation, unbiased for running_var,
+// running = (1-momentum)*running + momentum*batch).  HBM-bound: the forward reads x twice and writes y,
+// the backward reads (x, gy) twice and writes gx; column sums go through per-workgroup partials that are
+// combined in a fixed order (deterministic, no atomics).
+#include "common.h"
+
+namespace kagnn {
+
+// thread -> (row slot, 4 consecutive columns); a workgroup covers RS rows per iteration
+struct BnShape { int cl; int rs; };                       // cl = float4 column groups per row (<= 256), rs = 256 / cl
+static inline BnShape bn_shape(int F) { BnShape s; s.cl = min(256, cdiv(F, 4)); s.rs = 256 / s.cl; return s; }
+
+__device__ __forceinline__ void ld4c(const float* row, int c, int F, bool vec, float (&v)[4]) {
+    if (vec) { const float4 t = *reinterpret_cast<const float4*>(row + c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (c + i < F) ? row[c + i] : 0.0f;
+    }
+}
+__device__ __forceinline__ void st4c(float* row, int c, int F, bool vec, const float (&v)[4]) {
+    if (vec) *reinterpret_cast<float4*>(row + c) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (c + i < F) row[c + i] = v[i];
+    }
+}
+
+// partial[b][0][f] = sum_n a(n,f), partial[b][1][f] = sum_n b(n,f) over the rows of workgroup b, where
+//   MODE 0 (forward statistics):  a = x - shift_f,  b = (x - shift_f)^2      (shift_f = x[0][f]: no cancellation)
+//   MODE 1 (backward sums):       a = gy,           b = gy * (x - mean_f) * rstd_f
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict__ x, long ldx,
+                                                        const float* __restrict__ gy, long ldgy, long N, int F,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, int cl, int rs,
+                                                        long rows_per_block, float* __restrict__ partial) {
+    extern __shared__ float s_red[];                    // [rs][2][4*cl]
+    const int cg = threadIdx.x % cl, slot = threadIdx.x / cl;
+    const bool vec = ((F & 3) == 0) && ((ldx & 3) == 0) && (MODE == 0 || (ldgy & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (MODE == 0 || (reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+    const long r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    for (int c0 = 0; c0 < F; c0 += 4 * cl) {            // F > 1024 takes more than one pass; uniform trip count (barriers inside)
+        const int c = c0 + 4 * cg;
+        float m[4], q[4], a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = min(c + i, F - 1);
+            m[i] = MODE == 0 ? x[ci] : mean[ci];
+            q[i] = MODE == 0 ? 1.0f : rstd[ci];
+        }
+        if (slot < rs && c < F) {
+            for (long n = r0 + slot; n < r1; n += rs) {
+                float xv[4];
+                ld4c(x + n * ldx, c, F, vec, xv);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float d = xv[i] - m[i]; a[i] += d; b[i] = fmaf(d, d, b[i]); }
+                } else {
+                    float gv[4];
+                    ld4c(gy + n * ldgy, c, F, vec, gv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { a[i] += gv[i]; b[i] = fmaf(gv[i], (xv[i] - m[i]) * q[i], b[i]); }
+                }
+            }
+        }
+        // combine the row slots in a fixed order
+        __syncthreads();
+        if (slot < rs) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s_red[(slot * 2 + 0) * 4 * cl + 4 * cg + i] = a[i]; s_red[(slot * 2 + 1) * 4 * cl + 4 * cg + i] = b[i]; }
+        }
+        __syncthreads();
+        if (slot == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float ta = 0.f, tb = 0.f;
+                for (int s = 0; s < rs; ++s) { ta += s_red[(s * 2 + 0) * 4 * cl + 4 * cg + i]; tb += s_red[(s * 2 + 1) * 4 * cl + 4 * cg + i]; }
+                if (c + i < F) { partial[(blockIdx.x * 2L + 0) * F + c + i] = ta; partial[(blockIdx.x * 2L + 1) * F + c + i] = tb; }
+            }
+        }
+    }
+}
+
+// combine the partials (fixed order) and finish the statistics:  one thread group of 8 row slots per 32 columns
+//   MODE 0: mean, rstd (biased variance) -> save_mean / save_rstd, running stats update
+//   MODE 1: g_bias = sum gy, g_weight = sum gy*xhat; also left in sums[0][f], sums[1][f] for the gx pass
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ partial, long B, int F, long N,
+                                                        const float* __restrict__ x_row0, float eps, float momentum,
+                                                        float* __restrict__ out_a, float* __restrict__ out_b,
+                                                        float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var) {
+    __shared__ float s_p[8][2][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int f = blockIdx.x * 32 + c;
+    float a = 0.0f, b = 0.0f;
+    if (f < F)
+        for (long w = rg; w < B; w += 8) { a += partial[(w * 2 + 0) * F + f]; b += partial[(w * 2 + 1) * F + f]; }
+    s_p[rg][0][c] = a; s_p[rg][1][c] = b;
+    __syncthreads();
+    if (rg == 0 && f < F) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { ta += s_p[g][0][c]; tb += s_p[g][1][c]; }
+        if (MODE == 0) {
+            const float inv_n = 1.0f / (float)N;
+            const float d = ta * inv_n;                                  // mean - shift
+            const float mean = x_row0[f] + d;
+            const float var = fmaxf(tb * inv_n - d * d, 0.0f);           // biased
+            out_a[f] = mean;
+            out_b[f] = rsqrtf(var + eps);
+            if (running_mean) {
+                const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+                running_mean[f] = fmaf(momentum, mean - running_mean[f], running_mean[f]);
+                running_var[f] = fmaf(momentum, unb - running_var[f], running_var[f]);
+            }
+        } else {
+            out_a[f] = ta;        // g_bias
+            out_b[f] = tb;        // g_weight
+        }
+    }
+}
+
+// y = (x - mean) * rstd * gamma + beta          (gamma/beta may be null: affine=False)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long ldx, long N, int F,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, long ldy, int cl, int rs) {
+    const int cg = threadIdx.x % cl, slot = threadIdx.x / cl;
+    if (slot >= rs) return;
+    const bool vec = ((F & 3) == 0) && ((ldx & 3) == 0) && ((ldy & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    for (int c = 4 * cg; c < F; c += 4 * cl) {          // no barriers below: a per-thread trip count is fine
+        float sc[4], sh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = min(c + i, F - 1);
+            sc[i] = rstd[ci] * (gamma ? gamma[ci] : 1.0f);
+            sh[i] = fmaf(-mean[ci], sc[i], beta ? beta[ci] : 0.0f);
+        }
+        for (long n = blockIdx.x * (long)rs + slot; n < N; n += (long)gridDim.x * rs) {
+            float v[4];
+            ld4c(x + n * ldx, c, F, vec, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+            st4c(y + n * ldy, c, F, vec, v);
+        }
+    }
+}
+
+// training: gx = gamma*rstd * (gy - sum_gy/N - xhat * sum_gy_xhat/N);   eval: gx = gamma*rstd*gy
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, long ldx,
+                                                           const float* __restrict__ gy, long ldgy, long N, int F,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sum_gy,
+                                                           const float* __restrict__ sum_gyx, int training,
+                                                           float* __restrict__ gx, long ldgx, int cl, int rs) {
+    const int cg = threadIdx.x % cl, slot = threadIdx.x / cl;
+    if (slot >= rs) return;
+    const bool vec = ((F & 3) == 0) && ((ldx & 3) == 0) && ((ldgy & 3) == 0) && ((ldgx & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(gx) & 15) == 0);
+    const float inv_n = 1.0f / (float)N;
+    for (int c = 4 * cg; c < F; c += 4 * cl) {
+        float m[4], q[4], k[4], a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = min(c + i, F - 1);
+            m[i] = mean[ci]; q[i] = rstd[ci];
+            k[i] = q[i] * (gamma ? gamma[ci] : 1.0f);
+            a[i] = training ? sum_gy[ci] * inv_n : 0.0f;
+            b[i] = training ? sum_gyx[ci] * inv_n : 0.0f;
+        }
+        for (long n = blockIdx.x * (long)rs + slot; n < N; n += (long)gridDim.x * rs) {
+            float xv[4], gv[4], o[4];
+            ld4c(x + n * ldx, c, F, vec, xv);
+            ld4c(gy + n * ldgy, c, F, vec, gv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = k[i] * (gv[i] - a[i] - (xv[i] - m[i]) * q[i] * b[i]);
+            st4c(gx + n * ldgx, c, F, vec, o);
+        }
+    }
+}
+
+// rstd from a variance vector (eval mode: running_var)
+__global__ void bn_rstd_kernel(const float* __restrict__ var, int F, float eps, float* __restrict__ rstd) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < F) rstd[f] = rsqrtf(var[f] + eps);
+}
+
+// ------------------------------------------------------------------ host side
+struct BnPlan { int blocks; long rpb; size_t partial_bytes; };
+static BnPlan bn_plan(long N, int F) {
+    BnPlan p;
+    const BnShape s = bn_shape(F);
+    long b = min(2048L, max(1L, N / (4L * s.rs)));        // >= 4 iterations per workgroup
+    p.rpb = (N + b - 1) / b;
+    p.rpb = ((p.rpb + s.rs - 1) / s.rs) * s.rs;
+    p.blocks = (int)max(1L, (N + p.rpb - 1) / p.rpb);
+    p.partial_bytes = (size_t)p.blocks * 2 * F * sizeof(float);
+    return p;
+}
+
+size_t bn_ws_bytes(long N, int F) { return bn_plan(N, F).partial_bytes + 2 * (size_t)F * sizeof(float); }
+
+int bn_fwd(const float* x, long ldx, long N, int F, const float* gamma, const float* beta, float* running_mean,
+           float* running_var, float momentum, float eps, int training, float* y, long ldy, float* save_mean,
+           float* save_rstd, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ws_bytes < bn_ws_bytes(N, F)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "bn_fwd");
+    const BnShape s = bn_shape(F);
+    const BnPlan p = bn_plan(N, F);
+    if (training) {
+        float* partial = static_cast<float*>(ws);
+        const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
+        bn_colsum_kernel<0><<<p.blocks, 256, lds, st>>>(x, ldx, nullptr, 0, N, F, nullptr, nullptr, s.cl, s.rs, p.rpb, partial);
+        KAGNN_LAUNCH_CHECK();
+        bn_finish_kernel<0><<<cdiv(F, 32), 256, 0, st>>>(partial, p.blocks, F, N, x, eps, momentum, save_mean, save_rstd,
+                                                         running_mean, running_var);
+        KAGNN_LAUNCH_CHECK();
+    } else {
+        KAGNN_HIP(hipMemcpyAsync(save_mean, running_mean, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice, st));
+        bn_rstd_kernel<<<cdiv(F, 256), 256, 0, st>>>(running_var, F, eps, save_rstd);
+        KAGNN_LAUNCH_CHECK();
+    }
+    const int grid = (int)min(4096L, max(1L, (long)cdiv(N, s.rs)));
+    bn_apply_kernel<<<grid, 256, 0, st>>>(x, ldx, N, F, save_mean, save_rstd, gamma, beta, y, ldy, s.cl, s.rs);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int bn_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, int F, const float* gamma,
+           const float* save_mean, const float* save_rstd, int training, float* gx, long ldgx, float* g_gamma,
+           float* g_beta, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ws_bytes < bn_ws_bytes(N, F)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "bn_bwd");
+    const BnShape s = bn_shape(F);
+    const BnPlan p = bn_plan(N, F);
+    float* partial = static_cast<float*>(ws);
+    float* sums = reinterpret_cast<float*>(static_cast<char*>(ws) + p.partial_bytes);     // [2][F] when the caller wants no g_gamma / g_beta
+    float* sg = g_beta ? g_beta : sums;
+    float* sgx = g_gamma ? g_gamma : sums + F;
+    const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
+    bn_colsum_kernel<1><<<p.blocks, 256, lds, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, s.cl, s.rs, p.rpb, partial);
+    KAGNN_LAUNCH_CHECK();
+    bn_finish_kernel<1><<<cdiv(F, 32), 256, 0, st>>>(partial, p.blocks, F, N, nullptr, 0.f, 0.f, sg, sgx, nullptr, nullptr);
+    KAGNN_LAUNCH_CHECK();
+    if (gx) {
+        const int grid = (int)min(4096L, max(1L, (long)cdiv(N, s.rs)));
+        bn_bwd_apply_kernel<<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, gamma, sg, sgx, training, gx, ldgx, s.cl, s.rs);
+        KAGNN_LAUNCH_CHECK();
+    }
+    return KAGNN_OK;
+}
+
+}  // namespace kagnn

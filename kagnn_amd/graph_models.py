@@ -17,6 +17,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .models import GIFASTKANLayer, GIKANLayer, make_fastkan, make_kan
+from .norm import BatchNorm1d
 
 
 def _num_graphs(data) -> int:
@@ -45,7 +46,7 @@ class KAGIN(_GraphLevel):
         self.conv = nn.ModuleList(
             GIKANLayer(num_features if i == 0 else hidden_dim, hidden_dim, grid_size, spline_order, hidden_dim,
                        hidden_layers) for i in range(gnn_layers))
-        self.bn = nn.ModuleList(nn.BatchNorm1d(hidden_dim) for _ in range(gnn_layers))
+        self.bn = nn.ModuleList(BatchNorm1d(hidden_dim) for _ in range(gnn_layers))
         self.kan = make_kan(hidden_dim, hidden_dim, num_classes, hidden_layers, grid_size, spline_order)
         self.dropout = nn.Dropout(dropout)
 
@@ -62,7 +63,7 @@ class FASTKAGIN(_GraphLevel):
         self.conv = nn.ModuleList(
             GIFASTKANLayer(num_features if i == 0 else hidden_dim, hidden_dim, grid_size, hidden_dim, hidden_layers)
             for i in range(gnn_layers))
-        self.bn = nn.ModuleList(nn.BatchNorm1d(hidden_dim) for _ in range(gnn_layers))
+        self.bn = nn.ModuleList(BatchNorm1d(hidden_dim) for _ in range(gnn_layers))
         self.kan = make_fastkan(hidden_dim, hidden_dim, num_classes, hidden_layers, grid_size)
         self.dropout = nn.Dropout(dropout)
 
@@ -106,7 +107,7 @@ class KAGINRegression(_GraphLevel):
         self.conv = nn.ModuleList(
             GINEKANLayer(make_kan(hidden_dim, hidden_dim, hidden_dim, hidden_layers, grid_size, spline_order))
             for _ in range(gnn_layers))
-        self.bn = nn.ModuleList(nn.BatchNorm1d(hidden_dim) for _ in range(gnn_layers))
+        self.bn = nn.ModuleList(BatchNorm1d(hidden_dim) for _ in range(gnn_layers))
         self.kan = make_kan(hidden_dim, hidden_dim, num_classes, hidden_layers, grid_size, spline_order)
         self.dropout = nn.Dropout(dropout)
 

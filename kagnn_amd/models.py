@@ -26,6 +26,7 @@ import torch.nn as nn
 from . import ops
 from .ekan import KAN as eKAN, KANLinear
 from .fastkan import FastKAN, FastKANLayer
+from .norm import BatchNorm1d
 
 
 def make_kan(num_features, hidden_dim, out_dim, hidden_layers, grid_size, spline_order):
@@ -132,7 +133,7 @@ class _NodeModel(nn.Module):
         self.bns = nn.ModuleList()
         for i in range(mp_layers):
             self.convs.append(make_conv(num_features if i == 0 else hidden_channels))
-            self.bns.append(nn.BatchNorm1d(hidden_channels))
+            self.bns.append(BatchNorm1d(hidden_channels))
         self.skip = skip
         self.dropout = nn.Dropout(dropout)
         return num_features + mp_layers * hidden_channels if skip else hidden_channels

@@ -1,0 +1,30 @@
+"""BatchNorm1d with the stock module surface (same parameters, buffers and state_dict keys as
+``torch.nn.BatchNorm1d``, so ``bns.{i}.*`` checkpoints of the reference load unchanged), computed by
+``kagnn_batchnorm_fwd/bwd`` of libkagnn_hip.so -- the epilogue of every convolution in the node and graph
+models (reference ``node_classification_clean/models.py:195-202``, ``graph_regression/models.py:107-119``).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        self._check_input_dim(input)
+        if input.dim() != 2:
+            raise NotImplementedError("kagnn_amd.BatchNorm1d normalises [N, F] node rows only")
+        factor = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            factor = 1.0 / float(self.num_batches_tracked) if self.momentum is None else self.momentum
+        bn_training = self.training or (self.running_mean is None and self.running_var is None)
+        if bn_training and input.size(0) == 1:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(input.shape)}")
+        use_running = (not self.training) or self.track_running_stats
+        return ops.batch_norm(input, self.weight, self.bias,
+                              self.running_mean if use_running else None,
+                              self.running_var if use_running else None,
+                              bn_training, factor, self.eps)

@@ -409,6 +409,53 @@ class _FastKANFn(Function):
         return gx, glw, glb, gsw, gbw, (gbb if has_bb else None), None, None, None, None
 
 
+# ======================================================================== BatchNorm1d (conv epilogue)
+class _BatchNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
+        _need_cuda(x, weight, bias, running_mean, running_var)
+        x = _rows(x)
+        n, f = x.shape
+        nb = c_size_t(0)
+        _call("kagnn_batchnorm_workspace_bytes", n, f, byref(nb))
+        ws = _ws(nb.value, x.device)
+        y = torch.empty((n, f), dtype=torch.float32, device=x.device)
+        mean = torch.empty(f, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(f, dtype=torch.float32, device=x.device)
+        w = None if weight is None else weight.contiguous()
+        b = None if bias is None else bias.contiguous()
+        _call("kagnn_batchnorm_fwd", _ptr(x), _ld(x), n, f, _ptr(w), _ptr(b), _ptr(running_mean), _ptr(running_var),
+              float(momentum), float(eps), int(bool(training)), _ptr(y), f, _ptr(mean), _ptr(rstd), _ptr(ws),
+              ws.numel(), _stream())
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.training = bool(training)
+        ctx.has_bias = b is not None
+        return y                      # running statistics are grad-free buffers, updated in place by the kernel
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w, mean, rstd = ctx.saved_tensors
+        gy = _rows(gy)
+        n, f = x.shape
+        nb = c_size_t(0)
+        _call("kagnn_batchnorm_workspace_bytes", n, f, byref(nb))
+        ws = _ws(nb.value, x.device)
+        gx = torch.empty((n, f), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
+        gw = torch.empty(f, dtype=torch.float32, device=x.device) if w is not None else None
+        gb = torch.empty(f, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        _call("kagnn_batchnorm_bwd", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, f, _ptr(w), _ptr(mean), _ptr(rstd),
+              int(ctx.training), _ptr(gx), f, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), _stream())
+        return gx, gw, gb, None, None, None, None, None
+
+
+def batch_norm(x, weight, bias, running_mean, running_var, training: bool, momentum: float, eps: float):
+    """torch.nn.functional.batch_norm on [N, F] rows (reference ``models.py:195-202`` epilogue)."""
+    if x.size(0) == 0:
+        return x.new_empty(x.shape)
+    return _BatchNormFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps)
+
+
 class _ConcatColumnsFn(Function):
     """torch.cat(dim=1) whose backward hands every branch a CONTIGUOUS gradient (stock cat backward returns
     strided column slices, which sends BatchNorm1d's backward down a ~15x slower non-contiguous kernel)."""

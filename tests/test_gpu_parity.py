@@ -473,3 +473,49 @@ def test_kanlinear_degenerate_weights_and_gradients():
     assert float(y.abs().max()) == 0.0
     y.backward(torch.zeros_like(y))
     assert float(x.grad.abs().max()) == 0.0 and float(layer.spline_weight.grad.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ BatchNorm1d epilogue
+@pytest.mark.parametrize("shape", [(1000, 64), (257, 33), (5000, 256), (300, 1500), (16, 8), (70000, 16)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_batchnorm_vs_torch_fp64(shape, affine):
+    """training-mode forward / backward / running statistics and the eval-mode forward against
+    torch.nn.BatchNorm1d evaluated in fp64 on the CPU (reference models.py:195-202 uses the stock module)."""
+    n, f = shape
+    torch.manual_seed(n + f)
+    ref = torch.nn.BatchNorm1d(f, affine=affine, momentum=0.3).double()
+    bn = kagnn_amd.BatchNorm1d(f, affine=affine, momentum=0.3)
+    if affine:
+        ref.weight.data.uniform_(0.5, 1.5); ref.bias.data.uniform_(-0.5, 0.5)
+        bn.weight.data.copy_(ref.weight.data); bn.bias.data.copy_(ref.bias.data)
+    bn = bn.to(DEV)
+    x = torch.randn(n, f) * 2.0 + torch.linspace(-30, 30, f)          # column means far from 0: cancellation check
+    gy = torch.randn(n, f)
+    for step in range(2):                                               # two steps: running statistics accumulate
+        x64 = x.double().requires_grad_(True)
+        y64 = ref(x64); y64.backward(gy.double())
+        xd = x.to(DEV).requires_grad_(True)
+        y = bn(xd); y.backward(gy.to(DEV))
+        assert_close(y, y64, what="y")
+        assert_close(xd.grad, x64.grad, what="gx")
+        if affine:
+            assert_close(bn.weight.grad, ref.weight.grad, what="g_weight"); assert_close(bn.bias.grad, ref.bias.grad, what="g_bias")
+            bn.weight.grad = None; bn.bias.grad = None; ref.weight.grad = None; ref.bias.grad = None
+        assert_close(bn.running_mean, ref.running_mean, what="running_mean")
+        assert_close(bn.running_var, ref.running_var, what="running_var")
+        assert int(bn.num_batches_tracked) == step + 1
+    ref.eval(); bn.eval()
+    assert_close(bn(x.to(DEV)), ref(x.double()), what="eval y")
+    # strided input (a column slice of a wider activation), as the skip-concat produces
+    wide = torch.randn(n, f + 8)
+    ref.train(); bn.train()
+    assert_close(bn(wide.to(DEV)[:, 4:4 + f]), ref(wide.double()[:, 4:4 + f]), what="strided y")
+
+
+def test_batchnorm_state_dict_and_errors():
+    bn = kagnn_amd.BatchNorm1d(8)
+    assert sorted(bn.state_dict()) == sorted(torch.nn.BatchNorm1d(8).state_dict())
+    bn = bn.to(DEV)
+    with pytest.raises(ValueError):
+        bn(torch.randn(1, 8, device=DEV))
+    assert bn(torch.empty(0, 8, device=DEV)).shape == (0, 8)
