@@ -136,11 +136,18 @@ int kagnn_kan_pack(const float* base_weight, const float* spline_weight,
                    int32_t grid_size, int32_t spline_order, int32_t mode,
                    void* pack_fwd, void* pack_dx, void* stream);
 
-/* y[N,out] = silu(x) @ base_weight^T + bases(x) @ (spline_weight*scaler)^T                */
+/* y[N,out] = silu(x) @ base_weight^T + bases(x) @ (spline_weight*scaler)^T.
+ * Inputs with few rows and many features (Cora: 2708 x 1433) split the feature loop over more
+ * workgroups and sum per-split partial outputs in a fixed order; that needs a scratch buffer of
+ * kagnn_kan_fwd_workspace_bytes() bytes (0 for tall inputs: workspace may then be NULL).        */
+int kagnn_kan_fwd_workspace_bytes(int64_t num_rows, int32_t in_features, int32_t out_features,
+                                  int32_t grid_size, int32_t spline_order, int32_t mode,
+                                  size_t* bytes_host);
 int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t num_rows, const float* knots,
                          int32_t in_features, int32_t out_features, int32_t grid_size,
                          int32_t spline_order, int32_t mode, const void* pack_fwd,
-                         float* y, int64_t ldy, void* stream);
+                         float* y, int64_t ldy, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* gx[N,in] = d loss / d x given gy[N,out] (x is the saved layer input; bases' derivatives are
  * recomputed, nothing but x was saved).                                                   */

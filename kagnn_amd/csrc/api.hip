@@ -26,7 +26,8 @@ size_t kan_split_pack_fwd_bytes(int in, int out, int C);
 size_t kan_split_pack_dx_bytes(int in, int out, int C);
 int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
-int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t);
+int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t);
+size_t kan_split_fwd_ws_bytes(long N, int in, int out, int C);
 int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t);
 size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
 int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t);
@@ -156,9 +157,18 @@ int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in
     return KAGNN_OK;
 }
 
+int kagnn_kan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
+                                  size_t* bytes) {
+    int rc = check_kan_dims(__func__, in, out, G, K, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
+    *bytes = use_split_fwd(in, out, G, K, mode) ? kan_split_fwd_ws_bytes(N, in, out, G + K) : 0;
+    return KAGNN_OK;
+}
+
 int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* knots, int32_t in,
                          int32_t out, int32_t G, int32_t K, int32_t mode, const void* pack_fwd,
-                         float* y, int64_t ldy, void* stream) {
+                         float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldy >= out, "bad shape");
@@ -166,7 +176,7 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* kn
     KAGNN_CHECK_ARG(x && knots && pack_fwd && y, "null array");
     if (use_split_fwd(in, out, G, K, mode)) {
         if (!(fits32(N, ldx) && fits32(N, ldy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
-        return kan_split_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, as_stream(stream));
+        return kan_split_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
     }
     return kan_f32_fwd(x, ldx, N, knots, in, out, G, K, (const float*)pack_fwd, y, ldy, as_stream(stream));
 }

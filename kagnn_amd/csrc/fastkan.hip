@@ -18,7 +18,8 @@ size_t kan_split_pack_dx_bytes(int in, int out, int C);
 size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
 int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
-int kan_split_fwd_any(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, hipStream_t);
+int kan_split_fwd_any(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, void*, size_t, hipStream_t);
+size_t kan_split_fwd_ws_bytes(long N, int in, int out, int C);
 int kan_split_dx_any(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, hipStream_t);
 int kan_split_dw_any(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, const RbfArgs&, hipStream_t);
 
@@ -442,7 +443,7 @@ __global__ void fastkan_dw_unpack_kernel(const float* __restrict__ gcat, int in,
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng, int mode) {
-    if (fk_split(in, out, ng, mode)) return al256(kan_split_pack_fwd_bytes(in, out, ng));
+    if (fk_split(in, out, ng, mode)) return al256(kan_split_pack_fwd_bytes(in, out, ng)) + al256(kan_split_fwd_ws_bytes(N, in, out, ng));
     return al256(kan_f32_pack_fwd_bytes(in, out, ng)) + al256(kan_f32_pack_dx_bytes(in, out, ng));
 }
 
@@ -458,8 +459,10 @@ int fastkan_fwd(const float* x, long ldx, long N, int in, int out, int ng, const
             KAGNN_LAUNCH_CHECK();
         }
         { int rc = kan_split_pack_fwd_noscale(bw, sw, nullptr, in, out, ng, ws, st); if (rc) return rc; }
+        char* part = static_cast<char*>(ws) + al256(kan_split_pack_fwd_bytes(in, out, ng));
         return kan_split_fwd_any(x, ldx, N, nullptr, in, out, ng, 0, ws, y, ldy,
-                                 fk_rbf(centers, ng, den, lnw, lnb, stats, bb, nullptr), st);
+                                 fk_rbf(centers, ng, den, lnw, lnb, stats, bb, nullptr), part,
+                                 kan_split_fwd_ws_bytes(N, in, out, ng), st);
     }
     float* pf = (float*)ws;
     float* pd = (float*)((char*)ws + al256(kan_f32_pack_fwd_bytes(in, out, ng)));

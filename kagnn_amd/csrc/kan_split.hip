@@ -105,11 +105,17 @@ __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float*
 // Workgroup = 1024 threads = 16 waves (4 per SIMD, <= 128 VGPRs each) so that LDS / VALU latencies of
 // one wave hide under the other three; one wave = 32 rows.  x is consumed in groups of 8 features per
 // lane (two float4), the next group is prefetched while the current one is expanded.
-template <int K, int OT, int NT>
+// GEN == false: lean instantiation (<= 8 coefficients, no split-K) used by the cubic-spline hot path
+template <int K, int OT, int NT, bool GEN>
 __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g,
     int nknots, const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy,
-    int out, RbfArgs rb, int sh /* 1: two 8-slot windows per input feature (virtual features, see wcat_v) */) {
+    int out, RbfArgs rb, int sh_arg /* 1: two 8-slot windows per input feature (virtual features, see wcat_v) */,
+    int cps_arg /* split-K for few-row inputs: blockIdx.y owns this many chunks and writes a partial y */,
+    long part_stride /* elements between the partial outputs of consecutive splits (0: no split) */) {
+    const int sh = GEN ? sh_arg : 0;
+    const int chunks_per_split = GEN ? cps_arg : nchunks;
+    const int split = GEN ? (int)blockIdx.y : 0;
     constexpr int CF = (OT <= 2) ? 64 : 32, HF = CF / 2, SPC = CF / 2, BPC = CF / 16;
     constexpr int CHUNK_BYTES = SPC * OT * 2 * 1024 + BPC * OT * 3 * 1024;
     constexpr int NG = HF / 8;                       // groups of 8 features per lane-half and chunk
@@ -128,7 +134,10 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
         uint4* dst = reinterpret_cast<uint4*>(s_w);
         for (int i = tid; i < CHUNK_BYTES / 16; i += NT) dst[i] = src[i];
     };
-    if (nchunks == 1) stage_chunk(0);
+    const int ch_begin = split * chunks_per_split, ch_end = min(nchunks, ch_begin + chunks_per_split);
+    const bool resident = (ch_end - ch_begin) == 1;      // this workgroup's only chunk stays in LDS
+    if (resident) stage_chunk(ch_begin);
+    if (GEN) y += (long)split * part_stride;
     __syncthreads();
     SplineGeom geom{}; Frag3Geom f3geo{};
     float ca[8] = {}, cao[8] = {};                       // RBF centres of the even / odd virtual features
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     };
 
     float xn[8];
-    load8((long)blockIdx.x * ROWS + wave * 32, 0, 0, xn);
+    load8((long)blockIdx.x * ROWS + wave * 32, ch_begin, 0, xn);
     for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
         const long row0 = tile * ROWS + wave * 32;
         f32x16 acc[OT];
@@ -172,8 +181,8 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
             mean = rb.stats[2 * rc]; rstd = rb.stats[2 * rc + 1];
         }
 
-        for (int ch = 0; ch < nchunks; ++ch) {
-            if (nchunks > 1) {
+        for (int ch = ch_begin; ch < ch_end; ++ch) {
+            if (!resident) {
                 __syncthreads();
                 stage_chunk(ch);
                 __syncthreads();
@@ -185,8 +194,8 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                 for (int j = 0; j < 8; ++j) xv[j] = xn[j];
                 // prefetch the next group: same chunk, next chunk, or the first group of this wave's next tile
                 if (g + 1 < NG) load8(row0, ch, g + 1, xn);
-                else if (ch + 1 < nchunks) load8(row0, ch + 1, 0, xn);
-                else load8(row0 + (long)gridDim.x * ROWS, 0, 0, xn);
+                else if (ch + 1 < ch_end) load8(row0, ch + 1, 0, xn);
+                else load8(row0 + (long)gridDim.x * ROWS, ch_begin, 0, xn);
 
                 if constexpr (K == 3) {
                     // ---- software pipeline inside the group: while the 6*OT/2 MFMAs of feature j execute, the
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
             const int col = 32 * t + r;
             const unsigned base = (unsigned)(row0 + 4 * kg) * ldy4 + col * 4;
             if (col < out) {
-                const float bb = (K == 0 && rb.bias) ? rb.bias[col] : 0.0f;
+                const float bb = (K == 0 && rb.bias && split == 0) ? rb.bias[col] : 0.0f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped
                     gst_s(yb, base, (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, fmaf(acc[t][i], post, bb));
@@ -332,33 +341,90 @@ int kan_split_pack_fwd_noscale(const float* bw, const float* sw, const float* sc
     return KAGNN_OK;
 }
 
+// split-K plan for few-row inputs (Cora: 2708 rows x 1433 features): with fewer than ~128 row blocks the
+// chunk loop is spread over blockIdx.y; every split writes a partial y, summed in a fixed order afterwards
+struct FwdSplit { int splits, cps; };
+static FwdSplit fwd_split_plan(long N, int nchunks, int rows_per_block) {
+    FwdSplit p{1, nchunks};
+    const long row_blocks = cdiv(N, rows_per_block);
+    if (row_blocks >= 128 || nchunks < 2) return p;
+    const int want = (int)min((long)nchunks, 256 / row_blocks);
+    p.cps = cdiv(nchunks, max(want, 1));
+    p.splits = cdiv(nchunks, p.cps);
+    return p;
+}
+static inline int fwd_rows_per_block(int OT) {
+    static const bool narrow = getenv("KAGNN_FWD_NARROW") != nullptr;
+    return (OT <= 2 && !narrow) ? 512 : 256;
+}
+
+size_t kan_split_fwd_ws_bytes(long N, int in, int out, int C) {
+    size_t worst = 0;
+    for (int b = 0; b * kOutBlk < out; ++b) {
+        const int ob = min(kOutBlk, out - b * kOutBlk), OT = cdiv(ob, 32);
+        const FwdSplit p = fwd_split_plan(N, cdiv(in << vshift(C), split_cf(OT)), fwd_rows_per_block(OT));
+        if (p.splits > 1) worst = max(worst, (size_t)p.splits * N * ob * sizeof(float));
+    }
+    return worst;
+}
+
+__global__ void fwd_sum_splits_kernel(const float* __restrict__ part, int splits, long N, int out,
+                                      float* __restrict__ y, long ldy) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= N * out) return;
+    float a = 0.0f;
+    for (int s = 0; s < splits; ++s) a += part[(long)s * N * out + i];
+    y[(i / out) * ldy + (i % out)] = a;
+}
+
 template <int K, int OT, int NT>
 static int launch_fwd(const float* x, long ldx, long N, int in, const float* knots, int nknots,
                       const unsigned char* pack, int nchunks, float* y, long ldy, int out, const RbfArgs& rb,
-                      int sh, hipStream_t st) {
+                      int sh, float* ws, size_t ws_bytes, hipStream_t st) {
     const size_t lds = kLdsHdr + split_fwd_chunk_bytes(OT);
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT, NT>,
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT, NT, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (K == 3)
+            KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT, NT, K != 3>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    const int grid = (int)min((long)cdiv(N, NT / 2), 256L);
-    kan_split_fwd_kernel<K, OT, NT><<<grid, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, rb, sh);
+    const int gx = (int)min((long)cdiv(N, NT / 2), 256L);
+    const FwdSplit p = fwd_split_plan(N, nchunks, NT / 2);
+    if (p.splits > 1) {
+        if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
+            return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_split_fwd");
+        kan_split_fwd_kernel<K, OT, NT, true><<<dim3(gx, p.splits), NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks,
+                                                                               ws, out, out, rb, sh, p.cps, N * (long)out);
+        KAGNN_LAUNCH_CHECK();
+        fwd_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
+    static const bool force_gen = getenv("KAGNN_FWD_GEN") != nullptr;     // A/B switch for profiling
+    if (K == 3 && sh == 0 && !force_gen)
+        kan_split_fwd_kernel<K, OT, NT, K != 3><<<gx, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out,
+                                                                     rb, 0, nchunks, 0L);
+    else
+        kan_split_fwd_kernel<K, OT, NT, true><<<gx, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out,
+                                                                   rb, sh, nchunks, 0L);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
 
 // one <= 128-column output block
 static int fwd_block(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
-                     const unsigned char* p, float* y, long ldy, const RbfArgs& rb, hipStream_t st) {
+                     const unsigned char* p, float* y, long ldy, const RbfArgs& rb, float* ws, size_t ws_bytes,
+                     hipStream_t st) {
     const int sh = vshift(G + K);
     const int OT = cdiv(out, 32), nk = K ? G + 2 * K + 1 : 0, nch = cdiv(in << sh, split_cf(OT));
     // 4 waves per SIMD (1024 threads) when the accumulators leave room (<= 128 VGPRs); `narrow` launches
     // 2 waves per SIMD instead, which leaves half the register file to a co-resident memory-bound kernel
     static const bool narrow = getenv("KAGNN_FWD_NARROW") != nullptr;
-#define GO(KK, TT) return launch_fwd<KK, TT, 512>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, sh, st)
-#define GOW(KK, TT) if (narrow) GO(KK, TT); return launch_fwd<KK, TT, 1024>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, sh, st)
+#define GO(KK, TT) return launch_fwd<KK, TT, 512>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, sh, ws, ws_bytes, st)
+#define GOW(KK, TT) if (narrow) GO(KK, TT); return launch_fwd<KK, TT, 1024>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, sh, ws, ws_bytes, st)
 #define BYOT(KK) switch (OT) { case 1: GOW(KK, 1); case 2: GOW(KK, 2); case 3: GO(KK, 3); case 4: GO(KK, 4); }
     switch (K) {
         case 0: BYOT(0) break;
@@ -374,21 +440,23 @@ static int fwd_block(const float* x, long ldx, long N, const float* knots, int i
 
 // K == 0: Gaussian RBF basis with G = num_grids (rb holds centres / layernorm / bias), else B-splines
 int kan_split_fwd_any(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
-                      const void* pack, float* y, long ldy, const RbfArgs& rb, hipStream_t st) {
+                      const void* pack, float* y, long ldy, const RbfArgs& rb, void* ws, size_t ws_bytes,
+                      hipStream_t st) {
     const size_t stride = fwd_blk_bytes(in, min(out, kOutBlk), G + K);
     for (int b = 0; b * kOutBlk < out; ++b) {
         RbfArgs rbb = rb;
         if (rbb.bias) rbb.bias += b * kOutBlk;
         const int rc = fwd_block(x, ldx, N, knots, in, min(kOutBlk, out - b * kOutBlk), G, K,
-                                 static_cast<const unsigned char*>(pack) + b * stride, y + b * kOutBlk, ldy, rbb, st);
+                                 static_cast<const unsigned char*>(pack) + b * stride, y + b * kOutBlk, ldy, rbb,
+                                 static_cast<float*>(ws), ws_bytes, st);
         if (rc) return rc;
     }
     return KAGNN_OK;
 }
 
 int kan_split_fwd(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
-                  const void* pack, float* y, long ldy, hipStream_t st) {
-    return kan_split_fwd_any(x, ldx, N, knots, in, out, G, K, pack, y, ldy, RbfArgs{}, st);
+                  const void* pack, float* y, long ldy, void* ws, size_t ws_bytes, hipStream_t st) {
+    return kan_split_fwd_any(x, ldx, N, knots, in, out, G, K, pack, y, ldy, RbfArgs{}, ws, ws_bytes, st);
 }
 
 // ---- input-gradient / weight-gradient split kernels: see kan_split_bwd.hip

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
     const unsigned char* __restrict__ pack, int resident, float* __restrict__ gx, long ldgx,
-    RbfArgs rb, int sh_arg /* 1: virtual features, two 8-slot windows per input feature */, int acc_arg) {
+    RbfArgs rb, int sh_arg /* 1: virtual features, two 8-slot windows per input feature */, int acc_arg,
+    int ft_per_block /* feature tiles per blockIdx.y: few-row inputs spread their feature tiles over the chip */) {
     const int sh = GEN ? sh_arg : 0;
     const bool ACC = GEN && acc_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
         const int n16 = nft * FT_BYTES / 16;
         for (int i = tid; i < n16; i += 512) dst[i] = src[i];
     };
-    if (resident) stage(0, FT);
+    const int ft_begin = blockIdx.y * ft_per_block, ft_end = min(FT, ft_begin + ft_per_block);
+    if (resident) stage(ft_begin, ft_end - ft_begin);
     __syncthreads();
     SplineGeom geom{}; FastGeom fgeo{};
     const int li = lane & 15, kg = lane >> 4;
@@ -219,13 +221,13 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             for (int reg = 0; reg < 4; ++reg) rinv[rt][reg] = __shfl(mine, 4 * kg + reg);
         }
 
-        for (int ft = 0; ft < FT; ++ft) {
+        for (int ft = ft_begin; ft < ft_end; ++ft) {
             if (!resident) {
                 __syncthreads();
                 stage(ft, 1);
                 __syncthreads();
             }
-            const unsigned char* wft = s_w + (size_t)(resident ? ft : 0) * FT_BYTES + lane * 16;
+            const unsigned char* wft = s_w + (size_t)(resident ? ft - ft_begin : 0) * FT_BYTES + lane * 16;
             // this lane's 8 x values of the tile: issue the loads now, they land under the MFMAs
             const int f = 16 * ft + li;                  // (virtual) feature of this lane; fr = the real one
             const int fr = f >> sh;
@@ -335,17 +337,22 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
     const int sh = vshift(C), FT = cdiv(in << sh, 16);
     const size_t ft_bytes = (size_t)kCTmax * Q2 * 2 * 1024;
     const size_t budget = 160 * 1024 - kLdsHdr;
-    const bool resident = (size_t)FT * ft_bytes <= budget;
-    const size_t lds = kLdsHdr + (resident ? FT : 1) * ft_bytes;
+    // few rows, many features (Cora: 2708 x 1433): spread the feature tiles over blockIdx.y so the chip fills
+    const long row_blocks = cdiv(N, 256);
+    int splits = row_blocks >= 128 ? 1 : (int)min((long)FT, 256 / row_blocks);
+    const int fpb = cdiv(FT, splits);
+    splits = cdiv(FT, fpb);
+    const bool resident = (size_t)fpb * ft_bytes <= budget;
+    const size_t lds = kLdsHdr + (resident ? fpb : 1) * ft_bytes;
     static bool configured = false;
     if (!configured) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
     }
-    const int grid = (int)min((long)cdiv(N, 256), 256L);
+    const dim3 grid((unsigned)min(row_blocks, 256L), (unsigned)splits);
     kan_split_dx_kernel<K, Q2, GEN><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
-                                                            resident ? 1 : 0, gx, ldgx, rb, sh, accumulate);
+                                                            resident ? 1 : 0, gx, ldgx, rb, sh, accumulate, fpb);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }

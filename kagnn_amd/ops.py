@@ -315,8 +315,11 @@ class _KANLinearFn(Function):
         _call("kagnn_kan_pack", _ptr(bw), _ptr(sw), _ptr(sc), fin, fout, grid_size, spline_order, mode,
                   _ptr(pack_f), _ptr(pack_d), _stream())
         y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
+        wb = c_size_t(0)
+        _call("kagnn_kan_fwd_workspace_bytes", n, fin, fout, grid_size, spline_order, mode, byref(wb))
+        ws = _ws(wb.value, x.device) if wb.value else None
         _call("kagnn_kan_linear_fwd", _ptr(x), _ld(x), n, _ptr(knots), fin, fout, grid_size,
-                  spline_order, mode, _ptr(pack_f), _ptr(y), fout, _stream())
+                  spline_order, mode, _ptr(pack_f), _ptr(y), fout, _ptr(ws), wb.value, _stream())
         ctx.save_for_backward(x, sw, sc, knots, pack_d)
         ctx.dims = (fin, fout, grid_size, spline_order, mode)
         return y

@@ -54,6 +54,10 @@ if 1 in WANT:
     m = kagnn_amd.GKAN_Nodes('gcn', 2, 1433, 32, 7, grid_size=5, spline_order=3).to(dev)
     t, losses = time_model(m, x, ei, y, mask, nb_epochs=20, warmup=2)
     print("cfg1 Cora-shape KAN-GCN 2-layer hidden 32: s/epoch", t, losses[-1], flush=True)
+    torch.manual_seed(0)
+    m = kagnn_amd.GKAN_Nodes('gcn', 2, 1433, 32, 7, grid_size=5, spline_order=3).to(dev)
+    t, losses = time_model(m, x, ei, y, mask, nb_epochs=20, warmup=2, graphed=True)
+    print("cfg1 same, epoch captured in a HIP graph: s/epoch", t, losses[-1], flush=True)
 # config 4: ZINC-like batches
 if 4 in WANT:
     from types import SimpleNamespace

@@ -21,7 +21,7 @@ ops._call("kagnn_kan_pack", ops._ptr(lay.base_weight), ops._ptr(lay.spline_weigh
           ops._ptr(pack_f), ops._ptr(pack_d), ops._stream())
 yk = torch.empty(n, f, device=dev); ya = torch.empty(n, f, device=dev)
 def kan():
-    ops._call("kagnn_kan_linear_fwd", ops._ptr(h), f, n, ops._ptr(knots), f, f, 5, 3, 1, ops._ptr(pack_f), ops._ptr(yk), f, ops._stream())
+    ops._call("kagnn_kan_linear_fwd", ops._ptr(h), f, n, ops._ptr(knots), f, f, 5, 3, 1, ops._ptr(pack_f), ops._ptr(yk), f, None, 0, ops._stream())
 def agg():
     ops._aggregate_raw(x, g, False, 1.0, None, None, None, None, False, out=ya) if False else ops.aggregate_sum(x, g, self_scale=1.0)
 def timeit(fn, it=10):
