@@ -512,9 +512,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(r.g[t][j]));
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        return exp_for_max(mx);
+        return exp_for_max(wave_max_nonneg(mx));
     };
     // raw chunk -> fragments, with gy scaled by 2^(10 - Tfix) (Tfix >= the chunk's exponent)
     auto expand = [&](const DwRaw& r, int Tfix) {

@@ -349,6 +349,20 @@ __device__ __forceinline__ void make_rbf_frag(float z, float a, const float (&ca
     split_f16x2(v, hi, lo);
 }
 
+// wave-wide maximum of non-negative, NaN-free floats without touching LDS: DPP swaps inside each row of 16
+// lanes (quad_perm, row_half_mirror, row_mirror), then four v_readlane + scalar max (bit patterns of
+// non-negative floats order like unsigned integers).  __shfl_xor would cost six dependent ds_bpermute round trips.
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xf, 0xf, true)));  // row_half_mirror
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x140, 0xf, 0xf, true)));  // row_mirror
+    const unsigned u = __float_as_uint(v);
+    const unsigned a = __builtin_amdgcn_readlane(u, 0), b = __builtin_amdgcn_readlane(u, 16);
+    const unsigned c = __builtin_amdgcn_readlane(u, 32), d = __builtin_amdgcn_readlane(u, 48);
+    return __uint_as_float(max(max(a, b), max(c, d)));
+}
+
 // power-of-two scale that brings |v| <= m below 2^10 (exact); 1 for m == 0 / non-finite
 __device__ __forceinline__ int exp_for_max(float m) {
     if (!(m > 0.0f) || !(m <= 3.0e38f)) return 10;
