@@ -524,7 +524,12 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
             for (int j = 0; j < 8; ++j) v[j] = r.g[t][j] * gs;
             split_f16x2(v, bhi[t], blo[t]);
         }
-        // ---- bases of 8 rows of this lane's feature
+        // ---- bases of 8 rows of this lane's feature (cubic splines: two rows per packed-fp32 evaluation)
+        if constexpr (K == 3) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2)
+                make_spline_frag3_pair(r.x[j], r.x[j + 1], s_tbl, fgeo, rh[j], rl[j], rh[j + 1], rl[j + 1], woff);
+        } else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if constexpr (K == 0) {

@@ -138,6 +138,15 @@ __device__ __forceinline__ void split_f16x2(const float (&v)[8], u32x4& hi, u32x
     }
 }
 
+// drop a 4-half payload {p1:p0} (hi and lo parts) into an 8-slot window with the selectors of one table entry
+__device__ __forceinline__ void frag3_place_fwd(const u32x4& sel, unsigned h0, unsigned h1, unsigned l0,
+                                                unsigned l1, u32x4& ahi, u32x4& alo) {
+    ahi[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
+    ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
+    alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);
+    alo[2] = __builtin_amdgcn_perm(l1, l0, sel[2]); alo[3] = __builtin_amdgcn_perm(l1, l0, sel[3]);
+}
+
 // ---- uniform-grid fast path (K == 3, the order every KAGNN config uses) -------------------------
 // span index from arithmetic only: m = clamp(floor((x-g0)/h)), u = (x-g0)/h - m.  Right at a knot
 // the arithmetic may pick the neighbouring span with u ~ 1 or ~ 0; cubic pieces join C2 so values
@@ -221,6 +230,42 @@ __device__ __forceinline__ void make_spline_frag3(float x, const unsigned* __res
     ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
     alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);
     alo[2] = __builtin_amdgcn_perm(l1, l0, sel[2]); alo[3] = __builtin_amdgcn_perm(l1, l0, sel[3]);
+}
+
+// two scalars at once: the span arithmetic and the cubic pieces run on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32
+// process both elements in one issue slot), conversions and placement per element as above
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ void make_spline_frag3_pair(float x0, float x1, const unsigned* __restrict__ tbl,
+                                                       const FastGeom& g, u32x4& ahi0, u32x4& alo0,
+                                                       u32x4& ahi1, u32x4& alo1, unsigned woff = 0) {
+    const f32x2 x = {x0, x1};
+    const f32x2 t = fma2(x, splat2(g.inv_h), splat2(g.c0));
+    const f32x2 tf = {fminf(fmaxf(floorf(t.x), 0.0f), g.last_span), fminf(fmaxf(floorf(t.y), 0.0f), g.last_span)};
+    const int m0 = (int)tf.x, m1 = (int)tf.y;
+    const f32x2 u = t - tf;
+    const f32x2 w6 = {(x0 >= g.k_first && x0 < g.k_last) ? kAScale / 6.0f : 0.0f,
+                      (x1 >= g.k_first && x1 < g.k_last) ? kAScale / 6.0f : 0.0f};
+    const f32x2 u2 = u * u, om = splat2(1.0f) - u, uw = u * w6, ow = om * w6;
+    const f32x2 N0 = ow * (om * om);
+    const f32x2 N3 = uw * u2;
+    const f32x2 N1 = fma2(uw, fma2(u, splat2(3.0f), splat2(-6.0f)) * u, splat2(4.0f) * w6);
+    const f32x2 N2 = fma2(uw, fma2(fma2(u, splat2(-3.0f), splat2(3.0f)), u, splat2(3.0f)), w6);
+    {
+        const unsigned h0 = pk_f16_rtz(N0.x, N1.x), h1 = pk_f16_rtz(N2.x, N3.x);
+        const unsigned l0 = pk_f16_rtz(N0.x - f16lo_to_f32(h0), N1.x - f16hi_to_f32(h0));
+        const unsigned l1 = pk_f16_rtz(N2.x - f16lo_to_f32(h1), N3.x - f16hi_to_f32(h1));
+        const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + woff + 16 * (m0 + 1));
+        frag3_place_fwd(sel, h0, h1, l0, l1, ahi0, alo0);
+    }
+    {
+        const unsigned h0 = pk_f16_rtz(N0.y, N1.y), h1 = pk_f16_rtz(N2.y, N3.y);
+        const unsigned l0 = pk_f16_rtz(N0.y - f16lo_to_f32(h0), N1.y - f16hi_to_f32(h0));
+        const unsigned l1 = pk_f16_rtz(N2.y - f16lo_to_f32(h1), N3.y - f16hi_to_f32(h1));
+        const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + woff + 16 * (m1 + 1));
+        frag3_place_fwd(sel, h0, h1, l0, l1, ahi1, alo1);
+    }
 }
 
 // ---- the same K == 3 expansion in three pieces, so a caller can software-pipeline it under MFMAs:
