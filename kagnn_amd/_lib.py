@@ -11,7 +11,8 @@ import os
 from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkagnn_hip.so")
+# KAGNN_LIB: load another build of the same ABI (A/B timing of kernel variants inside one process launch)
+LIB_PATH = os.environ.get("KAGNN_LIB") or os.path.join(_HERE, "lib", "libkagnn_hip.so")
 
 PREC_FP32 = 0
 PREC_SPLIT = 1
