@@ -1,0 +1,28 @@
+#!/bin/bash
+# usage: tools/make_profiles.sh <tag>   (GPU box)  -- everything the committed profiles/ summaries are made from:
+#   rocprofv3 --kernel-trace --stats of the default bench command, separate --pmc passes (counters + HBM traffic),
+#   kernel traces of the other BASELINE.json configs.  Text summaries land in gpurun_out/profiles_<tag>/ (copy to profiles/).
+set -u
+TAG=${1:-r01}
+R=$PWD; OUT=$R/gpurun_out/profiles_$TAG; RAW=$R/gpurun_out/prof_$TAG
+rm -rf $OUT $RAW; mkdir -p $OUT
+python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
+tools/prof.sh $TAG > /dev/null 2>&1
+python tools/profsum.py $RAW > $OUT/${TAG}_bench_kernel_trace_and_pmc.txt
+python - <<PY
+import json, re
+txt = open("$OUT/${TAG}_bench_kernel_trace_and_pmc.txt").read()
+out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 3 (tools/prof.sh); per-launch "
+               "averages; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- the x2 on FETCH_SIZE is the gfx950 correction of "
+               "MI355X_MICROARCH.md (HBM) for 16 B/lane reads, which is what agg_rows_v4_kernel issues; WRITE_SIZE uncalibrated"}
+m = re.search(r"\nagg_rows_v4_kernel<16>\n(.*)", txt)
+if m:
+    vals = dict(kv.split("=") for kv in m.group(1).split())
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        out["kagnn_aggregate_sum"] = int((2 * float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024)
+json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
+print(out)
+PY
+for k in 2 3 5 1 4; do tools/prof_cfg.sh $k ${TAG}_cfg$k 40 > $OUT/${TAG}_config${k}_kernel_trace.txt 2>&1; done
+rm -rf $R/gpurun_out/prof_${TAG}* 
+ls -la $OUT
