@@ -69,6 +69,22 @@ def _call(name: str, *args) -> None:
     _timer.records.append((name, a, b))
 
 
+_SIZE_CACHE: dict = {}
+
+
+def _sizes(name: str, *args, outputs: int = 1):
+    """Size queries (``*_bytes`` entry points) are pure functions of their integer arguments: ask the library
+    once per distinct shape.  On small graphs the ctypes round trips were a measurable part of a step."""
+    key = (name, args)
+    hit = _SIZE_CACHE.get(key)
+    if hit is None:
+        outs = [c_size_t(0) for _ in range(outputs)]
+        _call(name, *args, *[byref(o) for o in outs])
+        hit = tuple(o.value for o in outs)
+        _SIZE_CACHE[key] = hit
+    return hit if outputs > 1 else hit[0]
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -309,17 +325,15 @@ class _KANLinearFn(Function):
         fout = base_weight.size(0)
         bw, sw = base_weight.contiguous(), spline_weight.contiguous()
         sc = None if spline_scaler is None else spline_scaler.contiguous()
-        fb, db = c_size_t(0), c_size_t(0)
-        _call("kagnn_kan_pack_bytes", fin, fout, grid_size, spline_order, mode, byref(fb), byref(db))
-        pack_f, pack_d = _ws(fb.value, x.device), _ws(db.value, x.device)
+        fb, db = _sizes("kagnn_kan_pack_bytes", fin, fout, grid_size, spline_order, mode, outputs=2)
+        pack_f, pack_d = _ws(fb, x.device), _ws(db, x.device)
         _call("kagnn_kan_pack", _ptr(bw), _ptr(sw), _ptr(sc), fin, fout, grid_size, spline_order, mode,
                   _ptr(pack_f), _ptr(pack_d), _stream())
         y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
-        wb = c_size_t(0)
-        _call("kagnn_kan_fwd_workspace_bytes", n, fin, fout, grid_size, spline_order, mode, byref(wb))
-        ws = _ws(wb.value, x.device) if wb.value else None
+        wb = _sizes("kagnn_kan_fwd_workspace_bytes", n, fin, fout, grid_size, spline_order, mode)
+        ws = _ws(wb, x.device) if wb else None
         _call("kagnn_kan_linear_fwd", _ptr(x), _ld(x), n, _ptr(knots), fin, fout, grid_size,
-                  spline_order, mode, _ptr(pack_f), _ptr(y), fout, _ptr(ws), wb.value, _stream())
+                  spline_order, mode, _ptr(pack_f), _ptr(y), fout, _ptr(ws), wb, _stream())
         ctx.save_for_backward(x, sw, sc, knots, pack_d)
         ctx.dims = (fin, fout, grid_size, spline_order, mode)
         return y
@@ -337,9 +351,7 @@ class _KANLinearFn(Function):
             _call("kagnn_kan_linear_bwd_input", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
                       fout, G, K, mode, _ptr(pack_d), _ptr(gx), fin, _stream())
         if any(ctx.needs_input_grad[1:4]):
-            nb = c_size_t(0)
-            _call("kagnn_kan_bwd_weight_workspace_bytes", n, fin, fout, G, K, mode, byref(nb))
-            ws = _ws(nb.value, x.device)
+            ws = _ws(_sizes("kagnn_kan_bwd_weight_workspace_bytes", n, fin, fout, G, K, mode), x.device)
             gbw = torch.empty((fout, fin), dtype=torch.float32, device=x.device)
             gsw = torch.empty((fout, fin, G + K), dtype=torch.float32, device=x.device)
             gsc = None if sc is None else torch.empty((fout, fin), dtype=torch.float32, device=x.device)
@@ -377,9 +389,7 @@ class _FastKANFn(Function):
         lb = None if ln_b is None else ln_b.contiguous()
         bw = None if base_w is None else base_w.contiguous()
         bb = None if base_b is None else base_b.contiguous()
-        nb = c_size_t(0)
-        _call("kagnn_fastkan_fwd_workspace_bytes", n, fin, fout, ng, mode, byref(nb))
-        ws = _ws(nb.value, x.device)
+        ws = _ws(_sizes("kagnn_fastkan_fwd_workspace_bytes", n, fin, fout, ng, mode), x.device)
         stats = torch.empty((n, 2), dtype=torch.float32, device=x.device) if lw is not None else None
         y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
         _call("kagnn_fastkan_fwd", _ptr(x), _ld(x), n, fin, fout, ng, _ptr(centers), float(denominator),
@@ -396,9 +406,7 @@ class _FastKANFn(Function):
         fin, fout, ng, den, eps, has_bb, mode = ctx.meta
         gy = _rows(gy)
         n, dev = x.size(0), x.device
-        nb = c_size_t(0)
-        _call("kagnn_fastkan_bwd_workspace_bytes", n, fin, fout, ng, mode, byref(nb))
-        ws = _ws(nb.value, dev)
+        ws = _ws(_sizes("kagnn_fastkan_bwd_workspace_bytes", n, fin, fout, ng, mode), dev)
         f32 = dict(dtype=torch.float32, device=dev)
         gx = torch.empty((n, fin), **f32)
         glw = torch.empty(fin, **f32) if lw is not None else None
@@ -419,9 +427,7 @@ class _BatchNormFn(Function):
         _need_cuda(x, weight, bias, running_mean, running_var)
         x = _rows(x)
         n, f = x.shape
-        nb = c_size_t(0)
-        _call("kagnn_batchnorm_workspace_bytes", n, f, byref(nb))
-        ws = _ws(nb.value, x.device)
+        ws = _ws(_sizes("kagnn_batchnorm_workspace_bytes", n, f), x.device)
         y = torch.empty((n, f), dtype=torch.float32, device=x.device)
         mean = torch.empty(f, dtype=torch.float32, device=x.device)
         rstd = torch.empty(f, dtype=torch.float32, device=x.device)
@@ -441,9 +447,7 @@ class _BatchNormFn(Function):
         x, w, mean, rstd = ctx.saved_tensors
         gy = _rows(gy)
         n, f = x.shape
-        nb = c_size_t(0)
-        _call("kagnn_batchnorm_workspace_bytes", n, f, byref(nb))
-        ws = _ws(nb.value, x.device)
+        ws = _ws(_sizes("kagnn_batchnorm_workspace_bytes", n, f), x.device)
         gx = torch.empty((n, f), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
         gw = torch.empty(f, dtype=torch.float32, device=x.device) if w is not None else None
         gb = torch.empty(f, dtype=torch.float32, device=x.device) if ctx.has_bias else None
