@@ -32,7 +32,7 @@ __host__ __device__ inline size_t split_fwd_chunk_bytes(int OT) {
 
 // K == 0 denotes the Gaussian RBF basis of FastKAN (G = num_grids slots)
 bool kan_split_fwd_ok(int in, int out, int G, int K) {
-    return K >= 0 && K <= 3 && G + K <= 16;
+    return K >= 0 && K <= 4 && G + K <= 16;
 }
 static inline int vshift(int C) { return C > 8 ? 1 : 0; }     // 9..16 coefficients: two 8-slot windows per feature
 
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (K > 0 && tid < nknots) s_knots[tid] = knots_g[tid];
     if (K == 3) build_perm_table3(s_tbl, tid, nknots); else if (K > 0) build_perm_table(s_tbl, tid);
+    if (K == 4) build_perm_fix_table(s_tbl, tid);
     const float post = reinterpret_cast<const float*>(pack)[0];
     const unsigned char* gw = pack + kHdrBytes;
     auto stage_chunk = [&](int ch) {
@@ -431,6 +432,7 @@ static int fwd_block(const float* x, long ldx, long N, const float* knots, int i
         case 1: BYOT(1) break;
         case 2: BYOT(2) break;
         case 3: BYOT(3) break;
+        case 4: BYOT(4) break;
     }
 #undef BYOT
 #undef GOW

@@ -26,7 +26,7 @@ int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP
 constexpr int kCTmax = 9;     // C + 1 <= 9 accumulators (8 spline coefficients + base); unused slots carry zero weights
 static inline int dx_q2(int out) { return out <= 32 ? 1 : (out <= 64 ? 2 : 4); }   // 32-wide k-steps
 
-bool kan_split_dx_ok(int in, int out, int G, int K) { return K >= 0 && K <= 3 && G + K <= 16; }   // K == 0: RBF basis
+bool kan_split_dx_ok(int in, int out, int G, int K) { return K >= 0 && K <= 4 && G + K <= 16; }   // K == 0: RBF basis
 static inline int vshift(int C) { return C > 8 ? 1 : 0; }     // 9..16 coefficients: two 8-slot windows per feature (wcat_v)
 
 // outputs (the contraction dimension here) go in blocks of <= 128, one pack / launch per block
@@ -369,6 +369,7 @@ static int dx_block(const float* x, long ldx, const float* gy, long ldgy, long N
         case 1: BYQ(1) break;
         case 2: BYQ(2) break;
         case 3: BYQ(3) break;
+        case 4: BYQ(4) break;
     }
 #undef BYQ
 #undef GO
@@ -394,7 +395,7 @@ int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, c
 }
 
 // ====================================================================== weight gradient
-bool kan_split_dw_ok(int in, int out, int G, int K) { return K >= 0 && K <= 3 && G + K <= 16; }   // K == 0: RBF basis
+bool kan_split_dw_ok(int in, int out, int G, int K) { return K >= 0 && K <= 4 && G + K <= 16; }   // K == 0: RBF basis
 
 struct DwPlan { int nbx; long rpw; long NS; long per; int FG, OC; long inP, outP; };
 
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (K > 0 && tid < nknots) s_knots[tid] = knots_g[tid];
     if (K > 0) build_perm_table(s_tbl, tid);
+    if (K == 4) build_perm_fix_table(s_tbl, tid);
     __syncthreads();
     SplineGeom geom{}; FastGeom fgeo{};
     const int fg = blockIdx.y / OC, oc = blockIdx.y % OC;
@@ -665,7 +667,8 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
         case 1: L(1); break;
         case 2: L(2); break;
         case 3: L(3); break;
-        default: return fail(KAGNN_ERR_UNSUPPORTED, "%s: spline_order must be 1..3", "kan_split_dw");
+        case 4: L(4); break;
+        default: return fail(KAGNN_ERR_UNSUPPORTED, "%s: spline_order must be 1..4", "kan_split_dw");
     }
 #undef L
     KAGNN_LAUNCH_CHECK();

@@ -7,7 +7,7 @@ namespace kagnn {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kHdrBytes = 256;           // pack header: [0] float 2^(e-10), [1] int e, [2] absmax bits
-constexpr int kLdsHdr = 1536;            // LDS: knots (48 f32) @0, perm tables (2 windows x 32 x 16 B) @256
+constexpr int kLdsHdr = 2560;            // LDS: knots (48 f32) @0, perm tables (2 windows x 32 x 16 B) @256, order-4 fix-up tables @1280
 constexpr unsigned kWinBytes = 512;      // byte distance between the selector tables of window 0 and window 1
 constexpr float kAScale = 1024.0f;       // bases / silu pre-scale (2^10)
 constexpr int kOutBlk = 128;             // output columns per launch of the fwd / input-gradient kernels
@@ -117,6 +117,23 @@ __device__ __forceinline__ void build_perm_table(unsigned* tbl /* LDS, 2*32*4 */
     }
 }
 
+// order-4 splines have FIVE non-zero bases: the fifth payload half lives in a third dword and is merged with a
+// second v_perm_b32 whose selectors keep the bytes placed so far and overwrite the slot that takes payload half 4.
+// Same [window][t][q] layout, 1 KiB after the main tables.
+constexpr unsigned kFixBytes = 1024;
+__device__ __forceinline__ void build_perm_fix_table(unsigned* tbl /* LDS, main tables */, int tid) {
+    if (tid < 256) {
+        const int w = tid >> 7, t = (tid >> 2) & 31, q = tid & 3, sh = t - 4 - 8 * w;
+        unsigned sel = 0;
+        for (int hh = 0; hh < 2; ++hh) {
+            const int r = 2 * q + hh - sh;
+            const unsigned b = (r == 4) ? 0x0504u : (unsigned)((2 * hh) | ((2 * hh + 1) << 8));
+            sel |= b << (16 * hh);
+        }
+        tbl[256 + tid] = sel;
+    }
+}
+
 __device__ __forceinline__ unsigned pk_f16_rtz(float a, float b) {
     auto v = __builtin_amdgcn_cvt_pkrtz(a, b);     // two fp16, round toward zero
     return __builtin_bit_cast(unsigned, v);
@@ -212,6 +229,17 @@ __device__ __forceinline__ void make_spline_frag(float x, const float* __restric
     ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
     alo[0] = __builtin_amdgcn_perm(l1, l0, sel[0]); alo[1] = __builtin_amdgcn_perm(l1, l0, sel[1]);
     alo[2] = __builtin_amdgcn_perm(l1, l0, sel[2]); alo[3] = __builtin_amdgcn_perm(l1, l0, sel[3]);
+    if constexpr (K >= 4) {                          // fifth basis (see build_perm_fix_table)
+        const float n4 = N[K >= 4 ? 4 : 0] * kAScale;
+        const unsigned h2 = pk_f16_rtz(n4, 0.0f);
+        const unsigned l2 = pk_f16_rtz(n4 - f16lo_to_f32(h2), 0.0f);
+        const u32x4 fix = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + kFixBytes + woff + 16 * t);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ahi[q] = __builtin_amdgcn_perm(h2, ahi[q], fix[q]);
+            alo[q] = __builtin_amdgcn_perm(l2, alo[q], fix[q]);
+        }
+    }
 }
 
 // K == 3 fast path: arithmetic span, closed-form cubic pieces, no knot lookups
