@@ -97,13 +97,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    # debugging aid for boxes with fewer GPUs than ranks: KAGNN_BENCH_BACKEND=gloo puts every rank on cuda:0 and
+    # moves the collectives to gloo (numbers measured that way are meaningless; the launch contract uses RCCL)
+    backend = os.environ.get("KAGNN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import kagnn_amd
     from kagnn_amd import ops
