@@ -7,9 +7,9 @@ dominant kernel and the CPU baseline (oracle, "port") on a bounded sample.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1: the hidden dimension is sharded over the ranks (feature sharding of the spline
-coefficient tensor, RCCL reduce-scatter / all-gather on the partial activations; see
-kagnn_amd/sharded.py and DESIGN.md) -- total work is fixed => "scaling": "strong".
+N > 1: the layer is sharded over the ranks (aggregation on feature-column shards, KAN chain on row
+shards, RCCL all-to-all in between; KAGNN_SHARDING=feature shards the spline coefficient tensor instead --
+see kagnn_amd/sharded.py and DESIGN.md) -- total work is fixed => "scaling": "strong".
 One JSON line on stdout (rank 0).
 """
 from __future__ import annotations
@@ -139,8 +139,13 @@ def main():
             y = conv(x, graph)
             y.backward(gy)
     else:
-        from kagnn_amd.sharded import ShardedGIKANLayer
-        sconv = ShardedGIKANLayer(conv, dist.group.WORLD).to(dev)
+        # default: aggregation on column shards, KAN chain on row shards, two all-to-alls per direction
+        # (kagnn_amd/sharded.py); KAGNN_SHARDING=feature selects the reduce-scatter / all-gather variant that
+        # shards the spline coefficient tensor itself (8x more wire traffic at this width)
+        from kagnn_amd.sharded import ShardedGIKANLayer, TransposedShardedGIKANLayer
+        sharding = os.environ.get("KAGNN_SHARDING", "transposed")
+        cls = ShardedGIKANLayer if sharding == "feature" else TransposedShardedGIKANLayer
+        sconv = cls(conv, dist.group.WORLD).to(dev)
         x = sconv.shard_columns(x_full.to(dev)).requires_grad_(True)
         gy = sconv.shard_columns(gy_full.to(dev))
 
@@ -212,7 +217,9 @@ def main():
                                    f"power-law graph N={n} E={e} seed 0 (SURVEY 8(d))",
                        "nodes": n, "edges": e, "hidden": f, "grid_size": args.grid, "spline_order": args.order,
                        "precision": args.precision,
-                       "parallelism": "single GPU" if world == 1 else f"feature-sharded x{world} (RCCL reduce-scatter/all-gather)"},
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"feature-sharded x{world} (RCCL reduce-scatter/all-gather)" if os.environ.get("KAGNN_SHARDING") == "feature"
+                           else f"column-sharded aggregation + row-sharded KAN chain x{world} (RCCL all-to-all, weight-gradient all-reduce)")},
             "layer_algorithmic_bytes": layer_bytes(n, e, f),
             "layer_hbm_GBs": layer_gbs, "layer_hbm_frac": layer_gbs / HBM_PEAK_GBS,
             "roofline": roof,
