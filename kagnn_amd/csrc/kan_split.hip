@@ -355,7 +355,7 @@ static FwdSplit fwd_split_plan(long N, int nchunks, int rows_per_block) {
     return p;
 }
 static inline int fwd_rows_per_block(int OT) {
-    static const bool narrow = getenv("KAGNN_FWD_NARROW") != nullptr;
+    static const bool narrow = getenv("KAGNN_FWD_WIDE") == nullptr;
     return (OT <= 2 && !narrow) ? 512 : 256;
 }
 
@@ -421,9 +421,11 @@ static int fwd_block(const float* x, long ldx, long N, const float* knots, int i
                      hipStream_t st) {
     const int sh = vshift(G + K);
     const int OT = cdiv(out, 32), nk = K ? G + 2 * K + 1 : 0, nch = cdiv(in << sh, split_cf(OT));
-    // 4 waves per SIMD (1024 threads) when the accumulators leave room (<= 128 VGPRs); `narrow` launches
-    // 2 waves per SIMD instead, which leaves half the register file to a co-resident memory-bound kernel
-    static const bool narrow = getenv("KAGNN_FWD_NARROW") != nullptr;
+    // The kernels with <= 128 VGPRs could run 4 waves per SIMD (1024 threads).  Measured on MI355X (tools/ab.sh,
+    // three boxes) that makes the forward itself 3 % faster but the whole layer step 1.3 % SLOWER: the chip is
+    // power-limited in these kernels and the denser forward costs the following kernels more clock than it
+    // gains.  Default = 2 waves per SIMD (512 threads); KAGNN_FWD_WIDE=1 selects the 4-wave launch.
+    static const bool narrow = getenv("KAGNN_FWD_WIDE") == nullptr;
 #define GO(KK, TT) return launch_fwd<KK, TT, 512>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, sh, ws, ws_bytes, st)
 #define GOW(KK, TT) if (narrow) GO(KK, TT); return launch_fwd<KK, TT, 1024>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, sh, ws, ws_bytes, st)
 #define BYOT(KK) switch (OT) { case 1: GOW(KK, 1); case 2: GOW(KK, 2); case 3: GO(KK, 3); case 4: GO(KK, 4); }
