@@ -32,6 +32,11 @@ int kan_split_dx(const float*, long, const float*, long, long, const float*, int
 size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
 int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t);
 bool kan_split_fwd_ok(int in, int out, int G, int K);
+bool kan_sparse_fwd_ok(int in, int out, int G, int K);
+size_t kan_sparse_pack_fwd_bytes(int in, int out);
+int kan_sparse_pack_fwd(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
+size_t kan_sparse_fwd_ws_bytes(long N, int in, int out);
+int kan_sparse_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t);
 bool kan_split_dx_ok(int in, int out, int G, int K);
 bool kan_split_dw_ok(int in, int out, int G, int K);
 
@@ -57,6 +62,7 @@ static int check_kan_dims(const char* fn, int in, int out, int G, int K, int mod
 // the split kernels address activations through buffer descriptors with 32-bit byte offsets
 static bool fits32(long N, long ld) { return (N + (1L << 18)) * ld * 4 < 0xF0000000L; }
 static bool use_split_fwd(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_fwd_ok(in, out, G, K); }
+static bool use_sparse_fwd(int in, int out, int G, int K, int mode) { return use_split_fwd(in, out, G, K, mode) && kan_sparse_fwd_ok(in, out, G, K); }
 static bool use_split_dx(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_dx_ok(in, out, G, K); }
 static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_dw_ok(in, out, G, K); }
 
@@ -138,7 +144,8 @@ int kagnn_kan_pack_bytes(int32_t in, int32_t out, int32_t G, int32_t K, int32_t 
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(fwd_bytes && dx_bytes, "null output");
-    *fwd_bytes = use_split_fwd(in, out, G, K, mode) ? kan_split_pack_fwd_bytes(in, out, G + K) : kan_f32_pack_fwd_bytes(in, out, G + K);
+    *fwd_bytes = use_sparse_fwd(in, out, G, K, mode) ? kan_sparse_pack_fwd_bytes(in, out)
+               : use_split_fwd(in, out, G, K, mode) ? kan_split_pack_fwd_bytes(in, out, G + K) : kan_f32_pack_fwd_bytes(in, out, G + K);
     *dx_bytes = use_split_dx(in, out, G, K, mode) ? kan_split_pack_dx_bytes(in, out, G + K) : kan_f32_pack_dx_bytes(in, out, G + K);
     return KAGNN_OK;
 }
@@ -150,7 +157,11 @@ int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in
     KAGNN_CHECK_ARG(bw && sw && pack_fwd && pack_dx, "null array");
     const bool sf = use_split_fwd(in, out, G, K, mode), sd = use_split_dx(in, out, G, K, mode);
     // one launch per layout; each workgroup derives the power-of-two weight scale itself
-    if (sf) { rc = kan_split_pack_fwd_noscale(bw, sw, sc, in, out, G + K, pack_fwd, as_stream(stream)); if (rc) return rc; }
+    if (sf) {
+        rc = use_sparse_fwd(in, out, G, K, mode) ? kan_sparse_pack_fwd(bw, sw, sc, in, out, G + K, pack_fwd, as_stream(stream))
+                                                 : kan_split_pack_fwd_noscale(bw, sw, sc, in, out, G + K, pack_fwd, as_stream(stream));
+        if (rc) return rc;
+    }
     if (sd) { rc = kan_split_pack_dx_noscale(bw, sw, sc, in, out, G + K, pack_dx, as_stream(stream)); if (rc) return rc; }
     if (!sf || !sd)
         return kan_f32_pack(bw, sw, sc, in, out, G + K, sf ? nullptr : (float*)pack_fwd, sd ? nullptr : (float*)pack_dx, as_stream(stream));
@@ -162,7 +173,8 @@ int kagnn_kan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G,
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
-    *bytes = use_split_fwd(in, out, G, K, mode) ? kan_split_fwd_ws_bytes(N, in, out, G + K) : 0;
+    *bytes = use_sparse_fwd(in, out, G, K, mode) ? kan_sparse_fwd_ws_bytes(N, in, out)
+           : use_split_fwd(in, out, G, K, mode) ? kan_split_fwd_ws_bytes(N, in, out, G + K) : 0;
     return KAGNN_OK;
 }
 
@@ -176,6 +188,8 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* kn
     KAGNN_CHECK_ARG(x && knots && pack_fwd && y, "null array");
     if (use_split_fwd(in, out, G, K, mode)) {
         if (!(fits32(N, ldx) && fits32(N, ldy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
+        if (use_sparse_fwd(in, out, G, K, mode))
+            return kan_sparse_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
         return kan_split_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
     }
     return kan_f32_fwd(x, ldx, N, knots, in, out, G, K, (const float*)pack_fwd, y, ldy, as_stream(stream));

@@ -1,0 +1,380 @@
+// KANLinear forward for cubic splines with <= 8 coefficients per feature on the 2:4-SPARSE matrix cores
+// (v_smfmac_f32_32x32x32_f16).  Same numerics as kan_split.hip (fp16 hi/lo split operands, three products per
+// fp32 product, fp32 accumulate) -- the sparse instruction multiplies exactly the stored values, so results are
+// bit-identical to the dense formulation -- at half the matrix-core work:
+//
+//   Of a feature's 8 coefficient slots only the 4 CONSECUTIVE ones c0..c0+3 (c0 = span - 3) are non-zero.  With
+//   the slots laid along K in the order [0,4,1,5 | 2,6,3,7] every window of 4 consecutive slots puts exactly two
+//   non-zeros into each group of four K positions: the 2:4 pattern the sparse MFMA wants.  A lane therefore feeds
+//   4 fp16 values + 8 index bits per feature instead of an 8-slot fragment with 4 zeros, and one instruction
+//   covers 4 features (K = 32) in the time the dense one covers 2.  The placement also shrinks from 8 to 4
+//   v_perm_b32 per scalar.
+//
+// Operand layout of v_smfmac_f32_32x32x32_f16, measured with tools/probes/smfmac_probe.hip (the ISA text is not
+// available offline): lane (m = l&31, kg = l>>5) stores pair i (values 2i, 2i+1) of K group 4*kg + i, index bits
+// [4i+1:4i] / [4i+3:4i+2] = their positions inside the group (low 16 bits of the index VGPR, ABID 0); the dense
+// operand's lane (n = l&31, kg) holds, for e = 0..15, K = 8*kg + (e&7) + 16*(e>>3).
+//
+// Reference behaviour replaced: node_classification_clean/ekan.py:79-112,146-162 (as kan_split.hip).
+#include "split_common.h"
+
+namespace kagnn {
+
+typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kSpCF = 64;                 // features per LDS chunk
+constexpr int kSpOutBlk = 64;             // output columns per launch (2 accumulator tiles: the 64-feature chunk of packed W is 152 KB)
+constexpr int kSpSteps = kSpCF / 4;       // sparse MFMA steps per chunk: 2 features per lane half and step
+__host__ __device__ inline size_t sparse_fwd_chunk_bytes(int OT) {
+    return (size_t)kSpSteps * OT * 2 * 2048 + (size_t)(kSpCF / 16) * OT * 3 * 1024;
+}
+
+bool kan_sparse_fwd_ok(int in, int out, int G, int K) { return K == 3 && G + K <= 8; }
+
+static size_t sp_blk_bytes(int in, int ob) { return kHdrBytes + (size_t)cdiv(in, kSpCF) * sparse_fwd_chunk_bytes(cdiv(ob, 32)); }
+size_t kan_sparse_pack_fwd_bytes(int in, int out) { return (size_t)cdiv(out, kSpOutBlk) * sp_blk_bytes(in, min(out, kSpOutBlk)); }
+
+// K position p of a feature's 8-slot block holds coefficient slot slot_at(p): order [0,4,1,5,2,6,3,7]
+__host__ __device__ inline int slot_at(int p) { return (p >> 1) + 4 * (p & 1); }
+
+// chunk = [step t 16][out tile][hi|lo][lane 64][16 halfs]  +  base fragments as in kan_split.hip
+__global__ void sparse_pack_fwd_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
+                                       const float* __restrict__ sc, int in, int out, int C,
+                                       unsigned char* __restrict__ pack) {
+    const int OT = cdiv(out, 32), HF = kSpCF / 2, BPC = kSpCF / 16;
+    __shared__ float s_m[17];
+    const float wmax = block_absmax_w(bw, sw, sc, in, out, C, s_m);
+    const int e = scale_exp_from_max(wmax);
+    const float wscale = ldexpf(1.0f, -e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        reinterpret_cast<float*>(pack)[0] = ldexpf(1.0f, e - 10);   // post scale: undo 2^10 and 2^-e
+        reinterpret_cast<int*>(pack)[1] = e;
+    }
+    const size_t chunk_bytes = sparse_fwd_chunk_bytes(OT);
+    const long spl_per_chunk = (long)kSpSteps * OT * 128, base_per_chunk = (long)BPC * OT * 64;   // spline items: (lane, half)
+    const long per_chunk = spl_per_chunk + base_per_chunk;
+    const long total = (long)cdiv(in, kSpCF) * per_chunk;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = i / per_chunk; long r = i % per_chunk;
+        unsigned char* cbase = pack + kHdrBytes + (size_t)ch * chunk_bytes;
+        if (r < spl_per_chunk) {
+            const int h = r & 1; r >>= 1;                 // which 8 of the lane's 16 halfs
+            const int lane = r & 63; r >>= 6;
+            const int ot = r % OT; const int t = r / OT;
+            const int o = 32 * ot + (lane & 31), kg = lane >> 5;
+            _Float16* dh = reinterpret_cast<_Float16*>(cbase + ((size_t)(t * OT + ot) * 2 + 0) * 2048 + lane * 32 + h * 16);
+            _Float16* dl = reinterpret_cast<_Float16*>(cbase + ((size_t)(t * OT + ot) * 2 + 1) * 2048 + lane * 32 + h * 16);
+            // element el = 8h + p holds K = 8*kg + p + 16*h: K block kg + 2h = feature #kg of A's lane half h
+            const int f = ch * kSpCF + h * HF + 2 * t + kg;
+            for (int p = 0; p < 8; ++p) {
+                const int slot = slot_at(p);
+                const float w = wcat_s(bw, sw, sc, in, out, C, o, f, slot < C ? slot : C + 1) * wscale;
+                const _Float16 hv = (_Float16)w;
+                dh[p] = hv;
+                dl[p] = (_Float16)(w - (float)hv);
+            }
+        } else {
+            r -= spl_per_chunk;
+            const int lane = r & 63; r >>= 6;
+            const int ot = r % OT; const int sb = r / OT;
+            const int o = 32 * ot + (lane & 31);
+            unsigned char* bb = cbase + (size_t)kSpSteps * OT * 2 * 2048 + (size_t)(sb * OT + ot) * 3 * 1024 + lane * 16;
+            for (int j = 0; j < 8; ++j) {
+                const int f = ch * kSpCF + (lane >> 5) * HF + 8 * sb + j;
+                float w = wcat_s(bw, sw, sc, in, out, C, o, f, C) * wscale;
+                for (int p = 0; p < 3; ++p) {              // truncating bf16 split: w = w1 + w2 + w3 (+2^-24)
+                    const unsigned bits = __float_as_uint(w) & 0xffff0000u;
+                    reinterpret_cast<unsigned short*>(bb + p * 1024)[j] = (unsigned short)(bits >> 16);
+                    w -= __uint_as_float(bits);
+                }
+            }
+        }
+    }
+}
+
+// per span index i = floor((x-g0)/h) + 1 (clamped to [0,31]): {selector of group 0, selector of group 1, index byte}
+// -- which payload halves (r = slot - c0, c0 = i - 4) land in the two stored values of each K group, and where.
+__device__ __forceinline__ void build_sparse_table(unsigned* tbl /* LDS, 32*4 */, int tid, int nknots) {
+    if (tid < 32) {
+        const int i = tid, c0 = i - 4;
+        const bool live = (i >= 1) && (i <= nknots - 1);
+        unsigned sel[2] = {0x0c0c0c0cu, 0x0c0c0c0cu}, ib = 0;
+        for (int g = 0; g < 2; ++g) {
+            int pos[2] = {-1, -1}, pay[2] = {-1, -1}, n = 0;
+            for (int p = 0; p < 4 && live; ++p) {
+                const int r = slot_at(4 * g + p) - c0;
+                if (r >= 0 && r <= 3 && n < 2) { pos[n] = p; pay[n] = r; ++n; }
+            }
+            for (int p = 0; p < 4 && n < 2; ++p) {      // pad with zero values at unused positions (ascending order kept)
+                if (p != pos[0]) { pos[n] = p; pay[n] = -1; ++n; }
+            }
+            if (pos[0] > pos[1]) { int t = pos[0]; pos[0] = pos[1]; pos[1] = t; t = pay[0]; pay[0] = pay[1]; pay[1] = t; }
+            unsigned s = 0;
+            for (int k = 0; k < 2; ++k) {
+                const unsigned b = pay[k] >= 0 ? (unsigned)((2 * pay[k]) | ((2 * pay[k] + 1) << 8)) : 0x0c0cu;
+                s |= b << (16 * k);
+            }
+            sel[g] = s;
+            ib |= (unsigned)(pos[0] | (pos[1] << 2)) << (4 * g);
+        }
+        tbl[4 * i + 0] = sel[0]; tbl[4 * i + 1] = sel[1]; tbl[4 * i + 2] = ib; tbl[4 * i + 3] = 0;
+    }
+}
+
+__device__ __forceinline__ f32x16 smfmac(const u32x4& a, const u32x4& b0, const u32x4& b1, const f32x16& c, int idx) {
+    typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+    const u32x8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    return __builtin_amdgcn_smfmac_f32_32x32x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x16, b), c, idx, 0, 0);
+}
+
+// 512 threads = 8 waves (2 per SIMD), one wave = 32 rows; persistent workgroups, packed W resident in LDS when the
+// layer has one chunk (in <= 64), split-K over blockIdx.y for few-row inputs (see kan_split.hip).
+template <int OT>
+__global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
+    const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g, int nknots,
+    const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy, int out,
+    int chunks_per_split, long part_stride) {
+    constexpr int NT = 512, CF = kSpCF, HF = CF / 2, BPC = CF / 16, NG = HF / 8, ROWS = (NT / 64) * 32;
+    constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 3 * 1024;
+    constexpr int SPL_BYTES = kSpSteps * OT * 2 * 2048;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* s_knots = reinterpret_cast<float*>(smem);
+    unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
+    unsigned char* s_w = smem + kLdsHdr;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < nknots) s_knots[tid] = knots_g[tid];
+    build_sparse_table(s_tbl, tid, nknots);
+    const float post = reinterpret_cast<const float*>(pack)[0];
+    const unsigned char* gw = pack + kHdrBytes;
+    auto stage_chunk = [&](int ch) {
+        const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)ch * CHUNK_BYTES);
+        uint4* dst = reinterpret_cast<uint4*>(s_w);
+        for (int i = tid; i < CHUNK_BYTES / 16; i += NT) dst[i] = src[i];
+    };
+    const int ch_begin = blockIdx.y * chunks_per_split, ch_end = min(nchunks, ch_begin + chunks_per_split);
+    const bool resident = (ch_end - ch_begin) == 1;
+    if (resident) stage_chunk(ch_begin);
+    y += (long)blockIdx.y * part_stride;
+    __syncthreads();
+    const Frag3Geom f3geo = frag3_geom(s_knots, nknots);
+    const int r = lane & 31, kg = lane >> 5;
+    const bool al4 = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const GBuf xb = gbuf(x, N, ldx, in), yb = gbuf(y, N, ldy, out);
+    const unsigned ldx4 = (unsigned)ldx * 4u, ldy4 = (unsigned)ldy * 4u;
+    auto load8 = [&](long row0t, int ch, int g, float (&v)[8]) {
+        const unsigned ro = (unsigned)(row0t + r) * ldx4 + kg * HF * 4;   // rows >= N: past the descriptor -> zeros
+        const unsigned so = (unsigned)(ch * CF + 8 * g) * 4u;
+        if (al4 && ch * CF + CF <= in) {                  // wave-uniform
+            gld4_s(xb, ro, so, v);
+            gld4_s(xb, ro, so + 16, v + 4);
+        } else {
+            const int f0 = ch * CF + kg * HF + 8 * g;
+            const unsigned rb = (unsigned)(row0t + r) * ldx4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gld(xb, rb + min(f0 + j, in - 1) * 4);   // features >= in meet zero weights
+        }
+    };
+    // one scalar -> its two stored dwords (hi and lo parts) and its index byte
+    auto expand1 = [&](float xv, const u32x4& e, float u, unsigned& hi0, unsigned& hi1, unsigned& lo0, unsigned& lo1) {
+        unsigned h0, h1, l0, l1;
+        frag3_payload(u, h0, h1, l0, l1);
+        hi0 = __builtin_amdgcn_perm(h1, h0, e[0]); hi1 = __builtin_amdgcn_perm(h1, h0, e[1]);
+        lo0 = __builtin_amdgcn_perm(l1, l0, e[0]); lo1 = __builtin_amdgcn_perm(l1, l0, e[1]);
+        (void)xv;
+    };
+
+    float xn[8];
+    load8((long)blockIdx.x * ROWS + wave * 32, ch_begin, 0, xn);
+    for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
+        const long row0 = tile * ROWS + wave * 32;
+        f32x16 acc[OT];
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+        for (int ch = ch_begin; ch < ch_end; ++ch) {
+            if (!resident) {
+                __syncthreads();
+                stage_chunk(ch);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float xv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = xn[j];
+                if (g + 1 < NG) load8(row0, ch, g + 1, xn);
+                else if (ch + 1 < ch_end) load8(row0, ch + 1, 0, xn);
+                else load8(row0 + (long)gridDim.x * ROWS, ch_begin, 0, xn);
+
+                // ---- 4 sparse steps per group (features 2s, 2s+1 of the group): while the 3*OT sparse MFMAs of step
+                // s execute, the VALU expands the two scalars of step s+1 and their weights / table entries are in flight
+                u32x4 ahi, alo, bw[4 * OT];
+                int aidx;
+                auto prep_reads = [&](int s, u32x4& e0, u32x4& e1, float& u0, float& u1, u32x4 (&w)[4 * OT]) {
+                    unsigned o0, o1;
+                    frag3_index<false>(xv[2 * s], f3geo, u0, o0);
+                    frag3_index<false>(xv[2 * s + 1], f3geo, u1, o1);
+                    e0 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + o0);
+                    e1 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + o1);
+                    const unsigned char* wp = s_w + (size_t)((4 * g + s) * OT) * 2 * 2048 + lane * 32;
+#pragma unroll
+                    for (int i = 0; i < 2 * OT; ++i) {      // [ot][hi|lo] x 32 bytes
+                        w[2 * i] = *reinterpret_cast<const u32x4*>(wp + i * 2048);
+                        w[2 * i + 1] = *reinterpret_cast<const u32x4*>(wp + i * 2048 + 16);
+                    }
+                };
+                auto build = [&](int s, const u32x4& e0, const u32x4& e1, float u0, float u1, u32x4& hi, u32x4& lo, int& idx) {
+                    unsigned a0, a1, a2, a3, b0, b1, b2, b3;
+                    expand1(xv[2 * s], e0, u0, a0, a1, b0, b1);
+                    expand1(xv[2 * s + 1], e1, u1, a2, a3, b2, b3);
+                    hi = u32x4{a0, a1, a2, a3};
+                    lo = u32x4{b0, b1, b2, b3};
+                    idx = (int)(e0[2] | (e1[2] << 8));
+                };
+                {
+                    u32x4 e0, e1; float u0, u1;
+                    prep_reads(0, e0, e1, u0, u1, bw);
+                    build(0, e0, e1, u0, u1, ahi, alo, aidx);
+                }
+                u32x4 a1, a2, a3;                          // SiLU fragments, prepared under the last step's MFMAs
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    u32x4 e0, e1, nbw[4 * OT]; float u0, u1;
+                    if (s < 3) prep_reads(s + 1, e0, e1, u0, u1, nbw);
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) acc[t] = smfmac(ahi, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) acc[t] = smfmac(ahi, bw[4 * t + 2], bw[4 * t + 3], acc[t], aidx);
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) acc[t] = smfmac(alo, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
+                    if (s < 3) {
+                        u32x4 nhi, nlo; int nidx;
+                        build(s + 1, e0, e1, u0, u1, nhi, nlo, nidx);
+                        ahi = nhi; alo = nlo; aidx = nidx;
+#pragma unroll
+                        for (int i = 0; i < 4 * OT; ++i) bw[i] = nbw[i];
+                    } else {
+                        float sv[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) sv[i] = (siluf(xv[i]) + (xv[i] - xv[i])) * kAScale;   // +-Inf -> NaN like the reference
+                        split_bf16x3(sv, a1, a2, a3);
+                    }
+                }
+                {
+                    const unsigned char* wp = s_w + SPL_BYTES + (size_t)(g * OT) * 3 * 1024 + lane * 16;
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) {
+                        const u32x4 w1 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 0) * 1024);
+                        const u32x4 w2 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 1) * 1024);
+                        const u32x4 w3 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 2) * 1024);
+                        acc[t] = mfma_bf16(a3, w1, acc[t]);
+                        acc[t] = mfma_bf16(a2, w2, acc[t]);
+                        acc[t] = mfma_bf16(a1, w3, acc[t]);
+                        acc[t] = mfma_bf16(a2, w1, acc[t]);
+                        acc[t] = mfma_bf16(a1, w2, acc[t]);
+                        acc[t] = mfma_bf16(a1, w1, acc[t]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < OT; ++t) {
+            const int col = 32 * t + r;
+            const unsigned base = (unsigned)(row0 + 4 * kg) * ldy4 + col * 4;
+            if (col < out) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped
+                    gst_s(yb, base, (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, acc[t][i] * post);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+int kan_sparse_pack_fwd(const float* bw, const float* sw, const float* sc, int in, int out, int C, void* pack_fwd,
+                        hipStream_t st) {
+    const size_t stride = sp_blk_bytes(in, min(out, kSpOutBlk));
+    for (int b = 0; b * kSpOutBlk < out; ++b) {
+        const int ob = min(kSpOutBlk, out - b * kSpOutBlk);
+        const long o0 = (long)b * kSpOutBlk;
+        const long items = (long)(sp_blk_bytes(in, ob) - kHdrBytes) / 16;
+        sparse_pack_fwd_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(
+            bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C,
+            static_cast<unsigned char*>(pack_fwd) + b * stride);
+        KAGNN_LAUNCH_CHECK();
+    }
+    return KAGNN_OK;
+}
+
+struct SpSplit { int splits, cps; };
+static SpSplit sp_split_plan(long N, int nchunks) {        // same policy as kan_split.hip
+    SpSplit p{1, nchunks};
+    const long row_blocks = cdiv(N, 256);
+    if (row_blocks >= 128 || nchunks < 2) return p;
+    const int want = (int)min((long)nchunks, 256 / row_blocks);
+    p.cps = cdiv(nchunks, max(want, 1));
+    p.splits = cdiv(nchunks, p.cps);
+    return p;
+}
+
+size_t kan_sparse_fwd_ws_bytes(long N, int in, int out) {
+    const SpSplit p = sp_split_plan(N, cdiv(in, kSpCF));
+    return p.splits > 1 ? (size_t)p.splits * N * min(out, kSpOutBlk) * sizeof(float) : 0;
+}
+
+__global__ void sparse_sum_splits_kernel(const float* __restrict__ part, int splits, long N, int out,
+                                         float* __restrict__ y, long ldy) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= N * out) return;
+    float a = 0.0f;
+    for (int s = 0; s < splits; ++s) a += part[(long)s * N * out + i];
+    y[(i / out) * ldy + (i % out)] = a;
+}
+
+template <int OT>
+static int launch_sparse(const float* x, long ldx, long N, int in, const float* knots, int nknots,
+                         const unsigned char* pack, float* y, long ldy, int out, float* ws, size_t ws_bytes,
+                         hipStream_t st) {
+    const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
+    static bool configured = false;
+    if (!configured) {
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const int nchunks = cdiv(in, kSpCF);
+    const int gx = (int)min((long)cdiv(N, 256), 256L);
+    const SpSplit p = sp_split_plan(N, nchunks);
+    if (p.splits > 1) {
+        if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
+            return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_sparse_fwd");
+        kan_sparse_fwd_kernel<OT><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
+                                                                         p.cps, N * (long)out);
+        KAGNN_LAUNCH_CHECK();
+        sparse_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
+    kan_sparse_fwd_kernel<OT><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int kan_sparse_fwd(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
+                   const void* pack, float* y, long ldy, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int nk = G + 2 * K + 1;
+    const size_t stride = sp_blk_bytes(in, min(out, kSpOutBlk));
+    for (int b = 0; b * kSpOutBlk < out; ++b) {
+        const int ob = min(kSpOutBlk, out - b * kSpOutBlk), OT = cdiv(ob, 32);
+        const unsigned char* p = static_cast<const unsigned char*>(pack) + b * stride;
+        float* yb = y + b * kSpOutBlk;
+        int rc;
+        if (OT == 1) rc = launch_sparse<1>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, st);
+        else rc = launch_sparse<2>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, st);
+        if (rc) return rc;
+    }
+    return KAGNN_OK;
+}
+
+}  // namespace kagnn
