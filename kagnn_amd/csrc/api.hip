@@ -33,6 +33,8 @@ size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
 int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t);
 bool kan_split_fwd_ok(int in, int out, int G, int K);
 bool kan_sparse_fwd_ok(int in, int out, int G, int K);
+bool kan_fused_pack_ok(int in, int out, int C);
+int kan_fused_pack(const float*, const float*, const float*, int, int, int, void*, void*, hipStream_t);
 size_t kan_sparse_pack_fwd_bytes(int in, int out);
 int kan_sparse_pack_fwd(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 size_t kan_sparse_fwd_ws_bytes(long N, int in, int out);
@@ -156,7 +158,9 @@ int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in
     if (rc) return rc;
     KAGNN_CHECK_ARG(bw && sw && pack_fwd && pack_dx, "null array");
     const bool sf = use_split_fwd(in, out, G, K, mode), sd = use_split_dx(in, out, G, K, mode);
-    // one launch per layout; each workgroup derives the power-of-two weight scale itself
+    // each workgroup derives the power-of-two weight scale itself; the hot case takes ONE launch for both layouts
+    if (sd && use_sparse_fwd(in, out, G, K, mode) && kan_fused_pack_ok(in, out, G + K))
+        return kan_fused_pack(bw, sw, sc, in, out, G + K, pack_fwd, pack_dx, as_stream(stream));
     if (sf) {
         rc = use_sparse_fwd(in, out, G, K, mode) ? kan_sparse_pack_fwd(bw, sw, sc, in, out, G + K, pack_fwd, as_stream(stream))
                                                  : kan_split_pack_fwd_noscale(bw, sw, sc, in, out, G + K, pack_fwd, as_stream(stream));

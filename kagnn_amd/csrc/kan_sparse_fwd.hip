@@ -38,23 +38,15 @@ size_t kan_sparse_pack_fwd_bytes(int in, int out) { return (size_t)cdiv(out, kSp
 __host__ __device__ inline int slot_at(int p) { return (p >> 1) + 4 * (p & 1); }
 
 // chunk = [step t 16][out tile][hi|lo][lane 64][16 halfs]  +  base fragments as in kan_split.hip
-__global__ void sparse_pack_fwd_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
-                                       const float* __restrict__ sc, int in, int out, int C,
-                                       unsigned char* __restrict__ pack) {
+__device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, const float* __restrict__ sw,
+                                                  const float* __restrict__ sc, int in, int out, int C,
+                                                  unsigned char* __restrict__ pack, float wscale, long first, long step) {
     const int OT = cdiv(out, 32), HF = kSpCF / 2, BPC = kSpCF / 16;
-    __shared__ float s_m[17];
-    const float wmax = block_absmax_w(bw, sw, sc, in, out, C, s_m);
-    const int e = scale_exp_from_max(wmax);
-    const float wscale = ldexpf(1.0f, -e);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        reinterpret_cast<float*>(pack)[0] = ldexpf(1.0f, e - 10);   // post scale: undo 2^10 and 2^-e
-        reinterpret_cast<int*>(pack)[1] = e;
-    }
     const size_t chunk_bytes = sparse_fwd_chunk_bytes(OT);
     const long spl_per_chunk = (long)kSpSteps * OT * 128, base_per_chunk = (long)BPC * OT * 64;   // spline items: (lane, half)
     const long per_chunk = spl_per_chunk + base_per_chunk;
     const long total = (long)cdiv(in, kSpCF) * per_chunk;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = first; i < total; i += step) {
         const int ch = i / per_chunk; long r = i % per_chunk;
         unsigned char* cbase = pack + kHdrBytes + (size_t)ch * chunk_bytes;
         if (r < spl_per_chunk) {
@@ -90,6 +82,40 @@ __global__ void sparse_pack_fwd_kernel(const float* __restrict__ bw, const float
             }
         }
     }
+}
+
+__device__ __forceinline__ float pack_header(const float* bw, const float* sw, const float* sc, int in, int out, int C,
+                                             unsigned char* pack, bool writer, float* s_m) {
+    const float wmax = block_absmax_w(bw, sw, sc, in, out, C, s_m);
+    const int e = scale_exp_from_max(wmax);
+    if (writer) {
+        reinterpret_cast<float*>(pack)[0] = ldexpf(1.0f, e - 10);   // post scale: undo 2^10 and 2^-e
+        reinterpret_cast<int*>(pack)[1] = e;
+    }
+    return ldexpf(1.0f, -e);
+}
+
+__global__ void sparse_pack_fwd_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
+                                       const float* __restrict__ sc, int in, int out, int C,
+                                       unsigned char* __restrict__ pack) {
+    __shared__ float s_m[17];
+    const float wscale = pack_header(bw, sw, sc, in, out, C, pack, blockIdx.x == 0 && threadIdx.x == 0, s_m);
+    pack_sparse_items(bw, sw, sc, in, out, C, pack, wscale, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// one launch for BOTH layouts of a layer (out <= 64: one block of each): workgroups [0, nbf) write the sparse
+// forward pack, the rest the input-gradient pack.  Two launches of ~15 us each were 2.5 % of the layer step.
+__global__ void fused_pack_kernel(const float* __restrict__ bw, const float* __restrict__ sw, const float* __restrict__ sc,
+                                  int in, int out, int C, unsigned char* __restrict__ pack_fwd,
+                                  unsigned char* __restrict__ pack_dx, int nbf) {
+    __shared__ float s_m[17];
+    const bool fwd = (int)blockIdx.x < nbf;
+    const int bid = fwd ? blockIdx.x : blockIdx.x - nbf, nb = fwd ? nbf : gridDim.x - nbf;
+    unsigned char* pack = fwd ? pack_fwd : pack_dx;
+    const float wscale = pack_header(bw, sw, sc, in, out, C, pack, bid == 0 && threadIdx.x == 0, s_m);
+    const long first = bid * (long)blockDim.x + threadIdx.x, step = (long)nb * blockDim.x;
+    if (fwd) pack_sparse_items(bw, sw, sc, in, out, C, pack, wscale, first, step);
+    else pack_dx_items(bw, sw, sc, in, out, C, dx_q2(out), pack, wscale, first, step);
 }
 
 // per span index i = floor((x-g0)/h) + 1 (clamped to [0,31]): {selector of group 0, selector of group 1, index byte}
@@ -305,6 +331,19 @@ int kan_sparse_pack_fwd(const float* bw, const float* sw, const float* sc, int i
             static_cast<unsigned char*>(pack_fwd) + b * stride);
         KAGNN_LAUNCH_CHECK();
     }
+    return KAGNN_OK;
+}
+
+// both packs of one layer in one launch; only for out <= 64 (one output block in either layout), C <= 8
+bool kan_fused_pack_ok(int in, int out, int C) { return out <= kSpOutBlk && C <= 8; }
+int kan_fused_pack(const float* bw, const float* sw, const float* sc, int in, int out, int C, void* pack_fwd,
+                   void* pack_dx, hipStream_t st) {
+    const long items_f = (long)(sp_blk_bytes(in, out) - kHdrBytes) / 16;
+    const long items_d = (long)cdiv(in, 16) * kCTmax * dx_q2(out) * 64;
+    const int nbf = (int)min((items_f + 1023) / 1024, 48L), nbd = (int)min((items_d + 1023) / 1024, 48L);
+    fused_pack_kernel<<<nbf + nbd, 1024, 0, st>>>(bw, sw, sc, in, out, C, static_cast<unsigned char*>(pack_fwd),
+                                                  static_cast<unsigned char*>(pack_dx), nbf);
+    KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
 

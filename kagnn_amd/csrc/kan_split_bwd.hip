@@ -23,8 +23,6 @@ int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP
                   const float* sc, float* g_bw, float* g_sw, float* g_sc, hipStream_t st);
 
 // ====================================================================== input gradient
-constexpr int kCTmax = 9;     // C + 1 <= 9 accumulators (8 spline coefficients + base); unused slots carry zero weights
-static inline int dx_q2(int out) { return out <= 32 ? 1 : (out <= 64 ? 2 : 4); }   // 32-wide k-steps
 
 bool kan_split_dx_ok(int in, int out, int G, int K) { return K >= 0 && K <= 4 && G + K <= 16; }   // K == 0: RBF basis
 static inline int vshift(int C) { return C > 8 ? 1 : 0; }     // 9..16 coefficients: two 8-slot windows per feature (wcat_v)
@@ -37,7 +35,6 @@ size_t kan_split_pack_dx_bytes(int in, int out, int C) {
     return (size_t)cdiv(out, kOutBlk) * dx_blk_bytes(in << vshift(C), min(out, kOutBlk));
 }
 
-// pack_dx[ft16][c][q2][part][lane][8] : lane (f = lane&15, kg = lane>>4), j -> W'[o = 32*q2+8*kg+j][16*ft16+f][c]
 __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
                                      const float* __restrict__ sc, int in, int out, int C, int Q2,
                                      unsigned char* __restrict__ pack, int self_scale) {
@@ -50,25 +47,7 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
         reinterpret_cast<float*>(pack)[0] = ldexpf(1.0f, e - 10);
         reinterpret_cast<int*>(pack)[1] = e;
     }
-    const int CT = kCTmax;
-    const int sh = C > 8 ? 1 : 0, inv = in << sh;
-    const long total = (long)cdiv(inv, 16) * CT * Q2 * 64;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int lane = i & 63; long r = i >> 6;
-        const int q = r % Q2; r /= Q2;
-        const int c = r % CT; const int ft = r / CT;
-        const int f = 16 * ft + (lane & 15);
-        _Float16* dh = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q2 + q) * 2 + 0) * 1024 + lane * 16);
-        _Float16* dl = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q2 + q) * 2 + 1) * 1024 + lane * 16);
-        for (int j = 0; j < 8; ++j) {
-            const int o = 32 * q + 8 * (lane >> 4) + j;
-            // slot 8 = base weight, slots 0..7 = spline coefficients of this (virtual) feature's window
-            const float w = wcat_v(bw, sw, sc, in, out, C, o, f, c, sh) * wscale;
-            const _Float16 h = (_Float16)w;
-            dh[j] = h;
-            dl[j] = (_Float16)(w - (float)h);
-        }
-    }
+    pack_dx_items(bw, sw, sc, in, out, C, Q2, pack, wscale, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 int kan_split_pack_dx_noscale(const float* bw, const float* sw, const float* sc, int in, int out, int C,

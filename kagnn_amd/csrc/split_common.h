@@ -31,6 +31,36 @@ __device__ __forceinline__ float wcat_v(const float* bw, const float* sw, const 
     return c < C ? wcat_s(bw, sw, sc, in, out, C, o, f, c) : 0.0f;
 }
 
+// ---- packed W^T fragments for the input-gradient kernel (kan_split_bwd.hip); the item loop lives here so that
+// the fused pack launch of kan_sparse_fwd.hip can run it next to the forward layout's
+constexpr int kCTmax = 9;     // C + 1 <= 9 accumulators (8 spline coefficients + base); unused slots carry zero weights
+__host__ __device__ inline int dx_q2(int out) { return out <= 32 ? 1 : (out <= 64 ? 2 : 4); }   // 32-wide k-steps
+
+// pack_dx[ft16][c][q2][part][lane][8] : lane (f = lane&15, kg = lane>>4), j -> W'[o = 32*q2+8*kg+j][16*ft16+f][c]
+__device__ __forceinline__ void pack_dx_items(const float* __restrict__ bw, const float* __restrict__ sw,
+                                              const float* __restrict__ sc, int in, int out, int C, int Q2,
+                                              unsigned char* __restrict__ pack, float wscale, long first, long step) {
+    const int CT = kCTmax;
+    const int sh = C > 8 ? 1 : 0, inv = in << sh;
+    const long total = (long)((inv + 15) / 16) * CT * Q2 * 64;
+    for (long i = first; i < total; i += step) {
+        const int lane = i & 63; long r = i >> 6;
+        const int q = r % Q2; r /= Q2;
+        const int c = r % CT; const int ft = r / CT;
+        const int f = 16 * ft + (lane & 15);
+        _Float16* dh = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q2 + q) * 2 + 0) * 1024 + lane * 16);
+        _Float16* dl = reinterpret_cast<_Float16*>(pack + kHdrBytes + ((size_t)((ft * CT + c) * Q2 + q) * 2 + 1) * 1024 + lane * 16);
+        for (int j = 0; j < 8; ++j) {
+            const int o = 32 * q + 8 * (lane >> 4) + j;
+            // slot 8 = base weight, slots 0..7 = spline coefficients of this (virtual) feature's window
+            const float w = wcat_v(bw, sw, sc, in, out, C, o, f, c, sh) * wscale;
+            const _Float16 h = (_Float16)w;
+            dh[j] = h;
+            dl[j] = (_Float16)(w - (float)h);
+        }
+    }
+}
+
 // ---- global memory through buffer descriptors: 32-bit byte offsets (no 64-bit VALU address math) and
 // hardware bounds checking -- a load past `bytes` returns 0, a store past it is dropped, so rows >= N
 // need neither clamping nor predication.  The host side only takes this path when the tensor (plus the
