@@ -163,7 +163,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = ops.EntryPointTimer()
+    # per-entry-point breakdown: three extra untimed steps with HIP events around every library call.  In the
+    # timed region only the dominant entry point keeps its events (the roofline figure is measured there, live);
+    # timing all ~25 calls of a step adds ~0.07 ms of event records to a 2.7 ms step.
+    PROFILE_STEPS = 3
+    warm_timer = ops.EntryPointTimer()
+    ops.set_timer(warm_timer)
+    sync()
+    for _ in range(PROFILE_STEPS):
+        step()
+    sync()
+    ops.set_timer(None)
+    warm = warm_timer.summary()
+    only = max(warm, key=lambda k: warm[k]["total_ms"]) if warm else None
+    timer = ops.EntryPointTimer(only=only)
     ops.set_timer(timer)
     sync()
     t0 = time.perf_counter()
@@ -183,10 +196,10 @@ def main():
         prof = timer.summary()
         c = args.grid + args.order
         fl = f // world if world > 1 else f
-        # dominant entry point of the layer (largest device time per step)
-        per_step = {k: v["total_ms"] / args.steps for k, v in prof.items()}
-        dom = max(per_step, key=per_step.get)
-        avg_ms = prof[dom]["avg_ms"]
+        # dominant entry point of the layer (largest device time per step); its launches were timed in the timed region
+        per_step = {k: v["total_ms"] / PROFILE_STEPS for k, v in warm.items()}
+        dom = only if only in prof else max(per_step, key=per_step.get)
+        avg_ms = prof[dom]["avg_ms"] if dom in prof else warm[dom]["avg_ms"]
         if dom == "kagnn_aggregate_sum":
             b = agg_bytes(n, e, fl)
             roof = {"kernel": dom, "bound": "hbm", "achieved": b / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
@@ -223,7 +236,7 @@ def main():
             "layer_algorithmic_bytes": layer_bytes(n, e, f),
             "layer_hbm_GBs": layer_gbs, "layer_hbm_frac": layer_gbs / HBM_PEAK_GBS,
             "roofline": roof,
-            "entry_points_ms_per_step": per_step,
+            "entry_points_ms_per_step": per_step, "entry_points_measured_in": "3 extra untimed steps after the warm-up (HIP events around every call)",
         }
         if not args.no_cpu_baseline and world == 1:
             ns = min(args.cpu_sample, n)

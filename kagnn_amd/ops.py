@@ -37,8 +37,9 @@ class EntryPointTimer:
     """Optional per-entry-point device timing (HIP events on the launch stream), used by bench.py
     to report the dominant kernel's duration live.  Off by default: zero overhead."""
 
-    def __init__(self):
+    def __init__(self, only: Optional[str] = None):
         self.records = []
+        self.only = only                 # time just this entry point (None: all of them)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -59,7 +60,7 @@ def set_timer(t: Optional[EntryPointTimer]) -> None:
 
 
 def _call(name: str, *args) -> None:
-    if _timer is None:
+    if _timer is None or (_timer.only is not None and _timer.only != name):
         _lib.call(name, *args)
         return
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
