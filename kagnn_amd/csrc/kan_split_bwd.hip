@@ -607,6 +607,45 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     }
 }
 
+// slab reduction and unpack in one launch (the non-virtual layout): thread (o, plane c) of workgroup (o-tile, f)
+// sums slab[.][c][f][o] in a fixed order, writes g_spline_weight (chain rule through spline_scaler), and the
+// planes of one (f, o) meet in LDS for g_spline_scaler = sum_c gW * spline_weight (fixed order, deterministic)
+__global__ void kan_dw_reduce_unpack_kernel(const float* __restrict__ slab, long NS, int in, int out, int C,
+                                            long inP, long outP, const float* __restrict__ sw,
+                                            const float* __restrict__ sc, float* __restrict__ g_bw,
+                                            float* __restrict__ g_sw, float* __restrict__ g_sc) {
+    extern __shared__ float s_red[];                 // [C][32]
+    const int ol = threadIdx.x & 31, c = threadIdx.x >> 5;
+    const int f = blockIdx.y, o = blockIdx.x * 32 + ol;
+    const long per = (long)(C + 1) * inP * outP;
+    const long i = ((long)c * inP + f) * outP + o;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long s = 0;
+    for (; s + 4 <= NS; s += 4) {
+        a0 += slab[(s + 0) * per + i];
+        a1 += slab[(s + 1) * per + i];
+        a2 += slab[(s + 2) * per + i];
+        a3 += slab[(s + 3) * per + i];
+    }
+    for (; s < NS; ++s) a0 += slab[s * per + i];
+    const float g = (a0 + a1) + (a2 + a3);
+    const bool live = o < out;
+    const long of = (long)min(o, out - 1) * in + f;
+    if (c < C) {
+        const float scale = sc ? sc[of] : 1.0f;
+        if (live) g_sw[of * C + c] = g * scale;
+        s_red[c * 32 + ol] = g * sw[of * C + c];
+    } else if (live && g_bw) {
+        g_bw[of] = g;
+    }
+    __syncthreads();
+    if (c == 0 && live && g_sc) {
+        float gs = 0.0f;
+        for (int k = 0; k < C; ++k) gs += s_red[k * 32 + ol];
+        g_sc[of] = gs;
+    }
+}
+
 // virtual-feature layout (sh == 1) back to the parameter layout, with the spline_scaler chain rule of
 // kan_dw_unpack: coefficient c of input feature f lives in plane c & 7 of virtual feature 2f + (c >> 3)
 __global__ void kan_dw_unpack_v_kernel(const float* __restrict__ gcat, int in, int out, int C, long inP,
@@ -651,6 +690,12 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
     }
 #undef L
     KAGNN_LAUNCH_CHECK();
+    if (!sh) {
+        kan_dw_reduce_unpack_kernel<<<dim3((unsigned)(p.outP / 32), (unsigned)in), 32 * (C + 1), (size_t)C * 32 * sizeof(float), st>>>(
+            slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
     { int rc = kan_dw_reduce(slab, p.NS, p.per, gcat, st); if (rc) return rc; }
     if (sh) {
         kan_dw_unpack_v_kernel<<<cdiv((long)in * out, 256), 256, 0, st>>>(gcat, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc);
