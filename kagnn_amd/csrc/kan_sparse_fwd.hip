@@ -26,18 +26,21 @@ constexpr int kSpCF = 64;                 // features per LDS chunk
 constexpr int kSpOutBlk = 64;             // output columns per launch (2 accumulator tiles: the 64-feature chunk of packed W is 152 KB)
 constexpr int kSpSteps = kSpCF / 4;       // sparse MFMA steps per chunk: 2 features per lane half and step
 __host__ __device__ inline size_t sparse_fwd_chunk_bytes(int OT) {
-    return (size_t)kSpSteps * OT * 2 * 2048 + (size_t)(kSpCF / 16) * OT * 3 * 1024;
+    return (size_t)kSpSteps * OT * 2 * 2048 + (size_t)(kSpCF / 16) * OT * 2 * 1024;
 }
 
 bool kan_sparse_fwd_ok(int in, int out, int G, int K) { return K == 3 && G + K <= 8; }
 
-static size_t sp_blk_bytes(int in, int ob) { return kHdrBytes + (size_t)cdiv(in, kSpCF) * sparse_fwd_chunk_bytes(cdiv(ob, 32)); }
+// one output block of the pack: header, chunks, then an fp32 copy of the block's base weights [ob][in] for the exact
+// SiLU path (so the forward entry point needs nothing but the pack)
+static size_t sp_chunks_bytes(int in, int ob) { return (size_t)cdiv(in, kSpCF) * sparse_fwd_chunk_bytes(cdiv(ob, 32)); }
+static size_t sp_blk_bytes(int in, int ob) { return kHdrBytes + sp_chunks_bytes(in, ob) + (((size_t)ob * in * 4 + 255) & ~(size_t)255); }
 size_t kan_sparse_pack_fwd_bytes(int in, int out) { return (size_t)cdiv(out, kSpOutBlk) * sp_blk_bytes(in, min(out, kSpOutBlk)); }
 
 // K position p of a feature's 8-slot block holds coefficient slot slot_at(p): order [0,4,1,5,2,6,3,7]
 __host__ __device__ inline int slot_at(int p) { return (p >> 1) + 4 * (p & 1); }
 
-// chunk = [step t 16][out tile][hi|lo][lane 64][16 halfs]  +  base fragments as in kan_split.hip
+// chunk = [step t 16][out tile][hi|lo][lane 64][16 halfs]  +  base fragments [group 4][out tile][hi|lo][lane 64][8 halfs]
 __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, const float* __restrict__ sw,
                                                   const float* __restrict__ sc, int in, int out, int C,
                                                   unsigned char* __restrict__ pack, float wscale, long first, long step) {
@@ -46,6 +49,8 @@ __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, 
     const long spl_per_chunk = (long)kSpSteps * OT * 128, base_per_chunk = (long)BPC * OT * 64;   // spline items: (lane, half)
     const long per_chunk = spl_per_chunk + base_per_chunk;
     const long total = (long)cdiv(in, kSpCF) * per_chunk;
+    float* bcopy = reinterpret_cast<float*>(pack + kHdrBytes + (size_t)cdiv(in, kSpCF) * chunk_bytes);
+    for (long i = first; i < (long)out * in; i += step) bcopy[i] = bw ? bw[i] : 0.0f;      // unscaled fp32 base weights
     for (long i = first; i < total; i += step) {
         const int ch = i / per_chunk; long r = i % per_chunk;
         unsigned char* cbase = pack + kHdrBytes + (size_t)ch * chunk_bytes;
@@ -70,15 +75,14 @@ __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, 
             const int lane = r & 63; r >>= 6;
             const int ot = r % OT; const int sb = r / OT;
             const int o = 32 * ot + (lane & 31);
-            unsigned char* bb = cbase + (size_t)kSpSteps * OT * 2 * 2048 + (size_t)(sb * OT + ot) * 3 * 1024 + lane * 16;
-            for (int j = 0; j < 8; ++j) {
+            _Float16* bh = reinterpret_cast<_Float16*>(cbase + (size_t)kSpSteps * OT * 2 * 2048 + ((size_t)(sb * OT + ot) * 2 + 0) * 1024 + lane * 16);
+            _Float16* bl = reinterpret_cast<_Float16*>(cbase + (size_t)kSpSteps * OT * 2 * 2048 + ((size_t)(sb * OT + ot) * 2 + 1) * 1024 + lane * 16);
+            for (int j = 0; j < 8; ++j) {                 // base weight of feature j of the group, fp16 hi / lo
                 const int f = ch * kSpCF + (lane >> 5) * HF + 8 * sb + j;
-                float w = wcat_s(bw, sw, sc, in, out, C, o, f, C) * wscale;
-                for (int p = 0; p < 3; ++p) {              // truncating bf16 split: w = w1 + w2 + w3 (+2^-24)
-                    const unsigned bits = __float_as_uint(w) & 0xffff0000u;
-                    reinterpret_cast<unsigned short*>(bb + p * 1024)[j] = (unsigned short)(bits >> 16);
-                    w -= __uint_as_float(bits);
-                }
+                const float w = wcat_s(bw, sw, sc, in, out, C, o, f, C) * wscale;
+                const _Float16 hv = (_Float16)w;
+                bh[j] = hv;
+                bl[j] = (_Float16)(w - (float)hv);
             }
         }
     }
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy, int out,
     int chunks_per_split, long part_stride) {
     constexpr int NT = 512, CF = kSpCF, HF = CF / 2, BPC = CF / 16, NG = HF / 8, ROWS = (NT / 64) * 32;
-    constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 3 * 1024;
+    constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 2 * 1024;
     constexpr int SPL_BYTES = kSpSteps * OT * 2 * 2048;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* s_knots = reinterpret_cast<float*>(smem);
@@ -171,6 +175,8 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     if (tid < nknots) s_knots[tid] = knots_g[tid];
     build_sparse_table(s_tbl, tid, nknots);
     const float post = reinterpret_cast<const float*>(pack)[0];
+    const float post_b = post * 64.0f;                  // the SiLU branch is fed at scale 2^4 instead of 2^10
+    const float* base_w = reinterpret_cast<const float*>(pack + kHdrBytes + (size_t)nchunks * CHUNK_BYTES);   // [out][in] fp32
     const unsigned char* gw = pack + kHdrBytes;
     auto stage_chunk = [&](int ch) {
         const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)ch * CHUNK_BYTES);
@@ -213,11 +219,13 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     load8((long)blockIdx.x * ROWS + wave * 32, ch_begin, 0, xn);
     for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
         const long row0 = tile * ROWS + wave * 32;
-        f32x16 acc[OT];
+        // acc: spline part (bases * 2^10); acc_b: SiLU branch through fp16 hi/lo at scale 2^4 (|silu| < 4094);
+        // acc_f: SiLU branch of the rare groups whose values do not fit that, exact fp32 MFMA on the unscaled weights
+        f32x16 acc[OT], acc_b[OT], acc_f[OT];
 #pragma unroll
         for (int t = 0; t < OT; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+            for (int i = 0; i < 16; ++i) { acc[t][i] = 0.0f; acc_b[t][i] = 0.0f; acc_f[t][i] = 0.0f; }
 
         for (int ch = ch_begin; ch < ch_end; ++ch) {
             if (!resident) {
@@ -264,7 +272,9 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     prep_reads(0, e0, e1, u0, u1, bw);
                     build(0, e0, e1, u0, u1, ahi, alo, aidx);
                 }
-                u32x4 a1, a2, a3;                          // SiLU fragments, prepared under the last step's MFMAs
+                u32x4 sh_hi, sh_lo;                        // SiLU fragments, prepared under the last step's MFMAs
+                float sv[8];
+                bool big = false;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     u32x4 e0, e1, nbw[4 * OT]; float u0, u1;
@@ -282,25 +292,39 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
 #pragma unroll
                         for (int i = 0; i < 4 * OT; ++i) bw[i] = nbw[i];
                     } else {
-                        float sv[8];
+                        float smx = 0.0f;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) sv[i] = (siluf(xv[i]) + (xv[i] - xv[i])) * kAScale;   // +-Inf -> NaN like the reference
-                        split_bf16x3(sv, a1, a2, a3);
+                        for (int i = 0; i < 8; ++i) {
+                            sv[i] = (siluf(xv[i]) + (xv[i] - xv[i])) * 16.0f;      // +-Inf -> NaN like the reference
+                            smx = fmaxf(smx, fabsf(sv[i]));
+                        }
+                        big = __any(!(smx < 60000.0f) || sv[0] != sv[0] || sv[1] != sv[1] || sv[2] != sv[2] || sv[3] != sv[3] ||
+                                    sv[4] != sv[4] || sv[5] != sv[5] || sv[6] != sv[6] || sv[7] != sv[7]);   // wave-uniform
+                        split_f16x2(sv, sh_hi, sh_lo);
                     }
                 }
-                {
-                    const unsigned char* wp = s_w + SPL_BYTES + (size_t)(g * OT) * 3 * 1024 + lane * 16;
+                if (!big) {
+                    const unsigned char* wp = s_w + SPL_BYTES + (size_t)(g * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
                     for (int t = 0; t < OT; ++t) {
-                        const u32x4 w1 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 0) * 1024);
-                        const u32x4 w2 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 1) * 1024);
-                        const u32x4 w3 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 2) * 1024);
-                        acc[t] = mfma_bf16(a3, w1, acc[t]);
-                        acc[t] = mfma_bf16(a2, w2, acc[t]);
-                        acc[t] = mfma_bf16(a1, w3, acc[t]);
-                        acc[t] = mfma_bf16(a2, w1, acc[t]);
-                        acc[t] = mfma_bf16(a1, w2, acc[t]);
-                        acc[t] = mfma_bf16(a1, w1, acc[t]);
+                        const u32x4 wh = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 0) * 1024);
+                        const u32x4 wl = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 1) * 1024);
+                        acc_b[t] = mfma_f16(sh_hi, wh, acc_b[t]);
+                        acc_b[t] = mfma_f16(sh_hi, wl, acc_b[t]);
+                        acc_b[t] = mfma_f16(sh_lo, wh, acc_b[t]);
+                    }
+                } else {
+                    // values beyond fp16 range (|x| > ~3700) or non-finite: this group's SiLU branch in exact fp32,
+                    // v_mfma_f32_32x32x2_f32 with k = lane half <-> this lane's own feature, weights straight from HBM
+                    const int f0 = ch * CF + kg * HF + 8 * g;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                        for (int t = 0; t < OT; ++t) {
+                            const int o = 32 * t + r;
+                            const float w = (o < out && f0 + j < in) ? base_w[(long)o * in + f0 + j] : 0.0f;
+                            acc_f[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j] * 0.0625f, w, acc_f[t], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -312,7 +336,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
             if (col < out) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped
-                    gst_s(yb, base, (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, acc[t][i] * post);
+                    gst_s(yb, base, (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, fmaf(acc[t][i], post, fmaf(acc_b[t][i], post_b, acc_f[t][i])));
             }
         }
     }
@@ -325,7 +349,7 @@ int kan_sparse_pack_fwd(const float* bw, const float* sw, const float* sc, int i
     for (int b = 0; b * kSpOutBlk < out; ++b) {
         const int ob = min(kSpOutBlk, out - b * kSpOutBlk);
         const long o0 = (long)b * kSpOutBlk;
-        const long items = (long)(sp_blk_bytes(in, ob) - kHdrBytes) / 16;
+        const long items = (long)sp_chunks_bytes(in, ob) / 16;
         sparse_pack_fwd_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(
             bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C,
             static_cast<unsigned char*>(pack_fwd) + b * stride);
@@ -338,7 +362,7 @@ int kan_sparse_pack_fwd(const float* bw, const float* sw, const float* sc, int i
 bool kan_fused_pack_ok(int in, int out, int C) { return out <= kSpOutBlk && C <= 8; }
 int kan_fused_pack(const float* bw, const float* sw, const float* sc, int in, int out, int C, void* pack_fwd,
                    void* pack_dx, hipStream_t st) {
-    const long items_f = (long)(sp_blk_bytes(in, out) - kHdrBytes) / 16;
+    const long items_f = (long)sp_chunks_bytes(in, out) / 16;
     const long items_d = (long)cdiv(in, 16) * kCTmax * dx_q2(out) * 64;
     const int nbf = (int)min((items_f + 1023) / 1024, 48L), nbd = (int)min((items_d + 1023) / 1024, 48L);
     fused_pack_kernel<<<nbf + nbd, 1024, 0, st>>>(bw, sw, sc, in, out, C, static_cast<unsigned char*>(pack_fwd),
