@@ -95,6 +95,37 @@ __device__ __forceinline__ float barrel_dot(const float (&d)[8], int m, const fl
 }
 
 
+// Cubic case of the same contraction with half the selects.  The window c0..c0+3 (c0 = m - 3) holds exactly one slot
+// of every residue class mod 4, so the candidate for residue rho is d[rho], d[rho+4] or nothing (the coefficient does
+// not exist): ONE v_perm_b32 per residue with a selector from a 16-entry LDS table indexed by m (dword selectors
+// "low source" / "high source" / zero).  The four survivors then only need a ROTATION by c0 & 3 to line up with
+// dN[0..3]: two more v_perm stages.  12 v_perm_b32, no compares, instead of 27 selects + 5 compares.
+__device__ __forceinline__ void build_barrel_table(unsigned* tbl /* LDS, 16*4 */, int tid) {
+    if (tid < 64) {
+        const int mm = tid >> 2, rho = tid & 3, c0 = mm - 3;
+        const int t = c0 + ((rho - c0) & 3);           // the slot of residue rho inside [c0, c0+3]
+        tbl[tid] = (mm >= 15) ? 0x0c0c0c0cu : (t == rho ? 0x03020100u : (t == rho + 4 ? 0x07060504u : 0x0c0c0c0cu));
+    }
+}
+__device__ __forceinline__ float barrel_dot3(const float (&d)[8], int mm /* m - 8*window */, const u32x4& sel,
+                                             const float (&dN)[4]) {
+    unsigned s4[4], r1[4];
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho)
+        s4[rho] = __builtin_amdgcn_perm(__float_as_uint(d[rho + 4]), __float_as_uint(d[rho]), sel[rho]);
+    // rotation e[r] = s4[(b + r) & 3], b = c0 & 3, as two v_perm stages whose dword selectors are computed
+    // arithmetically (no compares, no VCC): 0x03020100 keeps the low source, +0x04040404 takes the high one
+    const unsigned b = (unsigned)(mm + 1) & 3u;
+    const unsigned selA = 0x03020100u + (b & 1u) * 0x04040404u;
+    const unsigned selB = 0x03020100u + (b >> 1) * 0x04040404u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r1[i] = __builtin_amdgcn_perm(s4[(i + 1) & 3], s4[i], selA);
+    float e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __uint_as_float(__builtin_amdgcn_perm(r1[(i + 2) & 3], r1[i], selB));
+    return fmaf(e[3], dN[3], fmaf(e[2], dN[2], fmaf(e[1], dN[1], e[0] * dN[0])));
+}
+
 // One wave = 32 rows (two 16-row MFMA tiles) x one 16-feature tile at a time.  v_mfma_f32_16x16x32_f16:
 // A lane (row = l&15, kg = l>>4) holds gy[row][32*q2 + 8*kg + j]; B lane (f = l&15, kg) holds W^T;
 // D lane (f = l&15) holds rows 4*kg + reg.
@@ -114,6 +145,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     unsigned char* s_w = smem + kLdsHdr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (K > 0 && tid < nknots) s_knots[tid] = knots_g[tid];
+    unsigned* s_btbl = reinterpret_cast<unsigned*>(smem + 256);      // barrel selectors (K == 3)
+    if (K == 3) build_barrel_table(s_btbl, tid);
     const int inv = in << sh, FT = cdiv(inv, 16);
     constexpr int FT_BYTES = kCTmax * Q2 * 2 * 1024;
     const int e_w = reinterpret_cast<const int*>(pack)[1];
@@ -295,7 +328,15 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     float d[kCTmax - 1];                       // per-coefficient sums (slots >= C are exact zeros)
 #pragma unroll
                     for (int c = 0; c < kCTmax - 1; ++c) d[c] = D[c][rt][reg];
-                    float s = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot<K>(d, m - 8 * win, dN)) * rinv[rt][reg];
+                    float bar;
+                    if constexpr (K == 3) {
+                        const int mm = m - 8 * win;
+                        const u32x4 sel = *reinterpret_cast<const u32x4*>(s_btbl + 4 * min((unsigned)mm, 15u));
+                        bar = barrel_dot3(d, mm, sel, dN);
+                    } else {
+                        bar = barrel_dot<K>(d, m - 8 * win, dN);
+                    }
+                    float s = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), bar) * rinv[rt][reg];
                     if (sh) s += __shfl_xor(s, 1);                       // the two windows of one input feature (wave-uniform branch)
                     if (f < inv && win == 0) {
                         const unsigned so_x = (unsigned)(16 * rt + reg) * ldgx4;
