@@ -105,7 +105,7 @@ __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float*
 // Workgroup = 1024 threads = 16 waves (4 per SIMD, <= 128 VGPRs each) so that LDS / VALU latencies of
 // one wave hide under the other three; one wave = 32 rows.  x is consumed in groups of 8 features per
 // lane (two float4), the next group is prefetched while the current one is expanded.
-// GEN == false: lean instantiation (<= 8 coefficients, no split-K) used by the cubic-spline hot path
+// (GEN == false would drop the virtual-feature / split-K code; the hot cubic case now lives in kan_sparse_fwd.hip)
 template <int K, int OT, int NT, bool GEN>
 __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g,
@@ -387,9 +387,6 @@ static int launch_fwd(const float* x, long ldx, long N, int in, const float* kno
     if (!configured) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT, NT, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (K == 3)
-            KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT, NT, K != 3>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
     const int gx = (int)min((long)cdiv(N, NT / 2), 256L);
@@ -404,13 +401,9 @@ static int launch_fwd(const float* x, long ldx, long N, int in, const float* kno
         KAGNN_LAUNCH_CHECK();
         return KAGNN_OK;
     }
-    static const bool force_gen = getenv("KAGNN_FWD_GEN") != nullptr;     // A/B switch for profiling
-    if (K == 3 && sh == 0 && !force_gen)
-        kan_split_fwd_kernel<K, OT, NT, K != 3><<<gx, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out,
-                                                                     rb, 0, nchunks, 0L);
-    else
-        kan_split_fwd_kernel<K, OT, NT, true><<<gx, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out,
-                                                                   rb, sh, nchunks, 0L);
+    // (cubic splines with <= 8 coefficients never get here: kan_sparse_fwd.hip serves them)
+    kan_split_fwd_kernel<K, OT, NT, true><<<gx, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out,
+                                                               rb, sh, nchunks, 0L);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
