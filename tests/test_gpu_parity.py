@@ -538,3 +538,32 @@ def test_time_model_hip_graph_matches_eager():
         out.append(losses)
     for a, b in zip(*out):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), out
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+@pytest.mark.parametrize("off", [0, 4, 3])
+def test_kanlinear_and_fastkan_on_column_slices(mode, off):
+    """inputs that are column slices of a wider activation (row stride > width; 16-byte aligned or not), as the
+    sharded layers and the skip-concat hand them over: same results as on a contiguous copy"""
+    torch.manual_seed(21 + off)
+    n, fi, fo = 777, 64, 48
+    wide = (torch.randn(n, fi + 8) * 0.6).to(DEV)
+    gy = torch.randn(n, fo).to(DEV)
+    for make in (lambda: kagnn_amd.KANLinear(fi, fo, grid_size=5, spline_order=3),
+                 lambda: kagnn_amd.FastKANLayer(fi, fo, num_grids=8)):
+        layer = make().to(DEV)
+        layer.precision = mode
+        res = []
+        for strided in (False, True):
+            src = wide.clone().requires_grad_(True)
+            x = src[:, off:off + fi] if strided else src[:, off:off + fi].contiguous()
+            y = layer(x)
+            for p in layer.parameters():
+                p.grad = None
+            y.backward(gy)
+            res.append((y.detach().clone(), src.grad[:, off:off + fi].clone(),
+                        [p.grad.clone() for p in layer.parameters() if p.grad is not None]))
+        assert torch.equal(res[0][0], res[1][0]), "y differs between strided and contiguous input"
+        assert torch.equal(res[0][1], res[1][1]), "gx differs"
+        for a, b in zip(res[0][2], res[1][2]):
+            assert_close(a, b, 1e-6, what="parameter gradient")
