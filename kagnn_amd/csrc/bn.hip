@@ -83,27 +83,27 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict_
     }
 }
 
-// combine the partials (fixed order) and finish the statistics:  one thread group of 8 row slots per 32 columns
+// combine the partials (fixed order) and finish the statistics:  32 row groups per 32 columns
 //   MODE 0: mean, rstd (biased variance) -> save_mean / save_rstd, running stats update
 //   MODE 1: g_bias = sum gy, g_weight = sum gy*xhat; also left in sums[0][f], sums[1][f] for the gx pass
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ partial, long B, int F, long N,
+__global__ __launch_bounds__(1024) void bn_finish_kernel(const float* __restrict__ partial, long B, int F, long N,
                                                         const float* __restrict__ x_row0, float eps, float momentum,
                                                         float* __restrict__ out_a, float* __restrict__ out_b,
                                                         float* __restrict__ running_mean,
                                                         float* __restrict__ running_var) {
-    __shared__ float s_p[8][2][33];
-    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    __shared__ float s_p[32][2][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;       // 32 columns x 32 row groups
     const int f = blockIdx.x * 32 + c;
     float a = 0.0f, b = 0.0f;
     if (f < F)
-        for (long w = rg; w < B; w += 8) { a += partial[(w * 2 + 0) * F + f]; b += partial[(w * 2 + 1) * F + f]; }
+        for (long w = rg; w < B; w += 32) { a += partial[(w * 2 + 0) * F + f]; b += partial[(w * 2 + 1) * F + f]; }
     s_p[rg][0][c] = a; s_p[rg][1][c] = b;
     __syncthreads();
     if (rg == 0 && f < F) {
         float ta = 0.f, tb = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) { ta += s_p[g][0][c]; tb += s_p[g][1][c]; }
+        for (int g = 0; g < 32; ++g) { ta += s_p[g][0][c]; tb += s_p[g][1][c]; }
         if (MODE == 0) {
             const float inv_n = 1.0f / (float)N;
             const float d = ta * inv_n;                                  // mean - shift
@@ -196,7 +196,7 @@ struct BnPlan { int blocks; long rpb; size_t partial_bytes; };
 static BnPlan bn_plan(long N, int F) {
     BnPlan p;
     const BnShape s = bn_shape(F);
-    long b = min(2048L, max(1L, N / (4L * s.rs)));        // >= 4 iterations per workgroup
+    long b = min(512L, max(1L, N / (4L * s.rs)));         // >= 4 iterations per workgroup; few partial rows keep bn_finish short
     p.rpb = (N + b - 1) / b;
     p.rpb = ((p.rpb + s.rs - 1) / s.rs) * s.rs;
     p.blocks = (int)max(1L, (N + p.rpb - 1) / p.rpb);
@@ -217,7 +217,7 @@ int bn_fwd(const float* x, long ldx, long N, int F, const float* gamma, const fl
         const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
         bn_colsum_kernel<0><<<p.blocks, 256, lds, st>>>(x, ldx, nullptr, 0, N, F, nullptr, nullptr, s.cl, s.rs, p.rpb, partial);
         KAGNN_LAUNCH_CHECK();
-        bn_finish_kernel<0><<<cdiv(F, 32), 256, 0, st>>>(partial, p.blocks, F, N, x, eps, momentum, save_mean, save_rstd,
+        bn_finish_kernel<0><<<cdiv(F, 32), 1024, 0, st>>>(partial, p.blocks, F, N, x, eps, momentum, save_mean, save_rstd,
                                                          running_mean, running_var);
         KAGNN_LAUNCH_CHECK();
     } else {
@@ -244,7 +244,7 @@ int bn_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, int F, 
     const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
     bn_colsum_kernel<1><<<p.blocks, 256, lds, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, s.cl, s.rs, p.rpb, partial);
     KAGNN_LAUNCH_CHECK();
-    bn_finish_kernel<1><<<cdiv(F, 32), 256, 0, st>>>(partial, p.blocks, F, N, nullptr, 0.f, 0.f, sg, sgx, nullptr, nullptr);
+    bn_finish_kernel<1><<<cdiv(F, 32), 1024, 0, st>>>(partial, p.blocks, F, N, nullptr, 0.f, 0.f, sg, sgx, nullptr, nullptr);
     KAGNN_LAUNCH_CHECK();
     if (gx) {
         const int grid = (int)min(4096L, max(1L, (long)cdiv(N, s.rs)));
