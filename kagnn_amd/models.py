@@ -88,8 +88,10 @@ class _NormalisedConv(nn.Module):
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor,
                 edge_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
         if edge_weight is not None or (isinstance(edge_index, torch.Tensor) and edge_index.is_sparse):
-            raise NotImplementedError("weighted / sparse-matrix adjacency for the GCN flavour is not "
-                                      "implemented yet (SURVEY.md 8(f) rank 3)")
+            # weighted edges / the sparse adjacency of the reference's gcn timing branch (time_model.py:70-80)
+            wg = ops.weighted_gcn_graph(edge_index, edge_weight, x.size(0))
+            return ops.aggregate_sum(self.lin(x), wg.graph, self_scale=0.0, edge_weight=wg.weight,
+                                     in_scale=wg.dis, out_scale=wg.dis, bias=self.bias)
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
         dis = g.gcn_dis
         return ops.aggregate_sum(self.lin(x), g, self_scale=1.0, in_scale=dis, out_scale=dis,

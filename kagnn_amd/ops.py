@@ -195,6 +195,62 @@ def graph_index(edge_index: torch.Tensor, num_nodes: int) -> GraphIndex:
 
 def clear_graph_cache() -> None:
     _graph_cache.clear()
+    _gcn_cache.clear()
+
+
+class WeightedGcnGraph:
+    """``gcn_norm`` with edge weights (torch_geometric semantics, restated in oracle/kan_oracle.py:gcn_norm):
+    non-loop edges keep their weight, every node gets exactly one self loop (an existing loop keeps its weight,
+    otherwise 1), ``deg`` = weighted in-degree, ``dis = deg^-1/2`` (inf -> 0).  The augmented edge list is
+    indexed once (CSR + transpose); built with a handful of torch ops -- per graph, not per step."""
+
+    def __init__(self, edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int):
+        _need_cuda(edge_index)
+        dev = edge_index.device
+        src, dst = edge_index[0], edge_index[1]
+        w = (torch.ones(src.numel(), dtype=torch.float32, device=dev) if edge_weight is None
+             else edge_weight.to(device=dev, dtype=torch.float32))
+        keep = src != dst
+        loop_w = torch.ones(num_nodes, dtype=torch.float32, device=dev)
+        loop_w[src[~keep]] = w[~keep]
+        ar = torch.arange(num_nodes, dtype=src.dtype, device=dev)
+        ei = torch.stack([torch.cat([src[keep], ar]), torch.cat([dst[keep], ar])]).contiguous()
+        self.weight = torch.cat([w[keep], loop_w]).contiguous()
+        deg = torch.zeros(num_nodes, dtype=torch.float32, device=dev).index_add_(0, ei[1], self.weight)
+        dis = deg.pow(-0.5)
+        self.dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis).contiguous()
+        self.graph = GraphIndex(ei, num_nodes)
+        self._keepalive = (ei,)
+
+
+_gcn_cache: "dict[tuple, WeightedGcnGraph]" = {}
+
+
+def weighted_gcn_graph(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int) -> WeightedGcnGraph:
+    """Cached per (edge_index, edge_weight) identity / version.  ``edge_index`` may also be a torch sparse COO
+    matrix, read the way torch_geometric reads a sparse ``adj_t``: entry (i, j) = weight of the edge j -> i (the
+    form the reference's gcn timing branch passes, ``time_model.py:70-80``)."""
+    if isinstance(edge_index, torch.Tensor) and edge_index.is_sparse:
+        key = (id(edge_index), int(num_nodes))
+        hit = _gcn_cache.get(key)
+        if hit is not None and hit._owner is edge_index:
+            return hit
+        adj = edge_index.coalesce()
+        idx = adj.indices()
+        hit = WeightedGcnGraph(torch.stack([idx[1], idx[0]]).contiguous(), adj.values(), num_nodes)
+        hit._owner = edge_index
+    else:
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
+               None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version))
+        hit = _gcn_cache.get(key)
+        if hit is not None:
+            return hit
+        hit = WeightedGcnGraph(edge_index, edge_weight, num_nodes)
+        hit._owner = (edge_index, edge_weight)
+    if len(_gcn_cache) >= _GRAPH_CACHE_MAX:
+        _gcn_cache.pop(next(iter(_gcn_cache)))
+    _gcn_cache[key] = hit
+    return hit
 
 
 # ======================================================================== aggregation

@@ -567,3 +567,38 @@ def test_kanlinear_and_fastkan_on_column_slices(mode, off):
         assert torch.equal(res[0][1], res[1][1]), "gx differs"
         for a, b in zip(res[0][2], res[1][2]):
             assert_close(a, b, 1e-6, what="parameter gradient")
+
+
+def test_gcn_conv_weighted_edges_and_sparse_adjacency():
+    """KAGCNConv with edge weights, and with a torch sparse COO adjacency read as torch_geometric reads adj_t
+    (the reference's gcn timing branch, time_model.py:70-80), against the restated weighted gcn_norm."""
+    torch.manual_seed(3)
+    n, e, fi, fo = 400, 2500, 24, 16
+    ei = torch.randint(0, n, (2, e))
+    ei[:, :30] = torch.arange(30).repeat(2, 1)                    # some explicit self loops (their weight is kept)
+    w = torch.rand(e) + 0.1
+    x = torch.randn(n, fi) * 0.5
+    gy = torch.randn(n, fo)
+    conv = kagnn_amd.KAGCNConv(fi, fo, grid_size=5, spline_order=3)
+    conv.bias.data.uniform_(-0.2, 0.2)
+    p64 = {k: v.detach().double() for k, v in conv.lin.state_dict().items()}
+    x64 = x.double().requires_grad_(True)
+    ei2, w2 = orc.gcn_norm(ei, n, torch.float64, w.double())
+    h64 = orc.kan_linear_forward(x64, p64["base_weight"], p64["spline_weight"], p64["spline_scaler"], p64["grid"], 3)
+    y64 = orc.sum_aggregate(h64, ei2, n, w2) + conv.bias.detach().double()
+    y64.backward(gy.double())
+    conv = conv.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    y = conv(xd, ei.to(DEV), w.to(DEV))
+    y.backward(gy.to(DEV))
+    assert_close(y, y64, what="weighted y")
+    assert_close(xd.grad, x64.grad, what="weighted gx")
+    # sparse adjacency: entry (i, j) = weight of edge j -> i; duplicates are summed by coalesce(), so use unique edges
+    key = ei[1] * n + ei[0]
+    uniq = torch.unique(key, return_inverse=False)
+    ei_u = torch.stack([uniq % n, uniq // n])
+    w_u = torch.rand(ei_u.size(1)) + 0.1
+    adj_t = torch.sparse_coo_tensor(torch.stack([ei_u[1], ei_u[0]]), w_u, (n, n)).to(DEV)
+    y_sp = conv(x.to(DEV), adj_t)
+    y_ew = conv(x.to(DEV), ei_u.to(DEV), w_u.to(DEV))
+    assert_close(y_sp, y_ew, 1e-6, what="sparse adjacency vs edge list")
