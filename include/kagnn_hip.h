@@ -230,6 +230,35 @@ int kagnn_batchnorm_bwd(const float* x, int64_t ldx, const float* gy, int64_t ld
                         int64_t ldgx, float* g_weight, float* g_bias, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Attention aggregation of KAGATConv / FASTKAGATConv (node_classification_clean/models.py:39-46,
+ * 76-83: torch_geometric GATConv with `lin` = a KAN layer; heads concatenated, negative slope 0.2,
+ * existing self loops removed and one added per node, no attention dropout).
+ *   xh [N, heads*channels] = lin(x);  att_src / att_dst [heads, channels];  bias [heads*channels] or NULL
+ *   kagnn_gat_logits: a_src[N,heads], a_dst[N,heads]
+ *   kagnn_gat_fwd   : out [N, heads*channels], and the per-(node, head) softmax maximum / normaliser
+ *                     (row_max, row_sum: the only extra state the backward needs)
+ *   kagnn_gat_bwd   : gx = d loss / d xh (all three paths), g_src[N,heads] / g_dst[N,heads] = d loss / d a_src,
+ *                     a_dst (the caller contracts them with xh for the att_src / att_dst gradients);
+ *                     edge_scratch [E*heads] and self_scratch [N*heads] floats.  CSR arrays as built by
+ *                     kagnn_csr_build: (rowptr, col, perm) by destination, (rowptr_t, col_t, perm_t) by source.
+ * ------------------------------------------------------------------------------------------ */
+int kagnn_gat_logits(const float* xh, int64_t ldx, int64_t num_nodes, int32_t heads, int32_t channels,
+                     const float* att_src, const float* att_dst, float* a_src, float* a_dst,
+                     void* stream);
+int kagnn_gat_fwd(const float* xh, int64_t ldx, const float* a_src, const float* a_dst,
+                  const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int32_t heads,
+                  int32_t channels, const float* bias, float* out, int64_t ldo, float* row_max,
+                  float* row_sum, void* stream);
+int kagnn_gat_bwd(const float* xh, int64_t ldx, const float* gout, int64_t ldg, const float* out,
+                  int64_t ldo, const float* bias, const float* a_src, const float* a_dst,
+                  const float* row_max, const float* row_sum, const int32_t* rowptr,
+                  const int32_t* col, const int32_t* perm, const int32_t* rowptr_t,
+                  const int32_t* col_t, const int32_t* perm_t, const float* att_src,
+                  const float* att_dst, int64_t num_nodes, int32_t heads, int32_t channels,
+                  float* edge_scratch, float* self_scratch, float* g_dst, float* g_src, float* gx,
+                  int64_t ldgx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,8 +7,8 @@ C ABI of ``include/kagnn_hip.h``, reached through ``kagnn_amd.ops``.
 from . import _lib, ops                                                          # noqa: F401
 from .ekan import KAN, KANLinear                                                 # noqa: F401
 from .fastkan import FastKAN, FastKANLayer, RadialBasisFunction, SplineLinear    # noqa: F401
-from .models import (FASTKAGCNConv, FKANLayer, GFASTKAN_Nodes, GIFASTKANLayer,   # noqa: F401
-                     GIKANLayer, GKAN_Nodes, KAGCNConv, KANLayer)
+from .models import (FASTKAGATConv, FASTKAGCNConv, FKANLayer, GFASTKAN_Nodes,        # noqa: F401
+                     GIFASTKANLayer, GIKANLayer, GKAN_Nodes, KAGATConv, KAGCNConv, KANLayer)
 
 from .norm import BatchNorm1d                                                    # noqa: F401
 from .graph_models import FASTKAGIN, KAGIN, GINEKANLayer, KAGINRegression               # noqa: F401

@@ -103,6 +103,37 @@ class KAGCNConv(_NormalisedConv):
         super().__init__(KANLayer(in_feat, out_feat, grid_size, spline_order), out_feat)
 
 
+class _AttentionConv(nn.Module):
+    """GAT message passing around a KAN transform ``lin`` (torch_geometric 2.5.3 ``GATConv`` with int in_channels,
+    ``concat=True``, negative slope 0.2, self loops re-added, no attention dropout): same attribute names and
+    state_dict keys (``att_src, att_dst, bias, lin.*``)."""
+
+    def __init__(self, lin: nn.Module, out_channels: int, heads: int):
+        super().__init__()
+        self.lin = lin
+        self.heads, self.out_channels = heads, out_channels
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels))
+        nn.init.xavier_uniform_(self.att_src)         # glorot, as GATConv.reset_parameters
+        nn.init.xavier_uniform_(self.att_dst)
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+        g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
+        return ops.gat_aggregate(self.lin(x), self.att_src, self.att_dst, self.bias, g, self.heads, self.out_channels)
+
+
+class KAGATConv(_AttentionConv):
+    def __init__(self, in_feat: int, out_feat: int, heads: int, grid_size: int = 4, spline_order: int = 3):
+        super().__init__(KANLayer(in_feat, out_feat * heads, grid_size, spline_order), out_feat, heads)
+
+
+class FASTKAGATConv(_AttentionConv):
+    def __init__(self, in_feat: int, out_feat: int, heads: int, grid_size: int = 4):
+        super().__init__(FKANLayer(in_feat, out_feat * heads, num_grids=grid_size), out_feat, heads)
+        self.grid_size = grid_size
+
+
 class GIKANLayer(_SumAggregateConv):
     def __init__(self, in_feat: int, out_feat: int, grid_size: int = 4, spline_order: int = 3,
                  hidden_dim: int = 16, nb_layers: int = 2):
@@ -126,19 +157,20 @@ class _NodeModel(nn.Module):
     """mp_layers x {conv -> BatchNorm1d -> dropout}, skip-concat of the input and every layer
     output, then a KAN / FastKAN read-out (reference ``models.py:192-203,246-257``)."""
 
-    def _build(self, conv_type, mp_layers, num_features, hidden_channels, skip, dropout, make_conv):
-        if conv_type == "gat":
-            raise NotImplementedError("the GAT flavour is outside the KAGNN hot path (SURVEY.md 2 row 5)")
-        if conv_type not in ("gcn", "gin"):
+    def _build(self, conv_type, mp_layers, num_features, hidden_channels, skip, dropout, make_conv, heads=1):
+        if conv_type not in ("gcn", "gin", "gat"):
             raise ValueError("unknown conv_type")
+        if conv_type != "gat":
+            heads = 1
+        width = hidden_channels * heads                  # conv output width (reference models.py:165-190)
         self.convs = nn.ModuleList()
         self.bns = nn.ModuleList()
         for i in range(mp_layers):
-            self.convs.append(make_conv(num_features if i == 0 else hidden_channels))
-            self.bns.append(BatchNorm1d(hidden_channels))
+            self.convs.append(make_conv(num_features if i == 0 else width))
+            self.bns.append(BatchNorm1d(width))
         self.skip = skip
         self.dropout = nn.Dropout(dropout)
-        return num_features + mp_layers * hidden_channels if skip else hidden_channels
+        return num_features + mp_layers * width if skip else width
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
@@ -160,9 +192,11 @@ class GKAN_Nodes(_NodeModel):
         def make_conv(width):
             if conv_type == "gcn":
                 return KAGCNConv(width, hidden_channels, grid_size, spline_order)
+            if conv_type == "gat":
+                return KAGATConv(width, hidden_channels, heads, grid_size, spline_order)
             return GIKANLayer(width, hidden_channels, grid_size, spline_order, hidden_channels, hidden_layers)
 
-        dim = self._build(conv_type, mp_layers, num_features, hidden_channels, skip, dropout, make_conv)
+        dim = self._build(conv_type, mp_layers, num_features, hidden_channels, skip, dropout, make_conv, heads)
         self.lay_out = KANLinear(dim, num_classes, grid_size=grid_size, spline_order=spline_order)
 
 
@@ -175,7 +209,9 @@ class GFASTKAN_Nodes(_NodeModel):
         def make_conv(width):
             if conv_type == "gcn":
                 return FASTKAGCNConv(width, hidden_channels, grid_size)
+            if conv_type == "gat":
+                return FASTKAGATConv(width, hidden_channels, heads, grid_size)
             return GIFASTKANLayer(width, hidden_channels, grid_size, hidden_channels, hidden_layers)
 
-        dim = self._build(conv_type, mp_layers, num_features, hidden_channels, skip, dropout, make_conv)
+        dim = self._build(conv_type, mp_layers, num_features, hidden_channels, skip, dropout, make_conv, heads)
         self.lay_out = FastKANLayer(dim, num_classes, num_grids=grid_size)

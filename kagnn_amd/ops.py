@@ -477,6 +477,60 @@ class _FastKANFn(Function):
         return gx, glw, glb, gsw, gbw, (gbb if has_bb else None), None, None, None, None
 
 
+# ======================================================================== GAT attention aggregation
+class _GatFn(Function):
+    @staticmethod
+    def forward(ctx, xh, att_src, att_dst, bias, g, heads, channels):
+        _need_cuda(xh, att_src, att_dst)
+        xh = _rows(xh)
+        n = xh.size(0)
+        dev = xh.device
+        a_s = att_src.reshape(heads, channels).contiguous()
+        a_d = att_dst.reshape(heads, channels).contiguous()
+        b = None if bias is None else bias.contiguous()
+        ls = torch.empty((n, heads), dtype=torch.float32, device=dev)
+        ld_ = torch.empty((n, heads), dtype=torch.float32, device=dev)
+        _call("kagnn_gat_logits", _ptr(xh), _ld(xh), n, heads, channels, _ptr(a_s), _ptr(a_d), _ptr(ls), _ptr(ld_), _stream())
+        out = torch.empty((n, heads * channels), dtype=torch.float32, device=dev)
+        m = torch.empty((n, heads), dtype=torch.float32, device=dev)
+        z = torch.empty((n, heads), dtype=torch.float32, device=dev)
+        _call("kagnn_gat_fwd", _ptr(xh), _ld(xh), _ptr(ls), _ptr(ld_), _ptr(g.rowptr), _ptr(g.col), n, heads, channels,
+              _ptr(b), _ptr(out), heads * channels, _ptr(m), _ptr(z), _stream())
+        ctx.save_for_backward(xh, a_s, a_d, b, ls, ld_, m, z, out)
+        ctx.g, ctx.hc = g, (heads, channels)
+        ctx.att_shape = att_src.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        xh, a_s, a_d, b, ls, ld_, m, z, out = ctx.saved_tensors
+        g = ctx.g
+        heads, channels = ctx.hc
+        gout = _rows(gout)
+        n, dev = xh.size(0), xh.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        gpre = torch.empty(max(g.num_edges, 1) * heads, **f32)
+        gself = torch.empty((n, heads), **f32)
+        gd = torch.empty((n, heads), **f32)
+        gs = torch.empty((n, heads), **f32)
+        gx = torch.empty((n, heads * channels), **f32)
+        _call("kagnn_gat_bwd", _ptr(xh), _ld(xh), _ptr(gout), _ld(gout), _ptr(out), heads * channels, _ptr(b), _ptr(ls),
+              _ptr(ld_), _ptr(m), _ptr(z), _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm), _ptr(g.rowptr_t), _ptr(g.col_t),
+              _ptr(g.perm_t), _ptr(a_s), _ptr(a_d), n, heads, channels, _ptr(gpre), _ptr(gself), _ptr(gd), _ptr(gs),
+              _ptr(gx), heads * channels, _stream())
+        x3 = xh.reshape(n, heads, channels) if xh.is_contiguous() else xh.contiguous().view(n, heads, channels)
+        g_att_src = torch.einsum("nh,nhc->hc", gs, x3).reshape(ctx.att_shape)      # [H, C] contractions over the nodes
+        g_att_dst = torch.einsum("nh,nhc->hc", gd, x3).reshape(ctx.att_shape)
+        g_bias = gout.sum(0) if b is not None else None
+        return gx, g_att_src, g_att_dst, g_bias, None, None, None
+
+
+def gat_aggregate(xh, att_src, att_dst, bias, g: GraphIndex, heads: int, channels: int) -> torch.Tensor:
+    """GATConv message passing on ``xh = lin(x)`` (heads concatenated): see csrc/gat.hip."""
+    return _GatFn.apply(xh, att_src, att_dst, bias, g, int(heads), int(channels))
+
+
 # ======================================================================== BatchNorm1d (conv epilogue)
 class _BatchNormFn(Function):
     @staticmethod

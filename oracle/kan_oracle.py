@@ -11,7 +11,7 @@ Parity status
   the reference's own ``ekan.py`` / ``fastkan.py`` (``tests/golden/make_golden.py``);
   ``tests/test_oracle_golden.py`` checks this file against them (and against the live
   import when ``/root/reference`` is present).
-* Message passing (GIN / GCN / GINE / pool): the arithmetic lives in the un-vendored
+* Message passing (GIN / GCN / GAT / GINE / pool): the arithmetic lives in the un-vendored
   third-party dependency ``torch_geometric==2.5.3`` (reference ``requirements.txt:4``),
   which is neither under ``/root/reference`` nor installable here.  Its published
   semantics are restated below from the reference's call sites
@@ -190,6 +190,31 @@ def gcn_norm(edge_index: Tensor, num_nodes: int, dtype=torch.float32,
     dis = deg.pow(-0.5)
     dis.masked_fill_(dis == float("inf"), 0.0)
     return torch.stack([row2, col2]), dis[row2] * w2 * dis[col2]
+
+
+def gat_conv(x: Tensor, edge_index: Tensor, lin_fn, att_src: Tensor, att_dst: Tensor,
+             bias: Optional[Tensor], heads: int, negative_slope: float = 0.2) -> Tensor:
+    """PyG 2.5.3 ``GATConv.forward`` (int ``in_channels``, ``concat=True``, ``add_self_loops=True``, no attention
+    dropout) as subclassed by ``KAGATConv`` / ``FASTKAGATConv`` (``models.py:39-46,76-83``), restated
+    (third-party semantics: parity unpinned): ``xh = lin(x).view(N, H, C)``; logits ``(xh*att).sum(-1)``;
+    existing self loops removed, one added per node; ``alpha = softmax_j(leaky_relu(a_src[j] + a_dst[i]))`` over
+    the incoming edges of i; ``out_i = sum_j alpha_ij xh_j``, heads concatenated, plus bias."""
+    n = x.size(0)
+    xh = lin_fn(x).view(n, heads, -1)
+    a_s = (xh * att_src.view(1, heads, -1)).sum(-1)
+    a_d = (xh * att_dst.view(1, heads, -1)).sum(-1)
+    keep = edge_index[0] != edge_index[1]
+    ar = torch.arange(n, dtype=edge_index.dtype)
+    src = torch.cat([edge_index[0][keep], ar])
+    dst = torch.cat([edge_index[1][keep], ar])
+    e = F.leaky_relu(a_s[src] + a_d[dst], negative_slope)                       # [E', H]
+    emax = torch.full((n, heads), float("-inf"), dtype=e.dtype).scatter_reduce(0, dst.view(-1, 1).expand_as(e), e, "amax")
+    p = torch.exp(e - emax[dst])
+    z = torch.zeros((n, heads), dtype=e.dtype).index_add_(0, dst, p)
+    alpha = p / z[dst]
+    out = torch.zeros_like(xh).index_add_(0, dst, alpha.unsqueeze(-1) * xh[src])
+    out = out.reshape(n, -1)
+    return out if bias is None else out + bias
 
 
 def gcn_conv(x: Tensor, edge_index: Tensor, lin_fn, bias: Optional[Tensor]) -> Tensor:

@@ -602,3 +602,51 @@ def test_gcn_conv_weighted_edges_and_sparse_adjacency():
     y_sp = conv(x.to(DEV), adj_t)
     y_ew = conv(x.to(DEV), ei_u.to(DEV), w_u.to(DEV))
     assert_close(y_sp, y_ew, 1e-6, what="sparse adjacency vs edge list")
+
+
+# ------------------------------------------------------------------ GAT flavour
+@pytest.mark.parametrize("shape", [(500, 4000, 24, 8, 4), (300, 2500, 16, 20, 1), (1000, 15000, 32, 16, 3)])
+def test_kagat_conv_vs_oracle(shape):
+    """KAGATConv forward / input gradient / every parameter gradient against the restated GATConv (fp64), on a graph
+    with isolated nodes, explicit self loops (removed and re-added), duplicate edges and a hub."""
+    n, e, fi, c, heads = shape
+    torch.manual_seed(sum(shape))
+    ei = torch.randint(0, n - 10, (2, e))
+    ei[:, :20] = torch.arange(20).repeat(2, 1)                    # self loops
+    ei[1, 20:220] = 7                                             # a hub destination
+    ei[:, 300:320] = ei[:, 320:340]                               # duplicates
+    conv = kagnn_amd.KAGATConv(fi, c, heads, grid_size=5, spline_order=3)
+    conv.bias.data.uniform_(-0.2, 0.2)
+    assert sorted(k for k in conv.state_dict() if not k.startswith("lin.")) == ["att_dst", "att_src", "bias"]
+    x = torch.randn(n, fi) * 0.6
+    gy = torch.randn(n, c * heads)
+    p64 = {k: v.detach().double().requires_grad_(k != "grid") for k, v in conv.lin.state_dict().items()}
+    a_s, a_d, b = (conv.att_src.detach().double().requires_grad_(True), conv.att_dst.detach().double().requires_grad_(True),
+                   conv.bias.detach().double().requires_grad_(True))
+    x64 = x.double().requires_grad_(True)
+    lin = lambda t: orc.kan_linear_forward(t, p64["base_weight"], p64["spline_weight"], p64["spline_scaler"], p64["grid"], 3)
+    y64 = orc.gat_conv(x64, ei, lin, a_s, a_d, b, heads)
+    y64.backward(gy.double())
+    conv = conv.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    y = conv(xd, ei.to(DEV))
+    y.backward(gy.to(DEV))
+    assert_close(y, y64, what="y")
+    assert_close(xd.grad, x64.grad, what="gx")
+    assert_close(conv.att_src.grad, a_s.grad, what="g_att_src")
+    assert_close(conv.att_dst.grad, a_d.grad, what="g_att_dst")
+    assert_close(conv.bias.grad, b.grad, what="g_bias")
+    for k in ("base_weight", "spline_weight", "spline_scaler"):
+        assert_close(getattr(conv.lin, k).grad, p64[k].grad, what="g_lin." + k)
+
+
+def test_gat_node_models_run():
+    n, e = 400, 3000
+    ei = torch.randint(0, n, (2, e)).to(DEV)
+    x = torch.randn(n, 20).to(DEV)
+    for m in (kagnn_amd.GKAN_Nodes("gat", 2, 20, 8, 5, heads=4), kagnn_amd.GFASTKAN_Nodes("gat", 2, 20, 8, 5, heads=2)):
+        m = m.to(DEV)
+        out = m(x, ei)
+        assert out.shape == (n, 5) and torch.isfinite(out).all()
+        out.sum().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
