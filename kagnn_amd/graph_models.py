@@ -1,6 +1,7 @@
 """Graph-level KAN-GNN models with the reference's class surface (mini-batches of many small graphs).
 
-Mirrors ``graph_classification/models.py`` (``KAGIN`` :95-119, ``FASTKAGIN`` :125-151) and
+Mirrors ``graph_classification/models.py`` (``KAGIN`` :95-119, ``FASTKAGIN`` :125-151, ``KAGCN`` / ``KAGAT`` /
+``FASTKAGCN`` / ``FASTKAGAT`` :174-288) and
 ``graph_regression/models.py`` (``KAGIN`` :86-119 with GINE messages and node/edge encoders): same
 constructor arguments, attribute names (``conv``, ``bn``, ``kan``, ``atom_encoder``, ``bond_encoder``)
 and state_dict keys (``conv.{i}.eps``, ``conv.{i}.nn.layers.{j}.*``, ``bn.{i}.*``, ``kan.layers.{j}.*``).
@@ -16,7 +17,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .models import GIFASTKANLayer, GIKANLayer, make_fastkan, make_kan
+from .models import (FASTKAGATConv, FASTKAGCNConv, GIFASTKANLayer, GIKANLayer, KAGATConv, KAGCNConv, make_fastkan,
+                     make_kan)
 from .norm import BatchNorm1d
 
 
@@ -120,3 +122,124 @@ class KAGINRegression(_GraphLevel):
         g = ops.graph_index(data.edge_index, x.size(0))
         x = self._message_passing(x, g, edge_attr)
         return self.kan(self._pool(x, data))
+
+
+# ---------------------------------------------------------------------------------- GCN / GAT flavours
+class _ConvSiluStack(_GraphLevel):
+    """``{conv -> SiLU -> dropout} x L -> pool -> read-out`` of the reference's graph-level KAGCN / KAGAT families
+    (``graph_classification/models.py:174-216,245-288``, ``graph_regression/models.py:174-243``): attribute names
+    ``conv``, ``readout`` (and ``atom_encoder`` for the regression flavour) as there."""
+
+    def _stack(self, x, g):
+        for conv in self.conv:
+            x = self.dropout(F.silu(conv(x, g)))
+        return x
+
+
+class KAGCN(_ConvSiluStack):
+    """graph classification, mean pooling (``graph_classification/models.py:174-194``)."""
+
+    def __init__(self, gnn_layers, num_features, hidden_dim, num_classes, grid_size, spline_order, dropout):
+        super().__init__()
+        self.n_layers = gnn_layers
+        self.conv = nn.ModuleList(KAGCNConv(num_features if i == 0 else hidden_dim, hidden_dim, grid_size, spline_order)
+                                  for i in range(gnn_layers))
+        self.readout = make_kan(hidden_dim, hidden_dim, num_classes, 1, grid_size, spline_order)
+        self.dropout = nn.Dropout(p=dropout)
+
+    def forward(self, data):
+        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0)))
+        ptr = ops.segment_ptr(data.batch, _num_graphs(data))
+        return F.log_softmax(self.readout(ops.segment_pool(x, ptr, mean=True)), dim=1)
+
+
+class KAGAT(_ConvSiluStack):
+    """graph classification, sum pooling (``graph_classification/models.py:196-216``)."""
+
+    def __init__(self, gnn_layers, num_features, hidden_dim, num_classes, grid_size, spline_order, dropout, heads):
+        super().__init__()
+        self.n_layers = gnn_layers
+        self.conv = nn.ModuleList(
+            KAGATConv(num_features if i == 0 else hidden_dim * heads, hidden_dim, heads, grid_size, spline_order)
+            for i in range(gnn_layers))
+        self.readout = make_kan(hidden_dim * heads, hidden_dim, num_classes, 1, grid_size, spline_order)
+        self.dropout = nn.Dropout(p=dropout)
+
+    def forward(self, data):
+        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0)))
+        return F.log_softmax(self.readout(self._pool(x, data)), dim=1)
+
+
+class FASTKAGCN(_ConvSiluStack):
+    """``graph_classification/models.py:245-265``."""
+
+    def __init__(self, gnn_layers, num_features, hidden_dim, num_classes, grid_size, dropout):
+        super().__init__()
+        self.n_layers = gnn_layers
+        self.conv = nn.ModuleList(FASTKAGCNConv(num_features if i == 0 else hidden_dim, hidden_dim, grid_size)
+                                  for i in range(gnn_layers))
+        self.readout = make_fastkan(hidden_dim, hidden_dim, num_classes, 1, grid_size)
+        self.dropout = nn.Dropout(p=dropout)
+
+    def forward(self, data):
+        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0)))
+        ptr = ops.segment_ptr(data.batch, _num_graphs(data))
+        return F.log_softmax(self.readout(ops.segment_pool(x, ptr, mean=True)), dim=1)
+
+
+class FASTKAGAT(_ConvSiluStack):
+    """``graph_classification/models.py:267-288``."""
+
+    def __init__(self, gnn_layers, num_features, hidden_dim, num_classes, grid_size, dropout, heads):
+        super().__init__()
+        self.n_layers, self.heads = gnn_layers, heads
+        self.conv = nn.ModuleList(
+            FASTKAGATConv(num_features if i == 0 else hidden_dim * heads, hidden_dim, heads, grid_size)
+            for i in range(gnn_layers))
+        self.readout = make_fastkan(hidden_dim * heads, hidden_dim, num_classes, 1, grid_size)
+        self.dropout = nn.Dropout(p=dropout)
+
+    def forward(self, data):
+        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0)))
+        return F.log_softmax(self.readout(self._pool(x, data)), dim=1)
+
+
+class KAGCNRegression(_ConvSiluStack):
+    """graph regression (``graph_regression/models.py:174-198``): linear node encoder, GCN(KAN) stack, sum pooling,
+    KAN read-out.  As in the reference the conv layers are built with the DEFAULT grid (4) and order (3) -- the
+    constructor's grid_size / spline_order only reach the read-out."""
+
+    def __init__(self, num_node_features, gnn_layers, hidden_dim, grid_size, spline_order, num_classes, dropout,
+                 ogb_encoders=False):
+        super().__init__()
+        if ogb_encoders:
+            raise NotImplementedError("OGB embedding encoders are outside the hot path; embed upstream")
+        self.n_layers = gnn_layers
+        self.atom_encoder = nn.Linear(num_node_features, hidden_dim)
+        self.conv = nn.ModuleList(KAGCNConv(hidden_dim, hidden_dim) for _ in range(gnn_layers))
+        self.readout = make_kan(hidden_dim, hidden_dim, num_classes, 1, grid_size, spline_order)
+        self.dropout = nn.Dropout(p=dropout)
+
+    def forward(self, data):
+        x = self.atom_encoder(data.x)
+        x = self._stack(x, ops.graph_index(data.edge_index, x.size(0)))
+        return self.readout(self._pool(x, data))
+
+
+class FASTKAGCNRegression(_ConvSiluStack):
+    """``graph_regression/models.py:218-243``."""
+
+    def __init__(self, num_node_features, gnn_layers, hidden_dim, grid_size, num_classes, dropout, ogb_encoders=False):
+        super().__init__()
+        if ogb_encoders:
+            raise NotImplementedError("OGB embedding encoders are outside the hot path; embed upstream")
+        self.n_layers = gnn_layers
+        self.atom_encoder = nn.Linear(num_node_features, hidden_dim)
+        self.conv = nn.ModuleList(FASTKAGCNConv(hidden_dim, hidden_dim, grid_size) for _ in range(gnn_layers))
+        self.readout = make_fastkan(hidden_dim, hidden_dim, num_classes, 1, grid_size)
+        self.dropout = nn.Dropout(p=dropout)
+
+    def forward(self, data):
+        x = self.atom_encoder(data.x)
+        x = self._stack(x, ops.graph_index(data.edge_index, x.size(0)))
+        return self.readout(self._pool(x, data))

@@ -650,3 +650,39 @@ def test_gat_node_models_run():
         assert out.shape == (n, 5) and torch.isfinite(out).all()
         out.sum().backward()
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
+
+
+def test_graph_level_gcn_gat_flavours_match_their_composition():
+    """graph-level KAGCN / KAGAT / FASTKAGCN / FASTKAGAT (+ regression flavours): forward equals the composition of
+    the layer-level ops the other tests pin (conv -> SiLU -> pool -> read-out); gradients reach every parameter."""
+    from types import SimpleNamespace
+    torch.manual_seed(4)
+    sizes = torch.tensor([5, 9, 1, 12, 7])
+    n = int(sizes.sum()); off = torch.cumsum(sizes, 0) - sizes
+    src, dst = [], []
+    for b, nb in enumerate(sizes.tolist()):
+        eb = 3 * nb
+        src.append(torch.randint(0, nb, (eb,)) + off[b]); dst.append(torch.randint(0, nb, (eb,)) + off[b])
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), sizes)
+    d = SimpleNamespace(x=torch.randn(n, 6).to(DEV), edge_index=torch.stack([torch.cat(src), torch.cat(dst)]).to(DEV),
+                        batch=batch.to(DEV), num_graphs=len(sizes))
+    models = [kagnn_amd.KAGCN(2, 6, 8, 3, 4, 3, 0.0), kagnn_amd.KAGAT(2, 6, 8, 3, 4, 3, 0.0, 2),
+              kagnn_amd.FASTKAGCN(2, 6, 8, 3, 4, 0.0), kagnn_amd.FASTKAGAT(2, 6, 8, 3, 4, 0.0, 2),
+              kagnn_amd.KAGCNRegression(6, 2, 8, 4, 3, 1, 0.0), kagnn_amd.FASTKAGCNRegression(6, 2, 8, 4, 1, 0.0)]
+    for m in models:
+        m = m.to(DEV)
+        out = m(d)
+        assert out.shape[0] == len(sizes) and torch.isfinite(out).all()
+        x = d.x if not hasattr(m, "atom_encoder") else m.atom_encoder(d.x)
+        for conv in m.conv:
+            x = torch.nn.functional.silu(conv(x, d.edge_index))
+        mean = isinstance(m, (kagnn_amd.KAGCN, kagnn_amd.FASTKAGCN))
+        pooled = torch.zeros(len(sizes), x.size(1), device=DEV).index_add_(0, d.batch, x)
+        if mean:
+            pooled = pooled / sizes.to(DEV).unsqueeze(1)
+        ref = m.readout(pooled)
+        if not hasattr(m, "atom_encoder"):
+            ref = torch.log_softmax(ref, dim=1)
+        assert_close(out, ref, 1e-5, what=type(m).__name__)
+        out.sum().backward()
+        assert all(p.grad is not None for p in m.parameters() if p.requires_grad), type(m).__name__
