@@ -87,3 +87,19 @@ def time_model(model, x, edge_index, y, mask, nb_epochs: int = 20, warmup: int =
 
 def count_params(model) -> int:
     return int(sum(p.numel() for p in model.parameters()))
+
+
+def make_model(params: dict):
+    """``utils.make_model`` of the reference (``node_classification_clean/utils.py:88-123``) for the KAN / FastKAN
+    architectures: the same ``params`` dictionary builds the same model classes.  The MLP baselines
+    (``architecture == 'mlp'``) are stock torch_geometric models and outside this package."""
+    from .models import GFASTKAN_Nodes, GKAN_Nodes
+    common = dict(conv_type=params["conv_type"], mp_layers=params["mp_layers"], num_features=params["num_features"],
+                  hidden_channels=params["hidden_channels"], num_classes=params["num_classes"], skip=params["skip"],
+                  hidden_layers=params["hidden_layers"], dropout=params["dropout"], grid_size=params["grid_size"],
+                  heads=params.get("heads", 4))
+    if params["architecture"] == "kan":
+        return GKAN_Nodes(spline_order=params["spline_order"], **common)
+    if params["architecture"] == "fastkan":
+        return GFASTKAN_Nodes(**common)
+    raise ValueError("kagnn_amd.harness.make_model builds the 'kan' and 'fastkan' architectures")

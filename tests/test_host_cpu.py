@@ -108,3 +108,16 @@ def test_cpu_tensors_are_refused_not_emulated():
     conv = kagnn_amd.GIKANLayer(4, 4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         conv(torch.randn(5, 4), torch.zeros(2, 3, dtype=torch.long))
+
+
+def test_make_model_mirrors_the_reference_factory():
+    from kagnn_amd.harness import count_params, make_model
+    base = dict(conv_type="gin", mp_layers=2, num_features=10, hidden_channels=8, num_classes=3, skip=True,
+                hidden_layers=2, dropout=0.0, grid_size=4, spline_order=3, heads=2)
+    kan = make_model(dict(base, architecture="kan"))
+    fk = make_model(dict(base, architecture="fastkan", conv_type="gat"))
+    assert type(kan).__name__ == "GKAN_Nodes" and type(fk).__name__ == "GFASTKAN_Nodes"
+    assert count_params(kan) > 0 and fk.lay_out.input_dim == 10 + 2 * 8 * 2
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        make_model(dict(base, architecture="mlp"))
