@@ -241,7 +241,9 @@ int kagnn_batchnorm_bwd(const float* x, int64_t ldx, const float* gy, int64_t ld
  *   kagnn_gat_bwd   : gx = d loss / d xh (all three paths), g_src[N,heads] / g_dst[N,heads] = d loss / d a_src,
  *                     a_dst (the caller contracts them with xh for the att_src / att_dst gradients);
  *                     edge_scratch [E*heads] and self_scratch [N*heads] floats.  CSR arrays as built by
- *                     kagnn_csr_build: (rowptr, col, perm) by destination, (rowptr_t, col_t, perm_t) by source.
+ *                     kagnn_csr_build: (rowptr, col, perm) by destination, (rowptr_t, col_t, perm_t) by source;
+ *                     hub_seg / num_hub_seg / hub_threshold = the by-destination hub segments (rows with more
+ *                     edges get a whole workgroup per head; NULL / 0 disables that).
  * ------------------------------------------------------------------------------------------ */
 int kagnn_gat_logits(const float* xh, int64_t ldx, int64_t num_nodes, int32_t heads, int32_t channels,
                      const float* att_src, const float* att_dst, float* a_src, float* a_dst,
@@ -249,7 +251,8 @@ int kagnn_gat_logits(const float* xh, int64_t ldx, int64_t num_nodes, int32_t he
 int kagnn_gat_fwd(const float* xh, int64_t ldx, const float* a_src, const float* a_dst,
                   const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int32_t heads,
                   int32_t channels, const float* bias, float* out, int64_t ldo, float* row_max,
-                  float* row_sum, void* stream);
+                  float* row_sum, const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
+                  void* stream);
 int kagnn_gat_bwd(const float* xh, int64_t ldx, const float* gout, int64_t ldg, const float* out,
                   int64_t ldo, const float* bias, const float* a_src, const float* a_dst,
                   const float* row_max, const float* row_sum, const int32_t* rowptr,
@@ -257,7 +260,8 @@ int kagnn_gat_bwd(const float* xh, int64_t ldx, const float* gout, int64_t ldg, 
                   const int32_t* col_t, const int32_t* perm_t, const float* att_src,
                   const float* att_dst, int64_t num_nodes, int32_t heads, int32_t channels,
                   float* edge_scratch, float* self_scratch, float* g_dst, float* g_src, float* gx,
-                  int64_t ldgx, void* stream);
+                  int64_t ldgx, const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
+                  void* stream);
 
 #ifdef __cplusplus
 }

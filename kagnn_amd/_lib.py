@@ -56,9 +56,10 @@ _SIGNATURES = {
                                     c_float, _P, _P, c_float, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
                                     _P, c_int32, _P, c_size_t, _P]),
     "kagnn_gat_logits": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
-    "kagnn_gat_fwd": (c_int32, [_P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P]),
+    "kagnn_gat_fwd": (c_int32, [_P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P, c_int64,
+                                c_int32, _P]),
     "kagnn_gat_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, _P]),
+                                _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int32, _P]),
     "kagnn_batchnorm_workspace_bytes": (c_int32, [c_int64, c_int32, POINTER(c_size_t)]),
     "kagnn_batchnorm_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_float, c_float, c_int32,
                                       _P, c_int64, _P, _P, _P, c_size_t, _P]),

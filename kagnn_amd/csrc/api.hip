@@ -47,8 +47,8 @@ size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng, int mode);
 size_t fastkan_bwd_ws_bytes(long N, int in, int out, int ng, int mode);
 int fastkan_bwd(const float*, long, const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, float*, float*, float*, float*, void*, size_t, int, hipStream_t);
 int gat_logits(const float*, long, long, int, int, const float*, const float*, float*, float*, hipStream_t);
-int gat_fwd(const float*, long, const float*, const float*, const int*, const int*, long, int, int, const float*, float*, long, float*, float*, hipStream_t);
-int gat_bwd(const float*, long, const float*, long, const float*, long, const float*, const float*, const float*, const float*, const float*, const int*, const int*, const int*, const int*, const int*, const int*, const float*, const float*, long, int, int, float*, float*, float*, float*, float*, long, hipStream_t);
+int gat_fwd(const float*, long, const float*, const float*, const int*, const int*, long, int, int, const float*, float*, long, float*, float*, const int*, long, int, hipStream_t);
+int gat_bwd(const float*, long, const float*, long, const float*, long, const float*, const float*, const float*, const float*, const float*, const int*, const int*, const int*, const int*, const int*, const int*, const float*, const float*, long, int, int, float*, float*, float*, float*, float*, long, const int*, long, int, hipStream_t);
 size_t bn_ws_bytes(long N, int F);
 int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, float*, long, float*, float*, void*, size_t, hipStream_t);
 int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float*, long, float*, float*, void*, size_t, hipStream_t);
@@ -347,11 +347,13 @@ int kagnn_gat_logits(const float* xh, int64_t ldx, int64_t N, int32_t H, int32_t
 
 int kagnn_gat_fwd(const float* xh, int64_t ldx, const float* a_src, const float* a_dst, const int32_t* rowptr,
                   const int32_t* col, int64_t N, int32_t H, int32_t C, const float* bias, float* out, int64_t ldo,
-                  float* row_max, float* row_sum, void* stream) {
+                  float* row_max, float* row_sum, const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
+                  void* stream) {
     KAGNN_CHECK_ARG(N >= 0 && H >= 1 && C >= 1 && ldx >= (int64_t)H * C && ldo >= (int64_t)H * C, "bad shape");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(xh && a_src && a_dst && rowptr && out && row_max && row_sum, "null array");
-    return gat_fwd(xh, ldx, a_src, a_dst, rowptr, col, N, H, C, bias, out, ldo, row_max, row_sum, as_stream(stream));
+    return gat_fwd(xh, ldx, a_src, a_dst, rowptr, col, N, H, C, bias, out, ldo, row_max, row_sum, hub_seg, num_hub_seg,
+                   hub_threshold, as_stream(stream));
 }
 
 int kagnn_gat_bwd(const float* xh, int64_t ldx, const float* gout, int64_t ldg, const float* out, int64_t ldo,
@@ -359,14 +361,16 @@ int kagnn_gat_bwd(const float* xh, int64_t ldx, const float* gout, int64_t ldg, 
                   const float* row_sum, const int32_t* rowptr, const int32_t* col, const int32_t* perm,
                   const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t, const float* att_src,
                   const float* att_dst, int64_t N, int32_t H, int32_t C, float* edge_scratch, float* self_scratch,
-                  float* g_dst, float* g_src, float* gx, int64_t ldgx, void* stream) {
+                  float* g_dst, float* g_src, float* gx, int64_t ldgx, const int32_t* hub_seg, int64_t num_hub_seg,
+                  int32_t hub_threshold, void* stream) {
     KAGNN_CHECK_ARG(N >= 0 && H >= 1 && C >= 1 && ldx >= (int64_t)H * C && ldg >= (int64_t)H * C && ldo >= (int64_t)H * C &&
                     ldgx >= (int64_t)H * C, "bad shape");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(xh && gout && out && a_src && a_dst && row_max && row_sum && rowptr && rowptr_t && att_src && att_dst &&
                     self_scratch && g_dst && g_src && gx, "null array");
     return gat_bwd(xh, ldx, gout, ldg, out, ldo, bias, a_src, a_dst, row_max, row_sum, rowptr, col, perm, rowptr_t, col_t,
-                   perm_t, att_src, att_dst, N, H, C, edge_scratch, self_scratch, g_dst, g_src, gx, ldgx, as_stream(stream));
+                   perm_t, att_src, att_dst, N, H, C, edge_scratch, self_scratch, g_dst, g_src, gx, ldgx, hub_seg, num_hub_seg,
+                   hub_threshold, as_stream(stream));
 }
 
 }  // extern "C"

@@ -38,11 +38,12 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ a_d, const int* __restrict__ rowptr,
                                                       const int* __restrict__ col, long N, int H, int C,
                                                       const float* __restrict__ bias, float* __restrict__ out, long ldo,
-                                                      float* __restrict__ m_out, float* __restrict__ z_out) {
+                                                      float* __restrict__ m_out, float* __restrict__ z_out, int hub_threshold) {
     const long gid = (blockIdx.x * 256L + threadIdx.x) >> 4;
     const int l = threadIdx.x & 15;
     if (gid >= N * H) return;
     const long i = gid / H; const int h = gid % H;
+    if (rowptr[i + 1] - rowptr[i] > hub_threshold) return;      // long rows: gat_fwd_hub_kernel
     const float ad = a_d[gid];
     float acc[kGatMaxK];
     float m = lrelu(a_s[gid] + ad), z = 1.0f;           // the added self loop
@@ -74,6 +75,73 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const float* __restrict__ 
     if (l == 0) { m_out[gid] = m; z_out[gid] = z; }
 }
 
+// Rows with more than hub_threshold edges (power-law hubs): one workgroup per (row, head); its 16 lane groups each
+// walk every 16th edge with their own online softmax, the 16 partial (m, z, acc) states are merged through LDS in
+// a fixed order.  Launched over the hub SEGMENT list of the CSR build; only a row's first segment does the work.
+__global__ __launch_bounds__(256) void gat_fwd_hub_kernel(const float* __restrict__ xh, long ld, const float* __restrict__ a_s,
+                                                          const float* __restrict__ a_d, const int* __restrict__ rowptr,
+                                                          const int* __restrict__ col, const int* __restrict__ seg, int H,
+                                                          int C, const float* __restrict__ bias, float* __restrict__ out,
+                                                          long ldo, float* __restrict__ m_out, float* __restrict__ z_out) {
+    __shared__ float s_m[16], s_z[16], s_acc[16][16 * kGatMaxK];
+    const int sgi = blockIdx.x / H, h = blockIdx.x % H;
+    const long i = seg[3 * sgi];
+    if (seg[3 * sgi + 1] != rowptr[i]) return;            // not the first segment of its row
+    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const long gid = i * H + h;
+    const float ad = a_d[gid];
+    float acc[kGatMaxK];
+    float m = -3.0e38f, z = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kGatMaxK; ++k) acc[k] = 0.0f;
+    if (grp == 0) {                                       // the added self loop
+        m = lrelu(a_s[gid] + ad); z = 1.0f;
+#pragma unroll
+        for (int k = 0; k < kGatMaxK; ++k) { const int c = l + 16 * k; acc[k] = c < C ? xh[i * ld + (long)h * C + c] : 0.0f; }
+    }
+    for (int e = rowptr[i] + grp; e < rowptr[i + 1]; e += 16) {
+        const int j = col[e];
+        if (j == (int)i) continue;
+        const float v = lrelu(a_s[(long)j * H + h] + ad);
+        if (v > m) {
+            const float sc = __expf(m - v);
+            z *= sc;
+#pragma unroll
+            for (int k = 0; k < kGatMaxK; ++k) acc[k] *= sc;
+            m = v;
+        }
+        const float p = __expf(v - m);
+        z += p;
+        const float* xj = xh + (long)j * ld + (long)h * C;
+#pragma unroll
+        for (int k = 0; k < kGatMaxK; ++k) { const int c = l + 16 * k; if (c < C) acc[k] = fmaf(p, xj[c], acc[k]); }
+    }
+    if (l == 0) { s_m[grp] = m; s_z[grp] = z; }
+#pragma unroll
+    for (int k = 0; k < kGatMaxK; ++k) s_acc[grp][l + 16 * k] = acc[k];
+    __syncthreads();
+    if (grp == 0) {
+        float M = s_m[0];
+        for (int q = 1; q < 16; ++q) M = fmaxf(M, s_m[q]);
+        float Z = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kGatMaxK; ++k) acc[k] = 0.0f;
+        for (int q = 0; q < 16; ++q) {                    // fixed order
+            const float sc = __expf(s_m[q] - M);
+            Z = fmaf(s_z[q], sc, Z);
+#pragma unroll
+            for (int k = 0; k < kGatMaxK; ++k) acc[k] = fmaf(s_acc[q][l + 16 * k], sc, acc[k]);
+        }
+        const float inv = 1.0f / Z;
+#pragma unroll
+        for (int k = 0; k < kGatMaxK; ++k) {
+            const int c = l + 16 * k;
+            if (c < C) out[i * ldo + (long)h * C + c] = fmaf(acc[k], inv, bias ? bias[h * C + c] : 0.0f);
+        }
+        if (l == 0) { m_out[gid] = M; z_out[gid] = Z; }
+    }
+}
+
 // by-destination pass of the backward: g_pre per edge (indexed by the ORIGINAL edge id through perm) and per self
 // loop, and g_d[i,h] = sum_j g_pre_ij
 __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const float* __restrict__ xh, long ld, const float* __restrict__ gout,
@@ -83,10 +151,24 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const float* __restric
                                                           const float* __restrict__ z_in, const int* __restrict__ rowptr,
                                                           const int* __restrict__ col, const int* __restrict__ perm, long N,
                                                           int H, int C, float* __restrict__ gpre, float* __restrict__ gpre_self,
-                                                          float* __restrict__ g_d) {
-    const long gid = (blockIdx.x * 256L + threadIdx.x) >> 4;
-    const int l = threadIdx.x & 15;
-    if (gid >= N * H) return;
+                                                          float* __restrict__ g_d, int hub_threshold,
+                                                          const int* __restrict__ seg /* non-null: hub launch, one workgroup per (segment, head) */) {
+    // row launch: 16 (row, head) groups per workgroup, each walks its whole neighbour list, hub rows skipped;
+    // hub launch: the workgroup of a hub row's FIRST segment spreads the row's edges over its 16 groups
+    __shared__ float s_gd[16];
+    long gid; int first, stride;
+    const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    if (seg) {
+        const int sgi = blockIdx.x / H;
+        const long row = seg[3 * sgi];
+        if (seg[3 * sgi + 1] != rowptr[row]) return;
+        gid = row * H + blockIdx.x % H; first = grp; stride = 16;
+    } else {
+        gid = (blockIdx.x * 256L + threadIdx.x) >> 4; first = 0; stride = 1;
+        if (gid >= N * H) return;
+        const long row = gid / H;
+        if (rowptr[row + 1] - rowptr[row] > hub_threshold) return;
+    }
     const long i = gid / H; const int h = gid % H;
     const float ad = a_d[gid], m = m_in[gid], inv = 1.0f / z_in[gid];
     float g[kGatMaxK];
@@ -102,15 +184,15 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const float* __restric
     }
 #pragma unroll
     for (int o = 8; o >= 1; o >>= 1) { S += __shfl_xor(S, o); gself += __shfl_xor(gself, o); }
-    float gd;
-    {
+    float gd = 0.0f;
+    if (first == 0) {
         const float pre = a_s[gid] + ad;
         const float alpha = __expf(lrelu(pre) - m) * inv;
         const float gp = alpha * (gself - S) * (pre > 0.0f ? 1.0f : kSlope);
         gd = gp;
         if (l == 0) gpre_self[gid] = gp;
     }
-    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    for (int e = rowptr[i] + first; e < rowptr[i + 1]; e += stride) {
         const int j = col[e];
         if (j == (int)i) { if (l == 0) gpre[(long)perm[e] * H + h] = 0.0f; continue; }
         const float* xj = xh + (long)j * ld + (long)h * C;
@@ -125,7 +207,17 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const float* __restric
         gd += gp;
         if (l == 0) gpre[(long)perm[e] * H + h] = gp;
     }
-    if (l == 0) g_d[gid] = gd;
+    if (!seg) {
+        if (l == 0) g_d[gid] = gd;
+    } else {                                              // hub launch: fixed-order sum over the 16 groups
+        if (l == 0) s_gd[grp] = gd;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.0f;
+            for (int q = 0; q < 16; ++q) t += s_gd[q];
+            g_d[gid] = t;
+        }
+    }
 }
 
 // by-source pass: gradient w.r.t. xh through the aggregation and through both logits; g_s[j,h] for the att_src gradient
@@ -178,11 +270,18 @@ int gat_logits(const float* xh, long ld, long N, int H, int C, const float* att_
 }
 
 int gat_fwd(const float* xh, long ld, const float* a_s, const float* a_d, const int* rowptr, const int* col, long N,
-            int H, int C, const float* bias, float* out, long ldo, float* m, float* z, hipStream_t st) {
+            int H, int C, const float* bias, float* out, long ldo, float* m, float* z, const int* hub_seg,
+            long num_hub_seg, int hub_threshold, hipStream_t st) {
     if (N == 0) return KAGNN_OK;
     if (C > 16 * kGatMaxK) return fail(KAGNN_ERR_UNSUPPORTED, "%s: more than 128 channels per head", "gat_fwd");
-    gat_fwd_kernel<<<cdiv(N * H * 16, 256), 256, 0, st>>>(xh, ld, a_s, a_d, rowptr, col, N, H, C, bias, out, ldo, m, z);
+    const int thr = (hub_seg && num_hub_seg > 0) ? hub_threshold : 0x7fffffff;
+    gat_fwd_kernel<<<cdiv(N * H * 16, 256), 256, 0, st>>>(xh, ld, a_s, a_d, rowptr, col, N, H, C, bias, out, ldo, m, z, thr);
     KAGNN_LAUNCH_CHECK();
+    if (thr != 0x7fffffff) {
+        gat_fwd_hub_kernel<<<(unsigned)(num_hub_seg * H), 256, 0, st>>>(xh, ld, a_s, a_d, rowptr, col, hub_seg, H, C, bias, out,
+                                                                       ldo, m, z);
+        KAGNN_LAUNCH_CHECK();
+    }
     return KAGNN_OK;
 }
 
@@ -190,13 +289,19 @@ int gat_bwd(const float* xh, long ld, const float* gout, long ldg, const float* 
             const float* a_s, const float* a_d, const float* m, const float* z, const int* rowptr, const int* col,
             const int* perm, const int* rowptr_t, const int* col_t, const int* perm_t, const float* att_src,
             const float* att_dst, long N, int H, int C, float* gpre, float* gpre_self, float* g_d, float* g_s,
-            float* gx, long ldgx, hipStream_t st) {
+            float* gx, long ldgx, const int* hub_seg, long num_hub_seg, int hub_threshold, hipStream_t st) {
     if (N == 0) return KAGNN_OK;
     if (C > 16 * kGatMaxK) return fail(KAGNN_ERR_UNSUPPORTED, "%s: more than 128 channels per head", "gat_bwd");
     const int grid = cdiv(N * H * 16, 256);
+    const int thr = (hub_seg && num_hub_seg > 0) ? hub_threshold : 0x7fffffff;
     gat_bwd_dst_kernel<<<grid, 256, 0, st>>>(xh, ld, gout, ldg, y, ldy, bias, a_s, a_d, m, z, rowptr, col, perm, N, H, C,
-                                              gpre, gpre_self, g_d);
+                                              gpre, gpre_self, g_d, thr, nullptr);
     KAGNN_LAUNCH_CHECK();
+    if (thr != 0x7fffffff) {
+        gat_bwd_dst_kernel<<<(unsigned)(num_hub_seg * H), 256, 0, st>>>(xh, ld, gout, ldg, y, ldy, bias, a_s, a_d, m, z, rowptr, col,
+                                                                       perm, N, H, C, gpre, gpre_self, g_d, thr, hub_seg);
+        KAGNN_LAUNCH_CHECK();
+    }
     gat_bwd_src_kernel<<<grid, 256, 0, st>>>(gout, ldg, a_s, a_d, m, z, rowptr_t, col_t, perm_t, gpre, gpre_self, g_d,
                                               att_src, att_dst, N, H, C, gx, ldgx, g_s);
     KAGNN_LAUNCH_CHECK();

@@ -495,7 +495,8 @@ class _GatFn(Function):
         m = torch.empty((n, heads), dtype=torch.float32, device=dev)
         z = torch.empty((n, heads), dtype=torch.float32, device=dev)
         _call("kagnn_gat_fwd", _ptr(xh), _ld(xh), _ptr(ls), _ptr(ld_), _ptr(g.rowptr), _ptr(g.col), n, heads, channels,
-              _ptr(b), _ptr(out), heads * channels, _ptr(m), _ptr(z), _stream())
+              _ptr(b), _ptr(out), heads * channels, _ptr(m), _ptr(z), _ptr(g.hub_seg) if g.num_hub_seg else None,
+              g.num_hub_seg, g.hub_threshold, _stream())
         ctx.save_for_backward(xh, a_s, a_d, b, ls, ld_, m, z, out)
         ctx.g, ctx.hc = g, (heads, channels)
         ctx.att_shape = att_src.shape
@@ -518,7 +519,8 @@ class _GatFn(Function):
         _call("kagnn_gat_bwd", _ptr(xh), _ld(xh), _ptr(gout), _ld(gout), _ptr(out), heads * channels, _ptr(b), _ptr(ls),
               _ptr(ld_), _ptr(m), _ptr(z), _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm), _ptr(g.rowptr_t), _ptr(g.col_t),
               _ptr(g.perm_t), _ptr(a_s), _ptr(a_d), n, heads, channels, _ptr(gpre), _ptr(gself), _ptr(gd), _ptr(gs),
-              _ptr(gx), heads * channels, _stream())
+              _ptr(gx), heads * channels, _ptr(g.hub_seg) if g.num_hub_seg else None, g.num_hub_seg, g.hub_threshold,
+              _stream())
         x3 = xh.reshape(n, heads, channels) if xh.is_contiguous() else xh.contiguous().view(n, heads, channels)
         g_att_src = torch.einsum("nh,nhc->hc", gs, x3).reshape(ctx.att_shape)      # [H, C] contractions over the nodes
         g_att_dst = torch.einsum("nh,nhc->hc", gd, x3).reshape(ctx.att_shape)

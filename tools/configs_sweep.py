@@ -28,6 +28,9 @@ if 2 in WANT:
     m = kagnn_amd.GKAN_Nodes('gcn', 3, 128, 64, 40, grid_size=5, spline_order=3).to(dev)
     t, losses = time_model(m, x, ei, y, mask, nb_epochs=5, warmup=2)
     print("cfg2b GKAN_Nodes gcn arxiv-shape: s/epoch", t, losses[-1], flush=True)
+    m = kagnn_amd.GKAN_Nodes('gat', 3, 128, 16, 40, grid_size=5, spline_order=3, heads=4).to(dev)
+    t, losses = time_model(m, x, ei, y, mask, nb_epochs=5, warmup=2)
+    print("cfg2c GKAN_Nodes gat (4 heads x 16) arxiv-shape: s/epoch", t, losses[-1], flush=True)
 # config 5: FastKAN hidden 256 on arxiv shape
 if 5 in WANT:
     m = kagnn_amd.GFASTKAN_Nodes('gin', 3, 128, 256, 40, grid_size=8, hidden_layers=2).to(dev)
