@@ -11,7 +11,7 @@ from .models import (FASTKAGATConv, FASTKAGCNConv, FKANLayer, GFASTKAN_Nodes,   
                      GIFASTKANLayer, GIKANLayer, GKAN_Nodes, KAGATConv, KAGCNConv, KANLayer)
 
 from .norm import BatchNorm1d                                                    # noqa: F401
-from .graph_models import (FASTKAGAT, FASTKAGCN, FASTKAGCNRegression, FASTKAGIN, GINEKANLayer,   # noqa: F401
+from .graph_models import (AtomEncoder, BondEncoder, FASTKAGAT, FASTKAGCN, FASTKAGCNRegression, FASTKAGIN, GINEKANLayer,   # noqa: F401
                            KAGAT, KAGCN, KAGCNRegression, KAGIN, KAGINRegression)
 
 __version__ = "0.1.0"

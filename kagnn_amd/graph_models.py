@@ -22,6 +22,49 @@ from .models import (FASTKAGATConv, FASTKAGCNConv, GIFASTKANLayer, GIKANLayer, K
 from .norm import BatchNorm1d
 
 
+# OGB molecule feature cardinalities (lengths of the category lists the reference tabulates in
+# graph_regression/models.py:283-345): atomic number, chirality, degree, formal charge, #H, #radical e, hybridisation,
+# aromatic, in-ring; bond type, stereo, conjugated
+ATOM_FEATURE_DIMS = [119, 5, 12, 12, 10, 6, 6, 2, 2]
+BOND_FEATURE_DIMS = [5, 6, 2]
+
+
+class _SumOfEmbeddings(nn.Module):
+    """sum over the integer feature columns of one embedding table each (host-side torch: an index lookup, not part
+    of the hot path)"""
+
+    def __init__(self, dims, emb_dim, list_name):
+        super().__init__()
+        tables = nn.ModuleList()
+        for d in dims:
+            emb = nn.Embedding(d, emb_dim)
+            nn.init.xavier_uniform_(emb.weight.data)
+            tables.append(emb)
+        setattr(self, list_name, tables)
+        self._list_name = list_name
+
+    def forward(self, x):
+        tables = getattr(self, self._list_name)
+        out = 0
+        for i in range(x.shape[1]):
+            out = out + tables[i](x[:, i])
+        return out
+
+
+class AtomEncoder(_SumOfEmbeddings):
+    """``graph_regression/models.py:244-262`` (state_dict keys ``atom_embedding_list.{i}.weight``)."""
+
+    def __init__(self, emb_dim, optional_full_atom_features_dims=None):
+        super().__init__(optional_full_atom_features_dims or ATOM_FEATURE_DIMS, emb_dim, "atom_embedding_list")
+
+
+class BondEncoder(_SumOfEmbeddings):
+    """``graph_regression/models.py:264-281`` (state_dict keys ``bond_embedding_list.{i}.weight``)."""
+
+    def __init__(self, emb_dim):
+        super().__init__(BOND_FEATURE_DIMS, emb_dim, "bond_embedding_list")
+
+
 def _num_graphs(data) -> int:
     n = getattr(data, "num_graphs", None)
     return int(n) if n is not None else int(data.batch.max()) + 1
@@ -95,17 +138,14 @@ class GINEKANLayer(nn.Module):
 class KAGINRegression(_GraphLevel):
     """graph regression (ZINC / QM9 flavour of the reference, ``graph_regression/models.py:86-119``):
     linear (or caller-supplied) node / edge encoders -> GINE(KAN) stack -> global_add_pool -> KAN.
-    ``ogb_encoders=True`` (OGB Atom/BondEncoder embedding tables) is out of the hot path: pass already
-    embedded ``x`` / ``edge_attr`` or use the linear encoders."""
+    ``ogb_encoders=True`` uses the OGB Atom/BondEncoder embedding tables on integer features."""
 
     def __init__(self, num_node_features, num_edge_features, gnn_layers, hidden_dim, hidden_layers, grid_size,
                  spline_order, num_classes, dropout, ogb_encoders=False):
         super().__init__()
-        if ogb_encoders:
-            raise NotImplementedError("OGB embedding encoders are outside the hot path; embed upstream")
         self.n_layers = gnn_layers
-        self.atom_encoder = nn.Linear(num_node_features, hidden_dim)
-        self.bond_encoder = nn.Linear(num_edge_features, hidden_dim)
+        self.atom_encoder = AtomEncoder(hidden_dim) if ogb_encoders else nn.Linear(num_node_features, hidden_dim)
+        self.bond_encoder = BondEncoder(hidden_dim) if ogb_encoders else nn.Linear(num_edge_features, hidden_dim)
         self.conv = nn.ModuleList(
             GINEKANLayer(make_kan(hidden_dim, hidden_dim, hidden_dim, hidden_layers, grid_size, spline_order))
             for _ in range(gnn_layers))
@@ -212,10 +252,8 @@ class KAGCNRegression(_ConvSiluStack):
     def __init__(self, num_node_features, gnn_layers, hidden_dim, grid_size, spline_order, num_classes, dropout,
                  ogb_encoders=False):
         super().__init__()
-        if ogb_encoders:
-            raise NotImplementedError("OGB embedding encoders are outside the hot path; embed upstream")
         self.n_layers = gnn_layers
-        self.atom_encoder = nn.Linear(num_node_features, hidden_dim)
+        self.atom_encoder = AtomEncoder(hidden_dim) if ogb_encoders else nn.Linear(num_node_features, hidden_dim)
         self.conv = nn.ModuleList(KAGCNConv(hidden_dim, hidden_dim) for _ in range(gnn_layers))
         self.readout = make_kan(hidden_dim, hidden_dim, num_classes, 1, grid_size, spline_order)
         self.dropout = nn.Dropout(p=dropout)
@@ -231,10 +269,8 @@ class FASTKAGCNRegression(_ConvSiluStack):
 
     def __init__(self, num_node_features, gnn_layers, hidden_dim, grid_size, num_classes, dropout, ogb_encoders=False):
         super().__init__()
-        if ogb_encoders:
-            raise NotImplementedError("OGB embedding encoders are outside the hot path; embed upstream")
         self.n_layers = gnn_layers
-        self.atom_encoder = nn.Linear(num_node_features, hidden_dim)
+        self.atom_encoder = AtomEncoder(hidden_dim) if ogb_encoders else nn.Linear(num_node_features, hidden_dim)
         self.conv = nn.ModuleList(FASTKAGCNConv(hidden_dim, hidden_dim, grid_size) for _ in range(gnn_layers))
         self.readout = make_fastkan(hidden_dim, hidden_dim, num_classes, 1, grid_size)
         self.dropout = nn.Dropout(p=dropout)

@@ -121,3 +121,14 @@ def test_make_model_mirrors_the_reference_factory():
     import pytest as _pt
     with _pt.raises(ValueError):
         make_model(dict(base, architecture="mlp"))
+
+
+def test_ogb_encoders_surface():
+    import torch
+    import kagnn_amd
+    a, b = kagnn_amd.AtomEncoder(6), kagnn_amd.BondEncoder(6)
+    assert [e.num_embeddings for e in a.atom_embedding_list] == [119, 5, 12, 12, 10, 6, 6, 2, 2]
+    assert [e.num_embeddings for e in b.bond_embedding_list] == [5, 6, 2]
+    assert a(torch.zeros(3, 9, dtype=torch.long)).shape == (3, 6) and b(torch.ones(4, 3, dtype=torch.long)).shape == (4, 6)
+    m = kagnn_amd.KAGINRegression(9, 3, 2, 8, 2, 4, 3, 1, 0.0, ogb_encoders=True)
+    assert "atom_encoder.atom_embedding_list.0.weight" in m.state_dict() and "bond_encoder.bond_embedding_list.2.weight" in m.state_dict()
