@@ -45,6 +45,18 @@ def kan_flops(n, fin, fout, c):
     return 2.0 * n * fin * (c + 1) * fout
 
 
+def powerlaw_graph(num_nodes, num_edges, seed=0):
+    """The synthetic graph recipe of SURVEY.md 8(d): dst = perm[floor(N u^2)] (in-degree of rank r ~ r^-1/2), src
+    uniform, duplicates and self loops kept, unsorted.  (Same recipe as oracle/kan_oracle.py:powerlaw_graph, which the
+    tests use; restated here so that the measured path imports nothing from oracle/.)"""
+    g = torch.Generator().manual_seed(seed)
+    perm = torch.randperm(num_nodes, generator=g)
+    u = torch.rand(num_edges, generator=g, dtype=torch.float64)
+    dst = perm[torch.floor(num_nodes * u * u).long().clamp_(max=num_nodes - 1)]
+    src = torch.randint(0, num_nodes, (num_edges,), generator=g)
+    return torch.stack([src, dst])
+
+
 def cpu_baseline(n_sample, e_sample, f, grid, order, seed=0):
     """The reference's algorithm (oracle/kan_oracle.py: dense bases, F.linear, index_select +
     scatter_add_, stock autograd) on the host cores, bounded sample of the same workload.  torch's CPU
@@ -115,10 +127,9 @@ def main():
 
     import kagnn_amd
     from kagnn_amd import ops
-    from oracle import kan_oracle as orc          # graph recipe only; checker/baseline code
 
     n, e, f = args.nodes, args.edges, args.hidden
-    ei = orc.powerlaw_graph(n, e, seed=0).to(dev)
+    ei = powerlaw_graph(n, e, seed=0).to(dev)
     gen = torch.Generator().manual_seed(0)
     x_full = torch.randn(n, f, generator=gen) * 0.25
     gy_full = torch.Generator().manual_seed(1)
