@@ -105,17 +105,15 @@ __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float*
 // Workgroup = 1024 threads = 16 waves (4 per SIMD, <= 128 VGPRs each) so that LDS / VALU latencies of
 // one wave hide under the other three; one wave = 32 rows.  x is consumed in groups of 8 features per
 // lane (two float4), the next group is prefetched while the current one is expanded.
-// (GEN == false would drop the virtual-feature / split-K code; the hot cubic case now lives in kan_sparse_fwd.hip)
-template <int K, int OT, int NT, bool GEN>
+// (cubic splines with <= 8 coefficients take kan_sparse_fwd.hip instead)
+template <int K, int OT, int NT>
 __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g,
     int nknots, const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy,
-    int out, RbfArgs rb, int sh_arg /* 1: two 8-slot windows per input feature (virtual features, see wcat_v) */,
-    int cps_arg /* split-K for few-row inputs: blockIdx.y owns this many chunks and writes a partial y */,
+    int out, RbfArgs rb, int sh /* 1: two 8-slot windows per input feature (virtual features, see wcat_v) */,
+    int chunks_per_split /* split-K for few-row inputs: blockIdx.y owns this many chunks and writes a partial y */,
     long part_stride /* elements between the partial outputs of consecutive splits (0: no split) */) {
-    const int sh = GEN ? sh_arg : 0;
-    const int chunks_per_split = GEN ? cps_arg : nchunks;
-    const int split = GEN ? (int)blockIdx.y : 0;
+    const int split = (int)blockIdx.y;
     constexpr int CF = (OT <= 2) ? 64 : 32, HF = CF / 2, SPC = CF / 2, BPC = CF / 16;
     constexpr int CHUNK_BYTES = SPC * OT * 2 * 1024 + BPC * OT * 3 * 1024;
     constexpr int NG = HF / 8;                       // groups of 8 features per lane-half and chunk
@@ -138,7 +136,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     const int ch_begin = split * chunks_per_split, ch_end = min(nchunks, ch_begin + chunks_per_split);
     const bool resident = (ch_end - ch_begin) == 1;      // this workgroup's only chunk stays in LDS
     if (resident) stage_chunk(ch_begin);
-    if (GEN) y += (long)split * part_stride;
+    y += (long)split * part_stride;
     __syncthreads();
     SplineGeom geom{}; Frag3Geom f3geo{};
     float ca[8] = {}, cao[8] = {};                       // RBF centres of the even / odd virtual features
@@ -385,7 +383,7 @@ static int launch_fwd(const float* x, long ldx, long N, int in, const float* kno
     const size_t lds = kLdsHdr + split_fwd_chunk_bytes(OT);
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT, NT, true>,
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT, NT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
@@ -394,7 +392,7 @@ static int launch_fwd(const float* x, long ldx, long N, int in, const float* kno
     if (p.splits > 1) {
         if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_split_fwd");
-        kan_split_fwd_kernel<K, OT, NT, true><<<dim3(gx, p.splits), NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks,
+        kan_split_fwd_kernel<K, OT, NT><<<dim3(gx, p.splits), NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks,
                                                                                ws, out, out, rb, sh, p.cps, N * (long)out);
         KAGNN_LAUNCH_CHECK();
         fwd_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
@@ -402,7 +400,7 @@ static int launch_fwd(const float* x, long ldx, long N, int in, const float* kno
         return KAGNN_OK;
     }
     // (cubic splines with <= 8 coefficients never get here: kan_sparse_fwd.hip serves them)
-    kan_split_fwd_kernel<K, OT, NT, true><<<gx, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out,
+    kan_split_fwd_kernel<K, OT, NT><<<gx, NT, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out,
                                                                rb, sh, nchunks, 0L);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
