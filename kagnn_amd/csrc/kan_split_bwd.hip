@@ -654,33 +654,43 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
 __global__ void kan_dw_reduce_unpack_kernel(const float* __restrict__ slab, long NS, int in, int out, int C,
                                             long inP, long outP, const float* __restrict__ sw,
                                             const float* __restrict__ sc, float* __restrict__ g_bw,
-                                            float* __restrict__ g_sw, float* __restrict__ g_sc) {
-    extern __shared__ float s_red[];                 // [C][32]
-    const int ol = threadIdx.x & 31, c = threadIdx.x >> 5;
+                                            float* __restrict__ g_sw, float* __restrict__ g_sc, int SG) {
+    // thread = (output ol of 32, plane c of C+1, slab group sg of SG): the slab sum is split over SG groups (shorter
+    // dependent load chains), combined through LDS in group order -- still a fixed summation order
+    extern __shared__ float s_red[];                 // [SG][C+1][32] partial sums, then [C][32] products
+    const int ol = threadIdx.x & 31, pc = threadIdx.x >> 5;
+    const int c = pc % (C + 1), sg = pc / (C + 1);
     const int f = blockIdx.y, o = blockIdx.x * 32 + ol;
     const long per = (long)(C + 1) * inP * outP;
     const long i = ((long)c * inP + f) * outP + o;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    long s = 0;
-    for (; s + 4 <= NS; s += 4) {
-        a0 += slab[(s + 0) * per + i];
-        a1 += slab[(s + 1) * per + i];
-        a2 += slab[(s + 2) * per + i];
-        a3 += slab[(s + 3) * per + i];
+    long s = sg;
+    for (; s + 3 * SG < NS; s += 4 * SG) {
+        a0 += slab[(s + 0 * SG) * per + i];
+        a1 += slab[(s + 1 * SG) * per + i];
+        a2 += slab[(s + 2 * SG) * per + i];
+        a3 += slab[(s + 3 * SG) * per + i];
     }
-    for (; s < NS; ++s) a0 += slab[s * per + i];
-    const float g = (a0 + a1) + (a2 + a3);
+    for (; s < NS; s += SG) a0 += slab[s * per + i];
+    s_red[(sg * (C + 1) + c) * 32 + ol] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    float g = 0.0f;
+    if (sg == 0)
+        for (int q = 0; q < SG; ++q) g += s_red[(q * (C + 1) + c) * 32 + ol];
+    __syncthreads();
     const bool live = o < out;
     const long of = (long)min(o, out - 1) * in + f;
-    if (c < C) {
-        const float scale = sc ? sc[of] : 1.0f;
-        if (live) g_sw[of * C + c] = g * scale;
-        s_red[c * 32 + ol] = g * sw[of * C + c];
-    } else if (live && g_bw) {
-        g_bw[of] = g;
+    if (sg == 0) {
+        if (c < C) {
+            const float scale = sc ? sc[of] : 1.0f;
+            if (live) g_sw[of * C + c] = g * scale;
+            s_red[c * 32 + ol] = g * sw[of * C + c];
+        } else if (live && g_bw) {
+            g_bw[of] = g;
+        }
     }
     __syncthreads();
-    if (c == 0 && live && g_sc) {
+    if (sg == 0 && c == 0 && live && g_sc) {
         float gs = 0.0f;
         for (int k = 0; k < C; ++k) gs += s_red[k * 32 + ol];
         g_sc[of] = gs;
@@ -732,8 +742,10 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
 #undef L
     KAGNN_LAUNCH_CHECK();
     if (!sh) {
-        kan_dw_reduce_unpack_kernel<<<dim3((unsigned)(p.outP / 32), (unsigned)in), 32 * (C + 1), (size_t)C * 32 * sizeof(float), st>>>(
-            slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc);
+        const int SG = max(1, min(3, 1024 / (32 * (C + 1))));
+        kan_dw_reduce_unpack_kernel<<<dim3((unsigned)(p.outP / 32), (unsigned)in), 32 * (C + 1) * SG,
+                                      (size_t)SG * (C + 1) * 32 * sizeof(float), st>>>(
+            slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, SG);
         KAGNN_LAUNCH_CHECK();
         return KAGNN_OK;
     }
