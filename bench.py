@@ -156,7 +156,8 @@ def main():
         from kagnn_amd.sharded import ShardedGIKANLayer, TransposedShardedGIKANLayer
         sharding = os.environ.get("KAGNN_SHARDING", "transposed")
         cls = ShardedGIKANLayer if sharding == "feature" else TransposedShardedGIKANLayer
-        sconv = cls(conv, dist.group.WORLD).to(dev)
+        sconv = (cls(conv, dist.group.WORLD, sync_in_backward=False) if cls is TransposedShardedGIKANLayer
+                 else cls(conv, dist.group.WORLD)).to(dev)
         x = sconv.shard_columns(x_full.to(dev)).requires_grad_(True)
         gy = sconv.shard_columns(gy_full.to(dev))
 
@@ -166,6 +167,8 @@ def main():
                 p.grad = None
             y = sconv(x, graph)
             y.backward(gy)
+            if hasattr(sconv, "sync_gradients"):
+                sconv.sync_gradients()             # one flat all-reduce for all weight gradients
 
     def sync():
         if dist is not None:

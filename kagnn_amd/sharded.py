@@ -188,18 +188,34 @@ class TransposedShardedGIKANLayer(nn.Module):
     """``GIKANLayer`` with the aggregation on column shards and the KAN chain on row shards (see the module
     docstring).  Same interface as ``ShardedGIKANLayer``: column shard in, column shard out."""
 
-    def __init__(self, conv: GIKANLayer, group=None, local_ops=None):
+    def __init__(self, conv: GIKANLayer, group=None, local_ops=None, sync_in_backward: bool = True):
+        """``sync_in_backward=True``: every parameter's gradient is all-reduced inside autograd (one small
+        collective per parameter tensor -- transparent, like DDP without buckets).  ``False``: gradients stay
+        rank-local until ``sync_gradients()`` sums ALL of them with ONE flat all-reduce (what ``bench.py`` does)."""
         super().__init__()
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.local_ops = _hip_ops if local_ops is None else local_ops
+        self.sync_in_backward = sync_in_backward
         self.eps = float(conv.eps)
         for l in conv.nn.layers:
             if l.in_features % self.world or l.out_features % self.world:
                 raise ValueError("layer widths must be divisible by the world size")
         import copy
         self.layers = nn.ModuleList(copy.deepcopy(l) for l in conv.nn.layers)      # replicated parameters
+
+    def sync_gradients(self) -> None:
+        """sum the parameter gradients over the ranks with a single flat all-reduce (for ``sync_in_backward=False``)"""
+        grads = [p.grad for p in self.parameters() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
 
     def shard_columns(self, t: torch.Tensor) -> torch.Tensor:
         w = t.size(1) // self.world
@@ -212,9 +228,9 @@ class TransposedShardedGIKANLayer(nn.Module):
         for layer in self.layers:
             sc = layer.spline_scaler if layer.enable_standalone_scale_spline else None
             g = self.group
-            h = self.local_ops.kan_linear(h, _SumGradAcrossRanks.apply(layer.base_weight, g),
-                                          _SumGradAcrossRanks.apply(layer.spline_weight, g),
-                                          None if sc is None else _SumGradAcrossRanks.apply(sc, g),
+            wrap = (lambda p: _SumGradAcrossRanks.apply(p, g)) if self.sync_in_backward else (lambda p: p)
+            h = self.local_ops.kan_linear(h, wrap(layer.base_weight), wrap(layer.spline_weight),
+                                          None if sc is None else wrap(sc),
                                           layer.grid[0].contiguous(), layer.grid_size, layer.spline_order,
                                           layer.precision)
         return _RowsToCols.apply(h, n, self.group)

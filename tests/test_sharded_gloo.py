@@ -70,10 +70,12 @@ def _worker(rank, world, port, out_dir):
             x2 = torch.randn(n2, f, generator=gen) * 0.3
             gy2 = torch.randn(n2, f, generator=gen)
             y_ref, gx_ref, g_ref = orc.kan_gin_layer_fwd_bwd(x2, ei2, layers, 3, gy2)
-            tconv = TransposedShardedGIKANLayer(conv, None, local_ops=OracleOps)
+            tconv = TransposedShardedGIKANLayer(conv, None, local_ops=OracleOps, sync_in_backward=(n2 == 400))
             xs = tconv.shard_columns(x2).requires_grad_(True)
             y = tconv(xs, ei2)
             y.backward(tconv.shard_columns(gy2))
+            if n2 != 400:
+                tconv.sync_gradients()                        # the explicit single flat all-reduce
             assert torch.allclose(y, y_ref[:, sl], atol=tol, rtol=tol)
             assert torch.allclose(xs.grad, gx_ref[:, sl], atol=tol, rtol=tol)
             for li, layer in enumerate(tconv.layers):         # replicated parameters: full gradients on every rank
