@@ -50,10 +50,11 @@ const char* kagnn_last_error(void);
  *   perm[E]      = argsort(key, stable)                (bit-exact contract)
  *   col[E]       = val[perm]
  * (key=dst,val=src) gives the forward structure, (key=src,val=dst) its transpose for backward.
- * Rows whose degree exceeds `hub_threshold` are split into segments of at most
- * `hub_threshold` edges, listed in hub_seg[3*i+{0,1,2}] = {row, e_begin, e_end};
- * *num_hub_seg_host receives their count (never more than 2*E/hub_threshold + 1, so size
- * hub_seg for 3x that many int32).  This call synchronises `stream` once (to return the count).
+ * Rows whose degree exceeds `hub_threshold` are split into segments of L = max(hub_threshold/4, 32)
+ * edges, listed in hub_seg[3*i+{0,1,2}] = {row, e_begin, e_end} (a row's segments are contiguous
+ * in e and its first one starts at rowptr[row]); *num_hub_seg_host receives their count (never
+ * more than E/L + E/hub_threshold + 1, so size hub_seg for 3x that many int32).  This call
+ * synchronises `stream` once (to return the count).
  * ------------------------------------------------------------------------------------------ */
 int kagnn_csr_workspace_bytes(int64_t num_edges, int64_t num_nodes, size_t* bytes_host);
 int kagnn_csr_build(const int64_t* key, const int64_t* val, int64_t num_edges, int64_t num_nodes,

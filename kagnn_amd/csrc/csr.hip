@@ -40,13 +40,14 @@ __global__ void csr_hub_kernel(const int* __restrict__ rowptr, long N, int T, in
     if (i >= N) return;
     const int s = rowptr[i], t = rowptr[i + 1];
     if (t - s <= T) return;
-    const int nseg = (t - s + T - 1) / T;
+    const int L = max(T / 4, 32);                      // segment length: short segments = more workgroups per hub,
+    const int nseg = (t - s + L - 1) / L;             // a hub kernel is pure latency otherwise (<= T edges each, as documented)
     const int base = atomicAdd(counter, nseg);
     for (int k = 0; k < nseg; ++k) {
         if (base + k < cap) {
             seg[3 * (base + k) + 0] = (int)i;
-            seg[3 * (base + k) + 1] = s + k * T;
-            seg[3 * (base + k) + 2] = min(t, s + (k + 1) * T);
+            seg[3 * (base + k) + 1] = s + k * L;
+            seg[3 * (base + k) + 2] = min(t, s + (k + 1) * L);
         }
     }
 }

@@ -152,7 +152,8 @@ class GraphIndex:
         rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         col = torch.empty(e, dtype=torch.int32, device=dev)
         perm = torch.empty(e, dtype=torch.int32, device=dev)
-        cap = 2 * e // self.hub_threshold + 1
+        seg_len = max(self.hub_threshold // 4, 32)                  # as in csr.hip
+        cap = e // seg_len + e // self.hub_threshold + 1
         hub = torch.empty(3 * cap, dtype=torch.int32, device=dev)
         nseg = c_int64(0)
         _call("kagnn_csr_build", _ptr(key), _ptr(val), e, n, _ptr(rowptr), _ptr(col), _ptr(perm),
