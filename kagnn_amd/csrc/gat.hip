@@ -39,17 +39,25 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const float* __restrict__ 
                                                       const int* __restrict__ col, long N, int H, int C,
                                                       const float* __restrict__ bias, float* __restrict__ out, long ldo,
                                                       float* __restrict__ m_out, float* __restrict__ z_out, int hub_threshold) {
-    const long gid = (blockIdx.x * 256L + threadIdx.x) >> 4;
-    const int l = threadIdx.x & 15;
+    // one WAVE per (row, head): its four 16-lane groups take every 4th edge each (a 500-edge row is 125 dependent
+    // steps instead of 500 -- the kernel's run time is its longest row) and merge their softmax states with two
+    // butterfly steps across the groups, always in the same order
+    const long gid = (blockIdx.x * 256L + threadIdx.x) >> 6;
+    const int l = threadIdx.x & 15, grp = (threadIdx.x >> 4) & 3;
     if (gid >= N * H) return;
     const long i = gid / H; const int h = gid % H;
     if (rowptr[i + 1] - rowptr[i] > hub_threshold) return;      // long rows: gat_fwd_hub_kernel
     const float ad = a_d[gid];
     float acc[kGatMaxK];
-    float m = lrelu(a_s[gid] + ad), z = 1.0f;           // the added self loop
+    float m = -3.0e38f, z = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kGatMaxK; ++k) { const int c = l + 16 * k; acc[k] = c < C ? xh[i * ld + (long)h * C + c] : 0.0f; }
-    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    for (int k = 0; k < kGatMaxK; ++k) acc[k] = 0.0f;
+    if (grp == 0) {                                       // the added self loop
+        m = lrelu(a_s[gid] + ad); z = 1.0f;
+#pragma unroll
+        for (int k = 0; k < kGatMaxK; ++k) { const int c = l + 16 * k; acc[k] = c < C ? xh[i * ld + (long)h * C + c] : 0.0f; }
+    }
+    for (int e = rowptr[i] + grp; e < rowptr[i + 1]; e += 4) {
         const int j = col[e];
         if (j == (int)i) continue;                       // existing self loops are removed
         const float v = lrelu(a_s[(long)j * H + h] + ad);
@@ -66,13 +74,22 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < kGatMaxK; ++k) { const int c = l + 16 * k; if (c < C) acc[k] = fmaf(p, xj[c], acc[k]); }
     }
+    // merge the four groups: common maximum, rescale, butterfly sums (lanes l, l+16, l+32, l+48)
+    const float M = fmaxf(fmaxf(m, __shfl_xor(m, 16)), fmaxf(__shfl_xor(m, 32), __shfl_xor(m, 48)));
+    const float sc = __expf(m - M);
+    z *= sc;
+    z += __shfl_xor(z, 16); z += __shfl_xor(z, 32);
     const float inv = 1.0f / z;
 #pragma unroll
     for (int k = 0; k < kGatMaxK; ++k) {
-        const int c = l + 16 * k;
-        if (c < C) out[i * ldo + (long)h * C + c] = fmaf(acc[k], inv, bias ? bias[h * C + c] : 0.0f);
+        if (16 * k < C) {                                 // wave-uniform
+            float a = acc[k] * sc;
+            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            const int c = l + 16 * k;
+            if (grp == 0 && c < C) out[i * ldo + (long)h * C + c] = fmaf(a, inv, bias ? bias[h * C + c] : 0.0f);
+        }
     }
-    if (l == 0) { m_out[gid] = m; z_out[gid] = z; }
+    if (threadIdx.x % 64 == 0) { m_out[gid] = M; z_out[gid] = z; }
 }
 
 // Rows with more than hub_threshold edges (power-law hubs): one workgroup per (row, head); its 16 lane groups each
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const float* __restric
         if (seg[3 * sgi + 1] != rowptr[row]) return;
         gid = row * H + blockIdx.x % H; first = grp; stride = 16;
     } else {
-        gid = (blockIdx.x * 256L + threadIdx.x) >> 4; first = 0; stride = 1;
+        gid = (blockIdx.x * 256L + threadIdx.x) >> 6; first = grp & 3; stride = 4;    // one wave per (row, head)
         if (gid >= N * H) return;
         const long row = gid / H;
         if (rowptr[row + 1] - rowptr[row] > hub_threshold) return;
@@ -207,8 +224,9 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const float* __restric
         gd += gp;
         if (l == 0) gpre[(long)perm[e] * H + h] = gp;
     }
-    if (!seg) {
-        if (l == 0) g_d[gid] = gd;
+    if (!seg) {                                           // row launch: sum over the wave's four groups
+        gd += __shfl_xor(gd, 16); gd += __shfl_xor(gd, 32);
+        if (threadIdx.x % 64 == 0) g_d[gid] = gd;
     } else {                                              // hub launch: fixed-order sum over the 16 groups
         if (l == 0) s_gd[grp] = gd;
         __syncthreads();
@@ -275,7 +293,7 @@ int gat_fwd(const float* xh, long ld, const float* a_s, const float* a_d, const 
     if (N == 0) return KAGNN_OK;
     if (C > 16 * kGatMaxK) return fail(KAGNN_ERR_UNSUPPORTED, "%s: more than 128 channels per head", "gat_fwd");
     const int thr = (hub_seg && num_hub_seg > 0) ? hub_threshold : 0x7fffffff;
-    gat_fwd_kernel<<<cdiv(N * H * 16, 256), 256, 0, st>>>(xh, ld, a_s, a_d, rowptr, col, N, H, C, bias, out, ldo, m, z, thr);
+    gat_fwd_kernel<<<cdiv(N * H * 64, 256), 256, 0, st>>>(xh, ld, a_s, a_d, rowptr, col, N, H, C, bias, out, ldo, m, z, thr);
     KAGNN_LAUNCH_CHECK();
     if (thr != 0x7fffffff) {
         gat_fwd_hub_kernel<<<(unsigned)(num_hub_seg * H), 256, 0, st>>>(xh, ld, a_s, a_d, rowptr, col, hub_seg, H, C, bias, out,
@@ -294,7 +312,7 @@ int gat_bwd(const float* xh, long ld, const float* gout, long ldg, const float* 
     if (C > 16 * kGatMaxK) return fail(KAGNN_ERR_UNSUPPORTED, "%s: more than 128 channels per head", "gat_bwd");
     const int grid = cdiv(N * H * 16, 256);
     const int thr = (hub_seg && num_hub_seg > 0) ? hub_threshold : 0x7fffffff;
-    gat_bwd_dst_kernel<<<grid, 256, 0, st>>>(xh, ld, gout, ldg, y, ldy, bias, a_s, a_d, m, z, rowptr, col, perm, N, H, C,
+    gat_bwd_dst_kernel<<<cdiv(N * H * 64, 256), 256, 0, st>>>(xh, ld, gout, ldg, y, ldy, bias, a_s, a_d, m, z, rowptr, col, perm, N, H, C,
                                               gpre, gpre_self, g_d, thr, nullptr);
     KAGNN_LAUNCH_CHECK();
     if (thr != 0x7fffffff) {
