@@ -57,7 +57,7 @@ def test_gin_aggregation_golden(golden):
         assert_close(ops.aggregate_sum(x, gi, self_scale=1.0), z[f"{g}.kan.agg"], what=f"{g}.agg")
 
 
-@pytest.mark.parametrize("f", [64, 128, 16, 4, 7, 33, 300])
+@pytest.mark.parametrize("f", [64, 128, 16, 4, 7, 33, 300, 8, 12, 32])
 def test_aggregate_vs_oracle_with_hub_fwd_bwd(f):
     """power-law graph whose top hub exceeds the hub threshold; forward and backward."""
     n, e = 20000, 200000
