@@ -278,6 +278,227 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const float* __restric
     if (l == 0) g_s[gid] = gs;
 }
 
+
+// ====================================================================== packed-heads fast path
+// C in {4, 8, 16, 32, 64}, H*C <= 128, 16-byte aligned rows: ONE 16-lane group walks a row's neighbour list for ALL
+// heads at once (the per-head kernels above issue H times as many small gathers).  Lane l owns the float4 column
+// groups c4 = 4l + 64k (k = 0, 1); head(l, k) = c4 / C, a head's channels sit in C/4 consecutive lanes, so the
+// per-head reductions of the backward are butterflies over those lanes.  Softmax state per (lane, k), replicated
+// inside a head.  Hub rows are left to the per-head hub kernels (same outputs).
+constexpr int kPk = 2;
+__device__ __forceinline__ float4 f4ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void f4fma(float4& a, float w, const float4& v) {
+    a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
+}
+__device__ __forceinline__ float f4dot(const float4& a, const float4& b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+// sum over the lanes of one head (L = C/4 consecutive lanes, a power of two <= 16)
+// DPP swaps inside the 16-lane row (no LDS round trips: this sits on the per-edge dependency chain of the backward)
+__device__ __forceinline__ float dpp_add(float v, int ctrl_sel) {
+    const unsigned u = __float_as_uint(v);
+    unsigned t;
+    switch (ctrl_sel) {
+        case 0: t = __builtin_amdgcn_update_dpp(0, u, 0xB1, 0xf, 0xf, true); break;    // quad_perm [1,0,3,2]
+        case 1: t = __builtin_amdgcn_update_dpp(0, u, 0x4E, 0xf, 0xf, true); break;    // quad_perm [2,3,0,1]
+        case 2: t = __builtin_amdgcn_update_dpp(0, u, 0x141, 0xf, 0xf, true); break;   // row_half_mirror
+        default: t = __builtin_amdgcn_update_dpp(0, u, 0x140, 0xf, 0xf, true); break;  // row_mirror
+    }
+    return v + __uint_as_float(t);
+}
+__device__ __forceinline__ float head_sum(float v, int L) {
+    if (L >= 2) v = dpp_add(v, 0);
+    if (L >= 4) v = dpp_add(v, 1);
+    if (L >= 8) v = dpp_add(v, 2);
+    if (L >= 16) v = dpp_add(v, 3);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gat_fwd_rows_kernel(const float* __restrict__ xh, long ld, const float* __restrict__ a_s,
+                                                           const float* __restrict__ a_d, const int* __restrict__ rowptr,
+                                                           const int* __restrict__ col, long N, int H, int C,
+                                                           const float* __restrict__ bias, float* __restrict__ out, long ldo,
+                                                           float* __restrict__ m_out, float* __restrict__ z_out, int hub_threshold) {
+    const long i = (blockIdx.x * 256L + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15, HC = H * C;
+    if (i >= N) return;
+    if (rowptr[i + 1] - rowptr[i] > hub_threshold) return;
+    int hd[kPk]; float ad[kPk], m[kPk], z[kPk]; float4 acc[kPk]; bool on[kPk];
+#pragma unroll
+    for (int k = 0; k < kPk; ++k) {
+        const int c4 = 4 * l + 64 * k;
+        on[k] = c4 < HC;
+        hd[k] = on[k] ? c4 / C : 0;
+        ad[k] = a_d[i * H + hd[k]];
+        m[k] = lrelu(a_s[i * H + hd[k]] + ad[k]); z[k] = 1.0f;              // the added self loop
+        acc[k] = on[k] ? f4ld(xh + i * ld + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int e_end = rowptr[i + 1];
+    for (int e0 = rowptr[i]; e0 < e_end; e0 += 4) {        // four edges per step: independent gathers issued together
+        int j[4]; float4 xj[4][kPk]; float asj[4][kPk];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            j[q] = col[min(e0 + q, e_end - 1)];
+#pragma unroll
+            for (int k = 0; k < kPk; ++k) {
+                xj[q][k] = f4ld(xh + (long)j[q] * ld + (on[k] ? 4 * l + 64 * k : 0));
+                asj[q][k] = a_s[(long)j[q] * H + hd[k]];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (e0 + q >= e_end) break;                     // group-uniform
+            if (j[q] == (int)i) continue;                   // existing self loops are removed
+#pragma unroll
+            for (int k = 0; k < kPk; ++k) {
+                if (!on[k]) continue;
+                const float v = lrelu(asj[q][k] + ad[k]);
+                const float mn = fmaxf(m[k], v);
+                const float sc = __expf(m[k] - mn), p = __expf(v - mn);
+                z[k] = fmaf(z[k], sc, p);
+                acc[k].x = fmaf(acc[k].x, sc, p * xj[q][k].x); acc[k].y = fmaf(acc[k].y, sc, p * xj[q][k].y);
+                acc[k].z = fmaf(acc[k].z, sc, p * xj[q][k].z); acc[k].w = fmaf(acc[k].w, sc, p * xj[q][k].w);
+                m[k] = mn;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPk; ++k) {
+        if (!on[k]) continue;
+        const int c4 = 4 * l + 64 * k;
+        const float inv = 1.0f / z[k];
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) b = f4ld(bias + c4);
+        *reinterpret_cast<float4*>(out + i * ldo + c4) = make_float4(fmaf(acc[k].x, inv, b.x), fmaf(acc[k].y, inv, b.y),
+                                                                      fmaf(acc[k].z, inv, b.z), fmaf(acc[k].w, inv, b.w));
+        if (c4 % C == 0) { m_out[i * H + hd[k]] = m[k]; z_out[i * H + hd[k]] = z[k]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void gat_bwd_dst_rows_kernel(const float* __restrict__ xh, long ld, const float* __restrict__ gout,
+                                                               long ldg, const float* __restrict__ y, long ldy,
+                                                               const float* __restrict__ bias, const float* __restrict__ a_s,
+                                                               const float* __restrict__ a_d, const float* __restrict__ m_in,
+                                                               const float* __restrict__ z_in, const int* __restrict__ rowptr,
+                                                               const int* __restrict__ col, const int* __restrict__ perm, long N,
+                                                               int H, int C, float* __restrict__ gpre, float* __restrict__ gpre_self,
+                                                               float* __restrict__ g_d, int hub_threshold) {
+    const long i = (blockIdx.x * 256L + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15, HC = H * C, L = C / 4;
+    if (i >= N) return;                                   // (whole 16-lane groups leave together)
+    if (rowptr[i + 1] - rowptr[i] > hub_threshold) return;
+    int hd[kPk]; float ad[kPk], m[kPk], inv[kPk], S[kPk], gd[kPk]; float4 g[kPk]; bool on[kPk], first[kPk];
+#pragma unroll
+    for (int k = 0; k < kPk; ++k) {
+        const int c4 = 4 * l + 64 * k;
+        on[k] = c4 < HC;
+        const int cc = on[k] ? c4 : 0;
+        hd[k] = cc / C;
+        first[k] = on[k] && (cc % C == 0);
+        const long gi = i * H + hd[k];
+        ad[k] = a_d[gi]; m[k] = m_in[gi]; inv[k] = 1.0f / z_in[gi];
+        g[k] = on[k] ? f4ld(gout + i * ldg + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 yo = f4ld(y + i * ldy + cc);
+        if (bias) { const float4 b = f4ld(bias + cc); yo.x -= b.x; yo.y -= b.y; yo.z -= b.z; yo.w -= b.w; }
+        S[k] = head_sum(on[k] ? f4dot(g[k], yo) : 0.0f, L);
+        const float gself = head_sum(on[k] ? f4dot(g[k], f4ld(xh + i * ld + cc)) : 0.0f, L);
+        const float pre = a_s[gi] + ad[k];
+        const float alpha = __expf(lrelu(pre) - m[k]) * inv[k];
+        gd[k] = alpha * (gself - S[k]) * (pre > 0.0f ? 1.0f : kSlope);
+        if (first[k]) gpre_self[gi] = gd[k];
+    }
+    // four edges per step: their gathers are independent, so issue them all before the (DPP) reductions
+    const int e_end = rowptr[i + 1];
+    for (int e0 = rowptr[i]; e0 < e_end; e0 += 4) {
+        int j[4]; long eo[4]; float4 xj[4][kPk]; float asj[4][kPk];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = min(e0 + q, e_end - 1);
+            j[q] = col[e];
+            eo[q] = (long)perm[e] * H;
+#pragma unroll
+            for (int k = 0; k < kPk; ++k) {
+                const int cc = on[k] ? 4 * l + 64 * k : 0;
+                xj[q][k] = f4ld(xh + (long)j[q] * ld + cc);
+                asj[q][k] = a_s[(long)j[q] * H + hd[k]];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (e0 + q >= e_end) break;                     // group-uniform
+#pragma unroll
+            for (int k = 0; k < kPk; ++k) {
+                if (j[q] == (int)i) { if (first[k]) gpre[eo[q] + hd[k]] = 0.0f; continue; }
+                const float ga = head_sum(on[k] ? f4dot(g[k], xj[q][k]) : 0.0f, L);
+                const float pre = asj[q][k] + ad[k];
+                const float alpha = __expf(lrelu(pre) - m[k]) * inv[k];
+                const float gp = alpha * (ga - S[k]) * (pre > 0.0f ? 1.0f : kSlope);
+                gd[k] += gp;
+                if (first[k]) gpre[eo[q] + hd[k]] = gp;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPk; ++k)
+        if (first[k]) g_d[i * H + hd[k]] = gd[k];
+}
+
+__global__ __launch_bounds__(256) void gat_bwd_src_rows_kernel(const float* __restrict__ gout, long ldg, const float* __restrict__ a_s,
+                                                               const float* __restrict__ a_d, const float* __restrict__ m_in,
+                                                               const float* __restrict__ z_in, const int* __restrict__ rowptr_t,
+                                                               const int* __restrict__ col_t, const int* __restrict__ perm_t,
+                                                               const float* __restrict__ gpre, const float* __restrict__ gpre_self,
+                                                               const float* __restrict__ g_d, const float* __restrict__ att_src,
+                                                               const float* __restrict__ att_dst, long N, int H, int C,
+                                                               float* __restrict__ gx, long ldgx, float* __restrict__ g_s) {
+    const long j = (blockIdx.x * 256L + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15, HC = H * C;
+    if (j >= N) return;
+    int hd[kPk]; float as[kPk], gs[kPk]; float4 acc[kPk]; bool on[kPk];
+#pragma unroll
+    for (int k = 0; k < kPk; ++k) {
+        const int c4 = 4 * l + 64 * k;
+        on[k] = c4 < HC;
+        const int cc = on[k] ? c4 : 0;
+        hd[k] = cc / C;
+        const long gj = j * H + hd[k];
+        as[k] = a_s[gj];
+        gs[k] = gpre_self[gj];
+        const float alpha = __expf(lrelu(as[k] + a_d[gj]) - m_in[gj]) / z_in[gj];
+        const float4 go = f4ld(gout + j * ldg + cc);
+        acc[k] = make_float4(alpha * go.x, alpha * go.y, alpha * go.z, alpha * go.w);
+    }
+    for (int e = rowptr_t[j]; e < rowptr_t[j + 1]; ++e) {
+        const int i = col_t[e];
+        if (i == (int)j) continue;
+        const long eo = (long)perm_t[e] * H;
+#pragma unroll
+        for (int k = 0; k < kPk; ++k) {
+            if (!on[k]) continue;
+            const long gi = (long)i * H + hd[k];
+            const float alpha = __expf(lrelu(as[k] + a_d[gi]) - m_in[gi]) / z_in[gi];
+            gs[k] += gpre[eo + hd[k]];
+            f4fma(acc[k], alpha, f4ld(gout + (long)i * ldg + 4 * l + 64 * k));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPk; ++k) {
+        if (!on[k]) continue;
+        const int c4 = 4 * l + 64 * k;
+        const float gd = g_d[j * H + hd[k]];
+        const float4 s4 = f4ld(att_src + c4), d4 = f4ld(att_dst + c4);       // att_* are [H, C] = flat H*C
+        *reinterpret_cast<float4*>(gx + j * ldgx + c4) =
+            make_float4(fmaf(gs[k], s4.x, fmaf(gd, d4.x, acc[k].x)), fmaf(gs[k], s4.y, fmaf(gd, d4.y, acc[k].y)),
+                        fmaf(gs[k], s4.z, fmaf(gd, d4.z, acc[k].z)), fmaf(gs[k], s4.w, fmaf(gd, d4.w, acc[k].w)));
+        if (c4 % C == 0) g_s[j * H + hd[k]] = gs[k];
+    }
+}
+
+static bool gat_packed_ok(int H, int C, long ld0, long ld1, long ld2, long ld3, const void* p0, const void* p1, const void* p2,
+                          const void* p3) {
+    const bool pow2 = C == 4 || C == 8 || C == 16 || C == 32 || C == 64;
+    auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return pow2 && H * C <= 64 * kPk && ((ld0 | ld1 | ld2 | ld3) & 3) == 0 && al(p0) && al(p1) && al(p2) && al(p3);
+}
+
 // ------------------------------------------------------------------ host side
 int gat_logits(const float* xh, long ld, long N, int H, int C, const float* att_src, const float* att_dst, float* a_s,
                float* a_d, hipStream_t st) {
@@ -293,7 +514,10 @@ int gat_fwd(const float* xh, long ld, const float* a_s, const float* a_d, const 
     if (N == 0) return KAGNN_OK;
     if (C > 16 * kGatMaxK) return fail(KAGNN_ERR_UNSUPPORTED, "%s: more than 128 channels per head", "gat_fwd");
     const int thr = (hub_seg && num_hub_seg > 0) ? hub_threshold : 0x7fffffff;
-    gat_fwd_kernel<<<cdiv(N * H * 64, 256), 256, 0, st>>>(xh, ld, a_s, a_d, rowptr, col, N, H, C, bias, out, ldo, m, z, thr);
+    if (gat_packed_ok(H, C, ld, ldo, 0, 0, xh, out, bias, nullptr))
+        gat_fwd_rows_kernel<<<cdiv(N * 16, 256), 256, 0, st>>>(xh, ld, a_s, a_d, rowptr, col, N, H, C, bias, out, ldo, m, z, thr);
+    else
+        gat_fwd_kernel<<<cdiv(N * H * 64, 256), 256, 0, st>>>(xh, ld, a_s, a_d, rowptr, col, N, H, C, bias, out, ldo, m, z, thr);
     KAGNN_LAUNCH_CHECK();
     if (thr != 0x7fffffff) {
         gat_fwd_hub_kernel<<<(unsigned)(num_hub_seg * H), 256, 0, st>>>(xh, ld, a_s, a_d, rowptr, col, hub_seg, H, C, bias, out,
@@ -312,16 +536,27 @@ int gat_bwd(const float* xh, long ld, const float* gout, long ldg, const float* 
     if (C > 16 * kGatMaxK) return fail(KAGNN_ERR_UNSUPPORTED, "%s: more than 128 channels per head", "gat_bwd");
     const int grid = cdiv(N * H * 16, 256);
     const int thr = (hub_seg && num_hub_seg > 0) ? hub_threshold : 0x7fffffff;
-    gat_bwd_dst_kernel<<<cdiv(N * H * 64, 256), 256, 0, st>>>(xh, ld, gout, ldg, y, ldy, bias, a_s, a_d, m, z, rowptr, col, perm, N, H, C,
-                                              gpre, gpre_self, g_d, thr, nullptr);
+    const bool packed = gat_packed_ok(H, C, ld, ldg, ldy, ldgx, xh, gout, y, gx) &&
+                        (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
+                        (reinterpret_cast<uintptr_t>(att_src) & 15) == 0 && (reinterpret_cast<uintptr_t>(att_dst) & 15) == 0;
+    if (packed)
+        gat_bwd_dst_rows_kernel<<<cdiv(N * 16, 256), 256, 0, st>>>(xh, ld, gout, ldg, y, ldy, bias, a_s, a_d, m, z, rowptr, col, perm,
+                                                                   N, H, C, gpre, gpre_self, g_d, thr);
+    else
+        gat_bwd_dst_kernel<<<cdiv(N * H * 64, 256), 256, 0, st>>>(xh, ld, gout, ldg, y, ldy, bias, a_s, a_d, m, z, rowptr, col, perm, N,
+                                                                  H, C, gpre, gpre_self, g_d, thr, nullptr);
     KAGNN_LAUNCH_CHECK();
     if (thr != 0x7fffffff) {
         gat_bwd_dst_kernel<<<(unsigned)(num_hub_seg * H), 256, 0, st>>>(xh, ld, gout, ldg, y, ldy, bias, a_s, a_d, m, z, rowptr, col,
                                                                        perm, N, H, C, gpre, gpre_self, g_d, thr, hub_seg);
         KAGNN_LAUNCH_CHECK();
     }
-    gat_bwd_src_kernel<<<grid, 256, 0, st>>>(gout, ldg, a_s, a_d, m, z, rowptr_t, col_t, perm_t, gpre, gpre_self, g_d,
-                                              att_src, att_dst, N, H, C, gx, ldgx, g_s);
+    if (packed)
+        gat_bwd_src_rows_kernel<<<cdiv(N * 16, 256), 256, 0, st>>>(gout, ldg, a_s, a_d, m, z, rowptr_t, col_t, perm_t, gpre, gpre_self,
+                                                                   g_d, att_src, att_dst, N, H, C, gx, ldgx, g_s);
+    else
+        gat_bwd_src_kernel<<<grid, 256, 0, st>>>(gout, ldg, a_s, a_d, m, z, rowptr_t, col_t, perm_t, gpre, gpre_self, g_d,
+                                                  att_src, att_dst, N, H, C, gx, ldgx, g_s);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
