@@ -116,22 +116,33 @@ __global__ __launch_bounds__(256) void gat_fwd_hub_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < kGatMaxK; ++k) { const int c = l + 16 * k; acc[k] = c < C ? xh[i * ld + (long)h * C + c] : 0.0f; }
     }
-    for (int e = rowptr[i] + grp; e < rowptr[i + 1]; e += 16) {
-        const int j = col[e];
-        if (j == (int)i) continue;
-        const float v = lrelu(a_s[(long)j * H + h] + ad);
-        if (v > m) {
-            const float sc = __expf(m - v);
-            z *= sc;
+    const int e_end = rowptr[i + 1];
+    for (int e0 = rowptr[i] + grp; e0 < e_end; e0 += 64) {   // four edges (stride 16) per step: gathers issued together
+        int j[4]; float v[4]; float xv[4][kGatMaxK];
 #pragma unroll
-            for (int k = 0; k < kGatMaxK; ++k) acc[k] *= sc;
-            m = v;
+        for (int q = 0; q < 4; ++q) {
+            j[q] = col[min(e0 + 16 * q, e_end - 1)];
+            v[q] = lrelu(a_s[(long)j[q] * H + h] + ad);
+            const float* xj = xh + (long)j[q] * ld + (long)h * C;
+#pragma unroll
+            for (int k = 0; k < kGatMaxK; ++k) { const int c = l + 16 * k; xv[q][k] = c < C ? xj[c] : 0.0f; }
         }
-        const float p = __expf(v - m);
-        z += p;
-        const float* xj = xh + (long)j * ld + (long)h * C;
 #pragma unroll
-        for (int k = 0; k < kGatMaxK; ++k) { const int c = l + 16 * k; if (c < C) acc[k] = fmaf(p, xj[c], acc[k]); }
+        for (int q = 0; q < 4; ++q) {
+            if (e0 + 16 * q >= e_end) break;                // group-uniform
+            if (j[q] == (int)i) continue;
+            if (v[q] > m) {
+                const float sc = __expf(m - v[q]);
+                z *= sc;
+#pragma unroll
+                for (int k = 0; k < kGatMaxK; ++k) acc[k] *= sc;
+                m = v[q];
+            }
+            const float p = __expf(v[q] - m);
+            z += p;
+#pragma unroll
+            for (int k = 0; k < kGatMaxK; ++k) acc[k] = fmaf(p, xv[q][k], acc[k]);
+        }
     }
     if (l == 0) { s_m[grp] = m; s_z[grp] = z; }
 #pragma unroll
@@ -209,20 +220,33 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const float* __restric
         gd = gp;
         if (l == 0) gpre_self[gid] = gp;
     }
-    for (int e = rowptr[i] + first; e < rowptr[i + 1]; e += stride) {
-        const int j = col[e];
-        if (j == (int)i) { if (l == 0) gpre[(long)perm[e] * H + h] = 0.0f; continue; }
-        const float* xj = xh + (long)j * ld + (long)h * C;
-        float ga = 0.0f;
+    const int e_end = rowptr[i + 1];
+    for (int e0 = rowptr[i] + first; e0 < e_end; e0 += 4 * stride) {   // four edges per step: gathers issued together
+        int j[4], eid[4]; float asj[4]; float xv[4][kGatMaxK];
 #pragma unroll
-        for (int k = 0; k < kGatMaxK; ++k) { const int c = l + 16 * k; if (c < C) ga = fmaf(g[k], xj[c], ga); }
+        for (int q = 0; q < 4; ++q) {
+            const int e = min(e0 + q * stride, e_end - 1);
+            j[q] = col[e]; eid[q] = perm[e];
+            asj[q] = a_s[(long)j[q] * H + h];
+            const float* xj = xh + (long)j[q] * ld + (long)h * C;
 #pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) ga += __shfl_xor(ga, o);
-        const float pre = a_s[(long)j * H + h] + ad;
-        const float alpha = __expf(lrelu(pre) - m) * inv;
-        const float gp = alpha * (ga - S) * (pre > 0.0f ? 1.0f : kSlope);
-        gd += gp;
-        if (l == 0) gpre[(long)perm[e] * H + h] = gp;
+            for (int k = 0; k < kGatMaxK; ++k) { const int c = l + 16 * k; xv[q][k] = c < C ? xj[c] : 0.0f; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (e0 + q * stride >= e_end) break;            // group-uniform
+            if (j[q] == (int)i) { if (l == 0) gpre[(long)eid[q] * H + h] = 0.0f; continue; }
+            float ga = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kGatMaxK; ++k) ga = fmaf(g[k], xv[q][k], ga);
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) ga += __shfl_xor(ga, o);
+            const float pre = asj[q] + ad;
+            const float alpha = __expf(lrelu(pre) - m) * inv;
+            const float gp = alpha * (ga - S) * (pre > 0.0f ? 1.0f : kSlope);
+            gd += gp;
+            if (l == 0) gpre[(long)eid[q] * H + h] = gp;
+        }
     }
     if (!seg) {                                           // row launch: sum over the wave's four groups
         gd += __shfl_xor(gd, 16); gd += __shfl_xor(gd, 32);
