@@ -36,6 +36,8 @@ extern "C" {
 /* precision of the dense contraction (the `mode` argument of the KAN entry points) */
 #define KAGNN_PREC_FP32 0       /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate    */
 #define KAGNN_PREC_SPLIT 1      /* fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate */
+#define KAGNN_PREC_FP32_GRID 2  /* exact fp32, and `knots` is the whole [in, G+2k+1] grid buffer: per-feature,
+                                 * non-uniform knot rows (what KANLinear.update_grid leaves behind)       */
 
 int kagnn_version(void);
 const char* kagnn_last_error(void);
@@ -121,8 +123,9 @@ int kagnn_segment_broadcast(const float* gout, int64_t ldg, float* gx, int64_t l
  * b_splines :79-112 + scaled_spline_weight :146-152 + two F.linear) and its autograd backward.
  * The [N, in, G+k] basis tensor is never materialised.
  *
- *  knots        : ONE row of the module's `grid` buffer, G+2k+1 fp32 values (uniform grid;
- *                 the host side verifies all rows equal and uniform, else refuses)
+ *  knots        : ONE row of the module's `grid` buffer, G+2k+1 fp32 values (uniform grid; the host
+ *                 side verifies all rows equal and uniform) -- or, with mode KAGNN_PREC_FP32_GRID,
+ *                 the whole buffer [in, G+2k+1] with increasing, possibly non-uniform rows
  *  base_weight  [out,in], spline_weight [out,in,G+k], spline_scaler [out,in] or NULL
  *
  * kagnn_kan_pack rearranges (base_weight | spline_weight*scaler) into the MFMA fragment order
@@ -171,6 +174,27 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
                                 const float* spline_scaler, float* g_base_weight,
                                 float* g_spline_weight, float* g_spline_scaler,
                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adaptive grids.  Replaces the device work of KANLinear.update_grid (ekan.py:164-211) and the dense
+ * b_splines (:79-112).  `grid*` are whole grid buffers [in, G+2k+1] with increasing rows.
+ * ------------------------------------------------------------------------------------------ */
+/* bases[N, in, G+k] = b_splines(x) on per-feature knot rows (ekan.py:79-112).                  */
+int kagnn_kan_bsplines(const float* x, int64_t ldx, int64_t num_rows, const float* grid,
+                       int32_t in_features, int32_t grid_size, int32_t spline_order, float* bases,
+                       void* stream);
+
+/* the coefficient refit of update_grid (ekan.py:169-177 + curve2coeff :114-144 + :211):
+ *   new_spline_weight[o,f,:] = argmin_s || bases_new(x[:,f]) s - bases_old(x[:,f]) (spline_weight*scaler)[o,f,:] ||
+ * through per-feature fp64 Gram matrices (one streaming pass over x; no [N,in,out] intermediate), solved by
+ * Cholesky; a basis with no sample in its support gets coefficient 0.  G+k <= 16.  Not in place.           */
+int kagnn_kan_grid_refit_workspace_bytes(int64_t num_rows, int32_t in_features, int32_t grid_size,
+                                         int32_t spline_order, size_t* bytes_host);
+int kagnn_kan_grid_refit(const float* x, int64_t ldx, int64_t num_rows, const float* grid_old,
+                         const float* grid_new, int32_t in_features, int32_t out_features,
+                         int32_t grid_size, int32_t spline_order, const float* spline_weight,
+                         const float* spline_scaler, float* new_spline_weight, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * FastKAN layer.  Replaces FastKANLayer.forward (node_classification_clean/fastkan.py:76-85:

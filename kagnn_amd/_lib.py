@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("KAGNN_LIB") or os.path.join(_HERE, "lib", "libkagnn_h
 
 PREC_FP32 = 0
 PREC_SPLIT = 1
+PREC_FP32_GRID = 2      # exact fp32 on per-feature, non-uniform knot rows (after update_grid)
 
 _P = c_void_p
 _SIGNATURES = {
@@ -48,6 +49,10 @@ _SIGNATURES = {
     "kagnn_kan_linear_bwd_weight": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, c_int32, c_int32,
                                               c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P,
                                               c_size_t, _P]),
+    "kagnn_kan_bsplines": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "kagnn_kan_grid_refit_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+    "kagnn_kan_grid_refit": (c_int32, [_P, c_int64, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P,
+                                       _P, c_size_t, _P]),
     "kagnn_fastkan_fwd_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "kagnn_fastkan_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, c_int32, _P, c_float, _P, _P,
                                     c_float, _P, _P, _P, _P, c_int64, _P, c_int32, _P, c_size_t, _P]),

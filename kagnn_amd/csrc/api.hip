@@ -17,10 +17,10 @@ int csr_build(const int64_t*, const int64_t*, long, long, int*, int*, int*, int,
 size_t kan_f32_pack_fwd_bytes(int in, int out, int C);
 size_t kan_f32_pack_dx_bytes(int in, int out, int C);
 int kan_f32_pack(const float*, const float*, const float*, int, int, int, float*, float*, hipStream_t);
-int kan_f32_fwd(const float*, long, long, const float*, int, int, int, int, const float*, float*, long, hipStream_t);
-int kan_f32_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, float*, long, hipStream_t);
+int kan_f32_fwd(const float*, long, long, const float*, int, int, int, int, const float*, float*, long, bool, hipStream_t);
+int kan_f32_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, float*, long, bool, hipStream_t);
 size_t kan_f32_dw_ws_bytes(long N, int in, int out, int C);
-int kan_f32_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t);
+int kan_f32_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, bool, hipStream_t);
 
 size_t kan_split_pack_fwd_bytes(int in, int out, int C);
 size_t kan_split_pack_dx_bytes(int in, int out, int C);
@@ -49,6 +49,9 @@ int fastkan_bwd(const float*, long, const float*, long, long, int, int, int, con
 int gat_logits(const float*, long, long, int, int, const float*, const float*, float*, float*, hipStream_t);
 int gat_fwd(const float*, long, const float*, const float*, const int*, const int*, long, int, int, const float*, float*, long, float*, float*, const int*, long, int, hipStream_t);
 int gat_bwd(const float*, long, const float*, long, const float*, long, const float*, const float*, const float*, const float*, const float*, const int*, const int*, const int*, const int*, const int*, const int*, const float*, const float*, long, int, int, float*, float*, float*, float*, float*, long, const int*, long, int, hipStream_t);
+int kan_bsplines(const float*, long, long, const float*, int, int, int, float*, hipStream_t);
+size_t kan_grid_refit_ws_bytes(long N, int in);
+int kan_grid_refit(const float*, long, long, const float*, const float*, int, int, int, int, const float*, const float*, float*, void*, size_t, hipStream_t);
 size_t bn_ws_bytes(long N, int F);
 int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, float*, long, float*, float*, void*, size_t, hipStream_t);
 int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float*, long, float*, float*, void*, size_t, hipStream_t);
@@ -60,7 +63,7 @@ static int check_kan_dims(const char* fn, int in, int out, int G, int K, int mod
     if (in < 1 || out < 1) return fail(KAGNN_ERR_ARG, "%s: in_features/out_features must be >= 1", fn);
     if (K < 1 || K > kMaxOrder) return fail(KAGNN_ERR_UNSUPPORTED, "%s: spline_order must be 1..4", fn);
     if (G < 1 || G + 2 * K + 1 > kMaxKnots) return fail(KAGNN_ERR_UNSUPPORTED, "%s: grid_size out of range", fn);
-    if (mode != KAGNN_PREC_FP32 && mode != KAGNN_PREC_SPLIT) return fail(KAGNN_ERR_ARG, "%s: unknown precision mode", fn);
+    if (mode != KAGNN_PREC_FP32 && mode != KAGNN_PREC_SPLIT && mode != KAGNN_PREC_FP32_GRID) return fail(KAGNN_ERR_ARG, "%s: unknown precision mode", fn);
     return KAGNN_OK;
 }
 // the split path covers the hot shapes; everything else runs the exact-fp32 kernels (still HIP)
@@ -199,7 +202,7 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* kn
             return kan_sparse_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
         return kan_split_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
     }
-    return kan_f32_fwd(x, ldx, N, knots, in, out, G, K, (const float*)pack_fwd, y, ldy, as_stream(stream));
+    return kan_f32_fwd(x, ldx, N, knots, in, out, G, K, (const float*)pack_fwd, y, ldy, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
 }
 
 int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N,
@@ -214,7 +217,7 @@ int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int
         if (!(fits32(N, ldx) && fits32(N, ldgy) && fits32(N, ldgx))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
         return kan_split_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack_dx, gx, ldgx, as_stream(stream));
     }
-    return kan_f32_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, (const float*)pack_dx, gx, ldgx, as_stream(stream));
+    return kan_f32_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, (const float*)pack_dx, gx, ldgx, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
 }
 
 int kagnn_kan_bwd_weight_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K,
@@ -241,7 +244,7 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
         if (!(fits32(N, ldx) && fits32(N, ldgy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
         return kan_split_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream));
     }
-    return kan_f32_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream));
+    return kan_f32_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
 }
 
 // ---------------------------------------------------------------- FastKAN
@@ -250,6 +253,35 @@ static int check_fk(const char* fn, int in, int out, int ng, int mode) {
     if (ng < 1 || ng > kMaxKnots) return fail(KAGNN_ERR_UNSUPPORTED, "%s: num_grids out of range", fn);
     if (mode != KAGNN_PREC_FP32 && mode != KAGNN_PREC_SPLIT) return fail(KAGNN_ERR_ARG, "%s: unknown precision mode", fn);
     return KAGNN_OK;
+}
+
+// ---------------------------------------------------------------- adaptive grids (update_grid)
+int kagnn_kan_bsplines(const float* x, int64_t ldx, int64_t N, const float* grid, int32_t in, int32_t G,
+                       int32_t K, float* bases, void* stream) {
+    int rc = check_kan_dims(__func__, in, 1, G, K, KAGNN_PREC_FP32_GRID);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 0 && ldx >= in, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (x && grid && bases), "null array");
+    return kan_bsplines(x, ldx, N, grid, in, G, K, bases, as_stream(stream));
+}
+
+int kagnn_kan_grid_refit_workspace_bytes(int64_t N, int32_t in, int32_t G, int32_t K, size_t* bytes) {
+    int rc = check_kan_dims(__func__, in, 1, G, K, KAGNN_PREC_FP32_GRID);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(bytes != nullptr && N >= 1, "null output or no rows");
+    *bytes = kan_grid_refit_ws_bytes(N, in);
+    return KAGNN_OK;
+}
+
+int kagnn_kan_grid_refit(const float* x, int64_t ldx, int64_t N, const float* grid_old, const float* grid_new,
+                         int32_t in, int32_t out, int32_t G, int32_t K, const float* sw, const float* sc,
+                         float* new_sw, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_kan_dims(__func__, in, out, G, K, KAGNN_PREC_FP32_GRID);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 1 && ldx >= in, "bad shape");
+    KAGNN_CHECK_ARG(x && grid_old && grid_new && sw && new_sw && ws, "null array");
+    KAGNN_CHECK_ARG(sw != new_sw, "the refit is not in place");
+    return kan_grid_refit(x, ldx, N, grid_old, grid_new, in, out, G, K, sw, sc, new_sw, ws, ws_bytes, as_stream(stream));
 }
 
 int kagnn_fastkan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t ng, int32_t mode, size_t* bytes) {

@@ -128,6 +128,65 @@ __device__ __forceinline__ int bspline_local(float x, const float* __restrict__ 
     return m;
 }
 
+// ---------------------------------------------------------------- local B-spline on a per-feature, non-uniform
+// knot row (the grids KANLinear.update_grid writes, ekan.py:164-211).  Same contract as bspline_local: the span
+// m holding x (half-open test of ekan.py:95, knots assumed increasing) and the K+1 bases j = m-K .. m that can
+// be non-zero there, by the Cox-de Boor recursion of ekan.py:96-105 with the real knot differences:
+//   B_{j,p} = (x - t_j) / (t_{j+p} - t_j) B_{j,p-1} + (t_{j+p+1} - x) / (t_{j+p+1} - t_{j+1}) B_{j+1,p-1} .
+// w[q] = t[m-K+q] (indices clamped: they only feed bases j < 0 or j >= G+K, which pick_basis never selects).
+template <int K, bool DERIV>
+__device__ __forceinline__ int bspline_generic(float x, const float* __restrict__ t /* this feature's row */,
+                                               int nknots, float (&N)[K + 1], float (&dN)[K + 1]) {
+    int cnt = 0;
+    for (int j = 0; j < nknots; ++j) cnt += (x >= t[j]) ? 1 : 0;
+    const bool inside = cnt >= 1 && cnt < nknots;          // t[0] <= x < t[last]
+    const int m = min(max(cnt - 1, 0), nknots - 2);
+    float w[2 * K + 2];
+#pragma unroll
+    for (int q = 0; q < 2 * K + 2; ++q) w[q] = t[min(max(m - K + q, 0), nknots - 1)];
+    float n[K + 1], prev[K + 1];
+    n[0] = 1.0f;
+#pragma unroll
+    for (int r = 1; r <= K; ++r) n[r] = 0.0f;
+#pragma unroll
+    for (int p = 1; p <= K; ++p) {
+#pragma unroll
+        for (int r = 0; r <= K; ++r) prev[r] = n[r];
+#pragma unroll
+        for (int r = 0; r <= p; ++r) {
+            const int q0 = K - p + r;                       // w[q0] = t_j for j = m-p+r
+            const float a = (r >= 1) ? (x - w[q0]) / (w[q0 + p] - w[q0]) * prev[r - 1] : 0.0f;
+            const float b = (r <= p - 1) ? (w[q0 + p + 1] - x) / (w[q0 + p + 1] - w[q0 + 1]) * prev[r] : 0.0f;
+            n[r] = a + b;
+        }
+        if (DERIV && p == K) {
+#pragma unroll
+            for (int r = 0; r <= K; ++r) {
+                const float lo = (r >= 1) ? prev[r - 1] / (w[r + K] - w[r]) : 0.0f;
+                const float hi = (r <= K - 1) ? prev[r] / (w[r + K + 1] - w[r + 1]) : 0.0f;
+                dN[r] = (float)K * (lo - hi);
+            }
+        }
+    }
+    const bool finite = fabsf(x) <= 3.4028234e38f;
+    const float nanv = __builtin_nanf("");
+#pragma unroll
+    for (int r = 0; r <= K; ++r) {
+        N[r] = finite ? (inside ? n[r] : 0.0f) : nanv;
+        if (DERIV) dN[r] = finite ? (inside ? dN[r] : 0.0f) : nanv;
+    }
+    return m;
+}
+
+// PF: per-feature knot rows in global memory (knots_g is [in][nknots]); else the one shared uniform row in LDS
+template <int K, bool DERIV, bool PF>
+__device__ __forceinline__ int eval_basis(float x, const float* s_knots, const SplineGeom& g,
+                                          const float* __restrict__ knots_g, int f, float (&N)[K + 1],
+                                          float (&dN)[K + 1]) {
+    if constexpr (PF) return bspline_generic<K, DERIV>(x, knots_g + (long)f * g.nknots, g.nknots, N, dN);
+    else return bspline_local<K, DERIV>(x, s_knots, g, N, dN);
+}
+
 // value of basis index c given the local set: N[c - (m-K)] if 0 <= c-(m-K) <= K else 0
 template <int K>
 __device__ __forceinline__ float pick_basis(const float (&N)[K + 1], int m, int c) {

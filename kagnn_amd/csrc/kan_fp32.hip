@@ -50,7 +50,7 @@ __global__ void kan_pack_f32_kernel(const float* __restrict__ bw, const float* _
 }
 
 // ------------------------------------------------------------------ forward
-template <int K, int OT>
+template <int K, int OT, bool PF>
 __global__ __launch_bounds__(256) void kan_fwd_f32_kernel(
     const float* __restrict__ x, long ldx, long N, int in, int C, const float* __restrict__ knots_g,
     int nknots, const float* __restrict__ pack, int ot0, int OT_total,
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void kan_fwd_f32_kernel(
         const bool fv = rv && f < in;
         const float xv = xr[min(f, in - 1)];          // unconditional clamped load (masked below): no per-load branch
         float Nv[K + 1], dummy[K + 1];
-        int m = bspline_local<K, false>(xv, s_knots, geom, Nv, dummy);
+        int m = eval_basis<K, false, PF>(xv, s_knots, geom, knots_g, min(f, in - 1), Nv, dummy);
         float sl = siluf(xv);
         if (!fv) {
             sl = 0.0f;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void kan_fwd_f32_kernel(
 // owns all c for that (n,f), so the contraction over c is register-local.
 constexpr int kDxGroup = 9;   // accumulators held at once (C+1 <= 9 -> single pass)
 
-template <int K>
+template <int K, bool PF>
 __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
                 const bool ok = rr < N && f < in;
                 const float xv = x[min(rr, N - 1) * ldx + min(f, in - 1)];       // clamped; !ok lanes never store
                 float Nv[K + 1], dN[K + 1];
-                const int m = bspline_local<K, true>(xv, s_knots, geom, Nv, dN);
+                const int m = eval_basis<K, true, PF>(xv, s_knots, geom, knots_g, min(f, in - 1), Nv, dN);
                 const float sg = silu_gradf(xv);
                 float s = 0.0f;
 #pragma unroll
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
 // range and writes one partial slab; kan_dw_reduce sums the slabs in a fixed order.
 constexpr int kDwGroup = 9;
 
-template <int K>
+template <int K, bool PF>
 __global__ __launch_bounds__(256) void kan_dw_f32_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots, int OT, long rows_per_wave,
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void kan_dw_f32_kernel(
             const float xv = x[nc * ldx + min(f, in - 1)];
             const float b = gy[nc * ldgy + min(o, out - 1)];
             float Nv[K + 1], dummy[K + 1];
-            const int m = bspline_local<K, false>(xv, s_knots, geom, Nv, dummy);
+            const int m = eval_basis<K, false, PF>(xv, s_knots, geom, knots_g, min(f, in - 1), Nv, dummy);
             const float sl = siluf(xv);
             const bool live = nv && fv;
 #pragma unroll
@@ -322,14 +322,14 @@ int kan_f32_pack(const float* bw, const float* sw, const float* sc, int in, int 
     return KAGNN_OK;
 }
 
-template <int K>
+template <int K, bool PF>
 static int fwd_dispatch(const float* x, long ldx, long N, int in, int out, int C, const float* knots,
                         int g, const float* pack, float* y, long ldy, hipStream_t st) {
     const int OTt = cdiv(out, 32);
     dim3 grid(cdiv(N, 128));
     for (int ot0 = 0; ot0 < OTt; ot0 += 4) {
         const int n = min(4, OTt - ot0);
-#define L(OTN) kan_fwd_f32_kernel<K, OTN><<<grid, 256, 0, st>>>(x, ldx, N, in, C, knots, g, pack, ot0, OTt, y, ldy, out)
+#define L(OTN) kan_fwd_f32_kernel<K, OTN, PF><<<grid, 256, 0, st>>>(x, ldx, N, in, C, knots, g, pack, ot0, OTt, y, ldy, out)
         if (n == 1) L(1); else if (n == 2) L(2); else if (n == 3) L(3); else L(4);
 #undef L
         KAGNN_LAUNCH_CHECK();
@@ -338,21 +338,27 @@ static int fwd_dispatch(const float* x, long ldx, long N, int in, int out, int C
 }
 
 int kan_f32_fwd(const float* x, long ldx, long N, const float* knots, int in,
-                int out, int G, int K, const float* pack, float* y, long ldy, hipStream_t st) {
+                int out, int G, int K, const float* pack, float* y, long ldy, bool pf, hipStream_t st) {
     const int g = G + 2 * K + 1;   // number of knots
     const int C = G + K;
-    switch (K) {
-        case 1: return fwd_dispatch<1>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
-        case 2: return fwd_dispatch<2>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
-        case 3: return fwd_dispatch<3>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
-        case 4: return fwd_dispatch<4>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
+    if (pf) switch (K) {
+        case 1: return fwd_dispatch<1, true>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
+        case 2: return fwd_dispatch<2, true>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
+        case 3: return fwd_dispatch<3, true>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
+        case 4: return fwd_dispatch<4, true>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
+    }
+    else switch (K) {
+        case 1: return fwd_dispatch<1, false>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
+        case 2: return fwd_dispatch<2, false>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
+        case 3: return fwd_dispatch<3, false>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
+        case 4: return fwd_dispatch<4, false>(x, ldx, N, in, out, C, knots, g, pack, y, ldy, st);
     }
     return fail(KAGNN_ERR_UNSUPPORTED, "%s: spline_order must be 1..4", "kan_f32_fwd");
 }
 
 int kan_f32_dx(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots,
                int in, int out, int G, int K, const float* pack, float* gx,
-               long ldgx, hipStream_t st) {
+               long ldgx, bool pf, hipStream_t st) {
     const int g = G + 2 * K + 1;   // number of knots
     const int C = G + K, OTt = cdiv(out, 32);
     int W = 4;                                        // waves per workgroup: as many as the gy tiles leave LDS for
@@ -360,13 +366,14 @@ int kan_f32_dx(const float* x, long ldx, const float* gy, long ldgy, long N, con
     const size_t lds = (kMaxKnots + (size_t)W * 32 * (32 * OTt + 1)) * sizeof(float);
     if (lds > 160 * 1024) return fail(KAGNN_ERR_UNSUPPORTED, "%s: out_features too large for the fp32 dx kernel", "kan_f32_dx");
     dim3 grid(cdiv(N, 32 * W));
-#define L(KK)                                                                                     \
+#define L1(KK, PF)                                                                                \
     {                                                                                             \
         if (lds > 64 * 1024)                                                                      \
-            KAGNN_HIP(hipFuncSetAttribute((const void*)kan_dx_f32_kernel<KK>,                     \
+            KAGNN_HIP(hipFuncSetAttribute((const void*)kan_dx_f32_kernel<KK, PF>,                 \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kan_dx_f32_kernel<KK><<<grid, 64 * W, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, g, pack, OTt, gx, ldgx); \
+        kan_dx_f32_kernel<KK, PF><<<grid, 64 * W, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, g, pack, OTt, gx, ldgx); \
     }
+#define L(KK) { if (pf) L1(KK, true) else L1(KK, false) }
     switch (K) {
         case 1: L(1) break;
         case 2: L(2) break;
@@ -375,6 +382,7 @@ int kan_f32_dx(const float* x, long ldx, const float* gy, long ldgy, long N, con
         default: return fail(KAGNN_ERR_UNSUPPORTED, "%s: spline_order must be 1..4", "kan_f32_dx");
     }
 #undef L
+#undef L1
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -399,7 +407,7 @@ size_t kan_f32_dw_ws_bytes(long N, int in, int out, int C) {
 
 int kan_f32_dw(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots,
                int in, int out, int G, int K, const float* sw, const float* sc,
-               float* g_bw, float* g_sw, float* g_sc, float* ws, size_t ws_bytes, hipStream_t st) {
+               float* g_bw, float* g_sw, float* g_sc, float* ws, size_t ws_bytes, bool pf, hipStream_t st) {
     const int g = G + 2 * K + 1;   // number of knots
     const int C = G + K, FT = cdiv(in, 32), OT = cdiv(out, 32);
     if (ws_bytes < kan_f32_dw_ws_bytes(N, in, out, C)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "kan_f32_dw");
@@ -410,7 +418,8 @@ int kan_f32_dw(const float* x, long ldx, const float* gy, long ldgy, long N, con
     float* gcat = ws;
     float* slab = ws + per;
     dim3 grid(nb, FT * OT);
-#define L(KK) kan_dw_f32_kernel<KK><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, g, OT, rpw, slab)
+#define L(KK) if (pf) kan_dw_f32_kernel<KK, true><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, g, OT, rpw, slab); \
+              else kan_dw_f32_kernel<KK, false><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, g, OT, rpw, slab)
     switch (K) {
         case 1: L(1); break;
         case 2: L(2); break;

@@ -110,11 +110,12 @@ class KANLinear(nn.Module):
             steps = row[1:] - row[:-1]
             h = float(steps.mean())
             same = bool((g == row).all()) and bool(((steps - h).abs() <= 1e-4 * abs(h)).all()) and h > 0
-            if not same:
-                raise NotImplementedError(
-                    "KANLinear.grid is not one uniform knot vector shared by all features; adaptive "
-                    "grids (update_grid) are outside the KAGNN hot path and not implemented")
-            self._knots_row = row.contiguous().clone()
+            if same:
+                self._knots_row = row.contiguous().clone()
+            else:        # adaptive grid (update_grid was called): the whole buffer, per-feature knot rows
+                if not bool((g[:, 1:] > g[:, :-1]).all()):
+                    raise ValueError("KANLinear.grid rows must be strictly increasing")
+                self._knots_row = g.detach().to(torch.float32).contiguous().clone()
             self._knots_key = key
         return self._knots_row
 
@@ -125,9 +126,31 @@ class KANLinear(nn.Module):
                               self.grid_size, self.spline_order, self.precision)
 
     # ------------------------------------------------------------------ not on the KAGNN path
+    def b_splines(self, x: torch.Tensor) -> torch.Tensor:
+        """Dense bases ``[N, in, G+k]`` on this layer's grid (``ekan.py:79-112``); the forward never builds it."""
+        assert x.dim() == 2 and x.size(1) == self.in_features
+        return ops.kan_bsplines(x, self.grid, self.grid_size, self.spline_order)
+
+    @torch.no_grad()
     def update_grid(self, x: torch.Tensor, margin=0.01):
-        raise NotImplementedError("update_grid is never called by KAGNN (SURVEY.md 2, row 1); "
-                                  "adaptive grids are out of scope of this implementation")
+        """Move the knots to the batch's per-feature quantiles (blended with a uniform grid by ``grid_eps``) and
+        refit the coefficients so the layer's curves are kept, ``ekan.py:164-211``.  The knot arithmetic is a
+        handful of [G+1, in] torch ops in the reference's order; the refit is
+        ``kagnn_kan_grid_refit`` -- no [N, in, out] intermediate.  The layer then runs on per-feature knots."""
+        assert x.dim() == 2 and x.size(1) == self.in_features
+        n, g, k, dev = x.size(0), self.grid_size, self.spline_order, x.device
+        ranked = torch.sort(x, dim=0).values
+        quantiles = ranked[torch.linspace(0, n - 1, g + 1, dtype=torch.int64, device=dev)]       # [G+1, in]
+        step = (ranked[-1] - ranked[0] + 2 * margin) / g
+        even = torch.arange(g + 1, dtype=torch.float32, device=dev).unsqueeze(1) * step + ranked[0] - margin
+        inner = self.grid_eps * even + (1 - self.grid_eps) * quantiles
+        below = inner[:1] - step * torch.arange(k, 0, -1, device=dev).unsqueeze(1)
+        above = inner[-1:] + step * torch.arange(1, k + 1, device=dev).unsqueeze(1)
+        new_grid = torch.cat([below, inner, above], dim=0).T.contiguous()
+        scaler = self.spline_scaler if self.enable_standalone_scale_spline else None
+        fitted = ops.kan_grid_refit(x, self.grid, new_grid, self.spline_weight, scaler, g, k)
+        self.grid.copy_(new_grid)
+        self.spline_weight.data.copy_(fitted)
 
     def regularization_loss(self, regularize_activation=1.0, regularize_entropy=1.0):
         mag = self.spline_weight.abs().mean(-1)
@@ -152,9 +175,9 @@ class KAN(nn.Module):
             for a, b in zip(layers_hidden[:-1], layers_hidden[1:]))
 
     def forward(self, x: torch.Tensor, update_grid=False) -> torch.Tensor:
-        if update_grid:
-            raise NotImplementedError("update_grid=True is not used by KAGNN and not implemented")
         for layer in self.layers:
+            if update_grid:
+                layer.update_grid(x)
             x = layer(x)
         return x
 

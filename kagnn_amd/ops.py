@@ -18,7 +18,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from ._lib import PREC_FP32, PREC_SPLIT
+from ._lib import PREC_FP32, PREC_FP32_GRID, PREC_SPLIT
 
 HUB_THRESHOLD = 512
 
@@ -422,13 +422,53 @@ class _KANLinearFn(Function):
 def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
                mode: Optional[int] = None) -> torch.Tensor:
     """y = silu(x) @ base_weight.T + bases(x) @ (spline_weight*scaler).T  (ekan.py:154-162).
-    ``knots`` is ONE row of the layer's grid buffer (uniform), fp32 [G+2k+1] on the device."""
+    ``knots`` is ONE row of the layer's grid buffer (uniform), fp32 [G+2k+1] on the device -- or the whole
+    buffer [in, G+2k+1] when its rows differ / are non-uniform (after ``update_grid``): that runs the exact-fp32
+    kernels on per-feature knots (``KAGNN_PREC_FP32_GRID``)."""
+    if knots.dim() == 2:
+        if knots.size(0) != x.size(-1):
+            raise AssertionError("grid must be [in_features, G+2k+1]")
+        mode = PREC_FP32_GRID
     if mode is None:
         mode = default_precision()
     if mode == PREC_SPLIT and (x.size(0) + (1 << 18)) * max(x.stride(0), base_weight.size(0), 1) * 4 >= 0xF0000000:
         mode = PREC_FP32      # the split kernels use 32-bit buffer offsets; >= 3.75 GiB activations go fp32
     return _KANLinearFn.apply(x, base_weight, spline_weight, spline_scaler, knots, int(grid_size),
                               int(spline_order), int(mode))
+
+
+def kan_bsplines(x, grid, grid_size: int, spline_order: int) -> torch.Tensor:
+    """Dense B-spline bases ``[N, in, G+k]`` of ``x[N, in]`` on the per-feature knot rows ``grid[in, G+2k+1]``
+    (``KANLinear.b_splines``, ekan.py:79-112).  Not differentiable (the layer never stores this tensor)."""
+    _need_cuda(x, grid)
+    x = _rows(x.detach())
+    g = grid.detach().to(torch.float32).contiguous()
+    n, fin = x.shape
+    if g.shape != (fin, grid_size + 2 * spline_order + 1):
+        raise AssertionError("grid must be [in_features, G+2k+1]")
+    out = torch.empty((n, fin, grid_size + spline_order), dtype=torch.float32, device=x.device)
+    _call("kagnn_kan_bsplines", _ptr(x), _ld(x), n, _ptr(g), fin, int(grid_size), int(spline_order), _ptr(out),
+          _stream())
+    return out
+
+
+def kan_grid_refit(x, grid_old, grid_new, spline_weight, spline_scaler, grid_size: int,
+                   spline_order: int) -> torch.Tensor:
+    """Coefficients on ``grid_new`` that reproduce, in the least-squares sense over the rows of ``x``, the
+    per-feature curves the layer had on ``grid_old`` (the refit inside ``update_grid``, ekan.py:169-177,211)."""
+    _need_cuda(x, grid_old, grid_new, spline_weight, spline_scaler)
+    x = _rows(x.detach())
+    n, fin = x.shape
+    fout = spline_weight.size(0)
+    go = grid_old.detach().to(torch.float32).contiguous()
+    gn = grid_new.detach().to(torch.float32).contiguous()
+    sw = spline_weight.detach().contiguous()
+    sc = None if spline_scaler is None else spline_scaler.detach().contiguous()
+    ws = _ws(_sizes("kagnn_kan_grid_refit_workspace_bytes", n, fin, int(grid_size), int(spline_order)), x.device)
+    out = torch.empty_like(sw)
+    _call("kagnn_kan_grid_refit", _ptr(x), _ld(x), n, _ptr(go), _ptr(gn), fin, fout, int(grid_size),
+          int(spline_order), _ptr(sw), _ptr(sc), _ptr(out), _ptr(ws), ws.numel(), _stream())
+    return out
 
 
 # ======================================================================== FastKAN layer

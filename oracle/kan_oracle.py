@@ -104,6 +104,36 @@ def curve2coeff(xs: Tensor, ys: Tensor, knots: Tensor, spline_order: int) -> Ten
     return sol.permute(2, 0, 1).contiguous()
 
 
+def update_grid(x: Tensor, layer: dict, grid_size: int, spline_order: int, grid_eps: float = 0.02,
+                margin: float = 0.01, solve_dtype=None) -> Tuple[Tensor, Tensor]:
+    """``KANLinear.update_grid``, ``ekan.py:164-211``: returns ``(new_grid [in, G+2k+1], new_spline_weight
+    [out, in, C])`` for a layer dict with the state_dict keys.
+
+    The per-feature curves the layer currently draws, ``bases_old(x) @ (spline_weight*scaler)`` laid out
+    ``[N, in, out]`` (``:169-177``), are re-fitted on the new knots by ``curve2coeff`` (``:211``).  New knots:
+    ``G+1`` order statistics of each column at ``linspace(0, N-1, G+1)`` (int64, ``:180-186``), blended with an
+    even grid over ``[min - margin, max + margin]`` by ``grid_eps`` (``:188-198``), extended by ``k`` even steps
+    either side (``:199-209``).  ``solve_dtype=torch.float64`` runs the fit in double (tighter checker for the
+    device's fp64 normal-equation solve); ``None`` keeps the reference's fp32 ``lstsq``."""
+    n = x.size(0)
+    w = layer["spline_weight"]
+    if layer.get("spline_scaler") is not None:
+        w = w * layer["spline_scaler"].unsqueeze(-1)
+    curves = torch.bmm(bspline_bases(x, layer["grid"], spline_order).permute(1, 0, 2),
+                       w.permute(1, 2, 0)).permute(1, 0, 2)                       # [N, in, out]
+    xs = torch.sort(x, dim=0)[0]
+    adaptive = xs[torch.linspace(0, n - 1, grid_size + 1, dtype=torch.int64)]
+    step = (xs[-1] - xs[0] + 2 * margin) / grid_size
+    even = torch.arange(grid_size + 1, dtype=torch.float32).unsqueeze(1) * step + xs[0] - margin
+    inner = grid_eps * even + (1 - grid_eps) * adaptive
+    grid = torch.cat([inner[:1] - step * torch.arange(spline_order, 0, -1).unsqueeze(1), inner,
+                      inner[-1:] + step * torch.arange(1, spline_order + 1).unsqueeze(1)], dim=0).T.contiguous()
+    if solve_dtype is None:
+        return grid, curve2coeff(x, curves, grid, spline_order)
+    fit = curve2coeff(x.to(solve_dtype), curves.to(solve_dtype), grid.to(solve_dtype), spline_order)
+    return grid, fit.to(torch.float32)
+
+
 # --------------------------------------------------------------------------------------
 # FastKAN  (reference: node_classification_clean/fastkan.py)
 # --------------------------------------------------------------------------------------

@@ -349,8 +349,45 @@ def g9():
     save("g9_harness", **out)
 
 
+# ---------------------------------------------------------------- G10: update_grid (adaptive knots + refit)
+def g10():
+    out = {}
+    shapes = [(8, 6, 5, 3), (16, 4, 4, 3), (5, 3, 8, 2), (12, 7, 3, 1), (6, 5, 6, 4)]
+    for i, (fi, fo, G, k) in enumerate(shapes):
+        torch.manual_seed(1000 + i)
+        layer = ref_ekan.KANLinear(fi, fo, grid_size=G, spline_order=k)
+        gen = torch.Generator().manual_seed(1100 + i)
+        tag = f"{fi}_{fo}_{G}_{k}"
+        out[f"shape_{i}"] = np.array([fi, fo, G, k])
+        for kname, v in layer.state_dict().items():
+            out[f"{tag}.before.{kname}"] = npy(v).copy()
+        # two successive updates: the second starts from per-feature, non-uniform knots
+        for step, scale in enumerate((0.7, 1.3)):
+            xb = torch.randn(400, fi, generator=gen) * scale + 0.1 * step
+            layer.update_grid(xb)
+            out[f"{tag}.u{step}.x"] = npy(xb)
+            out[f"{tag}.u{step}.grid"] = npy(layer.grid).copy()          # the buffer is updated in place
+            out[f"{tag}.u{step}.spline_weight"] = npy(layer.spline_weight).copy()
+        # the layer on its adaptive grid: dense bases, forward, all gradients
+        x = (torch.randn(193, fi, generator=gen) * 1.1).requires_grad_(True)
+        gy = torch.randn(193, fo, generator=gen)
+        with torch.no_grad():
+            out[f"{tag}.bases"] = npy(layer.b_splines(x))
+        y = layer(x)
+        y.backward(gy)
+        out[f"{tag}.x"] = npy(x)
+        out[f"{tag}.gy"] = npy(gy)
+        out[f"{tag}.y"] = npy(y)
+        out[f"{tag}.gx"] = npy(x.grad)
+        out[f"{tag}.g_base_weight"] = npy(layer.base_weight.grad)
+        out[f"{tag}.g_spline_weight"] = npy(layer.spline_weight.grad)
+        out[f"{tag}.g_spline_scaler"] = npy(layer.spline_scaler.grad)
+        out[f"{tag}.reg_loss"] = npy(layer.regularization_loss(1.0, 0.5))
+    save("g10_update_grid", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g567", "g8", "g9"]
-    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g567": g5_g6_g7, "g8": g8, "g9": g9}
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g567", "g8", "g9", "g10"]
+    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g567": g5_g6_g7, "g8": g8, "g9": g9, "g10": g10}
     for w in which:
         fns[w]()

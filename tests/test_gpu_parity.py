@@ -686,3 +686,98 @@ def test_graph_level_gcn_gat_flavours_match_their_composition():
         assert_close(out, ref, 1e-5, what=type(m).__name__)
         out.sum().backward()
         assert all(p.grad is not None for p in m.parameters() if p.requires_grad), type(m).__name__
+
+
+# ------------------------------------------------------------------ adaptive grids (update_grid, ekan.py:164-211)
+def _g10_cases(z):
+    i = 0
+    while f"shape_{i}" in z:
+        fi, fo, G, k = [int(v) for v in z[f"shape_{i}"]]
+        yield f"{fi}_{fo}_{G}_{k}", fi, fo, G, k
+        i += 1
+
+
+def _g10_layer(z, tag, fi, fo, G, k, state):
+    layer = kagnn_amd.KANLinear(fi, fo, grid_size=G, spline_order=k)
+    sd = {n: T(z[f"{tag}.before.{n}"]) for n in KAN_KEYS}
+    if state == "after":
+        sd["grid"], sd["spline_weight"] = T(z[f"{tag}.u1.grid"]), T(z[f"{tag}.u1.spline_weight"])
+    layer.load_state_dict(sd)
+    return layer.to(DEV)
+
+
+def test_adaptive_grid_layer_golden(golden):
+    """a layer whose grid buffer holds per-feature, non-uniform knots: dense bases, forward, every gradient"""
+    z = golden("g10_update_grid")
+    for tag, fi, fo, G, k in _g10_cases(z):
+        layer = _g10_layer(z, tag, fi, fo, G, k, "after")
+        x = T(z[f"{tag}.x"], DEV).requires_grad_(True)
+        assert_close(layer.b_splines(x), z[f"{tag}.bases"], tol=2e-6, what=f"{tag} bases")
+        y = layer(x)
+        y.backward(T(z[f"{tag}.gy"], DEV))
+        assert_close(y, z[f"{tag}.y"], what=f"{tag} y")
+        assert_close(x.grad, z[f"{tag}.gx"], what=f"{tag} gx")
+        assert_close(layer.base_weight.grad, z[f"{tag}.g_base_weight"], what=f"{tag} g_bw")
+        assert_close(layer.spline_weight.grad, z[f"{tag}.g_spline_weight"], what=f"{tag} g_sw")
+        assert_close(layer.spline_scaler.grad, z[f"{tag}.g_spline_scaler"], what=f"{tag} g_sc")
+        assert_close(layer.regularization_loss(1.0, 0.5), z[f"{tag}.reg_loss"], what=f"{tag} reg")
+
+
+def test_update_grid_golden(golden):
+    """two successive update_grid calls (uniform -> adaptive -> adaptive): knots equal to the reference's to an ulp,
+    refitted coefficients against the reference (fp32 lstsq) and, tighter, against the oracle's fp64 fit"""
+    z = golden("g10_update_grid")
+    for tag, fi, fo, G, k in _g10_cases(z):
+        layer = _g10_layer(z, tag, fi, fo, G, k, "before")
+        p = {n: T(z[f"{tag}.before.{n}"]) for n in KAN_KEYS}
+        for step in range(2):
+            xb = T(z[f"{tag}.u{step}.x"])
+            layer.update_grid(xb.to(DEV))
+            # torch divides by a host scalar on the device as x * (1/s): knots agree to an ulp, not bitwise
+            assert_close(layer.grid, z[f"{tag}.u{step}.grid"], tol=5e-7, what=f"{tag} u{step} grid")
+            assert_close(layer.spline_weight, z[f"{tag}.u{step}.spline_weight"], tol=2e-4, what=f"{tag} u{step} fit")
+            _, fit64 = orc.update_grid(xb, p, G, k, solve_dtype=torch.float64)
+            assert_close(layer.spline_weight, fit64, tol=2e-5, what=f"{tag} u{step} fit vs fp64")
+            # continue from the reference's own state so the second step sees identical inputs
+            p = dict(p, grid=T(z[f"{tag}.u{step}.grid"]), spline_weight=T(z[f"{tag}.u{step}.spline_weight"]))
+            layer.load_state_dict({n: v for n, v in p.items()})
+
+
+@pytest.mark.parametrize("n,fi,fo,G,k", [(20000, 16, 8, 5, 3), (3001, 70, 5, 8, 3), (17, 3, 2, 3, 2), (5000, 4, 40, 12, 4)])
+def test_update_grid_vs_oracle(n, fi, fo, G, k):
+    torch.manual_seed(n)
+    layer = kagnn_amd.KANLinear(fi, fo, grid_size=G, spline_order=k)
+    p = {name: v.detach().clone() for name, v in layer.state_dict().items()}
+    gen = torch.Generator().manual_seed(n + 1)
+    x = torch.randn(n, fi, generator=gen) * torch.linspace(0.3, 2.0, fi) + torch.linspace(-1, 1, fi)
+    grid, fit = orc.update_grid(x, p, G, k, solve_dtype=torch.float64)
+    layer = layer.to(DEV)
+    layer.update_grid(x.to(DEV))
+    assert_close(layer.grid, grid, tol=5e-7, what="knots")
+    assert_close(layer.spline_weight, fit, tol=5e-5, what="refit")
+    # the refitted layer keeps the layer's function on the batch (least-squares sense) and trains on
+    xq = x[: min(n, 2048)]
+    want = orc.kan_linear_forward(xq.double(), p["base_weight"].double(), fit.double(), p["spline_scaler"].double(),
+                                  grid.double(), k)
+    xd = xq.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    y.sum().backward()
+    assert_close(y, want, what="forward on the adaptive grid")
+    assert torch.isfinite(xd.grad).all() and torch.isfinite(layer.spline_weight.grad).all()
+
+
+def test_kan_chain_update_grid_flag():
+    """KAN.forward(x, update_grid=True) (ekan.py:270-275): each layer re-grids on its own input first"""
+    torch.manual_seed(3)
+    net = kagnn_amd.KAN([6, 10, 4], grid_size=5, spline_order=3)
+    layers = [{n: v.detach().clone() for n, v in l.state_dict().items()} for l in net.layers]
+    x = torch.randn(600, 6) * 0.9
+    h = x
+    for p in layers:
+        grid, fit = orc.update_grid(h, p, 5, 3, solve_dtype=torch.float64)
+        p["grid"], p["spline_weight"] = grid, fit
+        h = orc.kan_linear_forward(h, p["base_weight"], p["spline_weight"], p["spline_scaler"], p["grid"], 3)
+    net = net.to(DEV)
+    y = net(x.to(DEV), update_grid=True)
+    assert_close(y, h, tol=5e-4, what="chain with update_grid")
+    assert_close(net(x.to(DEV)), y, tol=1e-6, what="same grids on the next call")

@@ -181,3 +181,33 @@ def test_live_reference_matches_oracle(reference_modules):
     sd = fk.state_dict()
     layers = [{n: sd[f"layers.{li}.{n}"] for n in FK_KEYS} for li in range(2)]
     close(orc.fastkan_forward(x, layers), fk(x).detach(), 1e-6)
+
+
+def test_g10_update_grid(golden):
+    """oracle.update_grid against the reference's KANLinear.update_grid: knots bit-identical (same op order),
+    refitted coefficients to the accuracy of an fp32 least-squares solve; then the layer on its adaptive grid."""
+    z = golden("g10_update_grid")
+    i = 0
+    while f"shape_{i}" in z:
+        fi, fo, G, k = [int(v) for v in z[f"shape_{i}"]]
+        tag = f"{fi}_{fo}_{G}_{k}"
+        p = {n: T(z[f"{tag}.before.{n}"]) for n in ("base_weight", "spline_weight", "spline_scaler", "grid")}
+        for step in range(2):
+            xb = T(z[f"{tag}.u{step}.x"])
+            grid, fit = orc.update_grid(xb, p, G, k)
+            assert torch.equal(grid, T(z[f"{tag}.u{step}.grid"]))
+            close(fit, z[f"{tag}.u{step}.spline_weight"], tol=2e-4)
+            _, fit64 = orc.update_grid(xb, p, G, k, solve_dtype=torch.float64)
+            close(fit64, z[f"{tag}.u{step}.spline_weight"], tol=2e-4)
+            p = dict(p, grid=T(z[f"{tag}.u{step}.grid"]), spline_weight=T(z[f"{tag}.u{step}.spline_weight"]))
+        x, gy = T(z[f"{tag}.x"]).requires_grad_(True), T(z[f"{tag}.gy"])
+        np.testing.assert_array_equal(orc.bspline_bases(x.detach(), p["grid"], k).numpy(), z[f"{tag}.bases"])
+        ps = {n: (v.clone().requires_grad_(True) if n != "grid" else v) for n, v in p.items()}
+        y = orc.kan_linear_forward(x, ps["base_weight"], ps["spline_weight"], ps["spline_scaler"], ps["grid"], k)
+        y.backward(gy)
+        close(y.detach(), z[f"{tag}.y"])
+        close(x.grad, z[f"{tag}.gx"])
+        close(ps["spline_weight"].grad, z[f"{tag}.g_spline_weight"])
+        close(ps["spline_scaler"].grad, z[f"{tag}.g_spline_scaler"])
+        i += 1
+    assert i == 5
