@@ -84,6 +84,42 @@ def cpu_baseline(n_sample, e_sample, f, grid, order, seed=0):
                       f"timed fwd+bwd per thread count {tried} (threads, s) on a {host}-thread host; best reported"}
 
 
+def secondary_figures(dev, conv, graph, x, n, e, f, grid, order):
+    """SURVEY.md 8(d)'s side figures, measured after (never inside) the timed region: what a device-to-device copy
+    reaches on this box next to the 8 TB/s the roofline is priced against, the share of the first KANLinear's inputs
+    that falls inside the spline support, and the full 3-layer GKAN_Nodes training step quoted as 3E / t_step."""
+    import kagnn_amd
+    from kagnn_amd import harness, ops
+    out = {}
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev)       # 1 GiB, well past the 256 MB of MALL
+    b = torch.empty_like(a)
+    b.copy_(a)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        b.copy_(a)
+    ev1.record()
+    torch.cuda.synchronize()
+    out["hbm_copy_GBs"] = 10 * 2.0 * a.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    del a, b
+    with torch.no_grad():
+        h0 = ops.aggregate_sum(x.detach(), graph, self_scale=1.0)
+        knots = conv.nn.layers[0].grid[0]
+        out["in_support_frac"] = float(((h0 >= knots[0]) & (h0 < knots[-1])).float().mean())
+        del h0
+    torch.manual_seed(0)
+    classes = 40
+    model = kagnn_amd.GKAN_Nodes("gin", 3, f, f, classes, skip=True, grid_size=grid, spline_order=order,
+                                 hidden_layers=2).to(dev)
+    y = torch.randint(0, classes, (n,), generator=torch.Generator().manual_seed(2)).to(dev)
+    mask = torch.ones(n, dtype=torch.bool, device=dev)
+    t_step, _ = harness.time_model(model, x.detach(), graph, y, mask, nb_epochs=5, warmup=2)
+    out["model_step"] = {"what": f"GKAN_Nodes(gin, 3 conv layers, hidden {f}, {classes} classes, skip, BatchNorm) training step "
+                                 "(forward, softmax + cross-entropy, backward, Adam), time_model.py:35-48",
+                         "ms_per_step": t_step * 1e3, "edges_per_s": 3 * e / t_step}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +133,7 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("KAGNN_PRECISION", "split"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="nodes in the CPU-baseline sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (copy bandwidth, full model step)")
     args = ap.parse_args()
     os.environ["KAGNN_PRECISION"] = args.precision
 
@@ -252,6 +289,8 @@ def main():
             "roofline": roof,
             "entry_points_ms_per_step": per_step, "entry_points_measured_in": "3 extra untimed steps after the warm-up (HIP events around every call)",
         }
+        if not args.no_extras and world == 1:
+            out["secondary"] = secondary_figures(dev, conv, graph, x, n, e, f, args.grid, args.order)
         if not args.no_cpu_baseline and world == 1:
             ns = min(args.cpu_sample, n)
             out["cpu_baseline"] = cpu_baseline(ns, ns * (e // n if n else 10), f, args.grid, args.order)

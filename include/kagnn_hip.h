@@ -288,6 +288,24 @@ int kagnn_gat_bwd(const float* xh, int64_t ldx, const float* gout, int64_t ldg, 
                   int64_t ldgx, const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
                   void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Loss tail of the timing harness (node_classification_clean/time_model.py:43-45):
+ *   out = softmax(logits, dim=1); loss = CrossEntropyLoss()(out[mask], y[mask])
+ * pre_softmax = 1 keeps the reference's softmax-before-CrossEntropyLoss (which applies log_softmax again);
+ * 0 is plain softmax cross-entropy (utils.py's training loop).  mean over the masked rows; `mask` [N] bytes
+ * (torch.bool storage) or NULL = every row; labels int64 in [0, num_classes) (anything else: loss = NaN).
+ * loss / count: device scalars (count = number of masked rows, kept for the backward; no host sync);
+ * row_stats [N,3] is the only tensor saved.  Deterministic.  g_logits rows outside the mask are written as 0. */
+int kagnn_softmax_xent_workspace_bytes(int64_t num_rows, size_t* bytes_host);
+int kagnn_softmax_xent_fwd(const float* logits, int64_t ld, int64_t num_rows, int32_t num_classes,
+                           const int64_t* labels, const uint8_t* mask, int32_t pre_softmax, float* loss,
+                           float* row_stats, float* count, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int kagnn_softmax_xent_bwd(const float* logits, int64_t ld, int64_t num_rows, int32_t num_classes,
+                           const int64_t* labels, const uint8_t* mask, int32_t pre_softmax,
+                           const float* row_stats, const float* count, const float* g_loss,
+                           float* g_logits, int64_t ldg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

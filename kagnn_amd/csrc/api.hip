@@ -52,6 +52,9 @@ int gat_bwd(const float*, long, const float*, long, const float*, long, const fl
 int kan_bsplines(const float*, long, long, const float*, int, int, int, float*, hipStream_t);
 size_t kan_grid_refit_ws_bytes(long N, int in);
 int kan_grid_refit(const float*, long, long, const float*, const float*, int, int, int, int, const float*, const float*, float*, void*, size_t, hipStream_t);
+size_t xent_ws_bytes(long N);
+int xent_fwd(const float*, long, long, int, const long*, const unsigned char*, int, float*, float*, float*, void*, size_t, hipStream_t);
+int xent_bwd(const float*, long, long, int, const long*, const unsigned char*, int, const float*, const float*, const float*, float*, long, hipStream_t);
 size_t bn_ws_bytes(long N, int F);
 int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, float*, long, float*, float*, void*, size_t, hipStream_t);
 int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float*, long, float*, float*, void*, size_t, hipStream_t);
@@ -403,6 +406,31 @@ int kagnn_gat_bwd(const float* xh, int64_t ldx, const float* gout, int64_t ldg, 
     return gat_bwd(xh, ldx, gout, ldg, out, ldo, bias, a_src, a_dst, row_max, row_sum, rowptr, col, perm, rowptr_t, col_t,
                    perm_t, att_src, att_dst, N, H, C, edge_scratch, self_scratch, g_dst, g_src, gx, ldgx, hub_seg, num_hub_seg,
                    hub_threshold, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- harness loss
+int kagnn_softmax_xent_workspace_bytes(int64_t N, size_t* bytes) {
+    KAGNN_CHECK_ARG(bytes != nullptr && N >= 0, "null output or negative size");
+    *bytes = xent_ws_bytes(N);
+    return KAGNN_OK;
+}
+
+int kagnn_softmax_xent_fwd(const float* logits, int64_t ld, int64_t N, int32_t C, const int64_t* labels,
+                           const uint8_t* mask, int32_t pre_softmax, float* loss, float* row_stats, float* count,
+                           void* ws, size_t ws_bytes, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && C >= 1 && ld >= C, "bad shape");
+    KAGNN_CHECK_ARG(loss && count && ws && (N == 0 || (logits && labels && row_stats)), "null array");
+    return xent_fwd(logits, ld, N, C, (const long*)labels, mask, pre_softmax, loss, row_stats, count, ws, ws_bytes,
+                    as_stream(stream));
+}
+
+int kagnn_softmax_xent_bwd(const float* logits, int64_t ld, int64_t N, int32_t C, const int64_t* labels,
+                           const uint8_t* mask, int32_t pre_softmax, const float* row_stats, const float* count,
+                           const float* g_loss, float* g_logits, int64_t ldg, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && C >= 1 && ld >= C && ldg >= C, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (logits && labels && row_stats && count && g_loss && g_logits), "null array");
+    return xent_bwd(logits, ld, N, C, (const long*)labels, mask, pre_softmax, row_stats, count, g_loss, g_logits, ldg,
+                    as_stream(stream));
 }
 
 }  // extern "C"

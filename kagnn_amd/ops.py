@@ -518,6 +518,48 @@ class _FastKANFn(Function):
         return gx, glw, glb, gsw, gbw, (gbb if has_bb else None), None, None, None, None
 
 
+# ======================================================================== harness loss
+class _SoftmaxXentFn(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, mask, pre_softmax):
+        _need_cuda(logits, labels, mask)
+        z = _rows(logits)
+        n, c = z.shape
+        y = labels.to(torch.int64).contiguous()
+        m = None if mask is None else mask.contiguous()
+        ws = _ws(_sizes("kagnn_softmax_xent_workspace_bytes", n), z.device)
+        out = torch.empty(2, dtype=torch.float32, device=z.device)          # (loss, row count)
+        stats = torch.empty((n, 3), dtype=torch.float32, device=z.device)
+        _call("kagnn_softmax_xent_fwd", _ptr(z), _ld(z), n, c, _ptr(y), _ptr(m), int(pre_softmax), _ptr(out),
+              _ptr(stats), ctypes.c_void_p(out.data_ptr() + 4), _ptr(ws), ws.numel(), _stream())
+        ctx.save_for_backward(z, y, m, stats, out)
+        ctx.pre = int(pre_softmax)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss):
+        z, y, m, stats, out = ctx.saved_tensors
+        n, c = z.shape
+        g = gloss.to(torch.float32).contiguous()
+        gz = torch.empty((n, c), dtype=torch.float32, device=z.device)
+        _call("kagnn_softmax_xent_bwd", _ptr(z), _ld(z), n, c, _ptr(y), _ptr(m), ctx.pre, _ptr(stats),
+              ctypes.c_void_p(out.data_ptr() + 4), _ptr(g), _ptr(gz), c, _stream())
+        return gz, None, None, None
+
+
+def softmax_cross_entropy(logits, labels, mask=None, pre_softmax: bool = False) -> torch.Tensor:
+    """``CrossEntropyLoss()(f(logits)[mask], labels[mask])`` (mean over the masked rows) in one kernel each way, with
+    ``f = softmax(dim=1)`` when ``pre_softmax`` (the reference harness, ``time_model.py:43-45``) and the identity
+    otherwise.  ``mask``: bool ``[N]`` or ``None``; an int64 index tensor of distinct rows is accepted too.  No
+    device-to-host sync (boolean indexing has one), so a whole epoch can be captured in a HIP graph."""
+    if mask is not None and mask.dtype != torch.bool:
+        picked = torch.zeros(logits.size(0), dtype=torch.bool, device=logits.device)
+        picked[mask] = True
+        mask = picked
+    return _SoftmaxXentFn.apply(logits, labels, mask, bool(pre_softmax))
+
+
 # ======================================================================== GAT attention aggregation
 class _GatFn(Function):
     @staticmethod

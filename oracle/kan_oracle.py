@@ -316,6 +316,17 @@ def init_kan_linear(in_features: int, out_features: int, grid_size: int, spline_
     return {"base_weight": bw, "spline_weight": sw, "spline_scaler": sc, "grid": knots}
 
 
+def harness_loss(logits: Tensor, labels: Tensor, mask: Optional[Tensor] = None, pre_softmax: bool = True) -> Tensor:
+    """The loss of the timing harness, ``node_classification_clean/time_model.py:43-45``: ``out = softmax(out, dim=1)``
+    then ``CrossEntropyLoss()(out[mask], y[mask])`` -- cross-entropy of the *probabilities* (log_softmax applied on
+    top of softmax), mean over the masked rows.  ``pre_softmax=False`` is the plain cross-entropy of the training
+    loop (``utils.py``)."""
+    out = F.softmax(logits, dim=1) if pre_softmax else logits
+    if mask is not None:
+        out, labels = out[mask], labels[mask]
+    return F.cross_entropy(out, labels)
+
+
 def powerlaw_graph(num_nodes: int, num_edges: int, seed: int = 0) -> Tensor:
     """The synthetic graph recipe of SURVEY.md section 8(d) (seeded, duplicates and
     self-loops kept, unsorted).  Returns ``edge_index[2, E]`` int64."""

@@ -222,15 +222,21 @@ def test_empty_batch():
     assert y.shape == (0, 4)
 
 
-def test_kanlinear_refuses_nonuniform_grid_and_cpu():
+def test_kanlinear_refuses_cpu_and_bad_grids_and_follows_edited_grid():
     layer = kagnn_amd.KANLinear(4, 4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         layer(torch.randn(3, 4))
     layer = layer.to(DEV)
+    x = torch.randn(64, 4)
     with torch.no_grad():
-        layer.grid[1, 3] += 0.05
-    with pytest.raises(NotImplementedError):
-        layer(torch.randn(3, 4, device=DEV))
+        layer.grid[1, 3] += 0.05                     # one knot of one feature moved: per-feature knot kernels
+    p = {n: v.detach().cpu() for n, v in layer.state_dict().items()}
+    want = orc.kan_linear_forward(x, p["base_weight"], p["spline_weight"], p["spline_scaler"], p["grid"], 3)
+    assert_close(layer(x.to(DEV)), want, what="edited grid")
+    with torch.no_grad():
+        layer.grid[2, 5] = layer.grid[2, 4]          # repeated knot: refused
+    with pytest.raises(ValueError, match="increasing"):
+        layer(x.to(DEV))
     with pytest.raises(AssertionError):
         kagnn_amd.KANLinear(4, 4).to(DEV)(torch.randn(3, 5, device=DEV))
 
@@ -470,7 +476,7 @@ def test_kanlinear_degenerate_weights_and_gradients():
             q.zero_()
     x = torch.randn(100, 16, device=DEV, requires_grad=True)
     y = layer(x)
-    assert float(y.abs().max()) == 0.0
+    assert float(y.detach().abs().max()) == 0.0
     y.backward(torch.zeros_like(y))
     assert float(x.grad.abs().max()) == 0.0 and float(layer.spline_weight.grad.abs().max()) == 0.0
 
@@ -781,3 +787,38 @@ def test_kan_chain_update_grid_flag():
     y = net(x.to(DEV), update_grid=True)
     assert_close(y, h, tol=5e-4, what="chain with update_grid")
     assert_close(net(x.to(DEV)), y, tol=1e-6, what="same grids on the next call")
+
+
+# ------------------------------------------------------------------ harness loss (time_model.py:43-45)
+@pytest.mark.parametrize("n,c", [(1, 2), (37, 3), (1000, 7), (5000, 40), (777, 64), (300, 100), (65, 300)])
+@pytest.mark.parametrize("pre", [True, False])
+@pytest.mark.parametrize("masked", [True, False])
+def test_softmax_cross_entropy_vs_oracle(n, c, pre, masked):
+    gen = torch.Generator().manual_seed(n * 31 + c)
+    z = torch.randn(n, c, generator=gen) * 3.0
+    y = torch.randint(0, c, (n,), generator=gen)
+    mask = (torch.rand(n, generator=gen) < 0.6) if masked else None
+    if masked:
+        mask[0] = True
+    zr = z.double().requires_grad_(True)
+    want = orc.harness_loss(zr, y, mask, pre_softmax=pre)
+    (want * 1.7).backward()
+    zd = z.to(DEV).requires_grad_(True)
+    got = ops.softmax_cross_entropy(zd, y.to(DEV), None if mask is None else mask.to(DEV), pre_softmax=pre)
+    (got * 1.7).backward()
+    assert got.dim() == 0
+    assert_close(got, want.detach(), tol=1e-5, what="loss")
+    assert_close(zd.grad * n, zr.grad * n, tol=1e-5, what="d loss / d logits (x N)")
+    if masked:                                                        # index-tensor form of the same mask
+        got_i = ops.softmax_cross_entropy(zd.detach(), y.to(DEV), mask.nonzero().squeeze(1).to(DEV), pre_softmax=pre)
+        assert torch.equal(got_i, got.detach())
+
+
+def test_softmax_cross_entropy_strided_and_bad_label():
+    z = torch.randn(50, 24, device=DEV)
+    y = torch.randint(0, 10, (50,), device=DEV)
+    a = ops.softmax_cross_entropy(z[:, 3:13], y, pre_softmax=True)          # column slice: row stride 24
+    b = ops.softmax_cross_entropy(z[:, 3:13].contiguous(), y, pre_softmax=True)
+    assert torch.equal(a, b)
+    y[7] = 10
+    assert torch.isnan(ops.softmax_cross_entropy(z[:, 3:13], y))
