@@ -48,7 +48,7 @@ def _time_model_graphed(model, x, edge_index, y, mask, nb_epochs: int, warmup: i
     t0 = time.perf_counter()
     for _ in range(nb_epochs):
         graph.replay()
-        losses.append(static_loss.clone())
+        losses.append(static_loss.detach().clone())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / nb_epochs
     return float(np.round(dt, 6)), [float(l) for l in losses]
