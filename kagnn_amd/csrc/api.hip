@@ -70,8 +70,9 @@ static int check_kan_dims(const char* fn, int in, int out, int G, int K, int mod
     return KAGNN_OK;
 }
 // the split path covers the hot shapes; everything else runs the exact-fp32 kernels (still HIP)
-// the split kernels address activations through buffer descriptors with 32-bit byte offsets
-static bool fits32(long N, long ld) { return (N + (1L << 18)) * ld * 4 < 0xF0000000L; }
+// the split kernels address activations through buffer descriptors with 32-bit byte offsets, re-opened at every
+// workgroup tile (<= 256 rows forward / input gradient, <= 2^17 rows weight gradient): any N, rows up to 7680 floats
+static bool fits32(long N, long ld) { (void)N; return ld <= 7680; }
 static bool use_split_fwd(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_fwd_ok(in, out, G, K); }
 static bool use_sparse_fwd(int in, int out, int G, int K, int mode) { return use_split_fwd(in, out, G, K, mode) && kan_sparse_fwd_ok(in, out, G, K); }
 static bool use_split_dx(int in, int out, int G, int K, int mode) { return mode == KAGNN_PREC_SPLIT && kan_split_dx_ok(in, out, G, K); }
@@ -200,7 +201,7 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* kn
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && knots && pack_fwd && y, "null array");
     if (use_split_fwd(in, out, G, K, mode)) {
-        if (!(fits32(N, ldx) && fits32(N, ldy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
+        if (!(fits32(N, ldx) && fits32(N, ldy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
         if (use_sparse_fwd(in, out, G, K, mode))
             return kan_sparse_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
         return kan_split_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
@@ -217,7 +218,7 @@ int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && gy && knots && pack_dx && gx, "null array");
     if (use_split_dx(in, out, G, K, mode)) {
-        if (!(fits32(N, ldx) && fits32(N, ldgy) && fits32(N, ldgx))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
+        if (!(fits32(N, ldx) && fits32(N, ldgy) && fits32(N, ldgx))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
         return kan_split_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack_dx, gx, ldgx, as_stream(stream));
     }
     return kan_f32_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, (const float*)pack_dx, gx, ldgx, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
@@ -244,7 +245,7 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
     KAGNN_CHECK_ARG(N == 0 || (x && gy), "null array");
     KAGNN_CHECK_ARG((sc == nullptr) == (g_sc == nullptr), "spline_scaler and its gradient must both be given or both be null");
     if (use_split_dw(in, out, G, K, mode)) {
-        if (!(fits32(N, ldx) && fits32(N, ldgy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
+        if (!(fits32(N, ldx) && fits32(N, ldgy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
         return kan_split_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream));
     }
     return kan_f32_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
@@ -307,7 +308,7 @@ int kagnn_fastkan_fwd(const float* x, int64_t ldx, int64_t N, int32_t in, int32_
     KAGNN_CHECK_ARG(denominator != 0.0f, "denominator is zero");
     KAGNN_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "layernorm weight and bias must both be given or both be null");
     if (mode == KAGNN_PREC_SPLIT && !(fits32(N, ldx) && fits32(N, ldy)))
-        return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
     return fastkan_fwd(x, ldx, N, in, out, ng, centers, denominator, ln_w, ln_b, ln_eps, spline_w, base_w,
                        base_b, y, ldy, row_stats, ws, ws_bytes, mode, as_stream(stream));
 }
@@ -334,7 +335,7 @@ int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy
     KAGNN_CHECK_ARG(ln_w == nullptr || (ln_b && row_stats && g_ln_w && g_ln_b), "layernorm needs bias, row_stats and both gradient outputs");
     KAGNN_CHECK_ARG(base_w == nullptr || (g_base_w && g_base_b), "base branch needs both gradient outputs");
     if (mode == KAGNN_PREC_SPLIT && !(fits32(N, ldx) && fits32(N, ldgy) && fits32(N, ldgx)))
-        return fail(KAGNN_ERR_UNSUPPORTED, "%s: activation spans >= 3.75 GiB; call with KAGNN_PREC_FP32", __func__);
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
     return fastkan_bwd(x, ldx, gy, ldgy, N, in, out, ng, centers, denominator, ln_w, ln_b, ln_eps, spline_w,
                        base_w, row_stats, gx, ldgx, g_ln_w, g_ln_b, g_spline_w, g_base_w, g_base_b, ws,
                        ws_bytes, mode, as_stream(stream));

@@ -191,17 +191,17 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const Frag3Geom f3geo = frag3_geom(s_knots, nknots);
     const int r = lane & 31, kg = lane >> 5;
     const bool al4 = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    const GBuf xb = gbuf(x, N, ldx, in), yb = gbuf(y, N, ldy, out);
     const unsigned ldx4 = (unsigned)ldx * 4u, ldy4 = (unsigned)ldy * 4u;
-    auto load8 = [&](long row0t, int ch, int g, float (&v)[8]) {
-        const unsigned ro = (unsigned)(row0t + r) * ldx4 + kg * HF * 4;   // rows >= N: past the descriptor -> zeros
+    auto load8 = [&](long tile0 /* first row of the workgroup's tile: wave-uniform */, int ch, int g, float (&v)[8]) {
+        const GBuf xb = gbuf_at(x, N, ldx, in, tile0);
+        const unsigned ro = (unsigned)(wave * 32 + r) * ldx4 + kg * HF * 4;   // rows >= N: past the descriptor -> zeros
         const unsigned so = (unsigned)(ch * CF + 8 * g) * 4u;
         if (al4 && ch * CF + CF <= in) {                  // wave-uniform
             gld4_s(xb, ro, so, v);
             gld4_s(xb, ro, so + 16, v + 4);
         } else {
             const int f0 = ch * CF + kg * HF + 8 * g;
-            const unsigned rb = (unsigned)(row0t + r) * ldx4;
+            const unsigned rb = (unsigned)(wave * 32 + r) * ldx4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = gld(xb, rb + min(f0 + j, in - 1) * 4);   // features >= in meet zero weights
         }
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     };
 
     float xn[8];
-    load8((long)blockIdx.x * ROWS + wave * 32, ch_begin, 0, xn);
+    load8((long)blockIdx.x * ROWS, ch_begin, 0, xn);
     for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
         const long row0 = tile * ROWS + wave * 32;
         // acc: spline part (bases * 2^10); acc_b: SiLU branch through fp16 hi/lo at scale 2^4 (|silu| < 4094);
@@ -238,9 +238,9 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                 float xv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = xn[j];
-                if (g + 1 < NG) load8(row0, ch, g + 1, xn);
-                else if (ch + 1 < ch_end) load8(row0, ch + 1, 0, xn);
-                else load8(row0 + (long)gridDim.x * ROWS, ch_begin, 0, xn);
+                if (g + 1 < NG) load8(tile * ROWS, ch, g + 1, xn);
+                else if (ch + 1 < ch_end) load8(tile * ROWS, ch + 1, 0, xn);
+                else load8((tile + gridDim.x) * ROWS, ch_begin, 0, xn);
 
                 // ---- 4 sparse steps per group (features 2s, 2s+1 of the group): while the 3*OT sparse MFMAs of step
                 // s execute, the VALU expands the two scalars of step s+1 and their weights / table entries are in flight
@@ -329,10 +329,11 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                 }
             }
         }
+        const GBuf yb = gbuf_at(y, N, ldy, out, tile * ROWS);
 #pragma unroll
         for (int t = 0; t < OT; ++t) {
             const int col = 32 * t + r;
-            const unsigned base = (unsigned)(row0 + 4 * kg) * ldy4 + col * 4;
+            const unsigned base = (unsigned)(wave * 32 + 4 * kg) * ldy4 + col * 4;
             if (col < out) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped

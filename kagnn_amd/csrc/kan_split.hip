@@ -149,24 +149,24 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     // 8 consecutive features (group g of chunk ch) of this lane's row.  Unconditional loads on clamped
     // addresses, never masked (a per-lane `cond ? load : const` makes hipcc branch around every load):
     // rows >= N are never stored, features >= in meet zero weights in the pack.
-    const GBuf xb = gbuf(x, N, ldx, in), yb = gbuf(y, N, ldy, out);
     const unsigned ldx4 = (unsigned)ldx * 4u, ldy4 = (unsigned)ldy * 4u;
-    auto load8 = [&](long row0t, int ch, int g, float (&v)[8]) {
-        const unsigned ro = (unsigned)(row0t + r) * ldx4 + kg * HF * 4;   // rows >= N: past the descriptor -> zeros
+    auto load8 = [&](long tile0 /* first row of the workgroup's tile: wave-uniform */, int ch, int g, float (&v)[8]) {
+        const GBuf xb = gbuf_at(x, N, ldx, in, tile0);
+        const unsigned ro = (unsigned)(wave * 32 + r) * ldx4 + kg * HF * 4;   // rows >= N: past the descriptor -> zeros
         const unsigned so = (unsigned)(ch * CF + 8 * g) * 4u;              // wave-uniform part of the offset
         if (al4 && sh == 0 && ch * CF + CF <= in) {       // wave-uniform
             gld4_s(xb, ro, so, v);
             gld4_s(xb, ro, so + 16, v + 4);
         } else {
             const int f0 = ch * CF + kg * HF + 8 * g;
-            const unsigned rb = (unsigned)(row0t + r) * ldx4;
+            const unsigned rb = (unsigned)(wave * 32 + r) * ldx4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = gld(xb, rb + min((f0 + j) >> sh, in - 1) * 4);
         }
     };
 
     float xn[8];
-    load8((long)blockIdx.x * ROWS + wave * 32, ch_begin, 0, xn);
+    load8((long)blockIdx.x * ROWS, ch_begin, 0, xn);
     for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
         const long row0 = tile * ROWS + wave * 32;
         f32x16 acc[OT];
@@ -192,9 +192,9 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = xn[j];
                 // prefetch the next group: same chunk, next chunk, or the first group of this wave's next tile
-                if (g + 1 < NG) load8(row0, ch, g + 1, xn);
-                else if (ch + 1 < ch_end) load8(row0, ch + 1, 0, xn);
-                else load8(row0 + (long)gridDim.x * ROWS, ch_begin, 0, xn);
+                if (g + 1 < NG) load8(tile * ROWS, ch, g + 1, xn);
+                else if (ch + 1 < ch_end) load8(tile * ROWS, ch + 1, 0, xn);
+                else load8((tile + gridDim.x) * ROWS, ch_begin, 0, xn);
 
                 if constexpr (K == 3) {
                     // ---- software pipeline inside the group: while the 6*OT/2 MFMAs of feature j execute, the
@@ -310,10 +310,11 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                 }
             }
         }
+        const GBuf yb = gbuf_at(y, N, ldy, out, tile * ROWS);
 #pragma unroll
         for (int t = 0; t < OT; ++t) {
             const int col = 32 * t + r;
-            const unsigned base = (unsigned)(row0 + 4 * kg) * ldy4 + col * 4;
+            const unsigned base = (unsigned)(wave * 32 + 4 * kg) * ldy4 + col * 4;
             if (col < out) {
                 const float bb = (K == 0 && rb.bias && split == 0) ? rb.bias[col] : 0.0f;
 #pragma unroll

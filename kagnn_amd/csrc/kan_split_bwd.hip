@@ -172,17 +172,19 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     }
     if constexpr (K > 0) { geom = geom_from_knots(s_knots, nknots); fgeo = fast_geom(s_knots, nknots); }
     const bool ln_on = (K == 0) && rb.ln_w != nullptr;           // wave-uniform
-    const GBuf gzb = gbuf(rb.gz, N, in, in);
     const bool al4 = ((ldgy & 3) == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
-    const GBuf xb = gbuf(x, N, ldx, in), gyb = gbuf(gy, N, ldgy, out), gxb = gbuf(gx, N, ldgx, in);
     const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u, ldgx4 = (unsigned)ldgx * 4u;
 
     for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
         const long row0 = tile * 256 + wave * 32;
-        const unsigned gy_ro = (unsigned)(row0 + li) * ldgy4;
-        const unsigned x_rb = (unsigned)(row0 + 4 * kg) * ldx4;
-        const unsigned gx_rb = (unsigned)(row0 + 4 * kg) * ldgx4;
-        const unsigned gz_rb = (unsigned)(row0 + 4 * kg) * (unsigned)in * 4u;
+        // descriptors opened at the workgroup's tile: per-lane offsets are tile-relative and 32-bit for any N
+        const GBuf gzb = gbuf_at(rb.gz, N, in, in, tile * 256);
+        const GBuf xb = gbuf_at(x, N, ldx, in, tile * 256), gyb = gbuf_at(gy, N, ldgy, out, tile * 256),
+                   gxb = gbuf_at(gx, N, ldgx, in, tile * 256);
+        const unsigned gy_ro = (unsigned)(wave * 32 + li) * ldgy4;
+        const unsigned x_rb = (unsigned)(wave * 32 + 4 * kg) * ldx4;
+        const unsigned gx_rb = (unsigned)(wave * 32 + 4 * kg) * ldgx4;
+        const unsigned gz_rb = (unsigned)(wave * 32 + 4 * kg) * (unsigned)in * 4u;
         float mu[2][4], rs[2][4];                          // layernorm statistics of this lane's 8 rows
         if (ln_on) {
 #pragma unroll
@@ -419,6 +421,9 @@ bool kan_split_dw_ok(int in, int out, int G, int K) { return K >= 0 && K <= 4 &&
 
 struct DwPlan { int nbx; long rpw; long NS; long per; int FG, OC; long inP, outP; };
 
+// rows one dW workgroup may own: with leading dimensions up to kDwMaxLd floats its slice of x / gy spans < 4 GiB
+constexpr long kDwMaxRowsPerBlock = 1L << 17;
+
 static DwPlan split_dw_plan(long N, int in, int out, int C) {
     DwPlan p;
     if (C > 8) { in <<= 1; C = 8; }                    // virtual features: 2*in features of 8 slots (wcat_v)
@@ -427,6 +432,7 @@ static DwPlan split_dw_plan(long N, int in, int out, int C) {
     int nb = max(1, 256 / roles);                      // ~1 workgroup per CU
     long r = (N + nb - 1) / nb;
     r = max(32L, (r + 31) & ~31L);                     // whole 32-row chunks
+    r = min(r, kDwMaxRowsPerBlock);                    // a workgroup's rows stay inside one 4 GiB buffer window
     nb = (int)max(1L, (long)cdiv(N, r));
     p.nbx = nb; p.rpw = r; p.NS = nb;
     p.inP = 32L * cdiv(in, 32); p.outP = 32L * cdiv(out, 32);
@@ -491,18 +497,20 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t) { Dh[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Df[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    const GBuf xb = gbuf(x, N, ldx, in), gyb = gbuf(gy, N, ldgy, out);
-    const GBuf stb = gbuf(rb.stats, ln_on ? N : 0, 2, 2);      // rows >= N: (0, 0) -> z = beta, finite; their gy is 0
+    // descriptors opened at this workgroup's first row and closed at its last: offsets are relative to rbeg (32-bit
+    // for any N; the host keeps rows_per_block * ld * 4 below 4 GiB) and rows >= rend read as 0
+    const GBuf xb = gbuf_at(x, rend, ldx, in, rbeg), gyb = gbuf_at(gy, rend, ldgy, out, rbeg);
+    const GBuf stb = gbuf_at(rb.stats, ln_on ? rend : 0, 2, 2, rbeg);   // rows >= N: (0, 0) -> z = beta, finite; their gy is 0
     const float gam = ln_on ? rb.ln_w[min(f, in - 1)] : 1.0f, bet = ln_on ? rb.ln_b[min(f, in - 1)] : 0.0f;
-    unsigned sto = (unsigned)(rbeg + 8 * kg) * 8u;
+    unsigned sto = (unsigned)(8 * kg) * 8u;
     const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u;
     // per-lane byte offsets of the chunk being fetched; rows advance by 32 per call.  Unconditional buffer
     // loads: rows >= N read as 0 through the descriptor (rows_per_block is a multiple of 32, so a chunk
     // never straddles two workgroups); features >= in / outputs >= out are clamped and only reach slab
     // entries nobody reads.
-    unsigned xo = (unsigned)(rbeg + 8 * kg) * ldx4 + (unsigned)min(f, in - 1) * 4u, gvo[4];
+    unsigned xo = (unsigned)(8 * kg) * ldx4 + (unsigned)min(f, in - 1) * 4u, gvo[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) gvo[t] = (unsigned)(rbeg + 8 * kg) * ldgy4 + (unsigned)min(64 * oc + 16 * t + li, out - 1) * 4u;
+    for (int t = 0; t < 4; ++t) gvo[t] = (unsigned)(8 * kg) * ldgy4 + (unsigned)min(64 * oc + 16 * t + li, out - 1) * 4u;
     auto load_raw = [&](DwRaw& r) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

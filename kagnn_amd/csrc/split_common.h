@@ -63,13 +63,24 @@ __device__ __forceinline__ void pack_dx_items(const float* __restrict__ bw, cons
 
 // ---- global memory through buffer descriptors: 32-bit byte offsets (no 64-bit VALU address math) and
 // hardware bounds checking -- a load past `bytes` returns 0, a store past it is dropped, so rows >= N
-// need neither clamping nor predication.  The host side only takes this path when the tensor (plus the
-// prefetch margin) spans < 4 GiB.
+// need neither clamping nor predication.
 struct GBuf { __amdgpu_buffer_rsrc_t r; };
 __device__ __forceinline__ GBuf gbuf(const void* p, long rows, long ld, int width) {
     const long bytes = rows > 0 ? ((rows - 1) * ld + width) * 4 : 0;
     GBuf b;
     b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (unsigned)bytes, 0x00020000);
+    return b;
+}
+// the same window opened at row `row0` (wave-uniform): 64-bit base arithmetic happens once, on the scalar unit,
+// and the per-lane offsets stay 32-bit however large the tensor is -- a kernel only ever needs the rows of its own
+// tile (plus the next one it prefetches) inside the 4 GiB a descriptor can span.
+__device__ __forceinline__ GBuf gbuf_at(const void* p, long rows, long ld, int width, long row0) {
+    const long left = rows - row0;
+    long bytes = left > 0 ? ((left - 1) * ld + width) * 4 : 0;
+    if (bytes > 0xFFFFFFF0L) bytes = 0xFFFFFFF0L;
+    GBuf b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p)) + row0 * ld * 4, 0,
+                                            (unsigned)bytes, 0x00020000);
     return b;
 }
 __device__ __forceinline__ float gld(const GBuf& b, unsigned off) {

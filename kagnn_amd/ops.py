@@ -439,8 +439,8 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
         mode = PREC_FP32_GRID
     if mode is None:
         mode = default_precision()
-    if mode == PREC_SPLIT and (x.size(0) + (1 << 18)) * max(x.stride(0), base_weight.size(0), 1) * 4 >= 0xF0000000:
-        mode = PREC_FP32      # the split kernels use 32-bit buffer offsets; >= 3.75 GiB activations go fp32
+    if mode == PREC_SPLIT and not _fits32(x, base_weight.size(0)):
+        mode = PREC_FP32
     return _KANLinearFn.apply(x, base_weight, spline_weight, spline_scaler, knots, int(grid_size),
                               int(spline_order), int(mode))
 
@@ -688,8 +688,9 @@ def concat_columns(parts) -> torch.Tensor:
 
 
 def _fits32(x, width) -> bool:
-    """The split kernels address activations with 32-bit byte offsets (< 3.75 GiB incl. prefetch margin)."""
-    return (x.size(0) + (1 << 18)) * max(x.stride(0), width, 1) * 4 < 0xF0000000
+    """The split kernels address activations with 32-bit byte offsets inside per-tile buffer windows: any number of
+    rows, row strides up to 7680 floats (wider inputs take the exact-fp32 kernels)."""
+    return max(x.stride(0) if x.dim() == 2 else 0, x.size(-1), width) <= 7680
 
 
 def fastkan_layer(x, ln_weight, ln_bias, spline_weight, base_weight, base_bias, centers,

@@ -156,3 +156,46 @@ def test_sharded_layer_world1_nccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_activations_beyond_4gib_stay_on_the_split_kernels():
+    """x [20M, 64] fp32 is 5.1 GB: byte offsets no longer fit 32 bits.  The split kernels re-open their buffer windows
+    per workgroup tile, so the layer must (a) not fall back to the fp32 kernels and (b) treat the far rows exactly
+    like the near ones.  Rows are independent in the forward and the input gradient (compare slices against the same
+    kernels on a small tensor); the weight gradient is a sum over rows (compare with the sum over two halves)."""
+    n = 20_000_000
+    torch.manual_seed(11)
+    layer = kagnn_amd.KANLinear(64, 64, grid_size=5, spline_order=3).to(DEV)
+    layer.precision = ops.PREC_SPLIT
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, 64, device=DEV, generator=gen).mul_(0.6).requires_grad_(True)
+    gy = torch.randn(n, 64, device=DEV, generator=gen)
+    assert x.numel() * 4 > (1 << 32) and ops._fits32(x.detach(), 64)      # no fp32 fallback for size
+    timer = ops.EntryPointTimer()
+    ops.set_timer(timer)
+    y = layer(x)
+    y.backward(gy)
+    ops.set_timer(None)
+    torch.cuda.synchronize()
+    assert {"kagnn_kan_linear_fwd", "kagnn_kan_linear_bwd_input", "kagnn_kan_linear_bwd_weight"} <= set(timer.summary())
+    full = {k: p.grad.clone() for k, p in layer.named_parameters()}
+    # slices across the 4 GiB boundary (row 16,777,216 is byte 2^32) and at both ends
+    for lo in (0, (1 << 24) - 700, n - 1500):
+        hi = lo + 1500
+        xs = x.detach()[lo:hi].clone().requires_grad_(True)
+        layer.zero_grad()
+        ys = layer(xs)
+        ys.backward(gy[lo:hi].clone())
+        assert torch.equal(ys, y.detach()[lo:hi]), lo           # same kernels, same per-row arithmetic
+        assert_close(x.grad[lo:hi], xs.grad, tol=1e-6, what=f"gx rows {lo}..")   # per-row scale exponents are row-local
+    del y
+    parts = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in full.items()}
+    half = n // 2
+    for lo, hi in ((0, half), (half, n)):
+        xs = x.detach()[lo:hi]
+        layer.zero_grad()
+        layer(xs.requires_grad_(False)).backward(gy[lo:hi])
+        for k, p in layer.named_parameters():
+            parts[k] += p.grad.double()
+    for k in full:
+        assert_close(full[k], parts[k], tol=1e-4, what=f"{k} gradient = sum over halves")
