@@ -199,3 +199,42 @@ def test_activations_beyond_4gib_stay_on_the_split_kernels():
             parts[k] += p.grad.double()
     for k in full:
         assert_close(full[k], parts[k], tol=1e-4, what=f"{k} gradient = sum over halves")
+
+
+def test_aggregation_and_batchnorm_beyond_4gib():
+    """the same 5.1 GB activation through the neighbour aggregation (both directions) and BatchNorm: column
+    checksums in fp64 and sampled rows against torch on the device"""
+    n, e = 20_000_000, 5_000_000
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(n, 64, device=DEV, generator=gen)
+    src = torch.randint(0, n, (e,), device=DEV, generator=gen)
+    dst = torch.randint(0, n, (e,), device=DEV, generator=gen)
+    dst[: e // 2] = dst[: e // 2] // 2 + n // 2             # half of the messages land beyond byte 2^32
+    gi = ops.GraphIndex(torch.stack([src, dst]), n)
+    for transposed, (a, b) in ((False, (src, dst)), (True, (dst, src))):
+        out = ops._aggregate_raw(x, gi, transposed, 1.0, None, None, None, None, False)
+        want = x.double().sum(0) + x.index_select(0, a).double().sum(0)
+        assert_close(out.double().sum(0), want, 1e-6, what=f"column checksum (transposed={transposed})")
+        rows = b[torch.randint(0, e, (2000,), device=DEV, generator=gen)]
+        rows = torch.cat([rows, torch.tensor([0, n - 1, (1 << 24) - 1, 1 << 24], device=DEV)])
+        ref = x[rows].double()
+        hit = torch.isin(b, rows)
+        ref_full = torch.zeros(n, 1, device=DEV, dtype=torch.float64)      # row -> slot map without an [n, 64] fp64 buffer
+        slot = torch.full((n,), -1, device=DEV, dtype=torch.long)
+        uniq = torch.unique(rows)
+        slot[uniq] = torch.arange(uniq.numel(), device=DEV)
+        acc = torch.zeros(uniq.numel(), 64, device=DEV, dtype=torch.float64)
+        acc.index_add_(0, slot[b[hit]], x[a[hit]].double())
+        assert_close(out[rows].double(), ref + acc[slot[rows]], what=f"sampled rows (transposed={transposed})")
+        del out, ref_full
+    w, bb = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV)
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    xr = x.requires_grad_(True)
+    y = ops.batch_norm(xr, w, bb, rm, rv, True, 0.1, 1e-5)
+    mean, var = x.detach().double().mean(0), x.detach().double().var(0, unbiased=False)
+    for lo in (0, (1 << 24) - 300, n - 1000):
+        want = (x.detach()[lo:lo + 1000].double() - mean) / torch.sqrt(var + 1e-5) * w.double() + bb.double()
+        assert_close(y[lo:lo + 1000], want, what=f"batchnorm rows {lo}..")
+    gyv = torch.ones(1, 64, device=DEV).expand(n, 64)
+    y.backward(gyv)                                                         # d/dx of sum(y) is 0 for batch statistics
+    assert float(xr.grad.abs().max()) < 1e-3
