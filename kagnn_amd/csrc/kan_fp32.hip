@@ -12,6 +12,7 @@
 // x[row,f] in registers and feeds them straight into the matrix core -- the [N,in,G+k] basis
 // tensor of the reference never exists.
 #include "common.h"
+#include "split_common.h"
 
 namespace kagnn {
 
@@ -114,18 +115,25 @@ __global__ __launch_bounds__(256) void kan_fwd_f32_kernel(
 // owns all c for that (n,f), so the contraction over c is register-local.
 constexpr int kDxGroup = 9;   // accumulators held at once (C+1 <= 9 -> single pass)
 
-template <int K, bool PF>
-__global__ __launch_bounds__(256) void kan_dx_f32_kernel(
+// STAGE: the W fragments of one (feature tile, coefficient group) -- [kDxGroup][Q][64 lanes] floats, 72 KB at
+// out = 64 -- are copied to LDS once per workgroup and read from there by all its waves (8 = two per SIMD, so one
+// wave's MFMAs cover the other's post-processing); without it every MFMA waits on its own global load of the B
+// operand (that version ran at 10 % of the fp32 MFMA peak).  Falls back to the unstaged form when the tile does
+// not fit beside the gy tiles (out > 96).  x is read and gx written through buffer descriptors opened at the
+// workgroup's first row (32-bit offsets, the row step in an SGPR): no 64-bit address registers per element.
+template <int K, bool PF, bool STAGE>
+__global__ __launch_bounds__(512) void kan_dx_f32_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
     const float* __restrict__ pack, int OT_total, float* __restrict__ gx, long ldgx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_knots = smem;                       // kMaxKnots
     const int Q = 16 * OT_total, outP = 2 * Q, ldt = outP + 1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     float* s_gy = smem + kMaxKnots + (long)wave * 32 * ldt;
+    float* s_w = smem + kMaxKnots + (long)nw * 32 * ldt;       // STAGE only
     if (threadIdx.x < nknots) s_knots[threadIdx.x] = knots_g[threadIdx.x];
-    const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 32;
+    const long blk0 = (long)blockIdx.x * nw * 32, row0 = blk0 + wave * 32;
     // stage this wave's gy tile [32][outP] (zero padded)
     for (int i = lane; i < 32 * outP; i += 64) {
         const int rr = i / outP, o = i - rr * outP;
@@ -134,14 +142,21 @@ __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
         s_gy[rr * ldt + o] = (row < N && o < out) ? gv : 0.0f;
     }
     __syncthreads();
-    if (row0 >= N) return;
+    if (!STAGE && row0 >= N) return;             // STAGE: every wave keeps walking (barriers below); rows >= N are never stored
     const SplineGeom geom = geom_from_knots(s_knots, nknots);
     const int r = lane & 31, kh = lane >> 5;
     const int CT = C + 1, FT = cdiv(in, 32);
     const float* arow = s_gy + r * ldt + kh * Q;
+    const GBuf xb = gbuf_at(x, N, ldx, in, blk0), gxb = gbuf_at(gx, N, ldgx, in, blk0);
+    const unsigned ldx4 = (unsigned)ldx * 4u, ldgx4 = (unsigned)ldgx * 4u;
+    const unsigned x_rb = (unsigned)(wave * 32 + 4 * kh) * ldx4, gx_rb = (unsigned)(wave * 32 + 4 * kh) * ldgx4;
 
     for (int ft = 0; ft < FT; ++ft) {
         const int f = 32 * ft + r;
+        const unsigned fcol = (unsigned)min(f, in - 1) * 4u;
+        float xq[16];                            // this lane's 16 x values of the tile: they land under the MFMAs
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xq[i] = gld_s(xb, x_rb + fcol, (unsigned)((i & 3) + 8 * (i >> 2)) * ldx4);
         float gacc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) gacc[i] = 0.0f;
@@ -151,7 +166,15 @@ __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
             for (int j = 0; j < kDxGroup; ++j)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) D[j][i] = 0.0f;
-            const float* wp = pack + ((long)ft * CT + c0) * Q * 64 + lane;
+            const float* gsrc = pack + ((long)ft * CT + c0) * Q * 64;
+            if (STAGE) {
+                const int n4 = min(kDxGroup, CT - c0) * Q * 16;           // float4 items
+                __syncthreads();                                           // the previous tile's readers are done
+                for (int i = threadIdx.x; i < n4; i += blockDim.x)
+                    reinterpret_cast<float4*>(s_w)[i] = reinterpret_cast<const float4*>(gsrc)[i];
+                __syncthreads();
+            }
+            const float* wp = (STAGE ? s_w : gsrc) + lane;
             for (int q = 0; q < Q; ++q) {
                 const float a = arow[q];
 #pragma unroll
@@ -161,9 +184,7 @@ __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const long rr = row0 + mfma32_row(i, kh);
-                const bool ok = rr < N && f < in;
-                const float xv = x[min(rr, N - 1) * ldx + min(f, in - 1)];       // clamped; !ok lanes never store
+                const float xv = xq[i];
                 float Nv[K + 1], dN[K + 1];
                 const int m = eval_basis<K, true, PF>(xv, s_knots, geom, knots_g, min(f, in - 1), Nv, dN);
                 const float sg = silu_gradf(xv);
@@ -179,10 +200,10 @@ __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
                 gacc[i] += s;
             }
         }
+        if (f < in) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const long rr = row0 + mfma32_row(i, kh);
-            if (rr < N && f < in) gx[rr * ldgx + f] = gacc[i];
+            for (int i = 0; i < 16; ++i)           // rows >= N fall past the descriptor: dropped
+                gst_s(gxb, gx_rb + fcol, (unsigned)((i & 3) + 8 * (i >> 2)) * ldgx4, gacc[i]);
         }
     }
 }
@@ -192,6 +213,7 @@ __global__ __launch_bounds__(256) void kan_dx_f32_kernel(
 // grid = (NBx, FT*OT): block.y picks the (f-tile, o-tile) role, every wave walks its own row
 // range and writes one partial slab; kan_dw_reduce sums the slabs in a fixed order.
 constexpr int kDwGroup = 9;
+constexpr int kDwAhead = 4;   // row pairs loaded ahead per trip of the weight-gradient loop
 
 template <int K, bool PF>
 __global__ __launch_bounds__(256) void kan_dw_f32_kernel(
@@ -220,22 +242,32 @@ __global__ __launch_bounds__(256) void kan_dw_f32_kernel(
         for (int j = 0; j < kDwGroup; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) D[j][i] = 0.0f;
-        for (long n = rbeg + kh; n < rend + kh; n += 2) {   // both halves run the same trip count
-            const bool nv = n < rend;
-            const long nc = min(n, N - 1);                 // clamped unconditional loads; `live` masks the products
-            const float xv = x[nc * ldx + min(f, in - 1)];
-            const float b = gy[nc * ldgy + min(o, out - 1)];
-            float Nv[K + 1], dummy[K + 1];
-            const int m = eval_basis<K, false, PF>(xv, s_knots, geom, knots_g, min(f, in - 1), Nv, dummy);
-            const float sl = siluf(xv);
-            const bool live = nv && fv;
+        // kDwAhead row pairs per trip: their x / gy loads are all in flight before the first basis is evaluated (one
+        // pair per trip left every trip waiting on its own two loads)
+        for (long n0 = rbeg; n0 < rend; n0 += 2 * kDwAhead) {
+            float xs[kDwAhead], bs[kDwAhead];
 #pragma unroll
-            for (int j = 0; j < kDwGroup; ++j) {
-                const int c = c0 + j;
-                if (c < CT) {
-                    float a = (c == C) ? sl : pick_basis<K>(Nv, m, c);
-                    a = live ? a : 0.0f;
-                    D[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, D[j], 0, 0, 0);
+            for (int u = 0; u < kDwAhead; ++u) {
+                const long nc = min(n0 + 2 * u + kh, N - 1);   // clamped unconditional loads; `live` masks the products
+                xs[u] = x[nc * ldx + min(f, in - 1)];
+                bs[u] = gy[nc * ldgy + min(o, out - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < kDwAhead; ++u) {
+                const bool nv = n0 + 2 * u + kh < rend;
+                const float xv = xs[u], b = bs[u];
+                float Nv[K + 1], dummy[K + 1];
+                const int m = eval_basis<K, false, PF>(xv, s_knots, geom, knots_g, min(f, in - 1), Nv, dummy);
+                const float sl = siluf(xv);
+                const bool live = nv && fv;
+#pragma unroll
+                for (int j = 0; j < kDwGroup; ++j) {
+                    const int c = c0 + j;
+                    if (c < CT) {
+                        float a = (c == C) ? sl : pick_basis<K>(Nv, m, c);
+                        a = live ? a : 0.0f;
+                        D[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, D[j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -361,18 +393,25 @@ int kan_f32_dx(const float* x, long ldx, const float* gy, long ldgy, long N, con
                long ldgx, bool pf, hipStream_t st) {
     const int g = G + 2 * K + 1;   // number of knots
     const int C = G + K, OTt = cdiv(out, 32);
-    int W = 4;                                        // waves per workgroup: as many as the gy tiles leave LDS for
-    while (W > 1 && (kMaxKnots + (size_t)W * 32 * (32 * OTt + 1)) * sizeof(float) > 160 * 1024) W >>= 1;
-    const size_t lds = (kMaxKnots + (size_t)W * 32 * (32 * OTt + 1)) * sizeof(float);
+    // waves per workgroup: 8 (two per SIMD) with the W tile staged in LDS when both fit, else as many as the gy tiles leave room for
+    const size_t wtile = (size_t)kDxGroup * 16 * OTt * 64 * sizeof(float);
+    auto gy_bytes = [&](int w) { return (kMaxKnots + (size_t)w * 32 * (32 * OTt + 1)) * sizeof(float); };
+    int W = 8;
+    while (W > 1 && gy_bytes(W) + wtile > 160 * 1024) W >>= 1;
+    const bool stage = gy_bytes(W) + wtile <= 160 * 1024 && W >= 2;
+    if (!stage) { W = 4; while (W > 1 && gy_bytes(W) > 160 * 1024) W >>= 1; }
+    const size_t lds = gy_bytes(W) + (stage ? wtile : 0);
     if (lds > 160 * 1024) return fail(KAGNN_ERR_UNSUPPORTED, "%s: out_features too large for the fp32 dx kernel", "kan_f32_dx");
+    if ((long)32 * W * max(ldx, ldgx) * 4 >= 0xF0000000L) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension too large", "kan_f32_dx");
     dim3 grid(cdiv(N, 32 * W));
-#define L1(KK, PF)                                                                                \
+#define L2(KK, PF, ST)                                                                            \
     {                                                                                             \
         if (lds > 64 * 1024)                                                                      \
-            KAGNN_HIP(hipFuncSetAttribute((const void*)kan_dx_f32_kernel<KK, PF>,                 \
+            KAGNN_HIP(hipFuncSetAttribute((const void*)kan_dx_f32_kernel<KK, PF, ST>,             \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kan_dx_f32_kernel<KK, PF><<<grid, 64 * W, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, g, pack, OTt, gx, ldgx); \
+        kan_dx_f32_kernel<KK, PF, ST><<<grid, 64 * W, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, g, pack, OTt, gx, ldgx); \
     }
+#define L1(KK, PF) { if (stage) L2(KK, PF, true) else L2(KK, PF, false) }
 #define L(KK) { if (pf) L1(KK, true) else L1(KK, false) }
     switch (K) {
         case 1: L(1) break;
@@ -381,6 +420,7 @@ int kan_f32_dx(const float* x, long ldx, const float* gy, long ldgy, long N, con
         case 4: L(4) break;
         default: return fail(KAGNN_ERR_UNSUPPORTED, "%s: spline_order must be 1..4", "kan_f32_dx");
     }
+#undef L2
 #undef L
 #undef L1
     KAGNN_LAUNCH_CHECK();
