@@ -216,7 +216,7 @@ constexpr int kDwGroup = 9;
 constexpr int kDwAhead = 4;   // row pairs loaded ahead per trip of the weight-gradient loop
 
 template <int K, bool PF>
-__global__ __launch_bounds__(256) void kan_dw_f32_kernel(
+__global__ __launch_bounds__(256, 2) void kan_dw_f32_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots, int OT, long rows_per_wave,
     float* __restrict__ slab) {
