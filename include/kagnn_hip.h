@@ -126,7 +126,7 @@ int kagnn_segment_broadcast(const float* gout, int64_t ldg, float* gx, int64_t l
  *  knots        : ONE row of the module's `grid` buffer, G+2k+1 fp32 values (uniform grid; the host
  *                 side verifies all rows equal and uniform) -- or, with mode KAGNN_PREC_FP32_GRID,
  *                 the whole buffer [in, G+2k+1] with increasing, possibly non-uniform rows
- *  base_weight  [out,in], spline_weight [out,in,G+k], spline_scaler [out,in] or NULL
+ *  base_weight  [out,in] or NULL (no SiLU branch), spline_weight [out,in,G+k], spline_scaler [out,in] or NULL
  *
  * kagnn_kan_pack rearranges (base_weight | spline_weight*scaler) into the MFMA fragment order
  * used by fwd (`pack_fwd`) and by the input-gradient kernel (`pack_dx`); call it whenever the
@@ -161,7 +161,7 @@ int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int
                                int32_t mode, const void* pack_dx, float* gx, int64_t ldgx,
                                void* stream);
 
-/* parameter gradients: g_base_weight[out,in], g_spline_weight[out,in,G+k],
+/* parameter gradients: g_base_weight[out,in] (NULL when not wanted), g_spline_weight[out,in,G+k],
  * g_spline_scaler[out,in] (NULL when the layer has no scaler).  `workspace` holds the per-wave
  * partial sums (size from kagnn_kan_bwd_weight_workspace_bytes); deterministic reduction.   */
 int kagnn_kan_bwd_weight_workspace_bytes(int64_t num_rows, int32_t in_features,

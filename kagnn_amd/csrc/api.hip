@@ -166,7 +166,7 @@ int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in
                    int32_t G, int32_t K, int32_t mode, void* pack_fwd, void* pack_dx, void* stream) {
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
-    KAGNN_CHECK_ARG(bw && sw && pack_fwd && pack_dx, "null array");
+    KAGNN_CHECK_ARG(sw && pack_fwd && pack_dx, "null array");          // base_weight NULL = no SiLU branch
     const bool sf = use_split_fwd(in, out, G, K, mode), sd = use_split_dx(in, out, G, K, mode);
     // each workgroup derives the power-of-two weight scale itself; the hot case takes ONE launch for both layouts
     if (sd && use_sparse_fwd(in, out, G, K, mode) && kan_fused_pack_ok(in, out, G + K))
@@ -241,7 +241,7 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out, "bad shape");
-    KAGNN_CHECK_ARG(knots && sw && g_bw && g_sw && ws, "null array");
+    KAGNN_CHECK_ARG(knots && sw && g_sw && ws, "null array");          // g_base_weight NULL: not wanted
     KAGNN_CHECK_ARG(N == 0 || (x && gy), "null array");
     KAGNN_CHECK_ARG((sc == nullptr) == (g_sc == nullptr), "spline_scaler and its gradient must both be given or both be null");
     if (use_split_dw(in, out, G, K, mode)) {

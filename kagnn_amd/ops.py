@@ -388,8 +388,9 @@ class _KANLinearFn(Function):
         _need_cuda(x, base_weight, spline_weight, spline_scaler, knots)
         x = _rows(x)
         n, fin = x.shape
-        fout = base_weight.size(0)
-        bw, sw = base_weight.contiguous(), spline_weight.contiguous()
+        fout = spline_weight.size(0)
+        bw = None if base_weight is None else base_weight.contiguous()     # None: no SiLU branch (coefficient groups)
+        sw = spline_weight.contiguous()
         sc = None if spline_scaler is None else spline_scaler.contiguous()
         fb, db = _sizes("kagnn_kan_pack_bytes", fin, fout, grid_size, spline_order, mode, outputs=2)
         pack_f, pack_d = _ws(fb, x.device), _ws(db, x.device)
@@ -402,6 +403,7 @@ class _KANLinearFn(Function):
                   spline_order, mode, _ptr(pack_f), _ptr(y), fout, _ptr(ws), wb, _stream())
         ctx.save_for_backward(x, sw, sc, knots, pack_d)
         ctx.dims = (fin, fout, grid_size, spline_order, mode)
+        ctx.has_base = bw is not None
         return y
 
     @staticmethod
@@ -418,7 +420,7 @@ class _KANLinearFn(Function):
                       fout, G, K, mode, _ptr(pack_d), _ptr(gx), fin, _stream())
         if any(ctx.needs_input_grad[1:4]):
             ws = _ws(_sizes("kagnn_kan_bwd_weight_workspace_bytes", n, fin, fout, G, K, mode), x.device)
-            gbw = torch.empty((fout, fin), dtype=torch.float32, device=x.device)
+            gbw = torch.empty((fout, fin), dtype=torch.float32, device=x.device) if ctx.has_base else None
             gsw = torch.empty((fout, fin, G + K), dtype=torch.float32, device=x.device)
             gsc = None if sc is None else torch.empty((fout, fin), dtype=torch.float32, device=x.device)
             _call("kagnn_kan_linear_bwd_weight", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
@@ -441,6 +443,23 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
         mode = default_precision()
     if mode == PREC_SPLIT and not _fits32(x, base_weight.size(0)):
         mode = PREC_FP32
+    n_coef = int(grid_size) + int(spline_order)
+    if mode == PREC_SPLIT and n_coef > 16 and knots.dim() == 1:
+        # More than 16 coefficients per feature (the reference's search space goes to grid_size 32): a uniform
+        # B-spline basis function only depends on its own k+2 knots, so the layer is the SUM of layers over
+        # consecutive coefficient groups, each on its slice of the knot vector -- every group has <= 16 coefficients
+        # and runs on the split-precision kernels (the SiLU branch rides with the first group).
+        groups = -(-n_coef // 16)
+        size, extra = divmod(n_coef, groups)
+        y, c0 = None, 0
+        for g in range(groups):
+            cg = size + (1 if g < extra else 0)
+            part = _KANLinearFn.apply(x, base_weight if g == 0 else None, spline_weight[:, :, c0:c0 + cg], spline_scaler,
+                                      knots[c0:c0 + cg + int(spline_order) + 1], cg - int(spline_order),
+                                      int(spline_order), int(mode))
+            y = part if y is None else y + part
+            c0 += cg
+        return y
     return _KANLinearFn.apply(x, base_weight, spline_weight, spline_scaler, knots, int(grid_size),
                               int(spline_order), int(mode))
 

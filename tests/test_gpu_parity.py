@@ -193,7 +193,10 @@ def test_kan_chain_golden(golden, mode):
                                    (1000, 65, 33, 5, 3), (513, 1433, 32, 4, 3), (300, 200, 7, 4, 3),
                                    (700, 128, 128, 8, 3), (257, 2, 2, 1, 1), (400, 40, 160, 3, 2), (300, 256, 256, 5, 3), (200, 70, 300, 4, 3), (300, 64, 64, 13, 3), (257, 33, 40, 8, 1), (200, 20, 24, 7, 2),
                                    (500, 128, 160, 8, 3), (300, 40, 24, 4, 4), (200, 33, 70, 10, 4), (129, 64, 64, 1, 4),
-                                   (64, 16, 16, 32, 4)])
+                                   (64, 16, 16, 32, 4),
+                                   # more than 16 coefficients: the split mode sums coefficient groups (ops.kan_linear)
+                                   (300, 64, 64, 14, 3), (257, 40, 70, 20, 3), (200, 33, 24, 30, 1), (129, 20, 20, 16, 2),
+                                   (500, 64, 40, 29, 4)])
 def test_kanlinear_ragged_shapes_vs_oracle(shape, mode):
     """ragged / edge shapes (N not a tile multiple, odd widths, Cora-sized input, out > 128) against
     the oracle in fp64; also reports how the HIP error compares with the reference's own fp32 error."""
