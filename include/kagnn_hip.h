@@ -201,7 +201,7 @@ int kagnn_kan_grid_refit(const float* x, int64_t ldx, int64_t num_rows, const fl
  * LayerNorm :77-78, RadialBasisFunction :46-47, SplineLinear :81, base_linear(silu(x)) :82-84)
  * and its autograd backward.  centers = the module's `rbf.grid` parameter (num_grids fp32
  * values, device pointer), denominator as in fastkan.py:44.  `precision` as for the KAN layer
- * (KAGNN_PREC_SPLIT covers num_grids <= 8; other shapes run the exact-fp32 kernels either way).  ln_weight/ln_bias NULL = no layernorm; base_weight NULL = no base branch.
+ * (KAGNN_PREC_SPLIT covers num_grids <= 16; the host sums wider layers over groups of centres).  ln_weight/ln_bias NULL = no layernorm; base_weight NULL = no base branch.
  *   spline_weight [out, in*num_grids]  (in major, grid minor), base_weight [out,in], base_bias [out]
  * ------------------------------------------------------------------------------------------ */
 int kagnn_fastkan_fwd_workspace_bytes(int64_t num_rows, int32_t in_features,

@@ -719,5 +719,22 @@ def fastkan_layer(x, ln_weight, ln_bias, spline_weight, base_weight, base_bias, 
         mode = default_precision()
     if mode == PREC_SPLIT and not _fits32(x, spline_weight.size(0)):
         mode = PREC_FP32
+    ng = centers.numel()
+    if mode == PREC_SPLIT and ng > 16:
+        # more than 16 centres: the layer is a sum over groups of centres (each <= 16, split-precision kernels);
+        # every group normalises x the same way, the base branch rides with the first
+        fout, fin = spline_weight.size(0), spline_weight.size(1) // ng
+        w3 = spline_weight.view(fout, fin, ng)
+        groups = -(-ng // 16)
+        size, extra = divmod(ng, groups)
+        y, c0 = None, 0
+        for g in range(groups):
+            cg = size + (1 if g < extra else 0)
+            part = _FastKANFn.apply(x, ln_weight, ln_bias, w3[:, :, c0:c0 + cg].reshape(fout, fin * cg),
+                                    base_weight if g == 0 else None, base_bias if g == 0 else None,
+                                    centers[c0:c0 + cg], float(denominator), float(ln_eps), int(mode))
+            y = part if y is None else y + part
+            c0 += cg
+        return y
     return _FastKANFn.apply(x, ln_weight, ln_bias, spline_weight, base_weight, base_bias, centers,
                             float(denominator), float(ln_eps), int(mode))

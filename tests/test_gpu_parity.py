@@ -310,7 +310,8 @@ def test_fastkan_layer_golden(golden, mode):
 @pytest.mark.parametrize("shape", [(1, 64, 64, 8, True, True), (300, 256, 256, 8, True, True), (129, 40, 160, 5, True, True),
                                    (1000, 65, 33, 8, False, True), (257, 33, 200, 3, True, False),
                                    (500, 1433, 32, 4, True, True), (64, 16, 16, 12, True, True), (200, 70, 150, 16, True, True),
-                                   (333, 24, 24, 9, False, True), (100, 8, 8, 20, True, True)])
+                                   (333, 24, 24, 9, False, True), (100, 8, 8, 20, True, True),
+                                   (300, 40, 24, 32, True, True), (200, 64, 64, 17, False, True), (150, 33, 20, 25, True, False)])
 def test_fastkan_ragged_shapes_vs_oracle(shape, mode):
     """ragged / wide shapes (out > 128, in > one LDS chunk, num_grids < 8 and > 8, no layernorm, no base
     branch) against the oracle evaluated in fp64."""
