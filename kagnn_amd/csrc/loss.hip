@@ -23,42 +23,74 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-// W lanes per row (power of two <= 64), 256 / W rows per workgroup pass.  stats[row] = (max, sum exp, sum exp of the
-// second softmax); partial[2b], partial[2b+1] = this workgroup's loss sum and row count.
-template <int W>
+// W lanes per row (power of two <= 64), KC classes per lane held in registers (C <= W * KC; KC == 0: any C, the row
+// is re-read from L1/L2 for every pass), kRows rows per group and trip so that enough loads are in flight.
+// stats[row] = (max, sum exp, sum exp of the second softmax); partial[2b], partial[2b+1] = this workgroup's loss sum
+// and row count.
+constexpr int kXentRows = 4;
+
+template <int W, int KC>
 __global__ __launch_bounds__(256) void xent_fwd_kernel(const float* __restrict__ z, long ld, long N, int C,
                                                         const long* __restrict__ y, const unsigned char* __restrict__ mask,
                                                         int pre, float* __restrict__ stats, float* __restrict__ partial) {
-    constexpr int G = 256 / W;
+    constexpr int G = 256 / W, KR = KC > 0 ? KC : 1;
     __shared__ float s_sum[256], s_cnt[256];
     const int l = threadIdx.x & (W - 1), g = threadIdx.x / W;
     float bsum = 0.0f, bcnt = 0.0f;
-    for (long base = (long)blockIdx.x * G; base < N; base += (long)gridDim.x * G) {
-        const long row = base + g;
-        const bool valid = row < N;
-        const float* zr = z + min(row, N - 1) * ld;
-        float m = -INFINITY;
-        for (int c = l; c < C; c += W) m = fmaxf(m, zr[c]);
-        m = group_max<W>(m);
-        float s = 0.0f;
-        for (int c = l; c < C; c += W) s += __expf(zr[c] - m);
-        s = group_sum<W>(s);
-        const long yv = y[min(row, N - 1)];
-        const bool label_ok = yv >= 0 && yv < C;
-        const float zy = zr[label_ok ? yv : 0];
-        float s2 = 0.0f, loss;
-        if (pre) {
-            const float inv = 1.0f / s;                      // = the largest probability: the second softmax's shift
-            for (int c = l; c < C; c += W) s2 += __expf(__expf(zr[c] - m) * inv - inv);
-            s2 = group_sum<W>(s2);
-            loss = -(__expf(zy - m) * inv - inv - __logf(s2));
-        } else {
-            loss = -(zy - m - __logf(s));
+    for (long base = (long)blockIdx.x * G * kXentRows; base < N; base += (long)gridDim.x * G * kXentRows) {
+        float v[kXentRows][KR];
+        long yv[kXentRows];
+#pragma unroll
+        for (int q = 0; q < kXentRows; ++q) {                 // all loads of the trip first
+            const long r = min(base + q * G + g, N - 1);
+            yv[q] = y[r];
+            if (KC > 0) {
+#pragma unroll
+                for (int k = 0; k < KR; ++k) { const int c = l + W * k; v[q][k] = c < C ? z[r * ld + c] : -INFINITY; }
+            }
         }
-        if (!label_ok) loss = __builtin_nanf("");
-        if (l == 0 && valid) {
-            stats[row * 3 + 0] = m; stats[row * 3 + 1] = s; stats[row * 3 + 2] = s2;
-            if (!mask || mask[row]) { bsum += loss; bcnt += 1.0f; }
+#pragma unroll
+        for (int q = 0; q < kXentRows; ++q) {
+            const long row = base + q * G + g;
+            const bool valid = row < N;
+            const float* zr = z + min(row, N - 1) * ld;
+            float m = -INFINITY;
+            if (KC > 0) {
+#pragma unroll
+                for (int k = 0; k < KR; ++k) m = fmaxf(m, v[q][k]);
+            } else {
+                for (int c = l; c < C; c += W) m = fmaxf(m, zr[c]);
+            }
+            m = group_max<W>(m);
+            float s = 0.0f, e[KR];
+            if (KC > 0) {
+#pragma unroll
+                for (int k = 0; k < KR; ++k) { e[k] = __expf(v[q][k] - m); s += e[k]; }       // exp(-inf) = 0 for c >= C
+            } else {
+                for (int c = l; c < C; c += W) s += __expf(zr[c] - m);
+            }
+            s = group_sum<W>(s);
+            const bool label_ok = yv[q] >= 0 && yv[q] < C;
+            const float zy = zr[label_ok ? yv[q] : 0];
+            float s2 = 0.0f, loss;
+            if (pre) {
+                const float inv = 1.0f / s;                  // = the largest probability: the second softmax's shift
+                if (KC > 0) {
+#pragma unroll
+                    for (int k = 0; k < KR; ++k) s2 += (l + W * k < C) ? __expf(e[k] * inv - inv) : 0.0f;
+                } else {
+                    for (int c = l; c < C; c += W) s2 += __expf(__expf(zr[c] - m) * inv - inv);
+                }
+                s2 = group_sum<W>(s2);
+                loss = -(__expf(zy - m) * inv - inv - __logf(s2));
+            } else {
+                loss = -(zy - m - __logf(s));
+            }
+            if (!label_ok) loss = __builtin_nanf("");
+            if (l == 0 && valid) {
+                stats[row * 3 + 0] = m; stats[row * 3 + 1] = s; stats[row * 3 + 2] = s2;
+                if (!mask || mask[row]) { bsum += loss; bcnt += 1.0f; }
+            }
         }
     }
     s_sum[threadIdx.x] = bsum; s_cnt[threadIdx.x] = bcnt;
@@ -84,56 +116,197 @@ __global__ void xent_finish_kernel(const float* __restrict__ partial, int nb, fl
     if (threadIdx.x == 0) { *loss = (float)(s_sum[0] / s_cnt[0]); *count = (float)s_cnt[0]; }   // no rows: NaN, as torch
 }
 
-template <int W>
+template <int W, int KC>
 __global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__ z, long ld, long N, int C,
                                                         const long* __restrict__ y, const unsigned char* __restrict__ mask,
                                                         int pre, const float* __restrict__ stats,
                                                         const float* __restrict__ count, const float* __restrict__ gloss,
                                                         float* __restrict__ gz, long ldg) {
-    constexpr int G = 256 / W;
+    constexpr int G = 256 / W, KR = KC > 0 ? KC : 1;
     const int l = threadIdx.x & (W - 1), g = threadIdx.x / W;
     const float scale = gloss[0] / count[0];
-    for (long base = (long)blockIdx.x * G; base < N; base += (long)gridDim.x * G) {
-        const long row = base + g;
-        const bool valid = row < N;
-        const long r = min(row, N - 1);
-        const float* zr = z + r * ld;
-        const bool on = valid && (!mask || mask[r]);
-        const float m = stats[r * 3], inv = 1.0f / stats[r * 3 + 1], inv2 = 1.0f / stats[r * 3 + 2];
-        const long yv = y[r];
-        float dot = 0.0f;
-        if (pre) {
-            for (int c = l; c < C; c += W) {
-                const float p = __expf(zr[c] - m) * inv;
-                const float d = __expf(p - inv) * inv2 - (c == yv ? 1.0f : 0.0f);
-                dot = fmaf(d, p, dot);
+    for (long base = (long)blockIdx.x * G * kXentRows; base < N; base += (long)gridDim.x * G * kXentRows) {
+        float v[kXentRows][KR], st[kXentRows][3];
+        long yv[kXentRows];
+        bool on[kXentRows];
+#pragma unroll
+        for (int q = 0; q < kXentRows; ++q) {
+            const long row = base + q * G + g, r = min(row, N - 1);
+            yv[q] = y[r];
+            on[q] = row < N && (!mask || mask[r]);
+            st[q][0] = stats[r * 3]; st[q][1] = stats[r * 3 + 1]; st[q][2] = stats[r * 3 + 2];
+            if (KC > 0) {
+#pragma unroll
+                for (int k = 0; k < KR; ++k) { const int c = l + W * k; v[q][k] = c < C ? z[r * ld + c] : -INFINITY; }
             }
-            dot = group_sum<W>(dot);
         }
-        if (!valid) continue;
-        float* gr = gz + row * ldg;
-        for (int c = l; c < C; c += W) {
-            const float p = __expf(zr[c] - m) * inv;
-            float v;
-            if (pre) v = p * (__expf(p - inv) * inv2 - (c == yv ? 1.0f : 0.0f) - dot);
-            else v = p - (c == yv ? 1.0f : 0.0f);
-            gr[c] = on ? v * scale : 0.0f;
+#pragma unroll
+        for (int q = 0; q < kXentRows; ++q) {
+            const long row = base + q * G + g;
+            const bool valid = row < N;
+            const float* zr = z + min(row, N - 1) * ld;
+            const float m = st[q][0], inv = 1.0f / st[q][1], inv2 = 1.0f / st[q][2];
+            float p[KR], d[KR], dot = 0.0f;
+            if (KC > 0) {
+#pragma unroll
+                for (int k = 0; k < KR; ++k) {
+                    p[k] = __expf(v[q][k] - m) * inv;                                  // 0 for c >= C
+                    d[k] = pre ? __expf(p[k] - inv) * inv2 - (l + W * k == yv[q] ? 1.0f : 0.0f) : 0.0f;
+                    dot = fmaf(d[k], p[k], dot);
+                }
+            } else if (pre) {
+                for (int c = l; c < C; c += W) {
+                    const float pc = __expf(zr[c] - m) * inv;
+                    dot = fmaf(__expf(pc - inv) * inv2 - (c == yv[q] ? 1.0f : 0.0f), pc, dot);
+                }
+            }
+            if (pre) dot = group_sum<W>(dot);
+            if (!valid) continue;
+            float* gr = gz + row * ldg;
+            if (KC > 0) {
+#pragma unroll
+                for (int k = 0; k < KR; ++k) {
+                    const int c = l + W * k;
+                    const float val = pre ? p[k] * (d[k] - dot) : p[k] - (c == yv[q] ? 1.0f : 0.0f);
+                    if (c < C) gr[c] = on[q] ? val * scale : 0.0f;
+                }
+            } else {
+                for (int c = l; c < C; c += W) {
+                    const float pc = __expf(zr[c] - m) * inv;
+                    const float val = pre ? pc * (__expf(pc - inv) * inv2 - (c == yv[q] ? 1.0f : 0.0f) - dot)
+                                          : pc - (c == yv[q] ? 1.0f : 0.0f);
+                    gr[c] = on[q] ? val * scale : 0.0f;
+                }
+            }
         }
     }
 }
 
-static int xent_blocks(long N, int W) { return (int)max(1L, min((long)cdiv(N, 256 / W), 2048L)); }
+// ---- few classes (C <= 64, every KAGNN dataset): one THREAD per row.  A wave per row spends ~100 wave instructions
+// on 40 useful values (three cross-lane reductions); here a workgroup stages 256 rows through LDS with coalesced
+// loads (row stride odd => conflict-free), each thread walks its own row, and the backward writes its rows back
+// through the same tile.  ~10 wave instructions per row.
+__device__ __forceinline__ void xent_stage_in(const float* __restrict__ z, long ld, long N, int C, long row0,
+                                              float* tile, int stride) {
+    const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
+#pragma unroll 8
+    for (int p = 0; p < 64; ++p) {
+        const int r = 4 * p + rq;
+        const long row = min(row0 + r, N - 1);
+        if (c < C) tile[r * stride + c] = z[row * ld + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void xent_fwd_rows_kernel(const float* __restrict__ z, long ld, long N, int C,
+                                                             const long* __restrict__ y, const unsigned char* __restrict__ mask,
+                                                             int pre, float* __restrict__ stats, float* __restrict__ partial) {
+    extern __shared__ float tile[];                       // [256][stride]
+    __shared__ float s_sum[256], s_cnt[256];
+    const int stride = C | 1;
+    float bsum = 0.0f, bcnt = 0.0f;
+    for (long row0 = (long)blockIdx.x * 256; row0 < N; row0 += (long)gridDim.x * 256) {
+        __syncthreads();
+        xent_stage_in(z, ld, N, C, row0, tile, stride);
+        __syncthreads();
+        const long row = row0 + threadIdx.x;
+        const float* v = tile + threadIdx.x * stride;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, v[c]);
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s += __expf(v[c] - m);
+        const long yv = y[min(row, N - 1)];
+        const bool label_ok = yv >= 0 && yv < C;
+        const float zy = v[label_ok ? yv : 0];
+        float s2 = 0.0f, loss;
+        if (pre) {
+            const float inv = 1.0f / s;
+            for (int c = 0; c < C; ++c) s2 += __expf(__expf(v[c] - m) * inv - inv);
+            loss = -(__expf(zy - m) * inv - inv - __logf(s2));
+        } else {
+            loss = -(zy - m - __logf(s));
+        }
+        if (!label_ok) loss = __builtin_nanf("");
+        if (row < N) {
+            stats[row * 3 + 0] = m; stats[row * 3 + 1] = s; stats[row * 3 + 2] = s2;
+            if (!mask || mask[row]) { bsum += loss; bcnt += 1.0f; }
+        }
+    }
+    s_sum[threadIdx.x] = bsum; s_cnt[threadIdx.x] = bcnt;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {                      // fixed tree => deterministic
+        if (threadIdx.x < o) { s_sum[threadIdx.x] += s_sum[threadIdx.x + o]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s_sum[0]; partial[2 * blockIdx.x + 1] = s_cnt[0]; }
+}
+
+__global__ __launch_bounds__(256) void xent_bwd_rows_kernel(const float* __restrict__ z, long ld, long N, int C,
+                                                             const long* __restrict__ y, const unsigned char* __restrict__ mask,
+                                                             int pre, const float* __restrict__ stats,
+                                                             const float* __restrict__ count, const float* __restrict__ gloss,
+                                                             float* __restrict__ gz, long ldg) {
+    extern __shared__ float tile[];
+    const int stride = C | 1;
+    const float scale = gloss[0] / count[0];
+    for (long row0 = (long)blockIdx.x * 256; row0 < N; row0 += (long)gridDim.x * 256) {
+        __syncthreads();
+        xent_stage_in(z, ld, N, C, row0, tile, stride);
+        __syncthreads();
+        const long row = row0 + threadIdx.x, r = min(row, N - 1);
+        float* v = tile + threadIdx.x * stride;
+        const bool on = row < N && (!mask || mask[r]);
+        const float m = stats[r * 3], inv = 1.0f / stats[r * 3 + 1], inv2 = 1.0f / stats[r * 3 + 2];
+        const long yv = y[r];
+        const float sc = on ? scale : 0.0f;
+        if (pre) {
+            float dot = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float p = __expf(v[c] - m) * inv;
+                dot = fmaf(__expf(p - inv) * inv2 - (c == yv ? 1.0f : 0.0f), p, dot);
+            }
+            for (int c = 0; c < C; ++c) {
+                const float p = __expf(v[c] - m) * inv;
+                v[c] = p * (__expf(p - inv) * inv2 - (c == yv ? 1.0f : 0.0f) - dot) * sc;
+            }
+        } else {
+            for (int c = 0; c < C; ++c) v[c] = (__expf(v[c] - m) * inv - (c == yv ? 1.0f : 0.0f)) * sc;
+        }
+        __syncthreads();
+        const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p) {
+            const int rr = 4 * p + rq;
+            if (c < C && row0 + rr < N) gz[(row0 + rr) * ldg + c] = tile[rr * stride + c];
+        }
+    }
+}
+
+static int xent_blocks(long N, int W) { return (int)max(1L, min((long)cdiv(N, (256 / W) * kXentRows), 4096L)); }
 static int xent_width(int C) { int w = 4; while (w < C && w < 64) w <<= 1; return w; }
 
-size_t xent_ws_bytes(long N) { return (size_t)2 * 2048 * sizeof(float); }
+size_t xent_ws_bytes(long N) { return (size_t)2 * 4096 * sizeof(float); }
 
 int xent_fwd(const float* z, long ld, long N, int C, const long* y, const unsigned char* mask, int pre, float* loss,
              float* stats, float* count, void* ws, size_t ws_bytes, hipStream_t st) {
     if (ws_bytes < xent_ws_bytes(N)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "xent_fwd");
     float* partial = (float*)ws;
-    const int W = xent_width(C), nb = N > 0 ? xent_blocks(N, W) : 0;
-#define L(WW) xent_fwd_kernel<WW><<<nb, 256, 0, st>>>(z, ld, N, C, y, mask, pre, stats, partial)
-    if (nb) switch (W) { case 4: L(4); break; case 8: L(8); break; case 16: L(16); break; case 32: L(32); break; default: L(64); }
+    const int W = xent_width(C);
+    int nb = N > 0 ? xent_blocks(N, W) : 0;
+    if (C <= 64 && N > 0) {
+        nb = (int)min((long)cdiv(N, 256), 4096L);
+        static bool big_lds = false;                       // 256 rows x 65 floats is just over the 64 KB default
+        if (!big_lds) {
+            KAGNN_HIP(hipFuncSetAttribute((const void*)xent_fwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+            KAGNN_HIP(hipFuncSetAttribute((const void*)xent_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+            big_lds = true;
+        }
+        xent_fwd_rows_kernel<<<nb, 256, (size_t)256 * (C | 1) * sizeof(float), st>>>(z, ld, N, C, y, mask, pre, stats, partial);
+    } else
+#define L(WW, KK) xent_fwd_kernel<WW, KK><<<nb, 256, 0, st>>>(z, ld, N, C, y, mask, pre, stats, partial)
+    if (nb) switch (W) {
+        case 4: L(4, 1); break; case 8: L(8, 1); break; case 16: L(16, 1); break; case 32: L(32, 1); break;
+        default: if (C <= 64) L(64, 1); else if (C <= 128) L(64, 2); else if (C <= 256) L(64, 4); else L(64, 0);
+    }
 #undef L
     KAGNN_LAUNCH_CHECK();
     xent_finish_kernel<<<1, 256, 0, st>>>(partial, nb, loss, count);
@@ -145,8 +318,17 @@ int xent_bwd(const float* z, long ld, long N, int C, const long* y, const unsign
              const float* stats, const float* count, const float* gloss, float* gz, long ldg, hipStream_t st) {
     if (N == 0) return KAGNN_OK;
     const int W = xent_width(C), nb = xent_blocks(N, W);
-#define L(WW) xent_bwd_kernel<WW><<<nb, 256, 0, st>>>(z, ld, N, C, y, mask, pre, stats, count, gloss, gz, ldg)
-    switch (W) { case 4: L(4); break; case 8: L(8); break; case 16: L(16); break; case 32: L(32); break; default: L(64); }
+    if (C <= 64) {
+        const int nbr = (int)min((long)cdiv(N, 256), 4096L);
+        xent_bwd_rows_kernel<<<nbr, 256, (size_t)256 * (C | 1) * sizeof(float), st>>>(z, ld, N, C, y, mask, pre, stats, count, gloss, gz, ldg);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
+#define L(WW, KK) xent_bwd_kernel<WW, KK><<<nb, 256, 0, st>>>(z, ld, N, C, y, mask, pre, stats, count, gloss, gz, ldg)
+    switch (W) {
+        case 4: L(4, 1); break; case 8: L(8, 1); break; case 16: L(16, 1); break; case 32: L(32, 1); break;
+        default: if (C <= 64) L(64, 1); else if (C <= 128) L(64, 2); else if (C <= 256) L(64, 4); else L(64, 0);
+    }
 #undef L
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
