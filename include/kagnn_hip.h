@@ -288,6 +288,14 @@ int kagnn_gat_bwd(const float* xh, int64_t ldx, const float* gout, int64_t ldg, 
                   int64_t ldgx, const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
                   void* stream);
 
+/* gradients of GATConv's attention vectors from the per-node terms kagnn_gat_bwd returns:
+ *   g_att_src[h,c] = sum_n g_src[n,h] * xh[n, h*C + c],  g_att_dst likewise with g_dst   (heads*channels <= 1024).
+ * One pass over xh, deterministic.                                                             */
+int kagnn_gat_att_grad_workspace_bytes(int64_t num_nodes, int32_t heads, int32_t channels, size_t* bytes_host);
+int kagnn_gat_att_grad(const float* xh, int64_t ld, const float* g_src, const float* g_dst, int64_t num_nodes,
+                       int32_t heads, int32_t channels, float* g_att_src, float* g_att_dst,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Loss tail of the timing harness (node_classification_clean/time_model.py:43-45):
  *   out = softmax(logits, dim=1); loss = CrossEntropyLoss()(out[mask], y[mask])

@@ -60,6 +60,8 @@ _SIGNATURES = {
     "kagnn_fastkan_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, _P,
                                     c_float, _P, _P, c_float, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
                                     _P, c_int32, _P, c_size_t, _P]),
+    "kagnn_gat_att_grad_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, POINTER(c_size_t)]),
+    "kagnn_gat_att_grad": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "kagnn_softmax_xent_workspace_bytes": (c_int32, [c_int64, POINTER(c_size_t)]),
     "kagnn_softmax_xent_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, c_int32, _P, _P, _P, _P, c_size_t, _P]),
     "kagnn_softmax_xent_bwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, c_int32, _P, _P, _P, _P, c_int64, _P]),

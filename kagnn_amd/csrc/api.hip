@@ -55,6 +55,8 @@ int kan_grid_refit(const float*, long, long, const float*, const float*, int, in
 size_t xent_ws_bytes(long N);
 int xent_fwd(const float*, long, long, int, const long*, const unsigned char*, int, float*, float*, float*, void*, size_t, hipStream_t);
 int xent_bwd(const float*, long, long, int, const long*, const unsigned char*, int, const float*, const float*, const float*, float*, long, hipStream_t);
+size_t gat_att_grad_ws_bytes(long N, int H, int C);
+int gat_att_grad(const float*, long, const float*, const float*, long, int, int, float*, float*, void*, size_t, hipStream_t);
 size_t bn_ws_bytes(long N, int F);
 int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, float*, long, float*, float*, void*, size_t, hipStream_t);
 int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float*, long, float*, float*, void*, size_t, hipStream_t);
@@ -407,6 +409,19 @@ int kagnn_gat_bwd(const float* xh, int64_t ldx, const float* gout, int64_t ldg, 
     return gat_bwd(xh, ldx, gout, ldg, out, ldo, bias, a_src, a_dst, row_max, row_sum, rowptr, col, perm, rowptr_t, col_t,
                    perm_t, att_src, att_dst, N, H, C, edge_scratch, self_scratch, g_dst, g_src, gx, ldgx, hub_seg, num_hub_seg,
                    hub_threshold, as_stream(stream));
+}
+
+int kagnn_gat_att_grad_workspace_bytes(int64_t N, int32_t H, int32_t C, size_t* bytes) {
+    KAGNN_CHECK_ARG(bytes && N >= 0 && H >= 1 && C >= 1, "bad argument");
+    *bytes = gat_att_grad_ws_bytes(N, H, C);
+    return KAGNN_OK;
+}
+
+int kagnn_gat_att_grad(const float* xh, int64_t ld, const float* g_src, const float* g_dst, int64_t N, int32_t H,
+                       int32_t C, float* g_att_src, float* g_att_dst, void* ws, size_t ws_bytes, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && H >= 1 && C >= 1 && ld >= (int64_t)H * C, "bad shape");
+    KAGNN_CHECK_ARG(g_att_src && g_att_dst && ws && (N == 0 || (xh && g_src && g_dst)), "null array");
+    return gat_att_grad(xh, ld, g_src, g_dst, N, H, C, g_att_src, g_att_dst, ws, ws_bytes, as_stream(stream));
 }
 
 // ---------------------------------------------------------------- harness loss

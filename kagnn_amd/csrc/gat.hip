@@ -585,4 +585,97 @@ int gat_bwd(const float* xh, long ld, const float* gout, long ldg, const float* 
     return KAGNN_OK;
 }
 
+// ------------------------------------------------------------------ gradients of the attention vectors
+// g_att_src[h][c] = sum_n g_src[n][h] * xh[n][h*C + c]  (and the same with g_dst): two skinny [N,H]^T x [N,H,C]
+// contractions -- as torch einsums they ran as two 130 us GEMMs on a 170k-node graph; one pass over xh here,
+// per-workgroup partial sums combined in a fixed order (deterministic).  Also the bias gradient (column sums of
+// gout) when asked for.
+template <int KC>             // columns per thread: H*C <= 64 * KC
+__global__ __launch_bounds__(256) void gat_att_grad_partial_kernel(const float* __restrict__ xh, long ld,
+                                                                   const float* __restrict__ g_src,
+                                                                   const float* __restrict__ g_dst, long N, int H, int C,
+                                                                   long rows_per_block, float* __restrict__ partial) {
+    __shared__ float s_red[4][2][64];
+    const int HC = H * C, cl = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    const long r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    float as[KC], ad[KC];
+    int hk[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { as[k] = 0.0f; ad[k] = 0.0f; hk[k] = min(cl + 64 * k, HC - 1) / C; }
+    for (long n0 = r0 + rq; n0 < r1; n0 += 16) {          // four rows (stride 4) per trip: their loads go out together
+        float v[4][KC], ws[4][KC], wd[4][KC];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long n = min(n0 + 4 * q, N - 1);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                v[q][k] = xh[n * ld + min(cl + 64 * k, HC - 1)];
+                ws[q][k] = g_src[n * H + hk[k]]; wd[q][k] = g_dst[n * H + hk[k]];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (n0 + 4 * q < r1) {
+#pragma unroll
+                for (int k = 0; k < KC; ++k) { as[k] = fmaf(ws[q][k], v[q][k], as[k]); ad[k] = fmaf(wd[q][k], v[q][k], ad[k]); }
+            }
+        }
+    }
+    float* out = partial + (long)blockIdx.x * 2 * HC;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {                         // combine the four row lanes in a fixed order, 64 columns at a time
+        s_red[rq][0][cl] = as[k]; s_red[rq][1][cl] = ad[k];
+        __syncthreads();
+        const int c = cl + 64 * k;
+        if (rq < 2 && c < HC) out[rq * HC + c] = (s_red[0][rq][cl] + s_red[1][rq][cl]) + (s_red[2][rq][cl] + s_red[3][rq][cl]);
+        __syncthreads();
+    }
+}
+
+// g_att[which][c] = sum over workgroups of partial[b][which][c]: 64 columns x 4 interleaved partial chains per
+// workgroup, chains combined in a fixed order
+__global__ __launch_bounds__(256) void gat_att_grad_finish_kernel(const float* __restrict__ partial, int nb, int HC,
+                                                                  float* __restrict__ g_att_src, float* __restrict__ g_att_dst) {
+    __shared__ float s_red[4][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, i = blockIdx.x * 64 + cl;
+    float a = 0.0f;
+    if (i < 2 * HC)
+        for (int b = q; b < nb; b += 4) a += partial[(long)b * 2 * HC + i];
+    s_red[q][cl] = a;
+    __syncthreads();
+    if (q == 0 && i < 2 * HC)
+        (i < HC ? g_att_src : g_att_dst)[i < HC ? i : i - HC] = (s_red[0][cl] + s_red[1][cl]) + (s_red[2][cl] + s_red[3][cl]);
+}
+
+static void att_plan(long N, int* nb, long* rpb) {
+    int b = (int)max(1L, min((long)cdiv(N, 256), 256L));
+    long r = (N + b - 1) / b;
+    *nb = (int)max(1L, (long)cdiv(N, max(r, 1L))); *rpb = max(r, 1L);
+}
+
+size_t gat_att_grad_ws_bytes(long N, int H, int C) {
+    int nb; long rpb;
+    att_plan(N, &nb, &rpb);
+    return (size_t)nb * 2 * H * C * sizeof(float);
+}
+
+int gat_att_grad(const float* xh, long ld, const float* g_src, const float* g_dst, long N, int H, int C, float* g_att_src,
+                 float* g_att_dst, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (H * C > 1024) return fail(KAGNN_ERR_UNSUPPORTED, "%s: heads * channels > 1024", "gat_att_grad");
+    if (ws_bytes < gat_att_grad_ws_bytes(N, H, C)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "gat_att_grad");
+    int nb; long rpb;
+    att_plan(N, &nb, &rpb);
+    if (N == 0) nb = 0;
+    if (nb) {
+        const int kc = cdiv(H * C, 64);
+#define L(KK) gat_att_grad_partial_kernel<KK><<<nb, 256, 0, st>>>(xh, ld, g_src, g_dst, N, H, C, rpb, (float*)ws)
+        if (kc <= 1) L(1); else if (kc <= 2) L(2); else if (kc <= 4) L(4); else if (kc <= 8) L(8); else L(16);
+#undef L
+        KAGNN_LAUNCH_CHECK();
+    }
+    gat_att_grad_finish_kernel<<<cdiv(2 * H * C, 64), 256, 0, st>>>((const float*)ws, nb, H * C, g_att_src, g_att_dst);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 }  // namespace kagnn

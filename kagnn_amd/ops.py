@@ -631,9 +631,16 @@ class _GatFn(Function):
               _ptr(g.perm_t), _ptr(a_s), _ptr(a_d), n, heads, channels, _ptr(gpre), _ptr(gself), _ptr(gd), _ptr(gs),
               _ptr(gx), heads * channels, _ptr(g.hub_seg) if g.num_hub_seg else None, g.num_hub_seg, g.hub_threshold,
               _stream())
-        x3 = xh.reshape(n, heads, channels) if xh.is_contiguous() else xh.contiguous().view(n, heads, channels)
-        g_att_src = torch.einsum("nh,nhc->hc", gs, x3).reshape(ctx.att_shape)      # [H, C] contractions over the nodes
-        g_att_dst = torch.einsum("nh,nhc->hc", gd, x3).reshape(ctx.att_shape)
+        if heads * channels <= 1024:                      # [H, C] contractions over the nodes: one pass over xh
+            ws = _ws(_sizes("kagnn_gat_att_grad_workspace_bytes", n, heads, channels), dev)
+            g_att = torch.empty((2, heads * channels), **f32)
+            _call("kagnn_gat_att_grad", _ptr(xh), _ld(xh), _ptr(gs), _ptr(gd), n, heads, channels, _ptr(g_att),
+                  ctypes.c_void_p(g_att.data_ptr() + 4 * heads * channels), _ptr(ws), ws.numel(), _stream())
+            g_att_src, g_att_dst = g_att[0].reshape(ctx.att_shape), g_att[1].reshape(ctx.att_shape)
+        else:
+            x3 = xh.reshape(n, heads, channels) if xh.is_contiguous() else xh.contiguous().view(n, heads, channels)
+            g_att_src = torch.einsum("nh,nhc->hc", gs, x3).reshape(ctx.att_shape)
+            g_att_dst = torch.einsum("nh,nhc->hc", gd, x3).reshape(ctx.att_shape)
         g_bias = gout.sum(0) if b is not None else None
         return gx, g_att_src, g_att_dst, g_bias, None, None, None
 
