@@ -18,6 +18,8 @@ The GAT variants (``KAGATConv`` / ``FASTKAGATConv``) are outside the hot path (S
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -55,6 +57,10 @@ class FKANLayer(FastKANLayer):
 
 
 # ---------------------------------------------------------------------------------- conv bases
+_SPLIT_READOUT = os.environ.get("KAGNN_SPLIT_READOUT", "1") != "0"
+_SPLIT_READOUT_MIN_ROWS = 400_000
+
+
 class _SumAggregateConv(nn.Module):
     """GIN message passing: ``nn((1 + eps) * x_i + sum_{j -> i} x_j)`` with a fixed eps buffer."""
 
@@ -179,6 +185,10 @@ class _NodeModel(nn.Module):
             x = self.dropout(bn(conv(x, g)))
             outs.append(x)
         if self.skip:
+            # large graphs: read-out over [x | h1 | ... ] without concatenating (12.2 vs 13.3 ms per step at 1M nodes;
+            # on a 170k-node graph the extra launches cancel the saved copies, so small graphs keep the concat)
+            if _SPLIT_READOUT and isinstance(self.lay_out, KANLinear) and x.size(0) >= _SPLIT_READOUT_MIN_ROWS:
+                return self.lay_out.forward_parts(outs)
             x = ops.concat_columns(outs)
         return self.lay_out(x)
 

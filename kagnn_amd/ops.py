@@ -464,6 +464,24 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
                               int(spline_order), int(mode))
 
 
+def kan_linear_parts(parts, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
+                     mode: Optional[int] = None) -> torch.Tensor:
+    """``kan_linear`` on the column-concatenation of ``parts`` without building it: both branches of the layer are
+    sums over input features, so the output is the sum of the layer restricted to each part's columns of the
+    weights.  For the skip-concat read-out of the node models this saves the concatenation, and -- in the backward --
+    the strided gradient slices that had to be copied contiguous for every branch."""
+    y, f0 = None, 0
+    for part in parts:
+        f1 = f0 + part.size(1)
+        sc = None if spline_scaler is None else spline_scaler[:, f0:f1]
+        out = kan_linear(part, base_weight[:, f0:f1], spline_weight[:, f0:f1], sc, knots, grid_size, spline_order, mode)
+        y = out if y is None else y + out
+        f0 = f1
+    if f0 != base_weight.size(1):
+        raise AssertionError("parts do not add up to in_features")
+    return y
+
+
 def kan_bsplines(x, grid, grid_size: int, spline_order: int) -> torch.Tensor:
     """Dense B-spline bases ``[N, in, G+k]`` of ``x[N, in]`` on the per-feature knot rows ``grid[in, G+2k+1]``
     (``KANLinear.b_splines``, ekan.py:79-112).  Not differentiable (the layer never stores this tensor)."""

@@ -826,3 +826,29 @@ def test_softmax_cross_entropy_strided_and_bad_label():
     assert torch.equal(a, b)
     y[7] = 10
     assert torch.isnan(ops.softmax_cross_entropy(z[:, 3:13], y))
+
+
+@pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
+def test_kanlinear_forward_parts_equals_forward_of_concat(mode):
+    """the read-out of the node models on large graphs: KANLinear over [x | h1 | h2] without concatenating"""
+    torch.manual_seed(21)
+    widths = [40, 64, 24]
+    layer = kagnn_amd.KANLinear(sum(widths), 10, grid_size=5, spline_order=3).to(DEV)
+    layer.precision = mode
+    parts = [(torch.randn(700, w, device=DEV) * 0.6).requires_grad_(True) for w in widths]
+    gy = torch.randn(700, 10, device=DEV)
+    y = layer.forward_parts(parts)
+    y.backward(gy)
+    got = {n: p.grad.clone() for n, p in layer.named_parameters()}
+    got_x = [p.grad.clone() for p in parts]
+    layer.zero_grad()
+    whole = torch.cat([p.detach() for p in parts], dim=1).requires_grad_(True)
+    want = layer(whole)
+    want.backward(gy)
+    assert_close(y, want, tol=2e-6, what="y")
+    f0 = 0
+    for p, gx in zip(parts, got_x):
+        assert_close(gx, whole.grad[:, f0:f0 + p.size(1)], tol=2e-6, what="gx part")
+        f0 += p.size(1)
+    for n, p in layer.named_parameters():
+        assert_close(got[n], p.grad, tol=2e-6, what=n)
