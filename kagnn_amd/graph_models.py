@@ -70,6 +70,15 @@ def _num_graphs(data) -> int:
     return int(n) if n is not None else int(data.batch.max()) + 1
 
 
+# the reference's graph-level files name their convolution layers differently from the node-level file
+# (graph_classification/models.py:157-172,... `KAGCN_Layer(GCNConv)`, `KAGAT_Layer(GATConv)`): same layers, same
+# constructor arguments
+KAGCN_Layer = KAGCNConv
+KAGAT_Layer = KAGATConv
+FASTKAGCN_Layer = FASTKAGCNConv
+FASTKAGAT_Layer = FASTKAGATConv
+
+
 class _GraphLevel(nn.Module):
     def _message_passing(self, x, g, edge_attr=None):
         for conv, bn in zip(self.conv, self.bn):
