@@ -132,3 +132,32 @@ def test_ogb_encoders_surface():
     assert a(torch.zeros(3, 9, dtype=torch.long)).shape == (3, 6) and b(torch.ones(4, 3, dtype=torch.long)).shape == (4, 6)
     m = kagnn_amd.KAGINRegression(9, 3, 2, 8, 2, 4, 3, 1, 0.0, ogb_encoders=True)
     assert "atom_encoder.atom_embedding_list.0.weight" in m.state_dict() and "bond_encoder.bond_embedding_list.2.weight" in m.state_dict()
+
+
+def test_size_queries_and_argument_checks_need_no_gpu():
+    """the *_bytes queries are host arithmetic and bad arguments are refused before any HIP call: both work here"""
+    from ctypes import byref, c_size_t
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    a, b = c_size_t(0), c_size_t(0)
+    for mode in (_lib.PREC_FP32, _lib.PREC_SPLIT, _lib.PREC_FP32_GRID):
+        assert lib.kagnn_kan_pack_bytes(64, 64, 5, 3, mode, byref(a), byref(b)) == 0 and a.value > 0 and b.value > 0
+    assert lib.kagnn_kan_bwd_weight_workspace_bytes(1_000_000, 64, 64, 5, 3, _lib.PREC_SPLIT, byref(a)) == 0
+    assert 0 < a.value < (1 << 30)                                   # per-workgroup slabs, not per-row storage
+    assert lib.kagnn_kan_fwd_workspace_bytes(1_000_000, 64, 64, 5, 3, _lib.PREC_SPLIT, byref(a)) == 0 and a.value == 0
+    assert lib.kagnn_kan_fwd_workspace_bytes(2708, 1433, 32, 5, 3, _lib.PREC_SPLIT, byref(a)) == 0 and a.value > 0   # split-K
+    assert lib.kagnn_softmax_xent_workspace_bytes(1000, byref(a)) == 0 and a.value > 0
+    assert lib.kagnn_kan_grid_refit_workspace_bytes(1000, 8, 5, 3, byref(a)) == 0 and a.value > 0
+    assert lib.kagnn_gat_att_grad_workspace_bytes(1000, 4, 16, byref(a)) == 0 and a.value > 0
+    assert lib.kagnn_batchnorm_workspace_bytes(1000, 64, byref(a)) == 0 and a.value > 0
+    # refused with a message, no crash, no device needed
+    assert lib.kagnn_kan_pack_bytes(64, 64, 5, 7, _lib.PREC_SPLIT, byref(a), byref(b)) != 0          # spline order 7
+    assert b"spline_order" in lib.kagnn_last_error()
+    assert lib.kagnn_kan_pack_bytes(64, 64, 5, 3, 9, byref(a), byref(b)) != 0                         # unknown mode
+    assert lib.kagnn_kan_pack_bytes(0, 64, 5, 3, _lib.PREC_SPLIT, byref(a), byref(b)) != 0
+    assert lib.kagnn_kan_linear_fwd(None, 3, 10, None, 64, 64, 5, 3, _lib.PREC_SPLIT, None, None, 64, None, 0, None) != 0   # ldx < in
+    assert b"argument check failed" in lib.kagnn_last_error()
+    assert lib.kagnn_softmax_xent_fwd(None, 4, 10, 40, None, None, 1, None, None, None, None, 0, None) != 0            # ld < classes
+    assert lib.kagnn_kan_grid_refit_workspace_bytes(0, 8, 5, 3, byref(a)) != 0                                         # no rows
