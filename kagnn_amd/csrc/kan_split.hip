@@ -200,11 +200,14 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                     // ---- software pipeline inside the group: while the 6*OT/2 MFMAs of feature j execute, the
                     // VALU expands feature j+1 (or prepares the SiLU fragments after the last feature) and the
                     // LDS reads of its weights / selectors are already in flight.
+                    // With virtual features (sh: two 8-slot windows per input feature) the odd one has the SAME x as
+                    // the even one before it: its cubic pieces and hi/lo payload are reused, only the placement
+                    // (selector row of the second window) differs.
                     u32x4 ahi, alo, bw[2 * OT];
+                    float u; unsigned off_even, h0, h1, l0, l1;
                     {
-                        float u; unsigned off, h0, h1, l0, l1;
-                        frag3_index<false>(xv[0], f3geo, u, off);
-                        const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + off);
+                        frag3_index<false>(xv[0], f3geo, u, off_even);
+                        const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + off_even);
                         const unsigned char* wp = s_w + (size_t)((8 * g) * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
                         for (int i = 0; i < 2 * OT; ++i) bw[i] = *reinterpret_cast<const u32x4*>(wp + i * 1024);
@@ -215,10 +218,11 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         u32x4 nhi, nlo, nbw[2 * OT], sel;
-                        float u; unsigned h0, h1, l0, l1;
+                        const bool reuse = sh && ((j + 1) & 1);   // wave-uniform; j is a compile-time constant
                         if (j < 7) {                      // issue the next feature's LDS reads first
                             unsigned off;
-                            frag3_index<false>(xv[j + 1], f3geo, u, off, ((j + 1) & 1) ? wodd : 0u);
+                            if (reuse) off = off_even + wodd;
+                            else { frag3_index<false>(xv[j + 1], f3geo, u, off_even); off = off_even; }
                             sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + off);
                             const unsigned char* wp = s_w + (size_t)((8 * g + j + 1) * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
 #pragma unroll
                         for (int t = 0; t < OT; ++t) acc[t] = mfma_f16(alo, bw[2 * t], acc[t]);
                         if (j < 7) {
-                            frag3_payload(u, h0, h1, l0, l1);
+                            if (!reuse) frag3_payload(u, h0, h1, l0, l1);
                             frag3_place(sel, h0, h1, l0, l1, nhi, nlo);
                             ahi = nhi; alo = nlo;
 #pragma unroll
