@@ -140,6 +140,15 @@ int kagnn_kan_pack(const float* base_weight, const float* spline_weight,
                    int32_t grid_size, int32_t spline_order, int32_t mode,
                    void* pack_fwd, void* pack_dx, void* stream);
 
+/* kagnn_kan_pack for the layers of a chain (<= 8, same grid_size / spline_order / mode) in ONE launch -- a pack
+ * launch is ~20 us of latency, not work.  Arrays of n_layers HOST-side entries (device pointers / sizes); `sc` may
+ * be NULL (no scalers) or hold NULL entries.  KAGNN_ERR_UNSUPPORTED unless every layer takes the sparse-forward /
+ * split-precision path with out_features <= 64 (the caller then packs layer by layer).                          */
+int kagnn_kan_pack_batch(int32_t n_layers, const float* const* base_weight, const float* const* spline_weight,
+                         const float* const* spline_scaler, const int32_t* in_features,
+                         const int32_t* out_features, int32_t grid_size, int32_t spline_order, int32_t mode,
+                         void* const* pack_fwd, void* const* pack_dx, void* stream);
+
 /* y[N,out] = silu(x) @ base_weight^T + bases(x) @ (spline_weight*scaler)^T.
  * Inputs with few rows and many features (Cora: 2708 x 1433) split the feature loop over more
  * workgroups and sum per-split partial outputs in a fixed order; that needs a scratch buffer of

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "kagnn_kan_pack_bytes": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32,
                                        POINTER(c_size_t), POINTER(c_size_t)]),
     "kagnn_kan_pack": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "kagnn_kan_pack_batch": (c_int32, [c_int32, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
     "kagnn_kan_fwd_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                                 POINTER(c_size_t)]),
     "kagnn_kan_linear_fwd": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, c_int32,

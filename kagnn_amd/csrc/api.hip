@@ -35,6 +35,7 @@ bool kan_split_fwd_ok(int in, int out, int G, int K);
 bool kan_sparse_fwd_ok(int in, int out, int G, int K);
 bool kan_fused_pack_ok(int in, int out, int C);
 int kan_fused_pack(const float*, const float*, const float*, int, int, int, void*, void*, hipStream_t);
+int kan_fused_pack_batch(int, const float* const*, const float* const*, const float* const*, const int*, const int*, int, void* const*, void* const*, hipStream_t);
 size_t kan_sparse_pack_fwd_bytes(int in, int out);
 int kan_sparse_pack_fwd(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 size_t kan_sparse_fwd_ws_bytes(long N, int in, int out);
@@ -182,6 +183,20 @@ int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in
     if (!sf || !sd)
         return kan_f32_pack(bw, sw, sc, in, out, G + K, sf ? nullptr : (float*)pack_fwd, sd ? nullptr : (float*)pack_dx, as_stream(stream));
     return KAGNN_OK;
+}
+
+int kagnn_kan_pack_batch(int32_t n_layers, const float* const* bw, const float* const* sw, const float* const* sc,
+                         const int32_t* in, const int32_t* out, int32_t G, int32_t K, int32_t mode,
+                         void* const* pack_fwd, void* const* pack_dx, void* stream) {
+    KAGNN_CHECK_ARG(n_layers >= 1 && bw && sw && in && out && pack_fwd && pack_dx, "null array");
+    for (int l = 0; l < n_layers; ++l) {
+        int rc = check_kan_dims(__func__, in[l], out[l], G, K, mode);
+        if (rc) return rc;
+        KAGNN_CHECK_ARG(sw[l] && pack_fwd[l] && pack_dx[l], "null array");
+        if (!(use_split_dx(in[l], out[l], G, K, mode) && use_sparse_fwd(in[l], out[l], G, K, mode)))
+            return fail(KAGNN_ERR_UNSUPPORTED, "%s: only layers on the sparse-forward / split path batch their packs", __func__);
+    }
+    return kan_fused_pack_batch(n_layers, bw, sw, sc, in, out, G + K, pack_fwd, pack_dx, as_stream(stream));
 }
 
 int kagnn_kan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,

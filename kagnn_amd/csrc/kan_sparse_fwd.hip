@@ -372,6 +372,51 @@ int kan_fused_pack(const float* bw, const float* sw, const float* sc, int in, in
     return KAGNN_OK;
 }
 
+// the same for up to kPackBatch layers of a chain in ONE launch (each ~22 us pack launch is latency, not work:
+// a two-layer chain saves one of them per step)
+constexpr int kPackBatch = 8;
+struct PackBatch {
+    const float* bw[kPackBatch]; const float* sw[kPackBatch]; const float* sc[kPackBatch];
+    unsigned char* pf[kPackBatch]; unsigned char* pd[kPackBatch];
+    int in[kPackBatch], out[kPackBatch], nbf[kPackBatch], blk0[kPackBatch + 1];
+    int n, C;
+};
+
+__global__ void fused_pack_batch_kernel(PackBatch b) {
+    __shared__ float s_m[17];
+    int l = 0;
+    while (l + 1 < b.n && (int)blockIdx.x >= b.blk0[l + 1]) ++l;                  // block-uniform
+    const int local = blockIdx.x - b.blk0[l], nbl = b.blk0[l + 1] - b.blk0[l];
+    const bool fwd = local < b.nbf[l];
+    const int bid = fwd ? local : local - b.nbf[l], nb = fwd ? b.nbf[l] : nbl - b.nbf[l];
+    const float *bw = b.bw[l], *sw = b.sw[l], *sc = b.sc[l];
+    const int in = b.in[l], out = b.out[l], C = b.C;
+    unsigned char* pack = fwd ? b.pf[l] : b.pd[l];
+    const float wscale = pack_header(bw, sw, sc, in, out, C, pack, bid == 0 && threadIdx.x == 0, s_m);
+    const long first = bid * (long)blockDim.x + threadIdx.x, step = (long)nb * blockDim.x;
+    if (fwd) pack_sparse_items(bw, sw, sc, in, out, C, pack, wscale, first, step);
+    else pack_dx_items(bw, sw, sc, in, out, C, dx_q2(out), pack, wscale, first, step);
+}
+
+int kan_fused_pack_batch(int n, const float* const* bw, const float* const* sw, const float* const* sc, const int* in,
+                         const int* out, int C, void* const* pack_fwd, void* const* pack_dx, hipStream_t st) {
+    if (n < 1 || n > kPackBatch) return fail(KAGNN_ERR_UNSUPPORTED, "%s: 1..8 layers per batch", "kan_fused_pack_batch");
+    PackBatch b{};
+    b.n = n; b.C = C; b.blk0[0] = 0;
+    for (int l = 0; l < n; ++l) {
+        if (!kan_fused_pack_ok(in[l], out[l], C)) return fail(KAGNN_ERR_UNSUPPORTED, "%s: layer shape not covered", "kan_fused_pack_batch");
+        const long items_f = (long)sp_chunks_bytes(in[l], out[l]) / 16;
+        const long items_d = (long)cdiv(in[l], 16) * kCTmax * dx_q2(out[l]) * 64;
+        const int nbf = (int)min((items_f + 1023) / 1024, 48L), nbd = (int)min((items_d + 1023) / 1024, 48L);
+        b.bw[l] = bw[l]; b.sw[l] = sw[l]; b.sc[l] = sc ? sc[l] : nullptr;
+        b.pf[l] = static_cast<unsigned char*>(pack_fwd[l]); b.pd[l] = static_cast<unsigned char*>(pack_dx[l]);
+        b.in[l] = in[l]; b.out[l] = out[l]; b.nbf[l] = nbf; b.blk0[l + 1] = b.blk0[l] + nbf + nbd;
+    }
+    fused_pack_batch_kernel<<<b.blk0[n], 1024, 0, st>>>(b);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 struct SpSplit { int splits, cps; };
 static SpSplit sp_split_plan(long N, int nchunks) {        // same policy as kan_split.hip
     SpSplit p{1, nchunks};

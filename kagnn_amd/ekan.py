@@ -12,12 +12,16 @@ reference's ``reset_parameters`` :57-77); it is not on the hot path.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
 from torch import nn
 
 from . import ops
+
+
+_PACK_CHAIN = os.environ.get("KAGNN_PACK_CHAIN", "1") != "0"     # all layers of a chain packed in one launch
 
 
 def _init_bases(points: torch.Tensor, knots: torch.Tensor, order: int) -> torch.Tensor:
@@ -119,11 +123,11 @@ class KANLinear(nn.Module):
             self._knots_key = key
         return self._knots_row
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, _packed=None) -> torch.Tensor:
         assert x.dim() == 2 and x.size(1) == self.in_features
         scaler = self.spline_scaler if self.enable_standalone_scale_spline else None
         return ops.kan_linear(x, self.base_weight, self.spline_weight, scaler, self._knots(),
-                              self.grid_size, self.spline_order, self.precision)
+                              self.grid_size, self.spline_order, self.precision, _packed)
 
     def forward_parts(self, parts) -> torch.Tensor:
         """``forward(torch.cat(parts, dim=1))`` without the concatenation (``ops.kan_linear_parts``)."""
@@ -184,11 +188,26 @@ class KAN(nn.Module):
             for a, b in zip(layers_hidden[:-1], layers_hidden[1:]))
 
     def forward(self, x: torch.Tensor, update_grid=False) -> torch.Tensor:
-        for layer in self.layers:
+        packs = None
+        if _PACK_CHAIN and not update_grid and x.is_cuda and len(self.layers) > 1:
+            packs = self._pack_chain(x)
+        for i, layer in enumerate(self.layers):
             if update_grid:
                 layer.update_grid(x)
-            x = layer(x)
+            x = layer(x) if packs is None else layer(x, _packed=packs[i])
         return x
+
+    def _pack_chain(self, x):
+        """all layers' weight packs in one launch when the chain runs on the sparse-forward / split kernels"""
+        first = self.layers[0]
+        mode = first.precision if first.precision is not None else ops.default_precision()
+        if mode != ops.PREC_SPLIT or any(l.precision != first.precision or l._knots().dim() != 1 for l in self.layers):
+            return None
+        if x.size(0) == 0 or not ops._fits32(x, 1):
+            return None
+        return ops.kan_pack_chain([(l.base_weight, l.spline_weight,
+                                    l.spline_scaler if l.enable_standalone_scale_spline else None) for l in self.layers],
+                                  self.grid_size, self.spline_order, mode)
 
     def regularization_loss(self, regularize_activation=1.0, regularize_entropy=1.0):
         return sum(l.regularization_loss(regularize_activation, regularize_entropy) for l in self.layers)

@@ -382,9 +382,42 @@ def segment_pool(x, seg_ptr, mean: bool = False) -> torch.Tensor:
 
 
 # ======================================================================== efficient-KAN layer
+def kan_pack_chain(layers, grid_size: int, spline_order: int, mode: int):
+    """Pack the weights of all layers of a KAN chain in ONE launch (``kagnn_kan_pack_batch``): ``layers`` is a list of
+    ``(base_weight, spline_weight, spline_scaler_or_None)``.  Returns ``[(pack_fwd, pack_dx, key), ...]`` to hand to
+    ``kan_linear(..., packed=)``, or ``None`` when the shapes are not covered (each layer then packs itself)."""
+    n = len(layers)
+    if not (2 <= n <= 8) or mode != PREC_SPLIT or spline_order != 3 or grid_size + spline_order > 8:
+        return None
+    if any(sw.size(0) > 64 or not sw.is_cuda for _, sw, _ in layers):
+        return None
+    dev = layers[0][1].device
+    keep, packs = [], []
+    arr = lambda vals, ty: (ty * n)(*vals)
+    bws, sws, scs, ins, outs, pfs, pds = [], [], [], [], [], [], []
+    for bw, sw, sc in layers:
+        bw_c, sw_c = bw.detach().contiguous(), sw.detach().contiguous()
+        sc_c = None if sc is None else sc.detach().contiguous()
+        keep += [bw_c, sw_c, sc_c]
+        fout, fin = sw_c.size(0), sw_c.size(1)
+        fb, db = _sizes("kagnn_kan_pack_bytes", fin, fout, grid_size, spline_order, mode, outputs=2)
+        pf, pd = _ws(fb, dev), _ws(db, dev)
+        packs.append((pf, pd, _weights_key(bw, sw, sc)))
+        bws.append(bw_c.data_ptr()); sws.append(sw_c.data_ptr()); scs.append(0 if sc_c is None else sc_c.data_ptr())
+        ins.append(fin); outs.append(fout); pfs.append(pf.data_ptr()); pds.append(pd.data_ptr())
+    vp = ctypes.c_void_p
+    _call("kagnn_kan_pack_batch", n, arr(bws, vp), arr(sws, vp), arr(scs, vp), arr(ins, ctypes.c_int32),
+          arr(outs, ctypes.c_int32), int(grid_size), int(spline_order), int(mode), arr(pfs, vp), arr(pds, vp), _stream())
+    return packs
+
+
+def _weights_key(bw, sw, sc):
+    return tuple((t.data_ptr(), t._version) for t in (bw, sw, sc) if t is not None)
+
+
 class _KANLinearFn(Function):
     @staticmethod
-    def forward(ctx, x, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode):
+    def forward(ctx, x, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, packed=None):
         _need_cuda(x, base_weight, spline_weight, spline_scaler, knots)
         x = _rows(x)
         n, fin = x.shape
@@ -392,10 +425,13 @@ class _KANLinearFn(Function):
         bw = None if base_weight is None else base_weight.contiguous()     # None: no SiLU branch (coefficient groups)
         sw = spline_weight.contiguous()
         sc = None if spline_scaler is None else spline_scaler.contiguous()
-        fb, db = _sizes("kagnn_kan_pack_bytes", fin, fout, grid_size, spline_order, mode, outputs=2)
-        pack_f, pack_d = _ws(fb, x.device), _ws(db, x.device)
-        _call("kagnn_kan_pack", _ptr(bw), _ptr(sw), _ptr(sc), fin, fout, grid_size, spline_order, mode,
-                  _ptr(pack_f), _ptr(pack_d), _stream())
+        if packed is not None and packed[2] == _weights_key(base_weight, spline_weight, spline_scaler):
+            pack_f, pack_d = packed[0], packed[1]         # packed with its chain (kan_pack_chain), weights unchanged since
+        else:
+            fb, db = _sizes("kagnn_kan_pack_bytes", fin, fout, grid_size, spline_order, mode, outputs=2)
+            pack_f, pack_d = _ws(fb, x.device), _ws(db, x.device)
+            _call("kagnn_kan_pack", _ptr(bw), _ptr(sw), _ptr(sc), fin, fout, grid_size, spline_order, mode,
+                      _ptr(pack_f), _ptr(pack_d), _stream())
         y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
         wb = _sizes("kagnn_kan_fwd_workspace_bytes", n, fin, fout, grid_size, spline_order, mode)
         ws = _ws(wb, x.device) if wb else None
@@ -426,11 +462,11 @@ class _KANLinearFn(Function):
             _call("kagnn_kan_linear_bwd_weight", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
                       fout, G, K, mode, _ptr(sw), _ptr(sc), _ptr(gbw), _ptr(gsw), _ptr(gsc), _ptr(ws),
                       ws.numel(), _stream())
-        return gx, gbw, gsw, gsc, None, None, None, None
+        return gx, gbw, gsw, gsc, None, None, None, None, None
 
 
 def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
-               mode: Optional[int] = None) -> torch.Tensor:
+               mode: Optional[int] = None, packed=None) -> torch.Tensor:
     """y = silu(x) @ base_weight.T + bases(x) @ (spline_weight*scaler).T  (ekan.py:154-162).
     ``knots`` is ONE row of the layer's grid buffer (uniform), fp32 [G+2k+1] on the device -- or the whole
     buffer [in, G+2k+1] when its rows differ / are non-uniform (after ``update_grid``): that runs the exact-fp32
@@ -443,6 +479,8 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
         mode = default_precision()
     if mode == PREC_SPLIT and not _fits32(x, base_weight.size(0)):
         mode = PREC_FP32
+    if mode != PREC_SPLIT:
+        packed = None                                    # chain packs are in the split kernels' layout
     n_coef = int(grid_size) + int(spline_order)
     if mode == PREC_SPLIT and n_coef > 16 and knots.dim() == 1:
         # More than 16 coefficients per feature (the reference's search space goes to grid_size 32): a uniform
@@ -461,7 +499,7 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
             c0 += cg
         return y
     return _KANLinearFn.apply(x, base_weight, spline_weight, spline_scaler, knots, int(grid_size),
-                              int(spline_order), int(mode))
+                              int(spline_order), int(mode), packed)
 
 
 def kan_linear_parts(parts, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
