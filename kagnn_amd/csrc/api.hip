@@ -36,9 +36,9 @@ bool kan_sparse_fwd_ok(int in, int out, int G, int K);
 bool kan_fused_pack_ok(int in, int out, int C);
 int kan_fused_pack(const float*, const float*, const float*, int, int, int, void*, void*, hipStream_t);
 int kan_fused_pack_batch(int, const float* const*, const float* const*, const float* const*, const int*, const int*, int, void* const*, void* const*, hipStream_t);
-size_t kan_sparse_pack_fwd_bytes(int in, int out);
+size_t kan_sparse_pack_fwd_bytes(int in, int out, int C);
 int kan_sparse_pack_fwd(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
-size_t kan_sparse_fwd_ws_bytes(long N, int in, int out);
+size_t kan_sparse_fwd_ws_bytes(long N, int in, int out, int C);
 int kan_sparse_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t);
 bool kan_split_dx_ok(int in, int out, int G, int K);
 bool kan_split_dw_ok(int in, int out, int G, int K);
@@ -159,7 +159,7 @@ int kagnn_kan_pack_bytes(int32_t in, int32_t out, int32_t G, int32_t K, int32_t 
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(fwd_bytes && dx_bytes, "null output");
-    *fwd_bytes = use_sparse_fwd(in, out, G, K, mode) ? kan_sparse_pack_fwd_bytes(in, out)
+    *fwd_bytes = use_sparse_fwd(in, out, G, K, mode) ? kan_sparse_pack_fwd_bytes(in, out, G + K)
                : use_split_fwd(in, out, G, K, mode) ? kan_split_pack_fwd_bytes(in, out, G + K) : kan_f32_pack_fwd_bytes(in, out, G + K);
     *dx_bytes = use_split_dx(in, out, G, K, mode) ? kan_split_pack_dx_bytes(in, out, G + K) : kan_f32_pack_dx_bytes(in, out, G + K);
     return KAGNN_OK;
@@ -204,7 +204,7 @@ int kagnn_kan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G,
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
-    *bytes = use_sparse_fwd(in, out, G, K, mode) ? kan_sparse_fwd_ws_bytes(N, in, out)
+    *bytes = use_sparse_fwd(in, out, G, K, mode) ? kan_sparse_fwd_ws_bytes(N, in, out, G + K)
            : use_split_fwd(in, out, G, K, mode) ? kan_split_fwd_ws_bytes(N, in, out, G + K) : 0;
     return KAGNN_OK;
 }

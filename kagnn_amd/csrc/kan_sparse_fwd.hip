@@ -1,4 +1,5 @@
-// KANLinear forward for cubic splines with <= 8 coefficients per feature on the 2:4-SPARSE matrix cores
+// KANLinear forward for cubic splines with <= 16 coefficients per feature (9..16: two 8-slot windows per input
+// feature, the second one reusing the first one's cubic pieces) on the 2:4-SPARSE matrix cores
 // (v_smfmac_f32_32x32x32_f16).  Same numerics as kan_split.hip (fp16 hi/lo split operands, three products per
 // fp32 product, fp32 accumulate) -- the sparse instruction multiplies exactly the stored values, so results are
 // bit-identical to the dense formulation -- at half the matrix-core work:
@@ -29,13 +30,16 @@ __host__ __device__ inline size_t sparse_fwd_chunk_bytes(int OT) {
     return (size_t)kSpSteps * OT * 2 * 2048 + (size_t)(kSpCF / 16) * OT * 2 * 1024;
 }
 
-bool kan_sparse_fwd_ok(int in, int out, int G, int K) { return K == 3 && G + K <= 8; }
+bool kan_sparse_fwd_ok(int in, int out, int G, int K) { return K == 3 && G + K <= 16; }
+// 9..16 coefficients: 2*in virtual features of 8 slots (wcat_v), as in kan_split.hip
+__host__ __device__ inline int sp_sh(int C) { return C > 8 ? 1 : 0; }
 
 // one output block of the pack: header, chunks, then an fp32 copy of the block's base weights [ob][in] for the exact
 // SiLU path (so the forward entry point needs nothing but the pack)
-static size_t sp_chunks_bytes(int in, int ob) { return (size_t)cdiv(in, kSpCF) * sparse_fwd_chunk_bytes(cdiv(ob, 32)); }
-static size_t sp_blk_bytes(int in, int ob) { return kHdrBytes + sp_chunks_bytes(in, ob) + (((size_t)ob * in * 4 + 255) & ~(size_t)255); }
-size_t kan_sparse_pack_fwd_bytes(int in, int out) { return (size_t)cdiv(out, kSpOutBlk) * sp_blk_bytes(in, min(out, kSpOutBlk)); }
+// `inv` = number of (virtual) features = in << sp_sh(C)
+static size_t sp_chunks_bytes(int inv, int ob) { return (size_t)cdiv(inv, kSpCF) * sparse_fwd_chunk_bytes(cdiv(ob, 32)); }
+static size_t sp_blk_bytes(int in, int inv, int ob) { return kHdrBytes + sp_chunks_bytes(inv, ob) + (((size_t)ob * in * 4 + 255) & ~(size_t)255); }
+size_t kan_sparse_pack_fwd_bytes(int in, int out, int C) { return (size_t)cdiv(out, kSpOutBlk) * sp_blk_bytes(in, in << sp_sh(C), min(out, kSpOutBlk)); }
 
 // K position p of a feature's 8-slot block holds coefficient slot slot_at(p): order [0,4,1,5,2,6,3,7]
 __host__ __device__ inline int slot_at(int p) { return (p >> 1) + 4 * (p & 1); }
@@ -48,8 +52,9 @@ __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, 
     const size_t chunk_bytes = sparse_fwd_chunk_bytes(OT);
     const long spl_per_chunk = (long)kSpSteps * OT * 128, base_per_chunk = (long)BPC * OT * 64;   // spline items: (lane, half)
     const long per_chunk = spl_per_chunk + base_per_chunk;
-    const long total = (long)cdiv(in, kSpCF) * per_chunk;
-    float* bcopy = reinterpret_cast<float*>(pack + kHdrBytes + (size_t)cdiv(in, kSpCF) * chunk_bytes);
+    const int sh = sp_sh(C), inv = in << sh;
+    const long total = (long)cdiv(inv, kSpCF) * per_chunk;
+    float* bcopy = reinterpret_cast<float*>(pack + kHdrBytes + (size_t)cdiv(inv, kSpCF) * chunk_bytes);
     for (long i = first; i < (long)out * in; i += step) bcopy[i] = bw ? bw[i] : 0.0f;      // unscaled fp32 base weights
     for (long i = first; i < total; i += step) {
         const int ch = i / per_chunk; long r = i % per_chunk;
@@ -65,7 +70,7 @@ __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, 
             const int f = ch * kSpCF + h * HF + 2 * t + kg;
             for (int p = 0; p < 8; ++p) {
                 const int slot = slot_at(p);
-                const float w = wcat_s(bw, sw, sc, in, out, C, o, f, slot < C ? slot : C + 1) * wscale;
+                const float w = wcat_v(bw, sw, sc, in, out, C, o, f, slot, sh) * wscale;     // f: (virtual) feature
                 const _Float16 hv = (_Float16)w;
                 dh[p] = hv;
                 dl[p] = (_Float16)(w - (float)hv);
@@ -79,7 +84,7 @@ __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, 
             _Float16* bl = reinterpret_cast<_Float16*>(cbase + (size_t)kSpSteps * OT * 2 * 2048 + ((size_t)(sb * OT + ot) * 2 + 1) * 1024 + lane * 16);
             for (int j = 0; j < 8; ++j) {                 // base weight of feature j of the group, fp16 hi / lo
                 const int f = ch * kSpCF + (lane >> 5) * HF + 8 * sb + j;
-                const float w = wcat_s(bw, sw, sc, in, out, C, o, f, C) * wscale;
+                const float w = wcat_v(bw, sw, sc, in, out, C, o, f, 8, sh) * wscale;
                 const _Float16 hv = (_Float16)w;
                 bh[j] = hv;
                 bl[j] = (_Float16)(w - (float)hv);
@@ -124,9 +129,10 @@ __global__ void fused_pack_kernel(const float* __restrict__ bw, const float* __r
 
 // per span index i = floor((x-g0)/h) + 1 (clamped to [0,31]): {selector of group 0, selector of group 1, index byte}
 // -- which payload halves (r = slot - c0, c0 = i - 4) land in the two stored values of each K group, and where.
-__device__ __forceinline__ void build_sparse_table(unsigned* tbl /* LDS, 32*4 */, int tid, int nknots) {
-    if (tid < 32) {
-        const int i = tid, c0 = i - 4;
+// Second window (9..16 coefficients, slots 8..15 of the feature): the same table shifted by 8 slots, 512 bytes on.
+__device__ __forceinline__ void build_sparse_table(unsigned* tbl /* LDS, 2*32*4 */, int tid, int nknots) {
+    if (tid < 64) {
+        const int i = tid & 31, c0 = i - 4 - 8 * (tid >> 5);
         const bool live = (i >= 1) && (i <= nknots - 1);
         unsigned sel[2] = {0x0c0c0c0cu, 0x0c0c0c0cu}, ib = 0;
         for (int g = 0; g < 2; ++g) {
@@ -147,7 +153,7 @@ __device__ __forceinline__ void build_sparse_table(unsigned* tbl /* LDS, 32*4 */
             sel[g] = s;
             ib |= (unsigned)(pos[0] | (pos[1] << 2)) << (4 * g);
         }
-        tbl[4 * i + 0] = sel[0]; tbl[4 * i + 1] = sel[1]; tbl[4 * i + 2] = ib; tbl[4 * i + 3] = 0;
+        tbl[4 * tid + 0] = sel[0]; tbl[4 * tid + 1] = sel[1]; tbl[4 * tid + 2] = ib; tbl[4 * tid + 3] = 0;
     }
 }
 
@@ -159,7 +165,7 @@ __device__ __forceinline__ f32x16 smfmac(const u32x4& a, const u32x4& b0, const 
 
 // 512 threads = 8 waves (2 per SIMD), one wave = 32 rows; persistent workgroups, packed W resident in LDS when the
 // layer has one chunk (in <= 64), split-K over blockIdx.y for few-row inputs (see kan_split.hip).
-template <int OT>
+template <int OT, bool SH>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
 __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g, int nknots,
     const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy, int out,
@@ -196,7 +202,12 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         const GBuf xb = gbuf_at(x, N, ldx, in, tile0);
         const unsigned ro = (unsigned)(wave * 32 + r) * ldx4 + kg * HF * 4;   // rows >= N: past the descriptor -> zeros
         const unsigned so = (unsigned)(ch * CF + 8 * g) * 4u;
-        if (al4 && ch * CF + CF <= in) {                  // wave-uniform
+        if constexpr (SH) {                               // 4 input features, each feeding its two windows
+            const int f0 = (ch * CF + kg * HF + 8 * g) >> 1;
+            const unsigned rb = (unsigned)(wave * 32 + r) * ldx4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[2 * i] = gld(xb, rb + min(f0 + i, in - 1) * 4); v[2 * i + 1] = v[2 * i]; }
+        } else if (al4 && ch * CF + CF <= in) {           // wave-uniform
             gld4_s(xb, ro, so, v);
             gld4_s(xb, ro, so + 16, v + 4);
         } else {
@@ -207,12 +218,10 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         }
     };
     // one scalar -> its two stored dwords (hi and lo parts) and its index byte
-    auto expand1 = [&](float xv, const u32x4& e, float u, unsigned& hi0, unsigned& hi1, unsigned& lo0, unsigned& lo1) {
-        unsigned h0, h1, l0, l1;
-        frag3_payload(u, h0, h1, l0, l1);
+    auto place1 = [&](const u32x4& e, unsigned h0, unsigned h1, unsigned l0, unsigned l1, unsigned& hi0, unsigned& hi1,
+                      unsigned& lo0, unsigned& lo1) {
         hi0 = __builtin_amdgcn_perm(h1, h0, e[0]); hi1 = __builtin_amdgcn_perm(h1, h0, e[1]);
         lo0 = __builtin_amdgcn_perm(l1, l0, e[0]); lo1 = __builtin_amdgcn_perm(l1, l0, e[1]);
-        (void)xv;
     };
 
     float xn[8];
@@ -249,7 +258,8 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                 auto prep_reads = [&](int s, u32x4& e0, u32x4& e1, float& u0, float& u1, u32x4 (&w)[4 * OT]) {
                     unsigned o0, o1;
                     frag3_index<false>(xv[2 * s], f3geo, u0, o0);
-                    frag3_index<false>(xv[2 * s + 1], f3geo, u1, o1);
+                    if constexpr (SH) { u1 = u0; o1 = o0 + 512u; }      // same x, second window's table
+                    else frag3_index<false>(xv[2 * s + 1], f3geo, u1, o1);
                     e0 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + o0);
                     e1 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + o1);
                     const unsigned char* wp = s_w + (size_t)((4 * g + s) * OT) * 2 * 2048 + lane * 32;
@@ -260,9 +270,11 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     }
                 };
                 auto build = [&](int s, const u32x4& e0, const u32x4& e1, float u0, float u1, u32x4& hi, u32x4& lo, int& idx) {
-                    unsigned a0, a1, a2, a3, b0, b1, b2, b3;
-                    expand1(xv[2 * s], e0, u0, a0, a1, b0, b1);
-                    expand1(xv[2 * s + 1], e1, u1, a2, a3, b2, b3);
+                    unsigned a0, a1, a2, a3, b0, b1, b2, b3, h0, h1, l0, l1;
+                    frag3_payload(u0, h0, h1, l0, l1);
+                    place1(e0, h0, h1, l0, l1, a0, a1, b0, b1);
+                    if constexpr (!SH) frag3_payload(u1, h0, h1, l0, l1);   // SH: the pair shares x -- one payload, two placements
+                    place1(e1, h0, h1, l0, l1, a2, a3, b2, b3);
                     hi = u32x4{a0, a1, a2, a3};
                     lo = u32x4{b0, b1, b2, b3};
                     idx = (int)(e0[2] | (e1[2] << 8));
@@ -322,7 +334,8 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
 #pragma unroll
                         for (int t = 0; t < OT; ++t) {
                             const int o = 32 * t + r;
-                            const float w = (o < out && f0 + j < in) ? base_w[(long)o * in + f0 + j] : 0.0f;
+                            const int fr = SH ? (f0 + j) >> 1 : f0 + j;          // SH: only the first window carries the base weight
+                            const float w = (o < out && fr < in && !(SH && (j & 1))) ? base_w[(long)o * in + fr] : 0.0f;
                             acc_f[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j] * 0.0625f, w, acc_f[t], 0, 0, 0);
                         }
                     }
@@ -346,11 +359,12 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
 // ------------------------------------------------------------------ host side
 int kan_sparse_pack_fwd(const float* bw, const float* sw, const float* sc, int in, int out, int C, void* pack_fwd,
                         hipStream_t st) {
-    const size_t stride = sp_blk_bytes(in, min(out, kSpOutBlk));
+    const int inv = in << sp_sh(C);
+    const size_t stride = sp_blk_bytes(in, inv, min(out, kSpOutBlk));
     for (int b = 0; b * kSpOutBlk < out; ++b) {
         const int ob = min(kSpOutBlk, out - b * kSpOutBlk);
         const long o0 = (long)b * kSpOutBlk;
-        const long items = (long)sp_chunks_bytes(in, ob) / 16;
+        const long items = (long)sp_chunks_bytes(inv, ob) / 16;
         sparse_pack_fwd_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(
             bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C,
             static_cast<unsigned char*>(pack_fwd) + b * stride);
@@ -428,8 +442,8 @@ static SpSplit sp_split_plan(long N, int nchunks) {        // same policy as kan
     return p;
 }
 
-size_t kan_sparse_fwd_ws_bytes(long N, int in, int out) {
-    const SpSplit p = sp_split_plan(N, cdiv(in, kSpCF));
+size_t kan_sparse_fwd_ws_bytes(long N, int in, int out, int C) {
+    const SpSplit p = sp_split_plan(N, cdiv(in << sp_sh(C), kSpCF));
     return p.splits > 1 ? (size_t)p.splits * N * min(out, kSpOutBlk) * sizeof(float) : 0;
 }
 
@@ -442,45 +456,47 @@ __global__ void sparse_sum_splits_kernel(const float* __restrict__ part, int spl
     y[(i / out) * ldy + (i % out)] = a;
 }
 
-template <int OT>
+template <int OT, bool SH>
 static int launch_sparse(const float* x, long ldx, long N, int in, const float* knots, int nknots,
                          const unsigned char* pack, float* y, long ldy, int out, float* ws, size_t ws_bytes,
                          hipStream_t st) {
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    const int nchunks = cdiv(in, kSpCF);
+    const int nchunks = cdiv(in << (SH ? 1 : 0), kSpCF);
     const int gx = (int)min((long)cdiv(N, 256), 256L);
     const SpSplit p = sp_split_plan(N, nchunks);
     if (p.splits > 1) {
         if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_sparse_fwd");
-        kan_sparse_fwd_kernel<OT><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
+        kan_sparse_fwd_kernel<OT, SH><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
                                                                          p.cps, N * (long)out);
         KAGNN_LAUNCH_CHECK();
         sparse_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
         KAGNN_LAUNCH_CHECK();
         return KAGNN_OK;
     }
-    kan_sparse_fwd_kernel<OT><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L);
+    kan_sparse_fwd_kernel<OT, SH><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
 
 int kan_sparse_fwd(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
                    const void* pack, float* y, long ldy, void* ws, size_t ws_bytes, hipStream_t st) {
-    const int nk = G + 2 * K + 1;
-    const size_t stride = sp_blk_bytes(in, min(out, kSpOutBlk));
+    const int nk = G + 2 * K + 1, sh = sp_sh(G + K);
+    const size_t stride = sp_blk_bytes(in, in << sh, min(out, kSpOutBlk));
     for (int b = 0; b * kSpOutBlk < out; ++b) {
         const int ob = min(kSpOutBlk, out - b * kSpOutBlk), OT = cdiv(ob, 32);
         const unsigned char* p = static_cast<const unsigned char*>(pack) + b * stride;
         float* yb = y + b * kSpOutBlk;
         int rc;
-        if (OT == 1) rc = launch_sparse<1>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, st);
-        else rc = launch_sparse<2>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, st);
+#define L(OO, SS) launch_sparse<OO, SS>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, st)
+        if (sh) rc = OT == 1 ? L(1, true) : L(2, true);
+        else rc = OT == 1 ? L(1, false) : L(2, false);
+#undef L
         if (rc) return rc;
     }
     return KAGNN_OK;
