@@ -185,6 +185,18 @@ __device__ __forceinline__ float f16lo_to_f32(unsigned p) {
 __device__ __forceinline__ float f16hi_to_f32(unsigned p) {
     return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16));
 }
+// v - (float)half of p, in ONE instruction: v_fma_mix_f32 reads the fp16 half directly (op_sel picks it).  hipcc
+// forms it for about half of these sites and emits v_cvt_f32_f16 + v_sub_f32 for the rest.
+__device__ __forceinline__ float sub_f16lo(float v, unsigned p) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(v));
+    return r;
+}
+__device__ __forceinline__ float sub_f16hi(float v, unsigned p) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(v));
+    return r;
+}
 
 // 8 fp32 values (already scaled into fp16 range) -> hi and lo fp16 fragments
 __device__ __forceinline__ void split_f16x2(const float (&v)[8], u32x4& hi, u32x4& lo) {
@@ -192,7 +204,7 @@ __device__ __forceinline__ void split_f16x2(const float (&v)[8], u32x4& hi, u32x
     for (int q = 0; q < 4; ++q) {
         const unsigned h = pk_f16_rtz(v[2 * q], v[2 * q + 1]);
         hi[q] = h;
-        lo[q] = pk_f16_rtz(v[2 * q] - f16lo_to_f32(h), v[2 * q + 1] - f16hi_to_f32(h));
+        lo[q] = pk_f16_rtz(sub_f16lo(v[2 * q], h), sub_f16hi(v[2 * q + 1], h));
     }
 }
 
@@ -261,8 +273,8 @@ __device__ __forceinline__ void make_spline_frag(float x, const float* __restric
     float n2 = (K >= 2) ? N[K >= 2 ? 2 : 0] * kAScale : 0.0f;
     float n3 = (K >= 3) ? N[K >= 3 ? 3 : 0] * kAScale : 0.0f;
     const unsigned h0 = pk_f16_rtz(n0, n1), h1 = pk_f16_rtz(n2, n3);
-    const unsigned l0 = pk_f16_rtz(n0 - f16lo_to_f32(h0), n1 - f16hi_to_f32(h0));
-    const unsigned l1 = pk_f16_rtz(n2 - f16lo_to_f32(h1), n3 - f16hi_to_f32(h1));
+    const unsigned l0 = pk_f16_rtz(sub_f16lo(n0, h0), sub_f16hi(n1, h0));
+    const unsigned l1 = pk_f16_rtz(sub_f16lo(n2, h1), sub_f16hi(n3, h1));
     int t = m - K + 4;
     t = t < 0 ? 0 : (t > 31 ? 31 : t);
     const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + woff + 16 * t);
@@ -273,7 +285,7 @@ __device__ __forceinline__ void make_spline_frag(float x, const float* __restric
     if constexpr (K >= 4) {                          // fifth basis (see build_perm_fix_table)
         const float n4 = N[K >= 4 ? 4 : 0] * kAScale;
         const unsigned h2 = pk_f16_rtz(n4, 0.0f);
-        const unsigned l2 = pk_f16_rtz(n4 - f16lo_to_f32(h2), 0.0f);
+        const unsigned l2 = pk_f16_rtz(sub_f16lo(n4, h2), 0.0f);
         const u32x4 fix = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + kFixBytes + woff + 16 * t);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -292,8 +304,8 @@ __device__ __forceinline__ void make_spline_frag3(float x, const unsigned* __res
     float N[4];
     cubic_bases(u, inside ? (kAScale / 6.0f) : 0.0f, N);
     const unsigned h0 = pk_f16_rtz(N[0], N[1]), h1 = pk_f16_rtz(N[2], N[3]);
-    const unsigned l0 = pk_f16_rtz(N[0] - f16lo_to_f32(h0), N[1] - f16hi_to_f32(h0));
-    const unsigned l1 = pk_f16_rtz(N[2] - f16lo_to_f32(h1), N[3] - f16hi_to_f32(h1));
+    const unsigned l0 = pk_f16_rtz(sub_f16lo(N[0], h0), sub_f16hi(N[1], h0));
+    const unsigned l1 = pk_f16_rtz(sub_f16lo(N[2], h1), sub_f16hi(N[3], h1));
     const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + woff + 16 * (m + 1));   // m - 3 + 4, m in [0, 30]
     ahi[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
     ahi[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
@@ -323,15 +335,15 @@ __device__ __forceinline__ void make_spline_frag3_pair(float x0, float x1, const
     const f32x2 N2 = fma2(uw, fma2(fma2(u, splat2(-3.0f), splat2(3.0f)), u, splat2(3.0f)), w6);
     {
         const unsigned h0 = pk_f16_rtz(N0.x, N1.x), h1 = pk_f16_rtz(N2.x, N3.x);
-        const unsigned l0 = pk_f16_rtz(N0.x - f16lo_to_f32(h0), N1.x - f16hi_to_f32(h0));
-        const unsigned l1 = pk_f16_rtz(N2.x - f16lo_to_f32(h1), N3.x - f16hi_to_f32(h1));
+        const unsigned l0 = pk_f16_rtz(sub_f16lo(N0.x, h0), sub_f16hi(N1.x, h0));
+        const unsigned l1 = pk_f16_rtz(sub_f16lo(N2.x, h1), sub_f16hi(N3.x, h1));
         const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + woff + 16 * (m0 + 1));
         frag3_place_fwd(sel, h0, h1, l0, l1, ahi0, alo0);
     }
     {
         const unsigned h0 = pk_f16_rtz(N0.y, N1.y), h1 = pk_f16_rtz(N2.y, N3.y);
-        const unsigned l0 = pk_f16_rtz(N0.y - f16lo_to_f32(h0), N1.y - f16hi_to_f32(h0));
-        const unsigned l1 = pk_f16_rtz(N2.y - f16lo_to_f32(h1), N3.y - f16hi_to_f32(h1));
+        const unsigned l0 = pk_f16_rtz(sub_f16lo(N0.y, h0), sub_f16hi(N1.y, h0));
+        const unsigned l1 = pk_f16_rtz(sub_f16lo(N2.y, h1), sub_f16hi(N3.y, h1));
         const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + woff + 16 * (m1 + 1));
         frag3_place_fwd(sel, h0, h1, l0, l1, ahi1, alo1);
     }
@@ -387,8 +399,8 @@ __device__ __forceinline__ void frag3_payload(float u, unsigned& h0, unsigned& h
     float N[4];
     cubic_bases(u, kAScale / 6.0f, N);
     h0 = pk_f16_rtz(N[0], N[1]); h1 = pk_f16_rtz(N[2], N[3]);
-    l0 = pk_f16_rtz(N[0] - f16lo_to_f32(h0), N[1] - f16hi_to_f32(h0));
-    l1 = pk_f16_rtz(N[2] - f16lo_to_f32(h1), N[3] - f16hi_to_f32(h1));
+    l0 = pk_f16_rtz(sub_f16lo(N[0], h0), sub_f16hi(N[1], h0));
+    l1 = pk_f16_rtz(sub_f16lo(N[2], h1), sub_f16hi(N[3], h1));
 }
 __device__ __forceinline__ void frag3_place(const u32x4& sel, unsigned h0, unsigned h1, unsigned l0,
                                             unsigned l1, u32x4& ahi, u32x4& alo) {
