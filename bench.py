@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on MI355X: edges/sec of ONE KAN-GIN conv layer
-(sum-aggregate + KAN([64,64,64]), grid 5, order 3) forward AND backward on the synthetic
-power-law graph of SURVEY.md 8(d) (1M nodes / 10M edges, fp32), plus the roofline of the
-dominant kernel and the CPU baseline (oracle, "port") on a bounded sample.
+(sum-aggregate + KAN([F,F,F])) forward AND backward on the synthetic power-law graph of
+SURVEY.md 8(d) (1M nodes / 10M edges, fp32 I/O).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|config3]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1: the layer is sharded over the ranks (aggregation on feature-column shards, KAN chain on row
-shards, RCCL all-to-all in between; KAGNN_SHARDING=feature shards the spline coefficient tensor instead --
-see kagnn_amd/sharded.py and DESIGN.md) -- total work is fixed => "scaling": "strong".
-One JSON line on stdout (rank 0).
+One JSON line on stdout (rank 0).  Besides the contract's fields it carries
+  layer_hbm_frac        the headline roofline figure: B_layer / t_step / 8 TB/s
+  roofline              the dominant entry point (largest device time per step), HIP events in the timed region
+  roofline_kernels      the four hot kernels (aggregation, KAN forward, dX, dW), each against BOTH its HBM bytes and
+                        its matrix-core flops -- the limiting ones are the KAN kernels, not the aggregation
+  fp32_mode_ms_per_step the same step on the exact-fp32 MFMA kernels (KAGNN_PRECISION=fp32)
+  cpu_baseline          the oracle (the reference's algorithm, "port") on the host cores, bounded sample
+N > 1 (one rank per GPU, RCCL): `value` is north_star's scheme (spline coefficients sharded by input feature,
+reduce-scatter / all-gather per KANLinear); the all-to-all scheme of kagnn_amd/sharded.py is timed next to it and
+reported under "alt_parallelism".  Total work is fixed => "scaling": "strong".
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import resource
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -29,6 +40,12 @@ sys.dont_write_bytecode = True
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3
 F16_MFMA_PEAK_TF = 2500.0
+
+WORKLOADS = {
+    # name: (hidden, grid) -- N / E / order come from the flags (defaults 1M / 10M / 3)
+    "headline": (64, 5),       # BASELINE.json metric: hidden=64 grid=5
+    "config3": (128, 8),       # BASELINE.json configs[2]: hidden=128 grid=8 (the 8-GPU config)
+}
 
 
 def layer_bytes(n, e, f):
@@ -57,40 +74,132 @@ def powerlaw_graph(num_nodes, num_edges, seed=0):
     return torch.stack([src, dst])
 
 
-def cpu_baseline(n_sample, e_sample, f, grid, order, seed=0):
-    """The reference's algorithm (oracle/kan_oracle.py: dense bases, F.linear, index_select +
-    scatter_add_, stock autograd) on the host cores, bounded sample of the same workload.  torch's CPU
-    elementwise kernels stop scaling (and then regress badly) beyond a few dozen threads, so a few thread
-    counts are tried and the best one is reported -- `cores` is the thread count actually used."""
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def _physical_cores():
+    try:
+        seen = set()
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                seen.add((pid, line.split(":")[1].strip()))
+        if seen:
+            return len(seen)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def _mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1e6
+    except Exception:
+        pass
+    return 0.0
+
+
+def cpu_baseline(n_sample, e_sample, f, grid, order, seed=0, full=False):
+    """The reference's algorithm (oracle/kan_oracle.py: dense bases, F.linear, index_select + scatter_add_, stock
+    autograd) on the host cores, on a bounded sample of the same workload (same graph recipe, 1/10 of the nodes and
+    edges by default: ~4 s and ~5 GB per pass; the full 1M / 10M layer needs ~45 GB and ~40 s per pass -- `--cpu-full`
+    runs it when MemAvailable allows).  torch's CPU elementwise kernels stop scaling beyond a few dozen threads, so
+    thread counts up to the physical core count are swept, 1 warm-up + best of 3 each; `cores` = the thread count of
+    the best run."""
     from oracle import kan_oracle as orc
     ei = orc.powerlaw_graph(n_sample, e_sample, seed=seed)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n_sample, f, generator=g) * 0.25
     layers = [orc.init_kan_linear(f, f, grid, order, g) for _ in range(2)]
-    host = os.cpu_count() or 1
+    host, phys = os.cpu_count() or 1, _physical_cores()
+    sweep = sorted({min(t, host) for t in (8, 32, 64, phys)})
+    if full:
+        sweep = [min(32, host)]
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     best, best_threads, tried = float("inf"), 1, []
-    for th in sorted({min(8, host), min(32, host)}):
+    for th in sweep:
         torch.set_num_threads(th)
-        if not tried:
-            orc.kan_gin_layer_fwd_bwd(x, ei, layers, order)          # warm-up (allocator, thread pool)
-        t0 = time.perf_counter()
-        orc.kan_gin_layer_fwd_bwd(x, ei, layers, order)
-        dt = time.perf_counter() - t0
-        tried.append((th, round(dt, 2)))
-        if dt < best:
-            best, best_threads = dt, th
+        orc.kan_gin_layer_fwd_bwd(x, ei, layers, order)              # warm-up (allocator, thread pool)
+        runs = []
+        for _ in range(1 if full else 3):
+            t0 = time.perf_counter()
+            orc.kan_gin_layer_fwd_bwd(x, ei, layers, order)
+            runs.append(time.perf_counter() - t0)
+        tried.append({"threads": th, "best_s": round(min(runs), 3), "runs_s": [round(r, 3) for r in runs]})
+        if min(runs) < best:
+            best, best_threads = min(runs), th
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     return {"value": e_sample / best, "unit": "edges/s", "cores": best_threads, "kind": "port",
-            "sample": f"same recipe at N={n_sample}, E={e_sample}, F={f}, grid={grid}, order={order}; 1 warm-up, then one "
-                      f"timed fwd+bwd per thread count {tried} (threads, s) on a {host}-thread host; best reported"}
+            "seconds": best, "host_threads": host, "physical_cores": phys, "thread_sweep": tried,
+            "peak_rss_GB": rss1 / 1e6, "peak_rss_growth_GB": (rss1 - rss0) / 1e6,
+            "sample": f"same recipe at N={n_sample}, E={e_sample}, F={f}, grid={grid}, order={order} "
+                      f"({'FULL size' if full else 'bounded sample of the 1M/10M workload'}); per thread count 1 warm-up + best of "
+                      f"{1 if full else 3} timed fwd+bwd passes; best thread count reported"}
 
 
-def secondary_figures(dev, conv, graph, x, n, e, f, grid, order):
-    """SURVEY.md 8(d)'s side figures, measured after (never inside) the timed region: what a device-to-device copy
-    reaches on this box next to the 8 TB/s the roofline is priced against, the share of the first KANLinear's inputs
-    that falls inside the spline support, and the full 3-layer GKAN_Nodes training step quoted as 3E / t_step."""
-    import kagnn_amd
-    from kagnn_amd import harness, ops
-    out = {}
+# ---------------------------------------------------------------------------------------------- PMC traffic
+def _profiler_active():
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre.lower() or any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)
+
+
+def _pmc_pass(counter, argv, timeout_s):
+    """one `rocprofv3 --pmc <counter>` pass over a short run of this script; per-kernel average of the counter"""
+    out = tempfile.mkdtemp(prefix="kagnn_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + argv
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+        agg = {}
+        for db in glob.glob(os.path.join(out, "**", "*.db"), recursive=True):
+            cur = sqlite3.connect(db).cursor()
+            cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+            if "kernel_name" not in cols:
+                continue
+            for kn, cn, v in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+                if cn == counter:
+                    a = agg.setdefault(kn, [0, 0.0])
+                    a[0] += 1
+                    a[1] += v
+        for csv in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            import csv as _csv
+            for row in _csv.DictReader(open(csv)):
+                if row.get("Counter_Name") == counter:
+                    a = agg.setdefault(row.get("Kernel_Name", "?"), [0, 0.0])
+                    a[0] += 1
+                    a[1] += float(row.get("Counter_Value", 0))
+        return {k: v[1] / v[0] for k, v in agg.items()}
+    except Exception:
+        return {}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def measure_traffic(args, kernel_prefix):
+    """HBM-side bytes per launch of the dominant kernel from the PMC counters, collected in THIS run (same box, same
+    lease): separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes (MI355X_MICROARCH.md: TCC has 4 slots, FETCH_SIZE
+    costs 3, WRITE_SIZE 2), bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- the x2 is the guide's gfx950 correction for
+    16 B/lane reads (FETCH_SIZE tallies 128-B requests at 64 B), which is what the aggregation and the KAN kernels
+    issue; WRITE_SIZE is uncalibrated there.  Counts Infinity-Cache hits (fabric-side, not physical HBM)."""
+    if shutil.which("rocprofv3") is None or _profiler_active():
+        return None, "rocprofv3 unavailable or this process is itself being profiled"
+    argv = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-traffic", "--no-fp32",
+            "--workload", args.workload, "--nodes", str(args.nodes), "--edges", str(args.edges), "--order", str(args.order),
+            "--precision", args.precision]
+    fetch = _pmc_pass("FETCH_SIZE", argv, 240)
+    write = _pmc_pass("WRITE_SIZE", argv, 240)
+    per_kernel = {}
+    for k in fetch:
+        if k in write:
+            short = k.split("(")[0].replace("void ", "").replace("kagnn::", "")
+            per_kernel[short] = int((2.0 * fetch[k] + write[k]) * 1024)
+    hit = [v for k, v in per_kernel.items() if k.startswith(kernel_prefix)]
+    return (hit[0] if hit else None), {k: v for k, v in per_kernel.items() if not k.startswith(("at::", "__amd", "rocprim"))}
+
+
+# ---------------------------------------------------------------------------------------------- secondary
+def copy_bandwidth(dev):
     a = torch.empty(1 << 28, dtype=torch.float32, device=dev)       # 1 GiB, well past the 256 MB of MALL
     b = torch.empty_like(a)
     b.copy_(a)
@@ -100,8 +209,16 @@ def secondary_figures(dev, conv, graph, x, n, e, f, grid, order):
         b.copy_(a)
     ev1.record()
     torch.cuda.synchronize()
-    out["hbm_copy_GBs"] = 10 * 2.0 * a.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
-    del a, b
+    return 10 * 2.0 * a.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+
+
+def secondary_figures(dev, conv, graph, x, n, e, f, grid, order):
+    """SURVEY.md 8(d)'s side figures, measured after (never inside) the timed region: the share of the first
+    KANLinear's inputs that falls inside the spline support and the full 3-layer GKAN_Nodes training step quoted as
+    3E / t_step."""
+    import kagnn_amd
+    from kagnn_amd import harness, ops
+    out = {}
     with torch.no_grad():
         h0 = ops.aggregate_sum(x.detach(), graph, self_scale=1.0)
         knots = conv.nn.layers[0].grid[0]
@@ -116,26 +233,35 @@ def secondary_figures(dev, conv, graph, x, n, e, f, grid, order):
     t_step, _ = harness.time_model(model, x.detach(), graph, y, mask, nb_epochs=5, warmup=2)
     out["model_step"] = {"what": f"GKAN_Nodes(gin, 3 conv layers, hidden {f}, {classes} classes, skip, BatchNorm) training step "
                                  "(forward, softmax + cross-entropy, backward, Adam), time_model.py:35-48",
-                         "ms_per_step": t_step * 1e3, "edges_per_s": 3 * e / t_step}
+                         "ms_per_step": t_step * 1e3, "edges_per_s": 3 * e / t_step,
+                         "conv_layers_share": None}
     return out
 
 
+# ---------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=os.environ.get("KAGNN_WORKLOAD", "headline"))
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--edges", type=int, default=10_000_000)
-    ap.add_argument("--hidden", type=int, default=64)
-    ap.add_argument("--grid", type=int, default=5)
+    ap.add_argument("--hidden", type=int, default=None, help="override the workload's hidden width")
+    ap.add_argument("--grid", type=int, default=None, help="override the workload's grid size")
     ap.add_argument("--order", type=int, default=3)
     ap.add_argument("--precision", default=os.environ.get("KAGNN_PRECISION", "split"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="nodes in the CPU-baseline sample")
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline at the full workload size (needs ~48 GB of free RAM, ~2 min)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (copy bandwidth, full model step)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 step timing")
     args = ap.parse_args()
     os.environ["KAGNN_PRECISION"] = args.precision
+    hidden, grid = WORKLOADS[args.workload]
+    f = args.hidden or hidden
+    grid = args.grid or grid
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,52 +291,83 @@ def main():
     import kagnn_amd
     from kagnn_amd import ops
 
-    n, e, f = args.nodes, args.edges, args.hidden
+    n, e = args.nodes, args.edges
+    fp32_mode = args.precision in ("fp32", "exact", "0")
     ei = powerlaw_graph(n, e, seed=0).to(dev)
     gen = torch.Generator().manual_seed(0)
     x_full = torch.randn(n, f, generator=gen) * 0.25
-    gy_full = torch.Generator().manual_seed(1)
-    gy_full = torch.randn(n, f, generator=gy_full)
+    gy_full = torch.randn(n, f, generator=torch.Generator().manual_seed(1))
     torch.manual_seed(0)
-    conv = kagnn_amd.GIKANLayer(f, f, grid_size=args.grid, spline_order=args.order, hidden_dim=f, nb_layers=2)
-
+    conv = kagnn_amd.GIKANLayer(f, f, grid_size=grid, spline_order=args.order, hidden_dim=f, nb_layers=2)
     graph = ops.GraphIndex(ei, n)
-    if world == 1:
-        conv = conv.to(dev)
-        x = x_full.to(dev).requires_grad_(True)
-        gy = gy_full.to(dev)
-
-        def step():
-            x.grad = None
-            for p in conv.parameters():
-                p.grad = None
-            y = conv(x, graph)
-            y.backward(gy)
-    else:
-        # default: aggregation on column shards, KAN chain on row shards, two all-to-alls per direction
-        # (kagnn_amd/sharded.py); KAGNN_SHARDING=feature selects the reduce-scatter / all-gather variant that
-        # shards the spline coefficient tensor itself (8x more wire traffic at this width)
-        from kagnn_amd.sharded import ShardedGIKANLayer, TransposedShardedGIKANLayer
-        sharding = os.environ.get("KAGNN_SHARDING", "transposed")
-        cls = ShardedGIKANLayer if sharding == "feature" else TransposedShardedGIKANLayer
-        sconv = (cls(conv, dist.group.WORLD, sync_in_backward=False) if cls is TransposedShardedGIKANLayer
-                 else cls(conv, dist.group.WORLD)).to(dev)
-        x = sconv.shard_columns(x_full.to(dev)).requires_grad_(True)
-        gy = sconv.shard_columns(gy_full.to(dev))
-
-        def step():
-            x.grad = None
-            for p in sconv.parameters():
-                p.grad = None
-            y = sconv(x, graph)
-            y.backward(gy)
-            if hasattr(sconv, "sync_gradients"):
-                sconv.sync_gradients()             # one flat all-reduce for all weight gradients
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed(step, steps):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt
+
+    alt = None
+    if world == 1:
+        conv = conv.to(dev)
+        x = x_full.to(dev).requires_grad_(True)
+        gy = gy_full.to(dev)
+        params = list(conv.parameters())
+
+        def step():
+            x.grad = None
+            for p in params:
+                p.grad = None
+            y = conv(x, graph)
+            y.backward(gy)
+        parallelism = "single GPU"
+    else:
+        from kagnn_amd.sharded import ShardedGIKANLayer, TransposedShardedGIKANLayer
+
+        def make(cls):
+            sconv = (cls(conv, dist.group.WORLD, sync_in_backward=False) if cls is TransposedShardedGIKANLayer
+                     else cls(conv, dist.group.WORLD)).to(dev)
+            xs = sconv.shard_columns(x_full.to(dev)).requires_grad_(True)
+            gs = sconv.shard_columns(gy_full.to(dev))
+            ps = list(sconv.parameters())
+
+            def step():
+                xs.grad = None
+                for p in ps:
+                    p.grad = None
+                y = sconv(xs, graph)
+                y.backward(gs)
+                if hasattr(sconv, "sync_gradients"):
+                    sconv.sync_gradients()             # one flat all-reduce for all weight gradients
+            return step
+        # north_star's scheme is the reported one; KAGNN_SHARDING=transposed swaps the two roles
+        primary = os.environ.get("KAGNN_SHARDING", "feature")
+        names = {"feature": f"feature-sharded x{world}: spline coefficients split by input feature, RCCL reduce-scatter (fwd) / "
+                            f"all-gather (bwd) per KANLinear (north_star)",
+                 "transposed": f"column-sharded aggregation + row-sharded KAN chain x{world}: RCCL all-to-all both ways, one flat "
+                               f"weight-gradient all-reduce"}
+        classes = {"feature": ShardedGIKANLayer, "transposed": TransposedShardedGIKANLayer}
+        other = "transposed" if primary == "feature" else "feature"
+        step = make(classes[primary])
+        parallelism = names[primary]
+        alt_step = make(classes[other])
+        for _ in range(args.warmup):
+            alt_step()
+        dt_alt = timed(alt_step, args.steps)
+        alt = {"parallelism": names[other], "ms_per_step": dt_alt / args.steps * 1e3, "value": e / (dt_alt / args.steps)}
+        del alt_step
 
     for _ in range(args.warmup):
         step()
@@ -229,71 +386,117 @@ def main():
     only = max(warm, key=lambda k: warm[k]["total_ms"]) if warm else None
     timer = ops.EntryPointTimer(only=only)
     ops.set_timer(timer)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
+    dt = timed(step, args.steps)
     ops.set_timer(None)
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
     ms = dt / args.steps * 1e3
     value = e / (dt / args.steps)
 
+    fp32_ms = None
+    if not args.no_fp32 and not fp32_mode and world == 1:
+        for l in conv.nn.layers:
+            l.precision = ops.PREC_FP32
+        for _ in range(2):
+            step()
+        k32 = max(3, min(args.steps, 5))
+        fp32_ms = timed(step, k32) / k32 * 1e3
+        for l in conv.nn.layers:
+            l.precision = None
+
     if rank == 0:
         prof = timer.summary()
-        c = args.grid + args.order
+        c = grid + args.order
         fl = f // world if world > 1 else f
-        # dominant entry point of the layer (largest device time per step); its launches were timed in the timed region
         per_step = {k: v["total_ms"] / PROFILE_STEPS for k, v in warm.items()}
         dom = only if only in prof else max(per_step, key=per_step.get)
-        avg_ms = prof[dom]["avg_ms"] if dom in prof else warm[dom]["avg_ms"]
-        if dom == "kagnn_aggregate_sum":
-            b = agg_bytes(n, e, fl)
-            roof = {"kernel": dom, "bound": "hbm", "achieved": b / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "algorithmic_bytes_per_launch": b}
+        mfma_peak = FP32_MFMA_PEAK_TF if fp32_mode else F16_MFMA_PEAK_TF
+        products = 1.0 if fp32_mode else 3.0            # split mode: hi*hi + hi*lo + lo*hi on the fp16 matrix cores
+        nrows = n if world == 1 else n                  # (feature sharding keeps all rows on every rank)
+        kan = kan_flops(nrows, fl, f, c)
+        spec = {   # entry point -> (what, algorithmic bytes per launch, algorithmic flops per launch)
+            "kagnn_aggregate_sum": ("neighbour aggregation (fwd; bwd = same kernel on the transposed CSR)", agg_bytes(n, e, fl), 2.0 * e * fl),
+            "kagnn_kan_linear_fwd": ("KANLinear forward", 4.0 * nrows * (fl + f), kan),
+            "kagnn_kan_linear_bwd_input": ("KANLinear input gradient (reads x, gy; writes gx)", 4.0 * nrows * (2 * fl + f), kan),
+            "kagnn_kan_linear_bwd_weight": ("KANLinear weight gradient (reads x, gy)", 4.0 * nrows * (fl + f), kan),
+        }
+        kernels = []
+        for name, (what, nbytes, flops) in spec.items():
+            if name not in warm:
+                continue
+            avg = (prof[name]["avg_ms"] if name in prof else warm[name]["avg_ms"]) * 1e-3
+            gbs = nbytes / avg / 1e9
+            tf = products * flops / avg / 1e12
+            kernels.append({"entry_point": name, "what": what, "avg_launch_ms": avg * 1e3,
+                            "launches_per_step": warm[name]["launches"] / PROFILE_STEPS,
+                            "ms_per_step": per_step[name],
+                            "measured_in": "timed region" if name in prof else "3 untimed profile steps",
+                            "algorithmic_bytes_per_launch": nbytes, "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                            "algorithmic_flops_per_launch": flops,
+                            "mfma_TFs_incl_split_products": tf, "mfma_frac": tf / mfma_peak if name != "kagnn_aggregate_sum" else 0.0,
+                            "bound": "hbm" if name == "kagnn_aggregate_sum" else "mfma/valu issue"})
+        by_name = {k["entry_point"]: k for k in kernels}
+        d = by_name.get(dom)
+        if d is not None and dom == "kagnn_aggregate_sum":
+            roof = {"kernel": dom, "bound": "hbm", "achieved": d["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"]}
+        elif d is not None:
+            roof = {"kernel": dom, "bound": "mfma", "achieved": d["mfma_TFs_incl_split_products"], "peak": mfma_peak,
+                    "unit": "TFLOP/s", "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"]}
         else:
-            fl_ops = kan_flops(n, fl, f, c)
-            peak = FP32_MFMA_PEAK_TF if args.precision in ("fp32", "exact", "0") else F16_MFMA_PEAK_TF
-            eff = fl_ops if peak == FP32_MFMA_PEAK_TF else 3.0 * fl_ops     # 3 MFMA products per fp32 product
-            roof = {"kernel": dom, "bound": "mfma", "achieved": eff / (avg_ms * 1e-3) / 1e12, "peak": peak,
-                    "unit": "TFLOP/s", "algorithmic_flops_per_launch": fl_ops}
+            roof = {"kernel": dom, "bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["avg_launch_ms"] = avg_ms
+        roof["avg_launch_ms"] = d["avg_launch_ms"] if d else None
         roof["traffic"] = None
-        tr = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr):
-            try:
-                roof["traffic"] = json.load(open(tr)).get(dom)
-            except Exception:
-                pass
+        roof["note"] = ("dominant = largest device time per step; it is the kernel closest to its roofline -- the limiting "
+                        "kernels are in roofline_kernels, and the headline figure is layer_hbm_frac")
         layer_gbs = layer_bytes(n, e, f) / (ms * 1e-3) / 1e9
         out = {
             "metric": "edges/sec KAN-GIN fwd+bwd, hidden=64 grid=5, 1M-node synthetic; HBM % peak",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision in ("fp32", "exact", "0") else "f32 (fp16 hi/lo split operands, fp32 accumulate)",
+            "vs_baseline": None, "dtype": "f32" if fp32_mode else "f32 (fp16 hi/lo split operands, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": f"KAN-GIN conv layer fwd+bwd (aggregate + KAN([{f},{f},{f}]) grid={args.grid} order={args.order}), "
+            "config": {"workload": f"{args.workload}: KAN-GIN conv layer fwd+bwd (aggregate + KAN([{f},{f},{f}]) grid={grid} order={args.order}), "
                                    f"power-law graph N={n} E={e} seed 0 (SURVEY 8(d))",
-                       "nodes": n, "edges": e, "hidden": f, "grid_size": args.grid, "spline_order": args.order,
-                       "precision": args.precision,
-                       "parallelism": "single GPU" if world == 1 else (
-                           f"feature-sharded x{world} (RCCL reduce-scatter/all-gather)" if os.environ.get("KAGNN_SHARDING") == "feature"
-                           else f"column-sharded aggregation + row-sharded KAN chain x{world} (RCCL all-to-all, weight-gradient all-reduce)")},
+                       "nodes": n, "edges": e, "hidden": f, "grid_size": grid, "spline_order": args.order,
+                       "precision": args.precision, "parallelism": parallelism},
             "layer_algorithmic_bytes": layer_bytes(n, e, f),
             "layer_hbm_GBs": layer_gbs, "layer_hbm_frac": layer_gbs / HBM_PEAK_GBS,
+            "fp32_mode_ms_per_step": fp32_ms,
+            "fp32_mode_layer_hbm_frac": (layer_bytes(n, e, f) / (fp32_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fp32_ms else None,
             "roofline": roof,
+            "roofline_kernels": kernels,
             "entry_points_ms_per_step": per_step, "entry_points_measured_in": "3 extra untimed steps after the warm-up (HIP events around every call)",
         }
+        if alt is not None:
+            out["alt_parallelism"] = alt
+        if world == 1:
+            copy_gbs = copy_bandwidth(dev)
+            out["hbm_copy_GBs"] = copy_gbs
+            out["layer_frac_of_copy_bw"] = layer_gbs / copy_gbs
+            roof["frac_of_copy_bw"] = (roof["achieved"] / copy_gbs) if roof["unit"] == "GB/s" else None
+            for k in kernels:
+                k["hbm_frac_of_copy_bw"] = k["hbm_GBs"] / copy_gbs
         if not args.no_extras and world == 1:
-            out["secondary"] = secondary_figures(dev, conv, graph, x, n, e, f, args.grid, args.order)
+            out["secondary"] = secondary_figures(dev, conv, graph, x, n, e, f, grid, args.order)
+            conv_ms = 3 * ms
+            out["secondary"]["model_step"]["conv_layers_share"] = conv_ms / out["secondary"]["model_step"]["ms_per_step"]
+        if not args.no_traffic and world == 1:
+            torch.cuda.synchronize()
+            prefix = {"kagnn_aggregate_sum": "agg_rows", "kagnn_kan_linear_fwd": "kan_sparse_fwd",
+                      "kagnn_kan_linear_bwd_input": "kan_split_dx", "kagnn_kan_linear_bwd_weight": "kan_split_dw"}.get(dom, "agg_rows")
+            traffic, detail = measure_traffic(args, prefix)
+            roof["traffic"] = traffic
+            roof["traffic_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes spawned by this run over 2 steps of the same "
+                                   "command; (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 correction for 16 B/lane reads); "
+                                   "fabric-side bytes, Infinity-Cache hits included") if traffic else str(detail)
+            if isinstance(detail, dict):
+                out["traffic_per_kernel_bytes"] = detail
         if not args.no_cpu_baseline and world == 1:
-            ns = min(args.cpu_sample, n)
-            out["cpu_baseline"] = cpu_baseline(ns, ns * (e // n if n else 10), f, args.grid, args.order)
+            if args.cpu_full and _mem_available_gb() >= 48:
+                out["cpu_baseline"] = cpu_baseline(n, e, f, grid, args.order, full=True)
+            else:
+                ns = min(args.cpu_sample, n)
+                out["cpu_baseline"] = cpu_baseline(ns, ns * (e // n if n else 10), f, grid, args.order)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -82,15 +82,18 @@ int kagnn_gcn_deg_inv_sqrt(const int32_t* rowptr, const int32_t* col, int64_t nu
  * add_remaining_self_loops).  GIN: self_scale = 1+eps, everything else NULL.  GCN: in_scale =
  * out_scale = dis, self_scale = 1, skip_self_loops = 1, bias = conv bias.  The backward of an
  * aggregation is the same call on the transposed CSR.
- * Deterministic except for rows listed in hub_seg (fp32 atomics across segments).
+ * Deterministic (bit-reproducible run to run): rows listed in hub_seg are summed per segment into
+ * `workspace` (kagnn_aggregate_workspace_bytes(num_hub_seg, num_feat) bytes; may be NULL when num_hub_seg
+ * is 0) and folded into the row in segment order -- no atomics anywhere.
  * ------------------------------------------------------------------------------------------ */
+int kagnn_aggregate_workspace_bytes(int64_t num_hub_seg, int32_t num_feat, size_t* bytes_host);
 int kagnn_aggregate_sum(const float* x, int64_t ldx, float* out, int64_t ldo,
                         const int32_t* rowptr, const int32_t* col, const float* edge_weight,
                         int64_t num_nodes, int32_t num_feat, float self_scale,
                         const float* in_scale, const float* out_scale, const float* bias,
                         int32_t skip_self_loops,
                         const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
-                        void* stream);
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* GINE message: out[i,:] = self_scale*x[i,:] + sum_e relu(x[col[e],:] + edge_attr[perm[e],:])
  * (torch_geometric GINEConv as used by graph_regression/models.py:98,113).              */

@@ -27,8 +27,9 @@ _SIGNATURES = {
     "kagnn_csr_build": (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int32, _P, c_int64,
                                   POINTER(c_int64), _P, c_size_t, _P]),
     "kagnn_gcn_deg_inv_sqrt": (c_int32, [_P, _P, c_int64, _P, _P]),
+    "kagnn_aggregate_workspace_bytes": (c_int32, [c_int64, c_int32, POINTER(c_size_t)]),
     "kagnn_aggregate_sum": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int32, c_float,
-                                      _P, _P, _P, c_int32, _P, c_int64, c_int32, _P]),
+                                      _P, _P, _P, c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
     "kagnn_aggregate_gine": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64,
                                        c_int32, c_float, _P]),
     "kagnn_aggregate_gine_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P,

@@ -106,10 +106,13 @@ __global__ __launch_bounds__(256) void agg_rows_ep_kernel(AggArgs a) {
     }
 }
 
-// one workgroup per hub segment {row, e0, e1}; adds its partial sum onto out[row] (which the row
-// kernel initialised with the self term and bias) with fp32 atomics.
+// one workgroup per hub segment {row, e0, e1}: its partial sum (fixed order inside the segment) goes to
+// part[segment][F]; agg_hub_merge_kernel then folds a row's segments into out[row] in segment order -- no atomics,
+// so hub rows are as reproducible run to run as every other row (reference utils.py:25-28 seeds everything and
+// expects repeatable runs).
 template <int LPR>
-__global__ __launch_bounds__(256) void agg_hub_v4_kernel(AggArgs a, const int* __restrict__ seg) {
+__global__ __launch_bounds__(256) void agg_hub_v4_kernel(AggArgs a, const int* __restrict__ seg,
+                                                         float* __restrict__ part, int ldp) {
     __shared__ float4 s_part[256];
     const int row = seg[3 * blockIdx.x], e0 = seg[3 * blockIdx.x + 1], e1 = seg[3 * blockIdx.x + 2];
     constexpr int G = 256 / LPR;
@@ -128,11 +131,30 @@ __global__ __launch_bounds__(256) void agg_hub_v4_kernel(AggArgs a, const int* _
             const float4 p = s_part[k * LPR + lg];
             acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
         }
-        const float os = a.out_scale ? a.out_scale[row] : 1.0f;
-        float* o = a.out + (long)row * a.ldo + c4;
-        atomicAdd(o + 0, os * acc.x); atomicAdd(o + 1, os * acc.y);
-        atomicAdd(o + 2, os * acc.z); atomicAdd(o + 3, os * acc.w);
+        *reinterpret_cast<float4*>(part + (long)blockIdx.x * ldp + c4) = acc;
     }
+}
+
+// LPR lanes per segment; only the lane group of a row's FIRST segment works: it walks the row's consecutive segments
+// (csr.hip lists them in edge order) and adds their sum, scaled, onto what the row kernel wrote (self term + bias).
+template <int LPR>
+__global__ __launch_bounds__(256) void agg_hub_merge_kernel(AggArgs a, const int* __restrict__ seg, long nseg,
+                                                            const float* __restrict__ part, int ldp) {
+    const long sidx = (blockIdx.x * 256L + threadIdx.x) / LPR;
+    const int c4 = (threadIdx.x % LPR) * 4;
+    if (sidx >= nseg || c4 >= a.F) return;
+    const int row = seg[3 * sidx];
+    if (sidx > 0 && seg[3 * (sidx - 1)] == row) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long k = sidx; k < nseg && seg[3 * k] == row; ++k) {
+        const float4 p = ld4(part + k * ldp + c4);
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    const float os = a.out_scale ? a.out_scale[row] : 1.0f;
+    float4* o = reinterpret_cast<float4*>(a.out + (long)row * a.ldo + c4);
+    float4 v = *o;
+    v.x = fmaf(os, acc.x, v.x); v.y = fmaf(os, acc.y, v.y); v.z = fmaf(os, acc.z, v.z); v.w = fmaf(os, acc.w, v.w);
+    *o = v;
 }
 
 // any F / any alignment: grid (N, ceil(F/256)), one thread per feature, edges walked in order.
@@ -247,7 +269,9 @@ static bool vec4_ok(const AggArgs& a) {
            (!a.bias || al(a.bias));
 }
 
-int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, hipStream_t st) {
+size_t aggregate_ws_bytes(long num_hub_seg, int F) { return (size_t)num_hub_seg * (size_t)((F + 3) & ~3) * sizeof(float); }
+
+int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, float* ws, size_t ws_bytes, hipStream_t st) {
     if (a.N == 0) return KAGNN_OK;
     if (!vec4_ok(a)) {
         AggArgs b = a;
@@ -259,23 +283,27 @@ int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, hipStr
     }
     AggArgs b = a;
     if (num_hub_seg == 0 || hub_seg == nullptr) b.hub_threshold = 0x7fffffff;
+    const int ldp = (a.F + 3) & ~3;
+    if (b.hub_threshold != 0x7fffffff && (ws == nullptr || ws_bytes < aggregate_ws_bytes(num_hub_seg, a.F)))
+        return fail(KAGNN_ERR_ARG, "%s: workspace too small for the hub segments (see kagnn_aggregate_workspace_bytes)", "aggregate_sum");
+#define HUBS(LPR)                                                                                   \
+    if (b.hub_threshold != 0x7fffffff) {                                                            \
+        agg_hub_v4_kernel<LPR><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg, ws, ldp);         \
+        KAGNN_LAUNCH_CHECK();                                                                       \
+        agg_hub_merge_kernel<LPR><<<cdiv(num_hub_seg * LPR, 256), 256, 0, st>>>(b, hub_seg, num_hub_seg, ws, ldp); \
+        KAGNN_LAUNCH_CHECK();                                                                       \
+    }
 #define ROWS(LPR)                                                                     \
     {                                                                                 \
         agg_rows_v4_kernel<LPR><<<cdiv(a.N * LPR, 256), 256, 0, st>>>(b);             \
         KAGNN_LAUNCH_CHECK();                                                         \
-        if (b.hub_threshold != 0x7fffffff) {                                          \
-            agg_hub_v4_kernel<LPR><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg); \
-            KAGNN_LAUNCH_CHECK();                                                     \
-        }                                                                             \
+        HUBS(LPR)                                                                     \
     }
 #define ROWS_EP(LPR)                                                                  \
     {                                                                                 \
         agg_rows_ep_kernel<LPR><<<cdiv(a.N * 16, 256), 256, 0, st>>>(b);              \
         KAGNN_LAUNCH_CHECK();                                                         \
-        if (b.hub_threshold != 0x7fffffff) {                                          \
-            agg_hub_v4_kernel<LPR><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg); \
-            KAGNN_LAUNCH_CHECK();                                                     \
-        }                                                                             \
+        HUBS(LPR)                                                                     \
     }
     // measured at N=1M / E=10M: edge-parallel wins for F <= 16 (0.19 vs 0.23 ms at F=8), loses slightly at F=32
     if (a.F <= 4) ROWS_EP(1) else if (a.F <= 8) ROWS_EP(2) else if (a.F <= 16) ROWS_EP(4) else if (a.F <= 32) ROWS(8)
@@ -283,6 +311,7 @@ int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, hipStr
     else if (a.F <= 128) ROWS(32) else ROWS(64)
 #undef ROWS
 #undef ROWS_EP
+#undef HUBS
     return KAGNN_OK;
 }
 

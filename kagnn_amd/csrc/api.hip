@@ -5,7 +5,8 @@
 namespace kagnn {
 thread_local char g_err[512] = "";
 
-int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, hipStream_t st);
+size_t aggregate_ws_bytes(long num_hub_seg, int F);
+int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, float* ws, size_t ws_bytes, hipStream_t st);
 int gcn_deg_inv_sqrt(const int* rowptr, const int* col, long N, float* dis, hipStream_t st);
 int gine_fwd(const float*, long, const float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
 int gine_bwd(const float*, long, const float*, long, const float*, long, float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
@@ -84,7 +85,7 @@ static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode 
 #pragma GCC visibility push(default)
 extern "C" {
 
-int kagnn_version(void) { return 100; }
+int kagnn_version(void) { return 200; }
 const char* kagnn_last_error(void) { return g_err; }
 
 int kagnn_csr_workspace_bytes(int64_t E, int64_t N, size_t* bytes) {
@@ -113,14 +114,21 @@ int kagnn_aggregate_sum(const float* x, int64_t ldx, float* out, int64_t ldo, co
                         const int32_t* col, const float* edge_weight, int64_t N, int32_t F,
                         float self_scale, const float* in_scale, const float* out_scale,
                         const float* bias, int32_t skip_self_loops, const int32_t* hub_seg,
-                        int64_t num_hub_seg, int32_t hub_threshold, void* stream) {
+                        int64_t num_hub_seg, int32_t hub_threshold, void* workspace, size_t workspace_bytes,
+                        void* stream) {
     KAGNN_CHECK_ARG(N >= 0 && F >= 1, "bad shape");
     KAGNN_CHECK_ARG(N == 0 || (x && out && rowptr), "null array");
     KAGNN_CHECK_ARG(ldx >= F && ldo >= F, "leading dimension smaller than num_feat");
     KAGNN_CHECK_ARG(x != out, "in-place aggregation is not supported");
     AggArgs a{x, ldx, out, ldo, rowptr, col, edge_weight, N, F, self_scale, in_scale, out_scale, bias,
               skip_self_loops, hub_threshold > 0 ? hub_threshold : 0x7fffffff};
-    return aggregate_sum(a, hub_seg, num_hub_seg, as_stream(stream));
+    return aggregate_sum(a, hub_seg, num_hub_seg, static_cast<float*>(workspace), workspace_bytes, as_stream(stream));
+}
+
+int kagnn_aggregate_workspace_bytes(int64_t num_hub_seg, int32_t F, size_t* bytes_host) {
+    KAGNN_CHECK_ARG(num_hub_seg >= 0 && F >= 1 && bytes_host, "bad argument");
+    *bytes_host = aggregate_ws_bytes(num_hub_seg, F);
+    return KAGNN_OK;
 }
 
 int kagnn_aggregate_gine(const float* x, int64_t ldx, const float* ea, int64_t lde, float* out,

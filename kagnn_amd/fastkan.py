@@ -7,6 +7,15 @@ spline_linear.weight, base_linear.weight, base_linear.bias``).  ``FastKANLayer.f
 call to ``kagnn_fastkan_fwd`` -- LayerNorm statistics, the Gaussian RBF expansion and both linear
 maps are fused in the kernel; ``plot_curve`` and the attention helper of the reference are not
 part of the KAGNN path and are not provided.
+
+Attribution: the module surface restated here (class names, constructor signatures, parameter layout and the
+trunc-normal / linspace initialisation of ``SplineLinear`` / ``RadialBasisFunction`` / ``FastKANLayer`` / ``FastKAN``)
+follows the reference's ``node_classification_clean/fastkan.py``, which is
+    Copyright 2024 Li, Ziyao -- Licensed under the Apache License, Version 2.0
+    (http://www.apache.org/licenses/LICENSE-2.0); distributed there on an "AS IS" BASIS, WITHOUT WARRANTIES OR
+    CONDITIONS OF ANY KIND.
+The state_dict / constructor contract is what forces the shared lines; the forward and backward
+are this package's HIP kernels.
 """
 from __future__ import annotations
 

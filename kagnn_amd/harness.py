@@ -24,7 +24,10 @@ def _time_model_graphed(model, x, edge_index, y, mask, nb_epochs: int, warmup: i
     optimizer = torch.optim.Adam(model.parameters(), lr=0.001, capturable=True)
     if mask.dtype != torch.bool:
         mask = torch.zeros(x.size(0), dtype=torch.bool, device=x.device).index_fill_(0, mask, True)
-    graph_index = ops.graph_index(edge_index, x.size(0)) if not isinstance(edge_index, ops.GraphIndex) else edge_index
+    if isinstance(edge_index, ops.GraphIndex) or (isinstance(edge_index, torch.Tensor) and edge_index.is_sparse):
+        graph_index = edge_index           # sparse adjacency (gcn timing branch): the convs index it, cached
+    else:
+        graph_index = ops.graph_index(edge_index, x.size(0))
 
     def epoch():
         optimizer.zero_grad(set_to_none=True)

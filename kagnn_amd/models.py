@@ -179,7 +179,16 @@ class _NodeModel(nn.Module):
         return num_features + mp_layers * width if skip else width
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
-        g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
+        if isinstance(edge_index, ops.GraphIndex):
+            g = edge_index
+        elif isinstance(edge_index, torch.Tensor) and edge_index.is_sparse:
+            # the sparse adjacency of the reference's gcn timing branch (time_model.py:70-80) goes to the convs as it
+            # is: _NormalisedConv indexes it once (ops.weighted_gcn_graph caches per tensor identity)
+            if not all(isinstance(c, _NormalisedConv) for c in self.convs):
+                raise ValueError("a sparse adjacency edge_index is only defined for the gcn convolutions")
+            g = edge_index
+        else:
+            g = ops.graph_index(edge_index, x.size(0))
         outs = [x]
         for conv, bn in zip(self.convs, self.bns):
             x = self.dropout(bn(conv(x, g)))

@@ -8,6 +8,7 @@ refused -- there is no CPU implementation in this package (the CPU restatement l
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 import weakref
 from ctypes import byref, c_int64, c_size_t
@@ -103,11 +104,51 @@ def _stream():
 
 
 def _need_cuda(*ts):
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError(
                 "kagnn_amd ops run only on MI355X device tensors (libkagnn_hip.so); got a CPU tensor. "
                 "There is no CPU fallback in this package.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"kagnn_amd ops need all operands on one device; got {dev} and {t.device}")
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _device_of(t):
+    """Context that makes ``t``'s GPU the current device (kernels launch on the CURRENT device's stream: a model moved
+    to ``cuda:1`` without ``torch.cuda.set_device(1)`` would otherwise launch on device 0).  Free when it already is."""
+    if t is None or not t.is_cuda or t.device.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(t.device)
+
+
+def _on_operand_device(fn):
+    """Decorator for ``Function.forward`` / ``.backward``: run on the device of the first CUDA tensor argument."""
+    @functools.wraps(fn)
+    def run(ctx, *args):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(ctx, *args)
+                break
+        return fn(ctx, *args)
+    return run
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -148,8 +189,9 @@ class GraphIndex:
         self.device = edge_index.device
         src = edge_index[0].contiguous()
         dst = edge_index[1].contiguous()
-        self.rowptr, self.col, self.perm, self.hub_seg, self.num_hub_seg = self._build(dst, src)
-        self.rowptr_t, self.col_t, self.perm_t, self.hub_seg_t, self.num_hub_seg_t = self._build(src, dst)
+        with _device_of(edge_index):
+            self.rowptr, self.col, self.perm, self.hub_seg, self.num_hub_seg = self._build(dst, src)
+            self.rowptr_t, self.col_t, self.perm_t, self.hub_seg_t, self.num_hub_seg_t = self._build(src, dst)
         self._dis = None
 
     def _build(self, key, val):
@@ -173,7 +215,8 @@ class GraphIndex:
         """deg^-1/2 with one self loop per node (gcn_norm, add_remaining_self_loops)."""
         if self._dis is None:
             dis = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
-            _call("kagnn_gcn_deg_inv_sqrt", _ptr(self.rowptr), _ptr(self.col), self.num_nodes,
+            with _device_of(self.rowptr):
+                _call("kagnn_gcn_deg_inv_sqrt", _ptr(self.rowptr), _ptr(self.col), self.num_nodes,
                       _ptr(dis), _stream())
             self._dis = dis
         return self._dis
@@ -208,20 +251,28 @@ def clear_graph_cache() -> None:
 
 
 class WeightedGcnGraph:
-    """``gcn_norm`` with edge weights (torch_geometric semantics, restated in oracle/kan_oracle.py:gcn_norm):
-    non-loop edges keep their weight, every node gets exactly one self loop (an existing loop keeps its weight,
-    otherwise 1), ``deg`` = weighted in-degree, ``dis = deg^-1/2`` (inf -> 0).  The augmented edge list is
-    indexed once (CSR + transpose); built with a handful of torch ops -- per graph, not per step."""
+    """``gcn_norm`` with edge weights (torch_geometric 2.5.3 semantics, restated in oracle/kan_oracle.py).
 
-    def __init__(self, edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int):
+    Dense ``edge_index`` (``gcn_norm`` -> ``add_remaining_self_loops``): non-loop edges keep their weight, every node
+    gets exactly one self loop (an existing loop keeps its weight, otherwise 1).  Sparse adjacency
+    (``sparse_loops=True``; ``gcn_norm`` -> ``add_self_loops`` + coalesce): every node gets a weight-1 loop ADDED to
+    whatever its diagonal entry already holds.  Either way ``deg`` = weighted in-degree, ``dis = deg^-1/2`` (inf -> 0).
+    The augmented edge list is indexed once (CSR + transpose); built with a handful of torch ops -- per graph, not
+    per step."""
+
+    def __init__(self, edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int,
+                 sparse_loops: bool = False):
         _need_cuda(edge_index)
         dev = edge_index.device
         src, dst = edge_index[0], edge_index[1]
         w = (torch.ones(src.numel(), dtype=torch.float32, device=dev) if edge_weight is None
              else edge_weight.to(device=dev, dtype=torch.float32))
         keep = src != dst
-        loop_w = torch.ones(num_nodes, dtype=torch.float32, device=dev)
-        loop_w[src[~keep]] = w[~keep]
+        if sparse_loops:         # coalesced input: at most one (i, i) entry per node
+            loop_w = torch.ones(num_nodes, dtype=torch.float32, device=dev).index_add_(0, src[~keep], w[~keep])
+        else:
+            loop_w = torch.ones(num_nodes, dtype=torch.float32, device=dev)
+            loop_w[src[~keep]] = w[~keep]
         ar = torch.arange(num_nodes, dtype=src.dtype, device=dev)
         ei = torch.stack([torch.cat([src[keep], ar]), torch.cat([dst[keep], ar])]).contiguous()
         self.weight = torch.cat([w[keep], loop_w]).contiguous()
@@ -238,7 +289,8 @@ _gcn_cache: "dict[tuple, WeightedGcnGraph]" = {}
 def weighted_gcn_graph(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int) -> WeightedGcnGraph:
     """Cached per (edge_index, edge_weight) identity / version.  ``edge_index`` may also be a torch sparse COO
     matrix, read the way torch_geometric reads a sparse ``adj_t``: entry (i, j) = weight of the edge j -> i (the
-    form the reference's gcn timing branch passes, ``time_model.py:70-80``)."""
+    form the reference's gcn timing branch passes, ``time_model.py:70-80``); its self loops follow
+    ``add_self_loops`` (+1 on the diagonal), see ``WeightedGcnGraph``."""
     if isinstance(edge_index, torch.Tensor) and edge_index.is_sparse:
         key = (id(edge_index), int(num_nodes))
         hit = _gcn_cache.get(key)
@@ -246,7 +298,7 @@ def weighted_gcn_graph(edge_index: torch.Tensor, edge_weight: Optional[torch.Ten
             return hit
         adj = edge_index.coalesce()
         idx = adj.indices()
-        hit = WeightedGcnGraph(torch.stack([idx[1], idx[0]]).contiguous(), adj.values(), num_nodes)
+        hit = WeightedGcnGraph(torch.stack([idx[1], idx[0]]).contiguous(), adj.values(), num_nodes, sparse_loops=True)
         hit._owner = edge_index
     else:
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
@@ -271,9 +323,11 @@ def _aggregate_raw(x, g: GraphIndex, transposed, self_scale, edge_weight, in_sca
         raise ValueError(f"x has {n} rows but the graph has {g.num_nodes} nodes")
     rowptr, col, _, hub, nhub = g.side(transposed)
     out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    ws = _ws(_sizes("kagnn_aggregate_workspace_bytes", nhub, f), x.device) if nhub else None   # per-segment partial sums
     _call("kagnn_aggregate_sum", _ptr(x), _ld(x), _ptr(out), f, _ptr(rowptr), _ptr(col),
               _ptr(edge_weight), n, f, float(self_scale), _ptr(in_scale), _ptr(out_scale), _ptr(bias),
-              int(skip_self), _ptr(hub) if nhub else None, nhub, g.hub_threshold, _stream())
+              int(skip_self), _ptr(hub) if nhub else None, nhub, g.hub_threshold, _ptr(ws),
+              ws.numel() if nhub else 0, _stream())
     return out
 
 
@@ -282,6 +336,7 @@ class _AggregateFn(Function):
     backward is the same kernel on the transposed CSR with in/out scales swapped."""
 
     @staticmethod
+    @_on_operand_device
     def forward(ctx, x, bias, g, self_scale, edge_weight, in_scale, out_scale, skip_self):
         _need_cuda(x)
         ctx.g, ctx.self_scale, ctx.skip_self = g, self_scale, skip_self
@@ -295,6 +350,7 @@ class _AggregateFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_on_operand_device
     def backward(ctx, gout):
         gx = gb = None
         if ctx.needs_input_grad[0]:
@@ -313,6 +369,7 @@ def aggregate_sum(x, g: GraphIndex, self_scale: float = 1.0, edge_weight=None, i
 
 class _GineFn(Function):
     @staticmethod
+    @_on_operand_device
     def forward(ctx, x, edge_attr, g, self_scale):
         _need_cuda(x, edge_attr)
         x, ea = _rows(x), _rows(edge_attr)
@@ -328,6 +385,7 @@ class _GineFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_on_operand_device
     def backward(ctx, gout):
         x, ea = ctx.saved_tensors
         g = ctx.g
@@ -357,6 +415,7 @@ def segment_ptr(batch: torch.Tensor, num_graphs: int) -> torch.Tensor:
 
 class _SegmentPoolFn(Function):
     @staticmethod
+    @_on_operand_device
     def forward(ctx, x, seg, mean):
         _need_cuda(x, seg)
         x = _rows(x)
@@ -368,6 +427,7 @@ class _SegmentPoolFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_on_operand_device
     def backward(ctx, gout):
         gout = _rows(gout)
         b, f = gout.shape
@@ -406,8 +466,9 @@ def kan_pack_chain(layers, grid_size: int, spline_order: int, mode: int):
         bws.append(bw_c.data_ptr()); sws.append(sw_c.data_ptr()); scs.append(0 if sc_c is None else sc_c.data_ptr())
         ins.append(fin); outs.append(fout); pfs.append(pf.data_ptr()); pds.append(pd.data_ptr())
     vp = ctypes.c_void_p
-    _call("kagnn_kan_pack_batch", n, arr(bws, vp), arr(sws, vp), arr(scs, vp), arr(ins, ctypes.c_int32),
-          arr(outs, ctypes.c_int32), int(grid_size), int(spline_order), int(mode), arr(pfs, vp), arr(pds, vp), _stream())
+    with _device_of(layers[0][1]):
+        _call("kagnn_kan_pack_batch", n, arr(bws, vp), arr(sws, vp), arr(scs, vp), arr(ins, ctypes.c_int32),
+              arr(outs, ctypes.c_int32), int(grid_size), int(spline_order), int(mode), arr(pfs, vp), arr(pds, vp), _stream())
     return packs
 
 
@@ -417,6 +478,7 @@ def _weights_key(bw, sw, sc):
 
 class _KANLinearFn(Function):
     @staticmethod
+    @_on_operand_device
     def forward(ctx, x, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, packed=None):
         _need_cuda(x, base_weight, spline_weight, spline_scaler, knots)
         x = _rows(x)
@@ -444,6 +506,7 @@ class _KANLinearFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_on_operand_device
     def backward(ctx, gy):
         x, sw, sc, knots, pack_d = ctx.saved_tensors
         fin, fout, G, K, mode = ctx.dims
@@ -530,8 +593,9 @@ def kan_bsplines(x, grid, grid_size: int, spline_order: int) -> torch.Tensor:
     if g.shape != (fin, grid_size + 2 * spline_order + 1):
         raise AssertionError("grid must be [in_features, G+2k+1]")
     out = torch.empty((n, fin, grid_size + spline_order), dtype=torch.float32, device=x.device)
-    _call("kagnn_kan_bsplines", _ptr(x), _ld(x), n, _ptr(g), fin, int(grid_size), int(spline_order), _ptr(out),
-          _stream())
+    with _device_of(x):
+        _call("kagnn_kan_bsplines", _ptr(x), _ld(x), n, _ptr(g), fin, int(grid_size), int(spline_order), _ptr(out),
+              _stream())
     return out
 
 
@@ -549,14 +613,16 @@ def kan_grid_refit(x, grid_old, grid_new, spline_weight, spline_scaler, grid_siz
     sc = None if spline_scaler is None else spline_scaler.detach().contiguous()
     ws = _ws(_sizes("kagnn_kan_grid_refit_workspace_bytes", n, fin, int(grid_size), int(spline_order)), x.device)
     out = torch.empty_like(sw)
-    _call("kagnn_kan_grid_refit", _ptr(x), _ld(x), n, _ptr(go), _ptr(gn), fin, fout, int(grid_size),
-          int(spline_order), _ptr(sw), _ptr(sc), _ptr(out), _ptr(ws), ws.numel(), _stream())
+    with _device_of(x):
+        _call("kagnn_kan_grid_refit", _ptr(x), _ld(x), n, _ptr(go), _ptr(gn), fin, fout, int(grid_size),
+              int(spline_order), _ptr(sw), _ptr(sc), _ptr(out), _ptr(ws), ws.numel(), _stream())
     return out
 
 
 # ======================================================================== FastKAN layer
 class _FastKANFn(Function):
     @staticmethod
+    @_on_operand_device
     def forward(ctx, x, ln_w, ln_b, spline_w, base_w, base_b, centers, denominator, ln_eps, mode):
         _need_cuda(x, spline_w, centers)
         x = _rows(x)
@@ -582,6 +648,7 @@ class _FastKANFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_on_operand_device
     def backward(ctx, gy):
         x, lw, lb, sw, bw, centers, stats = ctx.saved_tensors
         fin, fout, ng, den, eps, has_bb, mode = ctx.meta
@@ -604,6 +671,7 @@ class _FastKANFn(Function):
 # ======================================================================== harness loss
 class _SoftmaxXentFn(Function):
     @staticmethod
+    @_on_operand_device
     def forward(ctx, logits, labels, mask, pre_softmax):
         _need_cuda(logits, labels, mask)
         z = _rows(logits)
@@ -621,6 +689,7 @@ class _SoftmaxXentFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_on_operand_device
     def backward(ctx, gloss):
         z, y, m, stats, out = ctx.saved_tensors
         n, c = z.shape
@@ -646,6 +715,7 @@ def softmax_cross_entropy(logits, labels, mask=None, pre_softmax: bool = False) 
 # ======================================================================== GAT attention aggregation
 class _GatFn(Function):
     @staticmethod
+    @_on_operand_device
     def forward(ctx, xh, att_src, att_dst, bias, g, heads, channels):
         _need_cuda(xh, att_src, att_dst)
         xh = _rows(xh)
@@ -670,6 +740,7 @@ class _GatFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_on_operand_device
     def backward(ctx, gout):
         xh, a_s, a_d, b, ls, ld_, m, z, out = ctx.saved_tensors
         g = ctx.g
@@ -709,6 +780,7 @@ def gat_aggregate(xh, att_src, att_dst, bias, g: GraphIndex, heads: int, channel
 # ======================================================================== BatchNorm1d (conv epilogue)
 class _BatchNormFn(Function):
     @staticmethod
+    @_on_operand_device
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
         _need_cuda(x, weight, bias, running_mean, running_var)
         x = _rows(x)
@@ -729,6 +801,7 @@ class _BatchNormFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_on_operand_device
     def backward(ctx, gy):
         x, w, mean, rstd = ctx.saved_tensors
         gy = _rows(gy)
@@ -754,12 +827,14 @@ class _ConcatColumnsFn(Function):
     strided column slices, which sends BatchNorm1d's backward down a ~15x slower non-contiguous kernel)."""
 
     @staticmethod
+    @_on_operand_device
     def forward(ctx, *parts):
         ctx.widths = [p.size(1) for p in parts]
         return torch.cat(parts, dim=1)
 
     @staticmethod
     @once_differentiable
+    @_on_operand_device
     def backward(ctx, g):
         return tuple(c.contiguous() for c in torch.split(g, ctx.widths, dim=1))
 

@@ -51,3 +51,13 @@ def reference_modules():
     finally:
         sys.path.remove(REFERENCE)
     return ref_ekan, ref_fastkan
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """observed parity errors of this run (worst per check label) -> gpurun_out/parity_errors.json; the copy that is
+    judged lives under profiles/ (committed)"""
+    try:
+        import helpers
+        helpers.dump_error_log(os.path.join(ROOT, "gpurun_out", "parity_errors.json"))
+    except Exception:  # pragma: no cover
+        pass

@@ -1,13 +1,29 @@
-"""Shared helpers of the parity tests: tolerances, state loading, oracle drivers."""
+"""Shared helpers of the parity tests: tolerances, state loading, oracle drivers.
+
+Tolerances.  BASELINE.json's contract is "within 1e-4 fp32" (``CONTRACT``).  The tests pin an order of magnitude
+tighter: ``TOL`` = 2e-5 relative to ``max(1, max|reference|)`` for every element -- about 10x the error both
+precision modes actually show on the layer-level cases (``profiles/r02_parity_errors.json``), so a regression of the
+fp16 hi/lo split path (a dropped product, a wrong scale exponent: >= 2^-11) cannot hide behind the contract figure.
+On top of the max-norm bound every element at or above ``REL_FLOOR`` x scale must agree to ``CONTRACT`` RELATIVE to
+its own magnitude.  Tests that need more room (errors compounded through BatchNorm / several layers / Adam) pass an
+explicit ``tol`` and say why.
+"""
+import json
+import os
+
 import numpy as np
 import torch
 
 from oracle import kan_oracle as orc
 
-TOL = 1e-4   # BASELINE.json north_star: "within 1e-4 fp32" -- relative to max(1, max|reference|)
+CONTRACT = 1e-4   # BASELINE.json north_star: "within 1e-4 fp32"
+TOL = 2e-5        # what the tests hold both precision modes to (max-norm, relative to max(1, max|reference|))
+REL_FLOOR = 0.1   # elements >= REL_FLOOR * scale are also checked relative to their own magnitude (CONTRACT)
 KAN_KEYS = ("base_weight", "spline_weight", "spline_scaler", "grid")
 FK_KEYS = ("layernorm.weight", "layernorm.bias", "rbf.grid", "spline_linear.weight",
            "base_linear.weight", "base_linear.bias")
+
+ERROR_LOG = []    # (what, observed error / scale, tolerance): dumped by conftest.py at session end
 
 
 def T(a, device=None):
@@ -20,11 +36,34 @@ def assert_close(got, want, tol=TOL, what=""):
     want = T(want).double() if not torch.is_tensor(want) else want.detach().double().cpu()
     assert got.shape == want.shape, (what, got.shape, want.shape)
     assert torch.equal(torch.isnan(got), torch.isnan(want)), f"{what}: NaN pattern differs"
+    if not want.numel():
+        return 0.0
     g, w = torch.nan_to_num(got), torch.nan_to_num(want)
-    scale = max(1.0, float(w.abs().max())) if w.numel() else 1.0
-    err = float((g - w).abs().max()) if w.numel() else 0.0
+    scale = max(1.0, float(w.abs().max()))
+    diff = (g - w).abs()
+    err = float(diff.max())
+    ERROR_LOG.append((what, err / scale, tol))
     assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.0e} * {scale:.3g}"
+    big = w.abs() >= REL_FLOOR * scale
+    if bool(big.any()):
+        rel = float((diff[big] / w.abs()[big]).max())
+        assert rel <= max(CONTRACT, 5 * tol), f"{what}: element-wise relative error {rel:.3e} on a large element"
     return err / scale
+
+
+def dump_error_log(path):
+    if not ERROR_LOG:
+        return
+    worst = {}
+    for what, err, tol in ERROR_LOG:
+        key = what
+        if key not in worst or err > worst[key][0]:
+            worst[key] = (err, tol)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump({"n_checks": len(ERROR_LOG), "max_ratio_to_tol": max(e / t for _, e, t in ERROR_LOG if t > 0),
+                   "worst_per_label": {k: {"err": v[0], "tol": v[1]} for k, v in sorted(worst.items(), key=lambda kv: -kv[1][0])[:200]}},
+                  f, indent=1)
 
 
 def load_kanlinear(layer, z, prefix, device):
@@ -41,3 +80,27 @@ def oracle_kan_linear_fwd_bwd(x, gy, p, k, dtype=torch.float64):
     y = orc.kan_linear_forward(x, ps["base_weight"], ps["spline_weight"], ps["spline_scaler"], ps["grid"], k)
     y.backward(gy.detach().cpu().to(dtype))
     return y.detach(), x.grad, {n: ps[n].grad for n in ("base_weight", "spline_weight", "spline_scaler")}
+
+
+def oracle_node_model_fwd_bwd(x, edge_index, state, gout, arch, conv_type, mp_layers, spline_order=3, chunk=None,
+                              dtype=torch.float64):
+    """logits, d/dx and every parameter gradient of a GKAN_Nodes / GFASTKAN_Nodes model through the oracle
+    (``oracle.node_model_forward``) in ``dtype``; ``gout`` is the upstream gradient of the logits."""
+    frozen = ("grid", "rbf.grid", "eps", "running_mean", "running_var", "num_batches_tracked")
+    st, leaves = {}, {}
+    for k, v in state.items():
+        v = v.detach().cpu()
+        if v.is_floating_point():
+            v = v.to(dtype)
+        if k.endswith(frozen):
+            st[k] = v
+        else:
+            leaves[k] = v.clone().requires_grad_(True)
+            st[k] = leaves[k]
+    xr = x.detach().cpu().to(dtype).requires_grad_(True)
+    ei = edge_index
+    if isinstance(ei, torch.Tensor) and ei.is_sparse:
+        ei = ei.cpu().to(dtype)
+    out = orc.node_model_forward(xr, ei, st, arch, conv_type, mp_layers, spline_order, chunk=chunk)
+    out.backward(gout.detach().cpu().to(dtype))
+    return out.detach(), xr.grad, {k: v.grad for k, v in leaves.items()}

@@ -211,3 +211,92 @@ def test_g10_update_grid(golden):
         close(ps["spline_scaler"].grad, z[f"{tag}.g_spline_scaler"])
         i += 1
     assert i == 5
+
+
+# ------------------------------------------------------------------ round-2 fixtures
+def test_g4b_fastkan_wide(golden):
+    """the FastKAN shapes SURVEY 8(c) lists: (128, 256, 4) and the skip-concat read-out (896, 40, 4)"""
+    z = golden("g4b_fastkan_wide")
+    i = 0
+    while f"shape_{i}" in z:
+        fi, fo, ng = [int(v) for v in z[f"shape_{i}"]]
+        tag = f"fk_{fi}_{fo}_{ng}"
+        p = {n: T(z[f"{tag}.{n}"]) for n in FK_KEYS}
+        for n in FK_KEYS:
+            if n != "rbf.grid":
+                p[n].requires_grad_(True)
+        x = T(z[f"{tag}.x"]).requires_grad_(True)
+        y = orc.fastkan_forward(x, [p])
+        y.backward(T(z[f"{tag}.gy"]))
+        close(y.detach(), z[f"{tag}.y"], 2e-6)
+        close(x.grad, z[f"{tag}.gx"], 2e-6)
+        for n in FK_KEYS:
+            if n != "rbf.grid":
+                close(p[n].grad, z[f"{tag}.grad.{n}"], 5e-6)
+        i += 1
+    assert i == 2
+
+
+def test_g5b_gin_on_10k_node_powerlaw_graph(golden):
+    z = golden("g5b_gin_plaw10k")
+    ei = T(z["edge_index"])
+    assert torch.equal(ei, orc.powerlaw_graph(10000, 100000, seed=0))          # the recipe is part of the contract
+    layers = [{n: T(z[f"kan.layers.{li}.{n}"]) for n in ("base_weight", "spline_weight", "spline_scaler", "grid")}
+              for li in range(2)]
+    y, gx, grads = orc.kan_gin_layer_fwd_bwd(T(z["kan.x"]), ei, layers, 3, T(z["kan.gy"]))
+    close(y, z["kan.y"], 2e-6)
+    close(gx, z["kan.gx"], 2e-6)
+    for li in range(2):
+        for n in ("base_weight", "spline_weight", "spline_scaler"):
+            close(grads[li][n], z[f"kan.grad.layers.{li}.{n}"], 1e-5)
+    fl = [{n: T(z[f"fastkan.layers.{li}.{n}"]) for n in FK_KEYS} for li in range(2)]
+    x = T(z["fastkan.x"]).requires_grad_(True)
+    y = orc.gin_conv(x, ei, lambda h: orc.fastkan_forward(h, fl))
+    y.backward(T(z["fastkan.gy"]))
+    close(y.detach(), z["fastkan.y"], 2e-6)
+    close(x.grad, z["fastkan.gx"], 2e-6)
+
+
+@pytest.mark.parametrize("name,arch", [("g9_harness", "kan"), ("g11_fastkan_harness", "fastkan")])
+def test_node_model_restatement_matches_reference_made_logits(golden, name, arch):
+    """oracle.node_model_forward (GKAN_Nodes / GFASTKAN_Nodes.forward, models.py:192-203,246-257) against logits the
+    reference's own KAN / FastKAN modules produced inside the restated message passing (G9, G11); chunked rows must
+    not change anything"""
+    z = golden(name)
+    x, ei = T(z["x"]), T(z["edge_index"])
+    for kind in ("gin", "gcn"):
+        pre = f"{kind}.init."
+        st = {k[len(pre):]: T(z[k]) for k in z.files if k.startswith(pre)}
+        for chunk in (None, 97):
+            out = orc.node_model_forward(x, ei, st, arch, kind, 2, 3, chunk=chunk)
+            close(out, z[f"{kind}.logits0"], 2e-5)
+
+
+def test_g12_fastkan_gcn_conv(golden):
+    z, g7 = golden("g12_fastkan_gcn"), golden("g7_csr")
+    for g in ("small", "plaw"):
+        pre = f"{g}.fgcn"
+        ei = T(g7[f"{g}.edge_index"])
+        p = {n: T(z[f"{pre}.lin.{n}"]) for n in FK_KEYS}
+        x = T(z[f"{pre}.x"]).requires_grad_(True)
+        bias = T(z[f"{pre}.bias"]).requires_grad_(True)
+        y = orc.gcn_conv(x, ei, lambda h: orc.fastkan_forward(h, [p]), bias)
+        y.backward(T(z[f"{pre}.gy"]))
+        close(y.detach(), z[f"{pre}.y"], 2e-6)
+        close(x.grad, z[f"{pre}.gx"], 2e-6)
+        close(bias.grad, z[f"{pre}.grad.bias"], 2e-6)
+
+
+def test_gcn_norm_sparse_adds_a_unit_loop_on_top_of_the_diagonal():
+    """torch-sparse ``edge_index`` (time_model.py:70-80): add_self_loops semantics -- independent dense fp64 check"""
+    g = torch.Generator().manual_seed(7)
+    n = 40
+    dense = (torch.rand(n, n, generator=g) < 0.1).double() * torch.rand(n, n, generator=g).double()
+    dense[3, 3] = 0.7                                        # an existing loop keeps its weight AND gets +1
+    dense[:, 5] = 0; dense[5, :] = 0                         # an isolated node: only the added loop
+    ei, w = orc.gcn_norm_sparse(dense.to_sparse())
+    a_hat = dense + torch.eye(n, dtype=torch.float64)
+    dis = a_hat.sum(1).pow(-0.5)
+    want = dis[:, None] * a_hat * dis[None, :]
+    got = torch.zeros(n, n, dtype=torch.float64).index_put_((ei[1], ei[0]), w, accumulate=True)
+    close(got, want, 1e-12)
