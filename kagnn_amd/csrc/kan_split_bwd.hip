@@ -19,6 +19,7 @@
 namespace kagnn {
 
 int kan_dw_reduce(const float* slab, long NS, long per_slab, float* gcat, hipStream_t st);
+
 int kan_dw_unpack(const float* gcat, int in, int out, int C, long inP, long outP, const float* sw,
                   const float* sc, float* g_bw, float* g_sw, float* g_sc, hipStream_t st);
 
@@ -95,43 +96,23 @@ __device__ __forceinline__ float barrel_dot(const float (&d)[8], int m, const fl
 }
 
 
-// Cubic case of the same contraction with half the selects.  The window c0..c0+3 (c0 = m - 3) holds exactly one slot
-// of every residue class mod 4, so the candidate for residue rho is d[rho], d[rho+4] or nothing (the coefficient does
-// not exist): ONE v_perm_b32 per residue with a selector from a 16-entry LDS table indexed by m (dword selectors
-// "low source" / "high source" / zero).  The four survivors then only need a ROTATION by c0 & 3 to line up with
-// dN[0..3]: two more v_perm stages.  12 v_perm_b32, no compares, instead of 27 selects + 5 compares.
-__device__ __forceinline__ void build_barrel_table(unsigned* tbl /* LDS, 16*4 */, int tid) {
-    if (tid < 64) {
-        const int mm = tid >> 2, rho = tid & 3, c0 = mm - 3;
-        const int t = c0 + ((rho - c0) & 3);           // the slot of residue rho inside [c0, c0+3]
-        tbl[tid] = (mm >= 15) ? 0x0c0c0c0cu : (t == rho ? 0x03020100u : (t == rho + 4 ? 0x07060504u : 0x0c0c0c0cu));
-    }
-}
-__device__ __forceinline__ float barrel_dot3(const float (&d)[8], int mm /* m - 8*window */, const u32x4& sel,
-                                             const float (&dN)[4]) {
-    unsigned s4[4], r1[4];
-#pragma unroll
-    for (int rho = 0; rho < 4; ++rho)
-        s4[rho] = __builtin_amdgcn_perm(__float_as_uint(d[rho + 4]), __float_as_uint(d[rho]), sel[rho]);
-    // rotation e[r] = s4[(b + r) & 3], b = c0 & 3, as two v_perm stages whose dword selectors are computed
-    // arithmetically (no compares, no VCC): 0x03020100 keeps the low source, +0x04040404 takes the high one
-    const unsigned b = (unsigned)(mm + 1) & 3u;
-    const unsigned selA = 0x03020100u + (b & 1u) * 0x04040404u;
-    const unsigned selB = 0x03020100u + (b >> 1) * 0x04040404u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r1[i] = __builtin_amdgcn_perm(s4[(i + 1) & 3], s4[i], selA);
-    float e[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = __uint_as_float(__builtin_amdgcn_perm(r1[(i + 2) & 3], r1[i], selB));
-    return fmaf(e[3], dN[3], fmaf(e[2], dN[2], fmaf(e[1], dN[1], e[0] * dN[0])));
-}
-
 // One wave = 32 rows (two 16-row MFMA tiles) x one 16-feature tile at a time.  v_mfma_f32_16x16x32_f16:
 // A lane (row = l&15, kg = l>>4) holds gy[row][32*q2 + 8*kg + j]; B lane (f = l&15, kg) holds W^T;
 // D lane (f = l&15) holds rows 4*kg + reg.
 // GEN == false is the lean instantiation of the common case (one output block, <= 8 coefficients): no
 // accumulate / virtual-feature code at all.  GEN == true takes both as run-time (wave-uniform) flags.
-template <int K, int Q2, bool GEN>
+//
+// Schedule (PP).  A unit of work is (row tile, 16-feature tile): an M phase (9 slots x Q2 k-steps x 6 MFMAs, fed
+// from the W^T fragments in LDS) and a V phase (per scalar: basis derivatives, barrel contraction over the slots,
+// SiLU', store).  The two phases use different pipes but inside ONE wave they run back to back, and the two waves
+// that share a SIMD drift into the same phase (PMC, round 1: VALU-active 61 % + MFMA-busy 44 % of the SIMD's
+// time, 40 % of every wave's cycles parked in s_waitcnt -- the gy rows of a tile were loaded at its start).
+//   PP >= 1: the gy rows of the NEXT row tile are requested a whole tile ahead and split into fragments at the end
+//            of the current tile's last V phase (no exposed HBM latency at tile boundaries);
+//   PP == 2: the workgroup's waves 4..7 (the SIMD partners of waves 0..3) run one phase behind, held there by one
+//            s_barrier per phase: a SIMD always has one wave on the matrix pipe and one on the VALU
+//            (MI355X_MICROARCH.md, "Two waves per SIMD").
+template <int K, int Q2, bool GEN, int PP>
 __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
@@ -160,6 +141,9 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const int ft_begin = blockIdx.y * ft_per_block, ft_end = min(FT, ft_begin + ft_per_block);
     if (resident) stage(ft_begin, ft_end - ft_begin);
     __syncthreads();
+    // the phase barriers need every wave of the workgroup to run the same number of phases: that holds when the
+    // W^T fragments are resident (no staging barriers inside the loop); otherwise fall back to the plain schedule
+    const bool pingpong = (PP == 2) && resident;
     SplineGeom geom{}; FastGeom fgeo{};
     const int li = lane & 15, kg = lane >> 4;
     const int win = li & sh;                                     // this lane's slot window (virtual feature parity)
@@ -174,51 +158,43 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const bool ln_on = (K == 0) && rb.ln_w != nullptr;           // wave-uniform
     const bool al4 = ((ldgy & 3) == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
     const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u, ldgx4 = (unsigned)ldgx * 4u;
+    const unsigned gy_ro = (unsigned)(wave * 32 + li) * ldgy4;   // tile-relative byte offsets (descriptors open at the tile)
+    const unsigned x_rb = (unsigned)(wave * 32 + 4 * kg) * ldx4;
+    const unsigned gx_rb = (unsigned)(wave * 32 + 4 * kg) * ldgx4;
+    const unsigned gz_rb = (unsigned)(wave * 32 + 4 * kg) * (unsigned)in * 4u;
 
-    for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
-        const long row0 = tile * 256 + wave * 32;
-        // descriptors opened at the workgroup's tile: per-lane offsets are tile-relative and 32-bit for any N
-        const GBuf gzb = gbuf_at(rb.gz, N, in, in, tile * 256);
-        const GBuf xb = gbuf_at(x, N, ldx, in, tile * 256), gyb = gbuf_at(gy, N, ldgy, out, tile * 256),
-                   gxb = gbuf_at(gx, N, ldgx, in, tile * 256);
-        const unsigned gy_ro = (unsigned)(wave * 32 + li) * ldgy4;
-        const unsigned x_rb = (unsigned)(wave * 32 + 4 * kg) * ldx4;
-        const unsigned gx_rb = (unsigned)(wave * 32 + 4 * kg) * ldgx4;
-        const unsigned gz_rb = (unsigned)(wave * 32 + 4 * kg) * (unsigned)in * 4u;
-        float mu[2][4], rs[2][4];                          // layernorm statistics of this lane's 8 rows
-        if (ln_on) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const long rc = min(row0 + 16 * rt + 4 * kg + reg, N - 1);
-                    mu[rt][reg] = rb.stats[2 * rc]; rs[rt][reg] = rb.stats[2 * rc + 1];
-                }
-        }
-        // ---- A operand: gy rows scaled per row by 2^(10 - rexp), split into fp16 hi / lo
-        u32x4 ahi[2][Q2], alo[2][Q2];
-        float rinv[2][4];
+    // ---- gy rows of one row tile: raw loads (buffer loads with 32-bit offsets: rows >= N read as 0 and are never
+    // stored; columns >= out are clamped to the row's last value and meet zero weights in the pack) ...
+    auto load_gy = [&](long tile, float (&raw)[2][Q2][8]) {
+        const GBuf gyb = gbuf_at(gy, N, ldgy, out, tile * 256);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            // buffer loads with 32-bit offsets: rows >= N read as 0 (never stored anyway); columns >= out are
-            // clamped to the row's last value and meet zero weights in the pack
-            const unsigned ro = gy_ro + kg * 32;             // (row0 + li) * ldgy4 + 8*kg*4, tile-constant
+            const unsigned ro = gy_ro + kg * 32;             // (row0 + li) * ldgy4 + 8*kg*4
             const unsigned so = (unsigned)(16 * rt) * ldgy4; // wave-uniform
-            float raw[Q2][8];
-            float mx = 0.0f;
 #pragma unroll
             for (int q = 0; q < Q2; ++q) {
                 if (al4 && 32 * Q2 == out) {              // wave-uniform
-                    gld4_s(gyb, ro, so + 128 * q, raw[q]);
-                    gld4_s(gyb, ro, so + 128 * q + 16, raw[q] + 4);
+                    gld4_s(gyb, ro, so + 128 * q, raw[rt][q]);
+                    gld4_s(gyb, ro, so + 128 * q + 16, raw[rt][q] + 4);
                 } else {
                     const int o0 = 32 * q + 8 * kg;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) raw[q][j] = gld_s(gyb, gy_ro + min(o0 + j, out - 1) * 4, so);
+                    for (int j = 0; j < 8; ++j) raw[rt][q][j] = gld_s(gyb, gy_ro + min(o0 + j, out - 1) * 4, so);
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(raw[q][j]));
             }
+        }
+    };
+    // ... and their A fragments: scaled per row by 2^(10 - rexp), split into fp16 hi / lo
+    u32x4 ahi[2][Q2], alo[2][Q2];
+    float rinv[2][4];
+    auto split_gy = [&](const float (&raw)[2][Q2][8]) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            float mx = 0.0f;
+#pragma unroll
+            for (int q = 0; q < Q2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(raw[rt][q][j]));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const int rexp = exp_for_max(mx);
@@ -227,13 +203,47 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             for (int q = 0; q < Q2; ++q) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = raw[q][j] * sc;
+                for (int j = 0; j < 8; ++j) v[j] = raw[rt][q][j] * sc;
                 split_f16x2(v, ahi[rt][q], alo[rt][q]);
             }
             const float mine = ldexpf(1.0f, e_w + rexp - 10);      // undo factor of this lane's row
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) rinv[rt][reg] = __shfl(mine, 4 * kg + reg);
         }
+    };
+    float mu[2][4], rs[2][4];                          // layernorm statistics of this lane's 8 rows (RBF basis only)
+    auto load_stats = [&](long tile) {
+        if (ln_on) {
+            const long row0 = tile * 256 + wave * 32;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const long rc = min(row0 + 16 * rt + 4 * kg + reg, N - 1);
+                    mu[rt][reg] = rb.stats[2 * rc]; rs[rt][reg] = rb.stats[2 * rc + 1];
+                }
+        }
+    };
+
+    float graw[2][Q2][8];
+    long tile = blockIdx.x;
+    if (tile * 256 >= N) return;                                 // (workgroup-uniform; the grid never over-covers)
+    load_gy(tile, graw);
+    load_stats(tile);
+    split_gy(graw);
+    if (PP >= 1 && (tile + gridDim.x) * 256 < N) load_gy(tile + gridDim.x, graw);
+    if (pingpong && wave >= 4) __builtin_amdgcn_s_barrier();     // the partner half starts one phase late
+
+    for (; tile * 256 < N; tile += gridDim.x) {
+        const bool more = (tile + gridDim.x) * 256 < N;
+        if (PP == 0 && tile != (long)blockIdx.x) {               // plain schedule: load + split at the tile's start
+            load_gy(tile, graw);
+            load_stats(tile);
+            split_gy(graw);
+        }
+        // descriptors opened at the workgroup's tile: per-lane offsets are tile-relative and 32-bit for any N
+        const GBuf gzb = gbuf_at(rb.gz, N, in, in, tile * 256);
+        const GBuf xb = gbuf_at(x, N, ldx, in, tile * 256), gxb = gbuf_at(gx, N, ldgx, in, tile * 256);
 
         for (int ft = ft_begin; ft < ft_end; ++ft) {
             if (!resident) {
@@ -257,6 +267,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     // rows >= N -> 0 (never stored); a partial last feature tile re-reads the clamped column
                     xq[rt][reg] = gld_s(xb, x_rb + fcol, (unsigned)(16 * rt + reg) * ldx4);
                 }
+            // ================= M phase
             f32x4 D[kCTmax][2];
 #pragma unroll
             for (int c = 0; c < kCTmax; ++c) { D[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -285,7 +296,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // ---- contraction over c with the local basis derivatives (barrel shift by the span index)
+            if (pingpong) __builtin_amdgcn_s_barrier();
+            // ================= V phase: contraction over c with the local basis derivatives (barrel shift by the span index)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
@@ -348,14 +360,34 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     }
                 }
             }
+            if (PP >= 1 && ft + 1 == ft_end && more) {
+                // fragments of the next row tile (its rows arrived long ago), and the request for the one after
+                load_stats(tile + gridDim.x);
+                split_gy(graw);
+                if ((tile + 2 * (long)gridDim.x) * 256 < N) load_gy(tile + 2 * (long)gridDim.x, graw);
+            }
+            if (pingpong) __builtin_amdgcn_s_barrier();
         }
     }
+    if (pingpong && wave < 4) __builtin_amdgcn_s_barrier();      // balance the partner half's initial barrier
 }
 
-template <int K, int Q2, bool GEN>
-static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
-                     const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
-                     const RbfArgs& rb, int accumulate, hipStream_t st) {
+// KAGNN_DX_SCHEDULE = 0 plain | 1 gy prefetch (default) | 2 prefetch + phase ping-pong.  Measured round 2
+// (profiles/r02_experiments.md): 0.565 / 0.561 / 0.555 ms per step -- the schedule is not what limits this kernel.
+static int dx_schedule() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KAGNN_DX_SCHEDULE");
+        v = e ? atoi(e) : 1;
+        if (v < 0 || v > 2) v = 1;
+    }
+    return v;
+}
+
+template <int K, int Q2, bool GEN, int PP>
+static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
+                        const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
+                        const RbfArgs& rb, int accumulate, hipStream_t st) {
     const int sh = vshift(C), FT = cdiv(in << sh, 16);
     const size_t ft_bytes = (size_t)kCTmax * Q2 * 2 * 1024;
     const size_t budget = 160 * 1024 - kLdsHdr;
@@ -368,15 +400,30 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
     const size_t lds = kLdsHdr + (resident ? fpb : 1) * ft_bytes;
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN>,
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
     }
     const dim3 grid((unsigned)min(row_blocks, 256L), (unsigned)splits);
-    kan_split_dx_kernel<K, Q2, GEN><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
-                                                            resident ? 1 : 0, gx, ldgx, rb, sh, accumulate, fpb);
+    kan_split_dx_kernel<K, Q2, GEN, PP><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
+                                                                resident ? 1 : 0, gx, ldgx, rb, sh, accumulate, fpb);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
+}
+
+template <int K, int Q2, bool GEN>
+static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
+                     const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
+                     const RbfArgs& rb, int accumulate, hipStream_t st) {
+    // the schedule experiments only pay on the common cubic instantiation; the others keep the prefetch form
+    if constexpr (K == 3 && !GEN) {
+        switch (dx_schedule()) {
+            case 0: return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
+            case 2: return launch_dx_pp<K, Q2, GEN, 2>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
+            default: return launch_dx_pp<K, Q2, GEN, 1>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
+        }
+    }
+    return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
 }
 
 static int dx_block(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,

@@ -475,6 +475,37 @@ __device__ __forceinline__ void make_rbf_frag(float z, float a, const float (&ca
     split_f16x2(v, hi, lo);
 }
 
+// Cubic case of the same contraction with half the selects.  The window c0..c0+3 (c0 = m - 3) holds exactly one slot
+// of every residue class mod 4, so the candidate for residue rho is d[rho], d[rho+4] or nothing (the coefficient does
+// not exist): ONE v_perm_b32 per residue with a selector from a 16-entry LDS table indexed by m (dword selectors
+// "low source" / "high source" / zero).  The four survivors then only need a ROTATION by c0 & 3 to line up with
+// dN[0..3]: two more v_perm stages.  12 v_perm_b32, no compares, instead of 27 selects + 5 compares.
+__device__ __forceinline__ void build_barrel_table(unsigned* tbl /* LDS, 16*4 */, int tid) {
+    if (tid < 64) {
+        const int mm = tid >> 2, rho = tid & 3, c0 = mm - 3;
+        const int t = c0 + ((rho - c0) & 3);           // the slot of residue rho inside [c0, c0+3]
+        tbl[tid] = (mm >= 15) ? 0x0c0c0c0cu : (t == rho ? 0x03020100u : (t == rho + 4 ? 0x07060504u : 0x0c0c0c0cu));
+    }
+}
+__device__ __forceinline__ float barrel_dot3(const float (&d)[8], int mm /* m - 8*window */, const u32x4& sel,
+                                             const float (&dN)[4]) {
+    unsigned s4[4], r1[4];
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho)
+        s4[rho] = __builtin_amdgcn_perm(__float_as_uint(d[rho + 4]), __float_as_uint(d[rho]), sel[rho]);
+    // rotation e[r] = s4[(b + r) & 3], b = c0 & 3, as two v_perm stages whose dword selectors are computed
+    // arithmetically (no compares, no VCC): 0x03020100 keeps the low source, +0x04040404 takes the high one
+    const unsigned b = (unsigned)(mm + 1) & 3u;
+    const unsigned selA = 0x03020100u + (b & 1u) * 0x04040404u;
+    const unsigned selB = 0x03020100u + (b >> 1) * 0x04040404u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r1[i] = __builtin_amdgcn_perm(s4[(i + 1) & 3], s4[i], selA);
+    float e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __uint_as_float(__builtin_amdgcn_perm(r1[(i + 2) & 3], r1[i], selB));
+    return fmaf(e[3], dN[3], fmaf(e[2], dN[2], fmaf(e[1], dN[1], e[0] * dN[0])));
+}
+
 // wave-wide maximum of non-negative, NaN-free floats without touching LDS: DPP swaps inside each row of 16
 // lanes (quad_perm, row_half_mirror, row_mirror), then four v_readlane + scalar max (bit patterns of
 // non-negative floats order like unsigned integers).  __shfl_xor would cost six dependent ds_bpermute round trips.

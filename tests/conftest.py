@@ -15,6 +15,13 @@ REFERENCE = "/root/reference/node_classification_clean"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle's whole-tensor elementwise ops stop scaling (and then regress) beyond a few dozen threads; the
+    # GPU box has 256 hardware threads (bench.py's thread sweep: 32 is the best)
+    try:
+        import torch
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+    except Exception:  # pragma: no cover
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

@@ -127,14 +127,32 @@ def _model_vs_oracle(model, arch, kind, layers, x, ei, gout, label, tol, chunk=N
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     want, gx_want, g_want = oracle_node_model_fwd_bwd(x, ei, state, gout, arch, kind, layers, spline_order, chunk)
     model = model.to(DEV).train()
+    l1 = {}                                           # per conv: column-wise sum over the nodes of |d loss / d conv output|
+
+    def watch(i):
+        def fwd_hook(_m, _inp, out):
+            out.register_hook(lambda g: l1.__setitem__(i, float(g.abs().sum(0).max())))
+        return fwd_hook
+    hooks = [conv.register_forward_hook(watch(i)) for i, conv in enumerate(model.convs)]
     xd = x.to(DEV).requires_grad_(True)
     out = model(xd, ei.to(DEV) if ei_dev is None else ei_dev)
     out.backward(gout.to(DEV))
+    for h in hooks:
+        h.remove()
     assert_close(out, want, tol, what=f"{label}.logits")
     assert_close(xd.grad, gx_want, tol, what=f"{label}.gx")
     for name, p in model.named_parameters():
-        if p.requires_grad:
-            assert_close(p.grad, g_want[name], tol, what=f"{label}.grad.{name}")
+        if not p.requires_grad:
+            continue
+        parts = name.split(".")
+        if parts[0] == "convs" and parts[-1] == "bias" and len(parts) == 3:
+            # a bias in front of BatchNorm (training mode) has an identically ZERO gradient -- the batch mean is
+            # subtracted -- so what fp32 computes (here and in the reference) is the rounding noise of a cancelling
+            # sum over the nodes: bound it by 1e-5 of the sum of magnitudes instead of comparing noise with 0
+            assert float(g_want[name].abs().max()) <= 1e-9 * max(1.0, l1[int(parts[1])])
+            assert float(p.grad.abs().max()) <= 1e-5 * l1[int(parts[1])], (name, float(p.grad.abs().max()), l1)
+            continue
+        assert_close(p.grad, g_want[name], tol, what=f"{label}.grad.{name}")
     return want
 
 

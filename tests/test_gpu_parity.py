@@ -603,15 +603,20 @@ def test_gcn_conv_weighted_edges_and_sparse_adjacency():
     y.backward(gy.to(DEV))
     assert_close(y, y64, what="weighted y")
     assert_close(xd.grad, x64.grad, what="weighted gx")
-    # sparse adjacency: entry (i, j) = weight of edge j -> i; duplicates are summed by coalesce(), so use unique edges
-    key = ei[1] * n + ei[0]
-    uniq = torch.unique(key, return_inverse=False)
-    ei_u = torch.stack([uniq % n, uniq // n])
-    w_u = torch.rand(ei_u.size(1)) + 0.1
-    adj_t = torch.sparse_coo_tensor(torch.stack([ei_u[1], ei_u[0]]), w_u, (n, n)).to(DEV)
-    y_sp = conv(x.to(DEV), adj_t)
-    y_ew = conv(x.to(DEV), ei_u.to(DEV), w_u.to(DEV))
-    assert_close(y_sp, y_ew, 1e-6, what="sparse adjacency vs edge list")
+    # sparse adjacency: entry (i, j) = weight of edge j -> i, self loops by add_self_loops (+1 on top of an existing
+    # diagonal entry -- torch_geometric's gcn_norm for torch sparse input; oracle.gcn_norm_sparse), fp64 oracle
+    adj_cpu = torch.sparse_coo_tensor(torch.stack([ei[1], ei[0]]), w, (n, n)).coalesce()     # duplicates summed
+    ei_s, w_s = orc.gcn_norm_sparse(adj_cpu.double())
+    x64b = x.double().requires_grad_(True)
+    h64b = orc.kan_linear_forward(x64b, p64["base_weight"], p64["spline_weight"], p64["spline_scaler"], p64["grid"], 3)
+    y64b = orc.sum_aggregate(h64b, ei_s, n, w_s) + conv.bias.detach().cpu().double()
+    y64b.backward(gy.double())
+    xs = x.to(DEV).requires_grad_(True)
+    y_sp = conv(xs, adj_cpu.to(DEV))
+    y_sp.backward(gy.to(DEV))
+    assert_close(y_sp, y64b, what="sparse adjacency y")
+    assert_close(xs.grad, x64b.grad, what="sparse adjacency gx")
+    assert float((y_sp - y).abs().max()) > 1e-3                   # and it is NOT the dense-edge_index normalisation
 
 
 # ------------------------------------------------------------------ GAT flavour
