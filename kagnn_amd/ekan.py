@@ -107,6 +107,10 @@ class KANLinear(nn.Module):
 
     # ------------------------------------------------------------------ hot path
     def _knots(self) -> torch.Tensor:
+        if torch.compiler.is_compiling():
+            # dynamo cannot trace the data_ptr-keyed cache below or its host-side uniformity check: use what an eager
+            # call cached, else assume the (uniform) grid the constructor made -- adaptive grids need one eager call first
+            return self._knots_row if self._knots_row is not None else self.grid[0].contiguous()
         g = self.grid
         key = (g.data_ptr(), g._version, str(g.device))
         if key != self._knots_key:
@@ -189,7 +193,7 @@ class KAN(nn.Module):
 
     def forward(self, x: torch.Tensor, update_grid=False) -> torch.Tensor:
         packs = None
-        if _PACK_CHAIN and not update_grid and x.is_cuda and len(self.layers) > 1:
+        if _PACK_CHAIN and not update_grid and x.is_cuda and len(self.layers) > 1 and not torch.compiler.is_compiling():
             packs = self._pack_chain(x)
         for i, layer in enumerate(self.layers):
             if update_grid:

@@ -72,6 +72,8 @@ class _SumAggregateConv(nn.Module):
         self._eps_val = float(eps)
 
     def _eps(self) -> float:
+        if torch.compiler.is_compiling():
+            return self._eps_val          # the data_ptr-keyed refresh below is not traceable; eps is a fixed buffer
         key = (self.eps.data_ptr(), self.eps._version)
         if key != self._eps_key:              # one host read per change of the buffer, not per call
             self._eps_val = float(self.eps)

@@ -318,15 +318,23 @@ def weighted_gcn_graph(edge_index: torch.Tensor, edge_weight: Optional[torch.Ten
 def _aggregate_raw(x, g: GraphIndex, transposed, self_scale, edge_weight, in_scale, out_scale, bias,
                    skip_self) -> torch.Tensor:
     x = _rows(x)
-    n, f = x.shape
-    if n != g.num_nodes:
-        raise ValueError(f"x has {n} rows but the graph has {g.num_nodes} nodes")
+    if x.size(0) != g.num_nodes:
+        raise ValueError(f"x has {x.size(0)} rows but the graph has {g.num_nodes} nodes")
     rowptr, col, _, hub, nhub = g.side(transposed)
+    return _aggregate_csr(x, rowptr, col, hub, nhub, g.hub_threshold, self_scale, edge_weight, in_scale, out_scale, bias,
+                          skip_self)
+
+
+def _aggregate_csr(x, rowptr, col, hub, nhub, hub_threshold, self_scale, edge_weight, in_scale, out_scale, bias,
+                   skip_self) -> torch.Tensor:
+    n, f = x.shape
+    if rowptr.numel() != n + 1:
+        raise ValueError(f"x has {n} rows but the graph has {rowptr.numel() - 1} nodes")
     out = torch.empty((n, f), dtype=torch.float32, device=x.device)
     ws = _ws(_sizes("kagnn_aggregate_workspace_bytes", nhub, f), x.device) if nhub else None   # per-segment partial sums
     _call("kagnn_aggregate_sum", _ptr(x), _ld(x), _ptr(out), f, _ptr(rowptr), _ptr(col),
               _ptr(edge_weight), n, f, float(self_scale), _ptr(in_scale), _ptr(out_scale), _ptr(bias),
-              int(skip_self), _ptr(hub) if nhub else None, nhub, g.hub_threshold, _ptr(ws),
+              int(skip_self), _ptr(hub) if nhub else None, nhub, hub_threshold, _ptr(ws),
               ws.numel() if nhub else 0, _stream())
     return out
 
@@ -363,6 +371,9 @@ class _AggregateFn(Function):
 
 def aggregate_sum(x, g: GraphIndex, self_scale: float = 1.0, edge_weight=None, in_scale=None,
                   out_scale=None, bias=None, skip_self_loops: bool = False) -> torch.Tensor:
+    if torch.compiler.is_compiling():
+        from . import library
+        return library.aggregate(x, g, self_scale, edge_weight, in_scale, out_scale, bias, skip_self_loops)
     return _AggregateFn.apply(x, bias, g, float(self_scale), edge_weight, in_scale, out_scale,
                               bool(skip_self_loops))
 
@@ -413,31 +424,40 @@ def segment_ptr(batch: torch.Tensor, num_graphs: int) -> torch.Tensor:
     return ptr
 
 
+def _segment_pool_raw(x, seg, mean):
+    b, f = seg.numel() - 1, x.size(1)
+    out = torch.empty((b, f), dtype=torch.float32, device=x.device)
+    _call("kagnn_segment_pool", _ptr(x), _ld(x), _ptr(out), f, _ptr(seg), b, f, int(mean), _stream())
+    return out
+
+
+def _segment_broadcast_raw(gout, seg, n, mean):
+    b, f = gout.shape
+    gx = torch.empty((n, f), dtype=torch.float32, device=gout.device)
+    _call("kagnn_segment_broadcast", _ptr(gout), _ld(gout), _ptr(gx), f, _ptr(seg), b, f, int(mean), _stream())
+    return gx
+
+
 class _SegmentPoolFn(Function):
     @staticmethod
     @_on_operand_device
     def forward(ctx, x, seg, mean):
         _need_cuda(x, seg)
         x = _rows(x)
-        b, f = seg.numel() - 1, x.size(1)
-        out = torch.empty((b, f), dtype=torch.float32, device=x.device)
-        _call("kagnn_segment_pool", _ptr(x), _ld(x), _ptr(out), f, _ptr(seg), b, f, int(mean), _stream())
         ctx.seg, ctx.mean, ctx.n = seg, mean, x.size(0)
-        return out
+        return _segment_pool_raw(x, seg, mean)
 
     @staticmethod
     @once_differentiable
     @_on_operand_device
     def backward(ctx, gout):
-        gout = _rows(gout)
-        b, f = gout.shape
-        gx = torch.empty((ctx.n, f), dtype=torch.float32, device=gout.device)
-        _call("kagnn_segment_broadcast", _ptr(gout), _ld(gout), _ptr(gx), f, _ptr(ctx.seg), b, f,
-                  int(ctx.mean), _stream())
-        return gx, None, None
+        return _segment_broadcast_raw(_rows(gout), ctx.seg, ctx.n, ctx.mean), None, None
 
 
 def segment_pool(x, seg_ptr, mean: bool = False) -> torch.Tensor:
+    if torch.compiler.is_compiling():
+        from . import library
+        return library.segment_pool(x, seg_ptr, bool(mean))
     return _SegmentPoolFn.apply(x, seg_ptr, bool(mean))
 
 
@@ -476,29 +496,60 @@ def _weights_key(bw, sw, sc):
     return tuple((t.data_ptr(), t._version) for t in (bw, sw, sc) if t is not None)
 
 
+# raw (no autograd) pieces of the KANLinear forward / backward: shared by the autograd.Function below (eager) and by the
+# torch.library ops of kagnn_amd/library.py (torch.compile sees those as opaque ops)
+def _kan_fwd_raw(x, bw, sw, sc, knots, grid_size, spline_order, mode, packed=None, pack_key=None):
+    """-> (y, pack_dx): forward output and the input-gradient pack of the current weights"""
+    n, fin = x.shape
+    fout = sw.size(0)
+    if packed is not None and packed[2] == pack_key:
+        pack_f, pack_d = packed[0], packed[1]         # packed with its chain (kan_pack_chain), weights unchanged since
+    else:
+        fb, db = _sizes("kagnn_kan_pack_bytes", fin, fout, grid_size, spline_order, mode, outputs=2)
+        pack_f, pack_d = _ws(fb, x.device), _ws(db, x.device)
+        _call("kagnn_kan_pack", _ptr(bw), _ptr(sw), _ptr(sc), fin, fout, grid_size, spline_order, mode,
+              _ptr(pack_f), _ptr(pack_d), _stream())
+    y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
+    wb = _sizes("kagnn_kan_fwd_workspace_bytes", n, fin, fout, grid_size, spline_order, mode)
+    ws = _ws(wb, x.device) if wb else None
+    _call("kagnn_kan_linear_fwd", _ptr(x), _ld(x), n, _ptr(knots), fin, fout, grid_size,
+          spline_order, mode, _ptr(pack_f), _ptr(y), fout, _ptr(ws), wb, _stream())
+    return y, pack_d
+
+
+def _kan_bwd_input_raw(x, gy, knots, pack_d, fin, fout, G, K, mode):
+    n = x.size(0)
+    gx = torch.empty((n, fin), dtype=torch.float32, device=x.device)
+    _call("kagnn_kan_linear_bwd_input", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
+          fout, G, K, mode, _ptr(pack_d), _ptr(gx), fin, _stream())
+    return gx
+
+
+def _kan_bwd_weight_raw(x, gy, knots, sw, sc, fin, fout, G, K, mode, has_base):
+    n = x.size(0)
+    ws = _ws(_sizes("kagnn_kan_bwd_weight_workspace_bytes", n, fin, fout, G, K, mode), x.device)
+    gbw = torch.empty((fout, fin), dtype=torch.float32, device=x.device) if has_base else None
+    gsw = torch.empty((fout, fin, G + K), dtype=torch.float32, device=x.device)
+    gsc = None if sc is None else torch.empty((fout, fin), dtype=torch.float32, device=x.device)
+    _call("kagnn_kan_linear_bwd_weight", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
+          fout, G, K, mode, _ptr(sw), _ptr(sc), _ptr(gbw), _ptr(gsw), _ptr(gsc), _ptr(ws),
+          ws.numel(), _stream())
+    return gbw, gsw, gsc
+
+
 class _KANLinearFn(Function):
     @staticmethod
     @_on_operand_device
     def forward(ctx, x, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, packed=None):
         _need_cuda(x, base_weight, spline_weight, spline_scaler, knots)
         x = _rows(x)
-        n, fin = x.shape
+        fin = x.size(1)
         fout = spline_weight.size(0)
         bw = None if base_weight is None else base_weight.contiguous()     # None: no SiLU branch (coefficient groups)
         sw = spline_weight.contiguous()
         sc = None if spline_scaler is None else spline_scaler.contiguous()
-        if packed is not None and packed[2] == _weights_key(base_weight, spline_weight, spline_scaler):
-            pack_f, pack_d = packed[0], packed[1]         # packed with its chain (kan_pack_chain), weights unchanged since
-        else:
-            fb, db = _sizes("kagnn_kan_pack_bytes", fin, fout, grid_size, spline_order, mode, outputs=2)
-            pack_f, pack_d = _ws(fb, x.device), _ws(db, x.device)
-            _call("kagnn_kan_pack", _ptr(bw), _ptr(sw), _ptr(sc), fin, fout, grid_size, spline_order, mode,
-                      _ptr(pack_f), _ptr(pack_d), _stream())
-        y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
-        wb = _sizes("kagnn_kan_fwd_workspace_bytes", n, fin, fout, grid_size, spline_order, mode)
-        ws = _ws(wb, x.device) if wb else None
-        _call("kagnn_kan_linear_fwd", _ptr(x), _ld(x), n, _ptr(knots), fin, fout, grid_size,
-                  spline_order, mode, _ptr(pack_f), _ptr(y), fout, _ptr(ws), wb, _stream())
+        y, pack_d = _kan_fwd_raw(x, bw, sw, sc, knots, grid_size, spline_order, mode, packed,
+                                 _weights_key(base_weight, spline_weight, spline_scaler) if packed is not None else None)
         ctx.save_for_backward(x, sw, sc, knots, pack_d)
         ctx.dims = (fin, fout, grid_size, spline_order, mode)
         ctx.has_base = bw is not None
@@ -511,20 +562,11 @@ class _KANLinearFn(Function):
         x, sw, sc, knots, pack_d = ctx.saved_tensors
         fin, fout, G, K, mode = ctx.dims
         gy = _rows(gy)
-        n = x.size(0)
         gx = gbw = gsw = gsc = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty((n, fin), dtype=torch.float32, device=x.device)
-            _call("kagnn_kan_linear_bwd_input", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
-                      fout, G, K, mode, _ptr(pack_d), _ptr(gx), fin, _stream())
+            gx = _kan_bwd_input_raw(x, gy, knots, pack_d, fin, fout, G, K, mode)
         if any(ctx.needs_input_grad[1:4]):
-            ws = _ws(_sizes("kagnn_kan_bwd_weight_workspace_bytes", n, fin, fout, G, K, mode), x.device)
-            gbw = torch.empty((fout, fin), dtype=torch.float32, device=x.device) if ctx.has_base else None
-            gsw = torch.empty((fout, fin, G + K), dtype=torch.float32, device=x.device)
-            gsc = None if sc is None else torch.empty((fout, fin), dtype=torch.float32, device=x.device)
-            _call("kagnn_kan_linear_bwd_weight", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
-                      fout, G, K, mode, _ptr(sw), _ptr(sc), _ptr(gbw), _ptr(gsw), _ptr(gsc), _ptr(ws),
-                      ws.numel(), _stream())
+            gbw, gsw, gsc = _kan_bwd_weight_raw(x, gy, knots, sw, sc, fin, fout, G, K, mode, ctx.has_base)
         return gx, gbw, gsw, gsc, None, None, None, None, None
 
 
@@ -561,6 +603,10 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
             y = part if y is None else y + part
             c0 += cg
         return y
+    if torch.compiler.is_compiling():
+        from . import library
+        return library.kan_linear(x, base_weight, spline_weight, spline_scaler, knots, int(grid_size), int(spline_order),
+                                  int(mode))[0]
     return _KANLinearFn.apply(x, base_weight, spline_weight, spline_scaler, knots, int(grid_size),
                               int(spline_order), int(mode), packed)
 
@@ -620,30 +666,60 @@ def kan_grid_refit(x, grid_old, grid_new, spline_weight, spline_scaler, grid_siz
 
 
 # ======================================================================== FastKAN layer
+def _fastkan_fwd_raw(x, ln_w, ln_b, spline_w, base_w, base_b, centers, denominator, ln_eps, mode):
+    """-> (y, row_stats or None)"""
+    n, fin = x.shape
+    fout = spline_w.size(0)
+    ng = centers.numel()
+    if spline_w.size(1) != fin * ng:
+        raise AssertionError("spline_linear.weight must be [out, in*num_grids]")
+    sw = spline_w.contiguous()
+    lw = None if ln_w is None else ln_w.contiguous()
+    lb = None if ln_b is None else ln_b.contiguous()
+    bw = None if base_w is None else base_w.contiguous()
+    bb = None if base_b is None else base_b.contiguous()
+    ws = _ws(_sizes("kagnn_fastkan_fwd_workspace_bytes", n, fin, fout, ng, mode), x.device)
+    stats = torch.empty((n, 2), dtype=torch.float32, device=x.device) if lw is not None else None
+    y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
+    _call("kagnn_fastkan_fwd", _ptr(x), _ld(x), n, fin, fout, ng, _ptr(centers), float(denominator),
+          _ptr(lw), _ptr(lb), float(ln_eps), _ptr(sw), _ptr(bw), _ptr(bb), _ptr(y), fout,
+          _ptr(stats), mode, _ptr(ws), ws.numel(), _stream())
+    return y, stats
+
+
+def _fastkan_bwd_raw(x, gy, ln_w, ln_b, spline_w, base_w, centers, stats, denominator, ln_eps, mode):
+    """-> (gx, g_ln_weight, g_ln_bias, g_spline_weight, g_base_weight, g_base_bias); absent ones are None"""
+    n, fin = x.shape
+    fout = spline_w.size(0)
+    ng = centers.numel()
+    dev = x.device
+    sw = spline_w.contiguous()
+    lw = None if ln_w is None else ln_w.contiguous()
+    lb = None if ln_b is None else ln_b.contiguous()
+    bw = None if base_w is None else base_w.contiguous()
+    ws = _ws(_sizes("kagnn_fastkan_bwd_workspace_bytes", n, fin, fout, ng, mode), dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    gx = torch.empty((n, fin), **f32)
+    glw = torch.empty(fin, **f32) if lw is not None else None
+    glb = torch.empty(fin, **f32) if lw is not None else None
+    gsw = torch.empty((fout, fin * ng), **f32)
+    gbw = torch.empty((fout, fin), **f32) if bw is not None else None
+    gbb = torch.empty(fout, **f32) if bw is not None else None
+    _call("kagnn_fastkan_bwd", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, fin, fout, ng, _ptr(centers), float(denominator),
+          _ptr(lw), _ptr(lb), float(ln_eps), _ptr(sw), _ptr(bw), _ptr(stats), _ptr(gx), fin, _ptr(glw),
+          _ptr(glb), _ptr(gsw), _ptr(gbw), _ptr(gbb), mode, _ptr(ws), ws.numel(), _stream())
+    return gx, glw, glb, gsw, gbw, gbb
+
+
 class _FastKANFn(Function):
     @staticmethod
     @_on_operand_device
     def forward(ctx, x, ln_w, ln_b, spline_w, base_w, base_b, centers, denominator, ln_eps, mode):
         _need_cuda(x, spline_w, centers)
         x = _rows(x)
-        n, fin = x.shape
-        fout = spline_w.size(0)
-        ng = centers.numel()
-        if spline_w.size(1) != fin * ng:
-            raise AssertionError("spline_linear.weight must be [out, in*num_grids]")
-        sw = spline_w.contiguous()
-        lw = None if ln_w is None else ln_w.contiguous()
-        lb = None if ln_b is None else ln_b.contiguous()
-        bw = None if base_w is None else base_w.contiguous()
-        bb = None if base_b is None else base_b.contiguous()
-        ws = _ws(_sizes("kagnn_fastkan_fwd_workspace_bytes", n, fin, fout, ng, mode), x.device)
-        stats = torch.empty((n, 2), dtype=torch.float32, device=x.device) if lw is not None else None
-        y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
-        _call("kagnn_fastkan_fwd", _ptr(x), _ld(x), n, fin, fout, ng, _ptr(centers), float(denominator),
-                  _ptr(lw), _ptr(lb), float(ln_eps), _ptr(sw), _ptr(bw), _ptr(bb), _ptr(y), fout,
-                  _ptr(stats), mode, _ptr(ws), ws.numel(), _stream())
-        ctx.save_for_backward(x, lw, lb, sw, bw, centers, stats)
-        ctx.meta = (fin, fout, ng, float(denominator), float(ln_eps), bb is not None, mode)
+        y, stats = _fastkan_fwd_raw(x, ln_w, ln_b, spline_w, base_w, base_b, centers, denominator, ln_eps, mode)
+        ctx.save_for_backward(x, ln_w, ln_b, spline_w, base_w, centers, stats)
+        ctx.meta = (float(denominator), float(ln_eps), base_b is not None, mode)
         return y
 
     @staticmethod
@@ -651,20 +727,8 @@ class _FastKANFn(Function):
     @_on_operand_device
     def backward(ctx, gy):
         x, lw, lb, sw, bw, centers, stats = ctx.saved_tensors
-        fin, fout, ng, den, eps, has_bb, mode = ctx.meta
-        gy = _rows(gy)
-        n, dev = x.size(0), x.device
-        ws = _ws(_sizes("kagnn_fastkan_bwd_workspace_bytes", n, fin, fout, ng, mode), dev)
-        f32 = dict(dtype=torch.float32, device=dev)
-        gx = torch.empty((n, fin), **f32)
-        glw = torch.empty(fin, **f32) if lw is not None else None
-        glb = torch.empty(fin, **f32) if lw is not None else None
-        gsw = torch.empty((fout, fin * ng), **f32)
-        gbw = torch.empty((fout, fin), **f32) if bw is not None else None
-        gbb = torch.empty(fout, **f32) if bw is not None else None
-        _call("kagnn_fastkan_bwd", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, fin, fout, ng, _ptr(centers), den,
-                  _ptr(lw), _ptr(lb), eps, _ptr(sw), _ptr(bw), _ptr(stats), _ptr(gx), fin, _ptr(glw),
-                  _ptr(glb), _ptr(gsw), _ptr(gbw), _ptr(gbb), mode, _ptr(ws), ws.numel(), _stream())
+        den, eps, has_bb, mode = ctx.meta
+        gx, glw, glb, gsw, gbw, gbb = _fastkan_bwd_raw(x, _rows(gy), lw, lb, sw, bw, centers, stats, den, eps, mode)
         return gx, glw, glb, gsw, gbw, (gbb if has_bb else None), None, None, None, None
 
 
@@ -778,25 +842,43 @@ def gat_aggregate(xh, att_src, att_dst, bias, g: GraphIndex, heads: int, channel
 
 
 # ======================================================================== BatchNorm1d (conv epilogue)
+def _batchnorm_fwd_raw(x, weight, bias, running_mean, running_var, training, momentum, eps):
+    """-> (y, save_mean, save_rstd); running statistics are updated in place by the kernel"""
+    n, f = x.shape
+    ws = _ws(_sizes("kagnn_batchnorm_workspace_bytes", n, f), x.device)
+    y = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    mean = torch.empty(f, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(f, dtype=torch.float32, device=x.device)
+    w = None if weight is None else weight.contiguous()
+    b = None if bias is None else bias.contiguous()
+    _call("kagnn_batchnorm_fwd", _ptr(x), _ld(x), n, f, _ptr(w), _ptr(b), _ptr(running_mean), _ptr(running_var),
+          float(momentum), float(eps), int(bool(training)), _ptr(y), f, _ptr(mean), _ptr(rstd), _ptr(ws),
+          ws.numel(), _stream())
+    return y, mean, rstd
+
+
+def _batchnorm_bwd_raw(x, gy, weight, mean, rstd, training, want_gx, want_bias):
+    n, f = x.shape
+    w = None if weight is None else weight.contiguous()
+    ws = _ws(_sizes("kagnn_batchnorm_workspace_bytes", n, f), x.device)
+    gx = torch.empty((n, f), dtype=torch.float32, device=x.device) if want_gx else None
+    gw = torch.empty(f, dtype=torch.float32, device=x.device) if w is not None else None
+    gb = torch.empty(f, dtype=torch.float32, device=x.device) if want_bias else None
+    _call("kagnn_batchnorm_bwd", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, f, _ptr(w), _ptr(mean), _ptr(rstd),
+          int(training), _ptr(gx), f, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), _stream())
+    return gx, gw, gb
+
+
 class _BatchNormFn(Function):
     @staticmethod
     @_on_operand_device
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
         _need_cuda(x, weight, bias, running_mean, running_var)
         x = _rows(x)
-        n, f = x.shape
-        ws = _ws(_sizes("kagnn_batchnorm_workspace_bytes", n, f), x.device)
-        y = torch.empty((n, f), dtype=torch.float32, device=x.device)
-        mean = torch.empty(f, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(f, dtype=torch.float32, device=x.device)
-        w = None if weight is None else weight.contiguous()
-        b = None if bias is None else bias.contiguous()
-        _call("kagnn_batchnorm_fwd", _ptr(x), _ld(x), n, f, _ptr(w), _ptr(b), _ptr(running_mean), _ptr(running_var),
-              float(momentum), float(eps), int(bool(training)), _ptr(y), f, _ptr(mean), _ptr(rstd), _ptr(ws),
-              ws.numel(), _stream())
-        ctx.save_for_backward(x, w, mean, rstd)
+        y, mean, rstd = _batchnorm_fwd_raw(x, weight, bias, running_mean, running_var, training, momentum, eps)
+        ctx.save_for_backward(x, weight, mean, rstd)
         ctx.training = bool(training)
-        ctx.has_bias = b is not None
+        ctx.has_bias = bias is not None
         return y                      # running statistics are grad-free buffers, updated in place by the kernel
 
     @staticmethod
@@ -804,14 +886,7 @@ class _BatchNormFn(Function):
     @_on_operand_device
     def backward(ctx, gy):
         x, w, mean, rstd = ctx.saved_tensors
-        gy = _rows(gy)
-        n, f = x.shape
-        ws = _ws(_sizes("kagnn_batchnorm_workspace_bytes", n, f), x.device)
-        gx = torch.empty((n, f), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
-        gw = torch.empty(f, dtype=torch.float32, device=x.device) if w is not None else None
-        gb = torch.empty(f, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        _call("kagnn_batchnorm_bwd", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, f, _ptr(w), _ptr(mean), _ptr(rstd),
-              int(ctx.training), _ptr(gx), f, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), _stream())
+        gx, gw, gb = _batchnorm_bwd_raw(x, _rows(gy), w, mean, rstd, ctx.training, ctx.needs_input_grad[0], ctx.has_bias)
         return gx, gw, gb, None, None, None, None, None
 
 
@@ -819,6 +894,9 @@ def batch_norm(x, weight, bias, running_mean, running_var, training: bool, momen
     """torch.nn.functional.batch_norm on [N, F] rows (reference ``models.py:195-202`` epilogue)."""
     if x.size(0) == 0:
         return x.new_empty(x.shape)
+    if torch.compiler.is_compiling():
+        from . import library
+        return library.batch_norm_traced(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps))
     return _BatchNormFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps)
 
 
@@ -874,5 +952,9 @@ def fastkan_layer(x, ln_weight, ln_bias, spline_weight, base_weight, base_bias, 
             y = part if y is None else y + part
             c0 += cg
         return y
+    if torch.compiler.is_compiling():
+        from . import library
+        return library.fastkan_layer(x, ln_weight, ln_bias, spline_weight, base_weight, base_bias, centers,
+                                     float(denominator), float(ln_eps), int(mode))[0]
     return _FastKANFn.apply(x, ln_weight, ln_bias, spline_weight, base_weight, base_bias, centers,
                             float(denominator), float(ln_eps), int(mode))

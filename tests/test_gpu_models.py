@@ -348,6 +348,52 @@ def test_modules_on_a_non_current_device():
         ops.kan_linear(x.detach().to(DEV), layer.base_weight, layer.spline_weight, layer.spline_scaler, layer._knots(), 5, 3)
 
 
+# ------------------------------------------------------------------ torch.library registration
+@pytest.mark.parametrize("arch,kind", [("kan", "gin"), ("kan", "gcn"), ("fastkan", "gin"), ("fastkan", "gcn")])
+def test_models_trace_into_one_graph_of_kagnn_ops(arch, kind):
+    """torch.compile(fullgraph=True) must not graph-break on the ctypes calls: under dynamo the layers route to the
+    torch.library ops of kagnn_amd/library.py.  Same kernels => same results as eager, forward and backward
+    (backend aot_eager: the point is the opaque-op registration + autograd formulas, not a code generator)."""
+    import torch._dynamo
+    from kagnn_amd import library                                    # registers kagnn::*
+    assert "kagnn::kan_linear" in str(torch.ops.kagnn.kan_linear.default._schema)
+    torch._dynamo.reset()
+    n, e, fin, hid, classes = 3000, 24000, 24, 16, 5
+    ei = orc.powerlaw_graph(n, e, seed=7)
+    torch.manual_seed(11)
+    cls = kagnn_amd.GKAN_Nodes if arch == "kan" else kagnn_amd.GFASTKAN_Nodes
+    model = cls(kind, 2, fin, hid, classes, skip=True, grid_size=4).to(DEV).train()
+    g = ops.GraphIndex(ei.to(DEV), n)
+    x = (torch.randn(n, fin, generator=torch.Generator().manual_seed(1)) * 0.5).to(DEV)
+    gout = torch.randn(n, classes, generator=torch.Generator().manual_seed(2)).to(DEV)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(fn):
+        model.load_state_dict(state)                                 # same BatchNorm running statistics going in
+        model.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        out = fn(xr, g)
+        out.backward(gout)
+        return ([out.detach(), xr.grad] + [p.grad.clone() for p in model.parameters() if p.grad is not None],
+                {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
+    eager, eager_stats = run(model)
+    compiled = torch.compile(model, backend="aot_eager", fullgraph=True)
+    traced, traced_stats = run(compiled)
+    for a, b in zip(eager, traced):
+        assert_close(b, a, 1e-6, what=f"compiled vs eager {arch}/{kind}")
+    for k in eager_stats:
+        assert_close(traced_stats[k], eager_stats[k], 1e-6, what=f"compiled {k}")
+    # the traced graph holds the opaque ops
+    seen = []
+
+    def spy(gm, example_inputs):
+        seen.extend(str(nd.target) for nd in gm.graph.nodes if nd.op == "call_function")
+        return gm.forward
+    torch._dynamo.reset()
+    torch.compile(model, backend=spy, fullgraph=True)(x, g)
+    assert any("kagnn" in t for t in seen), seen[:20]
+
+
 # ------------------------------------------------------------------ precision report (VERDICT r01 weak #2/#3)
 def test_precision_report_split_vs_fp32_vs_reference_fp32():
     """errors against the fp64 oracle, side by side: the HIP path in exact-fp32 mode, in split mode, and the
