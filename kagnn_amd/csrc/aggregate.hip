@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void agg_hub_merge_kernel(AggArgs a, const int
     *o = v;
 }
 
+
 // any F / any alignment: grid (N, ceil(F/256)), one thread per feature, edges walked in order.
 __global__ __launch_bounds__(256) void agg_rows_generic_kernel(AggArgs a) {
     const long i = blockIdx.x;
