@@ -186,7 +186,7 @@ def measure_traffic(args, kernel_prefix):
         return None, "rocprofv3 unavailable or this process is itself being profiled"
     argv = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-traffic", "--no-fp32",
             "--workload", args.workload, "--nodes", str(args.nodes), "--edges", str(args.edges), "--order", str(args.order),
-            "--precision", args.precision]
+            "--precision", args.precision, "--act", args.act]
     fetch = _pmc_pass("FETCH_SIZE", argv, 240)
     write = _pmc_pass("WRITE_SIZE", argv, 240)
     per_kernel = {}
@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--grid", type=int, default=None, help="override the workload's grid size")
     ap.add_argument("--order", type=int, default=3)
     ap.add_argument("--precision", default=os.environ.get("KAGNN_PRECISION", "split"))
+    ap.add_argument("--act", default=os.environ.get("KAGNN_ACT", "fp32"), choices=["fp32", "bf16"],
+                    help="bf16: the rows the aggregation gathers are stored as bf16 (build-defined mode for config 2; NOT the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="nodes in the CPU-baseline sample")
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline at the full workload size (needs ~48 GB of free RAM, ~2 min)")
@@ -259,6 +261,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 step timing")
     args = ap.parse_args()
     os.environ["KAGNN_PRECISION"] = args.precision
+    os.environ["KAGNN_ACT"] = args.act
     hidden, grid = WORKLOADS[args.workload]
     f = args.hidden or hidden
     grid = args.grid or grid
@@ -322,7 +325,10 @@ def main():
     alt = None
     if world == 1:
         conv = conv.to(dev)
-        x = x_full.to(dev).requires_grad_(True)
+        x = x_full.to(dev)
+        if args.act == "bf16":
+            x = x.to(torch.bfloat16)                      # the mode's storage format: the activation ARRIVES as bf16
+        x = x.requires_grad_(True)
         gy = gy_full.to(dev)
         params = list(conv.parameters())
 
@@ -414,6 +420,8 @@ def main():
         kan = kan_flops(nrows, fl, f, c)
         spec = {   # entry point -> (what, algorithmic bytes per launch, algorithmic flops per launch)
             "kagnn_aggregate_sum": ("neighbour aggregation (fwd; bwd = same kernel on the transposed CSR)", agg_bytes(n, e, fl), 2.0 * e * fl),
+            "kagnn_aggregate_sum_bf16": ("neighbour aggregation, bf16 gather operands (fwd: bf16 in / fp32 out; bwd: bf16 in / bf16 out)",
+                                         e * (2 * fl + 4) + n * (2 * fl + 4 * fl + 4), 2.0 * e * fl),
             "kagnn_kan_linear_fwd": ("KANLinear forward", 4.0 * nrows * (fl + f), kan),
             "kagnn_kan_linear_bwd_input": ("KANLinear input gradient (reads x, gy; writes gx)", 4.0 * nrows * (2 * fl + f), kan),
             "kagnn_kan_linear_bwd_weight": ("KANLinear weight gradient (reads x, gy)", 4.0 * nrows * (fl + f), kan),
@@ -431,11 +439,11 @@ def main():
                             "measured_in": "timed region" if name in prof else "3 untimed profile steps",
                             "algorithmic_bytes_per_launch": nbytes, "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
                             "algorithmic_flops_per_launch": flops,
-                            "mfma_TFs_incl_split_products": tf, "mfma_frac": tf / mfma_peak if name != "kagnn_aggregate_sum" else 0.0,
-                            "bound": "hbm" if name == "kagnn_aggregate_sum" else "mfma/valu issue"})
+                            "mfma_TFs_incl_split_products": tf, "mfma_frac": tf / mfma_peak if not name.startswith("kagnn_aggregate_sum") else 0.0,
+                            "bound": "hbm" if name.startswith("kagnn_aggregate_sum") else "mfma/valu issue"})
         by_name = {k["entry_point"]: k for k in kernels}
         d = by_name.get(dom)
-        if d is not None and dom == "kagnn_aggregate_sum":
+        if d is not None and dom.startswith("kagnn_aggregate_sum"):
             roof = {"kernel": dom, "bound": "hbm", "achieved": d["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"]}
         elif d is not None:
@@ -453,12 +461,13 @@ def main():
             "metric": "edges/sec KAN-GIN fwd+bwd, hidden=64 grid=5, 1M-node synthetic; HBM % peak",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
-            "vs_baseline": None, "dtype": "f32" if fp32_mode else "f32 (fp16 hi/lo split operands, fp32 accumulate)",
+            "vs_baseline": None, "dtype": ("f32" if fp32_mode else "f32 (fp16 hi/lo split operands, fp32 accumulate)") +
+                                          (" + bf16 gather operands (KAGNN_ACT=bf16, build-defined config-2 mode)" if args.act == "bf16" else ""),
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: KAN-GIN conv layer fwd+bwd (aggregate + KAN([{f},{f},{f}]) grid={grid} order={args.order}), "
                                    f"power-law graph N={n} E={e} seed 0 (SURVEY 8(d))",
                        "nodes": n, "edges": e, "hidden": f, "grid_size": grid, "spline_order": args.order,
-                       "precision": args.precision, "parallelism": parallelism},
+                       "precision": args.precision, "activation_storage": args.act, "parallelism": parallelism},
             "layer_algorithmic_bytes": layer_bytes(n, e, f),
             "layer_hbm_GBs": layer_gbs, "layer_hbm_frac": layer_gbs / HBM_PEAK_GBS,
             "fp32_mode_ms_per_step": fp32_ms,
@@ -477,7 +486,7 @@ def main():
             for k in kernels:
                 k["hbm_frac_of_copy_bw"] = k["hbm_GBs"] / copy_gbs
         if not args.no_extras and world == 1:
-            out["secondary"] = secondary_figures(dev, conv, graph, x, n, e, f, grid, args.order)
+            out["secondary"] = secondary_figures(dev, conv, graph, x.detach().float(), n, e, f, grid, args.order)
             conv_ms = 3 * ms
             out["secondary"]["model_step"]["conv_layers_share"] = conv_ms / out["secondary"]["model_step"]["ms_per_step"]
         if not args.no_traffic and world == 1:

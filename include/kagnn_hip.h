@@ -39,6 +39,10 @@ extern "C" {
 #define KAGNN_PREC_FP32_GRID 2  /* exact fp32, and `knots` is the whole [in, G+2k+1] grid buffer: per-feature,
                                  * non-uniform knot rows (what KANLinear.update_grid leaves behind)       */
 
+/* element type of an activation / gradient matrix where an entry point accepts more than fp32 */
+#define KAGNN_DTYPE_F32 0
+#define KAGNN_DTYPE_BF16 1
+
 int kagnn_version(void);
 const char* kagnn_last_error(void);
 
@@ -94,6 +98,23 @@ int kagnn_aggregate_sum(const float* x, int64_t ldx, float* out, int64_t ldo,
                         int32_t skip_self_loops,
                         const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same aggregation with bf16 GATHER OPERANDS (`KAGNN_ACT=bf16`; BASELINE.json config 2 -- the reference has no
+ * reduced-precision path, SURVEY.md 8(d) makes this a build-defined mode): `x` rows are bf16 (leading dimension in
+ * ELEMENTS, a multiple of 8; 16-byte aligned), sums are accumulated in fp32 and written as fp32 (`out_dtype` =
+ * KAGNN_DTYPE_F32: the forward, feeding the KAN layer) or bf16 with ONE round-to-nearest-even per element
+ * (KAGNN_DTYPE_BF16: the input gradient of a bf16 activation).  Halves the E * num_feat * 4 bytes of the gather.
+ * num_feat % 8 == 0, <= 512 (else KAGNN_ERR_UNSUPPORTED: convert to fp32 and call kagnn_aggregate_sum).
+ * Deterministic; workspace as for kagnn_aggregate_sum.  kagnn_rows_to_bf16 converts fp32 rows (RNE). */
+int kagnn_aggregate_sum_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t out_dtype,
+                             const int32_t* rowptr, const int32_t* col, const float* edge_weight,
+                             int64_t num_nodes, int32_t num_feat, float self_scale,
+                             const float* in_scale, const float* out_scale, const float* bias,
+                             int32_t skip_self_loops,
+                             const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int kagnn_rows_to_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t num_rows, int32_t num_feat,
+                       void* stream);
 
 /* GINE message: out[i,:] = self_scale*x[i,:] + sum_e relu(x[col[e],:] + edge_attr[perm[e],:])
  * (torch_geometric GINEConv as used by graph_regression/models.py:98,113).              */
@@ -166,12 +187,14 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t num_rows, const fl
                          void* stream);
 
 /* gx[N,in] = d loss / d x given gy[N,out] (x is the saved layer input; bases' derivatives are
- * recomputed, nothing but x was saved).                                                   */
+ * recomputed, nothing but x was saved).  gx_dtype = KAGNN_DTYPE_F32, or KAGNN_DTYPE_BF16 (split-precision
+ * B-spline layers with <= 128 outputs: the rows the transposed aggregation gathers next, rounded once) with
+ * ldgx in bf16 elements.                                                                    */
 int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int64_t ldgy,
                                int64_t num_rows, const float* knots, int32_t in_features,
                                int32_t out_features, int32_t grid_size, int32_t spline_order,
-                               int32_t mode, const void* pack_dx, float* gx, int64_t ldgx,
-                               void* stream);
+                               int32_t mode, const void* pack_dx, void* gx, int64_t ldgx,
+                               int32_t gx_dtype, void* stream);
 
 /* parameter gradients: g_base_weight[out,in] (NULL when not wanted), g_spline_weight[out,in,G+k],
  * g_spline_scaler[out,in] (NULL when the layer has no scaler).  `workspace` holds the per-wave

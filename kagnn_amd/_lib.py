@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("KAGNN_LIB") or os.path.join(_HERE, "lib", "libkagnn_h
 PREC_FP32 = 0
 PREC_SPLIT = 1
 PREC_FP32_GRID = 2      # exact fp32 on per-feature, non-uniform knot rows (after update_grid)
+DTYPE_F32, DTYPE_BF16 = 0, 1
 
 _P = c_void_p
 _SIGNATURES = {
@@ -30,6 +31,9 @@ _SIGNATURES = {
     "kagnn_aggregate_workspace_bytes": (c_int32, [c_int64, c_int32, POINTER(c_size_t)]),
     "kagnn_aggregate_sum": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int32, c_float,
                                       _P, _P, _P, c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
+    "kagnn_aggregate_sum_bf16": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P, c_int64, c_int32, c_float,
+                                           _P, _P, _P, c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
+    "kagnn_rows_to_bf16": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P]),
     "kagnn_aggregate_gine": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64,
                                        c_int32, c_float, _P]),
     "kagnn_aggregate_gine_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P,
@@ -45,7 +49,7 @@ _SIGNATURES = {
     "kagnn_kan_linear_fwd": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, c_int32,
                                        c_int32, _P, _P, c_int64, _P, c_size_t, _P]),
     "kagnn_kan_linear_bwd_input": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, c_int32, c_int32,
-                                             c_int32, c_int32, c_int32, _P, _P, c_int64, _P]),
+                                             c_int32, c_int32, c_int32, _P, _P, c_int64, c_int32, _P]),
     "kagnn_kan_bwd_weight_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32,
                                                        c_int32, POINTER(c_size_t)]),
     "kagnn_kan_linear_bwd_weight": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, c_int32, c_int32,

@@ -6,6 +6,13 @@ namespace kagnn {
 thread_local char g_err[512] = "";
 
 size_t aggregate_ws_bytes(long num_hub_seg, int F);
+size_t aggregate_bf16_ws_bytes(long num_hub_seg, int F);
+bool aggregate_bf16_ok(const void* x, long ldx, const void* out, long ldo, int out_bf16, int F, const float* bias);
+int aggregate_sum_bf16(const void* x, long ldx, void* out, long ldo, int out_bf16, const int* rowptr, const int* col,
+                       const float* ew, long N, int F, float self_scale, const float* in_scale, const float* out_scale,
+                       const float* bias, int skip_self, const int* hub_seg, long num_hub_seg, int hub_threshold,
+                       float* ws, size_t ws_bytes, hipStream_t st);
+int rows_to_bf16(const float* x, long ldx, void* y, long ldy, long N, int F, hipStream_t st);
 int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, float* ws, size_t ws_bytes, hipStream_t st);
 int gcn_deg_inv_sqrt(const int* rowptr, const int* col, long N, float* dis, hipStream_t st);
 int gine_fwd(const float*, long, const float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
@@ -29,7 +36,7 @@ int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, in
 int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t);
 size_t kan_split_fwd_ws_bytes(long N, int in, int out, int C);
-int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t);
+int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t, int gx16);
 size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
 int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t);
 bool kan_split_fwd_ok(int in, int out, int G, int K);
@@ -125,9 +132,32 @@ int kagnn_aggregate_sum(const float* x, int64_t ldx, float* out, int64_t ldo, co
     return aggregate_sum(a, hub_seg, num_hub_seg, static_cast<float*>(workspace), workspace_bytes, as_stream(stream));
 }
 
+int kagnn_aggregate_sum_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t out_dtype, const int32_t* rowptr,
+                             const int32_t* col, const float* edge_weight, int64_t N, int32_t F, float self_scale,
+                             const float* in_scale, const float* out_scale, const float* bias, int32_t skip_self_loops,
+                             const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && F >= 1, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (x && out && rowptr), "null array");
+    KAGNN_CHECK_ARG(ldx >= F && ldo >= F, "leading dimension smaller than num_feat");
+    KAGNN_CHECK_ARG(out_dtype == KAGNN_DTYPE_F32 || out_dtype == KAGNN_DTYPE_BF16, "out_dtype must be KAGNN_DTYPE_F32 or KAGNN_DTYPE_BF16");
+    KAGNN_CHECK_ARG(x != out, "in-place aggregation is not supported");
+    if (!aggregate_bf16_ok(x, ldx, out, ldo, out_dtype == KAGNN_DTYPE_BF16, F, bias))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 rows need num_feat % 8 == 0 (<= 512) and 16-byte aligned rows", __func__);
+    return aggregate_sum_bf16(x, ldx, out, ldo, out_dtype == KAGNN_DTYPE_BF16, rowptr, col, edge_weight, N, F, self_scale, in_scale,
+                              out_scale, bias, skip_self_loops, hub_seg, num_hub_seg, hub_threshold,
+                              static_cast<float*>(workspace), workspace_bytes, as_stream(stream));
+}
+
+int kagnn_rows_to_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t N, int32_t F, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && F >= 1 && ldx >= F && ldy >= F, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (x && y), "null array");
+    return rows_to_bf16(x, ldx, y, ldy, N, F, as_stream(stream));
+}
+
 int kagnn_aggregate_workspace_bytes(int64_t num_hub_seg, int32_t F, size_t* bytes_host) {
     KAGNN_CHECK_ARG(num_hub_seg >= 0 && F >= 1 && bytes_host, "bad argument");
-    *bytes_host = aggregate_ws_bytes(num_hub_seg, F);
+    *bytes_host = aggregate_bf16_ws_bytes(num_hub_seg, F);       // (F rounded up to 8: covers the fp32 form's round-up to 4)
     return KAGNN_OK;
 }
 
@@ -236,17 +266,21 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* kn
 
 int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N,
                                const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
-                               int32_t mode, const void* pack_dx, float* gx, int64_t ldgx, void* stream) {
+                               int32_t mode, const void* pack_dx, void* gx, int64_t ldgx, int32_t gx_dtype, void* stream) {
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
+    KAGNN_CHECK_ARG(gx_dtype == KAGNN_DTYPE_F32 || gx_dtype == KAGNN_DTYPE_BF16, "gx_dtype must be KAGNN_DTYPE_F32 or KAGNN_DTYPE_BF16");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && gy && knots && pack_dx && gx, "null array");
     if (use_split_dx(in, out, G, K, mode)) {
         if (!(fits32(N, ldx) && fits32(N, ldgy) && fits32(N, ldgx))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
-        return kan_split_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack_dx, gx, ldgx, as_stream(stream));
+        return kan_split_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack_dx, static_cast<float*>(gx), ldgx, as_stream(stream),
+                            gx_dtype == KAGNN_DTYPE_BF16);
     }
-    return kan_f32_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, (const float*)pack_dx, gx, ldgx, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
+    if (gx_dtype != KAGNN_DTYPE_F32) return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 gradient rows are produced by the split-precision kernels only", __func__);
+    float* gxf = static_cast<float*>(gx);
+    return kan_f32_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, (const float*)pack_dx, gxf, ldgx, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
 }
 
 int kagnn_kan_bwd_weight_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K,

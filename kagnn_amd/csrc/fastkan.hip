@@ -20,7 +20,7 @@ int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, in
 int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_fwd_any(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, void*, size_t, hipStream_t);
 size_t kan_split_fwd_ws_bytes(long N, int in, int out, int C);
-int kan_split_dx_any(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, hipStream_t);
+int kan_split_dx_any(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, hipStream_t, int gx16);
 int kan_split_dw_any(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, const RbfArgs&, hipStream_t);
 
 int kan_f32_pack(const float*, const float*, const float*, int, int, int, float*, float*, hipStream_t);
@@ -538,7 +538,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
         if (N > 0) {
             int rc = kan_split_pack_dx_noscale(bw, sw, nullptr, in, out, ng, pd, st);
             if (rc) return rc;
-            rc = kan_split_dx_any(x, ldx, gy, ldgy, N, nullptr, in, out, ng, 0, pd, gx, ldgx, rb, st);
+            rc = kan_split_dx_any(x, ldx, gy, ldgy, N, nullptr, in, out, ng, 0, pd, gx, ldgx, rb, st, 0);
             if (rc) return rc;
         }
         if (lnw) {

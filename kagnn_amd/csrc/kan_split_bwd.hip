@@ -112,13 +112,15 @@ __device__ __forceinline__ float barrel_dot(const float (&d)[8], int m, const fl
 //   PP == 2: the workgroup's waves 4..7 (the SIMD partners of waves 0..3) run one phase behind, held there by one
 //            s_barrier per phase: a SIMD always has one wave on the matrix pipe and one on the VALU
 //            (MI355X_MICROARCH.md, "Two waves per SIMD").
-template <int K, int Q2, bool GEN, int PP>
+template <int K, int Q2, bool GEN, int PP, bool GX16 = false>
 __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
     const unsigned char* __restrict__ pack, int resident, float* __restrict__ gx, long ldgx,
     RbfArgs rb, int sh_arg /* 1: virtual features, two 8-slot windows per input feature */, int acc_arg,
     int ft_per_block /* feature tiles per blockIdx.y: few-row inputs spread their feature tiles over the chip */) {
+    // GX16: gx rows are bf16 (a compile-time variant of the lean cubic instantiation -- as a run-time flag the 2-byte
+    // store path cost every launch 14 %: round 2, profiles/r02_experiments.md)
     const int sh = GEN ? sh_arg : 0;
     const bool ACC = GEN && acc_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (K > 0 && tid < nknots) s_knots[tid] = knots_g[tid];
     unsigned* s_btbl = reinterpret_cast<unsigned*>(smem + 256);      // barrel selectors (K == 3)
+    constexpr unsigned gxes = GX16 ? 2u : 4u;                        // bytes per gx element
     if (K == 3) build_barrel_table(s_btbl, tid);
     const int inv = in << sh, FT = cdiv(inv, 16);
     constexpr int FT_BYTES = kCTmax * Q2 * 2 * 1024;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     if constexpr (K > 0) { geom = geom_from_knots(s_knots, nknots); fgeo = fast_geom(s_knots, nknots); }
     const bool ln_on = (K == 0) && rb.ln_w != nullptr;           // wave-uniform
     const bool al4 = ((ldgy & 3) == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0);
-    const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u, ldgx4 = (unsigned)ldgx * 4u;
+    const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u, ldgx4 = (unsigned)ldgx * gxes;
     const unsigned gy_ro = (unsigned)(wave * 32 + li) * ldgy4;   // tile-relative byte offsets (descriptors open at the tile)
     const unsigned x_rb = (unsigned)(wave * 32 + 4 * kg) * ldx4;
     const unsigned gx_rb = (unsigned)(wave * 32 + 4 * kg) * ldgx4;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
         }
         // descriptors opened at the workgroup's tile: per-lane offsets are tile-relative and 32-bit for any N
         const GBuf gzb = gbuf_at(rb.gz, N, in, in, tile * 256);
-        const GBuf xb = gbuf_at(x, N, ldx, in, tile * 256), gxb = gbuf_at(gx, N, ldgx, in, tile * 256);
+        const GBuf xb = gbuf_at(x, N, ldx, in, tile * 256), gxb = gbuf_at_es(gx, N, ldgx, in, tile * 256, (int)gxes);
 
         for (int ft = ft_begin; ft < ft_end; ++ft) {
             if (!resident) {
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             const int f = 16 * ft + li;                  // (virtual) feature of this lane; fr = the real one
             const int fr = f >> sh;
             const unsigned fcol = (unsigned)min(fr, in - 1) * 4u;
-            const unsigned gx_ro = gx_rb + fcol, gz_ro = gz_rb + fcol;
+            const unsigned gx_ro = gx_rb + (unsigned)min(fr, in - 1) * gxes, gz_ro = gz_rb + fcol;
             float gam = 1.0f, bet = 0.0f;
             if (ln_on) { gam = rb.ln_w[min(fr, in - 1)]; bet = rb.ln_b[min(fr, in - 1)]; }
             float xq[2][4];
@@ -355,7 +358,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     if (f < inv && win == 0) {
                         const unsigned so_x = (unsigned)(16 * rt + reg) * ldgx4;
                         if (ACC) s += gld_s(gxb, gx_ro, so_x);                          // second and later output blocks
-                        gst_s(gxb, gx_ro, so_x, s);                                     // rows >= N: dropped
+                        if constexpr (GX16) gst16_s(gxb, gx_ro, so_x, s);               // bf16 rows
+                        else gst_s(gxb, gx_ro, so_x, s);                                // rows >= N: dropped
                     }
                     }
                 }
@@ -384,7 +388,7 @@ static int dx_schedule() {
     return v;
 }
 
-template <int K, int Q2, bool GEN, int PP>
+template <int K, int Q2, bool GEN, int PP, bool GX16 = false>
 static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                         const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
                         const RbfArgs& rb, int accumulate, hipStream_t st) {
@@ -400,13 +404,13 @@ static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, lo
     const size_t lds = kLdsHdr + (resident ? fpb : 1) * ft_bytes;
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP>,
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
     }
     const dim3 grid((unsigned)min(row_blocks, 256L), (unsigned)splits);
-    kan_split_dx_kernel<K, Q2, GEN, PP><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
-                                                                resident ? 1 : 0, gx, ldgx, rb, sh, accumulate, fpb);
+    kan_split_dx_kernel<K, Q2, GEN, PP, GX16><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
+                                                                      resident ? 1 : 0, gx, ldgx, rb, sh, accumulate, fpb);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -414,24 +418,26 @@ static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, lo
 template <int K, int Q2, bool GEN>
 static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                      const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
-                     const RbfArgs& rb, int accumulate, hipStream_t st) {
+                     const RbfArgs& rb, int accumulate, int gx16, hipStream_t st) {
     // the schedule experiments only pay on the common cubic instantiation; the others keep the prefetch form
     if constexpr (K == 3 && !GEN) {
+        if (gx16) return launch_dx_pp<K, Q2, GEN, 1, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
         switch (dx_schedule()) {
             case 0: return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
             case 2: return launch_dx_pp<K, Q2, GEN, 2>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
             default: return launch_dx_pp<K, Q2, GEN, 1>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
         }
     }
+    if (gx16) return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 gradient rows need a cubic layer with <= 8 coefficients", "kan_split_dx");
     return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
 }
 
 static int dx_block(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
                     int out, int G, int K, const unsigned char* p, float* gx, long ldgx, const RbfArgs& rb,
-                    int accumulate, hipStream_t st) {
+                    int accumulate, int gx16, hipStream_t st) {
     const int C = G + K, nk = K ? G + 2 * K + 1 : 0, Q2 = dx_q2(out);
-#define GO(KK, QQ) return (accumulate || C > 8) ? launch_dx<KK, QQ, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, rb, accumulate, st) \
-                                                 : launch_dx<KK, QQ, false>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, rb, 0, st)
+#define GO(KK, QQ) return (accumulate || C > 8) ? launch_dx<KK, QQ, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, rb, accumulate, gx16, st) \
+                                                 : launch_dx<KK, QQ, false>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p, gx, ldgx, rb, 0, gx16, st)
 #define BYQ(KK) switch (Q2) { case 1: GO(KK, 1); case 2: GO(KK, 2); case 4: GO(KK, 4); }
     switch (K) {
         case 0: BYQ(0) break;
@@ -448,19 +454,21 @@ static int dx_block(const float* x, long ldx, const float* gy, long ldgy, long N
 // K == 0: Gaussian RBF basis (with layernorm: rb.gz receives dL/dz, gx the base-branch part only)
 int kan_split_dx_any(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
                      int out, int G, int K, const void* pack, float* gx, long ldgx, const RbfArgs& rb,
-                     hipStream_t st) {
+                     hipStream_t st, int gx16) {
+    if (gx16 && (K == 0 || out > kOutBlk))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 gradient rows need a B-spline layer with <= 128 outputs", "kan_split_dx");
     const size_t stride = dx_blk_bytes(in << vshift(G + K), min(out, kOutBlk));
     for (int b = 0; b * kOutBlk < out; ++b) {
         const int rc = dx_block(x, ldx, gy + b * kOutBlk, ldgy, N, knots, in, min(kOutBlk, out - b * kOutBlk), G, K,
-                                static_cast<const unsigned char*>(pack) + b * stride, gx, ldgx, rb, b > 0, st);
+                                static_cast<const unsigned char*>(pack) + b * stride, gx, ldgx, rb, b > 0, gx16, st);
         if (rc) return rc;
     }
     return KAGNN_OK;
 }
 
 int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
-                 int out, int G, int K, const void* pack, float* gx, long ldgx, hipStream_t st) {
-    return kan_split_dx_any(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack, gx, ldgx, RbfArgs{}, st);
+                 int out, int G, int K, const void* pack, float* gx, long ldgx, hipStream_t st, int gx16) {
+    return kan_split_dx_any(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack, gx, ldgx, RbfArgs{}, st, gx16);
 }
 
 // ====================================================================== weight gradient

@@ -83,6 +83,25 @@ __device__ __forceinline__ GBuf gbuf_at(const void* p, long rows, long ld, int w
                                             (unsigned)bytes, 0x00020000);
     return b;
 }
+// the same with `es`-byte elements (bf16 output rows: es = 2)
+__device__ __forceinline__ GBuf gbuf_at_es(const void* p, long rows, long ld, int width, long row0, int es) {
+    const long left = rows - row0;
+    long bytes = left > 0 ? ((left - 1) * ld + width) * es : 0;
+    if (bytes > 0xFFFFFFF0L) bytes = 0xFFFFFFF0L;
+    GBuf b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p)) + row0 * ld * es, 0,
+                                            (unsigned)bytes, 0x00020000);
+    return b;
+}
+// fp32 -> bf16, round to nearest even (NaN stays NaN); 2-byte store with a wave-uniform offset on top of the lane's
+__device__ __forceinline__ unsigned short bf16_bits(float f) {
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void gst16_s(const GBuf& b, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b16((short)bf16_bits(v), b.r, voff, soff, 0);
+}
 __device__ __forceinline__ float gld(const GBuf& b, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, off, 0, 0));
 }

@@ -58,6 +58,7 @@ class FKANLayer(FastKANLayer):
 
 # ---------------------------------------------------------------------------------- conv bases
 _SPLIT_READOUT = os.environ.get("KAGNN_SPLIT_READOUT", "1") != "0"
+_FUSED_LAYER = os.environ.get("KAGNN_FUSED_LAYER", "1") != "0"       # GIN + KAN chain as one autograd node (ops.gin_kan_layer)
 _SPLIT_READOUT_MIN_ROWS = 400_000
 
 
@@ -82,6 +83,15 @@ class _SumAggregateConv(nn.Module):
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
+        if _FUSED_LAYER and isinstance(self.nn, eKAN) and x.is_cuda and x.size(0) > 0 and not torch.compiler.is_compiling():
+            y = ops.gin_kan_layer(x, g, 1.0 + self._eps(), self.nn)        # one tape node: aggregate + KAN chain
+            if y is not None:
+                return y
+        if x.dtype == torch.bfloat16 or ops.default_activation_dtype() == torch.bfloat16:
+            # bf16 gather operands outside the fused node (FastKAN chains, traced code): the aggregation takes the bf16
+            # rows and hands fp32 sums to the chain
+            xg = x if x.dtype == torch.bfloat16 else ops.to_bf16_rows(x) if not x.requires_grad else x.to(torch.bfloat16)
+            return self.nn(ops.aggregate_sum(xg, g, self_scale=1.0 + self._eps()))
         return self.nn(ops.aggregate_sum(x, g, self_scale=1.0 + self._eps()))
 
 
@@ -191,7 +201,7 @@ class _NodeModel(nn.Module):
             g = edge_index
         else:
             g = ops.graph_index(edge_index, x.size(0))
-        outs = [x]
+        outs = [x if x.dtype == torch.float32 else x.float()]      # (bf16 activation storage: the read-out is fp32)
         for conv, bn in zip(self.convs, self.bns):
             x = self.dropout(bn(conv(x, g)))
             outs.append(x)

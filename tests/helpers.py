@@ -31,7 +31,7 @@ def T(a, device=None):
     return t if device is None else t.to(device)
 
 
-def assert_close(got, want, tol=TOL, what=""):
+def assert_close(got, want, tol=TOL, what="", elementwise=True):
     got = got.detach().double().cpu()
     want = T(want).double() if not torch.is_tensor(want) else want.detach().double().cpu()
     assert got.shape == want.shape, (what, got.shape, want.shape)
@@ -45,7 +45,7 @@ def assert_close(got, want, tol=TOL, what=""):
     ERROR_LOG.append((what, err / scale, tol))
     assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.0e} * {scale:.3g}"
     big = w.abs() >= REL_FLOOR * scale
-    if bool(big.any()):
+    if elementwise and bool(big.any()):
         rel = float((diff[big] / w.abs()[big]).max())
         assert rel <= max(CONTRACT, 5 * tol), f"{what}: element-wise relative error {rel:.3e} on a large element"
     return err / scale

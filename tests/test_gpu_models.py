@@ -348,6 +348,126 @@ def test_modules_on_a_non_current_device():
         ops.kan_linear(x.detach().to(DEV), layer.base_weight, layer.spline_weight, layer.spline_scaler, layer._knots(), 5, 3)
 
 
+# ------------------------------------------------------------------ fused layer node + bf16 gather operands (config 2)
+def test_fused_gin_kan_node_equals_the_composed_ops_bitwise(monkeypatch):
+    """ops.gin_kan_layer (one tape node: aggregate + KAN chain, chain-packed weights) runs the same kernels in the same
+    order as aggregate_sum -> KAN.forward: identical bits, forward and backward, both precision modes"""
+    from kagnn_amd import models as M
+    n, e, f = 20000, 150000, 64
+    ei = orc.powerlaw_graph(n, e, seed=8)
+    g = ops.GraphIndex(ei.to(DEV), n)
+    x = (torch.randn(n, f, generator=torch.Generator().manual_seed(3)) * 0.3).to(DEV)
+    gy = torch.randn(n, f, generator=torch.Generator().manual_seed(4)).to(DEV)
+    for mode in MODES:
+        torch.manual_seed(5)
+        conv = kagnn_amd.GIKANLayer(f, f, grid_size=5, spline_order=3, hidden_dim=f, nb_layers=2).to(DEV)
+        _set_precision(conv, mode)
+        res = []
+        for fused in (True, False):
+            monkeypatch.setattr(M, "_FUSED_LAYER", fused)
+            conv.zero_grad()
+            xr = x.clone().requires_grad_(True)
+            y = conv(xr, g)
+            y.backward(gy)
+            res.append([y.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in conv.parameters()])
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("f", [64, 128, 8, 24, 256, 12, 40])
+def test_bf16_aggregation_vs_oracle_on_the_rounded_rows(f):
+    """kagnn_aggregate_sum_bf16: fp32 accumulation of bf16 rows is EXACT arithmetic on the rounded inputs up to fp32
+    summation order -- compare with the fp64 oracle fed the same rounded rows (fp32 output: 2e-6; bf16 output: one
+    rounding, 2^-8 relative), hubs and isolated nodes included, both directions, GIN and GCN forms"""
+    n, e = 20000, 200000
+    ei = orc.powerlaw_graph(n, e, seed=1)
+    g = ops.GraphIndex(ei.to(DEV), n)
+    assert g.num_hub_seg > 0
+    gen = torch.Generator().manual_seed(f)
+    xb = torch.randn(n, f, generator=gen).to(torch.bfloat16)
+    x64 = xb.double()
+    want = orc.sum_aggregate(x64, ei) + 1.5 * x64
+    got = ops._aggregate_raw(xb.to(DEV), g, False, 1.5, None, None, None, None, False)
+    assert got.dtype == torch.float32
+    assert_close(got, want, 2e-6, what=f"bf16 gather, fp32 sums F={f}")
+    got16 = ops._aggregate_raw(xb.to(DEV), g, False, 1.5, None, None, None, None, False, out_dtype=torch.bfloat16)
+    assert got16.dtype == torch.bfloat16
+    err = (got16.double().cpu() - want).abs()
+    assert bool((err <= want.abs() * 2.0 ** -8 + 1e-30).all()), float((err / want.abs().clamp_min(1e-30)).max())
+    want_t = orc.sum_aggregate(x64, ei.flip(0)) + 1.5 * x64                         # transposed direction
+    got_t = ops._aggregate_raw(xb.to(DEV), g, True, 1.5, None, None, None, None, False)
+    assert_close(got_t, want_t, 2e-6, what=f"bf16 gather transposed F={f}")
+    # GCN form: in/out scales, bias, self loops skipped
+    dis = g.gcn_dis
+    bias = torch.randn(f, generator=gen)
+    ei2, w2 = orc.gcn_norm(ei, n, torch.float64)
+    want_g = orc.sum_aggregate(x64, ei2, n, w2) + bias.double()
+    got_g = ops._aggregate_raw(xb.to(DEV), g, False, 1.0, None, dis, dis, bias.to(DEV), True)
+    assert_close(got_g, want_g, 2e-6, what=f"bf16 gather GCN form F={f}")
+    # bit-reproducible (hub rows included)
+    assert torch.equal(got, ops._aggregate_raw(xb.to(DEV), g, False, 1.5, None, None, None, None, False))
+
+
+def test_bf16_mode_gin_kan_layer_vs_oracle(monkeypatch):
+    """KAGNN_ACT=bf16 on the KAN-GIN layer: (a) against the fp64 oracle fed the bf16-ROUNDED input the forward is as
+    tight as the fp32 mode (the KAN chain is untouched); (b) against the fp64 oracle on the ORIGINAL input everything
+    is within 4e-3 (bf16 has 8 significant bits: 2^-9 per gathered element) -- the tolerance of this build-defined
+    mode; (c) the gradient of a bf16 input comes back as bf16."""
+    monkeypatch.setenv("KAGNN_ACT", "bf16")
+    n, e, f = 30000, 300000, 64
+    ei = orc.powerlaw_graph(n, e, seed=2)
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(n, f, generator=gen) * 0.25
+    gy = torch.randn(n, f, generator=gen)
+    torch.manual_seed(7)
+    conv = kagnn_amd.GIKANLayer(f, f, grid_size=5, spline_order=3, hidden_dim=f, nb_layers=2)
+    layers = [{k: v.detach().clone().double() for k, v in l.state_dict().items()} for l in conv.nn.layers]
+    conv = conv.to(DEV)
+    g = ops.GraphIndex(ei.to(DEV), n)
+    xd = x.to(DEV).requires_grad_(True)
+    y = conv(xd, g)
+    y.backward(gy.to(DEV))
+    assert xd.grad.dtype == torch.float32
+    y_r, _, _ = orc.kan_gin_layer_fwd_bwd(x.to(torch.bfloat16).double(), ei, layers, 3, gy.double())
+    assert_close(y, y_r, what="bf16 mode: forward on the rounded input")
+    y64, gx64, g64 = orc.kan_gin_layer_fwd_bwd(x.double(), ei, layers, 3, gy.double())
+    # (max-norm only: sums of ~10 rounded terms with cancellation have no per-element relative bound)
+    assert_close(y, y64, 4e-3, what="bf16 mode y", elementwise=False)
+    assert_close(xd.grad, gx64, 4e-3, what="bf16 mode gx", elementwise=False)
+    for li, layer in enumerate(conv.nn.layers):
+        for k in ("base_weight", "spline_weight", "spline_scaler"):
+            # parameter gradients: sums over 30 000 rows of products with the rounded activations
+            assert_close(getattr(layer, k).grad, g64[li][k], 1e-2, what=f"bf16 mode L{li}.{k}", elementwise=False)
+    xb = x.to(torch.bfloat16).to(DEV).requires_grad_(True)
+    conv.zero_grad()
+    conv(xb, g).backward(gy.to(DEV))
+    assert xb.grad.dtype == torch.bfloat16
+    assert_close(xb.grad.float(), gx64, 8e-3, what="bf16 mode gx (bf16 rows)", elementwise=False)
+    # the mode really runs the bf16 kernels
+    timer = ops.EntryPointTimer()
+    ops.set_timer(timer)
+    conv(xd.detach().requires_grad_(True), g).sum().backward()
+    ops.set_timer(None)
+    assert timer.summary()["kagnn_aggregate_sum_bf16"]["launches"] == 2 and "kagnn_aggregate_sum" not in timer.summary()
+
+
+def test_bf16_mode_node_model_runs_and_stays_close(monkeypatch):
+    """GKAN_Nodes / GFASTKAN_Nodes under KAGNN_ACT=bf16 against their own fp32 run"""
+    n, e = 20000, 160000
+    ei = orc.powerlaw_graph(n, e, seed=3).to(DEV)
+    x = (torch.randn(n, 32, generator=torch.Generator().manual_seed(8)) * 0.5).to(DEV)
+    for cls in (kagnn_amd.GKAN_Nodes, kagnn_amd.GFASTKAN_Nodes):
+        torch.manual_seed(9)
+        model = cls("gin", 2, 32, 16, 6, skip=True, grid_size=4).to(DEV).train()
+        monkeypatch.setenv("KAGNN_ACT", "fp32")
+        ref = model(x, ei)
+        monkeypatch.setenv("KAGNN_ACT", "bf16")
+        out = model(x, ei)
+        out.sum().backward()
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.requires_grad)
+        assert_close(out, ref, 2e-2, what=f"{cls.__name__} bf16 vs fp32 logits", elementwise=False)     # two BatchNorms amplify the 2^-9 input rounding
+
+
 # ------------------------------------------------------------------ torch.library registration (SURVEY 8(b))
 @pytest.mark.parametrize("arch,kind", [("kan", "gin"), ("kan", "gcn"), ("fastkan", "gin"), ("fastkan", "gcn")])
 def test_models_trace_into_one_graph_of_kagnn_ops(arch, kind):
