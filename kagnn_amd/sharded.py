@@ -39,31 +39,100 @@ from .ekan import KANLinear
 from .models import GIKANLayer
 
 
-class _ReduceScatterColumns(Function):
-    """y_shard = (sum over ranks of partial)[:, lo:hi] as ONE reduce-scatter (each rank receives only its
-    ``out/P`` columns: half the wire traffic of all-reduce + slice); backward all-gathers the column shards."""
+class _Comm:
+    """Per-layer bookkeeping of the chunked, overlapped collectives.
+
+    Row chunks make the exchange of chunk i run beside the KAN kernels of chunk i+1 ("chunk along N and
+    overlap with the GEMM of the next node tile").  c10d makes a collective's stream wait for everything enqueued so far
+    on the CURRENT stream, so every collective is launched under a side stream that waits only for the event of the
+    tensor it sends; the compute stream waits for a chunk's result only where it is consumed."""
+
+    def __init__(self, group):
+        self.group = group
+        self.side = None
+        self.pending = []          # forward: (work, keep-alive tensors) of the reduce-scatters in flight
+        self.gathered = {}         # backward: chunk index -> (work, buffer) of the all-gathers launched ahead
+
+    def launch(self, fn, ready_after: torch.Tensor):
+        """run ``fn()`` (which issues ONE async collective and returns its work handle) so that it depends only on
+        ``ready_after`` having been produced"""
+        if not ready_after.is_cuda:
+            return fn()
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=ready_after.device)
+        ev = torch.cuda.Event()
+        ev.record()                                   # `ready_after` was just produced on the current stream
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            return fn()
+
+
+class _ReduceScatterChunk(Function):
+    """rows [r0, r1) of one KANLinear's partial sums: y_shard = (sum over ranks)[:, my columns], launched asynchronously;
+    the backward picks up the all-gather of this chunk's gradient rows that ``_Finish.backward`` launched ahead."""
 
     @staticmethod
-    def forward(ctx, partial, group, lo, hi):
+    def forward(ctx, partial, comm, chunk):
+        group = comm.group
         world = dist.get_world_size(group)
         n, out = partial.shape
         w = out // world
-        assert hi - lo == w and lo == dist.get_rank(group) * w
-        # rank-major blocks [P][N][out/P] so that block p is what rank p keeps
+        # rank-major blocks [P][n][out/P] so that block p is what rank p keeps
         blocks = partial.detach().view(n, world, w).permute(1, 0, 2).contiguous().view(world * n, w)
         y = torch.empty((n, w), dtype=partial.dtype, device=partial.device)
-        dist.reduce_scatter_tensor(y, blocks, op=dist.ReduceOp.SUM, group=group)
-        ctx.group = group
+        work = comm.launch(lambda: dist.reduce_scatter_tensor(y, blocks, op=dist.ReduceOp.SUM, group=group, async_op=True), blocks)
+        comm.pending.append((work, blocks, y))
+        ctx.comm, ctx.chunk, ctx.world = comm, chunk, world
         return y
 
     @staticmethod
     def backward(ctx, g_shard):
-        world = dist.get_world_size(ctx.group)
-        g = g_shard.contiguous()
-        n, w = g.shape
-        buf = torch.empty((world * n, w), dtype=g.dtype, device=g.device)     # rank-major concat
-        dist.all_gather_into_tensor(buf, g, group=ctx.group)
-        return buf.view(world, n, w).permute(1, 0, 2).reshape(n, world * w), None, None, None
+        comm, world = ctx.comm, ctx.world
+        hit = comm.gathered.pop(ctx.chunk, None)
+        if hit is None:                               # (not launched ahead: e.g. the output was consumed chunk-wise)
+            g = g_shard.contiguous()
+            buf = torch.empty((world * g.size(0), g.size(1)), dtype=g.dtype, device=g.device)
+            work = comm.launch(lambda: dist.all_gather_into_tensor(buf, g, group=comm.group, async_op=True), g)
+            hit = (work, buf, g)
+        work, buf, _ = hit
+        work.wait()                                   # CUDA: the compute stream waits for THIS chunk only
+        n = buf.size(0) // world
+        return buf.view(world, n, -1).permute(1, 0, 2).reshape(n, -1), None, None
+
+
+class _Finish(Function):
+    """forward: wait for every reduce-scatter of the layer (CUDA: the compute stream waits), THEN concatenate the row
+    chunks; backward (runs FIRST on the way back): the all-gathers of ALL row chunks of the incoming gradient are
+    launched at once on the side stream -- chunk i's gather then runs beside the backward kernels of chunk i+1."""
+
+    @staticmethod
+    def forward(ctx, comm, bounds, *parts):
+        for work, _, _ in comm.pending:
+            work.wait()
+        comm.pending.clear()
+        ctx.comm, ctx.bounds = comm, bounds
+        return parts[0].view_as(parts[0]) if len(parts) == 1 else torch.cat(parts, dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        comm = ctx.comm
+        world = dist.get_world_size(comm.group)
+        g = g.contiguous()
+        pieces = []
+        for i, (r0, r1) in enumerate(ctx.bounds):
+            gc = g[r0:r1]
+            buf = torch.empty((world * (r1 - r0), g.size(1)), dtype=g.dtype, device=g.device)
+            work = comm.launch(lambda gc=gc, buf=buf: dist.all_gather_into_tensor(buf, gc, group=comm.group, async_op=True), g)
+            comm.gathered[i] = (work, buf, gc)
+            pieces.append(gc)
+        return (None, None, *pieces)
+
+
+def _chunk_bounds(n: int, chunks: int):
+    chunks = max(1, min(chunks, n))
+    per = -(-n // chunks)
+    per = -(-per // 256) * 256 if n >= 4096 else per            # whole 256-row kernel tiles
+    return [(r, min(n, r + per)) for r in range(0, n, per)]
 
 
 class ShardedKANLinear(nn.Module):
@@ -93,11 +162,15 @@ class ShardedKANLinear(nn.Module):
 
 
 class ShardedGIKANLayer(nn.Module):
-    """``GIKANLayer`` (sum-aggregate + KAN chain) on 1/P of the feature columns per rank."""
+    """``GIKANLayer`` (sum-aggregate + KAN chain) on 1/P of the feature columns per rank.
 
-    def __init__(self, conv: GIKANLayer, group=None, local_ops=None):
+    ``chunks``: row chunks per KANLinear whose reduce-scatter (forward) / all-gather (backward) overlap with the KAN
+    kernels of the neighbouring chunk; ``None`` = 4 from 256k rows up, else 1."""
+
+    def __init__(self, conv: GIKANLayer, group=None, local_ops=None, chunks: Optional[int] = None):
         super().__init__()
         self.group = group
+        self.chunks = chunks
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.local_ops = _hip_ops if local_ops is None else local_ops
@@ -110,8 +183,12 @@ class ShardedGIKANLayer(nn.Module):
 
     def forward(self, x_shard: torch.Tensor, graph) -> torch.Tensor:
         h = self.local_ops.aggregate_sum(x_shard, graph, self_scale=1.0 + self.eps)
+        n = h.size(0)
+        bounds = _chunk_bounds(n, self.chunks if self.chunks is not None else (4 if n >= 262144 else 1))
         for layer in self.layers:
-            h = _ReduceScatterColumns.apply(layer(h, self.local_ops), self.group, layer.out_lo, layer.out_hi)
+            comm = _Comm(self.group)
+            parts = [_ReduceScatterChunk.apply(layer(h[r0:r1], self.local_ops), comm, i) for i, (r0, r1) in enumerate(bounds)]
+            h = _Finish.apply(comm, bounds, *parts)
         return h
 
 
@@ -184,14 +261,31 @@ class _SumGradAcrossRanks(Function):
         return g, None
 
 
+class _QueueFlatSync(Function):
+    """identity; its backward runs first on the way back and queues ``module.sync_gradients`` to run when the whole
+    backward pass has finished (``Variable._execution_engine.queue_callback``) -- one flat all-reduce per step"""
+
+    @staticmethod
+    def forward(ctx, y, module):
+        ctx.module = module
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        from torch.autograd import Variable
+        Variable._execution_engine.queue_callback(ctx.module.sync_gradients)
+        return g, None
+
+
 class TransposedShardedGIKANLayer(nn.Module):
     """``GIKANLayer`` with the aggregation on column shards and the KAN chain on row shards (see the module
     docstring).  Same interface as ``ShardedGIKANLayer``: column shard in, column shard out."""
 
-    def __init__(self, conv: GIKANLayer, group=None, local_ops=None, sync_in_backward: bool = True):
-        """``sync_in_backward=True``: every parameter's gradient is all-reduced inside autograd (one small
-        collective per parameter tensor -- transparent, like DDP without buckets).  ``False``: gradients stay
-        rank-local until ``sync_gradients()`` sums ALL of them with ONE flat all-reduce (what ``bench.py`` does)."""
+    def __init__(self, conv: GIKANLayer, group=None, local_ops=None, sync_in_backward="flat"):
+        """``sync_in_backward="flat"`` (default): ONE flat all-reduce over all parameter gradients, queued as an
+        end-of-backward callback of the autograd engine -- transparent to the caller.  ``True``: every parameter's
+        gradient is all-reduced inside autograd (one small collective per parameter tensor).  ``False``: gradients stay
+        rank-local until the caller runs ``sync_gradients()`` (what ``bench.py`` times explicitly)."""
         super().__init__()
         self.group = group
         self.rank = dist.get_rank(group)
@@ -228,9 +322,12 @@ class TransposedShardedGIKANLayer(nn.Module):
         for layer in self.layers:
             sc = layer.spline_scaler if layer.enable_standalone_scale_spline else None
             g = self.group
-            wrap = (lambda p: _SumGradAcrossRanks.apply(p, g)) if self.sync_in_backward else (lambda p: p)
+            wrap = (lambda p: _SumGradAcrossRanks.apply(p, g)) if self.sync_in_backward is True else (lambda p: p)
             h = self.local_ops.kan_linear(h, wrap(layer.base_weight), wrap(layer.spline_weight),
                                           None if sc is None else wrap(sc),
                                           layer.grid[0].contiguous(), layer.grid_size, layer.spline_order,
                                           layer.precision)
-        return _RowsToCols.apply(h, n, self.group)
+        out = _RowsToCols.apply(h, n, self.group)
+        if self.sync_in_backward == "flat" and torch.is_grad_enabled():
+            out = _QueueFlatSync.apply(out, self)
+        return out

@@ -49,32 +49,33 @@ def _worker(rank, world, port, out_dir):
         layers = [{k: v.detach().clone() for k, v in l.state_dict().items()} for l in conv.nn.layers]
         y_ref, gx_ref, g_ref = orc.kan_gin_layer_fwd_bwd(x, ei, layers, 3, gy)
 
-        sconv = ShardedGIKANLayer(conv, None, local_ops=OracleOps)
-        xs = sconv.shard_columns(x).requires_grad_(True)
-        y = sconv(xs, ei)
-        y.backward(sconv.shard_columns(gy))
         w = f // world
         sl = slice(rank * w, (rank + 1) * w)
         tol = 2e-5
-        assert torch.allclose(y, y_ref[:, sl], atol=tol, rtol=tol)
-        assert torch.allclose(xs.grad, gx_ref[:, sl], atol=tol, rtol=tol)
-        for li, layer in enumerate(sconv.layers):
-            isl = slice(layer.lo, layer.hi)
-            assert torch.allclose(layer.base_weight.grad, g_ref[li]["base_weight"][:, isl], atol=tol, rtol=tol)
-            assert torch.allclose(layer.spline_weight.grad, g_ref[li]["spline_weight"][:, isl], atol=tol, rtol=tol)
-            assert torch.allclose(layer.spline_scaler.grad, g_ref[li]["spline_scaler"][:, isl], atol=tol, rtol=tol)
+        for chunks in (1, 3, 7):                              # 3 / 7: overlapped row chunks (uneven: 400 = 134+134+132, 58*6+52)
+            sconv = ShardedGIKANLayer(conv, None, local_ops=OracleOps, chunks=chunks)
+            xs = sconv.shard_columns(x).requires_grad_(True)
+            y = sconv(xs, ei)
+            y.backward(sconv.shard_columns(gy))
+            assert torch.allclose(y, y_ref[:, sl], atol=tol, rtol=tol)
+            assert torch.allclose(xs.grad, gx_ref[:, sl], atol=tol, rtol=tol)
+            for li, layer in enumerate(sconv.layers):
+                isl = slice(layer.lo, layer.hi)
+                assert torch.allclose(layer.base_weight.grad, g_ref[li]["base_weight"][:, isl], atol=tol, rtol=tol)
+                assert torch.allclose(layer.spline_weight.grad, g_ref[li]["spline_weight"][:, isl], atol=tol, rtol=tol)
+                assert torch.allclose(layer.spline_scaler.grad, g_ref[li]["spline_scaler"][:, isl], atol=tol, rtol=tol)
         # ---- the transposed variant: column-sharded aggregation, all-to-all, row-sharded KAN chain, all-to-all
         from kagnn_amd.sharded import TransposedShardedGIKANLayer
-        for n2 in (400, 401):                                 # 401: uneven row split
+        for n2, sync in ((400, True), (401, False), (401, "flat")):   # per-parameter / explicit flat / queued flat all-reduce
             ei2 = orc.powerlaw_graph(n2, e, seed=12)
             x2 = torch.randn(n2, f, generator=gen) * 0.3
             gy2 = torch.randn(n2, f, generator=gen)
             y_ref, gx_ref, g_ref = orc.kan_gin_layer_fwd_bwd(x2, ei2, layers, 3, gy2)
-            tconv = TransposedShardedGIKANLayer(conv, None, local_ops=OracleOps, sync_in_backward=(n2 == 400))
+            tconv = TransposedShardedGIKANLayer(conv, None, local_ops=OracleOps, sync_in_backward=sync)
             xs = tconv.shard_columns(x2).requires_grad_(True)
             y = tconv(xs, ei2)
             y.backward(tconv.shard_columns(gy2))
-            if n2 != 400:
+            if sync is False:
                 tconv.sync_gradients()                        # the explicit single flat all-reduce
             assert torch.allclose(y, y_ref[:, sl], atol=tol, rtol=tol)
             assert torch.allclose(xs.grad, gx_ref[:, sl], atol=tol, rtol=tol)
@@ -126,8 +127,8 @@ def _gpu_worker(rank, world, port, out_dir):
             err = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
             assert err <= 1e-4, (what, err)
 
-        for cls in (ShardedGIKANLayer, TransposedShardedGIKANLayer):
-            sconv = cls(conv, None).to(dev)
+        for cls, kw in ((ShardedGIKANLayer, {}), (ShardedGIKANLayer, {"chunks": 3}), (TransposedShardedGIKANLayer, {})):
+            sconv = cls(conv, None, **kw).to(dev)
             xs = sconv.shard_columns(x).requires_grad_(True)
             y = sconv(xs, graph)
             y.backward(sconv.shard_columns(gy))
