@@ -3,6 +3,6 @@
 NAME=$1; REPS=${2:-3}
 P='import json,sys; d=json.loads(sys.stdin.read()); e=d["entry_points_ms_per_step"]; print(sys.argv[1], round(d["ms_per_step"],4), {k[6:]:round(v,3) for k,v in e.items() if v>0.05})'
 for i in $(seq $REPS); do
-  python bench.py --no-cpu-baseline --no-extras --steps 20 | python -c "$P" new
-  KAGNN_LIB=$PWD/kagnn_amd/lib/libkagnn_hip_$NAME.so python bench.py --no-cpu-baseline --no-extras --steps 20 | python -c "$P" $NAME
+  python bench.py --no-cpu-baseline --no-extras --no-traffic --no-fp32 --steps 20 | python -c "$P" new
+  KAGNN_LIB=$PWD/kagnn_amd/lib/libkagnn_hip_$NAME.so python bench.py --no-cpu-baseline --no-extras --no-traffic --no-fp32 --steps 20 | python -c "$P" $NAME
 done

@@ -24,5 +24,9 @@ json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
 print(out)
 PY
 for k in 2 3 5 1 4; do tools/prof_cfg.sh $k ${TAG}_cfg$k 40 > $OUT/${TAG}_config${k}_kernel_trace.txt 2>&1; done
+tools/prof_model.sh > $OUT/${TAG}_model_step_kernel_trace.txt 2>&1
+KAGNN_ACT=bf16 python tools/configs_sweep.py 2 2>/dev/null | grep "cfg2 " > $OUT/${TAG}_config2_bf16.txt
+python bench.py --act bf16 --no-cpu-baseline --no-extras --no-fp32 2>/dev/null | tail -1 > $OUT/${TAG}_bench_bf16_gather.json
+python bench.py --workload config3 --no-cpu-baseline --no-extras --no-traffic 2>/dev/null | tail -1 > $OUT/${TAG}_bench_config3.json
 rm -rf $R/gpurun_out/prof_${TAG}* 
 ls -la $OUT

@@ -5,4 +5,4 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --pmc "$@" -d $OUT/pmc_x -o x -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/log.txt 2>&1
+rocprofv3 --pmc "$@" -d $OUT/pmc_x -o x -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-traffic --no-fp32 > $OUT/log.txt 2>&1

@@ -5,7 +5,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+CMD="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-traffic --no-fp32"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_a -o a -- $CMD > $OUT/pmc_a.log 2>&1
