@@ -31,9 +31,9 @@ size_t kan_f32_dw_ws_bytes(long N, int in, int out, int C);
 int kan_f32_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, bool, hipStream_t);
 
 size_t kan_split_pack_fwd_bytes(int in, int out, int C);
-size_t kan_split_pack_dx_bytes(int in, int out, int C);
+size_t kan_split_pack_dx_bytes(int in, int out, int C, int K);
 int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
-int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
+int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, int, void*, hipStream_t);
 int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t);
 size_t kan_split_fwd_ws_bytes(long N, int in, int out, int C);
 int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t, int gx16);
@@ -199,7 +199,7 @@ int kagnn_kan_pack_bytes(int32_t in, int32_t out, int32_t G, int32_t K, int32_t 
     KAGNN_CHECK_ARG(fwd_bytes && dx_bytes, "null output");
     *fwd_bytes = use_sparse_fwd(in, out, G, K, mode) ? kan_sparse_pack_fwd_bytes(in, out, G + K)
                : use_split_fwd(in, out, G, K, mode) ? kan_split_pack_fwd_bytes(in, out, G + K) : kan_f32_pack_fwd_bytes(in, out, G + K);
-    *dx_bytes = use_split_dx(in, out, G, K, mode) ? kan_split_pack_dx_bytes(in, out, G + K) : kan_f32_pack_dx_bytes(in, out, G + K);
+    *dx_bytes = use_split_dx(in, out, G, K, mode) ? kan_split_pack_dx_bytes(in, out, G + K, K) : kan_f32_pack_dx_bytes(in, out, G + K);
     return KAGNN_OK;
 }
 
@@ -217,7 +217,7 @@ int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in
                                                  : kan_split_pack_fwd_noscale(bw, sw, sc, in, out, G + K, pack_fwd, as_stream(stream));
         if (rc) return rc;
     }
-    if (sd) { rc = kan_split_pack_dx_noscale(bw, sw, sc, in, out, G + K, pack_dx, as_stream(stream)); if (rc) return rc; }
+    if (sd) { rc = kan_split_pack_dx_noscale(bw, sw, sc, in, out, G + K, K, pack_dx, as_stream(stream)); if (rc) return rc; }
     if (!sf || !sd)
         return kan_f32_pack(bw, sw, sc, in, out, G + K, sf ? nullptr : (float*)pack_fwd, sd ? nullptr : (float*)pack_dx, as_stream(stream));
     return KAGNN_OK;

@@ -14,10 +14,10 @@ namespace kagnn {
 // split-precision kernels shared with the B-spline layer (K == 0 selects the RBF basis)
 bool kan_split_fwd_ok(int in, int out, int G, int K);
 size_t kan_split_pack_fwd_bytes(int in, int out, int C);
-size_t kan_split_pack_dx_bytes(int in, int out, int C);
+size_t kan_split_pack_dx_bytes(int in, int out, int C, int K);
 size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
 int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
-int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
+int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, int, void*, hipStream_t);
 int kan_split_fwd_any(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, void*, size_t, hipStream_t);
 size_t kan_split_fwd_ws_bytes(long N, int in, int out, int C);
 int kan_split_dx_any(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, hipStream_t, int gx16);
@@ -492,7 +492,7 @@ static FkBwdPlan fk_plan(long N, int in, int out, int ng, int mode) {
     p.gz = al256((size_t)N * in * 4);
     if (p.split) {
         p.pack_f = 0;
-        p.pack_d = al256(kan_split_pack_dx_bytes(in, out, ng));
+        p.pack_d = al256(kan_split_pack_dx_bytes(in, out, ng, 0));
         p.gcat = 0;                                   // gcat + slabs live inside the split kernel's own workspace
         p.slab = al256(kan_split_dw_ws_bytes(N, in, out, ng));
         p.nb = 0; p.rpw = 0; p.NS = 0; p.per = 0;
@@ -536,7 +536,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
         // same split-precision kernels as the B-spline layer, K == 0 selecting the RBF basis
         const RbfArgs rb = fk_rbf(centers, ng, den, lnw, lnb, stats, nullptr, gz);
         if (N > 0) {
-            int rc = kan_split_pack_dx_noscale(bw, sw, nullptr, in, out, ng, pd, st);
+            int rc = kan_split_pack_dx_noscale(bw, sw, nullptr, in, out, ng, 0, pd, st);
             if (rc) return rc;
             rc = kan_split_dx_any(x, ldx, gy, ldgy, N, nullptr, in, out, ng, 0, pd, gx, ldgx, rb, st, 0);
             if (rc) return rc;

@@ -32,13 +32,17 @@ static inline int vshift(int C) { return C > 8 ? 1 : 0; }     // 9..16 coefficie
 static size_t dx_blk_bytes(int inv /* virtual features */, int ob) {
     return kHdrBytes + (size_t)cdiv(inv, 16) * kCTmax * dx_q2(ob) * 2 * 1024;   // always 9 slots: branch-free MFMA loop
 }
-size_t kan_split_pack_dx_bytes(int in, int out, int C) {
-    return (size_t)cdiv(out, kOutBlk) * dx_blk_bytes(in << vshift(C), min(out, kOutBlk));
+// cubic layers with 9..16 coefficients and one output block: window-major tiles for kan_split_dx_w2_kernel
+bool kan_dx_w2_ok(int in, int out, int C, int K) { return K == 3 && C > 8 && C <= 16 && out <= kOutBlk; }
+static int dx_inv(int in, int out, int C, int K) { return kan_dx_w2_ok(in, out, C, K) ? 32 * cdiv(in, 16) : (in << vshift(C)); }
+
+size_t kan_split_pack_dx_bytes(int in, int out, int C, int K) {
+    return (size_t)cdiv(out, kOutBlk) * dx_blk_bytes(dx_inv(in, out, C, K), min(out, kOutBlk));
 }
 
 __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
                                      const float* __restrict__ sc, int in, int out, int C, int Q2,
-                                     unsigned char* __restrict__ pack, int self_scale) {
+                                     unsigned char* __restrict__ pack, int self_scale, int w2) {
     unsigned* hdr = reinterpret_cast<unsigned*>(pack);
     __shared__ float s_m[17];
     const float wmax = self_scale ? block_absmax_w(bw, sw, sc, in, out, C, s_m) : __uint_as_float(hdr[2]);
@@ -48,12 +52,13 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
         reinterpret_cast<float*>(pack)[0] = ldexpf(1.0f, e - 10);
         reinterpret_cast<int*>(pack)[1] = e;
     }
-    pack_dx_items(bw, sw, sc, in, out, C, Q2, pack, wscale, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+    pack_dx_items(bw, sw, sc, in, out, C, Q2, pack, wscale, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, w2);
 }
 
-int kan_split_pack_dx_noscale(const float* bw, const float* sw, const float* sc, int in, int out, int C,
+int kan_split_pack_dx_noscale(const float* bw, const float* sw, const float* sc, int in, int out, int C, int K,
                               void* pack_dx, hipStream_t st) {
-    const int inv = in << vshift(C);
+    const int w2 = kan_dx_w2_ok(in, out, C, K) ? 1 : 0;
+    const int inv = dx_inv(in, out, C, K);
     const size_t stride = dx_blk_bytes(inv, min(out, kOutBlk));
     for (int b = 0; b * kOutBlk < out; ++b) {
         const int ob = min(kOutBlk, out - b * kOutBlk), Q2 = dx_q2(ob);
@@ -61,7 +66,7 @@ int kan_split_pack_dx_noscale(const float* bw, const float* sw, const float* sc,
         const long items = (long)cdiv(inv, 16) * kCTmax * Q2 * 64;
         split_pack_dx_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(
             bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C, Q2,
-            static_cast<unsigned char*>(pack_dx) + b * stride, 1);
+            static_cast<unsigned char*>(pack_dx) + b * stride, 1, w2);
         KAGNN_LAUNCH_CHECK();
     }
     return KAGNN_OK;
@@ -432,6 +437,207 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
     return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cubic layers with 9..16 coefficients (grid 6..13; BASELINE config 3 is grid 8 => C = 11), one output block.
+// The general kernel above runs them as 2*in "virtual" features whose two 8-slot windows sit on neighbouring LANES:
+// the span / derivative / SiLU' arithmetic of a scalar runs twice and all 2 x 9 slots go through the matrix cores
+// although only C + 1 carry weights.  Here a lane owns ONE input feature and walks its two windows in turn over
+// window-major W^T tiles (wcat_v sh == 2): window 0 = 8 spline slots + base, window 1 = only its C - 8 live slots;
+// the scalar's span and SiLU' are evaluated once, the second window costs one more barrel contraction.
+// Per 32 rows x 16 input features: (9 + C - 8) * Q2 * 6 MFMAs and ~95 VALU per scalar instead of 18 * Q2 * 6 and 2 x 74.
+template <int Q2>
+__global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in, int out, int C,
+    const float* __restrict__ knots_g, int nknots, const unsigned char* __restrict__ pack,
+    float* __restrict__ gx, long ldgx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* s_knots = reinterpret_cast<float*>(smem);
+    unsigned* s_btbl = reinterpret_cast<unsigned*>(smem + 256);
+    unsigned char* s_w = smem + kLdsHdr;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < nknots) s_knots[tid] = knots_g[tid];
+    build_barrel_table(s_btbl, tid);
+    const int T = cdiv(in, 16), ns1 = C - 8;                     // real feature tiles; live slots of the second window
+    constexpr int FT_BYTES = kCTmax * Q2 * 2 * 1024;
+    const int e_w = reinterpret_cast<const int*>(pack)[1];
+    const unsigned char* gw = pack + kHdrBytes;
+    auto stage = [&](int tile, int nslots) {                     // [c][q][hi|lo] order: the first nslots slots are a prefix
+        const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)tile * FT_BYTES);
+        uint4* dst = reinterpret_cast<uint4*>(s_w);
+        const int n16 = nslots * Q2 * 2 * 1024 / 16;
+        for (int i = tid; i < n16; i += 512) dst[i] = src[i];
+    };
+    __syncthreads();
+    const FastGeom fgeo = fast_geom(s_knots, nknots);
+    const float wd = 0.5f * fgeo.inv_h;
+    const int li = lane & 15, kg = lane >> 4;
+    const bool al4 = ((ldgy & 3) == 0) && ((reinterpret_cast<uintptr_t>(gy) & 15) == 0) && (32 * Q2 == out);
+    const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u, ldgx4 = (unsigned)ldgx * 4u;
+    const unsigned gy_ro = (unsigned)(wave * 32 + li) * ldgy4;
+    const unsigned x_rb = (unsigned)(wave * 32 + 4 * kg) * ldx4;
+    const unsigned gx_rb = (unsigned)(wave * 32 + 4 * kg) * ldgx4;
+    const unsigned char* wl = s_w + lane * 16;
+
+    for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
+        const GBuf gyb = gbuf_at(gy, N, ldgy, out, tile * 256);
+        const GBuf xb = gbuf_at(x, N, ldx, in, tile * 256), gxb = gbuf_at(gx, N, ldgx, in, tile * 256);
+        // ---- A operand: gy rows scaled per row by 2^(10 - rexp), split into fp16 hi / lo (as in the general kernel)
+        u32x4 ahi[2][Q2], alo[2][Q2];
+        float rinv[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const unsigned ro = gy_ro + kg * 32, so = (unsigned)(16 * rt) * ldgy4;
+            float raw[Q2][8];
+            float mx = 0.0f;
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) {
+                if (al4) {
+                    gld4_s(gyb, ro, so + 128 * q, raw[q]);
+                    gld4_s(gyb, ro, so + 128 * q + 16, raw[q] + 4);
+                } else {
+                    const int o0 = 32 * q + 8 * kg;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) raw[q][j] = gld_s(gyb, gy_ro + min(o0 + j, out - 1) * 4, so);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(raw[q][j]));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const int rexp = exp_for_max(mx);
+            const float sc = ldexpf(1.0f, 10 - rexp);
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = raw[q][j] * sc;
+                split_f16x2(v, ahi[rt][q], alo[rt][q]);
+            }
+            const float mine = ldexpf(1.0f, e_w + rexp - 10);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) rinv[rt][reg] = __shfl(mine, 4 * kg + reg);
+        }
+
+        for (int t = 0; t < T; ++t) {
+            const int f = 16 * t + li;
+            const unsigned fcol = (unsigned)min(f, in - 1) * 4u;
+            float xq[2][4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) xq[rt][reg] = gld_s(xb, x_rb + fcol, (unsigned)(16 * rt + reg) * ldx4);
+            f32x4 D[kCTmax][2];
+            // ================= window 0: slots 0..7 + base
+            __syncthreads();
+            stage(2 * t, kCTmax);
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < kCTmax; ++c) { D[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            {
+                constexpr int NGRP = kCTmax * Q2;
+                u32x4 bh[2], bl[2];
+                bh[0] = *reinterpret_cast<const u32x4*>(wl + 0 * 1024);
+                bl[0] = *reinterpret_cast<const u32x4*>(wl + 1 * 1024);
+#pragma unroll
+                for (int g = 0; g < NGRP; ++g) {
+                    const int c = g / Q2, q = g % Q2;
+                    if (g + 1 < NGRP) {
+                        bh[(g + 1) & 1] = *reinterpret_cast<const u32x4*>(wl + (size_t)(2 * (g + 1) + 0) * 1024);
+                        bl[(g + 1) & 1] = *reinterpret_cast<const u32x4*>(wl + (size_t)(2 * (g + 1) + 1) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const u32x4 bhi = bh[g & 1], blo = bl[g & 1];
+                    D[c][0] = mfma16_f16(ahi[0][q], bhi, D[c][0]);
+                    D[c][1] = mfma16_f16(ahi[1][q], bhi, D[c][1]);
+                    D[c][0] = mfma16_f16(ahi[0][q], blo, D[c][0]);
+                    D[c][1] = mfma16_f16(ahi[1][q], blo, D[c][1]);
+                    D[c][0] = mfma16_f16(alo[0][q], bhi, D[c][0]);
+                    D[c][1] = mfma16_f16(alo[1][q], bhi, D[c][1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // V0: SiLU' once per scalar; first window's barrel contraction (the span is cheap enough to redo for the second
+            // window: keeping m / u / weight across its MFMAs costs 24 registers and spills at Q2 = 4)
+            float s0[2][4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                __builtin_amdgcn_sched_barrier(0);       // 4 scalars in flight, not 8: the barrel temporaries of 8 spill at Q2 = 4
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float xv = xq[rt][reg];
+                    int m; float u; bool inside;
+                    fast_span(xv, fgeo, m, u, inside);
+                    const float wq = inside ? wd : 0.0f;
+                    float dN[4];
+                    cubic_dbases(u, wq, dN);
+                    float d[kCTmax - 1];
+#pragma unroll
+                    for (int c = 0; c < kCTmax - 1; ++c) d[c] = D[c][rt][reg];
+                    const u32x4 sel = *reinterpret_cast<const u32x4*>(s_btbl + 4 * min((unsigned)m, 15u));
+                    s0[rt][reg] = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot3(d, m, sel, dN));
+                }
+            }
+            // ================= window 1: its C - 8 live slots only
+            __syncthreads();
+            stage(2 * t + 1, ns1);
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < kCTmax - 1; ++c) { D[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int c = 0; c < kCTmax - 1; ++c) {
+                if (c < ns1) {                                            // wave-uniform
+#pragma unroll
+                    for (int q = 0; q < Q2; ++q) {
+                        const u32x4 bhi = *reinterpret_cast<const u32x4*>(wl + (size_t)(2 * (c * Q2 + q) + 0) * 1024);
+                        const u32x4 blo = *reinterpret_cast<const u32x4*>(wl + (size_t)(2 * (c * Q2 + q) + 1) * 1024);
+                        D[c][0] = mfma16_f16(ahi[0][q], bhi, D[c][0]);
+                        D[c][1] = mfma16_f16(ahi[1][q], bhi, D[c][1]);
+                        D[c][0] = mfma16_f16(ahi[0][q], blo, D[c][0]);
+                        D[c][1] = mfma16_f16(ahi[1][q], blo, D[c][1]);
+                        D[c][0] = mfma16_f16(alo[0][q], bhi, D[c][0]);
+                        D[c][1] = mfma16_f16(alo[1][q], bhi, D[c][1]);
+                        __builtin_amdgcn_sched_barrier(0);                // keep the fragment reads of later slots where they are
+                    }
+                }
+            }
+            const unsigned gx_ro = gx_rb + fcol;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    int m; float u; bool inside;
+                    fast_span(xq[rt][reg], fgeo, m, u, inside);
+                    float dN[4];
+                    cubic_dbases(u, inside ? wd : 0.0f, dN);
+                    float d[kCTmax - 1];
+#pragma unroll
+                    for (int c = 0; c < kCTmax - 1; ++c) d[c] = D[c][rt][reg];
+                    const int m1 = m - 8;
+                    const u32x4 sel = *reinterpret_cast<const u32x4*>(s_btbl + 4 * min((unsigned)m1, 15u));
+                    const float s = (s0[rt][reg] + barrel_dot3(d, m1, sel, dN)) * rinv[rt][reg];
+                    if (f < in) gst_s(gxb, gx_ro, (unsigned)(16 * rt + reg) * ldgx4, s);      // rows >= N: dropped
+                }
+            }
+        }
+    }
+}
+
+template <int Q2>
+static int launch_dx_w2(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
+                        const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx, hipStream_t st) {
+    const size_t lds = kLdsHdr + (size_t)kCTmax * Q2 * 2 * 1024;
+    static bool configured = false;
+    if (!configured) {
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_w2_kernel<Q2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        configured = true;
+    }
+    kan_split_dx_w2_kernel<Q2><<<(unsigned)min((long)cdiv(N, 256), 256L), 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots,
+                                                                                   pack, gx, ldgx);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 static int dx_block(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
                     int out, int G, int K, const unsigned char* p, float* gx, long ldgx, const RbfArgs& rb,
                     int accumulate, int gx16, hipStream_t st) {
@@ -457,6 +663,16 @@ int kan_split_dx_any(const float* x, long ldx, const float* gy, long ldgy, long 
                      hipStream_t st, int gx16) {
     if (gx16 && (K == 0 || out > kOutBlk))
         return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 gradient rows need a B-spline layer with <= 128 outputs", "kan_split_dx");
+    if (kan_dx_w2_ok(in, out, G + K, K)) {               // 9..16 coefficients: one lane per input feature, two windows in turn
+        if (gx16) return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 gradient rows need <= 8 coefficients", "kan_split_dx");
+        const unsigned char* p = static_cast<const unsigned char*>(pack);
+        const int nk = G + 2 * K + 1;
+        switch (dx_q2(out)) {
+            case 1: return launch_dx_w2<1>(x, ldx, gy, ldgy, N, in, out, G + K, knots, nk, p, gx, ldgx, st);
+            case 2: return launch_dx_w2<2>(x, ldx, gy, ldgy, N, in, out, G + K, knots, nk, p, gx, ldgx, st);
+            default: return launch_dx_w2<4>(x, ldx, gy, ldgy, N, in, out, G + K, knots, nk, p, gx, ldgx, st);
+        }
+    }
     const size_t stride = dx_blk_bytes(in << vshift(G + K), min(out, kOutBlk));
     for (int b = 0; b * kOutBlk < out; ++b) {
         const int rc = dx_block(x, ldx, gy + b * kOutBlk, ldgy, N, knots, in, min(kOutBlk, out - b * kOutBlk), G, K,

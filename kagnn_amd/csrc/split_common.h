@@ -23,9 +23,11 @@ __device__ __forceinline__ float wcat_s(const float* bw, const float* sw, const 
 // Layers with 9..16 coefficients per input feature run as 2*in "virtual" features of 8 slots each (sh = 1):
 // virtual feature v = (input feature v >> 1, slot window v & 1); window 1 holds coefficients 8..15 and no
 // base weight.  slot 0..7 = coefficient inside the window, slot 8 = the base (SiLU) weight.
+// sh == 2: the same two windows, but WINDOW-MAJOR inside blocks of 32 virtual features -- tile 2t holds window 0 of
+// input features 16t .. 16t+15 and tile 2t+1 their window 1 (kan_split_dx_w2_kernel walks a lane's two windows in turn).
 __device__ __forceinline__ float wcat_v(const float* bw, const float* sw, const float* sc, int in,
                                         int out, int C, int o, int v, int slot, int sh) {
-    const int f = v >> sh, w = v & sh;
+    const int f = (sh == 2) ? (((v >> 5) << 4) | (v & 15)) : (v >> sh), w = (sh == 2) ? ((v >> 4) & 1) : (v & sh);
     if (slot == 8) return w == 0 ? wcat_s(bw, sw, sc, in, out, C, o, f, C) : 0.0f;
     const int c = slot + 8 * w;
     return c < C ? wcat_s(bw, sw, sc, in, out, C, o, f, c) : 0.0f;
@@ -39,9 +41,10 @@ __host__ __device__ inline int dx_q2(int out) { return out <= 32 ? 1 : (out <= 6
 // pack_dx[ft16][c][q2][part][lane][8] : lane (f = lane&15, kg = lane>>4), j -> W'[o = 32*q2+8*kg+j][16*ft16+f][c]
 __device__ __forceinline__ void pack_dx_items(const float* __restrict__ bw, const float* __restrict__ sw,
                                               const float* __restrict__ sc, int in, int out, int C, int Q2,
-                                              unsigned char* __restrict__ pack, float wscale, long first, long step) {
+                                              unsigned char* __restrict__ pack, float wscale, long first, long step,
+                                              int w2 = 0 /* window-major tiles (wcat_v sh == 2) */) {
     const int CT = kCTmax;
-    const int sh = C > 8 ? 1 : 0, inv = in << sh;
+    const int sh = w2 ? 2 : (C > 8 ? 1 : 0), inv = w2 ? 32 * ((in + 15) / 16) : (in << sh);
     const long total = (long)((inv + 15) / 16) * CT * Q2 * 64;
     for (long i = first; i < total; i += step) {
         const int lane = i & 63; long r = i >> 6;
