@@ -293,6 +293,10 @@ def main():
 
     import kagnn_amd
     from kagnn_amd import ops
+    # The product's GIKANLayer makes ONE library call each way (kagnn_gin_kan_layer_fwd / _bwd).  bench.py composes the
+    # same kernels from the per-op entry points instead, so that each of them can be bracketed by HIP events on the launch
+    # stream (roofline / roofline_kernels); bit-identical results, 0.5 % more host work (A/B: 2.483 vs 2.499 ms).
+    ops._LAYER_ABI = os.environ.get("KAGNN_BENCH_LAYER_ABI", "0") == "1"
 
     n, e = args.nodes, args.edges
     fp32_mode = args.precision in ("fp32", "exact", "0")

@@ -211,6 +211,45 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One KAN-GIN convolution per call -- GIKANLayer.forward (node_classification_clean/models.py:48-56: GINConv around
+ * make_kan's KAN chain, ekan.py:270-275) and its backward; the `gin_kan_fused_fwd / _bwd` of SURVEY.md 8(b).  The call
+ * sequences the library's own kernels on `stream` (aggregation, ONE weight-pack launch for the chain, the KANLinear
+ * forwards; on the way back per layer the weight and input gradients, then the transposed aggregation); the caller owns
+ * every buffer:
+ *   widths[L+1]        layer widths: in_features of layer 0 ... out_features of layer L-1 (L <= 8, same grid / order / mode)
+ *   acts[L+1]          fp32 [N, widths[l]]: acts[0] receives the aggregate h0, acts[l+1] the output of layer l (acts[L] = y);
+ *                      the backward reads acts[0..L-1] (the only saved tensors) -- contiguous, ld = width
+ *   pack_fwd/pack_dx   per layer, sized by kagnn_kan_pack_bytes; written by _fwd, pack_dx read by _bwd
+ *   x                  [N, widths[0]] fp32 or bf16 (x_dtype; bf16 = the gather-operand mode of kagnn_aggregate_sum_bf16)
+ *   _bwd: gx           d loss / d x in gx_dtype, or NULL; `bf16_gather` != 0 lets the first layer's input-gradient kernel
+ *                      write d loss / d h0 as bf16 rows for the transposed aggregation (split precision, cubic, <= 8
+ *                      coefficients; otherwise it stays fp32); g_base_weight / g_spline_weight / g_spline_scaler per layer
+ *   (rowptr, col, hub_seg): by destination for _fwd, the transposed (by source) structure for _bwd
+ * Workspace sizes from kagnn_gin_kan_layer_workspace_bytes (hub-segment counts of the two directions).  Deterministic.
+ * ------------------------------------------------------------------------------------------ */
+int kagnn_gin_kan_layer_workspace_bytes(int64_t num_nodes, int32_t num_layers, const int32_t* widths,
+                                        int32_t grid_size, int32_t spline_order, int32_t mode,
+                                        int64_t num_hub_seg, int64_t num_hub_seg_t,
+                                        size_t* fwd_bytes_host, size_t* bwd_bytes_host);
+int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t num_nodes,
+                            const int32_t* rowptr, const int32_t* col, const int32_t* hub_seg,
+                            int64_t num_hub_seg, int32_t hub_threshold, float self_scale,
+                            int32_t num_layers, const int32_t* widths, const float* const* base_weight,
+                            const float* const* spline_weight, const float* const* spline_scaler,
+                            const float* knots, int32_t grid_size, int32_t spline_order, int32_t mode,
+                            float* const* acts, void* const* pack_fwd, void* const* pack_dx,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t num_nodes, const int32_t* rowptr_t,
+                            const int32_t* col_t, const int32_t* hub_seg_t, int64_t num_hub_seg_t,
+                            int32_t hub_threshold, float self_scale, int32_t num_layers, const int32_t* widths,
+                            const float* const* spline_weight, const float* const* spline_scaler,
+                            const float* knots, int32_t grid_size, int32_t spline_order, int32_t mode,
+                            const float* const* acts, const void* const* pack_dx, void* gx, int32_t gx_dtype,
+                            int64_t ldgx, int32_t bf16_gather, float* const* g_base_weight,
+                            float* const* g_spline_weight, float* const* g_spline_scaler,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Adaptive grids.  Replaces the device work of KANLinear.update_grid (ekan.py:164-211) and the dense
  * b_splines (:79-112).  `grid*` are whole grid buffers [in, G+2k+1] with increasing rows.
  * ------------------------------------------------------------------------------------------ */

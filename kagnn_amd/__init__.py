@@ -12,7 +12,7 @@ from .models import (FASTKAGATConv, FASTKAGCNConv, FKANLayer, GFASTKAN_Nodes,   
 
 from .norm import BatchNorm1d                                                    # noqa: F401
 from .graph_models import (AtomEncoder, BondEncoder, FASTKAGAT, FASTKAGCN, FASTKAGCNRegression, FASTKAGIN, GINEKANLayer,   # noqa: F401
-                           KAGAT, KAGCN, KAGCNRegression, KAGIN, KAGINRegression,
+                           KAGAT, KAGCN, KAGCNRegression, KAGIN, KAGINRegression, FASTKAGINRegression,
                            KAGCN_Layer, KAGAT_Layer, FASTKAGCN_Layer, FASTKAGAT_Layer)
 
 __version__ = "0.1.0"

@@ -55,6 +55,13 @@ _SIGNATURES = {
     "kagnn_kan_linear_bwd_weight": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, c_int32, c_int32,
                                               c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P,
                                               c_size_t, _P]),
+    "kagnn_gin_kan_layer_workspace_bytes": (c_int32, [c_int64, c_int32, _P, c_int32, c_int32, c_int32, c_int64, c_int64,
+                                                      POINTER(c_size_t), POINTER(c_size_t)]),
+    "kagnn_gin_kan_layer_fwd": (c_int32, [_P, c_int32, c_int64, c_int64, _P, _P, _P, c_int64, c_int32, c_float, c_int32, _P,
+                                          _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_size_t, _P]),
+    "kagnn_gin_kan_layer_bwd": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, c_int64, c_int32, c_float, c_int32, _P, _P, _P,
+                                          _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P, _P, _P,
+                                          _P, c_size_t, _P]),
     "kagnn_kan_bsplines": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
     "kagnn_kan_grid_refit_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "kagnn_kan_grid_refit": (c_int32, [_P, c_int64, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P,

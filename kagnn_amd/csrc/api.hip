@@ -506,5 +506,139 @@ int kagnn_softmax_xent_bwd(const float* logits, int64_t ld, int64_t N, int32_t C
                     as_stream(stream));
 }
 
+
+// ---------------------------------------------------------------- one KAN-GIN convolution per call
+static size_t al256z(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int kagnn_gin_kan_layer_workspace_bytes(int64_t N, int32_t L, const int32_t* widths, int32_t G, int32_t K, int32_t mode,
+                                        int64_t num_hub_seg, int64_t num_hub_seg_t, size_t* fwd_bytes, size_t* bwd_bytes) {
+    KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && fwd_bytes && bwd_bytes, "bad argument");
+    size_t fw = 0, dw = 0;
+    int wmax = 0;
+    for (int l = 0; l < L; ++l) {
+        int rc = check_kan_dims(__func__, widths[l], widths[l + 1], G, K, mode);
+        if (rc) return rc;
+        size_t b = 0;
+        rc = kagnn_kan_fwd_workspace_bytes(N, widths[l], widths[l + 1], G, K, mode, &b); if (rc) return rc;
+        fw = b > fw ? b : fw;
+        rc = kagnn_kan_bwd_weight_workspace_bytes(N, widths[l], widths[l + 1], G, K, mode, &b); if (rc) return rc;
+        dw = b > dw ? b : dw;
+        wmax = widths[l] > wmax ? widths[l] : wmax;
+    }
+    const size_t hub_f = aggregate_bf16_ws_bytes(num_hub_seg, widths[0]), hub_t = aggregate_bf16_ws_bytes(num_hub_seg_t, widths[0]);
+    *fwd_bytes = al256z(hub_f) + al256z(fw) + 256;
+    // backward: hub partials | dW slabs | two ping-pong gradient matrices [N, max width] (fp32)
+    *bwd_bytes = al256z(hub_t) + al256z(dw) + 2 * al256z((size_t)N * wmax * sizeof(float)) + 256;
+    return KAGNN_OK;
+}
+
+int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t N, const int32_t* rowptr, const int32_t* col,
+                            const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, float self_scale,
+                            int32_t L, const int32_t* widths, const float* const* bw, const float* const* sw,
+                            const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
+                            float* const* acts, void* const* pack_fwd, void* const* pack_dx, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && bw && sw && acts && pack_fwd && pack_dx, "bad argument");
+    size_t need_f = 0, need_b = 0;
+    int rc = kagnn_gin_kan_layer_workspace_bytes(N, L, widths, G, K, mode, num_hub_seg, 0, &need_f, &need_b);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(workspace && workspace_bytes >= need_f, "workspace too small (kagnn_gin_kan_layer_workspace_bytes)");
+    if (N == 0) return KAGNN_OK;
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    const size_t hub_b = al256z(aggregate_bf16_ws_bytes(num_hub_seg, widths[0]));
+    // 1. h0 = self_scale * x_i + sum_{j -> i} x_j
+    if (x_dtype == KAGNN_DTYPE_BF16)
+        rc = kagnn_aggregate_sum_bf16(x, ldx, acts[0], widths[0], KAGNN_DTYPE_F32, rowptr, col, nullptr, N, widths[0], self_scale,
+                                      nullptr, nullptr, nullptr, 0, hub_seg, num_hub_seg, hub_threshold, ws, hub_b, stream);
+    else
+        rc = kagnn_aggregate_sum(static_cast<const float*>(x), ldx, acts[0], widths[0], rowptr, col, nullptr, N, widths[0],
+                                 self_scale, nullptr, nullptr, nullptr, 0, hub_seg, num_hub_seg, hub_threshold, ws, hub_b, stream);
+    if (rc) return rc;
+    // 2. weight packs: one launch for the whole chain where the shapes allow it
+    bool batched = L >= 2;
+    int in_[8], out_[8];
+    for (int l = 0; l < L; ++l) {
+        in_[l] = widths[l]; out_[l] = widths[l + 1];
+        batched = batched && use_split_dx(in_[l], out_[l], G, K, mode) && use_sparse_fwd(in_[l], out_[l], G, K, mode) &&
+                  kan_fused_pack_ok(in_[l], out_[l], G + K);
+    }
+    if (batched) {
+        rc = kagnn_kan_pack_batch(L, bw, sw, sc, in_, out_, G, K, mode, pack_fwd, pack_dx, stream);
+        if (rc) return rc;
+    } else {
+        for (int l = 0; l < L; ++l) {
+            rc = kagnn_kan_pack(bw[l], sw[l], sc ? sc[l] : nullptr, in_[l], out_[l], G, K, mode, pack_fwd[l], pack_dx[l], stream);
+            if (rc) return rc;
+        }
+    }
+    // 3. the chain
+    for (int l = 0; l < L; ++l) {
+        rc = kagnn_kan_linear_fwd(acts[l], in_[l], N, knots, in_[l], out_[l], G, K, mode, pack_fwd[l], acts[l + 1], out_[l],
+                                  ws + hub_b, need_f - hub_b, stream);
+        if (rc) return rc;
+    }
+    return KAGNN_OK;
+}
+
+int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t N, const int32_t* rowptr_t, const int32_t* col_t,
+                            const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
+                            int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
+                            const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
+                            const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
+                            float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && sw && acts && pack_dx && g_sw, "bad argument");
+    size_t need_f = 0, need_b = 0;
+    int rc = kagnn_gin_kan_layer_workspace_bytes(N, L, widths, G, K, mode, 0, num_hub_seg_t, &need_f, &need_b);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(workspace && workspace_bytes >= need_b, "workspace too small (kagnn_gin_kan_layer_workspace_bytes)");
+    if (N == 0) return KAGNN_OK;
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    int wmax = 0;
+    size_t dwb = 0;
+    for (int l = 0; l < L; ++l) {
+        wmax = widths[l] > wmax ? widths[l] : wmax;
+        size_t b = 0;
+        kagnn_kan_bwd_weight_workspace_bytes(N, widths[l], widths[l + 1], G, K, mode, &b);
+        dwb = b > dwb ? b : dwb;
+    }
+    const size_t hub_b = al256z(aggregate_bf16_ws_bytes(num_hub_seg_t, widths[0])), dw_b = al256z(dwb);
+    const size_t g_b = al256z((size_t)N * wmax * sizeof(float));
+    unsigned char* gbuf[2] = {ws + hub_b + dw_b, ws + hub_b + dw_b + g_b};
+    const float* g = gy;
+    long ldg = ldgy;
+    int cur = 0;
+    bool gh0_bf16 = false;
+    for (int l = L - 1; l >= 0; --l) {
+        const int in = widths[l], out = widths[l + 1];
+        rc = kagnn_kan_linear_bwd_weight(acts[l], in, g, ldg, N, knots, in, out, G, K, mode, sw[l], sc ? sc[l] : nullptr,
+                                         g_bw ? g_bw[l] : nullptr, g_sw[l], g_sc ? g_sc[l] : nullptr, ws + hub_b, dw_b, stream);
+        if (rc) return rc;
+        if (l == 0 && gx == nullptr) break;
+        // the gathered matrix of the transposed aggregation leaves the dX kernel as bf16 when the mode asks for it
+        const bool b16 = l == 0 && bf16_gather && mode == KAGNN_PREC_SPLIT && K == 3 && G + K <= 8 && out <= 128 && in % 8 == 0 &&
+                         use_split_dx(in, out, G, K, mode);
+        rc = kagnn_kan_linear_bwd_input(acts[l], in, g, ldg, N, knots, in, out, G, K, mode, pack_dx[l], gbuf[cur], in,
+                                        b16 ? KAGNN_DTYPE_BF16 : KAGNN_DTYPE_F32, stream);
+        if (rc) return rc;
+        g = reinterpret_cast<const float*>(gbuf[cur]); ldg = in; cur ^= 1;
+        gh0_bf16 = b16;
+    }
+    if (gx == nullptr) return KAGNN_OK;
+    const int f0 = widths[0];
+    if (gh0_bf16 || gx_dtype == KAGNN_DTYPE_BF16) {
+        const void* src = g;
+        if (!gh0_bf16) {                          // fp32 d loss / d h0 but a bf16 result wanted: convert, then the bf16 kernel
+            rc = kagnn_rows_to_bf16(g, ldg, gbuf[cur], f0, N, f0, stream);
+            if (rc) return rc;
+            src = gbuf[cur];
+        }
+        return kagnn_aggregate_sum_bf16(src, f0, gx, ldgx, gx_dtype, rowptr_t, col_t, nullptr, N, f0, self_scale, nullptr, nullptr,
+                                        nullptr, 0, hub_seg_t, num_hub_seg_t, hub_threshold, ws, hub_b, stream);
+    }
+    return kagnn_aggregate_sum(g, ldg, static_cast<float*>(gx), ldgx, rowptr_t, col_t, nullptr, N, f0, self_scale, nullptr,
+                               nullptr, nullptr, 0, hub_seg_t, num_hub_seg_t, hub_threshold, ws, hub_b, stream);
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

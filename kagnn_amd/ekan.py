@@ -156,6 +156,11 @@ class KANLinear(nn.Module):
         ``kagnn_kan_grid_refit`` -- no [N, in, out] intermediate.  The layer then runs on per-feature knots."""
         assert x.dim() == 2 and x.size(1) == self.in_features
         n, g, k, dev = x.size(0), self.grid_size, self.spline_order, x.device
+        if g + k > 16:
+            # the refit kernel solves per-feature normal equations for <= 16 coefficients (csrc/kan_grid.hip); the
+            # forward / backward handle more (coefficient groups), the reference's search space reaches grid_size 32
+            raise NotImplementedError(f"update_grid supports grid_size + spline_order <= 16 (got {g + k}); "
+                                      "KAGNN itself never calls update_grid (SURVEY.md 8(f) rank 4)")
         ranked = torch.sort(x, dim=0).values
         quantiles = ranked[torch.linspace(0, n - 1, g + 1, dtype=torch.int64, device=dev)]       # [G+1, in]
         step = (ranked[-1] - ranked[0] + 2 * margin) / g

@@ -105,7 +105,7 @@ class KAGIN(_GraphLevel):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, data):
-        g = ops.graph_index(data.edge_index, data.x.size(0))
+        g = ops.graph_index(data.edge_index, data.x.size(0), cache=False)
         x = self._message_passing(data.x, g)
         return F.log_softmax(self.kan(self._pool(x, data)), dim=1)
 
@@ -122,7 +122,7 @@ class FASTKAGIN(_GraphLevel):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, data):
-        g = ops.graph_index(data.edge_index, data.x.size(0))
+        g = ops.graph_index(data.edge_index, data.x.size(0), cache=False)
         x = self._message_passing(data.x, g)
         return F.log_softmax(self.kan(self._pool(x, data)), dim=1)
 
@@ -168,9 +168,26 @@ class KAGINRegression(_GraphLevel):
             edge_attr = edge_attr.unsqueeze(1)
         x = self.atom_encoder(x)
         edge_attr = self.bond_encoder(edge_attr)
-        g = ops.graph_index(data.edge_index, x.size(0))
+        g = ops.graph_index(data.edge_index, x.size(0), cache=False)
         x = self._message_passing(x, g, edge_attr)
         return self.kan(self._pool(x, data))
+
+
+class FASTKAGINRegression(KAGINRegression):
+    """the FastKAN flavour of the same model (``graph_regression/models.py:125-160``, class ``FASTKAGIN`` there):
+    GINE message passing around ``FastKAN`` chains, FastKAN read-out; same attribute names and state_dict keys."""
+
+    def __init__(self, num_node_features, num_edge_features, gnn_layers, hidden_dim, hidden_layers, grid_size,
+                 num_classes, dropout, ogb_encoders=False):
+        _GraphLevel.__init__(self)
+        self.n_layers = gnn_layers
+        self.atom_encoder = AtomEncoder(hidden_dim) if ogb_encoders else nn.Linear(num_node_features, hidden_dim)
+        self.bond_encoder = BondEncoder(hidden_dim) if ogb_encoders else nn.Linear(num_edge_features, hidden_dim)
+        self.conv = nn.ModuleList(
+            GINEKANLayer(make_fastkan(hidden_dim, hidden_dim, hidden_dim, hidden_layers, grid_size)) for _ in range(gnn_layers))
+        self.bn = nn.ModuleList(BatchNorm1d(hidden_dim) for _ in range(gnn_layers))
+        self.kan = make_fastkan(hidden_dim, hidden_dim, num_classes, hidden_layers, grid_size)
+        self.dropout = nn.Dropout(dropout)
 
 
 # ---------------------------------------------------------------------------------- GCN / GAT flavours
@@ -197,7 +214,7 @@ class KAGCN(_ConvSiluStack):
         self.dropout = nn.Dropout(p=dropout)
 
     def forward(self, data):
-        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0)))
+        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0), cache=False))
         ptr = ops.segment_ptr(data.batch, _num_graphs(data))
         return F.log_softmax(self.readout(ops.segment_pool(x, ptr, mean=True)), dim=1)
 
@@ -215,7 +232,7 @@ class KAGAT(_ConvSiluStack):
         self.dropout = nn.Dropout(p=dropout)
 
     def forward(self, data):
-        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0)))
+        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0), cache=False))
         return F.log_softmax(self.readout(self._pool(x, data)), dim=1)
 
 
@@ -231,7 +248,7 @@ class FASTKAGCN(_ConvSiluStack):
         self.dropout = nn.Dropout(p=dropout)
 
     def forward(self, data):
-        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0)))
+        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0), cache=False))
         ptr = ops.segment_ptr(data.batch, _num_graphs(data))
         return F.log_softmax(self.readout(ops.segment_pool(x, ptr, mean=True)), dim=1)
 
@@ -249,7 +266,7 @@ class FASTKAGAT(_ConvSiluStack):
         self.dropout = nn.Dropout(p=dropout)
 
     def forward(self, data):
-        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0)))
+        x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0), cache=False))
         return F.log_softmax(self.readout(self._pool(x, data)), dim=1)
 
 
@@ -269,7 +286,7 @@ class KAGCNRegression(_ConvSiluStack):
 
     def forward(self, data):
         x = self.atom_encoder(data.x)
-        x = self._stack(x, ops.graph_index(data.edge_index, x.size(0)))
+        x = self._stack(x, ops.graph_index(data.edge_index, x.size(0), cache=False))
         return self.readout(self._pool(x, data))
 
 
@@ -286,5 +303,5 @@ class FASTKAGCNRegression(_ConvSiluStack):
 
     def forward(self, data):
         x = self.atom_encoder(data.x)
-        x = self._stack(x, ops.graph_index(data.edge_index, x.size(0)))
+        x = self._stack(x, ops.graph_index(data.edge_index, x.size(0), cache=False))
         return self.readout(self._pool(x, data))

@@ -81,7 +81,8 @@ def _sizes(name: str, *args, outputs: int = 1):
     hit = _SIZE_CACHE.get(key)
     if hit is None:
         outs = [c_size_t(0) for _ in range(outputs)]
-        _call(name, *args, *[byref(o) for o in outs])
+        cargs = [(ctypes.c_int32 * len(a))(*a) if isinstance(a, tuple) else a for a in args]     # (int tuples: int32 arrays)
+        _call(name, *cargs, *[byref(o) for o in outs])
         hit = tuple(o.value for o in outs)
         _SIZE_CACHE[key] = hit
     return hit if outputs > 1 else hit[0]
@@ -244,8 +245,12 @@ _graph_cache: "dict[tuple, GraphIndex]" = {}
 _GRAPH_CACHE_MAX = 8
 
 
-def graph_index(edge_index: torch.Tensor, num_nodes: int) -> GraphIndex:
-    """Cached GraphIndex keyed on the identity and version of ``edge_index`` (SURVEY 8(b) ownership)."""
+def graph_index(edge_index: torch.Tensor, num_nodes: int, cache: bool = True) -> GraphIndex:
+    """Cached GraphIndex keyed on the identity and version of ``edge_index`` (SURVEY 8(b) ownership): full-batch node
+    models see the same ``edge_index`` every epoch.  ``cache=False`` (the graph-level models' mini-batches, which never
+    repeat): build and drop -- a cache that never hits only pins the last 8 batches and both of their CSRs."""
+    if not cache:
+        return GraphIndex(edge_index, num_nodes)
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
            edge_index.device.index)
     g = _graph_cache.get(key)
@@ -612,62 +617,133 @@ class _KANLinearFn(Function):
         return gx, gbw, gsw, gsc, None, None, None, None, None
 
 
+_LAYER_ABI = os.environ.get("KAGNN_LAYER_ABI", "1") != "0"     # 1: kagnn_gin_kan_layer_fwd / _bwd (one library call each way)
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
 class _GinKanLayerFn(Function):
-    """One KAN-GIN convolution -- ``KAN((1 + eps) x_i + sum_{j->i} x_j)`` -- as a single tape node (the
-    ``gin_kan_fused_fwd / _bwd`` of SURVEY.md 8(b)): forward = aggregation + the chain's KANLinear forwards (weights
-    of all layers packed in one launch), backward = per layer dX / dW, then the transposed aggregation.  Saves the layer
-    inputs only.  With ``act_bf16`` the two matrices the aggregation GATHERS travel as bf16: ``x`` on the way forward
-    and ``d loss / d h0`` on the way back (written as bf16 by the input-gradient kernel itself, no extra pass)."""
+    """One KAN-GIN convolution -- ``KAN((1 + eps) x_i + sum_{j->i} x_j)`` -- as a single tape node over
+    ``kagnn_gin_kan_layer_fwd / _bwd`` (the ``gin_kan_fused_fwd / _bwd`` of SURVEY.md 8(b)): forward = aggregation + ONE
+    weight-pack launch + the chain's KANLinear forwards, backward = per layer dW / dX, then the transposed aggregation --
+    one library call each way.  Saves the layer inputs only.  With ``act_bf16`` the two matrices the aggregation GATHERS
+    travel as bf16: ``x`` on the way forward and ``d loss / d h0`` on the way back (written as bf16 by the
+    input-gradient kernel itself, no extra pass).  ``KAGNN_LAYER_ABI=0`` composes the same kernels from the per-op entry
+    points instead (bit-identical; kept for A/B)."""
 
     @staticmethod
     @_on_operand_device
     def forward(ctx, x, g, self_scale, knots, grid_size, spline_order, mode, act_bf16, *params):
         _need_cuda(x, *params)
         nl = len(params) // 3
-        layers = [(params[3 * i], params[3 * i + 1], params[3 * i + 2]) for i in range(nl)]
+        layers = [(params[3 * i].contiguous(), params[3 * i + 1].contiguous(), params[3 * i + 2].contiguous()) for i in range(nl)]
         xg = _rows(x, allow_bf16=True)
         if act_bf16 and xg.dtype != torch.bfloat16:
             xg = to_bf16_rows(xg)
-        h = _aggregate_raw(xg, g, False, self_scale, None, None, None, None, False)
-        packs = kan_pack_chain(layers, grid_size, spline_order, mode) if nl > 1 else None
+        if xg.dtype == torch.bfloat16 and not _bf16_rows_ok(xg):
+            xg = xg.float()
+        n, dev = xg.size(0), xg.device
+        widths = [layers[0][1].size(1)] + [sw.size(0) for _, sw, _ in layers]
+        ctx.meta = (g, self_scale, grid_size, spline_order, mode, act_bf16, nl, x.dtype, widths)
+        if not _LAYER_ABI:
+            h = _aggregate_raw(xg, g, False, self_scale, None, None, None, None, False)
+            packs = kan_pack_chain(layers, grid_size, spline_order, mode) if nl > 1 else None
+            saved = []
+            for i, (bw, sw, sc) in enumerate(layers):
+                y, pack_d = _kan_fwd_raw(h, bw, sw, sc, knots[i], grid_size, spline_order, mode,
+                                         None if packs is None else packs[i], None if packs is None else packs[i][2])
+                saved += [h, sw, sc, pack_d]
+                h = y
+            ctx.save_for_backward(*saved, knots[0])
+            return h
+        acts = [torch.empty((n, w), dtype=torch.float32, device=dev) for w in widths]
+        pfs, pds = [], []
+        for i in range(nl):
+            fb, db = _sizes("kagnn_kan_pack_bytes", widths[i], widths[i + 1], grid_size, spline_order, mode, outputs=2)
+            pfs.append(_ws(fb, dev)); pds.append(_ws(db, dev))
+        warr = (ctypes.c_int32 * (nl + 1))(*widths)
+        wf, _ = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), grid_size, spline_order, mode,
+                       g.num_hub_seg, g.num_hub_seg_t, outputs=2)
+        ws = _ws(wf, dev)
+        _call("kagnn_gin_kan_layer_fwd", _ptr(xg), _lib.DTYPE_BF16 if xg.dtype == torch.bfloat16 else _lib.DTYPE_F32, _ld(xg), n,
+              _ptr(g.rowptr), _ptr(g.col), _ptr(g.hub_seg) if g.num_hub_seg else None, g.num_hub_seg, g.hub_threshold,
+              float(self_scale), nl, warr, _ptr_array([l[0] for l in layers]), _ptr_array([l[1] for l in layers]),
+              _ptr_array([l[2] for l in layers]), _ptr(knots[0]), grid_size, spline_order, mode, _ptr_array(acts),
+              _ptr_array(pfs), _ptr_array(pds), _ptr(ws), ws.numel(), _stream())
         saved = []
-        for i, (bw, sw, sc) in enumerate(layers):
-            bw_c, sw_c = bw.contiguous(), sw.contiguous()
-            sc_c = None if sc is None else sc.contiguous()
-            y, pack_d = _kan_fwd_raw(h, bw_c, sw_c, sc_c, knots[i], grid_size, spline_order, mode,
-                                     None if packs is None else packs[i], None if packs is None else packs[i][2])
-            saved += [h, sw_c, sc_c, pack_d]
-            h = y
-        ctx.save_for_backward(*saved, *knots)
-        ctx.meta = (g, self_scale, grid_size, spline_order, mode, act_bf16, nl, x.dtype,
-                    [(sw.size(1), sw.size(0)) for _, sw, _ in layers])
-        return h
+        for i in range(nl):
+            saved += [acts[i], layers[i][1], layers[i][2], pds[i]]
+        ctx.save_for_backward(*saved, knots[0])
+        return acts[nl]
 
     @staticmethod
     @once_differentiable
     @_on_operand_device
     def backward(ctx, gy):
-        g, self_scale, G, K, mode, act_bf16, nl, x_dtype, dims = ctx.meta
+        g, self_scale, G, K, mode, act_bf16, nl, x_dtype, widths = ctx.meta
         t = ctx.saved_tensors
-        knots = t[4 * nl:]
+        knots = t[4 * nl]
         gy = _rows(gy)
-        grads = [None] * (3 * nl)
         need_x = ctx.needs_input_grad[0]
-        for i in reversed(range(nl)):
-            h_in, sw, sc, pack_d = t[4 * i:4 * i + 4]
-            fin, fout = dims[i]
-            if any(ctx.needs_input_grad[8 + 3 * i:8 + 3 * i + 3]):
-                grads[3 * i], grads[3 * i + 1], grads[3 * i + 2] = _kan_bwd_weight_raw(h_in, gy, knots[i], sw, sc, fin, fout,
-                                                                                       G, K, mode, True)
-            if i > 0 or need_x:
-                bf16_out = (i == 0 and act_bf16 and mode == PREC_SPLIT and K == 3 and G + K <= 8 and fout <= 128
-                            and fin % 8 == 0 and _fits32(h_in, fout))      # the dX variant that stores bf16 rows
-                gy = _kan_bwd_input_raw(h_in, gy, knots[i], pack_d, fin, fout, G, K, mode, bf16_out)
-        gx = None
-        if need_x:
-            gx = _aggregate_raw(gy, g, True, self_scale, None, None, None, None, False,
-                                out_dtype=torch.bfloat16 if x_dtype == torch.bfloat16 else torch.float32)
+        gx_dtype = torch.bfloat16 if x_dtype == torch.bfloat16 else torch.float32
+        if not _LAYER_ABI:
+            grads = [None] * (3 * nl)
+            for i in reversed(range(nl)):
+                h_in, sw, sc, pack_d = t[4 * i:4 * i + 4]
+                fin, fout = widths[i], widths[i + 1]
+                if any(ctx.needs_input_grad[8 + 3 * i:8 + 3 * i + 3]):
+                    grads[3 * i], grads[3 * i + 1], grads[3 * i + 2] = _kan_bwd_weight_raw(h_in, gy, knots, sw, sc, fin, fout,
+                                                                                           G, K, mode, True)
+                if i > 0 or need_x:
+                    bf16_out = (i == 0 and act_bf16 and mode == PREC_SPLIT and K == 3 and G + K <= 8 and fout <= 128
+                                and fin % 8 == 0 and _fits32(h_in, fout))      # the dX variant that stores bf16 rows
+                    gy = _kan_bwd_input_raw(h_in, gy, knots, pack_d, fin, fout, G, K, mode, bf16_out)
+            gx = _aggregate_raw(gy, g, True, self_scale, None, None, None, None, False, out_dtype=gx_dtype) if need_x else None
+            return (gx, None, None, None, None, None, None, None, *grads)
+        n, dev = gy.size(0), gy.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        acts = [t[4 * i] for i in range(nl)]
+        sws, scs, pds = [t[4 * i + 1] for i in range(nl)], [t[4 * i + 2] for i in range(nl)], [t[4 * i + 3] for i in range(nl)]
+        gbw = [torch.empty((widths[i + 1], widths[i]), **f32) for i in range(nl)]
+        gsw = [torch.empty((widths[i + 1], widths[i], G + K), **f32) for i in range(nl)]
+        gsc = [torch.empty((widths[i + 1], widths[i]), **f32) for i in range(nl)]
+        gx = torch.empty((n, widths[0]), dtype=gx_dtype, device=dev) if need_x else None
+        if gx is not None and gx_dtype == torch.bfloat16 and not _bf16_rows_ok(gx):
+            gx = torch.empty((n, widths[0]), **f32)                       # widths the bf16 kernels do not take
+        warr = (ctypes.c_int32 * (nl + 1))(*widths)
+        _, wb = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), G, K, mode, g.num_hub_seg,
+                       g.num_hub_seg_t, outputs=2)
+        ws = _ws(wb, dev)
+        _call("kagnn_gin_kan_layer_bwd", _ptr(gy), _ld(gy), n, _ptr(g.rowptr_t), _ptr(g.col_t),
+              _ptr(g.hub_seg_t) if g.num_hub_seg_t else None, g.num_hub_seg_t, g.hub_threshold, float(self_scale), nl, warr,
+              _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, _ptr_array(acts), _ptr_array(pds), _ptr(gx),
+              _lib.DTYPE_BF16 if (gx is not None and gx.dtype == torch.bfloat16) else _lib.DTYPE_F32, widths[0],
+              int(bool(act_bf16) and widths[0] % 8 == 0), _ptr_array(gbw), _ptr_array(gsw), _ptr_array(gsc), _ptr(ws), ws.numel(),
+              _stream())
+        if gx is not None and gx.dtype != gx_dtype:
+            gx = gx.to(gx_dtype)
+        grads = []
+        for i in range(nl):
+            grads += [gbw[i], gsw[i], gsc[i]]
         return (gx, None, None, None, None, None, None, None, *grads)
+
+
+_KNOTS_EQUAL: dict = {}
+
+
+def _same_knots(layers, knots) -> bool:
+    """all layers of the chain on ONE knot vector (``KAN`` hands every layer the same grid_range)?  One host comparison per
+    distinct set of knot tensors, cached."""
+    key = tuple((k.data_ptr(), k._version) for k in knots)
+    hit = _KNOTS_EQUAL.get(key)
+    if hit is None:
+        hit = all(bool(torch.equal(k, knots[0])) for k in knots[1:])
+        if len(_KNOTS_EQUAL) > 256:
+            _KNOTS_EQUAL.clear()
+        _KNOTS_EQUAL[key] = hit
+    return hit
 
 
 def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optional[torch.dtype] = None):
@@ -682,7 +758,9 @@ def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optiona
            or l.grid_size + l.spline_order > 16 or not l.enable_standalone_scale_spline for l in layers):
         return None
     knots = [l._knots() for l in layers]
-    if any(k.dim() != 1 for k in knots):
+    if any(k.dim() != 1 or k.numel() != knots[0].numel() for k in knots):
+        return None
+    if not _same_knots(layers, knots):
         return None
     width = max(max(l.in_features, l.out_features) for l in layers)
     if mode == PREC_SPLIT and width > 7680:

@@ -235,8 +235,8 @@ def test_arxiv_shaped_fastkan_model_vs_oracle():
     torch.manual_seed(8)
     model = kagnn_amd.GFASTKAN_Nodes("gin", 3, 128, 256, 40, skip=True, grid_size=4, hidden_layers=2)
     gout = torch.randn(n, 40, generator=torch.Generator().manual_seed(9)) / n
-    # (the oracle in fp32 here -- the reference's own arithmetic: its 0.4 G RBF evaluations per pass take ~2 min in fp64)
-    _model_vs_oracle(model, "fastkan", "gin", 3, x, ei, gout, "arxiv.fastkan_gin", 1e-4, chunk=8192, dtype=torch.float32)
+    # (fp64 oracle: in fp32 -- the reference's own arithmetic -- the oracle itself is 5e-4 off at this depth and width)
+    _model_vs_oracle(model, "fastkan", "gin", 3, x, ei, gout, "arxiv.fastkan_gin", 1e-4, chunk=8192)
 
 
 # ------------------------------------------------------------------ config 3's layer at full size (hidden 128, grid 8)
@@ -365,15 +365,39 @@ def test_fused_gin_kan_node_equals_the_composed_ops_bitwise(monkeypatch):
         conv = kagnn_amd.GIKANLayer(f, f, grid_size=5, spline_order=3, hidden_dim=f, nb_layers=2).to(DEV)
         _set_precision(conv, mode)
         res = []
-        for fused in (True, False):
+        for fused, abi in ((True, True), (True, False), (False, False)):     # library layer call / composed node / separate ops
             monkeypatch.setattr(M, "_FUSED_LAYER", fused)
+            monkeypatch.setattr(ops, "_LAYER_ABI", abi)
             conv.zero_grad()
             xr = x.clone().requires_grad_(True)
             y = conv(xr, g)
             y.backward(gy)
             res.append([y.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in conv.parameters()])
-        for a, b in zip(*res):
-            assert torch.equal(a, b)
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                assert torch.equal(a, b)
+    # a chain the one-launch pack does not cover (3 layers, ragged widths, grid 8 => 11 coefficients) and an odd row count
+    n2 = 7001
+    ei2 = orc.powerlaw_graph(n2, 40000, seed=9)
+    g2 = ops.GraphIndex(ei2.to(DEV), n2)
+    conv = kagnn_amd.GIKANLayer(24, 40, grid_size=8, spline_order=3, hidden_dim=33, nb_layers=3).to(DEV)
+    x2 = (torch.randn(n2, 24, generator=torch.Generator().manual_seed(6)) * 0.4).to(DEV)
+    gy2 = torch.randn(n2, 40, generator=torch.Generator().manual_seed(7)).to(DEV)
+    res = []
+    for fused, abi in ((True, True), (False, False)):
+        monkeypatch.setattr(M, "_FUSED_LAYER", fused)
+        monkeypatch.setattr(ops, "_LAYER_ABI", abi)
+        conv.zero_grad()
+        xr = x2.clone().requires_grad_(True)
+        y = conv(xr, g2)
+        y.backward(gy2)
+        res.append([y.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in conv.parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    layers = [{k: v.detach().cpu().double() for k, v in l.state_dict().items()} for l in conv.nn.layers]
+    y64, gx64, _ = orc.kan_gin_layer_fwd_bwd(x2.cpu().double(), ei2, layers, 3, gy2.cpu().double())
+    assert_close(res[0][0], y64, what="3-layer ragged chain y")
+    assert_close(res[0][1], gx64, what="3-layer ragged chain gx")
 
 
 @pytest.mark.parametrize("f", [64, 128, 8, 24, 256, 12, 40])
@@ -445,7 +469,8 @@ def test_bf16_mode_gin_kan_layer_vs_oracle(monkeypatch):
     conv(xb, g).backward(gy.to(DEV))
     assert xb.grad.dtype == torch.bfloat16
     assert_close(xb.grad.float(), gx64, 8e-3, what="bf16 mode gx (bf16 rows)", elementwise=False)
-    # the mode really runs the bf16 kernels
+    # the mode really runs the bf16 kernels (composed form: the per-op entry points are visible to the timer)
+    monkeypatch.setattr(ops, "_LAYER_ABI", False)
     timer = ops.EntryPointTimer()
     ops.set_timer(timer)
     conv(xd.detach().requires_grad_(True), g).sum().backward()

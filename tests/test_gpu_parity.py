@@ -438,6 +438,13 @@ def test_graph_level_models_run_and_match_composition(golden):
     pred = r(d)
     pred.abs().mean().backward()                     # L1-style loss as in optuna_zinc.py
     assert pred.shape == (16, 1) and all(p.grad is not None for p in r.parameters())
+    # the FastKAN flavour (graph_regression/models.py:125-160): equals its own pieces run by hand
+    fr = kagnn_amd.FASTKAGINRegression(H, H, 2, H, 2, 4, 1, 0.0).to(DEV).eval()
+    pred = fr(d)
+    h, ea = fr.atom_encoder(d.x), fr.bond_encoder(d.edge_attr)
+    for conv, bn in zip(fr.conv, fr.bn):
+        h = bn(conv.nn(ops.aggregate_gine(h, ea, gi, self_scale=1.0)))
+    assert_close(pred, fr.kan(ops.segment_pool(h, ops.segment_ptr(d.batch, 16))), 1e-6, what="FASTKAGINRegression composition")
 
 
 # ------------------------------------------------------------------ range robustness of the split path
