@@ -37,7 +37,7 @@ int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int
 int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t);
 size_t kan_split_fwd_ws_bytes(long N, int in, int out, int C);
 int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t, int gx16);
-size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
+size_t kan_split_dw_ws_bytes(long N, int in, int out, int C, int K);
 int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t);
 bool kan_split_fwd_ok(int in, int out, int G, int K);
 bool kan_sparse_fwd_ok(int in, int out, int G, int K);
@@ -288,7 +288,7 @@ int kagnn_kan_bwd_weight_workspace_bytes(int64_t N, int32_t in, int32_t out, int
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
-    *bytes = use_split_dw(in, out, G, K, mode) ? kan_split_dw_ws_bytes(N, in, out, G + K)
+    *bytes = use_split_dw(in, out, G, K, mode) ? kan_split_dw_ws_bytes(N, in, out, G + K, K)
                                                                    : kan_f32_dw_ws_bytes(N, in, out, G + K);
     return KAGNN_OK;
 }

@@ -15,7 +15,7 @@ namespace kagnn {
 bool kan_split_fwd_ok(int in, int out, int G, int K);
 size_t kan_split_pack_fwd_bytes(int in, int out, int C);
 size_t kan_split_pack_dx_bytes(int in, int out, int C, int K);
-size_t kan_split_dw_ws_bytes(long N, int in, int out, int C);
+size_t kan_split_dw_ws_bytes(long N, int in, int out, int C, int K);
 int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, int, void*, hipStream_t);
 int kan_split_fwd_any(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, void*, size_t, hipStream_t);
@@ -494,7 +494,7 @@ static FkBwdPlan fk_plan(long N, int in, int out, int ng, int mode) {
         p.pack_f = 0;
         p.pack_d = al256(kan_split_pack_dx_bytes(in, out, ng, 0));
         p.gcat = 0;                                   // gcat + slabs live inside the split kernel's own workspace
-        p.slab = al256(kan_split_dw_ws_bytes(N, in, out, ng));
+        p.slab = al256(kan_split_dw_ws_bytes(N, in, out, ng, 0));
         p.nb = 0; p.rpw = 0; p.NS = 0; p.per = 0;
     } else {
         p.pack_f = al256(kan_f32_pack_fwd_bytes(in, out, ng));

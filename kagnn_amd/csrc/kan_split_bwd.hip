@@ -711,8 +711,26 @@ static DwPlan split_dw_plan(long N, int in, int out, int C) {
     return p;
 }
 
-size_t kan_split_dw_ws_bytes(long N, int in, int out, int C) {
-    const DwPlan p = split_dw_plan(N, in, out, C);
+// cubic layers with 9..12 coefficients: kan_split_dw_w2_kernel (one lane per input feature, both slot windows)
+bool kan_dw_w2_ok(int in, int out, int C, int K) { return K == 3 && C > 8 && C <= 12; }
+
+static DwPlan split_dw_plan_w2(long N, int in, int out, int C) {
+    DwPlan p;
+    p.FG = cdiv(in, 64); p.OC = cdiv(out, 64);
+    const int roles = p.FG * p.OC;
+    int nb = max(1, 256 / roles);
+    long r = (N + nb - 1) / nb;
+    r = max(32L, (r + 31) & ~31L);
+    r = min(r, kDwMaxRowsPerBlock);
+    nb = (int)max(1L, (long)cdiv(N, r));
+    p.nbx = nb; p.rpw = r; p.NS = nb;
+    p.inP = 32L * cdiv(in, 32); p.outP = 32L * cdiv(out, 32);
+    p.per = (long)(C + 1) * p.inP * p.outP;
+    return p;
+}
+
+size_t kan_split_dw_ws_bytes(long N, int in, int out, int C, int K) {
+    const DwPlan p = kan_dw_w2_ok(in, out, C, K) ? split_dw_plan_w2(N, in, out, C) : split_dw_plan(N, in, out, C);
     return (size_t)(p.NS + 1) * p.per * sizeof(float);
 }
 
@@ -927,6 +945,217 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient for cubic layers with 9..12 coefficients (grid 6..9; BASELINE config 3 is grid 8 => C = 11).
+// kan_split_dw_kernel runs them as 2*in virtual features: every scalar's span / cubic pieces / hi-lo split / SiLU is
+// evaluated twice (once per 8-slot window, on separate lanes) and 2 x 9 slot planes go through the matrix cores.  Here a
+// lane owns ONE input feature: the 4-value payload of a row is computed once and dropped into window 0 (8 slots) AND
+// into the low half of window 1 (its <= 4 live slots: two dwords per part); accumulators: 8 + NS1 spline planes + base
+// = 224 registers for NS1 = 4.  Slabs are written in the plain [C+1][in][out] plane order, so the fused reduce / unpack
+// kernel of the <= 8-coefficient path finishes the job.  Per 32 rows x 16 input features x 64 outputs:
+// (8 + C - 8 + 1) * 12 MFMAs and ~850 VALU instead of 216 and ~1550.
+template <int NS1>
+__global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
+    int out, int C, const float* __restrict__ knots_g, int nknots, int OC, long rows_per_block,
+    long inP, long outP, float* __restrict__ slab) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsHdr];
+    float* s_knots = reinterpret_cast<float*>(smem);
+    unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < nknots) s_knots[tid] = knots_g[tid];
+    build_perm_table(s_tbl, tid);
+    __syncthreads();
+    const FastGeom fgeo = fast_geom(s_knots, nknots);
+    const int fg = blockIdx.y / OC, oc = blockIdx.y % OC;
+    const int li = lane & 15, kg = lane >> 4;
+    const int f = 64 * fg + 16 * wave + li;
+    const int ns1 = C - 8;                                       // live slots of the second window (<= NS1)
+    const long s = blockIdx.x;
+    const long rbeg = s * rows_per_block, rend = min(N, rbeg + rows_per_block);
+
+    f32x4 D[kCTmax - 1][4];        // window 0: slots 0..7, scaled by 2^(20 - T)
+    f32x4 D1[NS1][4];              // window 1: slots 8..8+NS1-1
+    f32x4 Dh[4], Df[4];            // base weight: fp16 path (2^(14 - T)) / exact fp32 path
+#pragma unroll
+    for (int c = 0; c < kCTmax - 1; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) D[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NS1; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) D1[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { Dh[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Df[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const GBuf xb = gbuf_at(x, rend, ldx, in, rbeg), gyb = gbuf_at(gy, rend, ldgy, out, rbeg);
+    const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u;
+    unsigned xo = (unsigned)(8 * kg) * ldx4 + (unsigned)min(f, in - 1) * 4u, gvo[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gvo[t] = (unsigned)(8 * kg) * ldgy4 + (unsigned)min(64 * oc + 16 * t + li, out - 1) * 4u;
+    struct Raw { float x[8]; float g[4][8]; };
+    auto load_raw = [&](Raw& r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            r.x[j] = gld_s(xb, xo, (unsigned)j * ldx4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r.g[t][j] = gld_s(gyb, gvo[t], (unsigned)j * ldgy4);
+        }
+        xo += 32u * ldx4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gvo[t] += 32u * ldgy4;
+    };
+
+    u32x4 rh[8], rl[8];            // per row: window 0, 8 slots (hi / lo)
+    unsigned r1h[8][2], r1l[8][2]; // per row: window 1, slots 0..3
+    u32x4 bhi[4], blo[4];
+    u32x4 sah, sal;
+    int T;
+    bool base32 = false;
+
+    auto chunk_exp = [&](const Raw& r) -> int {
+        float mx = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(r.g[t][j]));
+        return exp_for_max(wave_max_nonneg(mx));
+    };
+    auto expand = [&](const Raw& r, int Tfix) {
+        const float gs = ldexpf(1.0f, 10 - Tfix);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = r.g[t][j] * gs;
+            split_f16x2(v, bhi[t], blo[t]);
+        }
+        // ---- one evaluation of the cubic pieces per row, two placements
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int m; float u; bool inside;
+            fast_span(r.x[j], fgeo, m, u, inside);
+            float Nv[4];
+            cubic_bases(u, inside ? (kAScale / 6.0f) : 0.0f, Nv);
+            const unsigned h0 = pk_f16_rtz(Nv[0], Nv[1]), h1 = pk_f16_rtz(Nv[2], Nv[3]);
+            const unsigned l0 = pk_f16_rtz(sub_f16lo(Nv[0], h0), sub_f16hi(Nv[1], h0));
+            const unsigned l1 = pk_f16_rtz(sub_f16lo(Nv[2], h1), sub_f16hi(Nv[3], h1));
+            const unsigned char* te = reinterpret_cast<const unsigned char*>(s_tbl) + 16 * (m + 1);
+            const u32x4 sel0 = *reinterpret_cast<const u32x4*>(te);
+            frag3_place_fwd(sel0, h0, h1, l0, l1, rh[j], rl[j]);
+            const uint2 sel1 = *reinterpret_cast<const uint2*>(te + kWinBytes);          // window 1: slots 0..3 only
+            r1h[j][0] = __builtin_amdgcn_perm(h1, h0, sel1.x); r1h[j][1] = __builtin_amdgcn_perm(h1, h0, sel1.y);
+            r1l[j][0] = __builtin_amdgcn_perm(l1, l0, sel1.x); r1l[j][1] = __builtin_amdgcn_perm(l1, l0, sel1.y);
+        }
+        float sv[8];
+        float smx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sv[j] = siluf(r.x[j]) * 16.0f; smx = fmaxf(smx, fabsf(sv[j])); }
+        base32 = __any(!(smx < 60000.0f));
+        split_f16x2(sv, sah, sal);
+        if (base32) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    Df[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[j] * 0.0625f, r.g[t][j], Df[t], 0, 0, 0);
+        }
+    };
+
+    Raw raw;
+    load_raw(raw);
+    T = chunk_exp(raw);
+    expand(raw, T);
+    long n0 = rbeg;
+    while (n0 < rend) {
+        bool grow = false;
+        for (; n0 < rend; n0 += 32) {
+            load_raw(raw);
+#pragma unroll
+            for (int c = 0; c < kCTmax - 1; ++c) {
+                const int q = c >> 1;
+                const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
+                u32x4 ah, al;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    ah[p] = __builtin_amdgcn_perm(rh[2 * p + 1][q], rh[2 * p][q], sel);
+                    al[p] = __builtin_amdgcn_perm(rl[2 * p + 1][q], rl[2 * p][q], sel);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(ah, bhi[t], D[c][t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(ah, blo[t], D[c][t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(al, bhi[t], D[c][t]);
+            }
+#pragma unroll
+            for (int c = 0; c < NS1; ++c) {
+                if (c < ns1) {                                   // wave-uniform
+                    const int q = c >> 1;
+                    const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
+                    u32x4 ah, al;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        ah[p] = __builtin_amdgcn_perm(r1h[2 * p + 1][q], r1h[2 * p][q], sel);
+                        al[p] = __builtin_amdgcn_perm(r1l[2 * p + 1][q], r1l[2 * p][q], sel);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) D1[c][t] = mfma16_f16(ah, bhi[t], D1[c][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) D1[c][t] = mfma16_f16(ah, blo[t], D1[c][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) D1[c][t] = mfma16_f16(al, bhi[t], D1[c][t]);
+                }
+            }
+            if (!base32) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sah, bhi[t], Dh[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sah, blo[t], Dh[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sal, bhi[t], Dh[t]);
+            }
+            if (n0 + 32 >= rend) { n0 += 32; break; }
+            if (chunk_exp(raw) > T) { grow = true; n0 += 32; break; }
+            expand(raw, T);
+        }
+        if (grow) {
+            const int ex = chunk_exp(raw);
+            const float dn = ldexpf(1.0f, T - ex);
+#pragma unroll
+            for (int c = 0; c < kCTmax - 1; ++c)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) D[c][t] *= dn;
+#pragma unroll
+            for (int c = 0; c < NS1; ++c)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) D1[c][t] *= dn;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Dh[t] *= dn;
+            T = ex;
+            expand(raw, T);
+        }
+    }
+    const float undo = ldexpf(1.0f, T - 20), undo_b = ldexpf(1.0f, T - 14);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const long o = 64 * oc + 16 * t + li;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const long fl = 64 * fg + 16 * wave + 4 * kg + reg;
+            if (fl < inP && o < outP) {
+#pragma unroll
+                for (int c = 0; c < kCTmax - 1; ++c)
+                    slab[((s * (C + 1) + c) * inP + fl) * outP + o] = D[c][t][reg] * undo;
+#pragma unroll
+                for (int c = 0; c < NS1; ++c)
+                    if (c < ns1) slab[((s * (C + 1) + 8 + c) * inP + fl) * outP + o] = D1[c][t][reg] * undo;
+                slab[((s * (C + 1) + C) * inP + fl) * outP + o] = fmaf(Dh[t][reg], undo_b, Df[t][reg]);
+            }
+        }
+    }
+}
+
 // slab reduction and unpack in one launch (the non-virtual layout): thread (o, plane c) of workgroup (o-tile, f)
 // sums slab[.][c][f][o] in a fixed order, writes g_spline_weight (chain rule through spline_scaler), and the
 // planes of one (f, o) meet in LDS for g_spline_scaler = sum_c gW * spline_weight (fixed order, deterministic)
@@ -1002,6 +1231,20 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
                      int out, int G, int K, const float* sw, const float* sc, float* g_bw, float* g_sw,
                      float* g_sc, float* ws, size_t ws_bytes, const RbfArgs& rb, hipStream_t st) {
     const int C = G + K, nk = K ? G + 2 * K + 1 : 0;
+    if (kan_dw_w2_ok(in, out, C, K) && rb.centers == nullptr) {
+        const DwPlan p = split_dw_plan_w2(N, in, out, C);
+        if (ws_bytes < (size_t)(p.NS + 1) * p.per * sizeof(float)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "kan_split_dw");
+        float* slab = ws + p.per;
+        kan_split_dw_w2_kernel<4><<<dim3(p.nbx, p.FG * p.OC), 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p.OC, p.rpw,
+                                                                          p.inP, p.outP, slab);
+        KAGNN_LAUNCH_CHECK();
+        const int SG = max(1, min(3, 1024 / (32 * (C + 1))));
+        kan_dw_reduce_unpack_kernel<<<dim3((unsigned)(p.outP / 32), (unsigned)in), 32 * (C + 1) * SG,
+                                      (size_t)SG * (C + 1) * 32 * sizeof(float), st>>>(
+            slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, SG);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
     const int sh = C > 8 ? 1 : 0, Ck = sh ? 8 : C;          // slots per (virtual) feature the kernel stores
     const DwPlan p = split_dw_plan(N, in, out, C);
     if (ws_bytes < (size_t)(p.NS + 1) * p.per * sizeof(float)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "kan_split_dw");
