@@ -187,8 +187,8 @@ def measure_traffic(args, kernel_prefix):
     argv = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-traffic", "--no-fp32",
             "--workload", args.workload, "--nodes", str(args.nodes), "--edges", str(args.edges), "--order", str(args.order),
             "--precision", args.precision, "--act", args.act]
-    fetch = _pmc_pass("FETCH_SIZE", argv, 240)
-    write = _pmc_pass("WRITE_SIZE", argv, 240)
+    fetch = _pmc_pass("FETCH_SIZE", argv, 150)
+    write = _pmc_pass("WRITE_SIZE", argv, 150)
     per_kernel = {}
     for k in fetch:
         if k in write:
@@ -242,8 +242,8 @@ def secondary_figures(dev, conv, graph, x, n, e, f, grid, order):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=os.environ.get("KAGNN_WORKLOAD", "headline"))
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--edges", type=int, default=10_000_000)
