@@ -138,25 +138,41 @@ __global__ __launch_bounds__(256) void agg16_hub_kernel(Agg16Args a, const int* 
     }
 }
 
-// the lane group of a row's FIRST segment: self term + its segments' partial sums in order, ONE rounding into out
+// the workgroup of a row's FIRST segment: its lane groups take the row's segments round-robin, the partial sums meet in
+// LDS in a fixed order; self term + sum, ONE rounding into out
 template <int LPR, bool OUT16>
 __global__ __launch_bounds__(256) void agg16_hub_merge_kernel(Agg16Args a, const int* __restrict__ seg, long nseg,
                                                               const float* __restrict__ part, int ldp) {
-    const long sidx = (blockIdx.x * 256L + threadIdx.x) / LPR;
-    const int c8 = (threadIdx.x % LPR) * 8;
-    if (sidx >= nseg || c8 >= a.F) return;
+    __shared__ f8 s_part[256];
+    const long sidx = blockIdx.x;
     const int row = seg[3 * sidx];
-    if (sidx > 0 && seg[3 * (sidx - 1)] == row) return;
-    f8 acc = ld8_bf16(a.x + (long)row * a.ldx + c8);
-    const float sw = a.self_scale * (a.in_scale ? a.in_scale[row] : 1.0f);
+    if (sidx > 0 && seg[3 * (sidx - 1)] == row) return;          // workgroup-uniform
+    constexpr int G = 256 / LPR;
+    const int g = threadIdx.x / LPR, lg = threadIdx.x % LPR, c8 = lg * 8;
+    f8 acc;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc.v[i] *= sw;
-    for (long k = sidx; k < nseg && seg[3 * k] == row; ++k) {
-        const float* p = part + k * ldp + c8;
+    for (int i = 0; i < 8; ++i) acc.v[i] = 0.0f;
+    if (c8 < a.F) {
+        for (long k = sidx + g; k < nseg && seg[3 * k] == row; k += G) {
+            const float* p = part + k * ldp + c8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc.v[i] += p[i];
+            for (int i = 0; i < 8; ++i) acc.v[i] += p[i];
+        }
     }
-    finish_row<OUT16>(a, row, c8, acc);
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && c8 < a.F) {
+        for (int k = 1; k < G; ++k) {
+            const f8 p = s_part[k * LPR + lg];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc.v[i] += p.v[i];
+        }
+        f8 self = ld8_bf16(a.x + (long)row * a.ldx + c8);
+        const float sw = a.self_scale * (a.in_scale ? a.in_scale[row] : 1.0f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc.v[i] = fmaf(sw, self.v[i], acc.v[i]);
+        finish_row<OUT16>(a, row, c8, acc);
+    }
 }
 
 size_t aggregate_bf16_ws_bytes(long num_hub_seg, int F) { return (size_t)num_hub_seg * (size_t)((F + 7) & ~7) * sizeof(float); }
@@ -179,7 +195,7 @@ static int run16(const Agg16Args& a, const int* hub_seg, long num_hub_seg, float
         if (hubs) {                                                                                               \
             agg16_hub_kernel<LPR><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg, ws, ldp);                     \
             KAGNN_LAUNCH_CHECK();                                                                                 \
-            agg16_hub_merge_kernel<LPR, OUT16><<<cdiv(num_hub_seg * LPR, 256), 256, 0, st>>>(b, hub_seg, num_hub_seg, ws, ldp); \
+            agg16_hub_merge_kernel<LPR, OUT16><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg, num_hub_seg, ws, ldp); \
             KAGNN_LAUNCH_CHECK();                                                                                 \
         }                                                                                                         \
     }

@@ -21,7 +21,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 from ._lib import PREC_FP32, PREC_FP32_GRID, PREC_SPLIT
 
-HUB_THRESHOLD = 512
+HUB_THRESHOLD = int(os.environ.get("KAGNN_HUB_THRESHOLD", "96"))       # rows above this many edges are split into segments
 
 
 def default_precision() -> int:

@@ -147,12 +147,14 @@ def test_sharded_layer_world1_nccl():
         conv = kagnn_amd.GIKANLayer(f, f, grid_size=5, spline_order=3, hidden_dim=f, nb_layers=2)
         layers = [{k: v.detach().clone() for k, v in l.state_dict().items()} for l in conv.nn.layers]
         y_ref, gx_ref, _ = orc.kan_gin_layer_fwd_bwd(x, ei, layers, 3, gy)
-        s = ShardedGIKANLayer(conv, None).to(DEV)
-        xs = x.to(DEV).requires_grad_(True)
-        y = s(xs, ops.GraphIndex(ei.to(DEV), n))
-        y.backward(gy.to(DEV))
-        assert_close(y, y_ref, what="sharded y")
-        assert_close(xs.grad, gx_ref, what="sharded gx")
+        graph = ops.GraphIndex(ei.to(DEV), n)
+        for chunks in (1, 3):                  # 3: row-chunked collectives launched under the side stream, gathers ahead
+            s = ShardedGIKANLayer(conv, None, chunks=chunks).to(DEV)
+            xs = x.to(DEV).requires_grad_(True)
+            y = s(xs, graph)
+            y.backward(gy.to(DEV))
+            assert_close(y, y_ref, what=f"sharded y (chunks={chunks})")
+            assert_close(xs.grad, gx_ref, what=f"sharded gx (chunks={chunks})")
     finally:
         if created:
             dist.destroy_process_group()
