@@ -186,6 +186,22 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t num_rows, const fl
                          float* y, int64_t ldy, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* The same forward, which also leaves the COLUMN MOMENTS of y in col_mean[out] (mean over the rows) and
+ * col_m2[out] (sum of squared deviations from it): the batch statistics of the BatchNorm1d that follows every
+ * convolution (node_classification_clean/models.py:198-200), handed to kagnn_batchnorm_fwd so that it needs no
+ * statistics pass over y.  Cubic-spline split-precision layers accumulate them in the forward kernel's epilogue
+ * (per wave over its row tiles, merged in a fixed order by the pairwise update of Chan et al.: deterministic, no
+ * cancellation); every other layer shape runs the plain forward and one column pass.  num_rows >= 1; the workspace
+ * (kagnn_kan_fwd_moments_workspace_bytes) is required.                                                          */
+int kagnn_kan_fwd_moments_workspace_bytes(int64_t num_rows, int32_t in_features, int32_t out_features,
+                                          int32_t grid_size, int32_t spline_order, int32_t mode,
+                                          size_t* bytes_host);
+int kagnn_kan_linear_fwd_moments(const float* x, int64_t ldx, int64_t num_rows, const float* knots,
+                                 int32_t in_features, int32_t out_features, int32_t grid_size,
+                                 int32_t spline_order, int32_t mode, const void* pack_fwd,
+                                 float* y, int64_t ldy, float* col_mean, float* col_m2,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* gx[N,in] = d loss / d x given gy[N,out] (x is the saved layer input; bases' derivatives are
  * recomputed, nothing but x was saved).  gx_dtype = KAGNN_DTYPE_F32, or KAGNN_DTYPE_BF16 (split-precision
  * B-spline layers with <= 128 outputs: the rows the transposed aggregation gathers next, rounded once) with
@@ -225,6 +241,8 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
  *                      write d loss / d h0 as bf16 rows for the transposed aggregation (split precision, cubic, <= 8
  *                      coefficients; otherwise it stays fp32); g_base_weight / g_spline_weight / g_spline_scaler per layer
  *   (rowptr, col, hub_seg): by destination for _fwd, the transposed (by source) structure for _bwd
+ *   _fwd: col_mean / col_m2  [widths[L]] each or both NULL: the column moments of y for the BatchNorm1d that follows
+ *                      (kagnn_kan_linear_fwd_moments; hand them to kagnn_batchnorm_fwd)
  * Workspace sizes from kagnn_gin_kan_layer_workspace_bytes (hub-segment counts of the two directions).  Deterministic.
  * ------------------------------------------------------------------------------------------ */
 int kagnn_gin_kan_layer_workspace_bytes(int64_t num_nodes, int32_t num_layers, const int32_t* widths,
@@ -238,6 +256,7 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
                             const float* const* spline_weight, const float* const* spline_scaler,
                             const float* knots, int32_t grid_size, int32_t spline_order, int32_t mode,
                             float* const* acts, void* const* pack_fwd, void* const* pack_dx,
+                            float* col_mean, float* col_m2,
                             void* workspace, size_t workspace_bytes, void* stream);
 int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t num_nodes, const int32_t* rowptr_t,
                             const int32_t* col_t, const int32_t* hub_seg_t, int64_t num_hub_seg_t,
@@ -316,16 +335,28 @@ int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy
  *                  1/sqrt(running_var + eps).
  * weight / bias may be NULL (affine=False).  The backward writes gx (may be NULL), g_weight and
  * g_bias (either may be NULL) for the same `training` flag as the forward.  Deterministic.
+ *
+ * Fused epilogue (models.py:198-201: `x = dropout(bn(conv(x)))`):
+ *   col_mean / col_m2 (both or neither, training only): the column moments of x from the kernel that produced
+ *                  it (kagnn_kan_linear_fwd_moments, kagnn_gin_kan_layer_fwd) -- the statistics pass is skipped;
+ *   dropout_p > 0 (training only): y = dropout(bn(x), p) in the same pass; element (row, col) is kept with
+ *                  probability 1-p (resolution 2^-16) and scaled by 1/(1-p), decided by a counter-based hash of
+ *                  (dropout_seed, row, col / 4) -- a pure function of the seed, NOT torch's Philox stream.  The
+ *                  backward regenerates the decisions from the same (dropout_p, dropout_seed): `gy` is the
+ *                  gradient of the dropped-out y.  No mask tensor exists.
  * ------------------------------------------------------------------------------------------ */
 int kagnn_batchnorm_workspace_bytes(int64_t num_rows, int32_t num_features, size_t* bytes_host);
 int kagnn_batchnorm_fwd(const float* x, int64_t ldx, int64_t num_rows, int32_t num_features,
                         const float* weight, const float* bias, float* running_mean,
-                        float* running_var, float momentum, float eps, int32_t training, float* y,
+                        float* running_var, float momentum, float eps, int32_t training,
+                        const float* col_mean, const float* col_m2, float dropout_p,
+                        uint64_t dropout_seed, float* y,
                         int64_t ldy, float* save_mean, float* save_rstd, void* workspace,
                         size_t workspace_bytes, void* stream);
 int kagnn_batchnorm_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy,
                         int64_t num_rows, int32_t num_features, const float* weight,
-                        const float* save_mean, const float* save_rstd, int32_t training, float* gx,
+                        const float* save_mean, const float* save_rstd, int32_t training,
+                        float dropout_p, uint64_t dropout_seed, float* gx,
                         int64_t ldgx, float* g_weight, float* g_bias, void* workspace,
                         size_t workspace_bytes, void* stream);
 

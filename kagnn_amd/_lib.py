@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p, POINTER
+from ctypes import c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KAGNN_LIB: load another build of the same ABI (A/B timing of kernel variants inside one process launch)
@@ -48,6 +48,10 @@ _SIGNATURES = {
                                                 POINTER(c_size_t)]),
     "kagnn_kan_linear_fwd": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, c_int32,
                                        c_int32, _P, _P, c_int64, _P, c_size_t, _P]),
+    "kagnn_kan_fwd_moments_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                                        POINTER(c_size_t)]),
+    "kagnn_kan_linear_fwd_moments": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, c_int32,
+                                               c_int32, _P, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "kagnn_kan_linear_bwd_input": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, c_int32, c_int32,
                                              c_int32, c_int32, c_int32, _P, _P, c_int64, c_int32, _P]),
     "kagnn_kan_bwd_weight_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32,
@@ -58,7 +62,7 @@ _SIGNATURES = {
     "kagnn_gin_kan_layer_workspace_bytes": (c_int32, [c_int64, c_int32, _P, c_int32, c_int32, c_int32, c_int64, c_int64,
                                                       POINTER(c_size_t), POINTER(c_size_t)]),
     "kagnn_gin_kan_layer_fwd": (c_int32, [_P, c_int32, c_int64, c_int64, _P, _P, _P, c_int64, c_int32, c_float, c_int32, _P,
-                                          _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_size_t, _P]),
+                                          _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "kagnn_gin_kan_layer_bwd": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, c_int64, c_int32, c_float, c_int32, _P, _P, _P,
                                           _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P, _P, _P,
                                           _P, c_size_t, _P]),
@@ -85,9 +89,9 @@ _SIGNATURES = {
                                 _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int32, _P]),
     "kagnn_batchnorm_workspace_bytes": (c_int32, [c_int64, c_int32, POINTER(c_size_t)]),
     "kagnn_batchnorm_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_float, c_float, c_int32,
+                                      _P, _P, c_float, c_uint64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "kagnn_batchnorm_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, c_int32, c_float, c_uint64,
                                       _P, c_int64, _P, _P, _P, c_size_t, _P]),
-    "kagnn_batchnorm_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, c_int32, _P,
-                                      c_int64, _P, _P, _P, c_size_t, _P]),
 }
 
 EXPORTED = tuple(_SIGNATURES)

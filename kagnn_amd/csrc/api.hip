@@ -47,7 +47,10 @@ int kan_fused_pack_batch(int, const float* const*, const float* const*, const fl
 size_t kan_sparse_pack_fwd_bytes(int in, int out, int C);
 int kan_sparse_pack_fwd(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 size_t kan_sparse_fwd_ws_bytes(long N, int in, int out, int C);
-int kan_sparse_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t);
+int kan_sparse_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, float*, float*, hipStream_t);
+bool kan_sparse_fwd_moments_ok(long N, int in, int out, int G, int K);
+size_t kan_sparse_fwd_moments_ws_bytes(long N, int out);
+int col_moments(const float*, long, long, int, float*, float*, void*, size_t, hipStream_t);
 bool kan_split_dx_ok(int in, int out, int G, int K);
 bool kan_split_dw_ok(int in, int out, int G, int K);
 
@@ -67,8 +70,8 @@ int xent_bwd(const float*, long, long, int, const long*, const unsigned char*, i
 size_t gat_att_grad_ws_bytes(long N, int H, int C);
 int gat_att_grad(const float*, long, const float*, const float*, long, int, int, float*, float*, void*, size_t, hipStream_t);
 size_t bn_ws_bytes(long N, int F);
-int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, float*, long, float*, float*, void*, size_t, hipStream_t);
-int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float*, long, float*, float*, void*, size_t, hipStream_t);
+int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, const float*, const float*, float, unsigned long long, float*, long, float*, float*, void*, size_t, hipStream_t);
+int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float, unsigned long long, float*, long, float*, float*, void*, size_t, hipStream_t);
 }  // namespace kagnn
 
 using namespace kagnn;
@@ -92,7 +95,7 @@ static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode 
 #pragma GCC visibility push(default)
 extern "C" {
 
-int kagnn_version(void) { return 200; }
+int kagnn_version(void) { return 210; }
 const char* kagnn_last_error(void) { return g_err; }
 
 int kagnn_csr_workspace_bytes(int64_t E, int64_t N, size_t* bytes) {
@@ -258,10 +261,46 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* kn
     if (use_split_fwd(in, out, G, K, mode)) {
         if (!(fits32(N, ldx) && fits32(N, ldy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
         if (use_sparse_fwd(in, out, G, K, mode))
-            return kan_sparse_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
+            return kan_sparse_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, nullptr, nullptr, as_stream(stream));
         return kan_split_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
     }
     return kan_f32_fwd(x, ldx, N, knots, in, out, G, K, (const float*)pack_fwd, y, ldy, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
+}
+
+// forward + column moments of its output (the statistics of the BatchNorm1d that follows a convolution)
+static bool fused_moments(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode) {
+    return use_split_fwd(in, out, G, K, mode) && use_sparse_fwd(in, out, G, K, mode) && kan_sparse_fwd_moments_ok(N, in, out, G, K);
+}
+
+int kagnn_kan_fwd_moments_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
+                                          size_t* bytes) {
+    size_t b = 0;
+    int rc = kagnn_kan_fwd_workspace_bytes(N, in, out, G, K, mode, &b);
+    if (rc) return rc;
+    const size_t m = fused_moments(N, in, out, G, K, mode) ? kan_sparse_fwd_moments_ws_bytes(N, out) : bn_ws_bytes(N, out);
+    *bytes = b > m ? b : m;
+    return KAGNN_OK;
+}
+
+int kagnn_kan_linear_fwd_moments(const float* x, int64_t ldx, int64_t N, const float* knots, int32_t in,
+                                 int32_t out, int32_t G, int32_t K, int32_t mode, const void* pack_fwd,
+                                 float* y, int64_t ldy, float* col_mean, float* col_m2, void* ws, size_t ws_bytes,
+                                 void* stream) {
+    int rc = check_kan_dims(__func__, in, out, G, K, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 1 && ldx >= in && ldy >= out, "bad shape (column moments need at least one row)");
+    KAGNN_CHECK_ARG(x && knots && pack_fwd && y && col_mean && col_m2, "null array");
+    size_t need = 0;
+    rc = kagnn_kan_fwd_moments_workspace_bytes(N, in, out, G, K, mode, &need);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(need == 0 || (ws && ws_bytes >= need), "workspace too small (kagnn_kan_fwd_moments_workspace_bytes)");
+    if (fused_moments(N, in, out, G, K, mode)) {
+        if (!(fits32(N, ldx) && fits32(N, ldy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
+        return kan_sparse_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, col_mean, col_m2, as_stream(stream));
+    }
+    rc = kagnn_kan_linear_fwd(x, ldx, N, knots, in, out, G, K, mode, pack_fwd, y, ldy, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return col_moments(y, ldy, N, out, col_mean, col_m2, ws, ws_bytes, as_stream(stream));
 }
 
 int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N,
@@ -409,6 +448,7 @@ int kagnn_batchnorm_workspace_bytes(int64_t N, int32_t F, size_t* bytes) {
 
 int kagnn_batchnorm_fwd(const float* x, int64_t ldx, int64_t N, int32_t F, const float* weight, const float* bias,
                         float* running_mean, float* running_var, float momentum, float eps, int32_t training,
+                        const float* col_mean, const float* col_m2, float dropout_p, uint64_t dropout_seed,
                         float* y, int64_t ldy, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes,
                         void* stream) {
     KAGNN_CHECK_ARG(N >= 0 && F >= 1 && ldx >= F && ldy >= F, "bad shape");
@@ -416,19 +456,23 @@ int kagnn_batchnorm_fwd(const float* x, int64_t ldx, int64_t N, int32_t F, const
     KAGNN_CHECK_ARG(x && y && save_mean && save_rstd && ws, "null array");
     KAGNN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var must both be given or both be null");
     KAGNN_CHECK_ARG(training || running_mean, "eval mode needs the running statistics");
-    return bn_fwd(x, ldx, N, F, weight, bias, running_mean, running_var, momentum, eps, training, y, ldy, save_mean,
-                  save_rstd, ws, ws_bytes, as_stream(stream));
+    KAGNN_CHECK_ARG((col_mean == nullptr) == (col_m2 == nullptr), "col_mean and col_m2 must both be given or both be null");
+    KAGNN_CHECK_ARG(dropout_p >= 0.0f && dropout_p <= 1.0f, "dropout_p outside [0, 1]");
+    return bn_fwd(x, ldx, N, F, weight, bias, running_mean, running_var, momentum, eps, training, col_mean, col_m2, dropout_p,
+                  dropout_seed, y, ldy, save_mean, save_rstd, ws, ws_bytes, as_stream(stream));
 }
 
 int kagnn_batchnorm_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N, int32_t F,
                         const float* weight, const float* save_mean, const float* save_rstd, int32_t training,
+                        float dropout_p, uint64_t dropout_seed,
                         float* gx, int64_t ldgx, float* g_weight, float* g_bias, void* ws, size_t ws_bytes,
                         void* stream) {
     KAGNN_CHECK_ARG(N >= 0 && F >= 1 && ldx >= F && ldgy >= F && (gx == nullptr || ldgx >= F), "bad shape");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && gy && save_mean && save_rstd && ws, "null array");
-    return bn_bwd(x, ldx, gy, ldgy, N, F, weight, save_mean, save_rstd, training, gx, ldgx, g_weight, g_bias, ws,
-                  ws_bytes, as_stream(stream));
+    KAGNN_CHECK_ARG(dropout_p >= 0.0f && dropout_p <= 1.0f, "dropout_p outside [0, 1]");
+    return bn_bwd(x, ldx, gy, ldgy, N, F, weight, save_mean, save_rstd, training, dropout_p, dropout_seed, gx, ldgx, g_weight,
+                  g_bias, ws, ws_bytes, as_stream(stream));
 }
 
 // ---------------------------------------------------------------- GAT attention aggregation
@@ -519,7 +563,8 @@ int kagnn_gin_kan_layer_workspace_bytes(int64_t N, int32_t L, const int32_t* wid
         int rc = check_kan_dims(__func__, widths[l], widths[l + 1], G, K, mode);
         if (rc) return rc;
         size_t b = 0;
-        rc = kagnn_kan_fwd_workspace_bytes(N, widths[l], widths[l + 1], G, K, mode, &b); if (rc) return rc;
+        rc = (l == L - 1 ? kagnn_kan_fwd_moments_workspace_bytes : kagnn_kan_fwd_workspace_bytes)(N, widths[l], widths[l + 1], G, K, mode, &b);
+        if (rc) return rc;
         fw = b > fw ? b : fw;
         rc = kagnn_kan_bwd_weight_workspace_bytes(N, widths[l], widths[l + 1], G, K, mode, &b); if (rc) return rc;
         dw = b > dw ? b : dw;
@@ -536,9 +581,10 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
                             const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, float self_scale,
                             int32_t L, const int32_t* widths, const float* const* bw, const float* const* sw,
                             const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
-                            float* const* acts, void* const* pack_fwd, void* const* pack_dx, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+                            float* const* acts, void* const* pack_fwd, void* const* pack_dx, float* col_mean,
+                            float* col_m2, void* workspace, size_t workspace_bytes, void* stream) {
     KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && bw && sw && acts && pack_fwd && pack_dx, "bad argument");
+    KAGNN_CHECK_ARG((col_mean == nullptr) == (col_m2 == nullptr), "col_mean and col_m2 must both be given or both be null");
     size_t need_f = 0, need_b = 0;
     int rc = kagnn_gin_kan_layer_workspace_bytes(N, L, widths, G, K, mode, num_hub_seg, 0, &need_f, &need_b);
     if (rc) return rc;
@@ -573,8 +619,12 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
     }
     // 3. the chain
     for (int l = 0; l < L; ++l) {
-        rc = kagnn_kan_linear_fwd(acts[l], in_[l], N, knots, in_[l], out_[l], G, K, mode, pack_fwd[l], acts[l + 1], out_[l],
-                                  ws + hub_b, need_f - hub_b, stream);
+        if (l == L - 1 && col_mean)          // the convolution's output: its column moments for the norm that follows
+            rc = kagnn_kan_linear_fwd_moments(acts[l], in_[l], N, knots, in_[l], out_[l], G, K, mode, pack_fwd[l], acts[l + 1],
+                                              out_[l], col_mean, col_m2, ws + hub_b, need_f - hub_b, stream);
+        else
+            rc = kagnn_kan_linear_fwd(acts[l], in_[l], N, knots, in_[l], out_[l], G, K, mode, pack_fwd[l], acts[l + 1], out_[l],
+                                      ws + hub_b, need_f - hub_b, stream);
         if (rc) return rc;
     }
     return KAGNN_OK;

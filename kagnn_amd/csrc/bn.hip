@@ -4,6 +4,13 @@
 // running = (1-momentum)*running + momentum*batch).  HBM-bound: the forward reads x twice and writes y,
 // the backward reads (x, gy) twice and writes gx; column sums go through per-workgroup partials that are
 // combined in a fixed order (deterministic, no atomics).
+//
+// Fused forms ("BatchNorm1d + dropout ... fused into the conv output"):
+//   * the forward statistics can arrive as column moments (mean, sum of squared deviations) that the producing
+//     KANLinear forward accumulated in its epilogue (kan_sparse_fwd.hip, MOM) -- the statistics pass over x is skipped;
+//   * dropout (reference models.py:201, F.dropout after the norm) is applied by the normalising kernel itself and
+//     regenerated from (seed, row, column) in the backward: no mask tensor, no extra pass.  Counter-based hash, so the
+//     mask is a pure function of the seed; it is NOT torch's Philox stream (same distribution, different bits).
 #include "common.h"
 
 namespace kagnn {
@@ -27,6 +34,29 @@ __device__ __forceinline__ void st4c(float* row, int c, int F, bool vec, const f
     }
 }
 
+// keep-and-scale factors of elements (n, c..c+3): two 32-bit hashes -> four 16-bit uniforms, keep when u < thr
+struct DropArgs { unsigned lo, hi, thr; float scale; };          // thr = round((1-p) * 65536); thr >= 65536: no dropout
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ void keep4(const DropArgs& d, long n, int c, float (&k)[4]) {
+    const unsigned a = mix32(mix32((unsigned)n ^ d.lo) + (unsigned)(n >> 32) + (unsigned)(c >> 2) * 0x9e3779b9U + d.hi);
+    const unsigned b = mix32(a ^ 0x85ebca6bU);
+    k[0] = (a & 0xffffU) < d.thr ? d.scale : 0.0f;
+    k[1] = (a >> 16) < d.thr ? d.scale : 0.0f;
+    k[2] = (b & 0xffffU) < d.thr ? d.scale : 0.0f;
+    k[3] = (b >> 16) < d.thr ? d.scale : 0.0f;
+}
+static DropArgs drop_args(float p, unsigned long long seed) {
+    DropArgs d;
+    d.lo = (unsigned)seed; d.hi = (unsigned)(seed >> 32);
+    const float keep = 1.0f - p;
+    d.thr = p > 0.0f ? (unsigned)lrintf(fminf(fmaxf(keep, 0.0f), 1.0f) * 65536.0f) : 65536u;
+    d.scale = (p > 0.0f && keep > 0.0f) ? 1.0f / keep : (p > 0.0f ? 0.0f : 1.0f);
+    return d;
+}
+
 // partial[b][0][f] = sum_n a(n,f), partial[b][1][f] = sum_n b(n,f) over the rows of workgroup b, where
 //   MODE 0 (forward statistics):  a = x - shift_f,  b = (x - shift_f)^2      (shift_f = x[0][f]: no cancellation)
 //   MODE 1 (backward sums):       a = gy,           b = gy * (x - mean_f) * rstd_f
@@ -35,7 +65,7 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict_
                                                         const float* __restrict__ gy, long ldgy, long N, int F,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, int cl, int rs,
-                                                        long rows_per_block, float* __restrict__ partial) {
+                                                        long rows_per_block, float* __restrict__ partial, DropArgs dr) {
     extern __shared__ float s_red[];                    // [rs][2][4*cl]
     const int cg = threadIdx.x % cl, slot = threadIdx.x / cl;
     const bool vec = ((F & 3) == 0) && ((ldx & 3) == 0) && (MODE == 0 || (ldgy & 3) == 0) &&
@@ -60,6 +90,12 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict_
                 } else {
                     float gv[4];
                     ld4c(gy + n * ldgy, c, F, vec, gv);
+                    if (dr.thr < 65536u) {                  // the gradient of the dropped-out output
+                        float k[4];
+                        keep4(dr, n, c, k);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) gv[i] *= k[i];
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { a[i] += gv[i]; b[i] = fmaf(gv[i], (xv[i] - m[i]) * q[i], b[i]); }
                 }
@@ -86,6 +122,7 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict_
 // combine the partials (fixed order) and finish the statistics:  32 row groups per 32 columns
 //   MODE 0: mean, rstd (biased variance) -> save_mean / save_rstd, running stats update
 //   MODE 1: g_bias = sum gy, g_weight = sum gy*xhat; also left in sums[0][f], sums[1][f] for the gx pass
+//   MODE 2: column moments only: mean, sum of squared deviations (col_moments below)
 template <int MODE>
 __global__ __launch_bounds__(1024) void bn_finish_kernel(const float* __restrict__ partial, long B, int F, long N,
                                                         const float* __restrict__ x_row0, float eps, float momentum,
@@ -104,7 +141,11 @@ __global__ __launch_bounds__(1024) void bn_finish_kernel(const float* __restrict
         float ta = 0.f, tb = 0.f;
 #pragma unroll
         for (int g = 0; g < 32; ++g) { ta += s_p[g][0][c]; tb += s_p[g][1][c]; }
-        if (MODE == 0) {
+        if (MODE == 2) {
+            const float d = ta / (float)N;
+            out_a[f] = x_row0[f] + d;
+            out_b[f] = fmaxf(tb - ta * d, 0.0f);
+        } else if (MODE == 0) {
             const float inv_n = 1.0f / (float)N;
             const float d = ta * inv_n;                                  // mean - shift
             const float mean = x_row0[f] + d;
@@ -127,7 +168,7 @@ __global__ __launch_bounds__(1024) void bn_finish_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long ldx, long N, int F,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float* __restrict__ y, long ldy, int cl, int rs) {
+                                                       float* __restrict__ y, long ldy, int cl, int rs, DropArgs dr) {
     const int cg = threadIdx.x % cl, slot = threadIdx.x / cl;
     if (slot >= rs) return;
     const bool vec = ((F & 3) == 0) && ((ldx & 3) == 0) && ((ldy & 3) == 0) &&
@@ -145,6 +186,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             ld4c(x + n * ldx, c, F, vec, v);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+            if (dr.thr < 65536u) {
+                float k[4];
+                keep4(dr, n, c, k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= k[i];
+            }
             st4c(y + n * ldy, c, F, vec, v);
         }
     }
@@ -157,7 +204,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sum_gy,
                                                            const float* __restrict__ sum_gyx, int training,
-                                                           float* __restrict__ gx, long ldgx, int cl, int rs) {
+                                                           float* __restrict__ gx, long ldgx, int cl, int rs,
+                                                           DropArgs dr) {
     const int cg = threadIdx.x % cl, slot = threadIdx.x / cl;
     if (slot >= rs) return;
     const bool vec = ((F & 3) == 0) && ((ldx & 3) == 0) && ((ldgy & 3) == 0) && ((ldgx & 3) == 0) &&
@@ -178,6 +226,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             float xv[4], gv[4], o[4];
             ld4c(x + n * ldx, c, F, vec, xv);
             ld4c(gy + n * ldgy, c, F, vec, gv);
+            if (dr.thr < 65536u) {
+                float kp[4];
+                keep4(dr, n, c, kp);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gv[i] *= kp[i];
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = k[i] * (gv[i] - a[i] - (xv[i] - m[i]) * q[i] * b[i]);
             st4c(gx + n * ldgx, c, F, vec, o);
@@ -189,6 +243,58 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 __global__ void bn_rstd_kernel(const float* __restrict__ var, int F, float eps, float* __restrict__ rstd) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < F) rstd[f] = rsqrtf(var[f] + eps);
+}
+
+// training statistics from column moments (mean, M2 = sum of squared deviations) a producer kernel left behind
+__global__ void bn_from_moments_kernel(const float* __restrict__ col_mean, const float* __restrict__ col_m2, long N, int F,
+                                       float eps, float momentum, float* __restrict__ save_mean,
+                                       float* __restrict__ save_rstd, float* __restrict__ running_mean,
+                                       float* __restrict__ running_var) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float mean = col_mean[f], var = fmaxf(col_m2[f] / (float)N, 0.0f);
+    save_mean[f] = mean;
+    save_rstd[f] = rsqrtf(var + eps);
+    if (running_mean) {
+        const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+        running_mean[f] = fmaf(momentum, mean - running_mean[f], running_mean[f]);
+        running_var[f] = fmaf(momentum, unb - running_var[f], running_var[f]);
+    }
+}
+
+// (count, mean, M2) of two disjoint row sets -> of their union (Chan et al.); b is folded into a
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+    if (nb <= 0.0f) return;
+    const float n = na + nb, d = mb - ma, w = nb / n;
+    ma = fmaf(d, w, ma);
+    qa += qb + d * d * na * w;
+    na = n;
+}
+
+// partial[p][{mean, M2, count}][F] of P producer workgroups, merged in a fixed order: 32 row groups x 32 columns
+__global__ __launch_bounds__(1024) void moments_finish_kernel(const float* __restrict__ partial, int P, int F,
+                                                             float* __restrict__ col_mean, float* __restrict__ col_m2) {
+    __shared__ float s_p[32][3][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int f = blockIdx.x * 32 + c;
+    float n = 0.0f, m = 0.0f, q = 0.0f;
+    if (f < F)
+        for (int w = rg; w < P; w += 32)
+            chan_merge(n, m, q, partial[((long)w * 3 + 2) * F + f], partial[((long)w * 3 + 0) * F + f], partial[((long)w * 3 + 1) * F + f]);
+    s_p[rg][0][c] = m; s_p[rg][1][c] = q; s_p[rg][2][c] = n;
+    __syncthreads();
+    if (rg == 0 && f < F) {
+        n = 0.0f; m = 0.0f; q = 0.0f;
+        for (int g = 0; g < 32; ++g) chan_merge(n, m, q, s_p[g][2][c], s_p[g][0][c], s_p[g][1][c]);
+        col_mean[f] = m;
+        col_m2[f] = q;
+    }
+}
+
+int moments_finish(const float* partial, int P, int F, float* col_mean, float* col_m2, hipStream_t st) {
+    moments_finish_kernel<<<cdiv(F, 32), 1024, 0, st>>>(partial, P, F, col_mean, col_m2);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
 }
 
 // ------------------------------------------------------------------ host side
@@ -206,16 +312,37 @@ static BnPlan bn_plan(long N, int F) {
 
 size_t bn_ws_bytes(long N, int F) { return bn_plan(N, F).partial_bytes + 2 * (size_t)F * sizeof(float); }
 
+// column moments of a row block by the statistics pass of the norm (producers without a fused epilogue)
+int col_moments(const float* x, long ldx, long N, int F, float* col_mean, float* col_m2, void* ws, size_t ws_bytes,
+                hipStream_t st) {
+    if (ws_bytes < bn_ws_bytes(N, F)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "col_moments");
+    const BnShape s = bn_shape(F);
+    const BnPlan p = bn_plan(N, F);
+    float* partial = static_cast<float*>(ws);
+    const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
+    bn_colsum_kernel<0><<<p.blocks, 256, lds, st>>>(x, ldx, nullptr, 0, N, F, nullptr, nullptr, s.cl, s.rs, p.rpb, partial, DropArgs{0, 0, 65536u, 1.0f});
+    KAGNN_LAUNCH_CHECK();
+    bn_finish_kernel<2><<<cdiv(F, 32), 1024, 0, st>>>(partial, p.blocks, F, N, x, 0.f, 0.f, col_mean, col_m2, nullptr, nullptr);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 int bn_fwd(const float* x, long ldx, long N, int F, const float* gamma, const float* beta, float* running_mean,
-           float* running_var, float momentum, float eps, int training, float* y, long ldy, float* save_mean,
+           float* running_var, float momentum, float eps, int training, const float* col_mean, const float* col_m2,
+           float dropout_p, unsigned long long dropout_seed, float* y, long ldy, float* save_mean,
            float* save_rstd, void* ws, size_t ws_bytes, hipStream_t st) {
     if (ws_bytes < bn_ws_bytes(N, F)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "bn_fwd");
     const BnShape s = bn_shape(F);
     const BnPlan p = bn_plan(N, F);
-    if (training) {
+    const DropArgs dr = drop_args(training ? dropout_p : 0.0f, dropout_seed);
+    if (training && col_mean) {
+        bn_from_moments_kernel<<<cdiv(F, 256), 256, 0, st>>>(col_mean, col_m2, N, F, eps, momentum, save_mean, save_rstd,
+                                                            running_mean, running_var);
+        KAGNN_LAUNCH_CHECK();
+    } else if (training) {
         float* partial = static_cast<float*>(ws);
         const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
-        bn_colsum_kernel<0><<<p.blocks, 256, lds, st>>>(x, ldx, nullptr, 0, N, F, nullptr, nullptr, s.cl, s.rs, p.rpb, partial);
+        bn_colsum_kernel<0><<<p.blocks, 256, lds, st>>>(x, ldx, nullptr, 0, N, F, nullptr, nullptr, s.cl, s.rs, p.rpb, partial, dr);
         KAGNN_LAUNCH_CHECK();
         bn_finish_kernel<0><<<cdiv(F, 32), 1024, 0, st>>>(partial, p.blocks, F, N, x, eps, momentum, save_mean, save_rstd,
                                                          running_mean, running_var);
@@ -226,29 +353,31 @@ int bn_fwd(const float* x, long ldx, long N, int F, const float* gamma, const fl
         KAGNN_LAUNCH_CHECK();
     }
     const int grid = (int)min(4096L, max(1L, (long)cdiv(N, s.rs)));
-    bn_apply_kernel<<<grid, 256, 0, st>>>(x, ldx, N, F, save_mean, save_rstd, gamma, beta, y, ldy, s.cl, s.rs);
+    bn_apply_kernel<<<grid, 256, 0, st>>>(x, ldx, N, F, save_mean, save_rstd, gamma, beta, y, ldy, s.cl, s.rs, dr);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
 
 int bn_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, int F, const float* gamma,
-           const float* save_mean, const float* save_rstd, int training, float* gx, long ldgx, float* g_gamma,
+           const float* save_mean, const float* save_rstd, int training, float dropout_p,
+           unsigned long long dropout_seed, float* gx, long ldgx, float* g_gamma,
            float* g_beta, void* ws, size_t ws_bytes, hipStream_t st) {
     if (ws_bytes < bn_ws_bytes(N, F)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "bn_bwd");
     const BnShape s = bn_shape(F);
     const BnPlan p = bn_plan(N, F);
+    const DropArgs dr = drop_args(training ? dropout_p : 0.0f, dropout_seed);
     float* partial = static_cast<float*>(ws);
     float* sums = reinterpret_cast<float*>(static_cast<char*>(ws) + p.partial_bytes);     // [2][F] when the caller wants no g_gamma / g_beta
     float* sg = g_beta ? g_beta : sums;
     float* sgx = g_gamma ? g_gamma : sums + F;
     const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
-    bn_colsum_kernel<1><<<p.blocks, 256, lds, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, s.cl, s.rs, p.rpb, partial);
+    bn_colsum_kernel<1><<<p.blocks, 256, lds, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, s.cl, s.rs, p.rpb, partial, dr);
     KAGNN_LAUNCH_CHECK();
     bn_finish_kernel<1><<<cdiv(F, 32), 1024, 0, st>>>(partial, p.blocks, F, N, nullptr, 0.f, 0.f, sg, sgx, nullptr, nullptr);
     KAGNN_LAUNCH_CHECK();
     if (gx) {
         const int grid = (int)min(4096L, max(1L, (long)cdiv(N, s.rs)));
-        bn_bwd_apply_kernel<<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, gamma, sg, sgx, training, gx, ldgx, s.cl, s.rs);
+        bn_bwd_apply_kernel<<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, gamma, sg, sgx, training, gx, ldgx, s.cl, s.rs, dr);
         KAGNN_LAUNCH_CHECK();
     }
     return KAGNN_OK;

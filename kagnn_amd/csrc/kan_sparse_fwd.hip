@@ -165,11 +165,15 @@ __device__ __forceinline__ f32x16 smfmac(const u32x4& a, const u32x4& b0, const 
 
 // 512 threads = 8 waves (2 per SIMD), one wave = 32 rows; persistent workgroups, packed W resident in LDS when the
 // layer has one chunk (in <= 64), split-K over blockIdx.y for few-row inputs (see kan_split.hip).
-template <int OT, bool SH>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
+// MOM: the epilogue also accumulates the COLUMN MOMENTS of y (count, mean, sum of squared deviations; per wave over its
+// row tiles, merged pairwise in a fixed order -- Chan et al., no cancellation) and leaves one (mean, M2, count) row per
+// workgroup in mom_partial[gridDim.x][3][out]: the BatchNorm1d that follows the convolution (reference
+// models.py:198-200) then needs no statistics pass over y (bn.hip: moments_finish, bn_from_moments_kernel).
+template <int OT, bool SH, bool MOM>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
 __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g, int nknots,
     const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy, int out,
-    int chunks_per_split, long part_stride) {
+    int chunks_per_split, long part_stride, float* __restrict__ mom_partial) {
     constexpr int NT = 512, CF = kSpCF, HF = CF / 2, BPC = CF / 16, NG = HF / 8, ROWS = (NT / 64) * 32;
     constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 2 * 1024;
     constexpr int SPL_BYTES = kSpSteps * OT * 2 * 2048;
@@ -224,6 +228,9 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         lo0 = __builtin_amdgcn_perm(l1, l0, e[0]); lo1 = __builtin_amdgcn_perm(l1, l0, e[1]);
     };
 
+    float mom_n = 0.0f, mom_m[OT], mom_q[OT];          // this wave's rows so far: count, column mean, column M2
+#pragma unroll
+    for (int t = 0; t < OT; ++t) { mom_m[t] = 0.0f; mom_q[t] = 0.0f; }
     float xn[8];
     load8((long)blockIdx.x * ROWS, ch_begin, 0, xn);
     for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
@@ -343,15 +350,70 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
             }
         }
         const GBuf yb = gbuf_at(y, N, ldy, out, tile * ROWS);
+        const long rows_here = min(32L, N - row0);         // wave-uniform; <= 0 for the waves past the last row
 #pragma unroll
         for (int t = 0; t < OT; ++t) {
             const int col = 32 * t + r;
             const unsigned base = (unsigned)(wave * 32 + 4 * kg) * ldy4 + col * 4;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaf(acc[t][i], post, fmaf(acc_b[t][i], post_b, acc_f[t][i]));
             if (col < out) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped
-                    gst_s(yb, base, (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, fmaf(acc[t][i], post, fmaf(acc_b[t][i], post_b, acc_f[t][i])));
+                    gst_s(yb, base, (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, v[i]);
             }
+            if constexpr (MOM) {
+                if (rows_here > 0) {                       // the 32-row tile's own (mean, M2), then merged into the wave's
+                    const float nt = (float)rows_here;
+                    float sm = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sm += (4 * kg + (i & 3) + 8 * (i >> 2) < rows_here) ? v[i] : 0.0f;
+                    sm += __shfl_xor(sm, 32);
+                    const float mt = sm / nt;
+                    float q = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float d = (4 * kg + (i & 3) + 8 * (i >> 2) < rows_here) ? v[i] - mt : 0.0f;
+                        q = fmaf(d, d, q);
+                    }
+                    q += __shfl_xor(q, 32);
+                    const float nn = mom_n + nt, d = mt - mom_m[t], w = nt / nn;
+                    mom_m[t] = fmaf(d, w, mom_m[t]);
+                    mom_q[t] += q + d * d * mom_n * w;
+                }
+            }
+        }
+        if constexpr (MOM) { if (rows_here > 0) mom_n += (float)rows_here; }
+    }
+    if constexpr (MOM) {
+        // the 8 waves' moments meet in LDS (the weight chunk is dead) and are merged in wave order
+        __syncthreads();
+        float* s_mom = reinterpret_cast<float*>(s_w);      // [wave 8][3][OT*32]
+        if (kg == 0) {
+#pragma unroll
+            for (int t = 0; t < OT; ++t) {
+                s_mom[(wave * 3 + 0) * (OT * 32) + 32 * t + r] = mom_m[t];
+                s_mom[(wave * 3 + 1) * (OT * 32) + 32 * t + r] = mom_q[t];
+                s_mom[(wave * 3 + 2) * (OT * 32) + 32 * t + r] = mom_n;
+            }
+        }
+        __syncthreads();
+        if (tid < OT * 32 && tid < out) {
+            float n = 0.0f, m = 0.0f, q = 0.0f;
+            for (int w8 = 0; w8 < NT / 64; ++w8) {
+                const float nb = s_mom[(w8 * 3 + 2) * (OT * 32) + tid];
+                if (nb > 0.0f) {
+                    const float mb = s_mom[(w8 * 3 + 0) * (OT * 32) + tid], qb = s_mom[(w8 * 3 + 1) * (OT * 32) + tid];
+                    const float nn = n + nb, d = mb - m, w = nb / nn;
+                    m = fmaf(d, w, m);
+                    q += qb + d * d * n * w;
+                    n = nn;
+                }
+            }
+            mom_partial[((long)blockIdx.x * 3 + 0) * out + tid] = m;
+            mom_partial[((long)blockIdx.x * 3 + 1) * out + tid] = q;
+            mom_partial[((long)blockIdx.x * 3 + 2) * out + tid] = n;
         }
     }
 }
@@ -456,36 +518,55 @@ __global__ void sparse_sum_splits_kernel(const float* __restrict__ part, int spl
     y[(i / out) * ldy + (i % out)] = a;
 }
 
-template <int OT, bool SH>
+int moments_finish(const float* partial, int P, int F, float* col_mean, float* col_m2, hipStream_t st);   // bn.hip
+
+static int sp_grid(long N) { return (int)min((long)cdiv(N, 256), 256L); }
+// column moments in the epilogue: whenever the launch is not split over the chunks (few-row inputs)
+bool kan_sparse_fwd_moments_ok(long N, int in, int out, int G, int K) {
+    return kan_sparse_fwd_ok(in, out, G, K) && sp_split_plan(N, cdiv(in << sp_sh(G + K), kSpCF)).splits == 1;
+}
+size_t kan_sparse_fwd_moments_ws_bytes(long N, int out) { return (size_t)sp_grid(N) * 3 * min(out, kSpOutBlk) * sizeof(float); }
+
+template <int OT, bool SH, bool MOM>
 static int launch_sparse(const float* x, long ldx, long N, int in, const float* knots, int nknots,
                          const unsigned char* pack, float* y, long ldy, int out, float* ws, size_t ws_bytes,
-                         hipStream_t st) {
+                         float* col_mean, float* col_m2, hipStream_t st) {
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH, MOM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
     const int nchunks = cdiv(in << (SH ? 1 : 0), kSpCF);
-    const int gx = (int)min((long)cdiv(N, 256), 256L);
+    const int gx = sp_grid(N);
     const SpSplit p = sp_split_plan(N, nchunks);
+    if constexpr (MOM) {
+        if (p.splits > 1) return fail(KAGNN_ERR_UNSUPPORTED, "%s: no column moments from a launch split over the chunks", "kan_sparse_fwd");
+        if (!ws || ws_bytes < (size_t)gx * 3 * out * sizeof(float))
+            return fail(KAGNN_ERR_ARG, "%s: workspace too small for the column moments", "kan_sparse_fwd");
+        kan_sparse_fwd_kernel<OT, SH, true><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, ws);
+        KAGNN_LAUNCH_CHECK();
+        return moments_finish(ws, gx, out, col_mean, col_m2, st);
+    }
     if (p.splits > 1) {
         if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_sparse_fwd");
-        kan_sparse_fwd_kernel<OT, SH><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
-                                                                         p.cps, N * (long)out);
+        kan_sparse_fwd_kernel<OT, SH, false><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
+                                                                                p.cps, N * (long)out, nullptr);
         KAGNN_LAUNCH_CHECK();
         sparse_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
         KAGNN_LAUNCH_CHECK();
         return KAGNN_OK;
     }
-    kan_sparse_fwd_kernel<OT, SH><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L);
+    kan_sparse_fwd_kernel<OT, SH, false><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, nullptr);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
 
+// col_mean / col_m2 (both or neither; [out]): also leave the column moments of y there (kan_sparse_fwd_moments_ok)
 int kan_sparse_fwd(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
-                   const void* pack, float* y, long ldy, void* ws, size_t ws_bytes, hipStream_t st) {
+                   const void* pack, float* y, long ldy, void* ws, size_t ws_bytes, float* col_mean, float* col_m2,
+                   hipStream_t st) {
     const int nk = G + 2 * K + 1, sh = sp_sh(G + K);
     const size_t stride = sp_blk_bytes(in, in << sh, min(out, kSpOutBlk));
     for (int b = 0; b * kSpOutBlk < out; ++b) {
@@ -493,9 +574,16 @@ int kan_sparse_fwd(const float* x, long ldx, long N, const float* knots, int in,
         const unsigned char* p = static_cast<const unsigned char*>(pack) + b * stride;
         float* yb = y + b * kSpOutBlk;
         int rc;
-#define L(OO, SS) launch_sparse<OO, SS>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, st)
-        if (sh) rc = OT == 1 ? L(1, true) : L(2, true);
-        else rc = OT == 1 ? L(1, false) : L(2, false);
+        float* cm = col_mean ? col_mean + b * kSpOutBlk : nullptr;
+        float* cq = col_mean ? col_m2 + b * kSpOutBlk : nullptr;
+#define L(OO, SS, MM) launch_sparse<OO, SS, MM>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, cm, cq, st)
+        if (col_mean) {
+            if (sh) rc = OT == 1 ? L(1, true, true) : L(2, true, true);
+            else rc = OT == 1 ? L(1, false, true) : L(2, false, true);
+        } else {
+            if (sh) rc = OT == 1 ? L(1, true, false) : L(2, true, false);
+            else rc = OT == 1 ? L(1, false, false) : L(2, false, false);
+        }
 #undef L
         if (rc) return rc;
     }

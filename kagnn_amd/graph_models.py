@@ -17,8 +17,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .models import (FASTKAGATConv, FASTKAGCNConv, GIFASTKANLayer, GIKANLayer, KAGATConv, KAGCNConv, make_fastkan,
-                     make_kan)
+from .models import (FASTKAGATConv, FASTKAGCNConv, GIFASTKANLayer, GIKANLayer, KAGATConv, KAGCNConv, conv_bn_dropout,
+                     make_fastkan, make_kan)
 from .norm import BatchNorm1d
 
 
@@ -82,8 +82,7 @@ FASTKAGAT_Layer = FASTKAGATConv
 class _GraphLevel(nn.Module):
     def _message_passing(self, x, g, edge_attr=None):
         for conv, bn in zip(self.conv, self.bn):
-            x = conv(x, g) if edge_attr is None else conv(x, g, edge_attr)
-            x = self.dropout(bn(x))
+            x = conv_bn_dropout(conv, bn, self.dropout, x, g, *(() if edge_attr is None else (edge_attr,)))
         return x
 
     def _pool(self, x, data):

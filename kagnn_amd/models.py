@@ -60,6 +60,7 @@ class FKANLayer(FastKANLayer):
 _SPLIT_READOUT = os.environ.get("KAGNN_SPLIT_READOUT", "1") != "0"
 _FUSED_LAYER = os.environ.get("KAGNN_FUSED_LAYER", "1") != "0"       # GIN + KAN chain as one autograd node (ops.gin_kan_layer)
 _SPLIT_READOUT_MIN_ROWS = 400_000
+_FUSED_EPILOGUE = os.environ.get("KAGNN_FUSED_EPILOGUE", "1") != "0"  # conv -> BatchNorm1d -> dropout: statistics + mask fused
 
 
 class _SumAggregateConv(nn.Module):
@@ -81,11 +82,25 @@ class _SumAggregateConv(nn.Module):
             self._eps_key = key
         return self._eps_val
 
+    def forward_with_moments(self, x: torch.Tensor, edge_index: torch.Tensor):
+        """``(y, moments)``: ``self(x, edge_index)`` (hooks included -- the module output stays a tensor) plus the
+        [2, out] column moments of y when the fused node produced them in its last forward kernel, else ``None``; for the
+        BatchNorm1d that follows: ``bn(y, moments=...)``"""
+        self.__dict__["_want_moments"] = True
+        try:
+            y = self(x, edge_index)
+        finally:
+            self.__dict__.pop("_want_moments", None)
+        return y, self.__dict__.pop("_moments", None)
+
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
         if _FUSED_LAYER and isinstance(self.nn, eKAN) and x.is_cuda and x.size(0) > 0 and not torch.compiler.is_compiling():
-            y = ops.gin_kan_layer(x, g, 1.0 + self._eps(), self.nn)        # one tape node: aggregate + KAN chain
+            want = self.__dict__.get("_want_moments", False) and x.size(0) > 1
+            y = ops.gin_kan_layer(x, g, 1.0 + self._eps(), self.nn, moments=want)   # one tape node: aggregate + KAN chain
             if y is not None:
+                if want:
+                    y, self.__dict__["_moments"] = y
                 return y
         if x.dtype == torch.bfloat16 or ops.default_activation_dtype() == torch.bfloat16:
             # bf16 gather operands outside the fused node (FastKAN chains, traced code): the aggregation takes the bf16
@@ -171,6 +186,25 @@ class GIFASTKANLayer(_SumAggregateConv):
 
 
 # ---------------------------------------------------------------------------------- node models
+def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args):
+    """The epilogue ``dropout(bn(conv(x)))`` of every message-passing layer (reference
+    ``node_classification_clean/models.py:198-201``, ``graph_regression/models.py:107-119``), fused (SURVEY.md 8(f)
+    rank 1): the batch statistics come out of the convolution's last forward kernel (``_SumAggregateConv`` over a KAN
+    chain) and the dropout mask is applied inside the normalising pass and regenerated in the backward
+    (``ops.batch_norm``).  Stock modules under torch.compile and, with dropout on, during stream capture (a captured
+    seed would repeat the mask on every replay)."""
+    fused = (_FUSED_EPILOGUE and x.is_cuda and not torch.compiler.is_compiling() and type(dropout) is nn.Dropout
+             and isinstance(bn, BatchNorm1d)
+             and not (dropout.p > 0.0 and dropout.training and torch.cuda.is_current_stream_capturing()))
+    if not fused:
+        return dropout(bn(conv(x, g, *conv_args)))
+    if isinstance(conv, _SumAggregateConv) and bn.training and not conv_args:
+        y, mom = conv.forward_with_moments(x, g)
+    else:
+        y, mom = conv(x, g, *conv_args), None
+    return bn(y, moments=mom, dropout_p=dropout.p if dropout.training else 0.0)
+
+
 class _NodeModel(nn.Module):
     """mp_layers x {conv -> BatchNorm1d -> dropout}, skip-concat of the input and every layer
     output, then a KAN / FastKAN read-out (reference ``models.py:192-203,246-257``)."""
@@ -203,7 +237,7 @@ class _NodeModel(nn.Module):
             g = ops.graph_index(edge_index, x.size(0))
         outs = [x if x.dtype == torch.float32 else x.float()]      # (bf16 activation storage: the read-out is fp32)
         for conv, bn in zip(self.convs, self.bns):
-            x = self.dropout(bn(conv(x, g)))
+            x = conv_bn_dropout(conv, bn, self.dropout, x, g)
             outs.append(x)
         if self.skip:
             # large graphs: read-out over [x | h1 | ... ] without concatenating (12.2 vs 13.3 ms per step at 1M nodes;

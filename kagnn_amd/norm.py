@@ -12,7 +12,9 @@ from . import ops
 
 
 class BatchNorm1d(nn.BatchNorm1d):
-    def forward(self, input: torch.Tensor) -> torch.Tensor:
+    def forward(self, input: torch.Tensor, moments=None, dropout_p: float = 0.0) -> torch.Tensor:
+        """``moments`` / ``dropout_p``: the fused epilogue of ``ops.batch_norm`` (column moments of ``input`` from its
+        producer; ``dropout(bn(input), p)`` in one pass while training)"""
         self._check_input_dim(input)
         if input.dim() != 2:
             raise NotImplementedError("kagnn_amd.BatchNorm1d normalises [N, F] node rows only")
@@ -27,4 +29,5 @@ class BatchNorm1d(nn.BatchNorm1d):
         return ops.batch_norm(input, self.weight, self.bias,
                               self.running_mean if use_running else None,
                               self.running_var if use_running else None,
-                              bn_training, factor, self.eps)
+                              bn_training, factor, self.eps, moments=moments if bn_training else None,
+                              dropout_p=dropout_p if self.training else 0.0)

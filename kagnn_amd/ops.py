@@ -545,8 +545,9 @@ def _weights_key(bw, sw, sc):
 
 # raw (no autograd) pieces of the KANLinear forward / backward: shared by the autograd.Function below (eager) and by the
 # torch.library ops of kagnn_amd/library.py (torch.compile sees those as opaque ops)
-def _kan_fwd_raw(x, bw, sw, sc, knots, grid_size, spline_order, mode, packed=None, pack_key=None):
-    """-> (y, pack_dx): forward output and the input-gradient pack of the current weights"""
+def _kan_fwd_raw(x, bw, sw, sc, knots, grid_size, spline_order, mode, packed=None, pack_key=None, moments=False):
+    """-> (y, pack_dx): forward output and the input-gradient pack of the current weights; with ``moments`` also the
+    column moments of y, ``(mean [out], M2 [out])`` (``kagnn_kan_linear_fwd_moments``: the BatchNorm1d statistics)"""
     n, fin = x.shape
     fout = sw.size(0)
     if packed is not None and packed[2] == pack_key:
@@ -557,6 +558,13 @@ def _kan_fwd_raw(x, bw, sw, sc, knots, grid_size, spline_order, mode, packed=Non
         _call("kagnn_kan_pack", _ptr(bw), _ptr(sw), _ptr(sc), fin, fout, grid_size, spline_order, mode,
               _ptr(pack_f), _ptr(pack_d), _stream())
     y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
+    if moments:
+        mom = torch.empty((2, fout), dtype=torch.float32, device=x.device)
+        wb = _sizes("kagnn_kan_fwd_moments_workspace_bytes", n, fin, fout, grid_size, spline_order, mode)
+        ws = _ws(wb, x.device) if wb else None
+        _call("kagnn_kan_linear_fwd_moments", _ptr(x), _ld(x), n, _ptr(knots), fin, fout, grid_size, spline_order, mode,
+              _ptr(pack_f), _ptr(y), fout, _ptr(mom[0]), _ptr(mom[1]), _ptr(ws), wb, _stream())
+        return y, pack_d, mom
     wb = _sizes("kagnn_kan_fwd_workspace_bytes", n, fin, fout, grid_size, spline_order, mode)
     ws = _ws(wb, x.device) if wb else None
     _call("kagnn_kan_linear_fwd", _ptr(x), _ld(x), n, _ptr(knots), fin, fout, grid_size,
@@ -635,7 +643,7 @@ class _GinKanLayerFn(Function):
 
     @staticmethod
     @_on_operand_device
-    def forward(ctx, x, g, self_scale, knots, grid_size, spline_order, mode, act_bf16, *params):
+    def forward(ctx, x, g, self_scale, knots, grid_size, spline_order, mode, act_bf16, moments, *params):
         _need_cuda(x, *params)
         nl = len(params) // 3
         layers = [(params[3 * i].contiguous(), params[3 * i + 1].contiguous(), params[3 * i + 2].contiguous()) for i in range(nl)]
@@ -651,12 +659,19 @@ class _GinKanLayerFn(Function):
             h = _aggregate_raw(xg, g, False, self_scale, None, None, None, None, False)
             packs = kan_pack_chain(layers, grid_size, spline_order, mode) if nl > 1 else None
             saved = []
+            mom = None
             for i, (bw, sw, sc) in enumerate(layers):
-                y, pack_d = _kan_fwd_raw(h, bw, sw, sc, knots[i], grid_size, spline_order, mode,
-                                         None if packs is None else packs[i], None if packs is None else packs[i][2])
+                out = _kan_fwd_raw(h, bw, sw, sc, knots[i], grid_size, spline_order, mode,
+                                   None if packs is None else packs[i], None if packs is None else packs[i][2],
+                                   moments=moments and i == nl - 1)
+                y, pack_d = out[0], out[1]
+                mom = out[2] if len(out) > 2 else mom
                 saved += [h, sw, sc, pack_d]
                 h = y
             ctx.save_for_backward(*saved, knots[0])
+            if moments:
+                ctx.mark_non_differentiable(mom)
+                return h, mom
             return h
         acts = [torch.empty((n, w), dtype=torch.float32, device=dev) for w in widths]
         pfs, pds = [], []
@@ -667,21 +682,26 @@ class _GinKanLayerFn(Function):
         wf, _ = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), grid_size, spline_order, mode,
                        g.num_hub_seg, g.num_hub_seg_t, outputs=2)
         ws = _ws(wf, dev)
+        mom = torch.empty((2, widths[nl]), dtype=torch.float32, device=dev) if moments else None
         _call("kagnn_gin_kan_layer_fwd", _ptr(xg), _lib.DTYPE_BF16 if xg.dtype == torch.bfloat16 else _lib.DTYPE_F32, _ld(xg), n,
               _ptr(g.rowptr), _ptr(g.col), _ptr(g.hub_seg) if g.num_hub_seg else None, g.num_hub_seg, g.hub_threshold,
               float(self_scale), nl, warr, _ptr_array([l[0] for l in layers]), _ptr_array([l[1] for l in layers]),
               _ptr_array([l[2] for l in layers]), _ptr(knots[0]), grid_size, spline_order, mode, _ptr_array(acts),
-              _ptr_array(pfs), _ptr_array(pds), _ptr(ws), ws.numel(), _stream())
+              _ptr_array(pfs), _ptr_array(pds), _ptr(mom[0]) if moments else None, _ptr(mom[1]) if moments else None,
+              _ptr(ws), ws.numel(), _stream())
         saved = []
         for i in range(nl):
             saved += [acts[i], layers[i][1], layers[i][2], pds[i]]
         ctx.save_for_backward(*saved, knots[0])
+        if moments:
+            ctx.mark_non_differentiable(mom)
+            return acts[nl], mom
         return acts[nl]
 
     @staticmethod
     @once_differentiable
     @_on_operand_device
-    def backward(ctx, gy):
+    def backward(ctx, gy, _g_moments=None):
         g, self_scale, G, K, mode, act_bf16, nl, x_dtype, widths = ctx.meta
         t = ctx.saved_tensors
         knots = t[4 * nl]
@@ -693,7 +713,7 @@ class _GinKanLayerFn(Function):
             for i in reversed(range(nl)):
                 h_in, sw, sc, pack_d = t[4 * i:4 * i + 4]
                 fin, fout = widths[i], widths[i + 1]
-                if any(ctx.needs_input_grad[8 + 3 * i:8 + 3 * i + 3]):
+                if any(ctx.needs_input_grad[9 + 3 * i:9 + 3 * i + 3]):
                     grads[3 * i], grads[3 * i + 1], grads[3 * i + 2] = _kan_bwd_weight_raw(h_in, gy, knots, sw, sc, fin, fout,
                                                                                            G, K, mode, True)
                 if i > 0 or need_x:
@@ -701,7 +721,7 @@ class _GinKanLayerFn(Function):
                                 and fin % 8 == 0 and _fits32(h_in, fout))      # the dX variant that stores bf16 rows
                     gy = _kan_bwd_input_raw(h_in, gy, knots, pack_d, fin, fout, G, K, mode, bf16_out)
             gx = _aggregate_raw(gy, g, True, self_scale, None, None, None, None, False, out_dtype=gx_dtype) if need_x else None
-            return (gx, None, None, None, None, None, None, None, *grads)
+            return (gx, None, None, None, None, None, None, None, None, *grads)
         n, dev = gy.size(0), gy.device
         f32 = dict(dtype=torch.float32, device=dev)
         acts = [t[4 * i] for i in range(nl)]
@@ -727,7 +747,7 @@ class _GinKanLayerFn(Function):
         grads = []
         for i in range(nl):
             grads += [gbw[i], gsw[i], gsc[i]]
-        return (gx, None, None, None, None, None, None, None, *grads)
+        return (gx, None, None, None, None, None, None, None, None, *grads)
 
 
 _KNOTS_EQUAL: dict = {}
@@ -746,10 +766,12 @@ def _same_knots(layers, knots) -> bool:
     return hit
 
 
-def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optional[torch.dtype] = None):
+def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optional[torch.dtype] = None,
+                  moments: bool = False):
     """``chain(aggregate_sum(x, g, self_scale))`` for a ``kagnn_amd.KAN`` chain as ONE autograd node, or ``None`` when the
     chain is outside what the fused node covers (adaptive grids, > 16 coefficients, mixed precisions): the caller then
-    composes the ops."""
+    composes the ops.  ``moments=True`` -> ``(y, moments)`` with the [2, out] column moments (mean, M2) of y from the
+    last forward kernel's epilogue, for ``batch_norm(..., moments=...)``."""
     layers = list(chain.layers)
     first = layers[0]
     mode = first.precision if first.precision is not None else default_precision()
@@ -769,7 +791,7 @@ def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optiona
     for l in layers:
         params += [l.base_weight, l.spline_weight, l.spline_scaler]
     return _GinKanLayerFn.apply(x, g, float(self_scale), knots, first.grid_size, first.spline_order, int(mode),
-                                act == torch.bfloat16 or x.dtype == torch.bfloat16, *params)
+                                act == torch.bfloat16 or x.dtype == torch.bfloat16, bool(moments), *params)
 
 
 def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
@@ -1044,8 +1066,10 @@ def gat_aggregate(xh, att_src, att_dst, bias, g: GraphIndex, heads: int, channel
 
 
 # ======================================================================== BatchNorm1d (conv epilogue)
-def _batchnorm_fwd_raw(x, weight, bias, running_mean, running_var, training, momentum, eps):
-    """-> (y, save_mean, save_rstd); running statistics are updated in place by the kernel"""
+def _batchnorm_fwd_raw(x, weight, bias, running_mean, running_var, training, momentum, eps, moments=None,
+                       dropout_p=0.0, dropout_seed=0):
+    """-> (y, save_mean, save_rstd); running statistics are updated in place by the kernel.  ``moments``: the [2, F]
+    column moments of x from its producer (no statistics pass); ``dropout_p`` > 0: y = dropout(bn(x)) in the same pass"""
     n, f = x.shape
     ws = _ws(_sizes("kagnn_batchnorm_workspace_bytes", n, f), x.device)
     y = torch.empty((n, f), dtype=torch.float32, device=x.device)
@@ -1053,13 +1077,15 @@ def _batchnorm_fwd_raw(x, weight, bias, running_mean, running_var, training, mom
     rstd = torch.empty(f, dtype=torch.float32, device=x.device)
     w = None if weight is None else weight.contiguous()
     b = None if bias is None else bias.contiguous()
+    use_mom = moments is not None and training
     _call("kagnn_batchnorm_fwd", _ptr(x), _ld(x), n, f, _ptr(w), _ptr(b), _ptr(running_mean), _ptr(running_var),
-          float(momentum), float(eps), int(bool(training)), _ptr(y), f, _ptr(mean), _ptr(rstd), _ptr(ws),
-          ws.numel(), _stream())
+          float(momentum), float(eps), int(bool(training)), _ptr(moments[0]) if use_mom else None,
+          _ptr(moments[1]) if use_mom else None, float(dropout_p), int(dropout_seed), _ptr(y), f, _ptr(mean),
+          _ptr(rstd), _ptr(ws), ws.numel(), _stream())
     return y, mean, rstd
 
 
-def _batchnorm_bwd_raw(x, gy, weight, mean, rstd, training, want_gx, want_bias):
+def _batchnorm_bwd_raw(x, gy, weight, mean, rstd, training, want_gx, want_bias, dropout_p=0.0, dropout_seed=0):
     n, f = x.shape
     w = None if weight is None else weight.contiguous()
     ws = _ws(_sizes("kagnn_batchnorm_workspace_bytes", n, f), x.device)
@@ -1067,19 +1093,23 @@ def _batchnorm_bwd_raw(x, gy, weight, mean, rstd, training, want_gx, want_bias):
     gw = torch.empty(f, dtype=torch.float32, device=x.device) if w is not None else None
     gb = torch.empty(f, dtype=torch.float32, device=x.device) if want_bias else None
     _call("kagnn_batchnorm_bwd", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, f, _ptr(w), _ptr(mean), _ptr(rstd),
-          int(training), _ptr(gx), f, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), _stream())
+          int(training), float(dropout_p), int(dropout_seed), _ptr(gx), f, _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(),
+          _stream())
     return gx, gw, gb
 
 
 class _BatchNormFn(Function):
     @staticmethod
     @_on_operand_device
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
-        _need_cuda(x, weight, bias, running_mean, running_var)
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, moments=None, dropout_p=0.0,
+                dropout_seed=0):
+        _need_cuda(x, weight, bias, running_mean, running_var, moments)
         x = _rows(x)
-        y, mean, rstd = _batchnorm_fwd_raw(x, weight, bias, running_mean, running_var, training, momentum, eps)
+        y, mean, rstd = _batchnorm_fwd_raw(x, weight, bias, running_mean, running_var, training, momentum, eps, moments,
+                                           dropout_p, dropout_seed)
         ctx.save_for_backward(x, weight, mean, rstd)
         ctx.training = bool(training)
+        ctx.dropout = (float(dropout_p), int(dropout_seed))
         ctx.has_bias = bias is not None
         return y                      # running statistics are grad-free buffers, updated in place by the kernel
 
@@ -1088,18 +1118,38 @@ class _BatchNormFn(Function):
     @_on_operand_device
     def backward(ctx, gy):
         x, w, mean, rstd = ctx.saved_tensors
-        gx, gw, gb = _batchnorm_bwd_raw(x, _rows(gy), w, mean, rstd, ctx.training, ctx.needs_input_grad[0], ctx.has_bias)
-        return gx, gw, gb, None, None, None, None, None
+        gx, gw, gb = _batchnorm_bwd_raw(x, _rows(gy), w, mean, rstd, ctx.training, ctx.needs_input_grad[0], ctx.has_bias,
+                                        *ctx.dropout)
+        return gx, gw, gb, None, None, None, None, None, None, None, None
 
 
-def batch_norm(x, weight, bias, running_mean, running_var, training: bool, momentum: float, eps: float):
-    """torch.nn.functional.batch_norm on [N, F] rows (reference ``models.py:195-202`` epilogue)."""
+def dropout_seed() -> int:
+    """a fresh 63-bit seed for the fused dropout, drawn from torch's CPU default generator (``torch.manual_seed``
+    reproduces it; no device work)"""
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
+
+
+def batch_norm(x, weight, bias, running_mean, running_var, training: bool, momentum: float, eps: float,
+               moments: Optional[torch.Tensor] = None, dropout_p: float = 0.0, seed: Optional[int] = None):
+    """torch.nn.functional.batch_norm on [N, F] rows (reference ``models.py:195-202`` epilogue).
+
+    The fused epilogue of SURVEY.md 8(f) rank 1: ``moments`` = the [2, F] column moments of ``x`` left by the kernel
+    that produced it (``gin_kan_layer(..., moments=True)``) replaces the statistics pass in training; ``dropout_p`` > 0
+    (training) returns ``dropout(batch_norm(x), p)`` from the same kernel, the mask being a hash of (seed, row, column)
+    that the backward regenerates -- same distribution as ``F.dropout``, not torch's random stream."""
     if x.size(0) == 0:
         return x.new_empty(x.shape)
+    if not 0.0 <= dropout_p <= 1.0:
+        raise ValueError(f"dropout probability has to be between 0 and 1, but got {dropout_p}")
+    p = float(dropout_p) if training else 0.0
     if torch.compiler.is_compiling():
         from . import library
-        return library.batch_norm_traced(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps))
-    return _BatchNormFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps)
+        y = library.batch_norm_traced(x, weight, bias, running_mean, running_var, bool(training), float(momentum), float(eps))
+        return torch.nn.functional.dropout(y, p, True) if p > 0.0 else y
+    if p > 0.0 and seed is None:
+        seed = dropout_seed()
+    return _BatchNormFn.apply(x, weight, bias, running_mean, running_var, training, momentum, eps, moments, p,
+                              seed if p > 0.0 else 0)
 
 
 class _ConcatColumnsFn(Function):

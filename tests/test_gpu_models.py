@@ -527,7 +527,8 @@ def test_models_trace_into_one_graph_of_kagnn_ops(arch, kind):
     compiled = torch.compile(model, backend="aot_eager", fullgraph=True)
     traced, traced_stats = run(compiled)
     for a, b in zip(eager, traced):
-        assert_close(b, a, 1e-6, what=f"compiled vs eager {arch}/{kind}")
+        # (eager takes the batch statistics from the convolution's epilogue, traced code from the statistics pass)
+        assert_close(b, a, 4e-6, what=f"compiled vs eager {arch}/{kind}")
     for k in eager_stats:
         assert_close(traced_stats[k], eager_stats[k], 1e-6, what=f"compiled {k}")
     # the traced graph holds the opaque ops
