@@ -351,6 +351,9 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         }
         const GBuf yb = gbuf_at(y, N, ldy, out, tile * ROWS);
         const long rows_here = min(32L, N - row0);         // wave-uniform; <= 0 for the waves past the last row
+        // (small integers: the reciprocals are the same instruction in every wave, so the merge order stays fixed)
+        const float mom_nt = (float)max(rows_here, 1L), mom_rnt = __builtin_amdgcn_rcpf(mom_nt);
+        const float mom_w = mom_nt * __builtin_amdgcn_rcpf(mom_n + mom_nt), mom_nw = mom_n * mom_w;
 #pragma unroll
         for (int t = 0; t < OT; ++t) {
             const int col = 32 * t + r;
@@ -365,12 +368,11 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
             }
             if constexpr (MOM) {
                 if (rows_here > 0) {                       // the 32-row tile's own (mean, M2), then merged into the wave's
-                    const float nt = (float)rows_here;
                     float sm = 0.0f;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) sm += (4 * kg + (i & 3) + 8 * (i >> 2) < rows_here) ? v[i] : 0.0f;
                     sm += __shfl_xor(sm, 32);
-                    const float mt = sm / nt;
+                    const float mt = sm * mom_rnt;
                     float q = 0.0f;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -378,9 +380,9 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                         q = fmaf(d, d, q);
                     }
                     q += __shfl_xor(q, 32);
-                    const float nn = mom_n + nt, d = mt - mom_m[t], w = nt / nn;
-                    mom_m[t] = fmaf(d, w, mom_m[t]);
-                    mom_q[t] += q + d * d * mom_n * w;
+                    const float d = mt - mom_m[t];
+                    mom_m[t] = fmaf(d, mom_w, mom_m[t]);
+                    mom_q[t] += fmaf(d * d, mom_nw, q);
                 }
             }
         }
