@@ -372,12 +372,17 @@ def main():
         other = "transposed" if primary == "feature" else "feature"
         step = make(classes[primary])
         parallelism = names[primary]
-        alt_step = make(classes[other])
-        for _ in range(args.warmup):
-            alt_step()
-        dt_alt = timed(alt_step, args.steps)
-        alt = {"parallelism": names[other], "ms_per_step": dt_alt / args.steps * 1e3, "value": e / (dt_alt / args.steps)}
-        del alt_step
+
+        def time_alt():
+            # the other scheme, timed AFTER the reported one; a failure here must not cost the run its line
+            try:
+                alt_step = make(classes[other])
+                for _ in range(args.warmup):
+                    alt_step()
+                dt_alt = timed(alt_step, args.steps)
+                return {"parallelism": names[other], "ms_per_step": dt_alt / args.steps * 1e3, "value": e / (dt_alt / args.steps)}
+            except Exception as ex:                       # noqa: BLE001 -- reported, not swallowed
+                return {"parallelism": names[other], "error": f"{type(ex).__name__}: {ex}"[:300]}
 
     for _ in range(args.warmup):
         step()
@@ -400,6 +405,8 @@ def main():
     ops.set_timer(None)
     ms = dt / args.steps * 1e3
     value = e / (dt / args.steps)
+    if world > 1 and os.environ.get("KAGNN_BENCH_ALT", "1") != "0":
+        alt = time_alt()
 
     fp32_ms = None
     if not args.no_fp32 and not fp32_mode and world == 1:
