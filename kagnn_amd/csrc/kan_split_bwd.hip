@@ -776,15 +776,18 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     const long s = blockIdx.x;
     const long rbeg = s * rows_per_block, rend = min(N, rbeg + rows_per_block);
 
-    f32x4 D[kCTmax - 1][4];        // spline coefficients x 4 o-tiles, scaled by 2^(20 - T)
-    f32x4 Dh[4];                   // base weight through the fp16 path, scaled by 2^(14 - T)
+    f32x4 D[kCTmax][4];            // spline coefficients x 4 o-tiles, scaled by 2^(20 - T); plane kCTmax - 1: the base
+                                   // weight through the fp16 path, scaled by 2^(14 - T).  (ONE array: as a separate
+                                   // `Dh[4]` the compiler kept the base plane in arch VGPRs and copied its 16 registers
+                                   // to the accumulation file and back around its MFMAs in every chunk)
+#define Dh D[kCTmax - 1]
     f32x4 Df[4];                   // base weight through the exact fp32 path (chunks whose silu overflows fp16)
 #pragma unroll
-    for (int c = 0; c < kCTmax - 1; ++c)
+    for (int c = 0; c < kCTmax; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) D[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { Dh[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Df[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < 4; ++t) Df[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // descriptors opened at this workgroup's first row and closed at its last: offsets are relative to rbeg (32-bit
     // for any N; the host keeps rows_per_block * ld * 4 below 4 GiB) and rows >= rend read as 0
@@ -918,11 +921,9 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
             const int ex = chunk_exp(raw);
             const float dn = ldexpf(1.0f, T - ex);
 #pragma unroll
-            for (int c = 0; c < kCTmax - 1; ++c)
+            for (int c = 0; c < kCTmax; ++c)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) D[c][t] *= dn;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) Dh[t] *= dn;
             T = ex;
             expand(raw, T);
         }
@@ -944,6 +945,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
         }
     }
 }
+#undef Dh
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradient for cubic layers with 9..12 coefficients (grid 6..9; BASELINE config 3 is grid 8 => C = 11).
@@ -975,18 +977,21 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
     const long rbeg = s * rows_per_block, rend = min(N, rbeg + rows_per_block);
 
     f32x4 D[kCTmax - 1][4];        // window 0: slots 0..7, scaled by 2^(20 - T)
-    f32x4 D1[NS1][4];              // window 1: slots 8..8+NS1-1
-    f32x4 Dh[4], Df[4];            // base weight: fp16 path (2^(14 - T)) / exact fp32 path
+    f32x4 D1[NS1 + 1][4];          // window 1: slots 8..8+NS1-1; plane NS1: the base weight through the fp16 path (2^(14 - T))
+    f32x4 Df[4];                   // base weight through the exact fp32 path
+    // (the base plane is a row of D1, not an array of its own: as `Dh[4]` the compiler kept it in arch VGPRs and copied all
+    // 16 registers to the accumulation file and back around its MFMAs in every chunk)
+#define Dh D1[NS1]
 #pragma unroll
     for (int c = 0; c < kCTmax - 1; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) D[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < NS1; ++c)
+    for (int c = 0; c < NS1 + 1; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) D1[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { Dh[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Df[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < 4; ++t) Df[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const GBuf xb = gbuf_at(x, rend, ldx, in, rbeg), gyb = gbuf_at(gy, rend, ldgy, out, rbeg);
     const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u;
@@ -1127,11 +1132,9 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) D[c][t] *= dn;
 #pragma unroll
-            for (int c = 0; c < NS1; ++c)
+            for (int c = 0; c < NS1 + 1; ++c)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) D1[c][t] *= dn;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) Dh[t] *= dn;
             T = ex;
             expand(raw, T);
         }
@@ -1155,6 +1158,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
         }
     }
 }
+#undef Dh
 
 // slab reduction and unpack in one launch (the non-virtual layout): thread (o, plane c) of workgroup (o-tile, f)
 // sums slab[.][c][f][o] in a fixed order, writes g_spline_weight (chain rule through spline_scaler), and the
