@@ -163,8 +163,24 @@ __device__ __forceinline__ f32x16 smfmac(const u32x4& a, const u32x4& b0, const 
     return __builtin_amdgcn_smfmac_f32_32x32x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x16, b), c, idx, 0, 0);
 }
 
-// 512 threads = 8 waves (2 per SIMD), one wave = 32 rows; persistent workgroups, packed W resident in LDS when the
-// layer has one chunk (in <= 64), split-K over blockIdx.y for few-row inputs (see kan_split.hip).
+// One wave copies 1 KiB global -> LDS without touching registers (global_load_lds_dwordx4: lane l's 16 bytes land at
+// lds_addr + 16 l; layout measured by tools/probes/lds_dma_probe.hip).  Inline asm on purpose: behind the builtin the
+// compiler cannot tell which LDS bytes an in-flight copy targets and puts s_waitcnt vmcnt(0) in front of EVERY later
+// ds_read, i.e. no overlap.  Completion is awaited explicitly (lds_dma_wait) before the barrier that publishes the buffer;
+// the compiler's own vmcnt bookkeeping for the x loads stays safe (memory returns in order: it can only over-wait).
+// M0 is written here and read by nothing else in these kernels.
+__device__ __forceinline__ void lds_dma_1k(const unsigned char* g_lane, unsigned lds_addr /* wave-uniform */) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g_lane), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// 512 threads = 8 waves (2 per SIMD), one wave = 32 rows; persistent workgroups, split-K over blockIdx.y for few-row
+// inputs (see kan_split.hip).  The packed W of a 64-feature chunk (152 KB for 64 outputs) lives in LDS as two HALVES
+// (8 sparse steps + 2 SiLU groups each).  One chunk (in <= 64): both halves are loaded once and stay.  More chunks: the
+// halves are a double buffer -- while the waves work through one half, the next one (of this chunk, the next chunk, or
+// the next row tile's first chunk) streams in by LDS-DMA; one barrier per half.  (Staging a whole chunk through
+// registers between two barriers, as before, was 37 % of the forward at 128 -> 128, grid 8: 2.4 GB of L2 -> LDS traffic
+// per 64-output launch that nothing overlapped.)
 // MOM: the epilogue also accumulates the COLUMN MOMENTS of y (count, mean, sum of squared deviations; per wave over its
 // row tiles, merged pairwise in a fixed order -- Chan et al., no cancellation) and leaves one (mean, M2, count) row per
 // workgroup in mom_partial[gridDim.x][3][out]: the BatchNorm1d that follows the convolution (reference
@@ -177,6 +193,8 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     constexpr int NT = 512, CF = kSpCF, HF = CF / 2, BPC = CF / 16, NG = HF / 8, ROWS = (NT / 64) * 32;
     constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 2 * 1024;
     constexpr int SPL_BYTES = kSpSteps * OT * 2 * 2048;
+    constexpr int HALF_SPL = SPL_BYTES / 2, HALF_BASE = (BPC / 2) * OT * 2 * 1024, HALF_BYTES = HALF_SPL + HALF_BASE;
+    static_assert(2 * HALF_BYTES == CHUNK_BYTES && NG == 4 && kSpSteps == 16, "two halves of 2 groups x 4 steps");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* s_knots = reinterpret_cast<float*>(smem);
     unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
@@ -188,14 +206,24 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const float post_b = post * 64.0f;                  // the SiLU branch is fed at scale 2^4 instead of 2^10
     const float* base_w = reinterpret_cast<const float*>(pack + kHdrBytes + (size_t)nchunks * CHUNK_BYTES);   // [out][in] fp32
     const unsigned char* gw = pack + kHdrBytes;
-    auto stage_chunk = [&](int ch) {
-        const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)ch * CHUNK_BYTES);
-        uint4* dst = reinterpret_cast<uint4*>(s_w);
-        for (int i = tid; i < CHUNK_BYTES / 16; i += NT) dst[i] = src[i];
+    // half h (0 / 1) of chunk ch -> LDS buffer h: 32 OT one-KiB pieces of sparse-step fragments + 4 OT of SiLU fragments
+    const unsigned lds_w = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)s_w);
+    auto dma_half = [&](int ch, int h) {
+        const unsigned char* src = gw + (size_t)ch * CHUNK_BYTES;
+        const unsigned dst = lds_w + h * HALF_BYTES;
+#pragma unroll
+        for (int k = 0; k < 4 * OT; ++k) {
+            const int blk = wave * (4 * OT) + k;
+            lds_dma_1k(src + h * HALF_SPL + blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(dst + blk * 1024));
+        }
+        if (wave < 4 * OT)
+            lds_dma_1k(src + SPL_BYTES + h * HALF_BASE + wave * 1024 + lane * 16,
+                       __builtin_amdgcn_readfirstlane(dst + HALF_SPL + wave * 1024));
     };
     const int ch_begin = blockIdx.y * chunks_per_split, ch_end = min(nchunks, ch_begin + chunks_per_split);
     const bool resident = (ch_end - ch_begin) == 1;
-    if (resident) stage_chunk(ch_begin);
+    dma_half(ch_begin, 0);
+    if (resident) { dma_half(ch_begin, 1); lds_dma_wait(); }
     y += (long)blockIdx.y * part_stride;
     __syncthreads();
     const Frag3Geom f3geo = frag3_geom(s_knots, nknots);
@@ -244,13 +272,18 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
             for (int i = 0; i < 16; ++i) { acc[t][i] = 0.0f; acc_b[t][i] = 0.0f; acc_f[t][i] = 0.0f; }
 
         for (int ch = ch_begin; ch < ch_end; ++ch) {
-            if (!resident) {
-                __syncthreads();
-                stage_chunk(ch);
-                __syncthreads();
-            }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
+                const unsigned char* hb = s_w + (g >> 1) * HALF_BYTES;     // this group's half buffer
+                if (!resident && (g & 1) == 0) {
+                    // my pieces of this half have landed; after the barrier so have everyone's, and everyone is done with
+                    // the other buffer -- which the half after this one now streams into
+                    lds_dma_wait();
+                    __syncthreads();
+                    if (g == 0) dma_half(ch, 1);
+                    else if (ch + 1 < ch_end) dma_half(ch + 1, 0);
+                    else if ((tile + gridDim.x) * ROWS < N) dma_half(ch_begin, 0);
+                }
                 float xv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = xn[j];
@@ -269,7 +302,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     else frag3_index<false>(xv[2 * s + 1], f3geo, u1, o1);
                     e0 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + o0);
                     e1 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + o1);
-                    const unsigned char* wp = s_w + (size_t)((4 * g + s) * OT) * 2 * 2048 + lane * 32;
+                    const unsigned char* wp = hb + (size_t)((4 * (g & 1) + s) * OT) * 2 * 2048 + lane * 32;
 #pragma unroll
                     for (int i = 0; i < 2 * OT; ++i) {      // [ot][hi|lo] x 32 bytes
                         w[2 * i] = *reinterpret_cast<const u32x4*>(wp + i * 2048);
@@ -323,7 +356,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     }
                 }
                 if (!big) {
-                    const unsigned char* wp = s_w + SPL_BYTES + (size_t)(g * OT) * 2 * 1024 + lane * 16;
+                    const unsigned char* wp = hb + HALF_SPL + (size_t)((g & 1) * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
                     for (int t = 0; t < OT; ++t) {
                         const u32x4 wh = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 0) * 1024);
