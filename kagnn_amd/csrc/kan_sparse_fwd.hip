@@ -163,17 +163,6 @@ __device__ __forceinline__ f32x16 smfmac(const u32x4& a, const u32x4& b0, const 
     return __builtin_amdgcn_smfmac_f32_32x32x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x16, b), c, idx, 0, 0);
 }
 
-// One wave copies 1 KiB global -> LDS without touching registers (global_load_lds_dwordx4: lane l's 16 bytes land at
-// lds_addr + 16 l; layout measured by tools/probes/lds_dma_probe.hip).  Inline asm on purpose: behind the builtin the
-// compiler cannot tell which LDS bytes an in-flight copy targets and puts s_waitcnt vmcnt(0) in front of EVERY later
-// ds_read, i.e. no overlap.  Completion is awaited explicitly (lds_dma_wait) before the barrier that publishes the buffer;
-// the compiler's own vmcnt bookkeeping for the x loads stays safe (memory returns in order: it can only over-wait).
-// M0 is written here and read by nothing else in these kernels.
-__device__ __forceinline__ void lds_dma_1k(const unsigned char* g_lane, unsigned lds_addr /* wave-uniform */) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g_lane), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 // 512 threads = 8 waves (2 per SIMD), one wave = 32 rows; persistent workgroups, split-K over blockIdx.y for few-row
 // inputs (see kan_split.hip).  The packed W of a 64-feature chunk (152 KB for 64 outputs) lives in LDS as two HALVES
 // (8 sparse steps + 2 SiLU groups each).  One chunk (in <= 64): both halves are loaded once and stay.  More chunks: the

@@ -128,10 +128,14 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     if (K == 4) build_perm_fix_table(s_tbl, tid);
     const float post = reinterpret_cast<const float*>(pack)[0];
     const unsigned char* gw = pack + kHdrBytes;
+    // global -> LDS by LDS-DMA (lds_dma_1k, split_common.h): one KiB per wave and instruction, no register round trip
+    static_assert(CHUNK_BYTES % 1024 == 0, "whole KiB pieces");
+    const unsigned lds_w = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)s_w);
     auto stage_chunk = [&](int ch) {
-        const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)ch * CHUNK_BYTES);
-        uint4* dst = reinterpret_cast<uint4*>(s_w);
-        for (int i = tid; i < CHUNK_BYTES / 16; i += NT) dst[i] = src[i];
+        const unsigned char* src = gw + (size_t)ch * CHUNK_BYTES;
+        for (int blk = wave; blk < CHUNK_BYTES / 1024; blk += NT / 64)
+            lds_dma_1k(src + blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_w + blk * 1024));
+        lds_dma_wait();
     };
     const int ch_begin = split * chunks_per_split, ch_end = min(nchunks, ch_begin + chunks_per_split);
     const bool resident = (ch_end - ch_begin) == 1;      // this workgroup's only chunk stays in LDS

@@ -140,11 +140,14 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     constexpr int FT_BYTES = kCTmax * Q2 * 2 * 1024;
     const int e_w = reinterpret_cast<const int*>(pack)[1];
     const unsigned char* gw = pack + kHdrBytes;
+    // global -> LDS by LDS-DMA (lds_dma_1k, split_common.h): one KiB per wave and instruction, no register round trip
+    const unsigned lds_w = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)s_w);
     auto stage = [&](int ft0, int nft) {
-        const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)ft0 * FT_BYTES);
-        uint4* dst = reinterpret_cast<uint4*>(s_w);
-        const int n16 = nft * FT_BYTES / 16;
-        for (int i = tid; i < n16; i += 512) dst[i] = src[i];
+        const unsigned char* src = gw + (size_t)ft0 * FT_BYTES;
+        const int nblk = nft * (FT_BYTES / 1024);
+        for (int blk = wave; blk < nblk; blk += 8)
+            lds_dma_1k(src + (size_t)blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_w + blk * 1024));
+        lds_dma_wait();
     };
     const int ft_begin = blockIdx.y * ft_per_block, ft_end = min(FT, ft_begin + ft_per_block);
     if (resident) stage(ft_begin, ft_end - ft_begin);
@@ -461,11 +464,17 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
     constexpr int FT_BYTES = kCTmax * Q2 * 2 * 1024;
     const int e_w = reinterpret_cast<const int*>(pack)[1];
     const unsigned char* gw = pack + kHdrBytes;
+    // global -> LDS by LDS-DMA (lds_dma_1k, split_common.h), one KiB per wave and instruction: copied through registers
+    // (global_load / s_waitcnt / ds_write by 512 threads between the two barriers) the two windows of the 8 feature tiles
+    // were 23 % of this kernel at 128 -> 128.  (A double-buffered, overlapped form -- as in kan_sparse_fwd.hip -- costs
+    // ~50 more registers than this kernel has: profiles/r02_experiments.md.)
+    const unsigned lds_w = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)s_w);
     auto stage = [&](int tile, int nslots) {                     // [c][q][hi|lo] order: the first nslots slots are a prefix
-        const uint4* src = reinterpret_cast<const uint4*>(gw + (size_t)tile * FT_BYTES);
-        uint4* dst = reinterpret_cast<uint4*>(s_w);
-        const int n16 = nslots * Q2 * 2 * 1024 / 16;
-        for (int i = tid; i < n16; i += 512) dst[i] = src[i];
+        const unsigned char* src = gw + (size_t)tile * FT_BYTES;
+        const int nblk = nslots * Q2 * 2;
+        for (int blk = wave; blk < nblk; blk += 8)
+            lds_dma_1k(src + blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_w + blk * 1024));
+        lds_dma_wait();
     };
     __syncthreads();
     const FastGeom fgeo = fast_geom(s_knots, nknots);
