@@ -56,6 +56,58 @@ __global__ __launch_bounds__(256) void fastkan_stats_kernel(const float* __restr
     if (l == 0 && row < N) { stats[2 * row] = mean; stats[2 * row + 1] = rsqrtf(v / (float)in + eps); }
 }
 
+// the same for rows of <= 64 NV features: a lane keeps its NV groups of 4 consecutive features in registers -- ONE pass
+// over x, 16-byte loads when VEC (the scalar two-pass form above read every row twice: 114 us vs the 256 MB / ~4.5 TB/s
+// = 57 us of a single pass at 1M x 64).  VEC or not, the same values meet in the same order: a column slice of a wider
+// activation (unaligned) gives the bits of its contiguous copy.
+template <int NV, bool VEC>
+__global__ __launch_bounds__(256) void fastkan_stats_v4_kernel(const float* __restrict__ x, long ldx, long N,
+                                                               int in, float eps, float* __restrict__ stats) {
+    const long row = (blockIdx.x * 256L + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    const float* xr = x + min(row, N - 1) * ldx;
+    float v[NV][4];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = 4 * l + 64 * j;
+        if (VEC) {
+            const float4 t = c < in ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[j][i] = c + i < in ? xr[c + i] : 0.0f;
+        }
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)in;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = (4 * l + 64 * j + i < in) ? v[j][i] - mean : 0.0f;
+            q = fmaf(d, d, q);
+        }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    if (l == 0 && row < N) { stats[2 * row] = mean; stats[2 * row + 1] = rsqrtf(q / (float)in + eps); }
+}
+
+static int launch_stats(const float* x, long ldx, long N, int in, float eps, float* stats, hipStream_t st) {
+    const bool vec = (in & 3) == 0 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const int grid = cdiv(N, 16);
+#define L(NV) do { if (vec) fastkan_stats_v4_kernel<NV, true><<<grid, 256, 0, st>>>(x, ldx, N, in, eps, stats); \
+                   else fastkan_stats_v4_kernel<NV, false><<<grid, 256, 0, st>>>(x, ldx, N, in, eps, stats); } while (0)
+    if (in <= 64) L(1); else if (in <= 128) L(2); else if (in <= 256) L(4);
+    else fastkan_stats_kernel<<<grid, 256, 0, st>>>(x, ldx, N, in, eps, stats);
+#undef L
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 static bool fk_split(int in, int out, int ng, int mode) { return mode == 1 && kan_split_fwd_ok(in, out, ng, 0); }
 
 static RbfArgs fk_rbf(const float* centers, int ng, float den, const float* lnw, const float* lnb,
@@ -355,15 +407,51 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     }
 }
 
-// column sums of gy (g_base_bias): block b sums rows [b*rpb, ...) for all columns
+// column sums of gy (g_base_bias): workgroup b sums rows [b*rpb, ...) for all columns.  Thread = (row slot, 4 consecutive
+// columns): the 256 / (F/4) row slots walk the rows in parallel with 16-byte loads and meet in LDS in slot order
+// (deterministic).  (One thread per column walking ~1000 rows serially -- 64 active lanes per workgroup at F = 64 -- took
+// 405 us per call at 1M x 64: 17 % of the FastKAN-GIN layer step.)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, long lda,
                                                              long N, int F, long rpb,
                                                              float* __restrict__ partial) {
+    __shared__ float4 s_red[256];
     const long r0 = blockIdx.x * rpb, r1 = min(N, r0 + rpb);
-    for (int f = threadIdx.x; f < F; f += 256) {
-        float s = 0.0f;
-        for (long r = r0; r < r1; ++r) s += a[r * lda + f];
-        partial[blockIdx.x * (long)F + f] = s;
+    const int cl = min(256, cdiv(F, 4)), rs = 256 / cl;          // column groups per pass, row slots
+    const int cg = threadIdx.x % cl, slot = threadIdx.x / cl;
+    const bool vec = ((F & 3) == 0) && ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+    for (int c0 = 0; c0 < F; c0 += 4 * cl) {                     // F > 1024: more than one pass (uniform trip count)
+        const int c = c0 + 4 * cg;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot < rs && c < F) {
+            if (vec) {
+                for (long r = r0 + slot; r < r1; r += rs) {
+                    const float4 v = *reinterpret_cast<const float4*>(a + r * lda + c);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            } else {
+                for (long r = r0 + slot; r < r1; r += rs) {
+                    const float* row = a + r * lda + c;
+                    acc.x += row[0];
+                    if (c + 1 < F) acc.y += row[1];
+                    if (c + 2 < F) acc.z += row[2];
+                    if (c + 3 < F) acc.w += row[3];
+                }
+            }
+        }
+        __syncthreads();
+        s_red[threadIdx.x] = acc;
+        __syncthreads();
+        if (slot == 0 && c < F) {
+            for (int k = 1; k < rs; ++k) {                       // fixed order over the row slots
+                const float4 v = s_red[k * cl + cg];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            float* o = partial + blockIdx.x * (long)F + c;
+            o[0] = acc.x;
+            if (c + 1 < F) o[1] = acc.y;
+            if (c + 2 < F) o[2] = acc.z;
+            if (c + 3 < F) o[3] = acc.w;
+        }
     }
 }
 
@@ -454,10 +542,7 @@ int fastkan_fwd(const float* x, long ldx, long N, int in, int out, int ng, const
     if (ws_bytes < fastkan_fwd_ws_bytes(N, in, out, ng, mode)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "fastkan_fwd");
     if (lnw && !stats) return fail(KAGNN_ERR_ARG, "%s: row_stats is required with layernorm", "fastkan_fwd");
     if (fk_split(in, out, ng, mode)) {
-        if (lnw) {
-            fastkan_stats_kernel<<<cdiv(N, 16), 256, 0, st>>>(x, ldx, N, in, eps, stats);
-            KAGNN_LAUNCH_CHECK();
-        }
+        if (lnw) { int rc = launch_stats(x, ldx, N, in, eps, stats, st); if (rc) return rc; }
         { int rc = kan_split_pack_fwd_noscale(bw, sw, nullptr, in, out, ng, ws, st); if (rc) return rc; }
         char* part = static_cast<char*>(ws) + al256(kan_split_pack_fwd_bytes(in, out, ng));
         return kan_split_fwd_any(x, ldx, N, nullptr, in, out, ng, 0, ws, y, ldy,
@@ -507,7 +592,7 @@ static FkBwdPlan fk_plan(long N, int in, int out, int ng, int mode) {
     }
     p.ln_blocks = (int)max(1L, min(2048L, (N + 15) / 16));       // >= 4 rows per wave, up to 8192 waves
     p.lnpart = al256((size_t)p.ln_blocks * 2 * in * 4);
-    p.col_blocks = (int)max(1L, min(1024L, N / 64 + 1));
+    p.col_blocks = (int)max(1L, min(512L, N / 256 + 1));
     p.col_rpb = (N + p.col_blocks - 1) / p.col_blocks;
     p.colpart = al256((size_t)p.col_blocks * out * 4);
     p.total = p.pack_f + p.pack_d + p.gz + p.gcat + p.slab + p.lnpart + p.colpart;
