@@ -387,22 +387,24 @@ static int launch_ln_bwd(int blocks, const float* x, long ldx, const float* gz, 
     return KAGNN_OK;
 }
 
-// out[j] = sum_w partial[w*stride + j], j < n  (fixed order).  One workgroup = 32 columns x 8 row groups;
+// out[j] = sum_w partial[w*stride + j], j < n  (fixed order).  One workgroup = 32 columns x 32 row groups (1024 threads:
+// with 8 groups the ~2000 partial rows were a 256-deep chain of dependent loads per thread, 51 us per call);
 // the groups are combined through LDS in a fixed order, so the result is deterministic.
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, long W, long stride, long n,
-                                                           float* __restrict__ out0, float* __restrict__ out1, long split) {
-    __shared__ float s_p[8][33];
+constexpr int kSumGroups = 32;
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ partial, long W, long stride, long n,
+                                                            float* __restrict__ out0, float* __restrict__ out1, long split) {
+    __shared__ float s_p[kSumGroups][33];
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const long j = blockIdx.x * 32L + c;
     float a = 0.0f;
     if (j < n)
-        for (long w = rg; w < W; w += 8) a += partial[w * stride + j];
+        for (long w = rg; w < W; w += kSumGroups) a += partial[w * stride + j];
     s_p[rg][c] = a;
     __syncthreads();
     if (rg == 0 && j < n) {
         float t = s_p[0][c];
 #pragma unroll
-        for (int g = 1; g < 8; ++g) t += s_p[g][c];
+        for (int g = 1; g < kSumGroups; ++g) t += s_p[g][c];
         if (j < split) out0[j] = t; else out1[j - split] = t;
     }
 }
@@ -629,7 +631,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
         if (lnw) {
             LnArgs ln{lnw, lnb, eps};
             { int rc = launch_ln_bwd(p.ln_blocks, x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart, st); if (rc) return rc; }
-            sum_partials_kernel<<<cdiv(2L * in, 32), 256, 0, st>>>(lnpart, p.ln_blocks, 2L * in, 2L * in, g_lnw, g_lnb, in);
+            sum_partials_kernel<<<cdiv(2L * in, 32), 32 * kSumGroups, 0, st>>>(lnpart, p.ln_blocks, 2L * in, 2L * in, g_lnw, g_lnb, in);
             KAGNN_LAUNCH_CHECK();
         }
         { int rc = kan_split_dw_any(x, ldx, gy, ldgy, N, nullptr, in, out, ng, 0, sw, nullptr, g_bw, g_sw, nullptr,
@@ -637,7 +639,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
         if (g_bb) {
             colsum_partial_kernel<<<p.col_blocks, 256, 0, st>>>(gy, ldgy, N, out, p.col_rpb, colpart);
             KAGNN_LAUNCH_CHECK();
-            sum_partials_kernel<<<cdiv(out, 32), 256, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
+            sum_partials_kernel<<<cdiv(out, 32), 32 * kSumGroups, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
             KAGNN_LAUNCH_CHECK();
         }
         return KAGNN_OK;
@@ -659,7 +661,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
     }
     if (lnw) {
         { int rc = launch_ln_bwd(p.ln_blocks, x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart, st); if (rc) return rc; }
-        sum_partials_kernel<<<cdiv(2L * in, 32), 256, 0, st>>>(lnpart, p.ln_blocks, 2L * in, 2L * in, g_lnw, g_lnb, in);
+        sum_partials_kernel<<<cdiv(2L * in, 32), 32 * kSumGroups, 0, st>>>(lnpart, p.ln_blocks, 2L * in, 2L * in, g_lnw, g_lnb, in);
         KAGNN_LAUNCH_CHECK();
     }
     dim3 grid(p.nb, FT * OTt);
@@ -671,7 +673,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
     if (g_bb) {
         colsum_partial_kernel<<<p.col_blocks, 256, 0, st>>>(gy, ldgy, N, out, p.col_rpb, colpart);
         KAGNN_LAUNCH_CHECK();
-        sum_partials_kernel<<<cdiv(out, 32), 256, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
+        sum_partials_kernel<<<cdiv(out, 32), 32 * kSumGroups, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
         KAGNN_LAUNCH_CHECK();
     }
     return KAGNN_OK;
