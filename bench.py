@@ -3,7 +3,7 @@
 (sum-aggregate + KAN([F,F,F])) forward AND backward on the synthetic power-law graph of
 SURVEY.md 8(d) (1M nodes / 10M edges, fp32 I/O).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|config3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|config3|fastkan]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One JSON line on stdout (rank 0).  Besides the contract's fields it carries
@@ -45,6 +45,8 @@ WORKLOADS = {
     # name: (hidden, grid) -- N / E / order come from the flags (defaults 1M / 10M / 3)
     "headline": (64, 5),       # BASELINE.json metric: hidden=64 grid=5
     "config3": (128, 8),       # BASELINE.json configs[2]: hidden=128 grid=8 (the 8-GPU config)
+    "fastkan": (64, 8),        # the RBF-basis twin of the headline layer (BASELINE.json configs[4]'s kernel path): FastKAN-GIN,
+                               # hidden 64, 8 grids -- BASELINE.md section 2 holds the reference CPU time of this very layer
 }
 
 
@@ -100,7 +102,7 @@ def _mem_available_gb():
     return 0.0
 
 
-def cpu_baseline(n_sample, e_sample, f, grid, order, seed=0, full=False):
+def cpu_baseline(n_sample, e_sample, f, grid, order, seed=0, full=False, arch="kan"):
     """The reference's algorithm (oracle/kan_oracle.py: dense bases, F.linear, index_select + scatter_add_, stock
     autograd) on the host cores, on a bounded sample of the same workload (same graph recipe, 1/10 of the nodes and
     edges by default: ~4 s and ~5 GB per pass; the full 1M / 10M layer needs ~45 GB and ~40 s per pass -- `--cpu-full`
@@ -111,7 +113,26 @@ def cpu_baseline(n_sample, e_sample, f, grid, order, seed=0, full=False):
     ei = orc.powerlaw_graph(n_sample, e_sample, seed=seed)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n_sample, f, generator=g) * 0.25
-    layers = [orc.init_kan_linear(f, f, grid, order, g) for _ in range(2)]
+    if arch == "fastkan":
+        import math
+
+        def init_fastkan(fi, fo):            # the reference's shapes and scales (fastkan.py:60-75); RNG stream not matched
+            return {"layernorm.weight": torch.ones(fi), "layernorm.bias": torch.zeros(fi),
+                    "rbf.grid": torch.linspace(-2.0, 2.0, grid),
+                    "spline_linear.weight": torch.randn(fo, fi * grid, generator=g) * 0.1,
+                    "base_linear.weight": (torch.rand(fo, fi, generator=g) * 2 - 1) / math.sqrt(fi),
+                    "base_linear.bias": (torch.rand(fo, generator=g) * 2 - 1) / math.sqrt(fi)}
+        fk = [init_fastkan(f, f) for _ in range(2)]
+
+        def layer_pass():
+            xr = x.clone().requires_grad_(True)
+            ps = [{k: (v.clone().requires_grad_(True) if k != "rbf.grid" else v) for k, v in p.items()} for p in fk]
+            orc.gin_conv(xr, ei, lambda h: orc.fastkan_forward(h, ps)).sum().backward()
+    else:
+        layers = [orc.init_kan_linear(f, f, grid, order, g) for _ in range(2)]
+
+        def layer_pass():
+            orc.kan_gin_layer_fwd_bwd(x, ei, layers, order)
     host, phys = os.cpu_count() or 1, _physical_cores()
     sweep = sorted({min(t, host) for t in (8, 32, 64, phys)})
     if full:
@@ -120,11 +141,11 @@ def cpu_baseline(n_sample, e_sample, f, grid, order, seed=0, full=False):
     best, best_threads, tried = float("inf"), 1, []
     for th in sweep:
         torch.set_num_threads(th)
-        orc.kan_gin_layer_fwd_bwd(x, ei, layers, order)              # warm-up (allocator, thread pool)
+        layer_pass()                                                 # warm-up (allocator, thread pool)
         runs = []
         for _ in range(1 if full else 3):
             t0 = time.perf_counter()
-            orc.kan_gin_layer_fwd_bwd(x, ei, layers, order)
+            layer_pass()
             runs.append(time.perf_counter() - t0)
         tried.append({"threads": th, "best_s": round(min(runs), 3), "runs_s": [round(r, 3) for r in runs]})
         if min(runs) < best:
@@ -283,6 +304,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    if world > 1 and args.workload == "fastkan":
+        raise SystemExit("--workload fastkan is a single-GPU figure (the sharded layers of kagnn_amd/sharded.py wrap the KAN-GIN layer)")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -305,7 +328,11 @@ def main():
     x_full = torch.randn(n, f, generator=gen) * 0.25
     gy_full = torch.randn(n, f, generator=torch.Generator().manual_seed(1))
     torch.manual_seed(0)
-    conv = kagnn_amd.GIKANLayer(f, f, grid_size=grid, spline_order=args.order, hidden_dim=f, nb_layers=2)
+    fastkan = args.workload == "fastkan"
+    if fastkan:
+        conv = kagnn_amd.GIFASTKANLayer(f, f, grid_size=grid, hidden_dim=f, nb_layers=2)
+    else:
+        conv = kagnn_amd.GIKANLayer(f, f, grid_size=grid, spline_order=args.order, hidden_dim=f, nb_layers=2)
     graph = ops.GraphIndex(ei, n)
 
     def sync():
@@ -421,7 +448,7 @@ def main():
 
     if rank == 0:
         prof = timer.summary()
-        c = grid + args.order
+        c = grid if fastkan else grid + args.order          # coefficients (RBF centres) per input feature
         fl = f // world if world > 1 else f
         per_step = {k: v["total_ms"] / PROFILE_STEPS for k, v in warm.items()}
         dom = only if only in prof else max(per_step, key=per_step.get)
@@ -436,6 +463,10 @@ def main():
             "kagnn_kan_linear_fwd": ("KANLinear forward", 4.0 * nrows * (fl + f), kan),
             "kagnn_kan_linear_bwd_input": ("KANLinear input gradient (reads x, gy; writes gx)", 4.0 * nrows * (2 * fl + f), kan),
             "kagnn_kan_linear_bwd_weight": ("KANLinear weight gradient (reads x, gy)", 4.0 * nrows * (fl + f), kan),
+            "kagnn_fastkan_fwd": ("FastKANLayer forward (LayerNorm statistics, RBF expansion, both linear maps, bias)",
+                                  4.0 * nrows * (fl + f) + 8.0 * nrows, kan),
+            "kagnn_fastkan_bwd": ("FastKANLayer backward (input gradient through the LayerNorm, LayerNorm / spline / base weight and "
+                                  "bias gradients)", 4.0 * nrows * (3 * fl + 2 * f), 2.0 * kan),
         }
         kernels = []
         for name, (what, nbytes, flops) in spec.items():
@@ -475,8 +506,10 @@ def main():
             "vs_baseline": None, "dtype": ("f32" if fp32_mode else "f32 (fp16 hi/lo split operands, fp32 accumulate)") +
                                           (" + bf16 gather operands (KAGNN_ACT=bf16, build-defined config-2 mode)" if args.act == "bf16" else ""),
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: KAN-GIN conv layer fwd+bwd (aggregate + KAN([{f},{f},{f}]) grid={grid} order={args.order}), "
-                                   f"power-law graph N={n} E={e} seed 0 (SURVEY 8(d))",
+            "config": {"workload": (f"{args.workload}: FastKAN-GIN conv layer fwd+bwd (aggregate + FastKAN([{f},{f},{f}]) num_grids={grid}), "
+                                    if fastkan else
+                                    f"{args.workload}: KAN-GIN conv layer fwd+bwd (aggregate + KAN([{f},{f},{f}]) grid={grid} order={args.order}), ")
+                                   + f"power-law graph N={n} E={e} seed 0 (SURVEY 8(d))",
                        "nodes": n, "edges": e, "hidden": f, "grid_size": grid, "spline_order": args.order,
                        "precision": args.precision, "activation_storage": args.act, "parallelism": parallelism},
             "layer_algorithmic_bytes": layer_bytes(n, e, f),
@@ -496,14 +529,15 @@ def main():
             roof["frac_of_copy_bw"] = (roof["achieved"] / copy_gbs) if roof["unit"] == "GB/s" else None
             for k in kernels:
                 k["hbm_frac_of_copy_bw"] = k["hbm_GBs"] / copy_gbs
-        if not args.no_extras and world == 1:
+        if not args.no_extras and world == 1 and not fastkan:
             out["secondary"] = secondary_figures(dev, conv, graph, x.detach().float(), n, e, f, grid, args.order)
             conv_ms = 3 * ms
             out["secondary"]["model_step"]["conv_layers_share"] = conv_ms / out["secondary"]["model_step"]["ms_per_step"]
         if not args.no_traffic and world == 1:
             torch.cuda.synchronize()
             prefix = {"kagnn_aggregate_sum": "agg_rows", "kagnn_kan_linear_fwd": "kan_sparse_fwd",
-                      "kagnn_kan_linear_bwd_input": "kan_split_dx", "kagnn_kan_linear_bwd_weight": "kan_split_dw"}.get(dom, "agg_rows")
+                      "kagnn_kan_linear_bwd_input": "kan_split_dx", "kagnn_kan_linear_bwd_weight": "kan_split_dw",
+                      "kagnn_fastkan_fwd": "kan_split_fwd", "kagnn_fastkan_bwd": "kan_split_dw"}.get(dom, "agg_rows")
             traffic, detail = measure_traffic(args, prefix)
             roof["traffic"] = traffic
             roof["traffic_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes spawned by this run over 2 steps of the same "
@@ -513,10 +547,11 @@ def main():
                 out["traffic_per_kernel_bytes"] = detail
         if not args.no_cpu_baseline and world == 1:
             if args.cpu_full and _mem_available_gb() >= 48:
-                out["cpu_baseline"] = cpu_baseline(n, e, f, grid, args.order, full=True)
+                out["cpu_baseline"] = cpu_baseline(n, e, f, grid, args.order, full=True, arch="fastkan" if fastkan else "kan")
             else:
                 ns = min(args.cpu_sample, n)
-                out["cpu_baseline"] = cpu_baseline(ns, ns * (e // n if n else 10), f, grid, args.order)
+                out["cpu_baseline"] = cpu_baseline(ns, ns * (e // n if n else 10), f, grid, args.order,
+                                                   arch="fastkan" if fastkan else "kan")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

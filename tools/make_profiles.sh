@@ -28,5 +28,6 @@ tools/prof_model.sh > $OUT/${TAG}_model_step_kernel_trace.txt 2>&1
 KAGNN_ACT=bf16 python tools/configs_sweep.py 2 2>/dev/null | grep "cfg2 " > $OUT/${TAG}_config2_bf16.txt
 python bench.py --act bf16 --no-cpu-baseline --no-extras --no-fp32 2>/dev/null | tail -1 > $OUT/${TAG}_bench_bf16_gather.json
 python bench.py --workload config3 --no-cpu-baseline --no-extras --no-traffic 2>/dev/null | tail -1 > $OUT/${TAG}_bench_config3.json
+python bench.py --workload fastkan 2>/dev/null | tail -1 > $OUT/${TAG}_bench_fastkan.json
 rm -rf $R/gpurun_out/prof_${TAG}* 
 ls -la $OUT
