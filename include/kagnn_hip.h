@@ -43,7 +43,7 @@ extern "C" {
 #define KAGNN_DTYPE_F32 0
 #define KAGNN_DTYPE_BF16 1
 
-int kagnn_version(void);
+int kagnn_version(void);          /* 210 = this header (200 + column moments / dropout arguments, kagnn_kan_linear_fwd_moments) */
 const char* kagnn_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
