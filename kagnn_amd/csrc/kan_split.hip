@@ -128,18 +128,27 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
     if (K == 4) build_perm_fix_table(s_tbl, tid);
     const float post = reinterpret_cast<const float*>(pack)[0];
     const unsigned char* gw = pack + kHdrBytes;
-    // global -> LDS by LDS-DMA (lds_dma_1k, split_common.h): one KiB per wave and instruction, no register round trip
-    static_assert(CHUNK_BYTES % 1024 == 0, "whole KiB pieces");
+    // Packed W lives in LDS as two HALVES of a chunk (NG / 2 feature groups each: their MFMA steps + SiLU fragments),
+    // filled by LDS-DMA (lds_dma_1k, split_common.h).  One chunk: both halves are loaded once and stay.  More chunks: the
+    // halves are a double buffer -- the next half (of this chunk, the next chunk, or the next row tile's first chunk)
+    // streams in while the waves work through this one; one barrier per half (as in kan_sparse_fwd.hip).
+    constexpr int GPH = NG / 2, HALF_SPL = (SPC / 2) * OT * 2 * 1024, HALF_BASE = (BPC / 2) * OT * 3 * 1024;
+    constexpr int HALF_BYTES = HALF_SPL + HALF_BASE, SPL_BYTES = SPC * OT * 2 * 1024;
+    static_assert(NG % 2 == 0 && 2 * HALF_BYTES == CHUNK_BYTES, "two halves of NG / 2 groups");
     const unsigned lds_w = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)s_w);
-    auto stage_chunk = [&](int ch) {
+    auto dma_half = [&](int ch, int h) {
         const unsigned char* src = gw + (size_t)ch * CHUNK_BYTES;
-        for (int blk = wave; blk < CHUNK_BYTES / 1024; blk += NT / 64)
-            lds_dma_1k(src + blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_w + blk * 1024));
-        lds_dma_wait();
+        const unsigned dst = lds_w + h * HALF_BYTES;
+        for (int blk = wave; blk < HALF_SPL / 1024; blk += NT / 64)
+            lds_dma_1k(src + h * HALF_SPL + blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(dst + blk * 1024));
+        for (int blk = wave; blk < HALF_BASE / 1024; blk += NT / 64)
+            lds_dma_1k(src + SPL_BYTES + h * HALF_BASE + blk * 1024 + lane * 16,
+                       __builtin_amdgcn_readfirstlane(dst + HALF_SPL + blk * 1024));
     };
     const int ch_begin = split * chunks_per_split, ch_end = min(nchunks, ch_begin + chunks_per_split);
     const bool resident = (ch_end - ch_begin) == 1;      // this workgroup's only chunk stays in LDS
-    if (resident) stage_chunk(ch_begin);
+    dma_half(ch_begin, 0);
+    if (resident) { dma_half(ch_begin, 1); lds_dma_wait(); }
     y += (long)split * part_stride;
     __syncthreads();
     SplineGeom geom{}; Frag3Geom f3geo{};
@@ -185,13 +194,19 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
         }
 
         for (int ch = ch_begin; ch < ch_end; ++ch) {
-            if (!resident) {
-                __syncthreads();
-                stage_chunk(ch);
-                __syncthreads();
-            }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
+                const unsigned char* hb = s_w + (g / GPH) * HALF_BYTES;       // this group's half buffer
+                const int gl = g % GPH;                                        // group inside the half
+                if (!resident && gl == 0) {
+                    // my pieces of this half have landed; after the barrier so have everyone's, and everyone is done with
+                    // the other buffer -- which the half after this one now streams into
+                    lds_dma_wait();
+                    __syncthreads();
+                    if (g == 0) dma_half(ch, 1);
+                    else if (ch + 1 < ch_end) dma_half(ch + 1, 0);
+                    else if ((tile + gridDim.x) * ROWS < N) dma_half(ch_begin, 0);
+                }
                 float xv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = xn[j];
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                     {
                         frag3_index<false>(xv[0], f3geo, u, off_even);
                         const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + off_even);
-                        const unsigned char* wp = s_w + (size_t)((8 * g) * OT) * 2 * 1024 + lane * 16;
+                        const unsigned char* wp = hb + (size_t)((8 * gl) * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
                         for (int i = 0; i < 2 * OT; ++i) bw[i] = *reinterpret_cast<const u32x4*>(wp + i * 1024);
                         frag3_payload(u, h0, h1, l0, l1);
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                             if (reuse) off = off_even + wodd;
                             else { frag3_index<false>(xv[j + 1], f3geo, u, off_even); off = off_even; }
                             sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + off);
-                            const unsigned char* wp = s_w + (size_t)((8 * g + j + 1) * OT) * 2 * 1024 + lane * 16;
+                            const unsigned char* wp = hb + (size_t)((8 * gl + j + 1) * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
                             for (int i = 0; i < 2 * OT; ++i) nbw[i] = *reinterpret_cast<const u32x4*>(wp + i * 1024);
                         }
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                         }
                     }
                     {
-                        const unsigned char* wp = s_w + (size_t)SPC * OT * 2 * 1024 + (size_t)(g * OT) * 3 * 1024 + lane * 16;
+                        const unsigned char* wp = hb + HALF_SPL + (size_t)(gl * OT) * 3 * 1024 + lane * 16;
 #pragma unroll
                         for (int t = 0; t < OT; ++t) {
                             const u32x4 w1 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 0) * 1024);
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int s = 8 * g + j;
+                    const int s = 8 * gl + j;                   // step inside the half
                     u32x4 ahi, alo;
                     if constexpr (K == 0) {
                         const float z = rb.ln_w ? fmaf((xv[j] - mean) * rstd, gam[j], bet[j]) : xv[j];
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                     } else {
                         make_spline_frag<K>(xv[j], s_knots, s_tbl, geom, ahi, alo, (j & 1) ? wodd : 0u);
                     }
-                    const unsigned char* wp = s_w + (size_t)(s * OT) * 2 * 1024 + lane * 16;
+                    const unsigned char* wp = hb + (size_t)(s * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
                     for (int t = 0; t < OT; ++t) {
                         const u32x4 bhi = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 0) * 1024);
@@ -301,7 +316,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
                     for (int j = 0; j < 8; ++j) sv[j] = (siluf(xv[j]) + (xv[j] - xv[j])) * kAScale;
                     u32x4 a1, a2, a3;
                     split_bf16x3(sv, a1, a2, a3);
-                    const unsigned char* wp = s_w + (size_t)SPC * OT * 2 * 1024 + (size_t)(g * OT) * 3 * 1024 + lane * 16;
+                    const unsigned char* wp = hb + HALF_SPL + (size_t)(gl * OT) * 3 * 1024 + lane * 16;
 #pragma unroll
                     for (int t = 0; t < OT; ++t) {
                         const u32x4 w1 = *reinterpret_cast<const u32x4*>(wp + (t * 3 + 0) * 1024);
