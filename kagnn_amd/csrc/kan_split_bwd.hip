@@ -812,18 +812,22 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     unsigned xo = (unsigned)(8 * kg) * ldx4 + (unsigned)min(f, in - 1) * 4u, gvo[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) gvo[t] = (unsigned)(8 * kg) * ldgy4 + (unsigned)min(64 * oc + 16 * t + li, out - 1) * 4u;
+    // x (and the layernorm statistics) first, gy after: the x side of a chunk is expanded before its gy is looked at
+    // (expand_x / expand_gy below), so the 32 gy loads have the ~2500 cycles of that arithmetic on top of the MFMA section
+    // to arrive -- issued one chunk ahead and consumed right after the section, they left 22 % of this one-wave-per-SIMD
+    // kernel's cycles parked in s_waitcnt (a second chunk in flight does not fit the register file: 3.4 ms, spills)
     auto load_raw = [&](DwRaw& r) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            r.x[j] = gld_s(xb, xo, (unsigned)j * ldx4);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) r.g[t][j] = gld_s(gyb, gvo[t], (unsigned)j * ldgy4);
-        }
+        for (int j = 0; j < 8; ++j) r.x[j] = gld_s(xb, xo, (unsigned)j * ldx4);
         if (ln_on) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { r.mu[j] = gld(stb, sto + 8u * j); r.rs[j] = gld(stb, sto + 8u * j + 4u); }
             sto += 32u * 8u;
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r.g[t][j] = gld_s(gyb, gvo[t], (unsigned)j * ldgy4);
         xo += 32u * ldx4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) gvo[t] += 32u * ldgy4;
@@ -845,17 +849,9 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
             for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(r.g[t][j]));
         return exp_for_max(wave_max_nonneg(mx));
     };
-    // raw chunk -> fragments, with gy scaled by 2^(10 - Tfix) (Tfix >= the chunk's exponent)
-    auto expand = [&](const DwRaw& r, int Tfix) {
-        const float gs = ldexpf(1.0f, 10 - Tfix);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = r.g[t][j] * gs;
-            split_f16x2(v, bhi[t], blo[t]);
-        }
-        // ---- bases of 8 rows of this lane's feature (cubic splines: two rows per packed-fp32 evaluation)
+    // raw chunk -> fragments.  x side: bases of 8 rows of this lane's feature (cubic splines: two rows per packed-fp32
+    // evaluation) and the SiLU values
+    auto expand_x = [&](const DwRaw& r) {
         if constexpr (K == 3) {
 #pragma unroll
             for (int j = 0; j < 8; j += 2)
@@ -877,19 +873,33 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
         for (int j = 0; j < 8; ++j) { sv[j] = siluf(r.x[j]) * 16.0f; smx = fmaxf(smx, fabsf(sv[j])); }
         base32 = __any(!(smx < 60000.0f));              // wave-uniform; also catches NaN / Inf
         split_f16x2(sv, sah, sal);
+    };
+    // gy side, scaled by 2^(10 - Tfix) (Tfix >= the chunk's exponent)
+    auto expand_gy = [&](const DwRaw& r, int Tfix) {
+        const float gs = ldexpf(1.0f, 10 - Tfix);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = r.g[t][j] * gs;
+            split_f16x2(v, bhi[t], blo[t]);
+        }
         if (base32) {                                    // rare: do this chunk's base branch right here, in exact fp32
 #pragma unroll                                           // (4 rows per MFMA, k-lane kg <-> row 8*kg + j)
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j) {
+                const float sj = siluf(r.x[j]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    Df[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[j] * 0.0625f, r.g[t][j], Df[t], 0, 0, 0);
+                    Df[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sj, r.g[t][j], Df[t], 0, 0, 0);
+            }
         }
     };
 
     DwRaw raw;
     load_raw(raw);
+    expand_x(raw);
     T = chunk_exp(raw);
-    expand(raw, T);
+    expand_gy(raw, T);
     long n0 = rbeg;
     while (n0 < rend) {
         // ---- hot loop: the scale exponent T is FIXED in here, so the 160 accumulators are only ever touched by
@@ -923,8 +933,9 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
                 for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sal, bhi[t], Dh[t]);
             }
             if (n0 + 32 >= rend) { n0 += 32; break; }    // that was the last chunk
+            expand_x(raw);                               // (the MFMAs above were the last readers of the old fragments)
             if (chunk_exp(raw) > T) { grow = true; n0 += 32; break; }   // wave-uniform, rare
-            expand(raw, T);
+            expand_gy(raw, T);
         }
         if (grow) {                                      // the pending chunk needs a larger scale: rescale once, exactly
             const int ex = chunk_exp(raw);
@@ -934,7 +945,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) D[c][t] *= dn;
             T = ex;
-            expand(raw, T);
+            expand_gy(raw, T);
         }
     }
     // ---- slab write: D rows <-> features 4*kg + reg, cols <-> outputs li
