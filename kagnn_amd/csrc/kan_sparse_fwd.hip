@@ -44,7 +44,7 @@ size_t kan_sparse_pack_fwd_bytes(int in, int out, int C) { return (size_t)cdiv(o
 // K position p of a feature's 8-slot block holds coefficient slot slot_at(p): order [0,4,1,5,2,6,3,7]
 __host__ __device__ inline int slot_at(int p) { return (p >> 1) + 4 * (p & 1); }
 
-// chunk = [step t 16][out tile][hi|lo][lane 64][16 halfs]  +  base fragments [group 4][out tile][hi|lo][lane 64][8 halfs]
+// chunk = [step t 16][out tile][hi|lo][half 2][lane 64][8 halfs]  +  base fragments [group 4][out tile][hi|lo][lane 64][8 halfs]
 __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, const float* __restrict__ sw,
                                                   const float* __restrict__ sc, int in, int out, int C,
                                                   unsigned char* __restrict__ pack, float wscale, long first, long step) {
@@ -64,8 +64,10 @@ __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, 
             const int lane = r & 63; r >>= 6;
             const int ot = r % OT; const int t = r / OT;
             const int o = 32 * ot + (lane & 31), kg = lane >> 5;
-            _Float16* dh = reinterpret_cast<_Float16*>(cbase + ((size_t)(t * OT + ot) * 2 + 0) * 2048 + lane * 32 + h * 16);
-            _Float16* dl = reinterpret_cast<_Float16*>(cbase + ((size_t)(t * OT + ot) * 2 + 1) * 2048 + lane * 32 + h * 16);
+            // the two 16-byte halves of a lane's 32 bytes sit in separate KiB: each ds_read_b128 then walks the lanes at a
+            // 16-byte stride (at 32 bytes per lane half the LDS banks idle: 42 % of the forward's LDS cycles were conflicts)
+            _Float16* dh = reinterpret_cast<_Float16*>(cbase + ((size_t)(t * OT + ot) * 2 + 0) * 2048 + h * 1024 + lane * 16);
+            _Float16* dl = reinterpret_cast<_Float16*>(cbase + ((size_t)(t * OT + ot) * 2 + 1) * 2048 + h * 1024 + lane * 16);
             // element el = 8h + p holds K = 8*kg + p + 16*h: K block kg + 2h = feature #kg of A's lane half h
             const int f = ch * kSpCF + h * HF + 2 * t + kg;
             for (int p = 0; p < 8; ++p) {
@@ -291,11 +293,11 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     else frag3_index<false>(xv[2 * s + 1], f3geo, u1, o1);
                     e0 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + o0);
                     e1 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + o1);
-                    const unsigned char* wp = hb + (size_t)((4 * (g & 1) + s) * OT) * 2 * 2048 + lane * 32;
+                    const unsigned char* wp = hb + (size_t)((4 * (g & 1) + s) * OT) * 2 * 2048 + lane * 16;
 #pragma unroll
-                    for (int i = 0; i < 2 * OT; ++i) {      // [ot][hi|lo] x 32 bytes
+                    for (int i = 0; i < 2 * OT; ++i) {      // [ot][hi|lo] x two 16-byte halves, a KiB apart
                         w[2 * i] = *reinterpret_cast<const u32x4*>(wp + i * 2048);
-                        w[2 * i + 1] = *reinterpret_cast<const u32x4*>(wp + i * 2048 + 16);
+                        w[2 * i + 1] = *reinterpret_cast<const u32x4*>(wp + i * 2048 + 1024);
                     }
                 };
                 auto build = [&](int s, const u32x4& e0, const u32x4& e1, float u0, float u1, u32x4& hi, u32x4& lo, int& idx) {
