@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = raw[rt][q][j] * sc;
-                split_f16x2(v, ahi[rt][q], alo[rt][q]);
+                split_f16x2_asm(v, ahi[rt][q], alo[rt][q]);
             }
             const float mine = ldexpf(1.0f, e_w + rexp - 10);      // undo factor of this lane's row
 #pragma unroll
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = raw[q][j] * sc;
-                split_f16x2(v, ahi[rt][q], alo[rt][q]);
+                split_f16x2_asm(v, ahi[rt][q], alo[rt][q]);
             }
             const float mine = ldexpf(1.0f, e_w + rexp - 10);
 #pragma unroll

@@ -207,17 +207,22 @@ __device__ __forceinline__ float f16lo_to_f32(unsigned p) {
 __device__ __forceinline__ float f16hi_to_f32(unsigned p) {
     return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16));
 }
-// v - (float)half of p, in ONE instruction: v_fma_mix_f32 reads the fp16 half directly (op_sel picks it).  hipcc
-// forms it for about half of these sites and emits v_cvt_f32_f16 + v_sub_f32 for the rest.
+// v - (float)half of p, in ONE instruction: v_fma_mix_f32 reads the fp16 half directly (op_sel picks it).  Written as
+// fma(half, -1, v) hipcc folds the constant and emits v_cvt_f32_f16 + v_sub_f32; with a -1.0 it cannot see through (an SGPR
+// set by a side-effect-free asm: merged and hoisted like any other pure value) it forms the mixed-precision fma itself at
+// every site -- schedulable like any other instruction, and without the s_nop it pads every inline-asm statement with
+// (84 of them in the forward kernel when these were asm v_fma_mix_f32 statements).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float opaque_minus_one() {
+    float m;
+    asm("s_mov_b32 %0, 0xbf800000" : "=s"(m));
+    return m;
+}
 __device__ __forceinline__ float sub_f16lo(float v, unsigned p) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(v));
-    return r;
+    return __builtin_fmaf((float)__builtin_bit_cast(f16x2_t, p)[0], opaque_minus_one(), v);
 }
 __device__ __forceinline__ float sub_f16hi(float v, unsigned p) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(v));
-    return r;
+    return __builtin_fmaf((float)__builtin_bit_cast(f16x2_t, p)[1], opaque_minus_one(), v);
 }
 
 // 8 fp32 values (already scaled into fp16 range) -> hi and lo fp16 fragments
@@ -227,6 +232,20 @@ __device__ __forceinline__ void split_f16x2(const float (&v)[8], u32x4& hi, u32x
         const unsigned h = pk_f16_rtz(v[2 * q], v[2 * q + 1]);
         hi[q] = h;
         lo[q] = pk_f16_rtz(sub_f16lo(v[2 * q], h), sub_f16hi(v[2 * q + 1], h));
+    }
+}
+// The same with the residual as an inline-asm v_fma_mix_f32 statement: the input-gradient kernels keep this form (their gy
+// prologue measured 2.5 % faster with the statements pinned where they are written than with the compiler-scheduled form
+// above; the forward and the weight-gradient kernels the other way round, profiles/r02_experiments.md).
+__device__ __forceinline__ void split_f16x2_asm(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned h = pk_f16_rtz(v[2 * q], v[2 * q + 1]);
+        hi[q] = h;
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(v[2 * q]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(v[2 * q + 1]));
+        lo[q] = pk_f16_rtz(r0, r1);
     }
 }
 
