@@ -60,7 +60,11 @@ for it in range(cases):
             got.backward(gy.to(DEV))
             assert_close(got, want.detach(), what="fwd")
             for nme, a, w in zip(("xh", "att_src", "att_dst", "bias"), dl, leaves):
-                assert_close(a.grad, w.grad, what="g_" + nme)
+                # the attention-vector gradients are sums over all nodes of (logit gradient) x (features): where a node has one
+                # incoming edge its softmax is the constant 1 and the exact term is 0, so what fp32 adds up is rounding noise
+                # that grows like sqrt(n) -- scale the bound with it instead of comparing noise with 0 (n = 20 000, e = 0: 5e-5)
+                tol = 2e-5 * max(1.0, 0.05 * n ** 0.5) if nme.startswith("att_") else 2e-5
+                assert_close(a.grad, w.grad, tol, what="g_" + nme)
         print("ok  ", tag, flush=True)
     except Exception as ex:
         bad += 1
