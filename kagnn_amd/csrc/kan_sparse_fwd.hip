@@ -247,6 +247,11 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         lo0 = __builtin_amdgcn_perm(l1, l0, e[0]); lo1 = __builtin_amdgcn_perm(l1, l0, e[1]);
     };
 
+    // A lane half owns 32 of the chunk's 64 (virtual) features, 8 per group: with fewer than 25 features in a one-chunk layer
+    // (the input slices of the feature-sharded layer: 8 / 16 / 32 of 64; first layers on narrow inputs) the last groups
+    // carry only zero weights and are skipped -- the forward of an 8-feature slice took the 0.20 ms of a 64-feature layer.
+    const int inv_live = in << (SH ? 1 : 0);
+    const int ng_live = (resident && inv_live < HF) ? max(1, (inv_live + 7) / 8) : NG;
     float mom_n = 0.0f, mom_m[OT], mom_q[OT];          // this wave's rows so far: count, column mean, column M2
 #pragma unroll
     for (int t = 0; t < OT; ++t) { mom_m[t] = 0.0f; mom_q[t] = 0.0f; }
@@ -265,6 +270,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         for (int ch = ch_begin; ch < ch_end; ++ch) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
+                if (g >= ng_live) continue;                                // narrow layer: nothing but zero weights left
                 const unsigned char* hb = s_w + (g >> 1) * HALF_BYTES;     // this group's half buffer
                 if (!resident && (g & 1) == 0) {
                     // my pieces of this half have landed; after the barrier so have everyone's, and everyone is done with
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                 float xv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = xn[j];
-                if (g + 1 < NG) load8(tile * ROWS, ch, g + 1, xn);
+                if (g + 1 < ng_live) load8(tile * ROWS, ch, g + 1, xn);
                 else if (ch + 1 < ch_end) load8(tile * ROWS, ch + 1, 0, xn);
                 else load8((tile + gridDim.x) * ROWS, ch_begin, 0, xn);
 

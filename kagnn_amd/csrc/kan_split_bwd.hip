@@ -699,13 +699,14 @@ int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, c
 // ====================================================================== weight gradient
 bool kan_split_dw_ok(int in, int out, int G, int K) { return K >= 0 && K <= 4 && G + K <= 16; }   // K == 0: RBF basis
 
-struct DwPlan { int nbx; long rpw; long NS; long per; int FG, OC; long inP, outP; };
+struct DwPlan { int nbx; long rpw; long NS; long per; int FG, OC; long inP, outP; int rs; };
 
 // rows one dW workgroup may own: with leading dimensions up to kDwMaxLd floats its slice of x / gy spans < 4 GiB
 constexpr long kDwMaxRowsPerBlock = 1L << 17;
 
-static DwPlan split_dw_plan(long N, int in, int out, int C) {
+static DwPlan split_dw_plan(long N, int in, int out, int C, int K) {
     DwPlan p;
+    const bool virt = C > 8;
     if (C > 8) { in <<= 1; C = 8; }                    // virtual features: 2*in features of 8 slots (wcat_v)
     p.FG = cdiv(in, 64); p.OC = cdiv(out, 64);
     const int roles = p.FG * p.OC;
@@ -714,7 +715,11 @@ static DwPlan split_dw_plan(long N, int in, int out, int C) {
     r = max(32L, (r + 31) & ~31L);                     // whole 32-row chunks
     r = min(r, kDwMaxRowsPerBlock);                    // a workgroup's rows stay inside one 4 GiB buffer window
     nb = (int)max(1L, (long)cdiv(N, r));
-    p.nbx = nb; p.rpw = r; p.NS = nb;
+    // narrow layers (<= 32 features: the input slices of the feature-sharded layer, first layers on few features): a
+    // workgroup's four waves own four 16-feature tiles, so with 1 / 2 live tiles 3 / 2 of them would work on padding --
+    // they take row sub-ranges of the live tiles instead (rs per tile), each with a slab of its own
+    p.rs = (virt || !(K == 3 || K == 0)) ? 1 : in <= 16 ? 4 : in <= 32 ? 2 : 1;   // (built for the cubic and RBF kernels)
+    p.nbx = nb; p.rpw = r; p.NS = (long)nb * p.rs;
     p.inP = 32L * cdiv(in, 32); p.outP = 32L * cdiv(out, 32);
     p.per = (long)(C + 1) * p.inP * p.outP;
     return p;
@@ -732,14 +737,14 @@ static DwPlan split_dw_plan_w2(long N, int in, int out, int C) {
     r = max(32L, (r + 31) & ~31L);
     r = min(r, kDwMaxRowsPerBlock);
     nb = (int)max(1L, (long)cdiv(N, r));
-    p.nbx = nb; p.rpw = r; p.NS = nb;
+    p.nbx = nb; p.rpw = r; p.NS = nb; p.rs = 1;
     p.inP = 32L * cdiv(in, 32); p.outP = 32L * cdiv(out, 32);
     p.per = (long)(C + 1) * p.inP * p.outP;
     return p;
 }
 
 size_t kan_split_dw_ws_bytes(long N, int in, int out, int C, int K) {
-    const DwPlan p = kan_dw_w2_ok(in, out, C, K) ? split_dw_plan_w2(N, in, out, C) : split_dw_plan(N, in, out, C);
+    const DwPlan p = kan_dw_w2_ok(in, out, C, K) ? split_dw_plan_w2(N, in, out, C) : split_dw_plan(N, in, out, C, K);
     return (size_t)(p.NS + 1) * p.per * sizeof(float);
 }
 
@@ -753,11 +758,14 @@ size_t kan_split_dw_ws_bytes(long N, int in, int out, int C, int K) {
 // 256 architectural VGPRs, so nothing shuttles through AGPRs.
 struct DwRaw { float x[8]; float g[4][8]; float mu[8], rs[8]; };   // mu / rs: layernorm statistics (RBF basis only)
 
-template <int K, bool GEN>      // GEN == false: <= 8 coefficients, no virtual-feature code (see kan_split_dx_kernel)
+// RS (1, 2, 4): row sub-ranges per feature tile -- narrow layers with 4 / RS live tiles, see split_dw_plan (a template
+// parameter: as a runtime value it cost the 64-feature layer 45 %)
+template <int K, bool GEN, int RS = 1>      // GEN == false: <= 8 coefficients, no virtual-feature code (see kan_split_dx_kernel)
 __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots, int OC, long rows_per_block,
     long inP, long outP, float* __restrict__ slab, RbfArgs rb, int sh_arg /* 1: virtual features (wcat_v); then C == 8 */) {
+    constexpr int rs = RS;
     const int sh = GEN ? sh_arg : 0;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsHdr];
     float* s_knots = reinterpret_cast<float*>(smem);
@@ -770,7 +778,11 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     SplineGeom geom{}; FastGeom fgeo{};
     const int fg = blockIdx.y / OC, oc = blockIdx.y % OC;
     const int li = lane & 15, kg = lane >> 4;
-    const int fv = 64 * fg + 16 * wave + li;           // A side: this lane's (virtual) feature
+    // this wave's 16-feature tile and row sub-range.  The wave index goes through readfirstlane: the row range feeds the
+    // buffer descriptors, and a descriptor the compiler cannot prove wave-uniform turns every load into a waterfall loop
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int tile = RS == 1 ? wave : wave_u % (4 / rs), rsub = RS == 1 ? 0 : wave_u / (4 / rs);
+    const int fv = 64 * fg + 16 * tile + li;           // A side: this lane's (virtual) feature
     const int f = fv >> sh, win = fv & sh;             // input feature and slot window
     const unsigned woff = win ? kWinBytes : 0u;
     float ca[8] = {};
@@ -782,8 +794,10 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     }
     if constexpr (K > 0) { geom = geom_from_knots(s_knots, nknots); fgeo = fast_geom(s_knots, nknots); }
     const bool ln_on = (K == 0) && rb.ln_w != nullptr;           // wave-uniform
-    const long s = blockIdx.x;
-    const long rbeg = s * rows_per_block, rend = min(N, rbeg + rows_per_block);
+    const long s = (long)blockIdx.x * rs + rsub;       // slab of this (row block, sub-range)
+    const long sub_rows = ((rows_per_block / 32 + rs - 1) / rs) * 32;     // whole 32-row chunks per sub-range
+    const long rbeg = blockIdx.x * rows_per_block + rsub * sub_rows;
+    const long rend = min(min(N, (blockIdx.x + 1L) * rows_per_block), rbeg + sub_rows);
 
     f32x4 D[kCTmax][4];            // spline coefficients x 4 o-tiles, scaled by 2^(20 - T); plane kCTmax - 1: the base
                                    // weight through the fp16 path, scaled by 2^(14 - T).  (ONE array: as a separate
@@ -955,7 +969,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
         const long o = 64 * oc + 16 * t + li;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const long fl = 64 * fg + 16 * wave + 4 * kg + reg;
+            const long fl = 64 * fg + 16 * tile + 4 * kg + reg;
             if (fl < inP && o < outP) {
 #pragma unroll
                 for (int c = 0; c < kCTmax - 1; ++c)
@@ -1270,22 +1284,28 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
         return KAGNN_OK;
     }
     const int sh = C > 8 ? 1 : 0, Ck = sh ? 8 : C;          // slots per (virtual) feature the kernel stores
-    const DwPlan p = split_dw_plan(N, in, out, C);
+    const DwPlan p = split_dw_plan(N, in, out, C, K);
     if (ws_bytes < (size_t)(p.NS + 1) * p.per * sizeof(float)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "kan_split_dw");
     float* gcat = ws;
     float* slab = ws + p.per;
     dim3 grid(p.nbx, p.FG * p.OC);
-#define L(KK) if (sh) kan_split_dw_kernel<KK, true><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, Ck, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb, sh); \
-              else kan_split_dw_kernel<KK, false><<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, Ck, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb, 0)
+#define ARGS x, ldx, gy, ldgy, N, in, out, Ck, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb
+#define L(KK) if (sh) kan_split_dw_kernel<KK, true><<<grid, 256, 0, st>>>(ARGS, sh); \
+              else kan_split_dw_kernel<KK, false><<<grid, 256, 0, st>>>(ARGS, 0)
+#define LN(KK) if (p.rs == 4) kan_split_dw_kernel<KK, false, 4><<<grid, 256, 0, st>>>(ARGS, 0); \
+               else if (p.rs == 2) kan_split_dw_kernel<KK, false, 2><<<grid, 256, 0, st>>>(ARGS, 0); \
+               else { L(KK); }
     switch (K) {
-        case 0: L(0); break;
+        case 0: LN(0); break;
         case 1: L(1); break;
         case 2: L(2); break;
-        case 3: L(3); break;
+        case 3: LN(3); break;
         case 4: L(4); break;
         default: return fail(KAGNN_ERR_UNSUPPORTED, "%s: spline_order must be 1..4", "kan_split_dw");
     }
 #undef L
+#undef LN
+#undef ARGS
     KAGNN_LAUNCH_CHECK();
     if (!sh) {
         const int SG = max(1, min(3, 1024 / (32 * (C + 1))));

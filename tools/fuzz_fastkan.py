@@ -20,6 +20,9 @@ for it in range(cases):
     fo = rng.choice([1, 2, 5, 16, 32, 33, 64, 65, 128, 129, 200])
     ng = rng.choice([2, 3, 4, 5, 8, 9, 12, 16, 17, 24, 32])     # 1 divides by zero in the reference constructor too
     use_ln, use_base = rng.random() < 0.7, rng.random() < 0.7
+    # LayerNorm over <= 3 features is degenerate (2 features: the output is +-1 whatever the input, the exact input gradient is
+    # O(eps) and fp32 -- here and in the reference -- returns rounding noise amplified by rstd ~ 1/sqrt(var + eps))
+    use_ln = use_ln and fi >= 4
     mode = rng.choice([ops.PREC_SPLIT, ops.PREC_SPLIT, ops.PREC_FP32])
     tag = f"case {it}: n={n} in={fi} out={fo} ng={ng} ln={use_ln} base={use_base} mode={mode}"
     try:
