@@ -737,7 +737,8 @@ static DwPlan split_dw_plan_w2(long N, int in, int out, int C) {
     r = max(32L, (r + 31) & ~31L);
     r = min(r, kDwMaxRowsPerBlock);
     nb = (int)max(1L, (long)cdiv(N, r));
-    p.nbx = nb; p.rpw = r; p.NS = nb; p.rs = 1;
+    p.rs = in <= 16 ? 4 : in <= 32 ? 2 : 1;            // narrow layers: idle waves take row sub-ranges (split_dw_plan)
+    p.nbx = nb; p.rpw = r; p.NS = (long)nb * p.rs;
     p.inP = 32L * cdiv(in, 32); p.outP = 32L * cdiv(out, 32);
     p.per = (long)(C + 1) * p.inP * p.outP;
     return p;
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
 // = 224 registers for NS1 = 4.  Slabs are written in the plain [C+1][in][out] plane order, so the fused reduce / unpack
 // kernel of the <= 8-coefficient path finishes the job.  Per 32 rows x 16 input features x 64 outputs:
 // (8 + C - 8 + 1) * 12 MFMAs and ~850 VALU instead of 216 and ~1550.
-template <int NS1>
+template <int NS1, int RS = 1>      // RS: row sub-ranges per feature tile (narrow layers), as in kan_split_dw_kernel
 __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots, int OC, long rows_per_block,
@@ -1005,10 +1006,14 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
     const FastGeom fgeo = fast_geom(s_knots, nknots);
     const int fg = blockIdx.y / OC, oc = blockIdx.y % OC;
     const int li = lane & 15, kg = lane >> 4;
-    const int f = 64 * fg + 16 * wave + li;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // uniform: the row range feeds the buffer descriptors
+    const int tile = RS == 1 ? wave : wave_u % (4 / RS), rsub = RS == 1 ? 0 : wave_u / (4 / RS);
+    const int f = 64 * fg + 16 * tile + li;
     const int ns1 = C - 8;                                       // live slots of the second window (<= NS1)
-    const long s = blockIdx.x;
-    const long rbeg = s * rows_per_block, rend = min(N, rbeg + rows_per_block);
+    const long s = (long)blockIdx.x * RS + rsub;       // slab of this (row block, sub-range)
+    const long sub_rows = ((rows_per_block / 32 + RS - 1) / RS) * 32;
+    const long rbeg = blockIdx.x * rows_per_block + rsub * sub_rows;
+    const long rend = min(min(N, (blockIdx.x + 1L) * rows_per_block), rbeg + sub_rows);
 
     f32x4 D[kCTmax - 1][4];        // window 0: slots 0..7, scaled by 2^(20 - T)
     f32x4 D1[NS1 + 1][4];          // window 1: slots 8..8+NS1-1; plane NS1: the base weight through the fp16 path (2^(14 - T))
@@ -1179,7 +1184,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
         const long o = 64 * oc + 16 * t + li;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const long fl = 64 * fg + 16 * wave + 4 * kg + reg;
+            const long fl = 64 * fg + 16 * tile + 4 * kg + reg;
             if (fl < inP && o < outP) {
 #pragma unroll
                 for (int c = 0; c < kCTmax - 1; ++c)
@@ -1273,8 +1278,10 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
         const DwPlan p = split_dw_plan_w2(N, in, out, C);
         if (ws_bytes < (size_t)(p.NS + 1) * p.per * sizeof(float)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "kan_split_dw");
         float* slab = ws + p.per;
-        kan_split_dw_w2_kernel<4><<<dim3(p.nbx, p.FG * p.OC), 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p.OC, p.rpw,
-                                                                          p.inP, p.outP, slab);
+#define W2(RR) kan_split_dw_w2_kernel<4, RR><<<dim3(p.nbx, p.FG * p.OC), 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p.OC, \
+                                                                                    p.rpw, p.inP, p.outP, slab)
+        if (p.rs == 4) W2(4); else if (p.rs == 2) W2(2); else W2(1);
+#undef W2
         KAGNN_LAUNCH_CHECK();
         const int SG = max(1, min(3, 1024 / (32 * (C + 1))));
         kan_dw_reduce_unpack_kernel<<<dim3((unsigned)(p.outP / 32), (unsigned)in), 32 * (C + 1) * SG,
