@@ -178,6 +178,10 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
         }
     };
 
+    // one-chunk layers narrower than a lane half's HF features: the last 8-feature groups carry only zero weights (as in
+    // kan_sparse_fwd.hip)
+    const int inv_live = in << sh;
+    const int ng_live = (resident && inv_live < HF) ? max(1, (inv_live + 7) / 8) : NG;
     float xn[8];
     load8((long)blockIdx.x * ROWS, ch_begin, 0, xn);
     for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
         for (int ch = ch_begin; ch < ch_end; ++ch) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
+                if (g >= ng_live) continue;                                    // narrow layer: only zero weights left
                 const unsigned char* hb = s_w + (g / GPH) * HALF_BYTES;       // this group's half buffer
                 const int gl = g % GPH;                                        // group inside the half
                 if (!resident && gl == 0) {
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = xn[j];
                 // prefetch the next group: same chunk, next chunk, or the first group of this wave's next tile
-                if (g + 1 < NG) load8(tile * ROWS, ch, g + 1, xn);
+                if (g + 1 < ng_live) load8(tile * ROWS, ch, g + 1, xn);
                 else if (ch + 1 < ch_end) load8(tile * ROWS, ch + 1, 0, xn);
                 else load8((tile + gridDim.x) * ROWS, ch_begin, 0, xn);
 
