@@ -33,6 +33,48 @@ def test_library_exports_every_declared_symbol():
     assert lib.kagnn_version() >= 100
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """every prototype of include/kagnn_hip.h against the ctypes table of kagnn_amd/_lib.py: number of parameters, and per
+    parameter pointer / 64-bit integer / 32-bit integer / float / size_t -- a drifted signature would otherwise only show up
+    as garbage arguments on the GPU box"""
+    import ctypes
+    src = open(os.path.join(ROOT, "include", "kagnn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = dict(re.findall(r"\b(kagnn_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
+
+    def kind_c(param):
+        param = " ".join(param.split())
+        if "*" in param:
+            return "ptr"
+        if re.search(r"\b(int64_t|uint64_t)\b", param):
+            return "i64"
+        if re.search(r"\bsize_t\b", param):
+            return "size"
+        if re.search(r"\bfloat\b", param):
+            return "f32"
+        if re.search(r"\b(int32_t|int)\b", param):
+            return "i32"
+        raise AssertionError(f"unclassified C parameter: {param}")
+
+    def kind_py(t):
+        if t in (ctypes.c_void_p,) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            return "ptr"
+        return {ctypes.c_int64: "i64", ctypes.c_uint64: "i64", ctypes.c_size_t: "size", ctypes.c_float: "f32",
+                ctypes.c_int32: "i32"}[t]
+
+    sizes = {"i64": 8, "size": ctypes.sizeof(ctypes.c_size_t), "ptr": ctypes.sizeof(ctypes.c_void_p)}
+    checked = 0
+    for name, (_res, argtypes) in _lib._SIGNATURES.items():
+        params = protos[name].strip()
+        c_kinds = [] if params in ("", "void") else [kind_c(q) for q in params.split(",")]
+        py_kinds = [kind_py(t) for t in argtypes]
+        assert len(c_kinds) == len(py_kinds), f"{name}: header has {len(c_kinds)} parameters, ctypes table {len(py_kinds)}"
+        for i, (a, b) in enumerate(zip(c_kinds, py_kinds)):
+            assert a == b or sizes.get(a, 4) == sizes.get(b, 4) and {a, b} <= {"i64", "size"}, f"{name}: parameter {i}: header {a}, ctypes {b}"
+        checked += 1
+    assert checked == len(protos) >= 20
+
+
 def test_state_dict_surface_matches_reference_names():
     m = kagnn_amd.GKAN_Nodes("gin", 2, 10, 8, 3, grid_size=5, spline_order=3)
     keys = set(m.state_dict())
