@@ -41,6 +41,12 @@ static size_t sp_chunks_bytes(int inv, int ob) { return (size_t)cdiv(inv, kSpCF)
 static size_t sp_blk_bytes(int in, int inv, int ob) { return kHdrBytes + sp_chunks_bytes(inv, ob) + (((size_t)ob * in * 4 + 255) & ~(size_t)255); }
 size_t kan_sparse_pack_fwd_bytes(int in, int out, int C) { return (size_t)cdiv(out, kSpOutBlk) * sp_blk_bytes(in, in << sp_sh(C), min(out, kSpOutBlk)); }
 
+// A lane half of the sparse MFMA's K owns `hf` consecutive (virtual) features of a chunk, 8 per group.  Layers of <= 32
+// features use BOTH halves all the same: hf = 16 (two groups) up to 32 features, 8 (one group) up to 16 -- with hf fixed
+// at 32 such a layer ran four groups with the second lane half on zero weights (the per-rank slices of the feature-sharded
+// layer; first layers on narrow inputs).
+__host__ __device__ inline int sp_hf(int inv) { return inv <= 16 ? 8 : inv <= 32 ? 16 : kSpCF / 2; }
+
 // K position p of a feature's 8-slot block holds coefficient slot slot_at(p): order [0,4,1,5,2,6,3,7]
 __host__ __device__ inline int slot_at(int p) { return (p >> 1) + 4 * (p & 1); }
 
@@ -48,7 +54,8 @@ __host__ __device__ inline int slot_at(int p) { return (p >> 1) + 4 * (p & 1); }
 __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, const float* __restrict__ sw,
                                                   const float* __restrict__ sc, int in, int out, int C,
                                                   unsigned char* __restrict__ pack, float wscale, long first, long step) {
-    const int OT = cdiv(out, 32), HF = kSpCF / 2, BPC = kSpCF / 16;
+    const int OT = cdiv(out, 32), BPC = kSpCF / 16;
+    const int HF = sp_hf(in << sp_sh(C));               // features per lane half (groups beyond it: zero weights, never read)
     const size_t chunk_bytes = sparse_fwd_chunk_bytes(OT);
     const long spl_per_chunk = (long)kSpSteps * OT * 128, base_per_chunk = (long)BPC * OT * 64;   // spline items: (lane, half)
     const long per_chunk = spl_per_chunk + base_per_chunk;
@@ -70,9 +77,10 @@ __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, 
             _Float16* dl = reinterpret_cast<_Float16*>(cbase + ((size_t)(t * OT + ot) * 2 + 1) * 2048 + h * 1024 + lane * 16);
             // element el = 8h + p holds K = 8*kg + p + 16*h: K block kg + 2h = feature #kg of A's lane half h
             const int f = ch * kSpCF + h * HF + 2 * t + kg;
+            const bool dead = 2 * t + kg >= HF;           // a step beyond the lane half's features (narrow layers)
             for (int p = 0; p < 8; ++p) {
                 const int slot = slot_at(p);
-                const float w = wcat_v(bw, sw, sc, in, out, C, o, f, slot, sh) * wscale;     // f: (virtual) feature
+                const float w = dead ? 0.0f : wcat_v(bw, sw, sc, in, out, C, o, f, slot, sh) * wscale;     // f: (virtual) feature
                 const _Float16 hv = (_Float16)w;
                 dh[p] = hv;
                 dl[p] = (_Float16)(w - (float)hv);
@@ -86,7 +94,7 @@ __device__ __forceinline__ void pack_sparse_items(const float* __restrict__ bw, 
             _Float16* bl = reinterpret_cast<_Float16*>(cbase + (size_t)kSpSteps * OT * 2 * 2048 + ((size_t)(sb * OT + ot) * 2 + 1) * 1024 + lane * 16);
             for (int j = 0; j < 8; ++j) {                 // base weight of feature j of the group, fp16 hi / lo
                 const int f = ch * kSpCF + (lane >> 5) * HF + 8 * sb + j;
-                const float w = wcat_v(bw, sw, sc, in, out, C, o, f, 8, sh) * wscale;
+                const float w = 8 * sb >= HF ? 0.0f : wcat_v(bw, sw, sc, in, out, C, o, f, 8, sh) * wscale;
                 const _Float16 hv = (_Float16)w;
                 bh[j] = hv;
                 bl[j] = (_Float16)(w - (float)hv);
@@ -176,12 +184,15 @@ __device__ __forceinline__ f32x16 smfmac(const u32x4& a, const u32x4& b0, const 
 // row tiles, merged pairwise in a fixed order -- Chan et al., no cancellation) and leaves one (mean, M2, count) row per
 // workgroup in mom_partial[gridDim.x][3][out]: the BatchNorm1d that follows the convolution (reference
 // models.py:198-200) then needs no statistics pass over y (bn.hip: moments_finish, bn_from_moments_kernel).
-template <int OT, bool SH, bool MOM>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
+// NARROW: a layer of <= 32 (virtual) features, laid over both lane halves (sp_hf); a template flag because the lane-half width
+// as a runtime value cost the 64-feature forward 1.7 %
+template <int OT, bool SH, bool MOM, bool NARROW = false>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
 __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g, int nknots,
     const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy, int out,
     int chunks_per_split, long part_stride, float* __restrict__ mom_partial) {
-    constexpr int NT = 512, CF = kSpCF, HF = CF / 2, BPC = CF / 16, NG = HF / 8, ROWS = (NT / 64) * 32;
+    constexpr int NT = 512, CF = kSpCF, BPC = CF / 16, NG = CF / 16, ROWS = (NT / 64) * 32;
+    const int HF = NARROW ? sp_hf(in << (SH ? 1 : 0)) : CF / 2;    // features per lane half: CF / 2, or 16 / 8 in narrow layers
     constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 2 * 1024;
     constexpr int SPL_BYTES = kSpSteps * OT * 2 * 2048;
     constexpr int HALF_SPL = SPL_BYTES / 2, HALF_BASE = (BPC / 2) * OT * 2 * 1024, HALF_BYTES = HALF_SPL + HALF_BASE;
@@ -247,11 +258,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         lo0 = __builtin_amdgcn_perm(l1, l0, e[0]); lo1 = __builtin_amdgcn_perm(l1, l0, e[1]);
     };
 
-    // A lane half owns 32 of the chunk's 64 (virtual) features, 8 per group: with fewer than 25 features in a one-chunk layer
-    // (the input slices of the feature-sharded layer: 8 / 16 / 32 of 64; first layers on narrow inputs) the last groups
-    // carry only zero weights and are skipped -- the forward of an 8-feature slice took the 0.20 ms of a 64-feature layer.
-    const int inv_live = in << (SH ? 1 : 0);
-    const int ng_live = (resident && inv_live < HF) ? max(1, (inv_live + 7) / 8) : NG;
+    const int ng_live = HF / 8;                          // groups a lane half really has (4 unless the layer is narrow)
     float mom_n = 0.0f, mom_m[OT], mom_q[OT];          // this wave's rows so far: count, column mean, column M2
 #pragma unroll
     for (int t = 0; t < OT; ++t) { mom_m[t] = 0.0f; mom_q[t] = 0.0f; }
@@ -559,14 +566,14 @@ bool kan_sparse_fwd_moments_ok(long N, int in, int out, int G, int K) {
 }
 size_t kan_sparse_fwd_moments_ws_bytes(long N, int out) { return (size_t)sp_grid(N) * 3 * min(out, kSpOutBlk) * sizeof(float); }
 
-template <int OT, bool SH, bool MOM>
+template <int OT, bool SH, bool MOM, bool NARROW>
 static int launch_sparse(const float* x, long ldx, long N, int in, const float* knots, int nknots,
                          const unsigned char* pack, float* y, long ldy, int out, float* ws, size_t ws_bytes,
                          float* col_mean, float* col_m2, hipStream_t st) {
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH, MOM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH, MOM, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
     const int nchunks = cdiv(in << (SH ? 1 : 0), kSpCF);
@@ -576,21 +583,21 @@ static int launch_sparse(const float* x, long ldx, long N, int in, const float* 
         if (p.splits > 1) return fail(KAGNN_ERR_UNSUPPORTED, "%s: no column moments from a launch split over the chunks", "kan_sparse_fwd");
         if (!ws || ws_bytes < (size_t)gx * 3 * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small for the column moments", "kan_sparse_fwd");
-        kan_sparse_fwd_kernel<OT, SH, true><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, ws);
+        kan_sparse_fwd_kernel<OT, SH, true, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, ws);
         KAGNN_LAUNCH_CHECK();
         return moments_finish(ws, gx, out, col_mean, col_m2, st);
     }
     if (p.splits > 1) {
         if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_sparse_fwd");
-        kan_sparse_fwd_kernel<OT, SH, false><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
+        kan_sparse_fwd_kernel<OT, SH, false, NARROW><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
                                                                                 p.cps, N * (long)out, nullptr);
         KAGNN_LAUNCH_CHECK();
         sparse_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
         KAGNN_LAUNCH_CHECK();
         return KAGNN_OK;
     }
-    kan_sparse_fwd_kernel<OT, SH, false><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, nullptr);
+    kan_sparse_fwd_kernel<OT, SH, false, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, nullptr);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -608,7 +615,9 @@ int kan_sparse_fwd(const float* x, long ldx, long N, const float* knots, int in,
         int rc;
         float* cm = col_mean ? col_mean + b * kSpOutBlk : nullptr;
         float* cq = col_mean ? col_m2 + b * kSpOutBlk : nullptr;
-#define L(OO, SS, MM) launch_sparse<OO, SS, MM>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, cm, cq, st)
+        const bool narrow = (in << sh) <= 32;
+#define LL(OO, SS, MM, NN) launch_sparse<OO, SS, MM, NN>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, cm, cq, st)
+#define L(OO, SS, MM) (narrow ? LL(OO, SS, MM, true) : LL(OO, SS, MM, false))
         if (col_mean) {
             if (sh) rc = OT == 1 ? L(1, true, true) : L(2, true, true);
             else rc = OT == 1 ? L(1, false, true) : L(2, false, true);
@@ -616,6 +625,7 @@ int kan_sparse_fwd(const float* x, long ldx, long N, const float* knots, int in,
             if (sh) rc = OT == 1 ? L(1, true, false) : L(2, true, false);
             else rc = OT == 1 ? L(1, false, false) : L(2, false, false);
         }
+#undef LL
 #undef L
         if (rc) return rc;
     }
