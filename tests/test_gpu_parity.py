@@ -196,7 +196,12 @@ def test_kan_chain_golden(golden, mode):
                                    (64, 16, 16, 32, 4),
                                    # more than 16 coefficients: the split mode sums coefficient groups (ops.kan_linear)
                                    (300, 64, 64, 14, 3), (257, 40, 70, 20, 3), (200, 33, 24, 30, 1), (129, 20, 20, 16, 2),
-                                   (500, 64, 40, 29, 4)])
+                                   (500, 64, 40, 29, 4),
+                                   # narrow layers (the per-rank slices of the feature-sharded layer, first layers on few features):
+                                   # the forward lays <= 32 features over both lane halves and skips empty groups, dW's idle waves
+                                   # take row sub-ranges (row counts that do not divide into the sub-ranges' 32-row chunks included)
+                                   (4097, 8, 64, 5, 3), (1000, 16, 64, 5, 3), (33, 24, 40, 5, 3), (5000, 32, 64, 5, 3),
+                                   (3000, 16, 128, 8, 3), (2049, 12, 128, 8, 3), (777, 9, 33, 3, 3), (95, 31, 64, 5, 3)])
 def test_kanlinear_ragged_shapes_vs_oracle(shape, mode):
     """ragged / edge shapes (N not a tile multiple, odd widths, Cora-sized input, out > 128) against
     the oracle in fp64; also reports how the HIP error compares with the reference's own fp32 error."""
