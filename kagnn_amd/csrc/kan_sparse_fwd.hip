@@ -201,11 +201,15 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     float* s_knots = reinterpret_cast<float*>(smem);
     unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
     unsigned char* s_w = smem + kLdsHdr;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave: an SGPR
     if (tid < nknots) s_knots[tid] = knots_g[tid];
     build_sparse_table(s_tbl, tid, nknots);
     const float post = reinterpret_cast<const float*>(pack)[0];
     const float post_b = post * 64.0f;                  // the SiLU branch is fed at scale 2^4 instead of 2^10
+    // exact-fp32 SiLU groups (values beyond fp16 range) accumulate into the SAME acc_b: their base weights are scaled by
+    // 2^(4 - e) so the products sit at acc_b's scale (an accumulator tile of their own cost 16 OT registers the kernel does
+    // not have: the column-moments instantiation spilled 53 VGPRs around its MFMA loop -- profiles/r03_kernel_resources.txt)
+    const float wsc16 = ldexpf(1.0f, 4 - reinterpret_cast<const int*>(pack)[1]);
     const float* base_w = reinterpret_cast<const float*>(pack + kHdrBytes + (size_t)nchunks * CHUNK_BYTES);   // [out][in] fp32
     const unsigned char* gw = pack + kHdrBytes;
     // half h (0 / 1) of chunk ch -> LDS buffer h: 32 OT one-KiB pieces of sparse-step fragments + 4 OT of SiLU fragments
@@ -259,20 +263,26 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     };
 
     const int ng_live = HF / 8;                          // groups a lane half really has (4 unless the layer is narrow)
-    float mom_n = 0.0f, mom_m[OT], mom_q[OT];          // this wave's rows so far: count, column mean, column M2
+    // this wave's rows so far: count (wave-uniform), column mean and column M2.  The per-column pairs live in LDS behind the
+    // weight chunk ([wave][t][mean | M2][32 columns], 4 KiB at OT = 2), not in registers: four more live VGPRs through the
+    // MFMA loop were what tipped the 256-register instantiation into scratch
+    float mom_n = 0.0f;
+    float* s_momw = reinterpret_cast<float*>(s_w + CHUNK_BYTES) + wave * (OT * 64);
+    if constexpr (MOM) {
 #pragma unroll
-    for (int t = 0; t < OT; ++t) { mom_m[t] = 0.0f; mom_q[t] = 0.0f; }
+        for (int t = 0; t < OT; ++t) s_momw[64 * t + lane] = 0.0f;      // (each wave touches only its own slice: no barrier)
+    }
     float xn[8];
     load8((long)blockIdx.x * ROWS, ch_begin, 0, xn);
     for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
         const long row0 = tile * ROWS + wave * 32;
-        // acc: spline part (bases * 2^10); acc_b: SiLU branch through fp16 hi/lo at scale 2^4 (|silu| < 4094);
-        // acc_f: SiLU branch of the rare groups whose values do not fit that, exact fp32 MFMA on the unscaled weights
-        f32x16 acc[OT], acc_b[OT], acc_f[OT];
+        // acc: spline part (bases * 2^10); acc_b: SiLU branch through fp16 hi/lo at scale 2^4 (|silu| < 4094) -- and, for the
+        // rare groups whose values do not fit that, exact fp32 MFMAs on the fp32 weights brought to the same scale
+        f32x16 acc[OT], acc_b[OT];
 #pragma unroll
         for (int t = 0; t < OT; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc[t][i] = 0.0f; acc_b[t][i] = 0.0f; acc_f[t][i] = 0.0f; }
+            for (int i = 0; i < 16; ++i) { acc[t][i] = 0.0f; acc_b[t][i] = 0.0f; }
 
         for (int ch = ch_begin; ch < ch_end; ++ch) {
 #pragma unroll
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                             const int o = 32 * t + r;
                             const int fr = SH ? (f0 + j) >> 1 : f0 + j;          // SH: only the first window carries the base weight
                             const float w = (o < out && fr < in && !(SH && (j & 1))) ? base_w[(long)o * in + fr] : 0.0f;
-                            acc_f[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j] * 0.0625f, w, acc_f[t], 0, 0, 0);
+                            acc_b[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j] * 0.0625f, w * wsc16, acc_b[t], 0, 0, 0);
                         }
                     }
                 }
@@ -397,53 +407,64 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
             const unsigned base = (unsigned)(wave * 32 + 4 * kg) * ldy4 + col * 4;
             float v[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = fmaf(acc[t][i], post, fmaf(acc_b[t][i], post_b, acc_f[t][i]));
+            for (int i = 0; i < 16; ++i) v[i] = fmaf(acc[t][i], post, acc_b[t][i] * post_b);
             if (col < out) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped
                     gst_s(yb, base, (unsigned)((i & 3) + 8 * (i >> 2)) * ldy4, v[i]);
             }
             if constexpr (MOM) {
-                if (rows_here > 0) {                       // the 32-row tile's own (mean, M2), then merged into the wave's
-                    float sm = 0.0f;
+                // the 32-row tile's own (mean, M2), then merged into the wave's.  Full tiles (all but the wave's last one)
+                // take the unmasked form: the 32 row-validity selects per column were most of this epilogue's VALU and,
+                // live next to the second accumulator tile, pushed the kernel into scratch
+                float sm = 0.0f, q = 0.0f, mt;
+                if (rows_here >= 32) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sm += v[i];
+                    sm += __shfl_xor(sm, 32);
+                    mt = sm * mom_rnt;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const float d = v[i] - mt; q = fmaf(d, d, q); }
+                } else {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) sm += (4 * kg + (i & 3) + 8 * (i >> 2) < rows_here) ? v[i] : 0.0f;
                     sm += __shfl_xor(sm, 32);
-                    const float mt = sm * mom_rnt;
-                    float q = 0.0f;
+                    mt = sm * mom_rnt;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const float d = (4 * kg + (i & 3) + 8 * (i >> 2) < rows_here) ? v[i] - mt : 0.0f;
                         q = fmaf(d, d, q);
                     }
+                }
+                if (rows_here > 0) {
                     q += __shfl_xor(q, 32);
-                    const float d = mt - mom_m[t];
-                    mom_m[t] = fmaf(d, mom_w, mom_m[t]);
-                    mom_q[t] += fmaf(d * d, mom_nw, q);
+                    const float m_old = s_momw[64 * t + r], q_old = s_momw[64 * t + 32 + r];
+                    const float d = mt - m_old;
+                    if (kg == 0) {
+                        s_momw[64 * t + r] = fmaf(d, mom_w, m_old);
+                        s_momw[64 * t + 32 + r] = q_old + fmaf(d * d, mom_nw, q);
+                    }
                 }
             }
         }
         if constexpr (MOM) { if (rows_here > 0) mom_n += (float)rows_here; }
     }
     if constexpr (MOM) {
-        // the 8 waves' moments meet in LDS (the weight chunk is dead) and are merged in wave order
+        // the 8 waves' moments already sit in LDS; merged in wave order
         __syncthreads();
-        float* s_mom = reinterpret_cast<float*>(s_w);      // [wave 8][3][OT*32]
-        if (kg == 0) {
-#pragma unroll
-            for (int t = 0; t < OT; ++t) {
-                s_mom[(wave * 3 + 0) * (OT * 32) + 32 * t + r] = mom_m[t];
-                s_mom[(wave * 3 + 1) * (OT * 32) + 32 * t + r] = mom_q[t];
-                s_mom[(wave * 3 + 2) * (OT * 32) + 32 * t + r] = mom_n;
-            }
-        }
+        const float* s_mom = reinterpret_cast<const float*>(s_w + CHUNK_BYTES);   // [wave 8][t][mean | M2][32]
+        float* s_cnt = reinterpret_cast<float*>(s_w);                              // (the weight chunk is dead)
+        // (lane / wave ids taken afresh: the prologue's copies would otherwise stay live -- in scratch -- across the MFMA loop)
+        const int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (lane2 == 0) s_cnt[wave] = mom_n;
         __syncthreads();
-        if (tid < OT * 32 && tid < out) {
+        if (wave == 0 && lane2 < OT * 32 && lane2 < out) {
+            const int tid = lane2;
             float n = 0.0f, m = 0.0f, q = 0.0f;
             for (int w8 = 0; w8 < NT / 64; ++w8) {
-                const float nb = s_mom[(w8 * 3 + 2) * (OT * 32) + tid];
+                const float nb = s_cnt[w8];
                 if (nb > 0.0f) {
-                    const float mb = s_mom[(w8 * 3 + 0) * (OT * 32) + tid], qb = s_mom[(w8 * 3 + 1) * (OT * 32) + tid];
+                    const float mb = s_mom[w8 * (OT * 64) + 64 * (tid >> 5) + (tid & 31)], qb = s_mom[w8 * (OT * 64) + 64 * (tid >> 5) + 32 + (tid & 31)];
                     const float nn = n + nb, d = mb - m, w = nb / nn;
                     m = fmaf(d, w, m);
                     q += qb + d * d * n * w;
@@ -570,7 +591,7 @@ template <int OT, bool SH, bool MOM, bool NARROW>
 static int launch_sparse(const float* x, long ldx, long N, int in, const float* knots, int nknots,
                          const unsigned char* pack, float* y, long ldy, int out, float* ws, size_t ws_bytes,
                          float* col_mean, float* col_m2, hipStream_t st) {
-    const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
+    const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT) + (MOM ? 8 * OT * 64 * sizeof(float) : 0);
     static bool configured = false;
     if (!configured) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH, MOM, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

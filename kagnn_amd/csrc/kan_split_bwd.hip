@@ -704,13 +704,27 @@ struct DwPlan { int nbx; long rpw; long NS; long per; int FG, OC; long inP, outP
 // rows one dW workgroup may own: with leading dimensions up to kDwMaxLd floats its slice of x / gy spans < 4 GiB
 constexpr long kDwMaxRowsPerBlock = 1L << 17;
 
+// KAGNN_DW_NTO = 4 | 2: output tiles per wave of the <= 8-coefficient cubic weight-gradient kernel (one wave per SIMD on 64
+// outputs, or two waves per SIMD on 32 outputs each; see kan_split_dw_kernel)
+static int dw_nto() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KAGNN_DW_NTO");
+        v = e ? atoi(e) : 4;
+        if (v != 2 && v != 4) v = 4;
+    }
+    return v;
+}
+static bool dw_two_waves(int in, int out, int C, int K) { return dw_nto() == 2 && K == 3 && C <= 8 && in > 32; }
+
 static DwPlan split_dw_plan(long N, int in, int out, int C, int K) {
     DwPlan p;
     const bool virt = C > 8;
+    const bool two = dw_two_waves(in, out, C, K);
     if (C > 8) { in <<= 1; C = 8; }                    // virtual features: 2*in features of 8 slots (wcat_v)
-    p.FG = cdiv(in, 64); p.OC = cdiv(out, 64);
+    p.FG = cdiv(in, 64); p.OC = cdiv(out, two ? 32 : 64);
     const int roles = p.FG * p.OC;
-    int nb = max(1, 256 / roles);                      // ~1 workgroup per CU
+    int nb = max(1, (two ? 512 : 256) / roles);        // ~1 workgroup per CU (two-wave form: 2)
     long r = (N + nb - 1) / nb;
     r = max(32L, (r + 31) & ~31L);                     // whole 32-row chunks
     r = min(r, kDwMaxRowsPerBlock);                    // a workgroup's rows stay inside one 4 GiB buffer window
@@ -757,12 +771,15 @@ size_t kan_split_dw_ws_bytes(long N, int in, int out, int C, int K) {
 // minimal instead of deeply pipelined: loads of chunk i+1 are issued, the MFMAs of chunk i run (and
 // cover the load latency), then chunk i+1 is expanded in place.  Everything non-accumulator fits the
 // 256 architectural VGPRs, so nothing shuttles through AGPRs.
-struct DwRaw { float x[8]; float g[4][8]; float mu[8], rs[8]; };   // mu / rs: layernorm statistics (RBF basis only)
+template <int NTO> struct DwRaw { float x[8]; float g[NTO][8]; float mu[8], rs[8]; };   // mu / rs: layernorm statistics (RBF basis only)
 
 // RS (1, 2, 4): row sub-ranges per feature tile -- narrow layers with 4 / RS live tiles, see split_dw_plan (a template
 // parameter: as a runtime value it cost the 64-feature layer 45 %)
-template <int K, bool GEN, int RS = 1>      // GEN == false: <= 8 coefficients, no virtual-feature code (see kan_split_dx_kernel)
-__global__ __launch_bounds__(256) void kan_split_dw_kernel(
+// NTO (4, 2): 16-wide output tiles per wave.  4 = one wave per SIMD owns 16 features x 64 outputs (160 accumulators);
+// 2 = 16 features x 32 outputs (80 accumulators, <= 256 registers): TWO waves share a SIMD, one issuing VALU (basis
+// expansion) while the other's MFMAs run -- the overlap a lone in-order wave does not get (round 3, profiles/r03_experiments.md)
+template <int K, bool GEN, int RS = 1, int NTO = 4>      // GEN == false: <= 8 coefficients, no virtual-feature code (see kan_split_dx_kernel)
+__global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots, int OC, long rows_per_block,
     long inP, long outP, float* __restrict__ slab, RbfArgs rb, int sh_arg /* 1: virtual features (wcat_v); then C == 8 */) {
@@ -800,18 +817,17 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     const long rbeg = blockIdx.x * rows_per_block + rsub * sub_rows;
     const long rend = min(min(N, (blockIdx.x + 1L) * rows_per_block), rbeg + sub_rows);
 
-    f32x4 D[kCTmax][4];            // spline coefficients x 4 o-tiles, scaled by 2^(20 - T); plane kCTmax - 1: the base
-                                   // weight through the fp16 path, scaled by 2^(14 - T).  (ONE array: as a separate
-                                   // `Dh[4]` the compiler kept the base plane in arch VGPRs and copied its 16 registers
-                                   // to the accumulation file and back around its MFMAs in every chunk)
+    f32x4 D[kCTmax][NTO];          // spline coefficients x NTO o-tiles, scaled by 2^(20 - T); plane kCTmax - 1: the base
+                                   // weight, scaled by 2^(14 - T): fp16 hi/lo products, and -- for chunks whose silu
+                                   // overflows fp16 -- exact fp32 MFMAs on gy brought to the same scale.  (ONE array: as a
+                                   // separate `Dh[4]` the compiler kept the base plane in arch VGPRs and copied its 16
+                                   // registers to the accumulation file and back around its MFMAs in every chunk; a third
+                                   // array for the fp32 path cost 16 more registers this kernel does not have)
 #define Dh D[kCTmax - 1]
-    f32x4 Df[4];                   // base weight through the exact fp32 path (chunks whose silu overflows fp16)
 #pragma unroll
     for (int c = 0; c < kCTmax; ++c)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) D[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) Df[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTO; ++t) D[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // descriptors opened at this workgroup's first row and closed at its last: offsets are relative to rbeg (32-bit
     // for any N; the host keeps rows_per_block * ld * 4 below 4 GiB) and rows >= rend read as 0
@@ -824,14 +840,10 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
     // loads: rows >= N read as 0 through the descriptor (rows_per_block is a multiple of 32, so a chunk
     // never straddles two workgroups); features >= in / outputs >= out are clamped and only reach slab
     // entries nobody reads.
-    unsigned xo = (unsigned)(8 * kg) * ldx4 + (unsigned)min(f, in - 1) * 4u, gvo[4];
+    unsigned xo = (unsigned)(8 * kg) * ldx4 + (unsigned)min(f, in - 1) * 4u, gvo[NTO];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) gvo[t] = (unsigned)(8 * kg) * ldgy4 + (unsigned)min(64 * oc + 16 * t + li, out - 1) * 4u;
-    // x (and the layernorm statistics) first, gy after: the x side of a chunk is expanded before its gy is looked at
-    // (expand_x / expand_gy below), so the 32 gy loads have the ~2500 cycles of that arithmetic on top of the MFMA section
-    // to arrive -- issued one chunk ahead and consumed right after the section, they left 22 % of this one-wave-per-SIMD
-    // kernel's cycles parked in s_waitcnt (a second chunk in flight does not fit the register file: 3.4 ms, spills)
-    auto load_raw = [&](DwRaw& r) {
+    for (int t = 0; t < NTO; ++t) gvo[t] = (unsigned)(8 * kg) * ldgy4 + (unsigned)min(16 * NTO * oc + 16 * t + li, out - 1) * 4u;
+    auto load_raw = [&](DwRaw<NTO>& r) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) r.x[j] = gld_s(xb, xo, (unsigned)j * ldx4);
         if (ln_on) {
@@ -842,132 +854,124 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) r.g[t][j] = gld_s(gyb, gvo[t], (unsigned)j * ldgy4);
+            for (int t = 0; t < NTO; ++t) r.g[t][j] = gld_s(gyb, gvo[t], (unsigned)j * ldgy4);
         xo += 32u * ldx4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) gvo[t] += 32u * ldgy4;
+        for (int t = 0; t < NTO; ++t) gvo[t] += 32u * ldgy4;
     };
 
-    // fragments of the current chunk
-    u32x4 rh[8], rl[8];            // per row: 8-slot windows (hi / lo) of this lane's feature
-    u32x4 bhi[4], blo[4];          // gy * 2^(10-T), per 16-wide output tile
-    u32x4 sah, sal;                // silu(x) * 2^4 over the 8 rows, hi / lo
-    int T;                         // running exponent: gy is fed as gy * 2^(10 - T)
-    bool base32 = false;           // this chunk's base branch already went through the fp32 path
-
     // wave-uniform exponent of the chunk's largest |gy|
-    auto chunk_exp = [&](const DwRaw& r) -> int {
+    auto chunk_exp = [&](const DwRaw<NTO>& r) -> int {
         float mx = 0.0f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NTO; ++t)
 #pragma unroll
             for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(r.g[t][j]));
         return exp_for_max(wave_max_nonneg(mx));
     };
-    // raw chunk -> fragments.  x side: bases of 8 rows of this lane's feature (cubic splines: two rows per packed-fp32
-    // evaluation) and the SiLU values
-    auto expand_x = [&](const DwRaw& r) {
-        if constexpr (K == 3) {
-#pragma unroll
-            for (int j = 0; j < 8; j += 2)
-                make_spline_frag3_pair(r.x[j], r.x[j + 1], s_tbl, fgeo, rh[j], rl[j], rh[j + 1], rl[j + 1], woff);
-        } else
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if constexpr (K == 0) {
-                const float z = ln_on ? fmaf((r.x[j] - r.mu[j]) * r.rs[j], gam, bet) : r.x[j];
-                make_rbf_frag(z, rb.a, ca, rh[j], rl[j]);
-            } else {
-                spline_frag<K>(r.x[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j], woff);
-            }
-        }
-        // ---- SiLU branch: fp16 hi/lo at scale 2^4 (|silu| < 4094); larger values take the fp32 MFMA
-        float sv[8];
-        float smx = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { sv[j] = siluf(r.x[j]) * 16.0f; smx = fmaxf(smx, fabsf(sv[j])); }
-        base32 = __any(!(smx < 60000.0f));              // wave-uniform; also catches NaN / Inf
-        split_f16x2(sv, sah, sal);
-    };
-    // gy side, scaled by 2^(10 - Tfix) (Tfix >= the chunk's exponent)
-    auto expand_gy = [&](const DwRaw& r, int Tfix) {
-        const float gs = ldexpf(1.0f, 10 - Tfix);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = r.g[t][j] * gs;
-            split_f16x2(v, bhi[t], blo[t]);
-        }
-        if (base32) {                                    // rare: do this chunk's base branch right here, in exact fp32
-#pragma unroll                                           // (4 rows per MFMA, k-lane kg <-> row 8*kg + j)
-            for (int j = 0; j < 8; ++j) {
-                const float sj = siluf(r.x[j]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    Df[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sj, r.g[t][j], Df[t], 0, 0, 0);
-            }
-        }
-    };
 
-    DwRaw raw;
+    // The loop is ROTATED: an iteration expands the chunk whose raw rows were requested one iteration earlier, requests the
+    // next chunk's rows (they land under the MFMAs) and runs the MFMAs.  The fragments are therefore defined and consumed
+    // inside ONE iteration; only the raw rows -- direct load destinations -- cross the back edge.  With the expansion at the
+    // bottom of the loop (round 2) the 104 fragment registers were loop-carried and the compiler closed every iteration with
+    // ~100 v_mov copies into them (16 % of the loop's VALU instructions).
+    DwRaw<NTO> raw;
     load_raw(raw);
-    expand_x(raw);
-    T = chunk_exp(raw);
-    expand_gy(raw, T);
+    int T = chunk_exp(raw);        // running exponent: gy is fed as gy * 2^(10 - T)
     long n0 = rbeg;
     while (n0 < rend) {
-        // ---- hot loop: the scale exponent T is FIXED in here, so the 160 accumulators are only ever touched by
-        // MFMAs (a conditional rescale inside the loop makes the compiler copy them around every iteration)
-        bool grow = false;
+        // ---- hot loop: the scale exponent T is FIXED in here, so the accumulators are only ever touched by MFMAs (a
+        // conditional rescale inside the loop makes the compiler copy them around every iteration)
         for (; n0 < rend; n0 += 32) {
-            load_raw(raw);                               // next chunk: lands under the MFMAs below
+            // raw chunk -> fragments.  x side first (bases of 8 rows of this lane's feature; cubic splines: two rows per
+            // packed-fp32 evaluation; SiLU values), so that the gy loads have that arithmetic on top of the MFMA section
+            // to arrive
+            u32x4 rh[8], rl[8];            // per row: 8-slot windows (hi / lo) of this lane's feature
+            u32x4 sah, sal;                // silu(x) * 2^4 over the 8 rows, hi / lo
+            if constexpr (K == 3) {
 #pragma unroll
-            for (int c = 0; c < kCTmax - 1; ++c) {       // all 8 slots, no branch: slots >= C are always zero
+                for (int j = 0; j < 8; j += 2)
+                    make_spline_frag3_pair(raw.x[j], raw.x[j + 1], s_tbl, fgeo, rh[j], rl[j], rh[j + 1], rl[j + 1], woff);
+            } else
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (K == 0) {
+                    const float z = ln_on ? fmaf((raw.x[j] - raw.mu[j]) * raw.rs[j], gam, bet) : raw.x[j];
+                    make_rbf_frag(z, rb.a, ca, rh[j], rl[j]);
+                } else {
+                    spline_frag<K>(raw.x[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j], woff);
+                }
+            }
+            // ---- SiLU branch: fp16 hi/lo at scale 2^4 (|silu| < 4094); larger values take the fp32 MFMA
+            float sv[8];
+            float smx = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sv[j] = siluf(raw.x[j]) * 16.0f; smx = fmaxf(smx, fabsf(sv[j])); }
+            const bool base32 = __any(!(smx < 60000.0f));   // wave-uniform; also catches NaN / Inf
+            split_f16x2(sv, sah, sal);
+            if (chunk_exp(raw) > T) break;                   // wave-uniform, rare: rescale outside, then redo this chunk
+            // gy side, scaled by 2^(10 - T)
+            u32x4 bhi[NTO], blo[NTO];      // gy * 2^(10-T), per 16-wide output tile
+            const float gs = ldexpf(1.0f, 10 - T);
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = raw.g[t][j] * gs;
+                split_f16x2(v, bhi[t], blo[t]);
+            }
+            if (base32) {                                    // rare: this chunk's base branch in exact fp32, at Dh's scale
+                const float gs16 = gs * 16.0f;               // (4 rows per MFMA, k-lane kg <-> row 8*kg + j)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float sj = sv[j] * 0.0625f;
+#pragma unroll
+                    for (int t = 0; t < NTO; ++t)
+                        Dh[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sj, raw.g[t][j] * gs16, Dh[t], 0, 0, 0);
+                }
+            }
+            load_raw(raw);                                   // next chunk: lands under the MFMAs below
+#pragma unroll
+            for (int c = 0; c < kCTmax - 1; ++c) {           // all 8 slots, no branch: slots >= C are always zero
                 const int q = c >> 1;
                 const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
-                u32x4 ah, al;                            // transpose (row, coefficient) 8x8 blocks on the fly
+                u32x4 ah, al;                                // transpose (row, coefficient) 8x8 blocks on the fly
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     ah[p] = __builtin_amdgcn_perm(rh[2 * p + 1][q], rh[2 * p][q], sel);
                     al[p] = __builtin_amdgcn_perm(rl[2 * p + 1][q], rl[2 * p][q], sel);
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(ah, bhi[t], D[c][t]);
+                for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(ah, bhi[t], D[c][t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(ah, blo[t], D[c][t]);
+                for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(ah, blo[t], D[c][t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) D[c][t] = mfma16_f16(al, bhi[t], D[c][t]);
+                for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(al, bhi[t], D[c][t]);
             }
             if (!base32) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sah, bhi[t], Dh[t]);
+                for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(sah, bhi[t], Dh[t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sah, blo[t], Dh[t]);
+                for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(sah, blo[t], Dh[t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sal, bhi[t], Dh[t]);
+                for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(sal, bhi[t], Dh[t]);
             }
-            if (n0 + 32 >= rend) { n0 += 32; break; }    // that was the last chunk
-            expand_x(raw);                               // (the MFMAs above were the last readers of the old fragments)
-            if (chunk_exp(raw) > T) { grow = true; n0 += 32; break; }   // wave-uniform, rare
-            expand_gy(raw, T);
         }
-        if (grow) {                                      // the pending chunk needs a larger scale: rescale once, exactly
+        if (n0 < rend) {                                     // the pending chunk needs a larger scale: rescale once, exactly
             const int ex = chunk_exp(raw);
             const float dn = ldexpf(1.0f, T - ex);
 #pragma unroll
             for (int c = 0; c < kCTmax; ++c)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) D[c][t] *= dn;
+                for (int t = 0; t < NTO; ++t) D[c][t] *= dn;
             T = ex;
-            expand_gy(raw, T);
         }
     }
     // ---- slab write: D rows <-> features 4*kg + reg, cols <-> outputs li
     const float undo = ldexpf(1.0f, T - 20), undo_b = ldexpf(1.0f, T - 14);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const long o = 64 * oc + 16 * t + li;
+    for (int t = 0; t < NTO; ++t) {
+        const long o = 16 * NTO * oc + 16 * t + li;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const long fl = 64 * fg + 16 * tile + 4 * kg + reg;
@@ -975,7 +979,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_kernel(
 #pragma unroll
                 for (int c = 0; c < kCTmax - 1; ++c)
                     if (c < C) slab[((s * (C + 1) + c) * inP + fl) * outP + o] = D[c][t][reg] * undo;
-                slab[((s * (C + 1) + C) * inP + fl) * outP + o] = fmaf(Dh[t][reg], undo_b, Df[t][reg]);
+                slab[((s * (C + 1) + C) * inP + fl) * outP + o] = Dh[t][reg] * undo_b;
             }
         }
     }
@@ -1009,15 +1013,17 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // uniform: the row range feeds the buffer descriptors
     const int tile = RS == 1 ? wave : wave_u % (4 / RS), rsub = RS == 1 ? 0 : wave_u / (4 / RS);
     const int f = 64 * fg + 16 * tile + li;
-    const int ns1 = C - 8;                                       // live slots of the second window (<= NS1)
+    constexpr int ns1 = NS1;                                     // live slots of the second window = C - 8, a template parameter:
+                                                                 // behind a run-time `c < C - 8` the conditional MFMAs on D1 made
+                                                                 // the compiler copy 64 accumulators around in every chunk
     const long s = (long)blockIdx.x * RS + rsub;       // slab of this (row block, sub-range)
     const long sub_rows = ((rows_per_block / 32 + RS - 1) / RS) * 32;
     const long rbeg = blockIdx.x * rows_per_block + rsub * sub_rows;
     const long rend = min(min(N, (blockIdx.x + 1L) * rows_per_block), rbeg + sub_rows);
 
     f32x4 D[kCTmax - 1][4];        // window 0: slots 0..7, scaled by 2^(20 - T)
-    f32x4 D1[NS1 + 1][4];          // window 1: slots 8..8+NS1-1; plane NS1: the base weight through the fp16 path (2^(14 - T))
-    f32x4 Df[4];                   // base weight through the exact fp32 path
+    f32x4 D1[NS1 + 1][4];          // window 1: slots 8..8+NS1-1; plane NS1: the base weight (2^(14 - T)), fp16 hi/lo products and,
+                                   // for chunks whose silu overflows fp16, exact fp32 MFMAs on gy at the same scale
     // (the base plane is a row of D1, not an array of its own: as `Dh[4]` the compiler kept it in arch VGPRs and copied all
     // 16 registers to the accumulation file and back around its MFMAs in every chunk)
 #define Dh D1[NS1]
@@ -1029,8 +1035,6 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
     for (int c = 0; c < NS1 + 1; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) D1[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) Df[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const GBuf xb = gbuf_at(x, rend, ldx, in, rbeg), gyb = gbuf_at(gy, rend, ldgy, out, rbeg);
     const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u;
@@ -1049,14 +1053,6 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) gvo[t] += 32u * ldgy4;
     };
-
-    u32x4 rh[8], rl[8];            // per row: window 0, 8 slots (hi / lo)
-    unsigned r1h[8][2], r1l[8][2]; // per row: window 1, slots 0..3
-    u32x4 bhi[4], blo[4];
-    u32x4 sah, sal;
-    int T;
-    bool base32 = false;
-
     auto chunk_exp = [&](const Raw& r) -> int {
         float mx = 0.0f;
 #pragma unroll
@@ -1065,56 +1061,65 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
             for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(r.g[t][j]));
         return exp_for_max(wave_max_nonneg(mx));
     };
-    auto expand = [&](const Raw& r, int Tfix) {
-        const float gs = ldexpf(1.0f, 10 - Tfix);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = r.g[t][j] * gs;
-            split_f16x2(v, bhi[t], blo[t]);
-        }
-        // ---- one evaluation of the cubic pieces per row, two placements
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int m; float u; bool inside;
-            fast_span(r.x[j], fgeo, m, u, inside);
-            float Nv[4];
-            cubic_bases(u, inside ? (kAScale / 6.0f) : 0.0f, Nv);
-            const unsigned h0 = pk_f16_rtz(Nv[0], Nv[1]), h1 = pk_f16_rtz(Nv[2], Nv[3]);
-            const unsigned l0 = pk_f16_rtz(sub_f16lo(Nv[0], h0), sub_f16hi(Nv[1], h0));
-            const unsigned l1 = pk_f16_rtz(sub_f16lo(Nv[2], h1), sub_f16hi(Nv[3], h1));
-            const unsigned char* te = reinterpret_cast<const unsigned char*>(s_tbl) + 16 * (m + 1);
-            const u32x4 sel0 = *reinterpret_cast<const u32x4*>(te);
-            frag3_place_fwd(sel0, h0, h1, l0, l1, rh[j], rl[j]);
-            const uint2 sel1 = *reinterpret_cast<const uint2*>(te + kWinBytes);          // window 1: slots 0..3 only
-            r1h[j][0] = __builtin_amdgcn_perm(h1, h0, sel1.x); r1h[j][1] = __builtin_amdgcn_perm(h1, h0, sel1.y);
-            r1l[j][0] = __builtin_amdgcn_perm(l1, l0, sel1.x); r1l[j][1] = __builtin_amdgcn_perm(l1, l0, sel1.y);
-        }
-        float sv[8];
-        float smx = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { sv[j] = siluf(r.x[j]) * 16.0f; smx = fmaxf(smx, fabsf(sv[j])); }
-        base32 = __any(!(smx < 60000.0f));
-        split_f16x2(sv, sah, sal);
-        if (base32) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    Df[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[j] * 0.0625f, r.g[t][j], Df[t], 0, 0, 0);
-        }
-    };
 
+    // rotated loop, as in kan_split_dw_kernel: the fragments live inside one iteration, only the raw rows cross the back
+    // edge.  (With the expansion at the bottom of the loop this kernel -- 208 accumulators -- spilled 652 VGPRs: 1 452 bytes
+    // of scratch per lane, ~470 scratch loads / stores in the loop; profiles/r03_kernel_resources.txt)
     Raw raw;
     load_raw(raw);
-    T = chunk_exp(raw);
-    expand(raw, T);
+    int T = chunk_exp(raw);
     long n0 = rbeg;
     while (n0 < rend) {
-        bool grow = false;
         for (; n0 < rend; n0 += 32) {
-            load_raw(raw);
+            u32x4 rh[8], rl[8];            // per row: window 0, 8 slots (hi / lo)
+            unsigned r1h[8][2], r1l[8][2]; // per row: window 1, slots 0..3
+            u32x4 bhi[4], blo[4];
+            u32x4 sah, sal;
+            // ---- one evaluation of the cubic pieces per row, two placements
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int m; float u; bool inside;
+                fast_span(raw.x[j], fgeo, m, u, inside);
+                float Nv[4];
+                cubic_bases(u, inside ? (kAScale / 6.0f) : 0.0f, Nv);
+                const unsigned h0 = pk_f16_rtz(Nv[0], Nv[1]), h1 = pk_f16_rtz(Nv[2], Nv[3]);
+                const unsigned l0 = pk_f16_rtz(sub_f16lo(Nv[0], h0), sub_f16hi(Nv[1], h0));
+                const unsigned l1 = pk_f16_rtz(sub_f16lo(Nv[2], h1), sub_f16hi(Nv[3], h1));
+                const unsigned char* te = reinterpret_cast<const unsigned char*>(s_tbl) + 16 * (m + 1);
+                const u32x4 sel0 = *reinterpret_cast<const u32x4*>(te);
+                frag3_place_fwd(sel0, h0, h1, l0, l1, rh[j], rl[j]);
+                const uint2 sel1 = *reinterpret_cast<const uint2*>(te + kWinBytes);          // window 1: slots 0..3 only
+                r1h[j][0] = __builtin_amdgcn_perm(h1, h0, sel1.x); r1h[j][1] = __builtin_amdgcn_perm(h1, h0, sel1.y);
+                r1l[j][0] = __builtin_amdgcn_perm(l1, l0, sel1.x); r1l[j][1] = __builtin_amdgcn_perm(l1, l0, sel1.y);
+                // fence the scheduler every two rows: left alone it hoists all sixteen selector reads and the eight rows'
+                // cubic pieces to the top (it budgets 512 registers, but everything a VALU instruction writes must sit in
+                // the 256 architectural ones next to 160..208 accumulators) and the kernel spills
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            float sv[8];
+            float smx = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sv[j] = siluf(raw.x[j]) * 16.0f; smx = fmaxf(smx, fabsf(sv[j])); }
+            const bool base32 = __any(!(smx < 60000.0f));
+            split_f16x2(sv, sah, sal);
+            if (chunk_exp(raw) > T) break;                   // wave-uniform, rare: rescale outside, then redo this chunk
+            const float gs = ldexpf(1.0f, 10 - T);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = raw.g[t][j] * gs;
+                split_f16x2(v, bhi[t], blo[t]);
+            }
+            if (base32) {
+                const float gs16 = gs * 16.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        Dh[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[j] * 0.0625f, raw.g[t][j] * gs16, Dh[t], 0, 0, 0);
+            }
+            load_raw(raw);                                   // next chunk: lands under the MFMAs below
 #pragma unroll
             for (int c = 0; c < kCTmax - 1; ++c) {
                 const int q = c >> 1;
@@ -1159,11 +1164,8 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) Dh[t] = mfma16_f16(sal, bhi[t], Dh[t]);
             }
-            if (n0 + 32 >= rend) { n0 += 32; break; }
-            if (chunk_exp(raw) > T) { grow = true; n0 += 32; break; }
-            expand(raw, T);
         }
-        if (grow) {
+        if (n0 < rend) {
             const int ex = chunk_exp(raw);
             const float dn = ldexpf(1.0f, T - ex);
 #pragma unroll
@@ -1175,7 +1177,6 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) D1[c][t] *= dn;
             T = ex;
-            expand(raw, T);
         }
     }
     const float undo = ldexpf(1.0f, T - 20), undo_b = ldexpf(1.0f, T - 14);
@@ -1192,7 +1193,7 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
 #pragma unroll
                 for (int c = 0; c < NS1; ++c)
                     if (c < ns1) slab[((s * (C + 1) + 8 + c) * inP + fl) * outP + o] = D1[c][t][reg] * undo;
-                slab[((s * (C + 1) + C) * inP + fl) * outP + o] = fmaf(Dh[t][reg], undo_b, Df[t][reg]);
+                slab[((s * (C + 1) + C) * inP + fl) * outP + o] = Dh[t][reg] * undo_b;
             }
         }
     }
@@ -1278,9 +1279,11 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
         const DwPlan p = split_dw_plan_w2(N, in, out, C);
         if (ws_bytes < (size_t)(p.NS + 1) * p.per * sizeof(float)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "kan_split_dw");
         float* slab = ws + p.per;
-#define W2(RR) kan_split_dw_w2_kernel<4, RR><<<dim3(p.nbx, p.FG * p.OC), 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p.OC, \
-                                                                                    p.rpw, p.inP, p.outP, slab)
-        if (p.rs == 4) W2(4); else if (p.rs == 2) W2(2); else W2(1);
+#define W2(NN, RR) kan_split_dw_w2_kernel<NN, RR><<<dim3(p.nbx, p.FG * p.OC), 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nk, p.OC, \
+                                                                                     p.rpw, p.inP, p.outP, slab)
+#define W2N(NN) if (p.rs == 4) W2(NN, 4); else if (p.rs == 2) W2(NN, 2); else W2(NN, 1)
+        switch (C - 8) { case 1: W2N(1); break; case 2: W2N(2); break; case 3: W2N(3); break; default: W2N(4); break; }
+#undef W2N
 #undef W2
         KAGNN_LAUNCH_CHECK();
         const int SG = max(1, min(3, 1024 / (32 * (C + 1))));
@@ -1301,6 +1304,7 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
               else kan_split_dw_kernel<KK, false><<<grid, 256, 0, st>>>(ARGS, 0)
 #define LN(KK) if (p.rs == 4) kan_split_dw_kernel<KK, false, 4><<<grid, 256, 0, st>>>(ARGS, 0); \
                else if (p.rs == 2) kan_split_dw_kernel<KK, false, 2><<<grid, 256, 0, st>>>(ARGS, 0); \
+               else if (KK == 3 && dw_two_waves(in, out, C, K)) kan_split_dw_kernel<3, false, 1, 2><<<grid, 256, 0, st>>>(ARGS, 0); \
                else { L(KK); }
     switch (K) {
         case 0: LN(0); break;
