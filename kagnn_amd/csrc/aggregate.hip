@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void agg_hub_v4_kernel(AggArgs a, const int* _
     s_part[threadIdx.x] = acc;
     __syncthreads();
     if (g == 0 && c4 < a.F) {
+#pragma unroll 8                               // (fully unrolled at G = 64 / 128 the loads of all partials are hoisted: 510 registers, scratch)
         for (int k = 1; k < G; ++k) {          // fixed order inside the segment
             const float4 p = s_part[k * LPR + lg];
             acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void agg_hub_merge_kernel(AggArgs a, const int
     s_part[threadIdx.x] = acc;
     __syncthreads();
     if (g == 0 && c4 < a.F) {
+#pragma unroll 8                               // (fully unrolled at G = 64 / 128 the loads of all partials are hoisted: 510 registers, scratch)
         for (int k = 1; k < G; ++k) {
             const float4 p = s_part[k * LPR + lg];
             acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;

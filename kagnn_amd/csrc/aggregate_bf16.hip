@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void agg16_hub_kernel(Agg16Args a, const int* 
     s_part[threadIdx.x] = acc;
     __syncthreads();
     if (g == 0 && c8 < a.F) {
+#pragma unroll 8                               // (fully unrolled at G = 64 / 128 the loads of all partials are hoisted: 510 registers, scratch)
         for (int k = 1; k < G; ++k) {
             const f8 p = s_part[k * LPR + lg];
 #pragma unroll
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void agg16_hub_merge_kernel(Agg16Args a, const
     s_part[threadIdx.x] = acc;
     __syncthreads();
     if (g == 0 && c8 < a.F) {
+#pragma unroll 8                               // (fully unrolled at G = 64 / 128 the loads of all partials are hoisted: 510 registers, scratch)
         for (int k = 1; k < G; ++k) {
             const f8 p = s_part[k * LPR + lg];
 #pragma unroll

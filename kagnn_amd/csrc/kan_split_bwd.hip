@@ -428,7 +428,12 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
                      const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
                      const RbfArgs& rb, int accumulate, int gx16, hipStream_t st) {
     // the schedule experiments only pay on the common cubic instantiation; the others keep the prefetch form
-    if constexpr (K == 3 && !GEN) {
+    if constexpr (K == 3 && !GEN && Q2 == 4) {
+        // 128 outputs: the prefetched gy rows of the next tile are 64 more live registers -- the kernel spilled 27..36 VGPRs
+        // with them (profiles/r03_kernel_resources.txt); plain schedule
+        if (gx16) return launch_dx_pp<K, Q2, GEN, 0, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
+        return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
+    } else if constexpr (K == 3 && !GEN) {
         if (gx16) return launch_dx_pp<K, Q2, GEN, 1, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
         switch (dx_schedule()) {
             case 0: return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
@@ -448,7 +453,10 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
 // window-major W^T tiles (wcat_v sh == 2): window 0 = 8 spline slots + base, window 1 = only its C - 8 live slots;
 // the scalar's span and SiLU' are evaluated once, the second window costs one more barrel contraction.
 // Per 32 rows x 16 input features: (9 + C - 8) * Q2 * 6 MFMAs and ~95 VALU per scalar instead of 18 * Q2 * 6 and 2 x 74.
-template <int Q2>
+// NS1: planes of the second window the kernel runs -- C - 8 when that is <= 4, else all 8 (slots >= C - 8 carry zero weights).
+// A template parameter: behind a run-time `c < C - 8` the conditional MFMAs made the compiler carry the whole 64-register
+// accumulator array through phi copies (21 spilled VGPRs at Q2 = 4).
+template <int Q2, int NS1>
 __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in, int out, int C,
     const float* __restrict__ knots_g, int nknots, const unsigned char* __restrict__ pack,
@@ -460,7 +468,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < nknots) s_knots[tid] = knots_g[tid];
     build_barrel_table(s_btbl, tid);
-    const int T = cdiv(in, 16), ns1 = C - 8;                     // real feature tiles; live slots of the second window
+    const int T = cdiv(in, 16);                                  // real feature tiles
+    constexpr int ns1 = NS1;                                     // planes of the second window (stage() copies that prefix)
     constexpr int FT_BYTES = kCTmax * Q2 * 2 * 1024;
     const int e_w = reinterpret_cast<const int*>(pack)[1];
     const unsigned char* gw = pack + kHdrBytes;
@@ -590,23 +599,22 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
             __syncthreads();
             stage(2 * t + 1, ns1);
             __syncthreads();
+            f32x4 D1[NS1][2];
 #pragma unroll
-            for (int c = 0; c < kCTmax - 1; ++c) { D[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int c = 0; c < NS1; ++c) { D1[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D1[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-            for (int c = 0; c < kCTmax - 1; ++c) {
-                if (c < ns1) {                                            // wave-uniform
+            for (int c = 0; c < NS1; ++c) {
 #pragma unroll
-                    for (int q = 0; q < Q2; ++q) {
-                        const u32x4 bhi = *reinterpret_cast<const u32x4*>(wl + (size_t)(2 * (c * Q2 + q) + 0) * 1024);
-                        const u32x4 blo = *reinterpret_cast<const u32x4*>(wl + (size_t)(2 * (c * Q2 + q) + 1) * 1024);
-                        D[c][0] = mfma16_f16(ahi[0][q], bhi, D[c][0]);
-                        D[c][1] = mfma16_f16(ahi[1][q], bhi, D[c][1]);
-                        D[c][0] = mfma16_f16(ahi[0][q], blo, D[c][0]);
-                        D[c][1] = mfma16_f16(ahi[1][q], blo, D[c][1]);
-                        D[c][0] = mfma16_f16(alo[0][q], bhi, D[c][0]);
-                        D[c][1] = mfma16_f16(alo[1][q], bhi, D[c][1]);
-                        __builtin_amdgcn_sched_barrier(0);                // keep the fragment reads of later slots where they are
-                    }
+                for (int q = 0; q < Q2; ++q) {
+                    const u32x4 bhi = *reinterpret_cast<const u32x4*>(wl + (size_t)(2 * (c * Q2 + q) + 0) * 1024);
+                    const u32x4 blo = *reinterpret_cast<const u32x4*>(wl + (size_t)(2 * (c * Q2 + q) + 1) * 1024);
+                    D1[c][0] = mfma16_f16(ahi[0][q], bhi, D1[c][0]);
+                    D1[c][1] = mfma16_f16(ahi[1][q], bhi, D1[c][1]);
+                    D1[c][0] = mfma16_f16(ahi[0][q], blo, D1[c][0]);
+                    D1[c][1] = mfma16_f16(ahi[1][q], blo, D1[c][1]);
+                    D1[c][0] = mfma16_f16(alo[0][q], bhi, D1[c][0]);
+                    D1[c][1] = mfma16_f16(alo[1][q], bhi, D1[c][1]);
+                    __builtin_amdgcn_sched_barrier(0);                // keep the fragment reads of later slots where they are
                 }
             }
             const unsigned gx_ro = gx_rb + fcol;
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
                     cubic_dbases(u, inside ? wd : 0.0f, dN);
                     float d[kCTmax - 1];
 #pragma unroll
-                    for (int c = 0; c < kCTmax - 1; ++c) d[c] = D[c][rt][reg];
+                    for (int c = 0; c < kCTmax - 1; ++c) d[c] = c < NS1 ? D1[c < NS1 ? c : 0][rt][reg] : 0.0f;
                     const int m1 = m - 8;
                     const u32x4 sel = *reinterpret_cast<const u32x4*>(s_btbl + 4 * min((unsigned)m1, 15u));
                     const float s = (s0[rt][reg] + barrel_dot3(d, m1, sel, dN)) * rinv[rt][reg];
@@ -632,17 +640,17 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
     }
 }
 
-template <int Q2>
+template <int Q2, int NS1>
 static int launch_dx_w2(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                         const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx, hipStream_t st) {
     const size_t lds = kLdsHdr + (size_t)kCTmax * Q2 * 2 * 1024;
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_w2_kernel<Q2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_w2_kernel<Q2, NS1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
     }
-    kan_split_dx_w2_kernel<Q2><<<(unsigned)min((long)cdiv(N, 256), 256L), 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots,
-                                                                                   pack, gx, ldgx);
+    kan_split_dx_w2_kernel<Q2, NS1><<<(unsigned)min((long)cdiv(N, 256), 256L), 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots,
+                                                                                        pack, gx, ldgx);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -676,11 +684,18 @@ int kan_split_dx_any(const float* x, long ldx, const float* gy, long ldgy, long 
         if (gx16) return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 gradient rows need <= 8 coefficients", "kan_split_dx");
         const unsigned char* p = static_cast<const unsigned char*>(pack);
         const int nk = G + 2 * K + 1;
+#define W2Q(QQ, NN) launch_dx_w2<QQ, NN>(x, ldx, gy, ldgy, N, in, out, G + K, knots, nk, p, gx, ldgx, st)
+#define W2(QQ) switch (G + K - 8) { case 1: return W2Q(QQ, 1); case 2: return W2Q(QQ, 2); case 3: return W2Q(QQ, 3); case 4: return W2Q(QQ, 4); \
+                                    default: return W2Q(QQ, 8); }
         switch (dx_q2(out)) {
-            case 1: return launch_dx_w2<1>(x, ldx, gy, ldgy, N, in, out, G + K, knots, nk, p, gx, ldgx, st);
-            case 2: return launch_dx_w2<2>(x, ldx, gy, ldgy, N, in, out, G + K, knots, nk, p, gx, ldgx, st);
-            default: return launch_dx_w2<4>(x, ldx, gy, ldgy, N, in, out, G + K, knots, nk, p, gx, ldgx, st);
+            case 1: W2(1)
+            case 2: W2(2)
+            default:                        // (Q2 = 4 with ONE plane happens to spill 32 VGPRs; two planes -- the second on zero weights -- do not)
+                if (G + K - 8 == 1) return W2Q(4, 2);
+                W2(4)
         }
+#undef W2
+#undef W2Q
     }
     const size_t stride = dx_blk_bytes(in << vshift(G + K), min(out, kOutBlk));
     for (int b = 0; b * kOutBlk < out; ++b) {

@@ -203,3 +203,30 @@ def test_size_queries_and_argument_checks_need_no_gpu():
     assert b"argument check failed" in lib.kagnn_last_error()
     assert lib.kagnn_softmax_xent_fwd(None, 4, 10, 40, None, None, 1, None, None, None, None, 0, None) != 0            # ld < classes
     assert lib.kagnn_kan_grid_refit_workspace_bytes(0, 8, 5, 3, byref(a)) != 0                                         # no rows
+
+
+def test_hot_path_kernels_do_not_spill_registers():
+    """Round 2's slow kernels (column-moments forward, config 3's weight gradient, the headline weight gradient) were all
+    visible in the compiler's own metadata: spilled VGPRs / scratch bytes per lane.  tools/kernel_resources.py reads that
+    metadata from the objects _build leaves in kagnn_amd/lib/obj; an instantiation on a measured path that spills fails here."""
+    import importlib.util
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    objdir = os.path.join(root, "kagnn_amd", "lib", "obj")
+    if not os.path.isdir(objdir) or not shutil.which("c++filt") or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no build objects / LLVM tools on this machine (the library was shipped prebuilt)")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = kr.collect(objdir)
+    report = kr.hot_path_report(rows)
+    names = [r[0] for r in report]
+    # the gate really covers the kernels bench.py times (a renamed kernel must not silently drop out of it)
+    for must in ("kan_sparse_fwd_kernel<2,false,false,false>", "kan_sparse_fwd_kernel<2,false,true,false>",
+                 "kan_split_dw_kernel<3,false,1,4>", "kan_split_dx_kernel<3,2,false,1,false>", "kan_split_dw_w2_kernel<3,1>",
+                 "kan_split_dx_w2_kernel<4,3>", "kan_split_dw_kernel<0,false,1,4>", "agg_rows_v4_kernel<16>"):
+        assert must in names, f"{must} is not covered by the spill gate: {sorted(names)[:5]}..."
+    bad = [r for r in report if r[1] > r[3] or r[2] > r[4]]
+    assert not bad, "hot-path kernels spill registers: " + "; ".join(f"{r[0]}: {r[1]} VGPRs / {r[2]} B" for r in bad)
+    # one wave per SIMD is the floor: nothing may need more than the 512-entry file
+    assert all(k["vgpr_count"] <= 512 for k in rows)
