@@ -286,18 +286,25 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             // read from LDS BEFORE the MFMAs of group g are issued, so the LDS latency hides under them.
             {
                 constexpr int NGRP = kCTmax * Q2;
-                u32x4 bh[2], bl[2];
-                bh[0] = *reinterpret_cast<const u32x4*>(wft + 0 * 1024);
-                bl[0] = *reinterpret_cast<const u32x4*>(wft + 1 * 1024);
+#ifndef KAGNN_DX_LDS_DEPTH
+#define KAGNN_DX_LDS_DEPTH 1      // (2 and 3 measured: no change -- the M phase does not wait on LDS; profiles/r03_experiments.md)
+#endif
+                constexpr int RD = KAGNN_DX_LDS_DEPTH;       // fragment reads in flight ahead of the MFMAs that use them
+                u32x4 bh[RD + 1], bl[RD + 1];
+#pragma unroll
+                for (int g = 0; g < RD; ++g) {
+                    bh[g] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * g + 0) * 1024);
+                    bl[g] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * g + 1) * 1024);
+                }
 #pragma unroll
                 for (int g = 0; g < NGRP; ++g) {
                     const int c = g / Q2, q = g % Q2;      // LDS order is [c][q][hi|lo], i.e. group g at 2g KiB
-                    if (g + 1 < NGRP) {
-                        bh[(g + 1) & 1] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * (g + 1) + 0) * 1024);
-                        bl[(g + 1) & 1] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * (g + 1) + 1) * 1024);
+                    if (g + RD < NGRP) {
+                        bh[(g + RD) % (RD + 1)] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * (g + RD) + 0) * 1024);
+                        bl[(g + RD) % (RD + 1)] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * (g + RD) + 1) * 1024);
                     }
                     __builtin_amdgcn_sched_barrier(0);     // pin: hipcc otherwise sinks the reads back to their first use
-                    const u32x4 bhi = bh[g & 1], blo = bl[g & 1];
+                    const u32x4 bhi = bh[g % (RD + 1)], blo = bl[g % (RD + 1)];
                     D[c][0] = mfma16_f16(ahi[0][q], bhi, D[c][0]);
                     D[c][1] = mfma16_f16(ahi[1][q], bhi, D[c][1]);
                     D[c][0] = mfma16_f16(ahi[0][q], blo, D[c][0]);
@@ -719,27 +726,13 @@ struct DwPlan { int nbx; long rpw; long NS; long per; int FG, OC; long inP, outP
 // rows one dW workgroup may own: with leading dimensions up to kDwMaxLd floats its slice of x / gy spans < 4 GiB
 constexpr long kDwMaxRowsPerBlock = 1L << 17;
 
-// KAGNN_DW_NTO = 4 | 2: output tiles per wave of the <= 8-coefficient cubic weight-gradient kernel (one wave per SIMD on 64
-// outputs, or two waves per SIMD on 32 outputs each; see kan_split_dw_kernel)
-static int dw_nto() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("KAGNN_DW_NTO");
-        v = e ? atoi(e) : 4;
-        if (v != 2 && v != 4) v = 4;
-    }
-    return v;
-}
-static bool dw_two_waves(int in, int out, int C, int K) { return dw_nto() == 2 && K == 3 && C <= 8 && in > 32; }
-
 static DwPlan split_dw_plan(long N, int in, int out, int C, int K) {
     DwPlan p;
     const bool virt = C > 8;
-    const bool two = dw_two_waves(in, out, C, K);
     if (C > 8) { in <<= 1; C = 8; }                    // virtual features: 2*in features of 8 slots (wcat_v)
-    p.FG = cdiv(in, 64); p.OC = cdiv(out, two ? 32 : 64);
+    p.FG = cdiv(in, 64); p.OC = cdiv(out, 64);
     const int roles = p.FG * p.OC;
-    int nb = max(1, (two ? 512 : 256) / roles);        // ~1 workgroup per CU (two-wave form: 2)
+    int nb = max(1, 256 / roles);                      // ~1 workgroup per CU
     long r = (N + nb - 1) / nb;
     r = max(32L, (r + 31) & ~31L);                     // whole 32-row chunks
     r = min(r, kDwMaxRowsPerBlock);                    // a workgroup's rows stay inside one 4 GiB buffer window
@@ -790,9 +783,10 @@ template <int NTO> struct DwRaw { float x[8]; float g[NTO][8]; float mu[8], rs[8
 
 // RS (1, 2, 4): row sub-ranges per feature tile -- narrow layers with 4 / RS live tiles, see split_dw_plan (a template
 // parameter: as a runtime value it cost the 64-feature layer 45 %)
-// NTO (4, 2): 16-wide output tiles per wave.  4 = one wave per SIMD owns 16 features x 64 outputs (160 accumulators);
-// 2 = 16 features x 32 outputs (80 accumulators, <= 256 registers): TWO waves share a SIMD, one issuing VALU (basis
-// expansion) while the other's MFMAs run -- the overlap a lone in-order wave does not get (round 3, profiles/r03_experiments.md)
+// NTO: 16-wide output tiles per wave.  4 = one wave per SIMD owns 16 features x 64 outputs (144 accumulators).  NTO = 2
+// (16 x 32 outputs, 72 accumulators, 198 registers: TWO waves per SIMD) was measured in round 3 and is not instantiated: the
+// basis expansion runs twice and the pair gains nothing from sharing the SIMD -- 0.769 vs 0.604 ms per step
+// (profiles/r03_experiments.md)
 template <int K, bool GEN, int RS = 1, int NTO = 4>      // GEN == false: <= 8 coefficients, no virtual-feature code (see kan_split_dx_kernel)
 __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
@@ -932,7 +926,10 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
             for (int t = 0; t < NTO; ++t) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = raw.g[t][j] * gs;
+                for (int j = 0; j < 8; j += 2) {             // (packed fp32: one v_pk_mul_f32 per two values)
+                    const f32x2 pr = f32x2{raw.g[t][j], raw.g[t][j + 1]} * splat2(gs);
+                    v[j] = pr.x; v[j + 1] = pr.y;
+                }
                 split_f16x2(v, bhi[t], blo[t]);
             }
             if (base32) {                                    // rare: this chunk's base branch in exact fp32, at Dh's scale
@@ -1319,7 +1316,6 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
               else kan_split_dw_kernel<KK, false><<<grid, 256, 0, st>>>(ARGS, 0)
 #define LN(KK) if (p.rs == 4) kan_split_dw_kernel<KK, false, 4><<<grid, 256, 0, st>>>(ARGS, 0); \
                else if (p.rs == 2) kan_split_dw_kernel<KK, false, 2><<<grid, 256, 0, st>>>(ARGS, 0); \
-               else if (KK == 3 && dw_two_waves(in, out, C, K)) kan_split_dw_kernel<3, false, 1, 2><<<grid, 256, 0, st>>>(ARGS, 0); \
                else { L(KK); }
     switch (K) {
         case 0: LN(0); break;
