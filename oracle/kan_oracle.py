@@ -168,7 +168,7 @@ def fastkan_forward(x: Tensor, layers: Sequence[dict]) -> Tensor:
     base_linear.weight, base_linear.bias``."""
     for p in layers:
         c = p["rbf.grid"]
-        den = (float(c[-1]) - float(c[0])) / (c.numel() - 1)
+        den = (float(c[-1].detach()) - float(c[0].detach())) / (c.numel() - 1)
         x = fastkan_layer_forward(x, p.get("layernorm.weight"), p.get("layernorm.bias"), c, den,
                                   p["spline_linear.weight"], p.get("base_linear.weight"),
                                   p.get("base_linear.bias"))
@@ -276,6 +276,38 @@ def global_mean_pool(x: Tensor, batch: Tensor, num_graphs: Optional[int] = None)
     b = int(batch.max()) + 1 if num_graphs is None else num_graphs
     cnt = torch.zeros(b, dtype=x.dtype).scatter_add_(0, batch, torch.ones_like(batch, dtype=x.dtype))
     return global_add_pool(x, batch, b) / cnt.clamp(min=1).view(-1, 1)
+
+
+def graph_regression_forward(x: Tensor, edge_index: Tensor, edge_attr: Tensor, batch: Tensor, num_graphs: int,
+                             state: dict, arch: str, gnn_layers: int, spline_order: int = 3, bn_eps: float = 1e-5) -> Tensor:
+    """``KAGIN.forward`` / ``FASTKAGIN.forward`` of ``graph_regression/models.py:107-119,148-160`` in TRAINING mode with dropout 0
+    on a reference-keyed ``state`` dict (``atom_encoder.atom_embedding_list.{i}.weight``, ``conv.{l}.nn.layers.{i}.*``,
+    ``bn.{l}.weight|bias``, ``kan.layers.{i}.*``): embedding-table encoders over integer features (``models.py:244-281``),
+    ``GINEConv`` around the KAN / FastKAN chain, BatchNorm1d on batch statistics, ``global_add_pool``, read-out chain.
+    Runs in the dtype of ``state`` (fp64 for the GPU parity tests)."""
+    def chain(prefix, h):
+        n = 1 + max(int(k[len(prefix) + 7:].split(".")[0]) for k in state if k.startswith(prefix + "layers."))
+        if arch == "kan":
+            return kan_forward(h, [{q: state[f"{prefix}layers.{i}.{q}"] for q in ("base_weight", "spline_weight", "spline_scaler", "grid")}
+                                   for i in range(n)], spline_order)
+        keys = ("layernorm.weight", "layernorm.bias", "rbf.grid", "spline_linear.weight", "base_linear.weight", "base_linear.bias")
+        return fastkan_forward(h, [{q: state[f"{prefix}layers.{i}.{q}"] for q in keys if f"{prefix}layers.{i}.{q}" in state}
+                                   for i in range(n)])
+
+    def tables(prefix, idx):
+        out, i = 0, 0
+        while f"{prefix}.{i}.weight" in state:
+            out = out + state[f"{prefix}.{i}.weight"][idx[:, i]]
+            i += 1
+        return out
+
+    h = tables("atom_encoder.atom_embedding_list", x)
+    e = tables("bond_encoder.bond_embedding_list", edge_attr)
+    for l in range(gnn_layers):
+        h = gine_conv(h, edge_index, e, lambda t: chain(f"conv.{l}.nn.", t), float(state.get(f"conv.{l}.eps", torch.zeros(1))[0]))
+        mu, var = h.mean(0), h.var(0, unbiased=False)
+        h = (h - mu) / torch.sqrt(var + bn_eps) * state[f"bn.{l}.weight"] + state[f"bn.{l}.bias"]
+    return chain("kan.", global_add_pool(h, batch, num_graphs))
 
 
 # --------------------------------------------------------------------------------------

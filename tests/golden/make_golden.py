@@ -275,6 +275,82 @@ def g8():
     save("g8_gine_pool", **out)
 
 
+# ---------------------------------------------------------------- G8b: BASELINE config 4 at its real batch shape
+class _RefGraphRegression(torch.nn.Module):
+    """forward of the reference's graph_regression KAGIN / FASTKAGIN (graph_regression/models.py:86-119,125-160) with the
+    reference's own KAN / FastKAN modules, torch's BatchNorm1d and embedding-table encoders (models.py:244-281) under the
+    reference's attribute names; only GINEConv / global_add_pool (torch_geometric, absent here) are the oracle's restatement."""
+
+    def __init__(self, kind, gnn_layers, hidden, hidden_layers, grid, order, atom_dims, bond_dims):
+        super().__init__()
+        def chain(out_dim):
+            sizes = [hidden] + [hidden] * (hidden_layers - 1) + [out_dim]
+            return ref_ekan.KAN(sizes, grid_size=grid, spline_order=order) if kind == "kan" else ref_fastkan.FastKAN(sizes, num_grids=grid)
+        def tables(dims):
+            lst = torch.nn.ModuleList()
+            for d in dims:
+                e = torch.nn.Embedding(d, hidden)
+                torch.nn.init.xavier_uniform_(e.weight.data)
+                lst.append(e)
+            return lst
+        self.atom_encoder = torch.nn.Module(); self.atom_encoder.atom_embedding_list = tables(atom_dims)
+        self.bond_encoder = torch.nn.Module(); self.bond_encoder.bond_embedding_list = tables(bond_dims)
+        self.conv = torch.nn.ModuleList()
+        for _ in range(gnn_layers):
+            c = torch.nn.Module(); c.nn = chain(hidden); c.register_buffer("eps", torch.zeros(1))
+            self.conv.append(c)
+        self.bn = torch.nn.ModuleList(torch.nn.BatchNorm1d(hidden) for _ in range(gnn_layers))
+        self.kan = chain(1)
+
+    def forward(self, x, ei, ea, batch, num_graphs):
+        h = sum(t(x[:, i]) for i, t in enumerate(self.atom_encoder.atom_embedding_list))
+        e = sum(t(ea[:, i]) for i, t in enumerate(self.bond_encoder.bond_embedding_list))
+        for c, bn in zip(self.conv, self.bn):
+            h = bn(orc.gine_conv(h, ei, e, c.nn))                 # dropout 0
+        return self.kan(orc.global_add_pool(h, batch, num_graphs))
+
+
+def g8b():
+    """ZINC-shaped mini-batch (optuna_zinc.py:56-66): 256 graphs of 23 +- 5 nodes and ~50 directed edges, integer atom / bond
+    types through the embedding encoders, 3 GINE(KAN) layers + BatchNorm (training statistics), global_add_pool, KAN read-out,
+    L1 loss; predictions, loss and EVERY parameter gradient -- for the KAN and the FastKAN flavour."""
+    gen = torch.Generator().manual_seed(880)
+    G = 256
+    xs, eis, eas, batch = [], [], [], []
+    off = 0
+    for g in range(G):
+        n = int(torch.randint(18, 29, (1,), generator=gen))
+        e = 2 * int(torch.randint(20, 31, (1,), generator=gen))     # bonds come in both directions
+        src = torch.randint(0, n, (e // 2,), generator=gen)
+        dst = torch.randint(0, n, (e // 2,), generator=gen)
+        bt = torch.randint(0, 4, (e // 2, 1), generator=gen)
+        xs.append(torch.randint(0, 21, (n, 1), generator=gen))
+        eis.append(torch.stack([torch.cat([src, dst]), torch.cat([dst, src])]) + off)
+        eas.append(torch.cat([bt, bt]))
+        batch.append(torch.full((n,), g, dtype=torch.int64))
+        off += n
+    x, ei, ea, batch = torch.cat(xs), torch.cat(eis, 1), torch.cat(eas), torch.cat(batch)
+    noise = torch.randn(G, generator=gen)
+    out = {"x": npy(x), "edge_index": npy(ei), "edge_attr": npy(ea), "batch": npy(batch)}
+    for kind, grid in (("kan", 4), ("fastkan", 6)):
+        torch.manual_seed(881)
+        m = _RefGraphRegression(kind, 3, 32, 2, grid, 3, [21], [4]).train()
+        pred = m(x, ei, ea, batch, G)
+        # targets at least 0.25 away from the predictions: the L1 loss's gradient is sign(pred - y) / G, and a residual
+        # within rounding of zero would make the fixture's gradients a coin toss
+        y = pred.detach().squeeze() + torch.sign(noise) * (0.25 + noise.abs())
+        out[f"{kind}.y"] = npy(y)
+        loss = torch.nn.L1Loss()(pred.squeeze(), y)
+        loss.backward()
+        out[f"{kind}.pred"] = npy(pred); out[f"{kind}.loss"] = npy(loss)
+        for name, v in m.state_dict().items():
+            out[f"{kind}.state.{name}"] = npy(v)                  # (running statistics AFTER the step, as the reference leaves them)
+        for name, p_ in m.named_parameters():
+            if p_.grad is not None:
+                out[f"{kind}.grad.{name}"] = npy(p_.grad)
+    save("g8b_zinc_batch", **out)
+
+
 # ---------------------------------------------------------------- G9: harness step (2 Adam steps)
 class _RefConv(torch.nn.Module):
     """reference KAN modules inside the restated GIN / GCN message passing, with the attribute names of
@@ -550,8 +626,8 @@ def g12():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4b", "g567", "g5b", "g8", "g9", "g10", "g11", "g12"]
-    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g4b": g4b, "g567": g5_g6_g7, "g5b": g5b, "g8": g8, "g9": g9,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4b", "g567", "g5b", "g8", "g8b", "g9", "g10", "g11", "g12"]
+    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g4b": g4b, "g567": g5_g6_g7, "g5b": g5b, "g8": g8, "g8b": g8b, "g9": g9,
            "g10": g10, "g11": g11, "g12": g12}
     for w in which:
         fns[w]()

@@ -300,3 +300,28 @@ def test_gcn_norm_sparse_adds_a_unit_loop_on_top_of_the_diagonal():
     want = dis[:, None] * a_hat * dis[None, :]
     got = torch.zeros(n, n, dtype=torch.float64).index_put_((ei[1], ei[0]), w, accumulate=True)
     close(got, want, 1e-12)
+
+
+@pytest.mark.parametrize("kind", ["kan", "fastkan"])
+def test_g8b_zinc_batch_whole_model_restatement(golden, kind):
+    """BASELINE config 4's model at its real batch shape: ``oracle.graph_regression_forward`` (the oracle's own layer
+    restatements + gine_conv + global_add_pool + batch statistics) reproduces the predictions and the L1 loss of the
+    fixture that was made with the reference's ekan.KAN / fastkan.FastKAN modules; its fp64 gradients agree with the
+    fixture's fp32 ones to the error of an fp32 chain this deep (three BatchNorms, relu kinks in 400k messages)."""
+    z = golden("g8b_zinc_batch")
+    pre = f"{kind}.state."
+    x, ei, ea, batch, y = T(z["x"]), T(z["edge_index"]), T(z["edge_attr"]), T(z["batch"]), T(z[f"{kind}.y"])
+    st32 = {k[len(pre):]: T(z[k]) for k in z.files if k.startswith(pre)}
+    pred = orc.graph_regression_forward(x, ei, ea, batch, 256, st32, kind, 3)
+    close(pred, z[f"{kind}.pred"], 2e-5)
+    assert abs(float((pred.squeeze() - y).abs().mean()) - float(z[f"{kind}.loss"])) < 1e-5
+    st = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in st32.items()}
+    pred64 = orc.graph_regression_forward(x, ei, ea, batch, 256, st, kind, 3)
+    close(pred64.detach(), z[f"{kind}.pred"], 5e-5)
+    (pred64.squeeze() - y.double()).abs().mean().backward()
+    checked = 0
+    for k in z.files:
+        if k.startswith(f"{kind}.grad."):
+            close(st[k[len(kind) + 6:]].grad, z[k], 5e-3)
+            checked += 1
+    assert checked >= 20
