@@ -488,7 +488,7 @@ def test_zinc_shaped_batch_regression_models_golden(golden, kind, mode, monkeypa
     loss.backward()
     # (1) the reference-made fixture: predictions and loss (fp32 arithmetic on both sides)
     assert_close(pred, z[f"{kind}.pred"], 1e-4, what=f"zinc {kind} pred vs fixture")
-    assert abs(float(loss) - float(z[f"{kind}.loss"])) < 5e-5
+    assert abs(float(loss.detach()) - float(z[f"{kind}.loss"])) < 5e-5
     # (2) every gradient against the fp64 oracle restatement of the same model (pinned to the same fixture by
     # tests/test_oracle_golden.py; the fixture's own fp32 gradients are 1e-4..4e-3 off at this depth -- three BatchNorms
     # on batch statistics, relu kinks in 400k GINE messages -- so they cannot referee a 1e-4 contract)
@@ -497,10 +497,18 @@ def test_zinc_shaped_batch_regression_models_golden(golden, kind, mode, monkeypa
     p64 = orc.graph_regression_forward(T(z["x"]), T(z["edge_index"]), T(z["edge_attr"]), T(z["batch"]), 256, st, kind, 3)
     (p64.squeeze() - T(z[f"{kind}.y"]).double()).abs().mean().backward()
     assert_close(pred, p64, 5e-5, what=f"zinc {kind} pred vs fp64 oracle")
+    # Referee: the fp64 oracle; yardstick: the error of the fixture's fp32 gradient (the reference's own arithmetic) against
+    # the same oracle.  relu(x_j + e_ij) has a kink: a message element within rounding of zero flips the upstream gradient
+    # by ~1e-3 of its scale, and which side an fp32 pipeline lands on is arithmetic-order luck (tools/zinc_grad_errors.py:
+    # KAN flavour 1e-6 in both modes and 7e-6 for the reference; FastKAN flavour exact-fp32 mode 5e-6, split mode 1.6e-3,
+    # the reference's own fp32 run 1.6e-3).  A gradient may be off by 1e-4, or by twice what the reference itself is off.
     checked = 0
     for name, p_ in m.named_parameters():
-        if st[name].grad is not None:
-            assert_close(p_.grad, st[name].grad, 1e-4, what=f"zinc {kind} grad.{name}", elementwise=False)
+        if p_.requires_grad and st[name].grad is not None:
+            g, w64, w32 = p_.grad.double().cpu(), st[name].grad, T(z[f"{kind}.grad.{name}"]).double()
+            scale = max(1.0, float(w64.abs().max()))
+            e64, eref = float((g - w64).abs().max()) / scale, float((w32 - w64).abs().max()) / scale
+            assert e64 <= max(1e-4, 2.0 * eref), f"zinc {kind} grad.{name}: {e64:.2e} from the fp64 oracle (the reference's fp32 gradient: {eref:.2e})"
             checked += 1
     assert checked >= 20
 
