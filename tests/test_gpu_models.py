@@ -495,6 +495,31 @@ def test_bf16_mode_node_model_runs_and_stays_close(monkeypatch):
         assert_close(out, ref, 2e-2, what=f"{cls.__name__} bf16 vs fp32 logits", elementwise=False)     # two BatchNorms amplify the 2^-9 input rounding
 
 
+def test_bf16_mode_arxiv_shaped_kan_gin_model_vs_oracle(monkeypatch):
+    """BASELINE config 2 AS WORDED ("ogbn-arxiv KAN-GIN 3-layer hidden=64 grid=5 bf16"): GKAN_Nodes('gin', 3, 128 -> 64, 40
+    classes) at ogbn-arxiv's shape under KAGNN_ACT=bf16 -- logits, d/dx and every parameter gradient against the fp64
+    oracle of the SAME model on the unrounded input, at the build-defined mode's tolerances (4e-3
+    outputs, 8e-3 input gradient, 1e-2 parameter gradients, relative to the largest element)."""
+    monkeypatch.setenv("KAGNN_ACT", "bf16")
+    n, ei, x = _arxiv_like()
+    torch.manual_seed(6)
+    model = kagnn_amd.GKAN_Nodes("gin", 3, 128, 64, 40, skip=True, grid_size=5, spline_order=3, hidden_layers=2)
+    gout = torch.randn(n, 40, generator=torch.Generator().manual_seed(7)) / n
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    want, gx_want, g_want = oracle_node_model_fwd_bwd(x, ei, state, gout, "kan", "gin", 3, 3, 1024, torch.float64)
+    model = model.to(DEV).train()
+    xd = x.to(DEV).requires_grad_(True)
+    out = model(xd, ei.to(DEV))
+    out.backward(gout.to(DEV))
+    assert_close(out, want, 4e-3, what="arxiv.bf16.logits", elementwise=False)
+    assert_close(xd.grad, gx_want, 8e-3, what="arxiv.bf16.gx", elementwise=False)
+    for name, p in model.named_parameters():
+        parts = name.split(".")
+        if not p.requires_grad or (parts[0] == "convs" and parts[-1] == "bias" and len(parts) == 3):
+            continue                                   # (a bias in front of BatchNorm: identically zero gradient, see _model_vs_oracle)
+        assert_close(p.grad, g_want[name], 1e-2, what=f"arxiv.bf16.grad.{name}", elementwise=False)
+
+
 # ------------------------------------------------------------------ torch.library registration (SURVEY 8(b))
 @pytest.mark.parametrize("arch,kind", [("kan", "gin"), ("kan", "gcn"), ("fastkan", "gin"), ("fastkan", "gcn")])
 def test_models_trace_into_one_graph_of_kagnn_ops(arch, kind):
