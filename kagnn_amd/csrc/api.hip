@@ -667,6 +667,7 @@ int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t N, const int3
         if (l == 0 && gx == nullptr) break;
         // the gathered matrix of the transposed aggregation leaves the dX kernel as bf16 when the mode asks for it
         const bool b16 = l == 0 && bf16_gather && mode == KAGNN_PREC_SPLIT && K == 3 && G + K <= 8 && out <= 128 && in % 8 == 0 &&
+                         in <= 512 /* the bf16 aggregation's row limit (aggregate_bf16_ok): wider first layers keep fp32 rows */ &&
                          use_split_dx(in, out, G, K, mode);
         rc = kagnn_kan_linear_bwd_input(acts[l], in, g, ldg, N, knots, in, out, G, K, mode, pack_dx[l], gbuf[cur], in,
                                         b16 ? KAGNN_DTYPE_BF16 : KAGNN_DTYPE_F32, stream);

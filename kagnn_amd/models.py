@@ -102,9 +102,10 @@ class _SumAggregateConv(nn.Module):
                 if want:
                     y, self.__dict__["_moments"] = y
                 return y
-        if x.dtype == torch.bfloat16 or ops.default_activation_dtype() == torch.bfloat16:
-            # bf16 gather operands outside the fused node (FastKAN chains, traced code): the aggregation takes the bf16
-            # rows and hands fp32 sums to the chain
+        if (x.dtype == torch.bfloat16 or ops.default_activation_dtype() == torch.bfloat16) and not torch.compiler.is_compiling():
+            # bf16 gather operands outside the fused node (FastKAN chains): the aggregation takes the bf16 rows and hands
+            # fp32 sums to the chain.  Traced code (torch.compile) keeps fp32 rows: the opaque kagnn::aggregate_sum op is
+            # registered for fp32 operands and the bf16 conversion is a ctypes call dynamo cannot trace
             xg = x if x.dtype == torch.bfloat16 else ops.to_bf16_rows(x) if not x.requires_grad else x.to(torch.bfloat16)
             return self.nn(ops.aggregate_sum(xg, g, self_scale=1.0 + self._eps()))
         return self.nn(ops.aggregate_sum(x, g, self_scale=1.0 + self._eps()))
@@ -195,7 +196,10 @@ def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args):
     seed would repeat the mask on every replay)."""
     fused = (_FUSED_EPILOGUE and x.is_cuda and not torch.compiler.is_compiling() and type(dropout) is nn.Dropout
              and isinstance(bn, BatchNorm1d)
-             and not (dropout.p > 0.0 and dropout.training and torch.cuda.is_current_stream_capturing()))
+             and not (dropout.p > 0.0 and dropout.training and torch.cuda.is_current_stream_capturing())
+             # a frozen BatchNorm (bn.eval()) under an active dropout: the fused pass ties the mask to the norm's training
+             # flag, the reference's dropout(bn(.)) does not -- stock modules then
+             and (bn.training or not (dropout.training and dropout.p > 0.0)))
     if not fused:
         return dropout(bn(conv(x, g, *conv_args)))
     if isinstance(conv, _SumAggregateConv) and bn.training and not conv_args:

@@ -648,8 +648,10 @@ class _GinKanLayerFn(Function):
         nl = len(params) // 3
         layers = [(params[3 * i].contiguous(), params[3 * i + 1].contiguous(), params[3 * i + 2].contiguous()) for i in range(nl)]
         xg = _rows(x, allow_bf16=True)
-        if act_bf16 and xg.dtype != torch.bfloat16:
-            xg = to_bf16_rows(xg)
+        if xg.size(0) != g.num_nodes:            # (the library call below indexes rowptr / x by this count)
+            raise ValueError(f"x has {xg.size(0)} rows but the graph has {g.num_nodes} nodes")
+        if act_bf16 and xg.dtype != torch.bfloat16 and xg.size(1) % 8 == 0 and xg.size(1) <= 512:
+            xg = to_bf16_rows(xg)                # (rows the bf16 aggregation cannot take stay fp32 -- unrounded)
         if xg.dtype == torch.bfloat16 and not _bf16_rows_ok(xg):
             xg = xg.float()
         n, dev = xg.size(0), xg.device
@@ -718,11 +720,13 @@ class _GinKanLayerFn(Function):
                                                                                            G, K, mode, True)
                 if i > 0 or need_x:
                     bf16_out = (i == 0 and act_bf16 and mode == PREC_SPLIT and K == 3 and G + K <= 8 and fout <= 128
-                                and fin % 8 == 0 and _fits32(h_in, fout))      # the dX variant that stores bf16 rows
+                                and fin % 8 == 0 and fin <= 512 and _fits32(h_in, fout))      # the dX variant that stores bf16 rows (<= 512: the bf16 aggregation's limit)
                     gy = _kan_bwd_input_raw(h_in, gy, knots, pack_d, fin, fout, G, K, mode, bf16_out)
             gx = _aggregate_raw(gy, g, True, self_scale, None, None, None, None, False, out_dtype=gx_dtype) if need_x else None
             return (gx, None, None, None, None, None, None, None, None, *grads)
         n, dev = gy.size(0), gy.device
+        if n != g.num_nodes:
+            raise ValueError(f"the incoming gradient has {n} rows but the graph has {g.num_nodes} nodes")
         f32 = dict(dtype=torch.float32, device=dev)
         acts = [t[4 * i] for i in range(nl)]
         sws, scs, pds = [t[4 * i + 1] for i in range(nl)], [t[4 * i + 2] for i in range(nl)], [t[4 * i + 3] for i in range(nl)]
@@ -740,7 +744,7 @@ class _GinKanLayerFn(Function):
               _ptr(g.hub_seg_t) if g.num_hub_seg_t else None, g.num_hub_seg_t, g.hub_threshold, float(self_scale), nl, warr,
               _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, _ptr_array(acts), _ptr_array(pds), _ptr(gx),
               _lib.DTYPE_BF16 if (gx is not None and gx.dtype == torch.bfloat16) else _lib.DTYPE_F32, widths[0],
-              int(bool(act_bf16) and widths[0] % 8 == 0), _ptr_array(gbw), _ptr_array(gsw), _ptr_array(gsc), _ptr(ws), ws.numel(),
+              int(bool(act_bf16) and widths[0] % 8 == 0 and widths[0] <= 512), _ptr_array(gbw), _ptr_array(gsw), _ptr_array(gsc), _ptr(ws), ws.numel(),
               _stream())
         if gx is not None and gx.dtype != gx_dtype:
             gx = gx.to(gx_dtype)

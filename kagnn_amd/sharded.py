@@ -129,6 +129,8 @@ class _Finish(Function):
 
 
 def _chunk_bounds(n: int, chunks: int):
+    if n <= 0:
+        return [(0, 0)]                                          # an empty shard still runs its (empty) collectives
     chunks = max(1, min(chunks, n))
     per = -(-n // chunks)
     per = -(-per // 256) * 256 if n >= 4096 else per            # whole 256-row kernel tiles
@@ -272,8 +274,7 @@ class _QueueFlatSync(Function):
 
     @staticmethod
     def backward(ctx, g):
-        from torch.autograd import Variable
-        Variable._execution_engine.queue_callback(ctx.module.sync_gradients)
+        ctx.module._arm_flat_sync()
         return g, None
 
 
@@ -298,9 +299,37 @@ class TransposedShardedGIKANLayer(nn.Module):
                 raise ValueError("layer widths must be divisible by the world size")
         import copy
         self.layers = nn.ModuleList(copy.deepcopy(l) for l in conv.nn.layers)      # replicated parameters
+        self._flat_pending = None          # gradients as they stood when this backward pass reached the module
+
+    def _arm_flat_sync(self) -> None:
+        """called by the first backward node of this module an engine run reaches (before any of the run's parameter
+        gradients has been accumulated): remember the gradients accumulated by EARLIER backward passes and queue ONE
+        end-of-backward callback.  The callback all-reduces only what this pass added -- with gradient accumulation
+        (two backward() calls without zero_grad) or the module used twice in one forward, already-synced sums must not
+        be summed over the ranks again (P*S1 + S2 instead of S1 + S2)."""
+        if self._flat_pending is not None:
+            return                         # a later use of the module in the same pass: already armed
+        from torch.autograd import Variable
+        self._flat_pending = [None if p.grad is None else p.grad.detach().clone() for p in self.parameters()]
+        Variable._execution_engine.queue_callback(self._flat_sync_delta)
+
+    def _flat_sync_delta(self) -> None:
+        prev, self._flat_pending = self._flat_pending, None
+        params = [p for p in self.parameters()]
+        live = [(p, b) for p, b in zip(params, prev) if p.grad is not None]
+        if not live:
+            return
+        flat = torch.cat([(p.grad if b is None else p.grad - b).reshape(-1) for p, b in live])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for p, b in live:
+            d = flat[off:off + p.grad.numel()].view_as(p.grad)
+            p.grad.copy_(d if b is None else b + d)
+            off += p.grad.numel()
 
     def sync_gradients(self) -> None:
-        """sum the parameter gradients over the ranks with a single flat all-reduce (for ``sync_in_backward=False``)"""
+        """sum the parameter gradients over the ranks with a single flat all-reduce (for ``sync_in_backward=False``;
+        reduces whatever sits in ``.grad`` -- call it once per optimiser step, after the last backward)"""
         grads = [p.grad for p in self.parameters() if p.grad is not None]
         if not grads:
             return

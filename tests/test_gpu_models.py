@@ -495,6 +495,38 @@ def test_bf16_mode_node_model_runs_and_stays_close(monkeypatch):
         assert_close(out, ref, 2e-2, what=f"{cls.__name__} bf16 vs fp32 logits", elementwise=False)     # two BatchNorms amplify the 2^-9 input rounding
 
 
+def test_bf16_mode_first_layer_wider_than_the_bf16_aggregation(monkeypatch):
+    """a first layer wider than the bf16 aggregation's 512-column limit (1024 -> 64) under KAGNN_ACT=bf16 --
+    the forward falls back to fp32 gathers; the backward used to have dX write bf16 rows and then fail in
+    kagnn_aggregate_sum_bf16.  Both directions must run and equal the fp32 mode."""
+    n, e = 3000, 20000
+    ei = orc.powerlaw_graph(n, e, seed=5).to(DEV)
+    x = (torch.randn(n, 1024, generator=torch.Generator().manual_seed(6)) * 0.3).to(DEV)
+    gy = torch.randn(n, 64, generator=torch.Generator().manual_seed(7)).to(DEV)
+    torch.manual_seed(8)
+    conv = kagnn_amd.GIKANLayer(1024, 64, grid_size=5, spline_order=3, hidden_dim=64, nb_layers=2).to(DEV)
+    res = {}
+    for act in ("fp32", "bf16"):
+        monkeypatch.setenv("KAGNN_ACT", act)
+        conv.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        y = conv(xd, ei)
+        y.backward(gy)
+        res[act] = (y.detach(), xd.grad.float(), conv.nn.layers[0].spline_weight.grad.clone())
+    for a, b, what in zip(res["bf16"], res["fp32"], ("y", "gx", "g_spline_weight")):
+        assert_close(a, b, 1e-6, what=f"bf16 mode, 1024-wide first layer: {what}", elementwise=False)
+
+
+def test_fused_layer_refuses_a_graph_built_for_another_node_count():
+    """the one-call layer ABI indexes rowptr / x by x.size(0); a GraphIndex of another size must raise, not read
+    out of bounds."""
+    ei = orc.powerlaw_graph(500, 3000, seed=1).to(DEV)
+    g = ops.GraphIndex(ei, 500)
+    conv = kagnn_amd.GIKANLayer(16, 16, grid_size=5, spline_order=3, hidden_dim=16, nb_layers=2).to(DEV)
+    with pytest.raises(ValueError, match="nodes"):
+        conv(torch.randn(400, 16, device=DEV), g)
+
+
 def test_bf16_mode_arxiv_shaped_kan_gin_model_vs_oracle(monkeypatch):
     """BASELINE config 2 AS WORDED ("ogbn-arxiv KAN-GIN 3-layer hidden=64 grid=5 bf16"): GKAN_Nodes('gin', 3, 128 -> 64, 40
     classes) at ogbn-arxiv's shape under KAGNN_ACT=bf16 -- logits, d/dx and every parameter gradient against the fp64

@@ -82,6 +82,21 @@ def _worker(rank, world, port, out_dir):
             for li, layer in enumerate(tconv.layers):         # replicated parameters: full gradients on every rank
                 for name in ("base_weight", "spline_weight", "spline_scaler"):
                     assert torch.allclose(getattr(layer, name).grad, g_ref[li][name], atol=tol, rtol=tol), (n2, li, name)
+        # ---- "flat" with gradient accumulation (two backward passes, no zero_grad) and the module used twice in one
+        # forward: only what a pass adds may be summed over the ranks (the queued callback used to all-reduce
+        # the accumulated .grad again: P*S1 + S2)
+        tconv = TransposedShardedGIKANLayer(conv, None, local_ops=OracleOps, sync_in_backward="flat")
+        xs = tconv.shard_columns(x2).requires_grad_(True)
+        for _ in range(2):
+            tconv(xs, ei2).backward(tconv.shard_columns(gy2))
+        for li, layer in enumerate(tconv.layers):
+            for name in ("base_weight", "spline_weight", "spline_scaler"):
+                assert torch.allclose(getattr(layer, name).grad, 2.0 * g_ref[li][name], atol=2 * tol, rtol=tol), ("accumulate", li, name)
+        tconv.zero_grad()
+        (tconv(xs, ei2) * tconv.shard_columns(gy2)).sum().add((tconv(xs, ei2) * tconv.shard_columns(gy2)).sum()).backward()
+        for li, layer in enumerate(tconv.layers):
+            for name in ("base_weight", "spline_weight", "spline_scaler"):
+                assert torch.allclose(getattr(layer, name).grad, 2.0 * g_ref[li][name], atol=2 * tol, rtol=tol), ("used twice", li, name)
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
