@@ -335,10 +335,16 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                 };
                 auto build = [&](int s, const u32x4& e0, const u32x4& e1, float u0, float u1, u32x4& hi, u32x4& lo, int& idx) {
                     unsigned a0, a1, a2, a3, b0, b1, b2, b3, h0, h1, l0, l1;
-                    frag3_payload(u0, h0, h1, l0, l1);
-                    place1(e0, h0, h1, l0, l1, a0, a1, b0, b1);
-                    if constexpr (!SH) frag3_payload(u1, h0, h1, l0, l1);   // SH: the pair shares x -- one payload, two placements
-                    place1(e1, h0, h1, l0, l1, a2, a3, b2, b3);
+                    if constexpr (!SH) {             // the step's two scalars on packed fp32 (forward 0.399 -> 0.388 ms per step)
+                        unsigned ph[2][2], pl[2][2];
+                        frag3_payload_pair(u0, u1, ph, pl);
+                        place1(e0, ph[0][0], ph[0][1], pl[0][0], pl[0][1], a0, a1, b0, b1);
+                        place1(e1, ph[1][0], ph[1][1], pl[1][0], pl[1][1], a2, a3, b2, b3);
+                    } else {                         // SH: the pair shares x -- one payload, two placements
+                        frag3_payload(u0, h0, h1, l0, l1);
+                        place1(e0, h0, h1, l0, l1, a0, a1, b0, b1);
+                        place1(e1, h0, h1, l0, l1, a2, a3, b2, b3);
+                    }
                     hi = u32x4{a0, a1, a2, a3};
                     lo = u32x4{b0, b1, b2, b3};
                     idx = (int)(e0[2] | (e1[2] << 8));

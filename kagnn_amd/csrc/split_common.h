@@ -5,6 +5,9 @@
 namespace kagnn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 
 constexpr int kHdrBytes = 256;           // pack header: [0] float 2^(e-10), [1] int e, [2] absmax bits
 constexpr int kLdsHdr = 2560;            // LDS: knots (48 f32) @0, perm tables (2 windows x 32 x 16 B) @256, order-4 fix-up tables @1280
@@ -356,9 +359,6 @@ __device__ __forceinline__ void make_spline_frag3(float x, const unsigned* __res
 
 // two scalars at once: the span arithmetic and the cubic pieces run on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32
 // process both elements in one issue slot), conversions and placement per element as above
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 __device__ __forceinline__ void make_spline_frag3_pair(float x0, float x1, const unsigned* __restrict__ tbl,
                                                        const FastGeom& g, u32x4& ahi0, u32x4& alo0,
                                                        u32x4& ahi1, u32x4& alo1, unsigned woff = 0) {
@@ -442,6 +442,22 @@ __device__ __forceinline__ void frag3_payload(float u, unsigned& h0, unsigned& h
     h0 = pk_f16_rtz(N[0], N[1]); h1 = pk_f16_rtz(N[2], N[3]);
     l0 = pk_f16_rtz(sub_f16lo(N[0], h0), sub_f16hi(N[1], h0));
     l1 = pk_f16_rtz(sub_f16lo(N[2], h1), sub_f16hi(N[3], h1));
+}
+// two scalars' payloads at once: the cubic pieces on packed fp32 (one v_pk_mul_f32 / v_pk_fma_f32 per TWO scalars: these
+// kernels are bound by instruction count, profiles/r03_experiments.md), conversions per scalar as above
+__device__ __forceinline__ void frag3_payload_pair(float u0, float u1, unsigned (&h)[2][2], unsigned (&l)[2][2]) {
+    const f32x2 u = {u0, u1}, w6 = splat2(kAScale / 6.0f);
+    const f32x2 u2 = u * u, om = splat2(1.0f) - u, uw = u * w6, ow = om * w6;
+    const f32x2 N0 = ow * (om * om);
+    const f32x2 N3 = uw * u2;
+    const f32x2 N1 = fma2(uw, fma2(u, splat2(3.0f), splat2(-6.0f)) * u, splat2(4.0f) * w6);
+    const f32x2 N2 = fma2(uw, fma2(fma2(u, splat2(-3.0f), splat2(3.0f)), u, splat2(3.0f)), w6);
+    h[0][0] = pk_f16_rtz(N0.x, N1.x); h[0][1] = pk_f16_rtz(N2.x, N3.x);
+    l[0][0] = pk_f16_rtz(sub_f16lo(N0.x, h[0][0]), sub_f16hi(N1.x, h[0][0]));
+    l[0][1] = pk_f16_rtz(sub_f16lo(N2.x, h[0][1]), sub_f16hi(N3.x, h[0][1]));
+    h[1][0] = pk_f16_rtz(N0.y, N1.y); h[1][1] = pk_f16_rtz(N2.y, N3.y);
+    l[1][0] = pk_f16_rtz(sub_f16lo(N0.y, h[1][0]), sub_f16hi(N1.y, h[1][0]));
+    l[1][1] = pk_f16_rtz(sub_f16lo(N2.y, h[1][1]), sub_f16hi(N3.y, h[1][1]));
 }
 __device__ __forceinline__ void frag3_place(const u32x4& sel, unsigned h0, unsigned h1, unsigned l0,
                                             unsigned l1, u32x4& ahi, u32x4& alo) {
