@@ -192,11 +192,6 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy, int out,
     int chunks_per_split, long part_stride, float* __restrict__ mom_partial) {
     constexpr int NT = 512, CF = kSpCF, BPC = CF / 16, NG = CF / 16, ROWS = (NT / 64) * 32;
-#ifdef KAGNN_EXP_NOACCF
-    constexpr bool ACCF = false;
-#else
-    constexpr bool ACCF = !MOM;
-#endif
     const int HF = NARROW ? sp_hf(in << (SH ? 1 : 0)) : CF / 2;    // features per lane half: CF / 2, or 16 / 8 in narrow layers
     constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 2 * 1024;
     constexpr int SPL_BYTES = kSpSteps * OT * 2 * 2048;
@@ -285,14 +280,13 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         const long row0 = tile * ROWS + wave * 32;
         // acc: spline part (bases * 2^10); acc_b: SiLU branch through fp16 hi/lo at scale 2^4 (|silu| < 4094) -- and, for the
         // rare groups whose values do not fit that, exact fp32 MFMAs on the fp32 weights brought to the same scale
-        // ACCF: the plain instantiation keeps an accumulator tile of its own for those groups (acc_f, unscaled weights): with
-        // the 16 OT registers free the compiler schedules its loop 4 % slower (same-box A/B, profiles/r03_experiments.md);
-        // the column-moments instantiation cannot afford them
-        f32x16 acc[OT], acc_b[OT], acc_f[ACCF ? OT : 1];
+        // (round 2 kept a third tile `acc_f` for them: 16 OT more registers; with the packed-fp32 payloads the leaner kernel is as
+        // fast -- 0.393 vs 0.394 ms per step, same-box A/B -- and nothing spills)
+        f32x16 acc[OT], acc_b[OT];
 #pragma unroll
         for (int t = 0; t < OT; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc[t][i] = 0.0f; acc_b[t][i] = 0.0f; if (ACCF) acc_f[t][i] = 0.0f; }
+            for (int i = 0; i < 16; ++i) { acc[t][i] = 0.0f; acc_b[t][i] = 0.0f; }
 
         for (int ch = ch_begin; ch < ch_end; ++ch) {
 #pragma unroll
@@ -406,8 +400,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                             const int o = 32 * t + r;
                             const int fr = SH ? (f0 + j) >> 1 : f0 + j;          // SH: only the first window carries the base weight
                             const float w = (o < out && fr < in && !(SH && (j & 1))) ? base_w[(long)o * in + fr] : 0.0f;
-                            if constexpr (ACCF) acc_f[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j] * 0.0625f, w, acc_f[t], 0, 0, 0);
-                            else acc_b[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j] * 0.0625f, w * wsc16, acc_b[t], 0, 0, 0);
+                            acc_b[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j] * 0.0625f, w * wsc16, acc_b[t], 0, 0, 0);
                         }
                     }
                 }
@@ -424,7 +417,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
             const unsigned base = (unsigned)(wave * 32 + 4 * kg) * ldy4 + col * 4;
             float v[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = ACCF ? fmaf(acc[t][i], post, fmaf(acc_b[t][i], post_b, acc_f[t][i])) : fmaf(acc[t][i], post, acc_b[t][i] * post_b);
+            for (int i = 0; i < 16; ++i) v[i] = fmaf(acc[t][i], post, acc_b[t][i] * post_b);
             if (col < out) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped
