@@ -286,6 +286,25 @@ static bool vec4_ok(const AggArgs& a) {
 
 size_t aggregate_ws_bytes(long num_hub_seg, int F) { return (size_t)num_hub_seg * (size_t)((F + 3) & ~3) * sizeof(float); }
 
+// only the hub part of aggregate_sum (segment partial sums + ordered fold ONTO a.out, which already holds the rows' self
+// terms): for the forward kernel that produces the other rows itself (kan_sparse_fwd_agg)
+int aggregate_hub_rows(const AggArgs& a, const int* hub_seg, long num_hub_seg, float* ws, size_t ws_bytes, hipStream_t st) {
+    if (num_hub_seg <= 0) return KAGNN_OK;
+    const int ldp = (a.F + 3) & ~3;
+    if ((size_t)num_hub_seg * ldp * sizeof(float) > ws_bytes) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "aggregate_hub_rows");
+#define HUBS(LPR)                                                                                   \
+    {                                                                                               \
+        agg_hub_v4_kernel<LPR><<<(unsigned)num_hub_seg, 256, 0, st>>>(a, hub_seg, ws, ldp);         \
+        KAGNN_LAUNCH_CHECK();                                                                       \
+        agg_hub_merge_kernel<LPR><<<(unsigned)num_hub_seg, 256, 0, st>>>(a, hub_seg, num_hub_seg, ws, ldp); \
+        KAGNN_LAUNCH_CHECK();                                                                       \
+    }
+    if (a.F <= 4) HUBS(1) else if (a.F <= 8) HUBS(2) else if (a.F <= 16) HUBS(4) else if (a.F <= 32) HUBS(8)
+    else if (a.F <= 64) HUBS(16) else if (a.F <= 128) HUBS(32) else HUBS(64)
+#undef HUBS
+    return KAGNN_OK;
+}
+
 int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, float* ws, size_t ws_bytes, hipStream_t st) {
     if (a.N == 0) return KAGNN_OK;
     if (!vec4_ok(a)) {

@@ -13,6 +13,11 @@ int aggregate_sum_bf16(const void* x, long ldx, void* out, long ldo, int out_bf1
                        const float* bias, int skip_self, const int* hub_seg, long num_hub_seg, int hub_threshold,
                        float* ws, size_t ws_bytes, hipStream_t st);
 int rows_to_bf16(const float* x, long ldx, void* y, long ldy, long N, int F, hipStream_t st);
+bool kan_sparse_fwd_agg_ok(const float* x, long ldx, long N, int in, int out, int G, int K);
+size_t kan_sparse_fwd_agg_ws_bytes(long num_hub_seg, int in, int out);
+int kan_sparse_fwd_agg(const float* x, long ldx, long N, const int* rowptr, const int* col, const int* hub_seg, long num_hub_seg,
+                       int hub_threshold, float self_scale, const float* knots, int in, int out, int G, int K, const void* pack,
+                       float* h0, long ldh, float* y, long ldy, void* ws, size_t ws_bytes, hipStream_t st);
 int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, float* ws, size_t ws_bytes, hipStream_t st);
 int gcn_deg_inv_sqrt(const int* rowptr, const int* col, long N, float* dis, hipStream_t st);
 int gine_fwd(const float*, long, const float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
@@ -571,7 +576,9 @@ int kagnn_gin_kan_layer_workspace_bytes(int64_t N, int32_t L, const int32_t* wid
         wmax = widths[l] > wmax ? widths[l] : wmax;
     }
     const size_t hub_f = aggregate_bf16_ws_bytes(num_hub_seg, widths[0]), hub_t = aggregate_bf16_ws_bytes(num_hub_seg_t, widths[0]);
-    *fwd_bytes = al256z(hub_f) + al256z(fw) + 256;
+    // (+ the hub-row fix-up of the aggregation fused into the first KANLinear, narrow first layers: kan_sparse_fwd_agg)
+    const size_t fuse_b = widths[0] <= 32 ? kan_sparse_fwd_agg_ws_bytes(num_hub_seg, widths[0], widths[1]) : 0;
+    *fwd_bytes = al256z(hub_f) + al256z(fw) + al256z(fuse_b) + 256;
     // backward: hub partials | dW slabs | two ping-pong gradient matrices [N, max width] (fp32)
     *bwd_bytes = al256z(hub_t) + al256z(dw) + 2 * al256z((size_t)N * wmax * sizeof(float)) + 256;
     return KAGNN_OK;
@@ -592,8 +599,20 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
     if (N == 0) return KAGNN_OK;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     const size_t hub_b = al256z(aggregate_bf16_ws_bytes(num_hub_seg, widths[0]));
+    // The aggregation fused INTO the first KANLinear (one kernel, north_star's producer -> consumer form) for narrow first
+    // layers (<= 32 features: the per-rank slices of the feature-sharded layer), split precision, fp32 rows: KAGNN_FUSE_AGG=1.
+    // Off by default -- bit-identical to the two launches (tests/test_gpu_models.py) but slower: the forward kernel gives a row
+    // ONE lane, so a wave walks its 32 neighbour lists at the pace of the longest with two dependent round trips per step
+    // (N = 1M, E = 10M, layer forward: 0.83 vs 0.56 ms at 8 input features; profiles/r03_experiments.md).
+    const char* fuse_e = getenv("KAGNN_FUSE_AGG");
+    const bool fuse_env = fuse_e != nullptr && atoi(fuse_e) != 0;
+    const bool fuse = fuse_env && x_dtype == KAGNN_DTYPE_F32 && mode == KAGNN_PREC_SPLIT && !(L == 1 && col_mean) &&
+                      use_sparse_fwd(widths[0], widths[1], G, K, mode) &&
+                      kan_sparse_fwd_agg_ok(static_cast<const float*>(x), ldx, N, widths[0], widths[1], G, K);
     // 1. h0 = self_scale * x_i + sum_{j -> i} x_j
-    if (x_dtype == KAGNN_DTYPE_BF16)
+    if (fuse)
+        rc = KAGNN_OK;                       // (produced by the first forward kernel, step 3)
+    else if (x_dtype == KAGNN_DTYPE_BF16)
         rc = kagnn_aggregate_sum_bf16(x, ldx, acts[0], widths[0], KAGNN_DTYPE_F32, rowptr, col, nullptr, N, widths[0], self_scale,
                                       nullptr, nullptr, nullptr, 0, hub_seg, num_hub_seg, hub_threshold, ws, hub_b, stream);
     else
@@ -619,6 +638,14 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
     }
     // 3. the chain
     for (int l = 0; l < L; ++l) {
+        if (l == 0 && fuse) {
+            const size_t fw_b = need_f - 256 - hub_b - al256z(kan_sparse_fwd_agg_ws_bytes(num_hub_seg, widths[0], widths[1]));
+            rc = kan_sparse_fwd_agg(static_cast<const float*>(x), ldx, N, rowptr, col, hub_seg, num_hub_seg, hub_threshold, self_scale,
+                                    knots, in_[0], out_[0], G, K, pack_fwd[0], acts[0], in_[0], acts[1], out_[0],
+                                    ws + hub_b + fw_b, need_f - hub_b - fw_b, as_stream(stream));
+            if (rc) return rc;
+            continue;
+        }
         if (l == L - 1 && col_mean)          // the convolution's output: its column moments for the norm that follows
             rc = kagnn_kan_linear_fwd_moments(acts[l], in_[l], N, knots, in_[l], out_[l], G, K, mode, pack_fwd[l], acts[l + 1],
                                               out_[l], col_mean, col_m2, ws + hub_b, need_f - hub_b, stream);

@@ -186,11 +186,28 @@ __device__ __forceinline__ f32x16 smfmac(const u32x4& a, const u32x4& b0, const 
 // models.py:198-200) then needs no statistics pass over y (bn.hip: moments_finish, bn_from_moments_kernel).
 // NARROW: a layer of <= 32 (virtual) features, laid over both lane halves (sp_hf); a template flag because the lane-half width
 // as a runtime value cost the 64-feature forward 1.7 %
-template <int OT, bool SH, bool MOM, bool NARROW = false>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
+// AGG (>= 0, narrow layers only): the kernel's input is NOT read from memory but produced in place -- the GIN neighbour
+// aggregation h0[i] = self_scale * x[i] + sum_{j -> i} x[j] of the convolution (reference models.py:48-56, GINConv around the KAN),
+// gathered by the lane that then expands it; h0 is also stored (the backward's saved input).  This is the
+// producer -> consumer fusion BASELINE.json's north_star names, in the form where it pays: layers of <= 32 input features
+// (the per-rank slices of the feature-sharded layer, first layers on narrow inputs) run the forward at 140..220 registers and
+// their aggregation is request-rate bound, not occupancy bound.  The summation ORDER is that of the stand-alone aggregation
+// kernels, so h0 and y are bit-identical to the two-launch form: AGG == 0 -> agg_rows_v4_kernel (16 < in <= 32: self term
+// first, edges in CSR order); AGG == 4 / 8 -> agg_rows_ep_kernel (in <= 16 / in <= 8: AGG edge slots walked in parallel,
+// combined pairwise, self term last).  Rows above the hub threshold get their self term only, exactly like the row kernels;
+// the hub kernels complete h0 and the caller recomputes y for those few rows (kan_sparse_fwd_agg).
+struct SpAgg {
+    const int* rowptr; const int* col; float self_scale; int hub_threshold;
+    float* h0; long ldh;
+};
+__device__ __forceinline__ float4 spagg_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int OT, bool SH, bool MOM, bool NARROW = false, int AGG = -1>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
 __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g, int nknots,
     const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy, int out,
-    int chunks_per_split, long part_stride, float* __restrict__ mom_partial) {
+    int chunks_per_split, long part_stride, float* __restrict__ mom_partial, SpAgg ag) {
+    static_assert(AGG < 0 || (NARROW && !SH && !MOM), "the fused aggregation serves plain narrow layers");
     constexpr int NT = 512, CF = kSpCF, BPC = CF / 16, NG = CF / 16, ROWS = (NT / 64) * 32;
     const int HF = NARROW ? sp_hf(in << (SH ? 1 : 0)) : CF / 2;    // features per lane half: CF / 2, or 16 / 8 in narrow layers
     constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 2 * 1024;
@@ -257,6 +274,77 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
             for (int j = 0; j < 8; ++j) v[j] = gld(xb, rb + min(f0 + j, in - 1) * 4);   // features >= in meet zero weights
         }
     };
+    // AGG: group g of this lane's row = 8 aggregated features (two float4 column groups), in the stand-alone kernels' order
+    auto gather8 = [&](long tile0, int g, float (&v)[8]) {
+        constexpr int EP = AGG > 0 ? AGG : 1;
+        const long row = tile0 + wave * 32 + r;
+        const int f0 = kg * HF + 8 * g;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        const bool l0 = f0 < in, l1 = f0 + 4 < in;
+        if (row < N && l0) {
+            const float* xs = x + row * ldx + f0;
+            const float4 s0 = spagg_ld4(xs), s1 = l1 ? spagg_ld4(xs + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int es = ag.rowptr[row], et = ag.rowptr[row + 1];
+            const bool hub = (et - es) > ag.hub_threshold;
+            const float sw = ag.self_scale;
+            if constexpr (AGG == 0) {                    // agg_rows_v4_kernel: acc = x * sw, then acc = fma(1, x_j, acc) edge by edge
+                a0 = make_float4(s0.x * sw, s0.y * sw, s0.z * sw, s0.w * sw);
+                a1 = make_float4(s1.x * sw, s1.y * sw, s1.z * sw, s1.w * sw);
+                if (!hub) {
+                    int e = es;
+                    for (; e + 4 <= et; e += 4) {
+                        const float* p[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) p[k] = x + (long)ag.col[e + k] * ldx + f0;
+                        float4 u0[4], u1[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { u0[k] = spagg_ld4(p[k]); u1[k] = l1 ? spagg_ld4(p[k] + 4) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            a0.x += u0[k].x; a0.y += u0[k].y; a0.z += u0[k].z; a0.w += u0[k].w;
+                            a1.x += u1[k].x; a1.y += u1[k].y; a1.z += u1[k].z; a1.w += u1[k].w;
+                        }
+                    }
+                    for (; e < et; ++e) {
+                        const float* pj = x + (long)ag.col[e] * ldx + f0;
+                        const float4 u0 = spagg_ld4(pj), u1 = l1 ? spagg_ld4(pj + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        a0.x += u0.x; a0.y += u0.y; a0.z += u0.z; a0.w += u0.w;
+                        a1.x += u1.x; a1.y += u1.y; a1.z += u1.z; a1.w += u1.w;
+                    }
+                }
+            } else {                                     // agg_rows_ep_kernel: EP edge slots, pairwise combination, self term last
+                float4 p0[EP], p1[EP];
+#pragma unroll
+                for (int k = 0; k < EP; ++k) { p0[k] = make_float4(0.f, 0.f, 0.f, 0.f); p1[k] = p0[k]; }
+                if (!hub) {
+                    for (int base = es; base < et; base += EP) {
+#pragma unroll
+                        for (int k = 0; k < EP; ++k) {
+                            if (base + k < et) {
+                                const float* pj = x + (long)ag.col[base + k] * ldx + f0;
+                                const float4 u0 = spagg_ld4(pj), u1 = l1 ? spagg_ld4(pj + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                                p0[k].x += u0.x; p0[k].y += u0.y; p0[k].z += u0.z; p0[k].w += u0.w;
+                                p1[k].x += u1.x; p1[k].y += u1.y; p1[k].z += u1.z; p1[k].w += u1.w;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < EP; o <<= 1)         // the butterfly of the stand-alone kernel, seen from slot 0
+#pragma unroll
+                    for (int k = 0; k < EP; k += 2 * o) {
+                        p0[k].x += p0[k + o].x; p0[k].y += p0[k + o].y; p0[k].z += p0[k + o].z; p0[k].w += p0[k + o].w;
+                        p1[k].x += p1[k + o].x; p1[k].y += p1[k + o].y; p1[k].z += p1[k + o].z; p1[k].w += p1[k + o].w;
+                    }
+                a0 = make_float4(fmaf(sw, s0.x, p0[0].x), fmaf(sw, s0.y, p0[0].y), fmaf(sw, s0.z, p0[0].z), fmaf(sw, s0.w, p0[0].w));
+                a1 = make_float4(fmaf(sw, s1.x, p1[0].x), fmaf(sw, s1.y, p1[0].y), fmaf(sw, s1.z, p1[0].z), fmaf(sw, s1.w, p1[0].w));
+            }
+            float* hp = ag.h0 + row * ag.ldh + f0;
+            *reinterpret_cast<float4*>(hp) = a0;
+            if (l1) *reinterpret_cast<float4*>(hp + 4) = a1;
+        }
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    };
     // one scalar -> its two stored dwords (hi and lo parts) and its index byte
     auto place1 = [&](const u32x4& e, unsigned h0, unsigned h1, unsigned l0, unsigned l1, unsigned& hi0, unsigned& hi1,
                       unsigned& lo0, unsigned& lo1) {
@@ -275,7 +363,8 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         for (int t = 0; t < OT; ++t) s_momw[64 * t + lane] = 0.0f;      // (each wave touches only its own slice: no barrier)
     }
     float xn[8];
-    load8((long)blockIdx.x * ROWS, ch_begin, 0, xn);
+    if constexpr (AGG >= 0) gather8((long)blockIdx.x * ROWS, 0, xn);
+    else load8((long)blockIdx.x * ROWS, ch_begin, 0, xn);
     for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
         const long row0 = tile * ROWS + wave * 32;
         // acc: spline part (bases * 2^10); acc_b: SiLU branch through fp16 hi/lo at scale 2^4 (|silu| < 4094) -- and, for the
@@ -305,7 +394,10 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                 float xv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = xn[j];
-                if (g + 1 < ng_live) load8(tile * ROWS, ch, g + 1, xn);
+                if constexpr (AGG >= 0) {                                  // (narrow: one chunk)
+                    if (g + 1 < ng_live) gather8(tile * ROWS, g + 1, xn);
+                    else gather8((tile + gridDim.x) * ROWS, 0, xn);
+                } else if (g + 1 < ng_live) load8(tile * ROWS, ch, g + 1, xn);
                 else if (ch + 1 < ch_end) load8(tile * ROWS, ch + 1, 0, xn);
                 else load8((tile + gridDim.x) * ROWS, ch_begin, 0, xn);
 
@@ -614,7 +706,7 @@ static int launch_sparse(const float* x, long ldx, long N, int in, const float* 
         if (p.splits > 1) return fail(KAGNN_ERR_UNSUPPORTED, "%s: no column moments from a launch split over the chunks", "kan_sparse_fwd");
         if (!ws || ws_bytes < (size_t)gx * 3 * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small for the column moments", "kan_sparse_fwd");
-        kan_sparse_fwd_kernel<OT, SH, true, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, ws);
+        kan_sparse_fwd_kernel<OT, SH, true, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, ws, SpAgg{});
         KAGNN_LAUNCH_CHECK();
         return moments_finish(ws, gx, out, col_mean, col_m2, st);
     }
@@ -622,13 +714,95 @@ static int launch_sparse(const float* x, long ldx, long N, int in, const float* 
         if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_sparse_fwd");
         kan_sparse_fwd_kernel<OT, SH, false, NARROW><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
-                                                                                p.cps, N * (long)out, nullptr);
+                                                                                p.cps, N * (long)out, nullptr, SpAgg{});
         KAGNN_LAUNCH_CHECK();
         sparse_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
         KAGNN_LAUNCH_CHECK();
         return KAGNN_OK;
     }
-    kan_sparse_fwd_kernel<OT, SH, false, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, nullptr);
+    kan_sparse_fwd_kernel<OT, SH, false, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, nullptr, SpAgg{});
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+// ------------------------------------------------------------------ aggregation fused into the first KANLinear (narrow layers)
+bool kan_sparse_fwd_agg_ok(const float* x, long ldx, long N, int in, int out, int G, int K) {
+    return K == 3 && G + K <= 8 && in >= 8 && in <= 32 && in % 4 == 0 && out <= kSpOutBlk && ldx % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(x) & 15) == 0 && sp_split_plan(N, 1).splits == 1;
+}
+
+// rows of the FIRST segment of every hub row: h0 rows -> compact rows (one per segment slot), and y rows back
+__global__ void hub_rows_gather_kernel(const float* __restrict__ h0, long ldh, const int* __restrict__ seg, long nseg, int F,
+                                       float* __restrict__ tmp) {
+    const long sidx = blockIdx.x;
+    const int row = seg[3 * sidx];
+    const bool first = sidx == 0 || seg[3 * (sidx - 1)] != row;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) tmp[sidx * F + f] = first ? h0[(long)row * ldh + f] : 0.0f;
+}
+__global__ void hub_rows_scatter_kernel(const float* __restrict__ ytmp, const int* __restrict__ seg, long nseg, int F,
+                                        float* __restrict__ y, long ldy) {
+    const long sidx = blockIdx.x;
+    const int row = seg[3 * sidx];
+    if (sidx > 0 && seg[3 * (sidx - 1)] == row) return;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) y[(long)row * ldy + f] = ytmp[sidx * F + f];
+}
+
+int aggregate_hub_rows(const AggArgs& a, const int* hub_seg, long num_hub_seg, float* ws, size_t ws_bytes, hipStream_t st);   // aggregate.hip
+int kan_sparse_fwd(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K, const void* pack, float* y,
+                   long ldy, void* ws, size_t ws_bytes, float* col_mean, float* col_m2, hipStream_t st);
+
+size_t kan_sparse_fwd_agg_ws_bytes(long num_hub_seg, int in, int out) {
+    return (size_t)num_hub_seg * (size_t)(((in + 3) & ~3) * 2 + out) * sizeof(float);       // hub partials | compact h0 rows | their y rows
+}
+
+template <int OT, int AGG>
+static int launch_sparse_agg(const float* x, long ldx, long N, int in, const float* knots, int nknots, const unsigned char* pack,
+                             float* y, long ldy, int out, const SpAgg& ag, hipStream_t st) {
+    const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
+    static bool configured = false;
+    if (!configured) {
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, false, false, true, AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    kan_sparse_fwd_kernel<OT, false, false, true, AGG><<<sp_grid(N), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, 1, y, ldy, out, 1, 0L,
+                                                                                      nullptr, ag);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+// h0 = self_scale * x + (sum over in-neighbours), y = KANLinear(h0): ONE kernel for every row below the hub threshold; the hub
+// rows' h0 is completed by the aggregation's hub kernels and their y recomputed on a compact copy (rows of a KANLinear are
+// independent, so those rows are bit-identical to a whole-matrix forward too)
+int kan_sparse_fwd_agg(const float* x, long ldx, long N, const int* rowptr, const int* col, const int* hub_seg, long num_hub_seg,
+                       int hub_threshold, float self_scale, const float* knots, int in, int out, int G, int K, const void* pack,
+                       float* h0, long ldh, float* y, long ldy, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!kan_sparse_fwd_agg_ok(x, ldx, N, in, out, G, K)) return fail(KAGNN_ERR_UNSUPPORTED, "%s: shape not covered", "kan_sparse_fwd_agg");
+    if (num_hub_seg > 0 && ws_bytes < kan_sparse_fwd_agg_ws_bytes(num_hub_seg, in, out))
+        return fail(KAGNN_ERR_ARG, "%s: workspace too small", "kan_sparse_fwd_agg");
+    const int nk = G + 2 * K + 1, OT = cdiv(out, 32);
+    const unsigned char* p = static_cast<const unsigned char*>(pack);
+    SpAgg ag{rowptr, col, self_scale, (num_hub_seg == 0 || hub_seg == nullptr) ? 0x7fffffff : hub_threshold, h0, ldh};
+    int rc;
+#define LA(AA) (OT == 1 ? launch_sparse_agg<1, AA>(x, ldx, N, in, knots, nk, p, y, ldy, out, ag, st) \
+                        : launch_sparse_agg<2, AA>(x, ldx, N, in, knots, nk, p, y, ldy, out, ag, st))
+    rc = in <= 8 ? LA(8) : in <= 16 ? LA(4) : LA(0);
+#undef LA
+    if (rc || num_hub_seg == 0 || hub_seg == nullptr) return rc;
+    // hub rows: partial sums per segment + ordered fold onto h0 (the stand-alone kernels), then y for those rows
+    AggArgs a{};
+    a.x = x; a.ldx = ldx; a.out = h0; a.ldo = ldh; a.rowptr = rowptr; a.col = col; a.N = N; a.F = in;
+    a.self_scale = self_scale; a.hub_threshold = hub_threshold;
+    float* wsf = static_cast<float*>(ws);
+    const size_t part = (size_t)num_hub_seg * ((in + 3) & ~3);
+    rc = aggregate_hub_rows(a, hub_seg, num_hub_seg, wsf, part * sizeof(float), st);
+    if (rc) return rc;
+    float* tmp = wsf + part;
+    float* ytmp = tmp + (size_t)num_hub_seg * in;
+    hub_rows_gather_kernel<<<(unsigned)num_hub_seg, 64, 0, st>>>(h0, ldh, hub_seg, num_hub_seg, in, tmp);
+    KAGNN_LAUNCH_CHECK();
+    rc = kan_sparse_fwd(tmp, in, num_hub_seg, knots, in, out, G, K, pack, ytmp, out, nullptr, 0, nullptr, nullptr, st);
+    if (rc) return rc;
+    hub_rows_scatter_kernel<<<(unsigned)num_hub_seg, 64, 0, st>>>(ytmp, hub_seg, num_hub_seg, out, y, ldy);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }

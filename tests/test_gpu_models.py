@@ -376,6 +376,32 @@ def test_fused_gin_kan_node_equals_the_composed_ops_bitwise(monkeypatch):
         for other in res[1:]:
             for a, b in zip(res[0], other):
                 assert torch.equal(a, b)
+    # narrow first layers: the library call runs the aggregation INSIDE the first KANLinear's forward kernel
+    # (kan_sparse_fwd_kernel<..., AGG>: north_star's producer -> consumer fusion; hub rows fixed up on a compact copy) --
+    # still the same bits as aggregate_sum -> KAN.forward, for the three summation orders (in <= 8, <= 16, <= 32), with hubs
+    # (this graph's top in-degree is ~500, threshold 96), an odd row count and a first layer not a multiple of 8 wide
+    monkeypatch.setenv("KAGNN_FUSE_AGG", "1")           # (read per call; off by default: measured slower, api.hip)
+    n3 = 20011
+    ei3 = orc.powerlaw_graph(n3, 150000, seed=10)
+    g3 = ops.GraphIndex(ei3.to(DEV), n3)
+    assert g3.num_hub_seg > 0
+    for fin, hid, fout in ((8, 64, 64), (16, 32, 64), (32, 64, 40), (24, 64, 64), (12, 64, 64)):
+        torch.manual_seed(11)
+        conv = kagnn_amd.GIKANLayer(fin, fout, grid_size=5, spline_order=3, hidden_dim=hid, nb_layers=2).to(DEV)
+        x3 = (torch.randn(n3, fin, generator=torch.Generator().manual_seed(12)) * 0.4).to(DEV)
+        gy3 = torch.randn(n3, fout, generator=torch.Generator().manual_seed(13)).to(DEV)
+        res = []
+        for fused, abi in ((True, True), (False, False)):
+            monkeypatch.setattr(M, "_FUSED_LAYER", fused)
+            monkeypatch.setattr(ops, "_LAYER_ABI", abi)
+            conv.zero_grad()
+            xr = x3.clone().requires_grad_(True)
+            y = conv(xr, g3)
+            y.backward(gy3)
+            res.append([y.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in conv.parameters()])
+        for a, b in zip(*res):
+            assert torch.equal(a, b), (fin, hid, fout)
+    monkeypatch.delenv("KAGNN_FUSE_AGG")
     # a chain the one-launch pack does not cover (3 layers, ragged widths, grid 8 => 11 coefficients) and an odd row count
     n2 = 7001
     ei2 = orc.powerlaw_graph(n2, 40000, seed=9)
