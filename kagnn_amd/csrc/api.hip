@@ -601,9 +601,9 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
     const size_t hub_b = al256z(aggregate_bf16_ws_bytes(num_hub_seg, widths[0]));
     // The aggregation fused INTO the first KANLinear (one kernel, north_star's producer -> consumer form) for narrow first
     // layers (<= 32 features: the per-rank slices of the feature-sharded layer), split precision, fp32 rows: KAGNN_FUSE_AGG=1.
-    // Off by default -- bit-identical to the two launches (tests/test_gpu_models.py) but slower: the forward kernel gives a row
-    // ONE lane, so a wave walks its 32 neighbour lists at the pace of the longest with two dependent round trips per step
-    // (N = 1M, E = 10M, layer forward: 0.83 vs 0.56 ms at 8 input features; profiles/r03_experiments.md).
+    // Off by default -- bit-identical to the two launches (tests/test_gpu_models.py) but not faster: a forward tile pays the
+    // gather's two dependent round trips with 2-3 waves per SIMD to hide them, the stand-alone kernel has 8 (N = 1M, E = 10M,
+    // layer forward: 0.60 vs 0.56 ms at 8 input features, 1.06 vs 0.62 at 32; profiles/r03_experiments.md).
     const char* fuse_e = getenv("KAGNN_FUSE_AGG");
     const bool fuse_env = fuse_e != nullptr && atoi(fuse_e) != 0;
     const bool fuse = fuse_env && x_dtype == KAGNN_DTYPE_F32 && mode == KAGNN_PREC_SPLIT && !(L == 1 && col_mean) &&

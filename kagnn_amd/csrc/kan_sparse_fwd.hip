@@ -190,8 +190,9 @@ __device__ __forceinline__ f32x16 smfmac(const u32x4& a, const u32x4& b0, const 
 // aggregation h0[i] = self_scale * x[i] + sum_{j -> i} x[j] of the convolution (reference models.py:48-56, GINConv around the KAN),
 // gathered by the lane that then expands it; h0 is also stored (the backward's saved input).  This is the
 // producer -> consumer fusion BASELINE.json's north_star names, in the form where it pays: layers of <= 32 input features
-// (the per-rank slices of the feature-sharded layer, first layers on narrow inputs) run the forward at 140..220 registers and
-// their aggregation is request-rate bound, not occupancy bound.  The summation ORDER is that of the stand-alone aggregation
+// (the per-rank slices of the feature-sharded layer, first layers on narrow inputs) run the forward at 160..250 registers.
+// Measured (profiles/r03_experiments.md): not faster than two launches, hence opt-in (KAGNN_FUSE_AGG=1, api.hip).
+// The summation ORDER is that of the stand-alone aggregation
 // kernels, so h0 and y are bit-identical to the two-launch form: AGG == 0 -> agg_rows_v4_kernel (16 < in <= 32: self term
 // first, edges in CSR order); AGG == 4 / 8 -> agg_rows_ep_kernel (in <= 16 / in <= 8: AGG edge slots walked in parallel,
 // combined pairwise, self term last).  Rows above the hub threshold get their self term only, exactly like the row kernels;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const int ch_begin = blockIdx.y * chunks_per_split, ch_end = min(nchunks, ch_begin + chunks_per_split);
     const bool resident = (ch_end - ch_begin) == 1;
     dma_half(ch_begin, 0);
-    if (resident) { dma_half(ch_begin, 1); lds_dma_wait(); }
+    if (resident) { if (AGG < 0) dma_half(ch_begin, 1); lds_dma_wait(); }      // (AGG: the second half buffer is the gather's staging area)
     y += (long)blockIdx.y * part_stride;
     __syncthreads();
     const Frag3Geom f3geo = frag3_geom(s_knots, nknots);
@@ -274,76 +275,136 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
             for (int j = 0; j < 8; ++j) v[j] = gld(xb, rb + min(f0 + j, in - 1) * 4);   // features >= in meet zero weights
         }
     };
-    // AGG: group g of this lane's row = 8 aggregated features (two float4 column groups), in the stand-alone kernels' order
-    auto gather8 = [&](long tile0, int g, float (&v)[8]) {
-        constexpr int EP = AGG > 0 ? AGG : 1;
-        const long row = tile0 + wave * 32 + r;
-        const int f0 = kg * HF + 8 * g;
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-        const bool l0 = f0 < in, l1 = f0 + 4 < in;
-        if (row < N && l0) {
-            const float* xs = x + row * ldx + f0;
-            const float4 s0 = spagg_ld4(xs), s1 = l1 ? spagg_ld4(xs + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const int es = ag.rowptr[row], et = ag.rowptr[row + 1];
-            const bool hub = (et - es) > ag.hub_threshold;
-            const float sw = ag.self_scale;
-            if constexpr (AGG == 0) {                    // agg_rows_v4_kernel: acc = x * sw, then acc = fma(1, x_j, acc) edge by edge
-                a0 = make_float4(s0.x * sw, s0.y * sw, s0.z * sw, s0.w * sw);
-                a1 = make_float4(s1.x * sw, s1.y * sw, s1.z * sw, s1.w * sw);
-                if (!hub) {
-                    int e = es;
-                    for (; e + 4 <= et; e += 4) {
-                        const float* p[4];
+    // AGG: the aggregated rows of one 32-row wave tile, all groups of this lane (xa[g][8]).  Cooperative and edge-parallel:
+    // the tile's rows own ONE contiguous CSR edge range; the wave's 64 lanes load it item by item (item = one float4 of one
+    // neighbour row: coalesced index loads, every gather independent of the others) into this wave's staging area in LDS --
+    // the second half buffer of the weight chunk, which narrow layers never read -- and then each (row, feature group) lane
+    // sums ITS edges from LDS in the stand-alone kernels' order.  (A lane walking its own neighbour list in global memory --
+    // the first form of this kernel -- ran at the pace of the longest of 32 lists, two dependent round trips per step:
+    // 0.83 vs 0.56 ms for the layer forward, profiles/r03_experiments.md.)  Edge ranges of hub rows are skipped.
+    const int ng_live_c = HF / 8;
+    constexpr int AGRP = AGG == 0 ? 2 : 1;                 // groups per lane half: in <= 16 -> 1, in <= 32 -> 2
+    constexpr int AEP = AGG > 0 ? AGG : 1;
+    constexpr int STAGE_BYTES = (HALF_BYTES / 8) & ~15;    // per wave
+    auto gather_tile = [&](long tile0, float (&xa)[AGRP][8]) {
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+        float4* stage = reinterpret_cast<float4*>(s_w + HALF_BYTES + wave_s * STAGE_BYTES);
+        const int Q = in >> 2;                             // float4 per row
+        const int cap = STAGE_BYTES / (16 * Q);            // edges per staging round
+        const float rq = 1.0f / (float)Q;
+        const long row0 = tile0 + wave_s * 32;
+        const long row = row0 + r;
+        const bool live_row = row < N;
+        const int es = live_row ? ag.rowptr[row] : 0, et = live_row ? ag.rowptr[row + 1] : 0;
+        const bool hub = (et - es) > ag.hub_threshold;
+        const float sw = ag.self_scale;
+        float4 acc[AGRP][2][AEP];
+        float4 self[AGRP][2];
+        bool l0[AGRP], l1[AGRP];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) p[k] = x + (long)ag.col[e + k] * ldx + f0;
-                        float4 u0[4], u1[4];
+        for (int g = 0; g < AGRP; ++g) {
+            const int f0 = kg * HF + 8 * g;
+            l0[g] = live_row && f0 < in && g < ng_live_c; l1[g] = l0[g] && f0 + 4 < in;
+            self[g][0] = l0[g] ? spagg_ld4(x + row * ldx + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            self[g][1] = l1[g] ? spagg_ld4(x + row * ldx + f0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { u0[k] = spagg_ld4(p[k]); u1[k] = l1 ? spagg_ld4(p[k] + 4) : make_float4(0.f, 0.f, 0.f, 0.f); }
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            a0.x += u0[k].x; a0.y += u0[k].y; a0.z += u0[k].z; a0.w += u0[k].w;
-                            a1.x += u1[k].x; a1.y += u1[k].y; a1.z += u1[k].z; a1.w += u1[k].w;
-                        }
-                    }
-                    for (; e < et; ++e) {
-                        const float* pj = x + (long)ag.col[e] * ldx + f0;
-                        const float4 u0 = spagg_ld4(pj), u1 = l1 ? spagg_ld4(pj + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        a0.x += u0.x; a0.y += u0.y; a0.z += u0.z; a0.w += u0.w;
-                        a1.x += u1.x; a1.y += u1.y; a1.z += u1.z; a1.w += u1.w;
-                    }
-                }
-            } else {                                     // agg_rows_ep_kernel: EP edge slots, pairwise combination, self term last
-                float4 p0[EP], p1[EP];
-#pragma unroll
-                for (int k = 0; k < EP; ++k) { p0[k] = make_float4(0.f, 0.f, 0.f, 0.f); p1[k] = p0[k]; }
-                if (!hub) {
-                    for (int base = es; base < et; base += EP) {
-#pragma unroll
-                        for (int k = 0; k < EP; ++k) {
-                            if (base + k < et) {
-                                const float* pj = x + (long)ag.col[base + k] * ldx + f0;
-                                const float4 u0 = spagg_ld4(pj), u1 = l1 ? spagg_ld4(pj + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                                p0[k].x += u0.x; p0[k].y += u0.y; p0[k].z += u0.z; p0[k].w += u0.w;
-                                p1[k].x += u1.x; p1[k].y += u1.y; p1[k].z += u1.z; p1[k].w += u1.w;
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int o = 1; o < EP; o <<= 1)         // the butterfly of the stand-alone kernel, seen from slot 0
-#pragma unroll
-                    for (int k = 0; k < EP; k += 2 * o) {
-                        p0[k].x += p0[k + o].x; p0[k].y += p0[k + o].y; p0[k].z += p0[k + o].z; p0[k].w += p0[k + o].w;
-                        p1[k].x += p1[k + o].x; p1[k].y += p1[k + o].y; p1[k].z += p1[k + o].z; p1[k].w += p1[k + o].w;
-                    }
-                a0 = make_float4(fmaf(sw, s0.x, p0[0].x), fmaf(sw, s0.y, p0[0].y), fmaf(sw, s0.z, p0[0].z), fmaf(sw, s0.w, p0[0].w));
-                a1 = make_float4(fmaf(sw, s1.x, p1[0].x), fmaf(sw, s1.y, p1[0].y), fmaf(sw, s1.z, p1[0].z), fmaf(sw, s1.w, p1[0].w));
-            }
-            float* hp = ag.h0 + row * ag.ldh + f0;
-            *reinterpret_cast<float4*>(hp) = a0;
-            if (l1) *reinterpret_cast<float4*>(hp + 4) = a1;
+                for (int k = 0; k < AEP; ++k)
+                    acc[g][h][k] = (AGG == 0) ? make_float4(self[g][h].x * sw, self[g][h].y * sw, self[g][h].z * sw, self[g][h].w * sw)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        // the tile's edge range (wave-uniform) and its hub rows
+        const int E0 = __builtin_amdgcn_readfirstlane(row0 < N ? ag.rowptr[row0] : 0);
+        const int E1 = __builtin_amdgcn_readfirstlane(row0 < N ? ag.rowptr[min(row0 + 32, N)] : 0);
+        const unsigned long long hubs = __builtin_amdgcn_ballot_w64(hub && kg == 0);
+        int cb = E0;
+        while (cb < E1) {
+            int ce = min(cb + cap, E1);
+            for (unsigned long long m = hubs; m; m &= m - 1) {        // (scalar loop; usually no hub in the tile)
+                const int bpos = __builtin_ctzll(m);
+                const int hs = __builtin_amdgcn_readlane(es, bpos), he = __builtin_amdgcn_readlane(et, bpos);
+                if (cb >= hs && cb < he) { cb = he; ce = min(cb + cap, E1); }
+                else if (hs > cb && hs < ce) ce = hs;
+            }
+            if (cb >= E1) break;
+            const int nitems = (ce - cb) * Q;
+            for (int it0 = 0; it0 < nitems; it0 += 256) {             // 4 items per lane in flight
+                int idx[4], quad[4], jj[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    idx[u] = it0 + 64 * u + lane;
+                    ok[u] = idx[u] < nitems;
+                    const int edge = (int)(((float)idx[u] + 0.5f) * rq);     // idx / Q (exact: idx < 2^10)
+                    quad[u] = idx[u] - edge * Q;
+                    jj[u] = ok[u] ? ag.col[cb + edge] : 0;
+                }
+                float4 vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    vv[u] = ok[u] ? spagg_ld4(x + (long)jj[u] * ldx + 4 * quad[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u]) stage[idx[u]] = vv[u];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // this lane's edges inside [cb, ce)
+            const int lo = max(es, cb), hi = hub ? lo : min(et, ce);
+            if constexpr (AGG == 0) {
+                for (int e = lo; e < hi; ++e) {
+                    const float4* p = stage + (e - cb) * Q + ((kg * HF) >> 2);
+#pragma unroll
+                    for (int g = 0; g < AGRP; ++g) {
+                        if (l0[g]) { const float4 v = p[2 * g]; acc[g][0][0].x += v.x; acc[g][0][0].y += v.y; acc[g][0][0].z += v.z; acc[g][0][0].w += v.w; }
+                        if (l1[g]) { const float4 v = p[2 * g + 1]; acc[g][1][0].x += v.x; acc[g][1][0].y += v.y; acc[g][1][0].z += v.z; acc[g][1][0].w += v.w; }
+                    }
+                }
+            } else {
+                // edge number k of the row goes to slot k % AEP: walk k in aligned groups of AEP so that the slot index is static
+                for (int kk = ((lo - es) / AEP) * AEP; es + kk < hi; kk += AEP) {
+#pragma unroll
+                    for (int sl = 0; sl < AEP; ++sl) {
+                        const int e = es + kk + sl;
+                        if (e >= lo && e < hi) {
+                            const float4* p = stage + (e - cb) * Q + ((kg * HF) >> 2);
+                            if (l0[0]) { const float4 v = p[0]; acc[0][0][sl].x += v.x; acc[0][0][sl].y += v.y; acc[0][0][sl].z += v.z; acc[0][0][sl].w += v.w; }
+                            if (l1[0]) { const float4 v = p[1]; acc[0][1][sl].x += v.x; acc[0][1][sl].y += v.y; acc[0][1][sl].z += v.z; acc[0][1][sl].w += v.w; }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cb = ce;
+        }
+#pragma unroll
+        for (int g = 0; g < AGRP; ++g) {
+            float4 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if constexpr (AGG == 0) o[h] = acc[g][h][0];
+                else {
+#pragma unroll
+                    for (int st = 1; st < AEP; st <<= 1)     // the butterfly of the stand-alone kernel, seen from slot 0
+#pragma unroll
+                        for (int k = 0; k < AEP; k += 2 * st) {
+                            acc[g][h][k].x += acc[g][h][k + st].x; acc[g][h][k].y += acc[g][h][k + st].y;
+                            acc[g][h][k].z += acc[g][h][k + st].z; acc[g][h][k].w += acc[g][h][k + st].w;
+                        }
+                    o[h] = make_float4(fmaf(sw, self[g][h].x, acc[g][h][0].x), fmaf(sw, self[g][h].y, acc[g][h][0].y),
+                                       fmaf(sw, self[g][h].z, acc[g][h][0].z), fmaf(sw, self[g][h].w, acc[g][h][0].w));
+                }
+            }
+            const int f0 = kg * HF + 8 * g;
+            if (l0[g]) *reinterpret_cast<float4*>(ag.h0 + row * ag.ldh + f0) = o[0];
+            if (l1[g]) *reinterpret_cast<float4*>(ag.h0 + row * ag.ldh + f0 + 4) = o[1];
+            if (!l0[g]) o[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!l1[g]) o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xa[g][0] = o[0].x; xa[g][1] = o[0].y; xa[g][2] = o[0].z; xa[g][3] = o[0].w;
+            xa[g][4] = o[1].x; xa[g][5] = o[1].y; xa[g][6] = o[1].z; xa[g][7] = o[1].w;
+        }
     };
     // one scalar -> its two stored dwords (hi and lo parts) and its index byte
     auto place1 = [&](const u32x4& e, unsigned h0, unsigned h1, unsigned l0, unsigned l1, unsigned& hi0, unsigned& hi1,
@@ -353,6 +414,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     };
 
     const int ng_live = HF / 8;                          // groups a lane half really has (4 unless the layer is narrow)
+    (void)ng_live;
     // this wave's rows so far: count (wave-uniform), column mean and column M2.  The per-column pairs live in LDS behind the
     // weight chunk ([wave][t][mean | M2][32 columns], 4 KiB at OT = 2), not in registers: four more live VGPRs through the
     // MFMA loop were what tipped the 256-register instantiation into scratch
@@ -363,8 +425,12 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         for (int t = 0; t < OT; ++t) s_momw[64 * t + lane] = 0.0f;      // (each wave touches only its own slice: no barrier)
     }
     float xn[8];
-    if constexpr (AGG >= 0) gather8((long)blockIdx.x * ROWS, 0, xn);
-    else load8((long)blockIdx.x * ROWS, ch_begin, 0, xn);
+    float xa[AGG >= 0 ? AGRP : 1][8];
+    if constexpr (AGG >= 0) {
+        gather_tile((long)blockIdx.x * ROWS, xa);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xn[j] = xa[0][j];
+    } else load8((long)blockIdx.x * ROWS, ch_begin, 0, xn);
     for (long tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
         const long row0 = tile * ROWS + wave * 32;
         // acc: spline part (bases * 2^10); acc_b: SiLU branch through fp16 hi/lo at scale 2^4 (|silu| < 4094) -- and, for the
@@ -394,9 +460,15 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                 float xv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = xn[j];
-                if constexpr (AGG >= 0) {                                  // (narrow: one chunk)
-                    if (g + 1 < ng_live) gather8(tile * ROWS, g + 1, xn);
-                    else gather8((tile + gridDim.x) * ROWS, 0, xn);
+                if constexpr (AGG >= 0) {                                  // (narrow: one chunk, one or two groups)
+                    if (g + 1 < ng_live) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xn[j] = xa[AGRP - 1][j];
+                    } else {
+                        gather_tile((tile + gridDim.x) * ROWS, xa);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xn[j] = xa[0][j];
+                    }
                 } else if (g + 1 < ng_live) load8(tile * ROWS, ch, g + 1, xn);
                 else if (ch + 1 < ch_end) load8(tile * ROWS, ch + 1, 0, xn);
                 else load8((tile + gridDim.x) * ROWS, ch_begin, 0, xn);
