@@ -475,6 +475,15 @@ def main():
     if world > 1 and os.environ.get("KAGNN_BENCH_ALT", "1") != "0":
         alt = time_alt()
 
+    # N > 1: what each rank's device spent INSIDE the library (kernels, summed over the entry points of the profile steps) vs the
+    # step time -- the rest is exposed waiting on the collectives (+ launch gaps): explains the driver's scaling curve
+    per_rank = None
+    if world > 1:
+        mine = {"rank": rank, "library_ms_per_step": sum(v["total_ms"] for v in warm.values()) / PROFILE_STEPS}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = [dict(g, not_in_library_ms_per_step=max(0.0, ms - g["library_ms_per_step"])) for g in gathered]
+
     fp32_ms = None
     if not args.no_fp32 and not fp32_mode and world == 1:
         for l in conv.nn.layers:
@@ -568,6 +577,10 @@ def main():
         }
         if alt is not None:
             out["alt_parallelism"] = alt
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["per_rank_note"] = ("library_ms_per_step: HIP-event time of this rank's kernels (3 profile steps); not_in_library: the rest of "
+                                    "the step = exposed waiting on RCCL collectives + launch gaps")
         if world == 1:
             copy_gbs = copy_bandwidth(dev)
             out["hbm_copy_GBs"] = copy_gbs
