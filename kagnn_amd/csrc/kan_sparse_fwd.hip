@@ -534,9 +534,11 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     } else {
                         float smx = 0.0f;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            sv[i] = (siluf(xv[i]) + (xv[i] - xv[i])) * 16.0f;      // +-Inf -> NaN like the reference
-                            smx = fmaxf(smx, fabsf(sv[i]));
+                        for (int i = 0; i < 8; i += 2) {     // packed fp32, two scalars per instruction
+                            const f32x2 xp = {xv[i], xv[i + 1]};
+                            const f32x2 pr = silu16_pair(xp) + (xp - xp) * splat2(16.0f);      // +-Inf -> NaN like the reference
+                            sv[i] = pr.x; sv[i + 1] = pr.y;
+                            smx = fmaxf(fmaxf(smx, fabsf(pr.x)), fabsf(pr.y));
                         }
                         big = __any(!(smx < 60000.0f) || sv[0] != sv[0] || sv[1] != sv[1] || sv[2] != sv[2] || sv[3] != sv[3] ||
                                     sv[4] != sv[4] || sv[5] != sv[5] || sv[6] != sv[6] || sv[7] != sv[7]);   // wave-uniform

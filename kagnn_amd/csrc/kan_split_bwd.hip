@@ -915,7 +915,11 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
             float sv[8];
             float smx = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { sv[j] = siluf(raw.x[j]) * 16.0f; smx = fmaxf(smx, fabsf(sv[j])); }
+            for (int j = 0; j < 8; j += 2) {                 // packed fp32, two rows per instruction (bit-identical to siluf(x) * 16)
+                const f32x2 pr = silu16_pair(f32x2{raw.x[j], raw.x[j + 1]});
+                sv[j] = pr.x; sv[j + 1] = pr.y;
+                smx = fmaxf(fmaxf(smx, fabsf(pr.x)), fabsf(pr.y));
+            }
             const bool base32 = __any(!(smx < 60000.0f));   // wave-uniform; also catches NaN / Inf
             split_f16x2(sv, sah, sal);
             if (chunk_exp(raw) > T) break;                   // wave-uniform, rare: rescale outside, then redo this chunk
@@ -1111,7 +1115,11 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
             float sv[8];
             float smx = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { sv[j] = siluf(raw.x[j]) * 16.0f; smx = fmaxf(smx, fabsf(sv[j])); }
+            for (int j = 0; j < 8; j += 2) {                 // packed fp32, two rows per instruction (bit-identical to siluf(x) * 16)
+                const f32x2 pr = silu16_pair(f32x2{raw.x[j], raw.x[j + 1]});
+                sv[j] = pr.x; sv[j + 1] = pr.y;
+                smx = fmaxf(fmaxf(smx, fabsf(pr.x)), fabsf(pr.y));
+            }
             const bool base32 = __any(!(smx < 60000.0f));
             split_f16x2(sv, sah, sal);
             if (chunk_exp(raw) > T) break;                   // wave-uniform, rare: rescale outside, then redo this chunk

@@ -443,6 +443,16 @@ __device__ __forceinline__ void frag3_payload(float u, unsigned& h0, unsigned& h
     l0 = pk_f16_rtz(sub_f16lo(N[0], h0), sub_f16hi(N[1], h0));
     l1 = pk_f16_rtz(sub_f16lo(N[2], h1), sub_f16hi(N[3], h1));
 }
+// 16 * silu(x) for two scalars on packed fp32: x * rcp((1 + exp(-x)) / 16) -- bit-identical to (x * rcp(1 + exp(-x))) * 16
+// (scaling by a power of two commutes with every rounding here), 3.5 issue slots per scalar instead of 6
+__device__ __forceinline__ f32x2 silu16_pair(f32x2 x) {
+    const f32x2 a = x * splat2(-1.4426950408889634f);
+    const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f32x2 d = fma2(e, splat2(0.0625f), splat2(0.0625f));
+    const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return x * r;
+}
+
 // two scalars' payloads at once: the cubic pieces on packed fp32 (one v_pk_mul_f32 / v_pk_fma_f32 per TWO scalars: these
 // kernels are bound by instruction count, profiles/r03_experiments.md), conversions per scalar as above
 __device__ __forceinline__ void frag3_payload_pair(float u0, float u1, unsigned (&h)[2][2], unsigned (&l)[2][2]) {
