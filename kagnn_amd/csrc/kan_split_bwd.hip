@@ -350,9 +350,14 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     float dN[K + 1];
                     int m;
                     if constexpr (K == 3) {
-                        float u; bool inside;
-                        fast_span(xv, fgeo, m, u, inside);
-                        cubic_dbases(u, inside ? 0.5f * fgeo.inv_h : 0.0f, dN);
+                        // span from arithmetic only, support folded into the barrel table: floor(t) outside [0, last span] selects an
+                        // all-zero entry (negative -> 15 through the unsigned min; beyond the last span the window holds only slots
+                        // >= C, whose sums are exact zeros), so no compare / select per scalar; the derivative scale 1/(2h) is applied
+                        // once to the contracted sum instead of to the four pieces
+                        const float t = fmaf(xv, fgeo.inv_h, fgeo.c0);
+                        const float u = __builtin_amdgcn_fractf(t);
+                        m = (int)floorf(t);
+                        cubic_dbases(u, 1.0f, dN);           // (round 3: -9 instructions per scalar, dX -4.7 %)
                     } else {
                         float Nv[K + 1];
                         m = bspline_local<K, true>(xv, s_knots, geom, Nv, dN);
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     if constexpr (K == 3) {
                         const int mm = m - 8 * win;
                         const u32x4 sel = *reinterpret_cast<const u32x4*>(s_btbl + 4 * min((unsigned)mm, 15u));
-                        bar = barrel_dot3(d, mm, sel, dN);
+                        bar = barrel_dot3(d, mm, sel, dN) * (0.5f * fgeo.inv_h);
                     } else {
                         bar = barrel_dot<K>(d, m - 8 * win, dN);
                     }
@@ -590,16 +595,18 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const float xv = xq[rt][reg];
-                    int m; float u; bool inside;
-                    fast_span(xv, fgeo, m, u, inside);
-                    const float wq = inside ? wd : 0.0f;
+                    // (span from arithmetic only, support folded into the barrel table, 1/(2h) applied to the contracted sum:
+                    // see kan_split_dx_kernel)
+                    const float tt = fmaf(xv, fgeo.inv_h, fgeo.c0);
+                    const float u = __builtin_amdgcn_fractf(tt);
+                    const int m = (int)floorf(tt);
                     float dN[4];
-                    cubic_dbases(u, wq, dN);
+                    cubic_dbases(u, 1.0f, dN);
                     float d[kCTmax - 1];
 #pragma unroll
                     for (int c = 0; c < kCTmax - 1; ++c) d[c] = D[c][rt][reg];
                     const u32x4 sel = *reinterpret_cast<const u32x4*>(s_btbl + 4 * min((unsigned)m, 15u));
-                    s0[rt][reg] = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot3(d, m, sel, dN));
+                    s0[rt][reg] = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot3(d, m, sel, dN) * wd);
                 }
             }
             // ================= window 1: its C - 8 live slots only
@@ -630,16 +637,17 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    int m; float u; bool inside;
-                    fast_span(xq[rt][reg], fgeo, m, u, inside);
+                    const float tt = fmaf(xq[rt][reg], fgeo.inv_h, fgeo.c0);
+                    const float u = __builtin_amdgcn_fractf(tt);
+                    const int m = (int)floorf(tt);
                     float dN[4];
-                    cubic_dbases(u, inside ? wd : 0.0f, dN);
+                    cubic_dbases(u, 1.0f, dN);
                     float d[kCTmax - 1];
 #pragma unroll
                     for (int c = 0; c < kCTmax - 1; ++c) d[c] = c < NS1 ? D1[c < NS1 ? c : 0][rt][reg] : 0.0f;
                     const int m1 = m - 8;
                     const u32x4 sel = *reinterpret_cast<const u32x4*>(s_btbl + 4 * min((unsigned)m1, 15u));
-                    const float s = (s0[rt][reg] + barrel_dot3(d, m1, sel, dN)) * rinv[rt][reg];
+                    const float s = fmaf(barrel_dot3(d, m1, sel, dN), wd, s0[rt][reg]) * rinv[rt][reg];
                     if (f < in) gst_s(gxb, gx_ro, (unsigned)(16 * rt + reg) * ldgx4, s);      // rows >= N: dropped
                 }
             }
