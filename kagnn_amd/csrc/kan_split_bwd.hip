@@ -907,8 +907,9 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
             u32x4 sah, sal;                // silu(x) * 2^4 over the 8 rows, hi / lo
             if constexpr (K == 3) {
 #pragma unroll
-                for (int j = 0; j < 8; j += 2)
+                for (int j = 0; j < 8; j += 2) {
                     make_spline_frag3_pair(raw.x[j], raw.x[j + 1], s_tbl, fgeo, rh[j], rl[j], rh[j + 1], rl[j + 1], woff);
+                }
             } else
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
