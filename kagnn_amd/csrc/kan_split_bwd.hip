@@ -368,8 +368,10 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     float bar;
                     if constexpr (K == 3) {
                         const int mm = m - 8 * win;
-                        const u32x4 sel = *reinterpret_cast<const u32x4*>(s_btbl + 4 * min((unsigned)mm, 15u));
-                        bar = barrel_dot3(d, mm, sel, dN) * (0.5f * fgeo.inv_h);
+                        const unsigned* be = s_btbl + kBarrelDw * min((unsigned)mm, 15u);
+                        const u32x4 sel = *reinterpret_cast<const u32x4*>(be);
+                        const uint2 rot = *reinterpret_cast<const uint2*>(be + 4);
+                        bar = barrel_dot3(d, sel, rot.x, rot.y, dN) * (0.5f * fgeo.inv_h);
                     } else {
                         bar = barrel_dot<K>(d, m - 8 * win, dN);
                     }
@@ -605,8 +607,10 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
                     float d[kCTmax - 1];
 #pragma unroll
                     for (int c = 0; c < kCTmax - 1; ++c) d[c] = D[c][rt][reg];
-                    const u32x4 sel = *reinterpret_cast<const u32x4*>(s_btbl + 4 * min((unsigned)m, 15u));
-                    s0[rt][reg] = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot3(d, m, sel, dN) * wd);
+                    const unsigned* be = s_btbl + kBarrelDw * min((unsigned)m, 15u);
+                    const u32x4 sel = *reinterpret_cast<const u32x4*>(be);
+                    const uint2 rot = *reinterpret_cast<const uint2*>(be + 4);
+                    s0[rt][reg] = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), barrel_dot3(d, sel, rot.x, rot.y, dN) * wd);
                 }
             }
             // ================= window 1: its C - 8 live slots only
@@ -646,8 +650,10 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
 #pragma unroll
                     for (int c = 0; c < kCTmax - 1; ++c) d[c] = c < NS1 ? D1[c < NS1 ? c : 0][rt][reg] : 0.0f;
                     const int m1 = m - 8;
-                    const u32x4 sel = *reinterpret_cast<const u32x4*>(s_btbl + 4 * min((unsigned)m1, 15u));
-                    const float s = fmaf(barrel_dot3(d, m1, sel, dN), wd, s0[rt][reg]) * rinv[rt][reg];
+                    const unsigned* be = s_btbl + kBarrelDw * min((unsigned)m1, 15u);
+                    const u32x4 sel = *reinterpret_cast<const u32x4*>(be);
+                    const uint2 rot = *reinterpret_cast<const uint2*>(be + 4);
+                    const float s = fmaf(barrel_dot3(d, sel, rot.x, rot.y, dN), wd, s0[rt][reg]) * rinv[rt][reg];
                     if (f < in) gst_s(gxb, gx_ro, (unsigned)(16 * rt + reg) * ldgx4, s);      // rows >= N: dropped
                 }
             }

@@ -547,24 +547,31 @@ __device__ __forceinline__ void make_rbf_frag(float z, float a, const float (&ca
 // not exist): ONE v_perm_b32 per residue with a selector from a 16-entry LDS table indexed by m (dword selectors
 // "low source" / "high source" / zero).  The four survivors then only need a ROTATION by c0 & 3 to line up with
 // dN[0..3]: two more v_perm stages.  12 v_perm_b32, no compares, instead of 27 selects + 5 compares.
-__device__ __forceinline__ void build_barrel_table(unsigned* tbl /* LDS, 16*4 */, int tid) {
-    if (tid < 64) {
-        const int mm = tid >> 2, rho = tid & 3, c0 = mm - 3;
-        const int t = c0 + ((rho - c0) & 3);           // the slot of residue rho inside [c0, c0+3]
-        tbl[tid] = (mm >= 15) ? 0x0c0c0c0cu : (t == rho ? 0x03020100u : (t == rho + 4 ? 0x07060504u : 0x0c0c0c0cu));
+// Entry mm (0..15) = 8 dwords: [0..3] the residue selectors, [4] / [5] the two rotation-stage selectors of b = (mm + 1) & 3
+// (round 3: computed per scalar they were 2 and + 2 compare + 2 select = 6 of the input gradient's ~45 VALU per scalar)
+constexpr int kBarrelDw = 8;
+__device__ __forceinline__ void build_barrel_table(unsigned* tbl /* LDS, 16*8 */, int tid) {
+    if (tid < 128) {
+        const int mm = tid >> 3, k = tid & 7, c0 = mm - 3;
+        unsigned v = 0x03020100u;
+        if (k < 4) {
+            const int rho = k, t = c0 + ((rho - c0) & 3);   // the slot of residue rho inside [c0, c0+3]
+            v = (mm >= 15) ? 0x0c0c0c0cu : (t == rho ? 0x03020100u : (t == rho + 4 ? 0x07060504u : 0x0c0c0c0cu));
+        } else if (k < 6) {
+            const unsigned bb = (unsigned)(mm + 1) & 3u;
+            v = 0x03020100u + ((k == 4 ? (bb & 1u) : (bb >> 1)) * 0x04040404u);
+        }
+        tbl[tid] = v;
     }
 }
-__device__ __forceinline__ float barrel_dot3(const float (&d)[8], int mm /* m - 8*window */, const u32x4& sel,
+// sel = dwords 0..3 of the entry, rot = dwords 4, 5
+__device__ __forceinline__ float barrel_dot3(const float (&d)[8], const u32x4& sel, unsigned selA, unsigned selB,
                                              const float (&dN)[4]) {
     unsigned s4[4], r1[4];
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho)
         s4[rho] = __builtin_amdgcn_perm(__float_as_uint(d[rho + 4]), __float_as_uint(d[rho]), sel[rho]);
-    // rotation e[r] = s4[(b + r) & 3], b = c0 & 3, as two v_perm stages whose dword selectors are computed
-    // arithmetically (no compares, no VCC): 0x03020100 keeps the low source, +0x04040404 takes the high one
-    const unsigned b = (unsigned)(mm + 1) & 3u;
-    const unsigned selA = 0x03020100u + (b & 1u) * 0x04040404u;
-    const unsigned selB = 0x03020100u + (b >> 1) * 0x04040404u;
+    // rotation e[r] = s4[(b + r) & 3], b = c0 & 3, as two v_perm stages: 0x03020100 keeps the low source, 0x07060504 takes the high one
 #pragma unroll
     for (int i = 0; i < 4; ++i) r1[i] = __builtin_amdgcn_perm(s4[(i + 1) & 3], s4[i], selA);
     float e[4];
