@@ -415,7 +415,7 @@ def main():
 
         def make(cls):
             sconv = (cls(conv, dist.group.WORLD, sync_in_backward=False) if cls is TransposedShardedGIKANLayer
-                     else cls(conv, dist.group.WORLD)).to(dev)
+                     else cls(conv, dist.group.WORLD, comm=comm)).to(dev)
             xs = sconv.shard_columns(x_full.to(dev)).requires_grad_(True)
             gs = sconv.shard_columns(gy_full.to(dev))
             ps = list(sconv.parameters())
@@ -429,10 +429,14 @@ def main():
                 if hasattr(sconv, "sync_gradients"):
                     sconv.sync_gradients()             # one flat all-reduce for all weight gradients
             return step
-        # north_star's scheme is the reported one; KAGNN_SHARDING=transposed swaps the two roles
+        # north_star's scheme is the reported one; KAGNN_SHARDING=transposed swaps the two roles.  KAGNN_COMM=p2p runs its
+        # exchanges as direct peer-to-peer kernels over hipIpc-mapped buffers (kagnn_p2p_*) instead of RCCL collectives
+        comm = os.environ.get("KAGNN_COMM", "rccl")
         primary = os.environ.get("KAGNN_SHARDING", "feature")
-        names = {"feature": f"feature-sharded x{world}: spline coefficients split by input feature, RCCL reduce-scatter (fwd) / "
-                            f"all-gather (bwd) per KANLinear (north_star)",
+        names = {"feature": (f"feature-sharded x{world}: spline coefficients split by input feature, RCCL reduce-scatter (fwd) / "
+                             f"all-gather (bwd) per KANLinear (north_star)") if comm == "rccl" else
+                            (f"feature-sharded x{world}: spline coefficients split by input feature, direct peer-to-peer reduce-scatter (fwd) / "
+                             f"all-gather (bwd) kernels over hipIpc-mapped peer buffers per KANLinear (KAGNN_COMM=p2p)"),
                  "transposed": f"column-sharded aggregation + row-sharded KAN chain x{world}: RCCL all-to-all both ways, one flat "
                                f"weight-gradient all-reduce"}
         classes = {"feature": ShardedGIKANLayer, "transposed": TransposedShardedGIKANLayer}

@@ -419,6 +419,20 @@ int kagnn_softmax_xent_bwd(const float* logits, int64_t ld, int64_t num_rows, in
                            const float* row_stats, const float* count, const float* g_loss,
                            float* g_logits, int64_t ldg, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Direct peer-to-peer exchange steps of the feature-sharded layer (no reference counterpart: the reference has no
+ * multi-GPU code; contract = BASELINE.json north_star, SURVEY.md 8(b)/(e): "sharded variants", "hand-rolled
+ * direct P2P over hipIpcMemHandle peer buffers").  `parts` / `shards`: HOST arrays of `world` DEVICE pointers -- entry p is
+ * rank p's exchange buffer as mapped into THIS process (hipIpcOpenMemHandle; own entry = own buffer).  The caller orders the
+ * ranks (every peer's buffer complete before the call, not overwritten before every reader is done).
+ *   reduce_scatter: y[n][c] = sum_p parts[p][n*ld + rank*(out/world) + c], c < out/world, summed in rank order (deterministic)
+ *   all_gather:     g[n][p*w + c] = shards[p][n*lds + c]
+ * out/world (resp. w) and the leading dimensions must be multiples of 4 floats, bases 16-byte aligned; world <= 16. */
+int kagnn_p2p_reduce_scatter(const float* const* parts, int32_t world, int32_t rank, int64_t num_rows, int32_t out_features,
+                             int64_t ld, float* y, int64_t ldy, void* stream);
+int kagnn_p2p_all_gather(const float* const* shards, int32_t world, int64_t num_rows, int32_t shard_width, int64_t lds,
+                         float* g, int64_t ldg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

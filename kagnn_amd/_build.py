@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIBPATH = os.path.join(LIBDIR, "libkagnn_hip.so")
-SOURCES = ["api.hip", "csr.hip", "aggregate.hip", "aggregate_bf16.hip", "kan_fp32.hip", "kan_split.hip", "kan_sparse_fwd.hip", "kan_split_bwd.hip", "kan_grid.hip", "fastkan.hip", "bn.hip", "gat.hip", "loss.hip"]
+SOURCES = ["api.hip", "csr.hip", "aggregate.hip", "aggregate_bf16.hip", "kan_fp32.hip", "kan_split.hip", "kan_sparse_fwd.hip", "kan_split_bwd.hip", "kan_grid.hip", "fastkan.hip", "bn.hip", "gat.hip", "loss.hip", "p2p.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wno-unused-result", "-DNDEBUG"]
 

@@ -40,6 +40,8 @@ _SIGNATURES = {
                                            c_int64, _P, _P, _P, c_int64, c_int32, c_float, _P]),
     "kagnn_segment_pool": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
     "kagnn_segment_broadcast": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
+    "kagnn_p2p_reduce_scatter": (c_int32, [_P, c_int32, c_int32, c_int64, c_int32, c_int64, _P, c_int64, _P]),
+    "kagnn_p2p_all_gather": (c_int32, [_P, c_int32, c_int64, c_int32, c_int64, _P, c_int64, _P]),
     "kagnn_kan_pack_bytes": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32,
                                        POINTER(c_size_t), POINTER(c_size_t)]),
     "kagnn_kan_pack": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),

@@ -77,6 +77,8 @@ int gat_att_grad(const float*, long, const float*, const float*, long, int, int,
 size_t bn_ws_bytes(long N, int F);
 int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, const float*, const float*, float, unsigned long long, float*, long, float*, float*, void*, size_t, hipStream_t);
 int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float, unsigned long long, float*, long, float*, float*, void*, size_t, hipStream_t);
+int p2p_reduce_scatter(const float* const* parts, int P, int rank, long N, int out, long ld, float* y, long ldy, hipStream_t st);
+int p2p_all_gather(const float* const* shards, int P, long N, int w, long lds, float* g, long ldg, hipStream_t st);
 }  // namespace kagnn
 
 using namespace kagnn;
@@ -555,6 +557,20 @@ int kagnn_softmax_xent_bwd(const float* logits, int64_t ld, int64_t N, int32_t C
                     as_stream(stream));
 }
 
+
+// ---------------------------------------------------------------- direct peer-to-peer exchange (p2p.hip)
+
+int kagnn_p2p_reduce_scatter(const float* const* parts, int32_t world, int32_t rank, int64_t N, int32_t out, int64_t ld, float* y,
+                             int64_t ldy, void* stream) {
+    KAGNN_CHECK_ARG(parts && N >= 0 && out >= 1 && ld >= out && (N == 0 || y), "bad argument");
+    return p2p_reduce_scatter(parts, world, rank, N, out, ld, y, ldy, as_stream(stream));
+}
+
+int kagnn_p2p_all_gather(const float* const* shards, int32_t world, int64_t N, int32_t w, int64_t lds, float* g, int64_t ldg,
+                         void* stream) {
+    KAGNN_CHECK_ARG(shards && N >= 0 && w >= 1 && lds >= w && ldg >= (int64_t)w * world && (N == 0 || g), "bad argument");
+    return p2p_all_gather(shards, world, N, w, lds, g, ldg, as_stream(stream));
+}
 
 // ---------------------------------------------------------------- one KAN-GIN convolution per call
 static size_t al256z(size_t b) { return (b + 255) & ~(size_t)255; }

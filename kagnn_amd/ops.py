@@ -545,7 +545,7 @@ def _weights_key(bw, sw, sc):
 
 # raw (no autograd) pieces of the KANLinear forward / backward: shared by the autograd.Function below (eager) and by the
 # torch.library ops of kagnn_amd/library.py (torch.compile sees those as opaque ops)
-def _kan_fwd_raw(x, bw, sw, sc, knots, grid_size, spline_order, mode, packed=None, pack_key=None, moments=False):
+def _kan_fwd_raw(x, bw, sw, sc, knots, grid_size, spline_order, mode, packed=None, pack_key=None, moments=False, out=None):
     """-> (y, pack_dx): forward output and the input-gradient pack of the current weights; with ``moments`` also the
     column moments of y, ``(mean [out], M2 [out])`` (``kagnn_kan_linear_fwd_moments``: the BatchNorm1d statistics)"""
     n, fin = x.shape
@@ -557,7 +557,9 @@ def _kan_fwd_raw(x, bw, sw, sc, knots, grid_size, spline_order, mode, packed=Non
         pack_f, pack_d = _ws(fb, x.device), _ws(db, x.device)
         _call("kagnn_kan_pack", _ptr(bw), _ptr(sw), _ptr(sc), fin, fout, grid_size, spline_order, mode,
               _ptr(pack_f), _ptr(pack_d), _stream())
-    y = torch.empty((n, fout), dtype=torch.float32, device=x.device)
+    if out is not None and (out.shape != (n, fout) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device):
+        raise ValueError("out must be a contiguous fp32 [rows, out_features] tensor on the input's device")
+    y = out if out is not None else torch.empty((n, fout), dtype=torch.float32, device=x.device)
     if moments:
         mom = torch.empty((2, fout), dtype=torch.float32, device=x.device)
         wb = _sizes("kagnn_kan_fwd_moments_workspace_bytes", n, fin, fout, grid_size, spline_order, mode)
@@ -592,10 +594,22 @@ def _kan_bwd_weight_raw(x, gy, knots, sw, sc, fin, fout, G, K, mode, has_base):
     return gbw, gsw, gsc
 
 
+class _OutBuffer:
+    """a caller-owned destination for a forward output, hidden from autograd (see _KANLinearFn.forward)"""
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+    def view(self, n: int, f: int) -> torch.Tensor:
+        if self.t.numel() < n * f or self.t.dtype != torch.float32 or not self.t.is_contiguous():
+            raise ValueError("out must be a contiguous fp32 buffer of at least rows * out_features elements")
+        return self.t.detach().view(-1)[: n * f].view(n, f)
+
+
 class _KANLinearFn(Function):
     @staticmethod
     @_on_operand_device
-    def forward(ctx, x, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, packed=None):
+    def forward(ctx, x, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, packed=None, out=None):
         _need_cuda(x, base_weight, spline_weight, spline_scaler, knots)
         x = _rows(x)
         fin = x.size(1)
@@ -603,8 +617,11 @@ class _KANLinearFn(Function):
         bw = None if base_weight is None else base_weight.contiguous()     # None: no SiLU branch (coefficient groups)
         sw = spline_weight.contiguous()
         sc = None if spline_scaler is None else spline_scaler.contiguous()
+        # out: an _OutBuffer (NOT a tensor argument: autograd must not see the caller's buffer -- e.g. a peer-mapped exchange
+        # buffer -- as an input modified in place); the output is a fresh view of it made here, under the forward's no_grad
         y, pack_d = _kan_fwd_raw(x, bw, sw, sc, knots, grid_size, spline_order, mode, packed,
-                                 _weights_key(base_weight, spline_weight, spline_scaler) if packed is not None else None)
+                                 _weights_key(base_weight, spline_weight, spline_scaler) if packed is not None else None,
+                                 out=None if out is None else out.view(x.size(0), fout))
         ctx.save_for_backward(x, sw, sc, knots, pack_d)
         ctx.dims = (fin, fout, grid_size, spline_order, mode)
         ctx.has_base = bw is not None
@@ -622,7 +639,7 @@ class _KANLinearFn(Function):
             gx = _kan_bwd_input_raw(x, gy, knots, pack_d, fin, fout, G, K, mode)
         if any(ctx.needs_input_grad[1:4]):
             gbw, gsw, gsc = _kan_bwd_weight_raw(x, gy, knots, sw, sc, fin, fout, G, K, mode, ctx.has_base)
-        return gx, gbw, gsw, gsc, None, None, None, None, None
+        return gx, gbw, gsw, gsc, None, None, None, None, None, None
 
 
 _LAYER_ABI = os.environ.get("KAGNN_LAYER_ABI", "1") != "0"     # 1: kagnn_gin_kan_layer_fwd / _bwd (one library call each way)
@@ -799,7 +816,7 @@ def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optiona
 
 
 def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
-               mode: Optional[int] = None, packed=None) -> torch.Tensor:
+               mode: Optional[int] = None, packed=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = silu(x) @ base_weight.T + bases(x) @ (spline_weight*scaler).T  (ekan.py:154-162).
     ``knots`` is ONE row of the layer's grid buffer (uniform), fp32 [G+2k+1] on the device -- or the whole
     buffer [in, G+2k+1] when its rows differ / are non-uniform (after ``update_grid``): that runs the exact-fp32
@@ -815,6 +832,8 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
     if mode != PREC_SPLIT:
         packed = None                                    # chain packs are in the split kernels' layout
     n_coef = int(grid_size) + int(spline_order)
+    if out is not None and ((mode == PREC_SPLIT and n_coef > 16 and knots.dim() == 1) or torch.compiler.is_compiling()):
+        raise ValueError("out= is not supported for layers with more than 16 coefficients or under torch.compile")
     if mode == PREC_SPLIT and n_coef > 16 and knots.dim() == 1:
         # More than 16 coefficients per feature (the reference's search space goes to grid_size 32): a uniform
         # B-spline basis function only depends on its own k+2 knots, so the layer is the SUM of layers over
@@ -836,7 +855,7 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
         return library.kan_linear(x, base_weight, spline_weight, spline_scaler, knots, int(grid_size), int(spline_order),
                                   int(mode))[0]
     return _KANLinearFn.apply(x, base_weight, spline_weight, spline_scaler, knots, int(grid_size),
-                              int(spline_order), int(mode), packed)
+                              int(spline_order), int(mode), packed, None if out is None else _OutBuffer(out))
 
 
 def kan_linear_parts(parts, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,

@@ -1,0 +1,76 @@
+"""Peer-mapped exchange buffers for the direct peer-to-peer steps of the feature-sharded layer.
+
+One process per GPU (the launch contract of bench.py); every rank allocates its exchange buffer with the caching allocator,
+exports it as an IPC handle (hipIpcGetMemHandle underneath ``UntypedStorage._share_cuda_``; the pool's driver speaks dmabuf IPC:
+``HSA_ENABLE_IPC_MODE_LEGACY=0``), the handles travel through ``torch.distributed.all_gather_object`` (control plane only -- any
+backend) and every rank maps its peers' buffers (hipIpcOpenMemHandle underneath ``UntypedStorage._new_shared_cuda``).  The data
+path is then ``kagnn_p2p_reduce_scatter`` / ``kagnn_p2p_all_gather`` (csrc/p2p.hip): kernels that READ the peers' buffers over
+xGMI.  The reference has no multi-GPU code."""
+from __future__ import annotations
+
+import ctypes
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class PeerBuffers:
+    """``numel`` fp32 elements per rank, mapped on every rank: ``local`` is this rank's buffer, ``views[p]`` rank p's."""
+
+    def __init__(self, numel: int, device: torch.device, group=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = torch.device(device)
+        # a storage of its own (not a slice of a cached block shared with other tensors: the whole allocation is exported)
+        self.local = torch.empty(max(int(numel), 4), dtype=torch.float32, device=self.device)
+        handle = self.local.untyped_storage()._share_cuda_()
+        handles = [None] * self.world
+        dist.all_gather_object(handles, handle, group=group)
+        self.views: List[torch.Tensor] = []
+        self._keep = []
+        for p, h in enumerate(handles):
+            if p == self.rank:
+                self.views.append(self.local)
+                continue
+            st = torch.UntypedStorage._new_shared_cuda(*h)
+            self._keep.append(st)
+            t = torch.empty(0, dtype=torch.float32, device=st.device).set_(st, 0, (self.local.numel(),))
+            if t.device != self.device:                       # first touch enables peer access from this device to the peer's
+                torch.empty(1, dtype=torch.float32, device=self.device).copy_(t[:1])
+            self.views.append(t)
+        self._ptrs = (ctypes.c_void_p * self.world)(*[v.data_ptr() for v in self.views])
+        dist.barrier(group=group)                             # nobody proceeds (and frees) before everybody has mapped
+
+    def ptr_array(self):
+        return self._ptrs
+
+
+def rank_barrier(group=None) -> None:
+    """every rank's device work enqueued so far is complete on all ranks after this (stream-ordered with RCCL: a one-element
+    all-reduce on the current stream; host-side with any other backend)"""
+    if dist.get_backend(group) == "nccl":
+        t = torch.zeros(1, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, group=group)
+    else:
+        torch.cuda.current_stream().synchronize()
+        dist.barrier(group=group)
+
+
+def reduce_scatter(bufs: PeerBuffers, n: int, out: int) -> torch.Tensor:
+    """rank r's column block of the sum over ranks of the ``[n, out]`` partial matrices sitting in ``bufs``"""
+    w = out // bufs.world
+    y = torch.empty((n, w), dtype=torch.float32, device=bufs.device)
+    with ops._device_of(y):
+        ops._call("kagnn_p2p_reduce_scatter", bufs.ptr_array(), bufs.world, bufs.rank, n, out, out, ops._ptr(y), w, ops._stream())
+    return y
+
+
+def all_gather(bufs: PeerBuffers, n: int, w: int) -> torch.Tensor:
+    """``[n, world*w]``: the ``[n, w]`` shards sitting in ``bufs``, side by side in rank order"""
+    g = torch.empty((n, w * bufs.world), dtype=torch.float32, device=bufs.device)
+    with ops._device_of(g):
+        ops._call("kagnn_p2p_all_gather", bufs.ptr_array(), bufs.world, n, w, w, ops._ptr(g), w * bufs.world, ops._stream())
+    return g

@@ -128,6 +128,44 @@ class _Finish(Function):
         return (None, None, *pieces)
 
 
+class _P2PReduceScatter(Function):
+    """the direct peer-to-peer form of one KANLinear's exchange (``comm="p2p"``): ``partial`` already sits in this rank's
+    peer-mapped buffer (the KAN forward wrote it there); forward = rank barrier + ONE kernel that reads every peer's column
+    block and sums in rank order (``kagnn_p2p_reduce_scatter``: no rank-major staging copy, no ring); backward = this rank's
+    gradient shard into its peer-mapped buffer, rank barrier, ONE kernel that pulls all shards into the final ``[n, out]``
+    layout (``kagnn_p2p_all_gather``: no un-permute)."""
+
+    @staticmethod
+    def forward(ctx, partial, xch):
+        from . import p2p
+        n, out = partial.shape
+        p2p.rank_barrier(xch.group)                   # every rank's partial sums are complete
+        y = p2p.reduce_scatter(xch.part, n, out)
+        ctx.xch, ctx.n, ctx.out = xch, n, out
+        return y
+
+    @staticmethod
+    def backward(ctx, g_shard):
+        from . import p2p
+        xch, n, out = ctx.xch, ctx.n, ctx.out
+        w = out // xch.part.world
+        xch.grad.local[: n * w].view(n, w).copy_(g_shard)
+        p2p.rank_barrier(xch.group)
+        g = p2p.all_gather(xch.grad, n, w)
+        return g, None
+
+
+class _P2PExchange:
+    """the two peer-mapped buffers of one KANLinear of the feature-sharded layer: partial sums [n, out] and gradient shards
+    [n, out/P]; allocated (and their IPC handles exchanged) once per (layer, row count)"""
+
+    def __init__(self, n: int, out: int, device, group):
+        from . import p2p
+        self.group, self.n, self.out = group, n, out
+        self.part = p2p.PeerBuffers(n * out, device, group)
+        self.grad = p2p.PeerBuffers(n * (out // self.part.world), device, group)
+
+
 def _chunk_bounds(n: int, chunks: int):
     if n <= 0:
         return [(0, 0)]                                          # an empty shard still runs its (empty) collectives
@@ -169,8 +207,17 @@ class ShardedGIKANLayer(nn.Module):
     ``chunks``: row chunks per KANLinear whose reduce-scatter (forward) / all-gather (backward) overlap with the KAN
     kernels of the neighbouring chunk; ``None`` = 4 from 256k rows up, else 1."""
 
-    def __init__(self, conv: GIKANLayer, group=None, local_ops=None, chunks: Optional[int] = None):
+    def __init__(self, conv: GIKANLayer, group=None, local_ops=None, chunks: Optional[int] = None, comm: str = "rccl"):
+        """``comm="rccl"`` (default): reduce-scatter / all-gather through ``torch.distributed`` (RCCL), row-chunked and
+        overlapped.  ``comm="p2p"``: the direct form of SURVEY.md 8(e) -- every rank maps its peers' exchange buffers
+        (hipIpc, ``kagnn_amd/p2p.py``) and ONE kernel per exchange pulls the column blocks over xGMI
+        (``kagnn_p2p_reduce_scatter`` / ``kagnn_p2p_all_gather``); the KAN forward writes its partial sums straight into the
+        peer-mapped buffer and the gathered gradient lands in its final layout: no staging passes, no ring."""
         super().__init__()
+        if comm not in ("rccl", "p2p"):
+            raise ValueError("comm must be 'rccl' or 'p2p'")
+        self.comm = comm
+        self._xch = {}
         self.group = group
         self.chunks = chunks
         self.rank = dist.get_rank(group)
@@ -186,6 +233,17 @@ class ShardedGIKANLayer(nn.Module):
     def forward(self, x_shard: torch.Tensor, graph) -> torch.Tensor:
         h = self.local_ops.aggregate_sum(x_shard, graph, self_scale=1.0 + self.eps)
         n = h.size(0)
+        if self.comm == "p2p":
+            for li, layer in enumerate(self.layers):
+                key = (li, n)
+                if key not in self._xch:              # (collective: every rank reaches this at the same layer and row count)
+                    self._xch[key] = _P2PExchange(n, layer.out_features, h.device, self.group)
+                xch = self._xch[key]
+                partial = self.local_ops.kan_linear(h, layer.base_weight, layer.spline_weight, layer.spline_scaler, layer.knots,
+                                                    layer.grid_size, layer.spline_order, layer.precision,
+                                                    out=xch.part.local[: n * layer.out_features].view(n, layer.out_features))
+                h = _P2PReduceScatter.apply(partial, xch)
+            return h
         bounds = _chunk_bounds(n, self.chunks if self.chunks is not None else (4 if n >= 262144 else 1))
         for layer in self.layers:
             comm = _Comm(self.group)

@@ -513,6 +513,36 @@ def test_zinc_shaped_batch_regression_models_golden(golden, kind, mode, monkeypa
     assert checked >= 20
 
 
+def test_p2p_exchange_kernels_on_local_buffers():
+    """kagnn_p2p_reduce_scatter / kagnn_p2p_all_gather (csrc/p2p.hip) through the C ABI with the "peers" being buffers of this
+    process: the column block of the rank-ordered sum, and the shards side by side (the two-process, hipIpc-mapped form runs in
+    tests/test_sharded_gloo.py)."""
+    import ctypes
+    P, n, out = 4, 1037, 48
+    w = out // P
+    gen = torch.Generator().manual_seed(5)
+    parts = [torch.randn(n, out, generator=gen).to(DEV) for _ in range(P)]
+    ptrs = (ctypes.c_void_p * P)(*[t.data_ptr() for t in parts])
+    want = parts[0].double()
+    for t in parts[1:]:
+        want = want + t.double()
+    for rank in range(P):
+        y = torch.empty(n, w, device=DEV)
+        ops._call("kagnn_p2p_reduce_scatter", ptrs, P, rank, n, out, out, ops._ptr(y), w, ops._stream())
+        acc = parts[0][:, rank * w:(rank + 1) * w].clone()
+        for t in parts[1:]:
+            acc += t[:, rank * w:(rank + 1) * w]
+        assert torch.equal(y, acc)                                   # rank order, fp32: bit-exact
+        assert_close(y, want[:, rank * w:(rank + 1) * w], 1e-6, what="p2p reduce-scatter")
+    shards = [torch.randn(n, w, generator=gen).to(DEV) for _ in range(P)]
+    sptr = (ctypes.c_void_p * P)(*[t.data_ptr() for t in shards])
+    g = torch.empty(n, out, device=DEV)
+    ops._call("kagnn_p2p_all_gather", sptr, P, n, w, w, ops._ptr(g), out, ops._stream())
+    assert torch.equal(g, torch.cat(shards, dim=1))
+    with pytest.raises(Exception):                                   # a shard width that is not a multiple of 4 floats is refused, loudly
+        ops._call("kagnn_p2p_reduce_scatter", ptrs, 8, 0, n, out, out, ops._ptr(y), 6, ops._stream())
+
+
 # ------------------------------------------------------------------ range robustness of the split path
 @pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
 def test_kanlinear_extreme_ranges_vs_oracle(mode):

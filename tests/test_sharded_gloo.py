@@ -142,11 +142,18 @@ def _gpu_worker(rank, world, port, out_dir):
             err = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
             assert err <= 1e-4, (what, err)
 
-        for cls, kw in ((ShardedGIKANLayer, {}), (ShardedGIKANLayer, {"chunks": 3}), (TransposedShardedGIKANLayer, {})):
+        # comm="p2p": hipIpc peer-mapped exchange buffers + kagnn_p2p_reduce_scatter / _all_gather (two processes, one GPU)
+        for cls, kw in ((ShardedGIKANLayer, {}), (ShardedGIKANLayer, {"chunks": 3}), (ShardedGIKANLayer, {"comm": "p2p"}),
+                        (TransposedShardedGIKANLayer, {})):
             sconv = cls(conv, None, **kw).to(dev)
             xs = sconv.shard_columns(x).requires_grad_(True)
             y = sconv(xs, graph)
             y.backward(sconv.shard_columns(gy))
+            if kw.get("comm") == "p2p":               # a second step through the same exchange buffers (reuse across steps)
+                xs.grad = None
+                sconv.zero_grad()
+                y = sconv(xs, graph)
+                y.backward(sconv.shard_columns(gy))
             close(y, y_ref[:, sl], cls.__name__ + ".y")
             close(xs.grad, xr.grad[:, sl], cls.__name__ + ".gx")
             for li, (layer, full) in enumerate(zip(sconv.layers, conv.nn.layers)):
