@@ -414,7 +414,7 @@ def main():
         from kagnn_amd.sharded import ShardedGIKANLayer, TransposedShardedGIKANLayer
 
         def make(cls):
-            sconv = (cls(conv, dist.group.WORLD, sync_in_backward=False) if cls is TransposedShardedGIKANLayer
+            sconv = (cls(conv, dist.group.WORLD, sync_in_backward=False, comm=comm) if cls is TransposedShardedGIKANLayer
                      else cls(conv, dist.group.WORLD, comm=comm)).to(dev)
             xs = sconv.shard_columns(x_full.to(dev)).requires_grad_(True)
             gs = sconv.shard_columns(gy_full.to(dev))
@@ -437,8 +437,9 @@ def main():
                              f"all-gather (bwd) per KANLinear (north_star)") if comm == "rccl" else
                             (f"feature-sharded x{world}: spline coefficients split by input feature, direct peer-to-peer reduce-scatter (fwd) / "
                              f"all-gather (bwd) kernels over hipIpc-mapped peer buffers per KANLinear (KAGNN_COMM=p2p)"),
-                 "transposed": f"column-sharded aggregation + row-sharded KAN chain x{world}: RCCL all-to-all both ways, one flat "
-                               f"weight-gradient all-reduce"}
+                 "transposed": f"column-sharded aggregation + row-sharded KAN chain x{world}: " +
+                               ("RCCL all-to-all both ways" if comm == "rccl" else "direct peer-to-peer pulls over hipIpc-mapped buffers both ways (KAGNN_COMM=p2p)") +
+                               ", one flat weight-gradient all-reduce"}
         classes = {"feature": ShardedGIKANLayer, "transposed": TransposedShardedGIKANLayer}
         other = "transposed" if primary == "feature" else "feature"
         step = make(classes[primary])

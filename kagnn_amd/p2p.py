@@ -74,3 +74,36 @@ def all_gather(bufs: PeerBuffers, n: int, w: int) -> torch.Tensor:
     with ops._device_of(g):
         ops._call("kagnn_p2p_all_gather", bufs.ptr_array(), bufs.world, n, w, w, ops._ptr(g), w * bufs.world, ops._stream())
     return g
+
+
+def _shifted(bufs: PeerBuffers, offsets_elems):
+    """host array of the peers' buffer pointers advanced by per-peer element offsets"""
+    return (ctypes.c_void_p * len(offsets_elems))(*[bufs.views[p].data_ptr() + 4 * int(o) for p, o in enumerate(offsets_elems)])
+
+
+def cols_to_rows(bufs: PeerBuffers, n: int, w: int, splits) -> torch.Tensor:
+    """all-to-all, column shards -> row shards: every rank's ``[n, w]`` column shard sits in ``bufs``; returns this rank's rows of
+    ALL columns ``[n_me, world*w]`` (rank order) -- one pull kernel (``kagnn_p2p_all_gather`` on row-shifted peer pointers)"""
+    r0 = sum(splits[:bufs.rank])
+    n_me = splits[bufs.rank]
+    out = torch.empty((n_me, w * bufs.world), dtype=torch.float32, device=bufs.device)
+    if n_me:
+        with ops._device_of(out):
+            ops._call("kagnn_p2p_all_gather", _shifted(bufs, [r0 * w] * bufs.world), bufs.world, n_me, w, w, ops._ptr(out),
+                      w * bufs.world, ops._stream())
+    return out
+
+
+def rows_to_cols(bufs: PeerBuffers, n: int, w: int, splits) -> torch.Tensor:
+    """all-to-all, row shards -> column shards: rank p's ``[n_p, world*w]`` row block sits in ``bufs``; returns this rank's columns
+    of ALL rows ``[n, w]`` -- one strided pull per peer (``kagnn_p2p_all_gather`` with world = 1)"""
+    out = torch.empty((n, w), dtype=torch.float32, device=bufs.device)
+    f = w * bufs.world
+    r0 = 0
+    with ops._device_of(out):
+        for p, n_p in enumerate(splits):
+            if n_p:
+                src = (ctypes.c_void_p * 1)(bufs.views[p].data_ptr() + 4 * bufs.rank * w)
+                ops._call("kagnn_p2p_all_gather", src, 1, n_p, w, f, out.data_ptr() + 4 * r0 * w, w, ops._stream())
+            r0 += n_p
+    return out

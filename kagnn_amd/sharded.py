@@ -306,6 +306,48 @@ class _RowsToCols(Function):
         return _cols_to_rows(g_cols.contiguous(), ctx.group), None, None
 
 
+class _P2PTranspose(Function):
+    """the two all-to-alls of the transposed layer as direct peer-to-peer pulls (``comm="p2p"``): ``to_rows=True`` turns this
+    rank's column shard ``[n, w]`` into its row shard ``[n_me, P*w]``, ``False`` the other way; the backward is the opposite
+    direction through the partner buffer.  The operand is copied into this rank's peer-mapped buffer (1/P of an activation),
+    a rank barrier follows, one kernel (or one per peer) pulls over xGMI into the final layout -- no send-side packing pass."""
+
+    @staticmethod
+    def forward(ctx, x, xch, to_rows, n):
+        ctx.xch, ctx.to_rows, ctx.n = xch, to_rows, n
+        return xch.run(x, to_rows, n, fwd=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.xch.run(g.contiguous(), not ctx.to_rows, ctx.n, fwd=False), None, None, None
+
+
+class _P2PTransposeExchange:
+    """peer-mapped buffers of the transposed layer: [n, w] column shards and [n_max, P*w] row blocks, one pair per direction
+    of the tape (forward / backward), allocated once per (row count, width)"""
+
+    def __init__(self, n: int, w: int, device, group):
+        from . import p2p
+        world = dist.get_world_size(group)
+        self.group, self.w = group, w
+        self.splits = _row_splits(n, world)
+        self.cols = [p2p.PeerBuffers(n * w, device, group) for _ in range(2)]                     # fwd, bwd
+        self.rows = [p2p.PeerBuffers(max(self.splits) * w * world, device, group) for _ in range(2)]
+
+    def run(self, x, to_rows, n, fwd):
+        from . import p2p
+        k = 0 if fwd else 1
+        if to_rows:
+            buf = self.cols[k]
+            buf.local[: x.numel()].view_as(x).copy_(x)
+            p2p.rank_barrier(self.group)
+            return p2p.cols_to_rows(buf, n, self.w, self.splits)
+        buf = self.rows[k]
+        buf.local[: x.numel()].view_as(x).copy_(x)
+        p2p.rank_barrier(self.group)
+        return p2p.rows_to_cols(buf, n, self.w, self.splits)
+
+
 class _SumGradAcrossRanks(Function):
     """identity on a (replicated) parameter; its gradient is summed over the ranks' row shards"""
 
@@ -340,12 +382,16 @@ class TransposedShardedGIKANLayer(nn.Module):
     """``GIKANLayer`` with the aggregation on column shards and the KAN chain on row shards (see the module
     docstring).  Same interface as ``ShardedGIKANLayer``: column shard in, column shard out."""
 
-    def __init__(self, conv: GIKANLayer, group=None, local_ops=None, sync_in_backward="flat"):
+    def __init__(self, conv: GIKANLayer, group=None, local_ops=None, sync_in_backward="flat", comm: str = "rccl"):
         """``sync_in_backward="flat"`` (default): ONE flat all-reduce over all parameter gradients, queued as an
         end-of-backward callback of the autograd engine -- transparent to the caller.  ``True``: every parameter's
         gradient is all-reduced inside autograd (one small collective per parameter tensor).  ``False``: gradients stay
         rank-local until the caller runs ``sync_gradients()`` (what ``bench.py`` times explicitly)."""
         super().__init__()
+        if comm not in ("rccl", "p2p"):
+            raise ValueError("comm must be 'rccl' or 'p2p'")
+        self.comm = comm                  # "p2p": the two all-to-alls as direct pulls over hipIpc-mapped peer buffers (_P2PTranspose)
+        self._xch = {}
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -405,7 +451,13 @@ class TransposedShardedGIKANLayer(nn.Module):
     def forward(self, x_shard: torch.Tensor, graph) -> torch.Tensor:
         n = x_shard.size(0)
         h = self.local_ops.aggregate_sum(x_shard, graph, self_scale=1.0 + self.eps)
-        h = _ColsToRows.apply(h, self.group)
+        xin = xout = None
+        if self.comm == "p2p":                    # (the layer's input and output widths may differ: one exchange object each)
+            for key, width in (("in", h.size(1)), ("out", self.layers[-1].out_features // self.world)):
+                if (key, n, width) not in self._xch:
+                    self._xch[(key, n, width)] = _P2PTransposeExchange(n, width, h.device, self.group)
+            xin, xout = self._xch[("in", n, h.size(1))], self._xch[("out", n, self.layers[-1].out_features // self.world)]
+        h = _P2PTranspose.apply(h, xin, True, n) if xin is not None else _ColsToRows.apply(h, self.group)
         for layer in self.layers:
             sc = layer.spline_scaler if layer.enable_standalone_scale_spline else None
             g = self.group
@@ -414,7 +466,7 @@ class TransposedShardedGIKANLayer(nn.Module):
                                           None if sc is None else wrap(sc),
                                           layer.grid[0].contiguous(), layer.grid_size, layer.spline_order,
                                           layer.precision)
-        out = _RowsToCols.apply(h, n, self.group)
+        out = _P2PTranspose.apply(h, xout, False, n) if xout is not None else _RowsToCols.apply(h, n, self.group)
         if self.sync_in_backward == "flat" and torch.is_grad_enabled():
             out = _QueueFlatSync.apply(out, self)
         return out

@@ -144,7 +144,7 @@ def _gpu_worker(rank, world, port, out_dir):
 
         # comm="p2p": hipIpc peer-mapped exchange buffers + kagnn_p2p_reduce_scatter / _all_gather (two processes, one GPU)
         for cls, kw in ((ShardedGIKANLayer, {}), (ShardedGIKANLayer, {"chunks": 3}), (ShardedGIKANLayer, {"comm": "p2p"}),
-                        (TransposedShardedGIKANLayer, {})):
+                        (TransposedShardedGIKANLayer, {}), (TransposedShardedGIKANLayer, {"comm": "p2p"})):
             sconv = cls(conv, None, **kw).to(dev)
             xs = sconv.shard_columns(x).requires_grad_(True)
             y = sconv(xs, graph)
