@@ -797,7 +797,8 @@ template <int NTO> struct DwRaw { float x[8]; float g[NTO][8]; float mu[8], rs[8
 
 // RS (1, 2, 4): row sub-ranges per feature tile -- narrow layers with 4 / RS live tiles, see split_dw_plan (a template
 // parameter: as a runtime value it cost the 64-feature layer 45 %)
-// NTO: 16-wide output tiles per wave.  4 = one wave per SIMD owns 16 features x 64 outputs (144 accumulators).  NTO = 2
+// NTO: 16-wide output tiles per wave.  4 = one wave per SIMD owns 16 features x 64 outputs (144 accumulators); 1..3 serve layers of
+// <= 48 outputs (read-outs) with only the tiles that exist.  As a way to put TWO waves on a SIMD for 64-output layers, NTO = 2
 // (16 x 32 outputs, 72 accumulators, 198 registers: TWO waves per SIMD) was measured in round 3 and is not instantiated: the
 // basis expansion runs twice and the pair gains nothing from sharing the SIMD -- 0.769 vs 0.604 ms per step
 // (profiles/r03_experiments.md)
@@ -1337,8 +1338,14 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
 #define ARGS x, ldx, gy, ldgy, N, in, out, Ck, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb
 #define L(KK) if (sh) kan_split_dw_kernel<KK, true><<<grid, 256, 0, st>>>(ARGS, sh); \
               else kan_split_dw_kernel<KK, false><<<grid, 256, 0, st>>>(ARGS, 0)
+    // narrow OUTPUTS (read-out layers: 40 classes, 1 regression target): only the 16-wide output tiles that exist -- at 64 the
+    // wave split 64 - out columns of gy and ran their MFMAs for nothing (out = 40: 3 tiles instead of 4)
+    const int nto = (!sh && out <= 48) ? cdiv(out, 16) : 4;
 #define LN(KK) if (p.rs == 4) kan_split_dw_kernel<KK, false, 4><<<grid, 256, 0, st>>>(ARGS, 0); \
                else if (p.rs == 2) kan_split_dw_kernel<KK, false, 2><<<grid, 256, 0, st>>>(ARGS, 0); \
+               else if (nto == 3) kan_split_dw_kernel<KK, false, 1, 3><<<grid, 256, 0, st>>>(ARGS, 0); \
+               else if (nto == 2) kan_split_dw_kernel<KK, false, 1, 2><<<grid, 256, 0, st>>>(ARGS, 0); \
+               else if (nto == 1) kan_split_dw_kernel<KK, false, 1, 1><<<grid, 256, 0, st>>>(ARGS, 0); \
                else { L(KK); }
     switch (K) {
         case 0: LN(0); break;
