@@ -899,14 +899,10 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
     // inside ONE iteration; only the raw rows -- direct load destinations -- cross the back edge.  With the expansion at the
     // bottom of the loop (round 2) the 104 fragment registers were loop-carried and the compiler closed every iteration with
     // ~100 v_mov copies into them (16 % of the loop's VALU instructions).
-    DwRaw<NTO> raw;
-    load_raw(raw);
-    int T = chunk_exp(raw);        // running exponent: gy is fed as gy * 2^(10 - T)
-    long n0 = rbeg;
-    while (n0 < rend) {
-        // ---- hot loop: the scale exponent T is FIXED in here, so the accumulators are only ever touched by MFMAs (a
-        // conditional rescale inside the loop makes the compiler copy them around every iteration)
-        for (; n0 < rend; n0 += 32) {
+    int T;                         // running exponent: gy is fed as gy * 2^(10 - T)
+    // one chunk: expansion of `raw`, request of the chunk that will next live in `raw`, MFMAs.  false = the chunk needs a larger
+    // scale (nothing was touched: rescale outside, then redo it)
+    auto step = [&](DwRaw<NTO>& raw) -> bool {
             // raw chunk -> fragments.  x side first (bases of 8 rows of this lane's feature; cubic splines: two rows per
             // packed-fp32 evaluation; SiLU values), so that the gy loads have that arithmetic on top of the MFMA section
             // to arrive
@@ -938,7 +934,7 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
             }
             const bool base32 = __any(!(smx < 60000.0f));   // wave-uniform; also catches NaN / Inf
             split_f16x2(sv, sah, sal);
-            if (chunk_exp(raw) > T) break;                   // wave-uniform, rare: rescale outside, then redo this chunk
+            if (chunk_exp(raw) > T) return false;            // wave-uniform, rare: rescale outside, then redo this chunk
             // gy side, scaled by 2^(10 - T)
             u32x4 bhi[NTO], blo[NTO];      // gy * 2^(10-T), per 16-wide output tile
             const float gs = ldexpf(1.0f, 10 - T);
@@ -988,16 +984,27 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
 #pragma unroll
                 for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(sal, bhi[t], Dh[t]);
             }
-        }
-        if (n0 < rend) {                                     // the pending chunk needs a larger scale: rescale once, exactly
-            const int ex = chunk_exp(raw);
-            const float dn = ldexpf(1.0f, T - ex);
+        return true;
+    };
+    auto rescale = [&](DwRaw<NTO>& raw) {                        // the pending chunk needs a larger scale: rescale once, exactly
+        const int ex = chunk_exp(raw);
+        const float dn = ldexpf(1.0f, T - ex);
 #pragma unroll
-            for (int c = 0; c < kCTmax; ++c)
+        for (int c = 0; c < kCTmax; ++c)
 #pragma unroll
-                for (int t = 0; t < NTO; ++t) D[c][t] *= dn;
-            T = ex;
-        }
+            for (int t = 0; t < NTO; ++t) D[c][t] *= dn;
+        T = ex;
+    };
+    long n0 = rbeg;
+    DwRaw<NTO> raw;
+    load_raw(raw);
+    T = chunk_exp(raw);
+    while (n0 < rend) {
+        // ---- hot loop: the scale exponent T is FIXED in here, so the accumulators are only ever touched by MFMAs (a
+        // conditional rescale inside the loop makes the compiler copy them around every iteration)
+        for (; n0 < rend; n0 += 32)
+            if (!step(raw)) break;
+        if (n0 < rend) rescale(raw);
     }
     // ---- slab write: D rows <-> features 4*kg + reg, cols <-> outputs li
     const float undo = ldexpf(1.0f, T - 20), undo_b = ldexpf(1.0f, T - 14);
