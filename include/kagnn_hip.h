@@ -186,6 +186,20 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t num_rows, const fl
                          float* y, int64_t ldy, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* The same forward on an input given as COLUMN BLOCKS [x_0 | x_1 | ...] held in different buffers: replaces `self.lay_out(torch.cat(l, dim=1))` of the node models (reference
+ * node_classification_clean/models.py:202-203, 256-257) without building the concatenation -- one launch, y written once.
+ * x_parts / part_widths / part_ld are HOST arrays of num_parts device pointers / widths / leading dimensions; pack_fwd is
+ * the pack of the whole layer (in_features = sum of the widths).  Covered: cubic layers of <= 8 coefficients in the split
+ * mode, every block a multiple of 64 columns, <= 512 columns in all, 16-byte aligned rows (leading dimensions: multiples
+ * of 4, <= 7680); kagnn_kan_fwd_parts_ok() says (1 / 0) whether a shape is.
+ * Anything else returns KAGNN_ERR_UNSUPPORTED (concatenate and call kagnn_kan_linear_fwd).                          */
+int kagnn_kan_fwd_parts_ok(const int32_t* part_widths, int32_t num_parts, int32_t in_features, int32_t out_features,
+                           int32_t grid_size, int32_t spline_order, int32_t mode);
+int kagnn_kan_linear_fwd_parts(const float* const* x_parts, const int32_t* part_widths, const int64_t* part_ld,
+                               int32_t num_parts, int64_t num_rows, const float* knots, int32_t in_features, int32_t out_features,
+                               int32_t grid_size, int32_t spline_order, int32_t mode, const void* pack_fwd,
+                               float* y, int64_t ldy, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same forward, which also leaves the COLUMN MOMENTS of y in col_mean[out] (mean over the rows) and
  * col_m2[out] (sum of squared deviations from it): the batch statistics of the BatchNorm1d that follows every
  * convolution (node_classification_clean/models.py:198-200), handed to kagnn_batchnorm_fwd so that it needs no

@@ -50,6 +50,9 @@ _SIGNATURES = {
                                                 POINTER(c_size_t)]),
     "kagnn_kan_linear_fwd": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, c_int32,
                                        c_int32, _P, _P, c_int64, _P, c_size_t, _P]),
+    "kagnn_kan_fwd_parts_ok": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "kagnn_kan_linear_fwd_parts": (c_int32, [_P, _P, _P, c_int32, c_int64, _P, c_int32, c_int32, c_int32, c_int32,
+                                             c_int32, _P, _P, c_int64, _P, c_size_t, _P]),
     "kagnn_kan_fwd_moments_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                                         POINTER(c_size_t)]),
     "kagnn_kan_linear_fwd_moments": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, c_int32,

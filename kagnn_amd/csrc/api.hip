@@ -53,6 +53,8 @@ size_t kan_sparse_pack_fwd_bytes(int in, int out, int C);
 int kan_sparse_pack_fwd(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 size_t kan_sparse_fwd_ws_bytes(long N, int in, int out, int C);
 int kan_sparse_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, float*, float*, hipStream_t);
+bool kan_sparse_fwd_parts_ok(const int*, int, int, int, int, int);
+int kan_sparse_fwd_parts(const float* const*, const int*, const long*, int, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t);
 bool kan_sparse_fwd_moments_ok(long N, int in, int out, int G, int K);
 size_t kan_sparse_fwd_moments_ws_bytes(long N, int out);
 int col_moments(const float*, long, long, int, float*, float*, void*, size_t, hipStream_t);
@@ -272,6 +274,30 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* kn
         return kan_split_fwd(x, ldx, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
     }
     return kan_f32_fwd(x, ldx, N, knots, in, out, G, K, (const float*)pack_fwd, y, ldy, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
+}
+
+// forward on an input given as column blocks [x_0 | x_1 | ...] that live in different buffers: the
+// skip-concat read-out of the node models (reference node_classification_clean/models.py:202 `torch.cat(l, dim=1)` feeding
+// `lay_out`) without building the concatenation, one launch, one write of y.  pack_fwd is the pack of the WHOLE layer.
+int kagnn_kan_fwd_parts_ok(const int32_t* part_widths, int32_t num_parts, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode) {
+    if (!part_widths || check_kan_dims(__func__, in, out, G, K, mode)) return 0;
+    return use_sparse_fwd(in, out, G, K, mode) && kan_sparse_fwd_parts_ok(part_widths, num_parts, in, out, G, K) ? 1 : 0;
+}
+
+int kagnn_kan_linear_fwd_parts(const float* const* x_parts, const int32_t* part_widths, const int64_t* part_ld, int32_t num_parts,
+                               int64_t N, const float* knots, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
+                               const void* pack_fwd, float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_kan_dims(__func__, in, out, G, K, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(x_parts && part_widths && part_ld && num_parts >= 1, "null block table");
+    KAGNN_CHECK_ARG(N >= 0 && ldy >= out, "bad shape");
+    if (!kagnn_kan_fwd_parts_ok(part_widths, num_parts, in, out, G, K, mode))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: blocks not covered (kagnn_kan_fwd_parts_ok): concatenate and call kagnn_kan_linear_fwd", __func__);
+    if (N == 0) return KAGNN_OK;
+    KAGNN_CHECK_ARG(knots && pack_fwd && y, "null array");
+    if (!fits32(N, ldy)) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats", __func__);
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+    return kan_sparse_fwd_parts(x_parts, part_widths, reinterpret_cast<const long*>(part_ld), num_parts, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
 }
 
 // forward + column moments of its output (the statistics of the BatchNorm1d that follows a convolution)

@@ -203,12 +203,18 @@ struct SpAgg {
 };
 __device__ __forceinline__ float4 spagg_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int OT, bool SH, bool MOM, bool NARROW = false, int AGG = -1>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
+// PARTS: the input is the column concatenation of up to 8 row-major blocks that live in different buffers (the skip-concat
+// read-out of the node models: [x | h1 | h2 | ...] is never built).  Every block is a whole number of 64-feature chunks wide,
+// so chunk ch reads from p[ch] with leading dimension ld[ch] (the host resolves the blocks to per-chunk entries).
+struct SpParts { const float* p[8]; int ld[8]; };
+
+template <int OT, bool SH, bool MOM, bool NARROW = false, int AGG = -1, bool PARTS = false>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
 __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g, int nknots,
     const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy, int out,
-    int chunks_per_split, long part_stride, float* __restrict__ mom_partial, SpAgg ag) {
+    int chunks_per_split, long part_stride, float* __restrict__ mom_partial, SpAgg ag, SpParts xp) {
     static_assert(AGG < 0 || (NARROW && !SH && !MOM), "the fused aggregation serves plain narrow layers");
+    static_assert(!PARTS || (!NARROW && !SH && !MOM && AGG < 0), "column blocks: plain wide layers");
     constexpr int NT = 512, CF = kSpCF, BPC = CF / 16, NG = CF / 16, ROWS = (NT / 64) * 32;
     const int HF = NARROW ? sp_hf(in << (SH ? 1 : 0)) : CF / 2;    // features per lane half: CF / 2, or 16 / 8 in narrow layers
     constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 2 * 1024;
@@ -257,6 +263,17 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const bool al4 = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const unsigned ldx4 = (unsigned)ldx * 4u, ldy4 = (unsigned)ldy * 4u;
     auto load8 = [&](long tile0 /* first row of the workgroup's tile: wave-uniform */, int ch, int g, float (&v)[8]) {
+        if constexpr (PARTS) {                            // this chunk's block (scalar selects: ch is wave-uniform)
+            const float* xc = xp.p[0];
+            int ldc = xp.ld[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) { xc = ch == i ? xp.p[i] : xc; ldc = ch == i ? xp.ld[i] : ldc; }
+            const GBuf xb = gbuf_at(xc, N, ldc, CF, tile0);
+            const unsigned ro = (unsigned)(wave * 32 + r) * ((unsigned)ldc * 4u) + kg * HF * 4;
+            gld4_s(xb, ro, (unsigned)(8 * g) * 4u, v);
+            gld4_s(xb, ro, (unsigned)(8 * g) * 4u + 16, v + 4);
+            return;
+        }
         const GBuf xb = gbuf_at(x, N, ldx, in, tile0);
         const unsigned ro = (unsigned)(wave * 32 + r) * ldx4 + kg * HF * 4;   // rows >= N: past the descriptor -> zeros
         const unsigned so = (unsigned)(ch * CF + 8 * g) * 4u;
@@ -780,7 +797,7 @@ static int launch_sparse(const float* x, long ldx, long N, int in, const float* 
         if (p.splits > 1) return fail(KAGNN_ERR_UNSUPPORTED, "%s: no column moments from a launch split over the chunks", "kan_sparse_fwd");
         if (!ws || ws_bytes < (size_t)gx * 3 * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small for the column moments", "kan_sparse_fwd");
-        kan_sparse_fwd_kernel<OT, SH, true, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, ws, SpAgg{});
+        kan_sparse_fwd_kernel<OT, SH, true, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, ws, SpAgg{}, SpParts{});
         KAGNN_LAUNCH_CHECK();
         return moments_finish(ws, gx, out, col_mean, col_m2, st);
     }
@@ -788,13 +805,13 @@ static int launch_sparse(const float* x, long ldx, long N, int in, const float* 
         if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_sparse_fwd");
         kan_sparse_fwd_kernel<OT, SH, false, NARROW><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
-                                                                                p.cps, N * (long)out, nullptr, SpAgg{});
+                                                                                p.cps, N * (long)out, nullptr, SpAgg{}, SpParts{});
         KAGNN_LAUNCH_CHECK();
         sparse_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
         KAGNN_LAUNCH_CHECK();
         return KAGNN_OK;
     }
-    kan_sparse_fwd_kernel<OT, SH, false, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, nullptr, SpAgg{});
+    kan_sparse_fwd_kernel<OT, SH, false, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, nullptr, SpAgg{}, SpParts{});
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -839,7 +856,7 @@ static int launch_sparse_agg(const float* x, long ldx, long N, int in, const flo
         configured = true;
     }
     kan_sparse_fwd_kernel<OT, false, false, true, AGG><<<sp_grid(N), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, 1, y, ldy, out, 1, 0L,
-                                                                                      nullptr, ag);
+                                                                                      nullptr, ag, SpParts{});
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -906,6 +923,70 @@ int kan_sparse_fwd(const float* x, long ldx, long N, const float* knots, int in,
         }
 #undef LL
 #undef L
+        if (rc) return rc;
+    }
+    return KAGNN_OK;
+}
+
+// ------------------------------------------------------------------ input given as column blocks (skip-concat read-out)
+// blocks: cubic layer of <= 8 coefficients, every block a whole number of 64-feature chunks, at most 8 chunks in all,
+// 16-byte aligned rows (leading dimensions: multiples of 4, <= 7680)
+bool kan_sparse_fwd_parts_ok(const int* widths, int nparts, int in, int out, int G, int K) {
+    if (!kan_sparse_fwd_ok(in, out, G, K) || sp_sh(G + K) || nparts < 1 || nparts > 8 || in > 8 * kSpCF) return false;
+    int sum = 0;
+    for (int i = 0; i < nparts; ++i) {
+        if (widths[i] <= 0 || widths[i] % kSpCF) return false;
+        sum += widths[i];
+    }
+    return sum == in;
+}
+
+template <int OT>
+static int launch_sparse_parts(const SpParts& xp, long N, int in, const float* knots, int nknots, const unsigned char* pack,
+                               float* y, long ldy, int out, float* ws, size_t ws_bytes, hipStream_t st) {
+    const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
+    static bool configured = false;
+    if (!configured) {
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, false, false, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const int nchunks = in / kSpCF, gx = sp_grid(N);
+    const SpSplit p = sp_split_plan(N, nchunks);
+    if (p.splits > 1) {
+        if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
+            return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_sparse_fwd_parts");
+        kan_sparse_fwd_kernel<OT, false, false, false, -1, true><<<dim3(gx, p.splits), 512, lds, st>>>(
+            xp.p[0], xp.ld[0], N, in, knots, nknots, pack, nchunks, ws, out, out, p.cps, N * (long)out, nullptr, SpAgg{}, xp);
+        KAGNN_LAUNCH_CHECK();
+        sparse_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
+    kan_sparse_fwd_kernel<OT, false, false, false, -1, true><<<gx, 512, lds, st>>>(xp.p[0], xp.ld[0], N, in, knots, nknots, pack, nchunks, y, ldy,
+                                                                                    out, nchunks, 0L, nullptr, SpAgg{}, xp);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int kan_sparse_fwd_parts(const float* const* parts, const int* widths, const long* lds, int nparts, long N, const float* knots, int in, int out,
+                         int G, int K, const void* pack, float* y, long ldy, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!kan_sparse_fwd_parts_ok(widths, nparts, in, out, G, K))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: blocks not covered (kagnn_kan_fwd_parts_ok)", "kan_sparse_fwd_parts");
+    SpParts xp{};
+    int c = 0;
+    for (int i = 0; i < nparts; ++i) {
+        if (!parts[i] || (reinterpret_cast<uintptr_t>(parts[i]) & 15) || lds[i] % 4 || lds[i] < widths[i] || lds[i] > 7680)
+            return fail(KAGNN_ERR_ARG, "%s: block %d is null, not 16-byte aligned, or its leading dimension is not a multiple of 4 in [width, 7680]", "kan_sparse_fwd_parts", i);
+        for (int k = 0; k < widths[i] / kSpCF; ++k) { xp.p[c] = parts[i] + (long)k * kSpCF; xp.ld[c++] = (int)lds[i]; }
+    }
+    for (; c < 8; ++c) { xp.p[c] = xp.p[0]; xp.ld[c] = xp.ld[0]; }
+    const int nk = G + 2 * K + 1;
+    const size_t stride = sp_blk_bytes(in, in, min(out, kSpOutBlk));
+    for (int b = 0; b * kSpOutBlk < out; ++b) {
+        const int ob = min(kSpOutBlk, out - b * kSpOutBlk), OT = cdiv(ob, 32);
+        const unsigned char* p = static_cast<const unsigned char*>(pack) + b * stride;
+        const int rc = OT == 1 ? launch_sparse_parts<1>(xp, N, in, knots, nk, p, y + b * kSpOutBlk, ldy, ob, static_cast<float*>(ws), ws_bytes, st)
+                               : launch_sparse_parts<2>(xp, N, in, knots, nk, p, y + b * kSpOutBlk, ldy, ob, static_cast<float*>(ws), ws_bytes, st);
         if (rc) return rc;
     }
     return KAGNN_OK;

@@ -858,12 +858,105 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
                               int(spline_order), int(mode), packed, None if out is None else _OutBuffer(out))
 
 
+_PARTS_OK: dict = {}
+_PARTS_ONE_LAUNCH = os.environ.get("KAGNN_PARTS_ONE_LAUNCH", "1") != "0"     # 0: per-block layers summed (kept for A/B)
+
+
+def _parts_one_launch(parts, fout: int, grid_size: int, spline_order: int, mode: int) -> bool:
+    """the column blocks qualify for ``kagnn_kan_linear_fwd_parts`` (one forward launch over all of them)"""
+    p0 = parts[0]
+    if not all(t.is_cuda and t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 4 == 0
+               and t.size(1) <= t.stride(0) <= 7680 and t.size(0) == p0.size(0) and t.device == p0.device and t.data_ptr() % 16 == 0
+               for t in parts):
+        return False
+    widths = tuple(int(t.size(1)) for t in parts)
+    key = (widths, fout, grid_size, spline_order, mode)
+    hit = _PARTS_OK.get(key)
+    if hit is None:
+        hit = bool(getattr(_lib.load(), "kagnn_kan_fwd_parts_ok")((ctypes.c_int32 * len(widths))(*widths), len(widths), sum(widths),
+                                                                    fout, grid_size, spline_order, mode))
+        _PARTS_OK[key] = hit
+    return hit
+
+
+class _KANLinearPartsFn(Function):
+    """``KANLinear`` on ``[x_0 | x_1 | ...]`` as ONE tape node: the forward is a single launch that reads every block where
+    it lies (``kagnn_kan_linear_fwd_parts``: no concatenation, no partial outputs to add up); the backward runs the
+    input-gradient kernel per block that needs it and the weight-gradient kernel per block, and assembles the parameter
+    gradients with one concatenation each."""
+
+    @staticmethod
+    @_on_operand_device
+    def forward(ctx, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, *parts):
+        _need_cuda(base_weight, spline_weight, spline_scaler, knots, *parts)
+        n, fout = parts[0].size(0), spline_weight.size(0)
+        widths = [int(t.size(1)) for t in parts]
+        fin = sum(widths)
+        bw, sw = base_weight.contiguous(), spline_weight.contiguous()
+        sc = None if spline_scaler is None else spline_scaler.contiguous()
+        fb, db = _sizes("kagnn_kan_pack_bytes", fin, fout, grid_size, spline_order, mode, outputs=2)
+        pack_f, pack_d = _ws(fb, bw.device), _ws(db, bw.device)
+        _call("kagnn_kan_pack", _ptr(bw), _ptr(sw), _ptr(sc), fin, fout, grid_size, spline_order, mode, _ptr(pack_f), _ptr(pack_d),
+              _stream())
+        y = torch.empty((n, fout), dtype=torch.float32, device=bw.device)
+        wb = _sizes("kagnn_kan_fwd_workspace_bytes", n, fin, fout, grid_size, spline_order, mode)
+        ws = _ws(wb, bw.device) if wb else None
+        _call("kagnn_kan_linear_fwd_parts", _ptr_array(parts), (ctypes.c_int32 * len(widths))(*widths),
+              (ctypes.c_int64 * len(widths))(*[_ld(t) for t in parts]), len(widths), n,
+              _ptr(knots), fin, fout, grid_size, spline_order, mode, _ptr(pack_f), _ptr(y), fout, _ptr(ws), wb, _stream())
+        ctx.save_for_backward(bw, sw, sc, knots, *parts)
+        ctx.dims = (widths, fout, grid_size, spline_order, mode)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    @_on_operand_device
+    def backward(ctx, gy):
+        bw, sw, sc, knots, *parts = ctx.saved_tensors
+        widths, fout, G, K, mode = ctx.dims
+        gy = _rows(gy)
+        want_w = any(ctx.needs_input_grad[0:3])
+        gxs, gbws, gsws, gscs, f0 = [], [], [], [], 0
+        for i, part in enumerate(parts):
+            f1 = f0 + widths[i]
+            want_x = ctx.needs_input_grad[7 + i]
+            bwp = swp = scp = None
+            if want_x or want_w:
+                bwp, swp = bw[:, f0:f1].contiguous(), sw[:, f0:f1].contiguous()
+                scp = None if sc is None else sc[:, f0:f1].contiguous()
+            gx = None
+            if want_x:
+                fb, db = _sizes("kagnn_kan_pack_bytes", widths[i], fout, G, K, mode, outputs=2)
+                pack_f, pack_d = _ws(fb, part.device), _ws(db, part.device)
+                _call("kagnn_kan_pack", _ptr(bwp), _ptr(swp), _ptr(scp), widths[i], fout, G, K, mode, _ptr(pack_f), _ptr(pack_d),
+                      _stream())
+                gx = _kan_bwd_input_raw(part, gy, knots, pack_d, widths[i], fout, G, K, mode)
+            gxs.append(gx)
+            if want_w:
+                gbw, gsw, gsc = _kan_bwd_weight_raw(part, gy, knots, swp, scp, widths[i], fout, G, K, mode, True)
+                gbws.append(gbw); gsws.append(gsw); gscs.append(gsc)
+            f0 = f1
+        gbw = torch.cat(gbws, dim=1) if want_w else None
+        gsw = torch.cat(gsws, dim=1) if want_w else None
+        gsc = torch.cat(gscs, dim=1) if want_w and sc is not None else None
+        return (gbw, gsw, gsc, None, None, None, None, *gxs)
+
+
 def kan_linear_parts(parts, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
                      mode: Optional[int] = None) -> torch.Tensor:
     """``kan_linear`` on the column-concatenation of ``parts`` without building it: both branches of the layer are
     sums over input features, so the output is the sum of the layer restricted to each part's columns of the
     weights.  For the skip-concat read-out of the node models this saves the concatenation, and -- in the backward --
-    the strided gradient slices that had to be copied contiguous for every branch."""
+    the strided gradient slices that had to be copied contiguous for every branch.  Blocks the forward kernel can read
+    in place (``kagnn_kan_fwd_parts_ok``) run as ONE launch and one tape node; anything else is the sum of per-block
+    layers."""
+    parts = list(parts)
+    if sum(int(t.size(1)) for t in parts) != base_weight.size(1):
+        raise AssertionError("parts do not add up to in_features")
+    m = default_precision() if mode is None else int(mode)
+    if (_PARTS_ONE_LAUNCH and m == PREC_SPLIT and knots.dim() == 1 and len(parts) > 1 and not torch.compiler.is_compiling()
+            and _parts_one_launch(parts, spline_weight.size(0), int(grid_size), int(spline_order), m)):
+        return _KANLinearPartsFn.apply(base_weight, spline_weight, spline_scaler, knots, int(grid_size), int(spline_order), m, *parts)
     y, f0 = None, 0
     for part in parts:
         f1 = f0 + part.size(1)
@@ -871,8 +964,6 @@ def kan_linear_parts(parts, base_weight, spline_weight, spline_scaler, knots, gr
         out = kan_linear(part, base_weight[:, f0:f1], spline_weight[:, f0:f1], sc, knots, grid_size, spline_order, mode)
         y = out if y is None else y + out
         f0 = f1
-    if f0 != base_weight.size(1):
-        raise AssertionError("parts do not add up to in_features")
     return y
 
 

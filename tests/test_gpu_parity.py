@@ -936,6 +936,65 @@ def test_softmax_cross_entropy_strided_and_bad_label():
     assert torch.isnan(ops.softmax_cross_entropy(z[:, 3:13], y))
 
 
+@pytest.mark.parametrize("widths,out,n", [([64, 64, 64, 64], 40, 3000), ([128, 64, 64], 40, 777), ([64, 128], 70, 1500),
+                                          ([64] * 8, 16, 300), ([64, 64], 8, 90)])
+def test_kanlinear_forward_parts_one_launch_is_the_forward_of_the_concat(widths, out, n):
+    """blocks of whole 64-feature chunks: ONE forward launch reads them in place (kagnn_kan_linear_fwd_parts) -- the same
+    chunks in the same order as the forward of the concatenation, so y is bit-identical; one tape node, gradients per block"""
+    torch.manual_seed(33)
+    layer = kagnn_amd.KANLinear(sum(widths), out, grid_size=5, spline_order=3).to(DEV)
+    parts = [(torch.randn(n, w, device=DEV) * 0.6).requires_grad_(i > 0) for i, w in enumerate(widths)]
+    assert ops._parts_one_launch(parts, out, 5, 3, ops.PREC_SPLIT)
+    gy = torch.randn(n, out, device=DEV)
+    y = layer.forward_parts(parts)
+    assert type(y.grad_fn).__name__ == "_KANLinearPartsFnBackward"
+    y.backward(gy)
+    got = {k: p.grad.clone() for k, p in layer.named_parameters()}
+    got_x = [p.grad for p in parts]
+    assert got_x[0] is None
+    layer.zero_grad()
+    whole = torch.cat([p.detach() for p in parts], dim=1).requires_grad_(True)
+    want = layer(whole)
+    want.backward(gy)
+    assert torch.equal(y, want)
+    f0 = 0
+    for p, gx in zip(parts, got_x):
+        if gx is not None:
+            assert_close(gx, whole.grad[:, f0:f0 + p.size(1)], tol=2e-6, what="gx block")
+        f0 += p.size(1)
+    for k, p in layer.named_parameters():
+        assert_close(got[k], p.grad, tol=2e-6, what=k)
+    # blocks that are column slices of a wider buffer (shared leading dimension)
+    buf = torch.randn(n, sum(widths) + 64, device=DEV) * 0.6
+    views, f0 = [], 0
+    for w in widths:
+        views.append(buf[:, f0:f0 + w])
+        f0 += w
+    assert torch.equal(layer.forward_parts(views), layer(buf[:, :f0].contiguous()))
+    # a block the kernel cannot read in place (width not a multiple of 64): the per-block sum, as before
+    odd = [torch.randn(n, 40, device=DEV), torch.randn(n, sum(widths) - 40, device=DEV)]
+    assert not ops._parts_one_launch(odd, out, 5, 3, ops.PREC_SPLIT)
+    assert_close(layer.forward_parts(odd), layer(torch.cat(odd, dim=1)), tol=2e-6, what="odd blocks")
+
+
+def test_kan_linear_fwd_parts_entry_point_refuses_what_it_does_not_cover():
+    import ctypes
+    from kagnn_amd import _lib
+    lib = _lib.load()
+    w = (ctypes.c_int32 * 2)(64, 40)
+    assert lib.kagnn_kan_fwd_parts_ok(w, 2, 104, 10, 5, 3, ops.PREC_SPLIT) == 0
+    w = (ctypes.c_int32 * 2)(64, 64)
+    assert lib.kagnn_kan_fwd_parts_ok(w, 2, 128, 10, 5, 3, ops.PREC_SPLIT) == 1
+    assert lib.kagnn_kan_fwd_parts_ok(w, 2, 128, 10, 5, 3, ops.PREC_FP32) == 0        # exact-fp32 mode: concatenate
+    assert lib.kagnn_kan_fwd_parts_ok(w, 2, 128, 10, 9, 3, ops.PREC_SPLIT) == 0        # > 8 coefficients
+    assert lib.kagnn_kan_fwd_parts_ok(w, 2, 192, 10, 5, 3, ops.PREC_SPLIT) == 0        # widths do not add up
+    x = torch.randn(10, 64, device=DEV)
+    ptrs = (ctypes.c_void_p * 2)(x.data_ptr(), x.data_ptr())
+    ld = (ctypes.c_int64 * 2)(64, 64)
+    rc = lib.kagnn_kan_linear_fwd_parts(ptrs, w, ld, 2, 10, None, 128, 10, 9, 3, ops.PREC_SPLIT, None, None, 10, None, 0, None)
+    assert rc == -3                                  # KAGNN_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
 def test_kanlinear_forward_parts_equals_forward_of_concat(mode):
     """the read-out of the node models on large graphs: KANLinear over [x | h1 | h2] without concatenating"""

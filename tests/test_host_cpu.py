@@ -222,7 +222,8 @@ def test_hot_path_kernels_do_not_spill_registers():
     report = kr.hot_path_report(rows)
     names = [r[0] for r in report]
     # the gate really covers the kernels bench.py times (a renamed kernel must not silently drop out of it)
-    for must in ("kan_sparse_fwd_kernel<2,false,false,false,-1>", "kan_sparse_fwd_kernel<2,false,true,false,-1>", "kan_sparse_fwd_kernel<2,false,false,true,8>",
+    for must in ("kan_sparse_fwd_kernel<2,false,false,false,-1,false>", "kan_sparse_fwd_kernel<2,false,true,false,-1,false>", "kan_sparse_fwd_kernel<2,false,false,true,8,false>",
+                 "kan_sparse_fwd_kernel<2,false,false,false,-1,true>",
                  "kan_split_dw_kernel<3,false,1,4>", "kan_split_dx_kernel<3,2,false,1,false>", "kan_split_dw_w2_kernel<3,1>",
                  "kan_split_dx_w2_kernel<4,3>", "kan_split_dw_kernel<0,false,1,4>", "agg_rows_v4_kernel<16>"):
         assert must in names, f"{must} is not covered by the spill gate: {sorted(names)[:5]}..."

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "kagnn_amd", "csrc")
 KERNELS = [
     # (source, mangled-name prefix, label, scalars per lane and loop iteration, what one iteration covers)
-    ("kan_sparse_fwd.hip", "_ZN5kagnn21kan_sparse_fwd_kernelILi2ELb0ELb0ELb0ELin1E", "forward  kan_sparse_fwd_kernel<2,false,false,false>", 8 * 4,
+    ("kan_sparse_fwd.hip", "_ZN5kagnn21kan_sparse_fwd_kernelILi2ELb0ELb0ELb0ELin1ELb0E", "forward  kan_sparse_fwd_kernel<2,false,false,false>", 8 * 4,
      "one row tile: 4 groups x 8 scalars per lane (32 rows x 64 features per wave), 64 outputs"),
     ("kan_split_bwd.hip", "_ZN5kagnn19kan_split_dx_kernelILi3ELi2ELb0ELi1ELb0E", "dX       kan_split_dx_kernel<3,2,false,1,false>", 8,
      "one (row tile, 16-feature tile): 8 scalars per lane (32 rows x 16 features per wave), 64 outputs"),
