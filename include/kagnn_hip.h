@@ -98,6 +98,18 @@ int kagnn_aggregate_sum(const float* x, int64_t ldx, float* out, int64_t ldo,
                         int32_t skip_self_loops,
                         const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* out = <the aggregation above> + addend (fp32 [num_nodes, num_feat], leading dimension ld_addend; NULL = none), added
+ * last, in the kernel's epilogue: where the tape would otherwise sum two gradients of one activation in a pass of its own
+ * (the skip-concat models: the read-out's gradient of h_l and the next convolution's -- reference
+ * node_classification_clean/models.py:196-202).  Bit-identical to kagnn_aggregate_sum followed by the addition.        */
+int kagnn_aggregate_sum_add(const float* x, int64_t ldx, float* out, int64_t ldo,
+                            const int32_t* rowptr, const int32_t* col, const float* edge_weight,
+                            int64_t num_nodes, int32_t num_feat, float self_scale,
+                            const float* in_scale, const float* out_scale, const float* bias,
+                            int32_t skip_self_loops,
+                            const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
+                            const float* addend, int64_t ld_addend,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same aggregation with bf16 GATHER OPERANDS (`KAGNN_ACT=bf16`; BASELINE.json config 2 -- the reference has no
  * reduced-precision path, SURVEY.md 8(d) makes this a build-defined mode): `x` rows are bf16 (leading dimension in
@@ -281,6 +293,17 @@ int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t num_nodes, co
                             int64_t ldgx, int32_t bf16_gather, float* const* g_base_weight,
                             float* const* g_spline_weight, float* const* g_spline_scaler,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* the same backward with gx = <input gradient> + gx_addend (fp32 [num_nodes, widths[0]]; needs an fp32 gx and
+ * bf16_gather == 0): the addition rides in the transposed aggregation's epilogue (kagnn_aggregate_sum_add)            */
+int kagnn_gin_kan_layer_bwd_add(const float* gy, int64_t ldgy, int64_t num_nodes, const int32_t* rowptr_t,
+                                const int32_t* col_t, const int32_t* hub_seg_t, int64_t num_hub_seg_t,
+                                int32_t hub_threshold, float self_scale, int32_t num_layers, const int32_t* widths,
+                                const float* const* spline_weight, const float* const* spline_scaler,
+                                const float* knots, int32_t grid_size, int32_t spline_order, int32_t mode,
+                                const float* const* acts, const void* const* pack_dx, void* gx, int32_t gx_dtype,
+                                int64_t ldgx, int32_t bf16_gather, const float* gx_addend, int64_t ld_addend,
+                                float* const* g_base_weight, float* const* g_spline_weight,
+                                float* const* g_spline_scaler, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Adaptive grids.  Replaces the device work of KANLinear.update_grid (ekan.py:164-211) and the dense

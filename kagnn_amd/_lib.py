@@ -31,6 +31,8 @@ _SIGNATURES = {
     "kagnn_aggregate_workspace_bytes": (c_int32, [c_int64, c_int32, POINTER(c_size_t)]),
     "kagnn_aggregate_sum": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int32, c_float,
                                       _P, _P, _P, c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
+    "kagnn_aggregate_sum_add": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int32, c_float,
+                                          _P, _P, _P, c_int32, _P, c_int64, c_int32, _P, c_int64, _P, c_size_t, _P]),
     "kagnn_aggregate_sum_bf16": (c_int32, [_P, c_int64, _P, c_int64, c_int32, _P, _P, _P, c_int64, c_int32, c_float,
                                            _P, _P, _P, c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
     "kagnn_rows_to_bf16": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P]),
@@ -71,6 +73,9 @@ _SIGNATURES = {
     "kagnn_gin_kan_layer_bwd": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, c_int64, c_int32, c_float, c_int32, _P, _P, _P,
                                           _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P, _P, _P,
                                           _P, c_size_t, _P]),
+    "kagnn_gin_kan_layer_bwd_add": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, c_int64, c_int32, c_float, c_int32, _P, _P, _P,
+                                              _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P, c_int64,
+                                              _P, _P, _P, _P, c_size_t, _P]),
     "kagnn_kan_bsplines": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
     "kagnn_kan_grid_refit_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "kagnn_kan_grid_refit": (c_int32, [_P, c_int64, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P,

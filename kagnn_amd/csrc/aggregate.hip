@@ -56,6 +56,10 @@ __global__ __launch_bounds__(256) void agg_rows_v4_kernel(AggArgs a) {
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias) b = ld4(a.bias + c4);
     float4 o = make_float4(fmaf(os, acc.x, b.x), fmaf(os, acc.y, b.y), fmaf(os, acc.z, b.z), fmaf(os, acc.w, b.w));
+    if (a.addend && !hub) {                    // (hub rows: agg_hub_merge_kernel adds it after the segments -- the order of the separate sum)
+        const float4 d = ld4(a.addend + gid * a.lda + c4);
+        o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+    }
     *reinterpret_cast<float4*>(a.out + gid * a.ldo + c4) = o;
 }
 
@@ -102,6 +106,10 @@ __global__ __launch_bounds__(256) void agg_rows_ep_kernel(AggArgs a) {
         if (a.bias) b = ld4(a.bias + c4);
         float4 o = make_float4(fmaf(os, fmaf(sw, xs.x, acc.x), b.x), fmaf(os, fmaf(sw, xs.y, acc.y), b.y),
                                fmaf(os, fmaf(sw, xs.z, acc.z), b.z), fmaf(os, fmaf(sw, xs.w, acc.w), b.w));
+        if (a.addend && !hub) {
+            const float4 d = ld4(a.addend + row * a.lda + c4);
+            o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+        }
         *reinterpret_cast<float4*>(a.out + row * a.ldo + c4) = o;
     }
 }
@@ -168,6 +176,10 @@ __global__ __launch_bounds__(256) void agg_hub_merge_kernel(AggArgs a, const int
         float4* o = reinterpret_cast<float4*>(a.out + (long)row * a.ldo + c4);
         float4 v = *o;
         v.x = fmaf(os, acc.x, v.x); v.y = fmaf(os, acc.y, v.y); v.z = fmaf(os, acc.z, v.z); v.w = fmaf(os, acc.w, v.w);
+        if (a.addend) {
+            const float4 d = ld4(a.addend + (long)row * a.lda + c4);
+            v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+        }
         *o = v;
     }
 }
@@ -184,7 +196,8 @@ __global__ __launch_bounds__(256) void agg_rows_generic_kernel(AggArgs a) {
         acc = fmaf(edge_w(a, e, j, i), a.x[(long)j * a.ldx + f], acc);
     }
     const float os = a.out_scale ? a.out_scale[i] : 1.0f;
-    a.out[i * a.ldo + f] = fmaf(os, acc, a.bias ? a.bias[f] : 0.0f);
+    const float o = fmaf(os, acc, a.bias ? a.bias[f] : 0.0f);
+    a.out[i * a.ldo + f] = a.addend ? o + a.addend[i * a.lda + f] : o;
 }
 
 __global__ void gcn_deg_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, long N,
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256) void segment_bcast_kernel(const float* __restr
 static bool vec4_ok(const AggArgs& a) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return a.F % 4 == 0 && a.F <= 256 && a.ldx % 4 == 0 && a.ldo % 4 == 0 && al(a.x) && al(a.out) &&
-           (!a.bias || al(a.bias));
+           (!a.bias || al(a.bias)) && (!a.addend || (al(a.addend) && a.lda % 4 == 0));
 }
 
 size_t aggregate_ws_bytes(long num_hub_seg, int F) { return (size_t)num_hub_seg * (size_t)((F + 3) & ~3) * sizeof(float); }

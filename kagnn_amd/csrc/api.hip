@@ -129,19 +129,29 @@ int kagnn_gcn_deg_inv_sqrt(const int32_t* rowptr, const int32_t* col, int64_t N,
     return gcn_deg_inv_sqrt(rowptr, col, N, dis, as_stream(stream));
 }
 
+int kagnn_aggregate_sum_add(const float* x, int64_t ldx, float* out, int64_t ldo, const int32_t* rowptr,
+                            const int32_t* col, const float* edge_weight, int64_t N, int32_t F,
+                            float self_scale, const float* in_scale, const float* out_scale,
+                            const float* bias, int32_t skip_self_loops, const int32_t* hub_seg,
+                            int64_t num_hub_seg, int32_t hub_threshold, const float* addend, int64_t ld_addend,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && F >= 1, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (x && out && rowptr), "null array");
+    KAGNN_CHECK_ARG(ldx >= F && ldo >= F && (!addend || ld_addend >= F), "leading dimension smaller than num_feat");
+    KAGNN_CHECK_ARG(x != out, "in-place aggregation is not supported");
+    AggArgs a{x, ldx, out, ldo, rowptr, col, edge_weight, N, F, self_scale, in_scale, out_scale, bias,
+              skip_self_loops, hub_threshold > 0 ? hub_threshold : 0x7fffffff, addend, ld_addend};
+    return aggregate_sum(a, hub_seg, num_hub_seg, static_cast<float*>(workspace), workspace_bytes, as_stream(stream));
+}
+
 int kagnn_aggregate_sum(const float* x, int64_t ldx, float* out, int64_t ldo, const int32_t* rowptr,
                         const int32_t* col, const float* edge_weight, int64_t N, int32_t F,
                         float self_scale, const float* in_scale, const float* out_scale,
                         const float* bias, int32_t skip_self_loops, const int32_t* hub_seg,
                         int64_t num_hub_seg, int32_t hub_threshold, void* workspace, size_t workspace_bytes,
                         void* stream) {
-    KAGNN_CHECK_ARG(N >= 0 && F >= 1, "bad shape");
-    KAGNN_CHECK_ARG(N == 0 || (x && out && rowptr), "null array");
-    KAGNN_CHECK_ARG(ldx >= F && ldo >= F, "leading dimension smaller than num_feat");
-    KAGNN_CHECK_ARG(x != out, "in-place aggregation is not supported");
-    AggArgs a{x, ldx, out, ldo, rowptr, col, edge_weight, N, F, self_scale, in_scale, out_scale, bias,
-              skip_self_loops, hub_threshold > 0 ? hub_threshold : 0x7fffffff};
-    return aggregate_sum(a, hub_seg, num_hub_seg, static_cast<float*>(workspace), workspace_bytes, as_stream(stream));
+    return kagnn_aggregate_sum_add(x, ldx, out, ldo, rowptr, col, edge_weight, N, F, self_scale, in_scale, out_scale, bias,
+                                   skip_self_loops, hub_seg, num_hub_seg, hub_threshold, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
 int kagnn_aggregate_sum_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t out_dtype, const int32_t* rowptr,
@@ -699,14 +709,20 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
     return KAGNN_OK;
 }
 
-int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t N, const int32_t* rowptr_t, const int32_t* col_t,
-                            const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
-                            int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
-                            const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
-                            const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
-                            float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+// gx_addend (optional, fp32 [N, widths[0]]): gx = <the layer's input gradient> + gx_addend, added inside the transposed
+// aggregation's epilogue -- the skip-concat models hand the read-out's gradient of the same activation in here instead of
+// letting the tape sum the two in a pass of its own (reference node_classification_clean/models.py:196-202)
+int kagnn_gin_kan_layer_bwd_add(const float* gy, int64_t ldgy, int64_t N, const int32_t* rowptr_t, const int32_t* col_t,
+                                const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
+                                int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
+                                const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
+                                const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
+                                const float* gx_addend, int64_t ld_addend,
+                                float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
+                                size_t workspace_bytes, void* stream) {
     KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && sw && acts && pack_dx && g_sw, "bad argument");
+    KAGNN_CHECK_ARG(!gx_addend || (gx && gx_dtype == KAGNN_DTYPE_F32 && !bf16_gather && ld_addend >= widths[0]),
+                    "gx_addend needs an fp32 gx and fp32 gather operands");
     size_t need_f = 0, need_b = 0;
     int rc = kagnn_gin_kan_layer_workspace_bytes(N, L, widths, G, K, mode, 0, num_hub_seg_t, &need_f, &need_b);
     if (rc) return rc;
@@ -756,8 +772,20 @@ int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t N, const int3
         return kagnn_aggregate_sum_bf16(src, f0, gx, ldgx, gx_dtype, rowptr_t, col_t, nullptr, N, f0, self_scale, nullptr, nullptr,
                                         nullptr, 0, hub_seg_t, num_hub_seg_t, hub_threshold, ws, hub_b, stream);
     }
-    return kagnn_aggregate_sum(g, ldg, static_cast<float*>(gx), ldgx, rowptr_t, col_t, nullptr, N, f0, self_scale, nullptr,
-                               nullptr, nullptr, 0, hub_seg_t, num_hub_seg_t, hub_threshold, ws, hub_b, stream);
+    return kagnn_aggregate_sum_add(g, ldg, static_cast<float*>(gx), ldgx, rowptr_t, col_t, nullptr, N, f0, self_scale, nullptr,
+                                   nullptr, nullptr, 0, hub_seg_t, num_hub_seg_t, hub_threshold, gx_addend, ld_addend, ws, hub_b, stream);
+}
+
+int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t N, const int32_t* rowptr_t, const int32_t* col_t,
+                            const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
+                            int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
+                            const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
+                            const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
+                            float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    return kagnn_gin_kan_layer_bwd_add(gy, ldgy, N, rowptr_t, col_t, hub_seg_t, num_hub_seg_t, hub_threshold, self_scale, L, widths, sw,
+                                       sc, knots, G, K, mode, acts, pack_dx, gx, gx_dtype, ldgx, bf16_gather, nullptr, 0, g_bw, g_sw,
+                                       g_sc, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -206,6 +206,8 @@ struct AggArgs {
     float self_scale;
     const float* in_scale; const float* out_scale; const float* bias;
     int skip_self; int hub_threshold;
+    const float* addend; long lda;     // optional [N, F] matrix added to the result row by row, LAST (after scale and bias): e.g. a
+                                       // second gradient of the same activation (the skip branch), saving the separate sum pass
 };
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

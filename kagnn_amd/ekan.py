@@ -133,14 +133,14 @@ class KANLinear(nn.Module):
         return ops.kan_linear(x, self.base_weight, self.spline_weight, scaler, self._knots(),
                               self.grid_size, self.spline_order, self.precision, _packed)
 
-    def forward_parts(self, parts) -> torch.Tensor:
+    def forward_parts(self, parts, skip_gradients=None) -> torch.Tensor:
         """``forward(torch.cat(parts, dim=1))`` without the concatenation (``ops.kan_linear_parts``)."""
         knots = self._knots()
         if knots.dim() != 1:                             # adaptive grid: per-feature knot rows, keep it simple
             return self.forward(ops.concat_columns(list(parts)))
         scaler = self.spline_scaler if self.enable_standalone_scale_spline else None
         return ops.kan_linear_parts(parts, self.base_weight, self.spline_weight, scaler, knots, self.grid_size,
-                                    self.spline_order, self.precision)
+                                    self.spline_order, self.precision, skip_gradients)
 
     # ------------------------------------------------------------------ not on the KAGNN path
     def b_splines(self, x: torch.Tensor) -> torch.Tensor:

@@ -60,6 +60,7 @@ class FKANLayer(FastKANLayer):
 _SPLIT_READOUT = os.environ.get("KAGNN_SPLIT_READOUT", "1") != "0"
 _FUSED_LAYER = os.environ.get("KAGNN_FUSED_LAYER", "1") != "0"       # GIN + KAN chain as one autograd node (ops.gin_kan_layer)
 _SPLIT_READOUT_MIN_ROWS = 400_000
+_SKIP_GRADIENT = os.environ.get("KAGNN_SKIP_GRADIENT", "1") != "0"     # skip-branch gradient added inside the next convolution's backward
 _FUSED_EPILOGUE = os.environ.get("KAGNN_FUSED_EPILOGUE", "1") != "0"  # conv -> BatchNorm1d -> dropout: statistics + mask fused
 
 
@@ -82,22 +83,26 @@ class _SumAggregateConv(nn.Module):
             self._eps_key = key
         return self._eps_val
 
-    def forward_with_moments(self, x: torch.Tensor, edge_index: torch.Tensor):
+    def forward_with_moments(self, x: torch.Tensor, edge_index: torch.Tensor, want_moments: bool = True, skip_gradient=None):
         """``(y, moments)``: ``self(x, edge_index)`` (hooks included -- the module output stays a tensor) plus the
         [2, out] column moments of y when the fused node produced them in its last forward kernel, else ``None``; for the
-        BatchNorm1d that follows: ``bn(y, moments=...)``"""
-        self.__dict__["_want_moments"] = True
+        BatchNorm1d that follows: ``bn(y, moments=...)``.  ``skip_gradient``: an ``ops.SkipGradient`` the fused node
+        registers with when it can add a second gradient of ``x`` in its own backward (the skip-concat models)."""
+        self.__dict__["_want_moments"] = want_moments
+        self.__dict__["_skip_gradient"] = skip_gradient
         try:
             y = self(x, edge_index)
         finally:
             self.__dict__.pop("_want_moments", None)
+            self.__dict__.pop("_skip_gradient", None)
         return y, self.__dict__.pop("_moments", None)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
         if _FUSED_LAYER and isinstance(self.nn, eKAN) and x.is_cuda and x.size(0) > 0 and not torch.compiler.is_compiling():
             want = self.__dict__.get("_want_moments", False) and x.size(0) > 1
-            y = ops.gin_kan_layer(x, g, 1.0 + self._eps(), self.nn, moments=want)   # one tape node: aggregate + KAN chain
+            y = ops.gin_kan_layer(x, g, 1.0 + self._eps(), self.nn, moments=want,    # one tape node: aggregate + KAN chain
+                                  skip_gradient=self.__dict__.get("_skip_gradient"))
             if y is not None:
                 if want:
                     y, self.__dict__["_moments"] = y
@@ -187,7 +192,7 @@ class GIFASTKANLayer(_SumAggregateConv):
 
 
 # ---------------------------------------------------------------------------------- node models
-def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args):
+def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args, skip_gradient=None):
     """The epilogue ``dropout(bn(conv(x)))`` of every message-passing layer (reference
     ``node_classification_clean/models.py:198-201``, ``graph_regression/models.py:107-119``), fused (SURVEY.md 8(f)
     rank 1): the batch statistics come out of the convolution's last forward kernel (``_SumAggregateConv`` over a KAN
@@ -202,8 +207,8 @@ def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args):
              and (bn.training or not (dropout.training and dropout.p > 0.0)))
     if not fused:
         return dropout(bn(conv(x, g, *conv_args)))
-    if isinstance(conv, _SumAggregateConv) and bn.training and not conv_args:
-        y, mom = conv.forward_with_moments(x, g)
+    if isinstance(conv, _SumAggregateConv) and not conv_args and (bn.training or skip_gradient is not None):
+        y, mom = conv.forward_with_moments(x, g, want_moments=bn.training, skip_gradient=skip_gradient)
     else:
         y, mom = conv(x, g, *conv_args), None
     return bn(y, moments=mom, dropout_p=dropout.p if dropout.training else 0.0)
@@ -240,14 +245,21 @@ class _NodeModel(nn.Module):
         else:
             g = ops.graph_index(edge_index, x.size(0))
         outs = [x if x.dtype == torch.float32 else x.float()]      # (bf16 activation storage: the read-out is fp32)
+        # large graphs: read-out over [x | h1 | ... ] without concatenating (12.2 vs 13.3 ms per step at 1M nodes;
+        # on a 170k-node graph the extra launches cancel the saved copies, so small graphs keep the concat)
+        split = self.skip and _SPLIT_READOUT and isinstance(self.lay_out, KANLinear) and x.size(0) >= _SPLIT_READOUT_MIN_ROWS
+        # h_l feeds the next convolution and the read-out: the read-out's gradient of h_l is added inside the convolution's
+        # backward instead of by the tape (ops.SkipGradient; only between the two fused nodes, everything else sums as usual)
+        carry = split and _SKIP_GRADIENT and x.is_cuda and torch.is_grad_enabled() and not torch.compiler.is_compiling()
+        skips = []
         for conv, bn in zip(self.convs, self.bns):
-            x = conv_bn_dropout(conv, bn, self.dropout, x, g)
+            sk = ops.SkipGradient() if carry and x.requires_grad else None
+            skips.append(sk)
+            x = conv_bn_dropout(conv, bn, self.dropout, x, g, skip_gradient=sk)
             outs.append(x)
         if self.skip:
-            # large graphs: read-out over [x | h1 | ... ] without concatenating (12.2 vs 13.3 ms per step at 1M nodes;
-            # on a 170k-node graph the extra launches cancel the saved copies, so small graphs keep the concat)
-            if _SPLIT_READOUT and isinstance(self.lay_out, KANLinear) and x.size(0) >= _SPLIT_READOUT_MIN_ROWS:
-                return self.lay_out.forward_parts(outs)
+            if split:
+                return self.lay_out.forward_parts(outs, skips + [None] if carry else None)
             x = ops.concat_columns(outs)
         return self.lay_out(x)
 

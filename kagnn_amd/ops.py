@@ -334,13 +334,16 @@ def weighted_gcn_graph(edge_index: torch.Tensor, edge_weight: Optional[torch.Ten
 
 # ======================================================================== aggregation
 def _aggregate_raw(x, g: GraphIndex, transposed, self_scale, edge_weight, in_scale, out_scale, bias,
-                   skip_self, out_dtype=torch.float32) -> torch.Tensor:
+                   skip_self, out_dtype=torch.float32, addend=None) -> torch.Tensor:
     x = _rows(x, allow_bf16=True)
     if x.size(0) != g.num_nodes:
         raise ValueError(f"x has {x.size(0)} rows but the graph has {g.num_nodes} nodes")
     rowptr, col, _, hub, nhub = g.side(transposed)
+    if addend is not None and (x.dtype != torch.float32 or out_dtype != torch.float32):
+        return _aggregate_csr(x, rowptr, col, hub, nhub, g.hub_threshold, self_scale, edge_weight, in_scale, out_scale, bias,
+                              skip_self, out_dtype) + addend.to(out_dtype)
     return _aggregate_csr(x, rowptr, col, hub, nhub, g.hub_threshold, self_scale, edge_weight, in_scale, out_scale, bias,
-                          skip_self, out_dtype)
+                          skip_self, out_dtype, addend)
 
 
 def _bf16_rows_ok(t: torch.Tensor) -> bool:
@@ -358,7 +361,7 @@ def to_bf16_rows(x: torch.Tensor) -> torch.Tensor:
 
 
 def _aggregate_csr(x, rowptr, col, hub, nhub, hub_threshold, self_scale, edge_weight, in_scale, out_scale, bias,
-                   skip_self, out_dtype=torch.float32) -> torch.Tensor:
+                   skip_self, out_dtype=torch.float32, addend=None) -> torch.Tensor:
     n, f = x.shape
     if rowptr.numel() != n + 1:
         raise ValueError(f"x has {n} rows but the graph has {rowptr.numel() - 1} nodes")
@@ -378,10 +381,10 @@ def _aggregate_csr(x, rowptr, col, hub, nhub, hub_threshold, self_scale, edge_we
         return out
     out = torch.empty((n, f), dtype=torch.float32, device=x.device)
     ws = _ws(_sizes("kagnn_aggregate_workspace_bytes", nhub, f), x.device) if nhub else None   # per-segment partial sums
-    _call("kagnn_aggregate_sum", _ptr(x), _ld(x), _ptr(out), f, _ptr(rowptr), _ptr(col),
+    _call("kagnn_aggregate_sum_add", _ptr(x), _ld(x), _ptr(out), f, _ptr(rowptr), _ptr(col),
               _ptr(edge_weight), n, f, float(self_scale), _ptr(in_scale), _ptr(out_scale), _ptr(bias),
-              int(skip_self), _ptr(hub) if nhub else None, nhub, hub_threshold, _ptr(ws),
-              ws.numel() if nhub else 0, _stream())
+              int(skip_self), _ptr(hub) if nhub else None, nhub, hub_threshold, _ptr(addend),
+              _ld(addend) if addend is not None else 0, _ptr(ws), ws.numel() if nhub else 0, _stream())
     return out
 
 
@@ -660,7 +663,7 @@ class _GinKanLayerFn(Function):
 
     @staticmethod
     @_on_operand_device
-    def forward(ctx, x, g, self_scale, knots, grid_size, spline_order, mode, act_bf16, moments, *params):
+    def forward(ctx, x, g, self_scale, knots, grid_size, spline_order, mode, act_bf16, moments, skip_gradient, *params):
         _need_cuda(x, *params)
         nl = len(params) // 3
         layers = [(params[3 * i].contiguous(), params[3 * i + 1].contiguous(), params[3 * i + 2].contiguous()) for i in range(nl)]
@@ -674,6 +677,13 @@ class _GinKanLayerFn(Function):
         n, dev = xg.size(0), xg.device
         widths = [layers[0][1].size(1)] + [sw.size(0) for _, sw, _ in layers]
         ctx.meta = (g, self_scale, grid_size, spline_order, mode, act_bf16, nl, x.dtype, widths)
+        # a second gradient of x that another tape node (the skip-concat read-out) hands over outside the tape: this node's
+        # backward adds it inside the transposed aggregation's epilogue (SkipGradient)
+        ctx.skip_gradient = None
+        if (skip_gradient is not None and x.requires_grad and x.dtype == torch.float32 and xg.dtype == torch.float32
+                and not act_bf16):
+            skip_gradient.consumer = True
+            ctx.skip_gradient = skip_gradient
         if not _LAYER_ABI:
             h = _aggregate_raw(xg, g, False, self_scale, None, None, None, None, False)
             packs = kan_pack_chain(layers, grid_size, spline_order, mode) if nl > 1 else None
@@ -727,20 +737,27 @@ class _GinKanLayerFn(Function):
         gy = _rows(gy)
         need_x = ctx.needs_input_grad[0]
         gx_dtype = torch.bfloat16 if x_dtype == torch.bfloat16 else torch.float32
+        addend = None
+        if ctx.skip_gradient is not None:
+            addend, ctx.skip_gradient.grad = ctx.skip_gradient.grad, None
+            if addend is not None:
+                addend = _rows(addend)
+                if addend.shape != (gy.size(0), widths[0]) or not need_x:
+                    raise RuntimeError("SkipGradient: the gradient handed over does not belong to this convolution's input")
         if not _LAYER_ABI:
             grads = [None] * (3 * nl)
             for i in reversed(range(nl)):
                 h_in, sw, sc, pack_d = t[4 * i:4 * i + 4]
                 fin, fout = widths[i], widths[i + 1]
-                if any(ctx.needs_input_grad[9 + 3 * i:9 + 3 * i + 3]):
+                if any(ctx.needs_input_grad[10 + 3 * i:10 + 3 * i + 3]):
                     grads[3 * i], grads[3 * i + 1], grads[3 * i + 2] = _kan_bwd_weight_raw(h_in, gy, knots, sw, sc, fin, fout,
                                                                                            G, K, mode, True)
                 if i > 0 or need_x:
                     bf16_out = (i == 0 and act_bf16 and mode == PREC_SPLIT and K == 3 and G + K <= 8 and fout <= 128
                                 and fin % 8 == 0 and fin <= 512 and _fits32(h_in, fout))      # the dX variant that stores bf16 rows (<= 512: the bf16 aggregation's limit)
                     gy = _kan_bwd_input_raw(h_in, gy, knots, pack_d, fin, fout, G, K, mode, bf16_out)
-            gx = _aggregate_raw(gy, g, True, self_scale, None, None, None, None, False, out_dtype=gx_dtype) if need_x else None
-            return (gx, None, None, None, None, None, None, None, None, *grads)
+            gx = _aggregate_raw(gy, g, True, self_scale, None, None, None, None, False, out_dtype=gx_dtype, addend=addend) if need_x else None
+            return (gx, None, None, None, None, None, None, None, None, None, *grads)
         n, dev = gy.size(0), gy.device
         if n != g.num_nodes:
             raise ValueError(f"the incoming gradient has {n} rows but the graph has {g.num_nodes} nodes")
@@ -757,18 +774,33 @@ class _GinKanLayerFn(Function):
         _, wb = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), G, K, mode, g.num_hub_seg,
                        g.num_hub_seg_t, outputs=2)
         ws = _ws(wb, dev)
-        _call("kagnn_gin_kan_layer_bwd", _ptr(gy), _ld(gy), n, _ptr(g.rowptr_t), _ptr(g.col_t),
+        _call("kagnn_gin_kan_layer_bwd_add", _ptr(gy), _ld(gy), n, _ptr(g.rowptr_t), _ptr(g.col_t),
               _ptr(g.hub_seg_t) if g.num_hub_seg_t else None, g.num_hub_seg_t, g.hub_threshold, float(self_scale), nl, warr,
               _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, _ptr_array(acts), _ptr_array(pds), _ptr(gx),
               _lib.DTYPE_BF16 if (gx is not None and gx.dtype == torch.bfloat16) else _lib.DTYPE_F32, widths[0],
-              int(bool(act_bf16) and widths[0] % 8 == 0 and widths[0] <= 512), _ptr_array(gbw), _ptr_array(gsw), _ptr_array(gsc), _ptr(ws), ws.numel(),
-              _stream())
+              int(bool(act_bf16) and widths[0] % 8 == 0 and widths[0] <= 512), _ptr(addend), _ld(addend) if addend is not None else 0,
+              _ptr_array(gbw), _ptr_array(gsw), _ptr_array(gsc), _ptr(ws), ws.numel(), _stream())
         if gx is not None and gx.dtype != gx_dtype:
             gx = gx.to(gx_dtype)
         grads = []
         for i in range(nl):
             grads += [gbw[i], gsw[i], gsc[i]]
-        return (gx, None, None, None, None, None, None, None, None, *grads)
+        return (gx, None, None, None, None, None, None, None, None, None, *grads)
+
+
+class SkipGradient:
+    """A gradient that travels from one tape node to another OUTSIDE the tape.  In the skip-concat node models an activation
+    ``h_l`` feeds the next convolution AND the read-out (reference ``node_classification_clean/models.py:196-202``); autograd
+    would materialise both gradients and add them in a pass of its own (0.12 ms per layer at 1M x 64).  Instead: the
+    convolution's fused node registers as the ``consumer`` of this object in its forward; the read-out's node
+    (``_KANLinearPartsFn``) -- whose backward always runs first, the convolution's output feeds it -- leaves its gradient of
+    ``h_l`` in ``grad`` and reports none to the tape; the convolution's backward adds it inside the transposed aggregation's
+    epilogue (``kagnn_gin_kan_layer_bwd_add``).  Bit-identical to the separate sum."""
+    __slots__ = ("grad", "consumer")
+
+    def __init__(self):
+        self.grad = None
+        self.consumer = False
 
 
 _KNOTS_EQUAL: dict = {}
@@ -788,7 +820,7 @@ def _same_knots(layers, knots) -> bool:
 
 
 def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optional[torch.dtype] = None,
-                  moments: bool = False):
+                  moments: bool = False, skip_gradient: Optional["SkipGradient"] = None):
     """``chain(aggregate_sum(x, g, self_scale))`` for a ``kagnn_amd.KAN`` chain as ONE autograd node, or ``None`` when the
     chain is outside what the fused node covers (adaptive grids, > 16 coefficients, mixed precisions): the caller then
     composes the ops.  ``moments=True`` -> ``(y, moments)`` with the [2, out] column moments (mean, M2) of y from the
@@ -812,7 +844,7 @@ def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optiona
     for l in layers:
         params += [l.base_weight, l.spline_weight, l.spline_scaler]
     return _GinKanLayerFn.apply(x, g, float(self_scale), knots, first.grid_size, first.spline_order, int(mode),
-                                act == torch.bfloat16 or x.dtype == torch.bfloat16, bool(moments), *params)
+                                act == torch.bfloat16 or x.dtype == torch.bfloat16, bool(moments), skip_gradient, *params)
 
 
 def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
@@ -887,8 +919,9 @@ class _KANLinearPartsFn(Function):
 
     @staticmethod
     @_on_operand_device
-    def forward(ctx, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, *parts):
+    def forward(ctx, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, skip_gradients, *parts):
         _need_cuda(base_weight, spline_weight, spline_scaler, knots, *parts)
+        ctx.skip_gradients = skip_gradients
         n, fout = parts[0].size(0), spline_weight.size(0)
         widths = [int(t.size(1)) for t in parts]
         fin = sum(widths)
@@ -919,7 +952,7 @@ class _KANLinearPartsFn(Function):
         gxs, gbws, gsws, gscs, f0 = [], [], [], [], 0
         for i, part in enumerate(parts):
             f1 = f0 + widths[i]
-            want_x = ctx.needs_input_grad[7 + i]
+            want_x = ctx.needs_input_grad[8 + i]
             bwp = swp = scp = None
             if want_x or want_w:
                 bwp, swp = bw[:, f0:f1].contiguous(), sw[:, f0:f1].contiguous()
@@ -931,6 +964,9 @@ class _KANLinearPartsFn(Function):
                 _call("kagnn_kan_pack", _ptr(bwp), _ptr(swp), _ptr(scp), widths[i], fout, G, K, mode, _ptr(pack_f), _ptr(pack_d),
                       _stream())
                 gx = _kan_bwd_input_raw(part, gy, knots, pack_d, widths[i], fout, G, K, mode)
+                sk = ctx.skip_gradients[i] if ctx.skip_gradients is not None else None
+                if sk is not None and sk.consumer:         # the convolution that consumed this block adds it in its own backward
+                    sk.grad, gx = gx, None
             gxs.append(gx)
             if want_w:
                 gbw, gsw, gsc = _kan_bwd_weight_raw(part, gy, knots, swp, scp, widths[i], fout, G, K, mode, True)
@@ -939,24 +975,26 @@ class _KANLinearPartsFn(Function):
         gbw = torch.cat(gbws, dim=1) if want_w else None
         gsw = torch.cat(gsws, dim=1) if want_w else None
         gsc = torch.cat(gscs, dim=1) if want_w and sc is not None else None
-        return (gbw, gsw, gsc, None, None, None, None, *gxs)
+        return (gbw, gsw, gsc, None, None, None, None, None, *gxs)
 
 
 def kan_linear_parts(parts, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
-                     mode: Optional[int] = None) -> torch.Tensor:
+                     mode: Optional[int] = None, skip_gradients=None) -> torch.Tensor:
     """``kan_linear`` on the column-concatenation of ``parts`` without building it: both branches of the layer are
     sums over input features, so the output is the sum of the layer restricted to each part's columns of the
     weights.  For the skip-concat read-out of the node models this saves the concatenation, and -- in the backward --
     the strided gradient slices that had to be copied contiguous for every branch.  Blocks the forward kernel can read
     in place (``kagnn_kan_fwd_parts_ok``) run as ONE launch and one tape node; anything else is the sum of per-block
-    layers."""
+    layers.  ``skip_gradients``: per block ``None`` or a ``SkipGradient`` whose consumer adds this layer's gradient of
+    the block itself (only honoured by the one-node form; everywhere else the tape sums as usual)."""
     parts = list(parts)
     if sum(int(t.size(1)) for t in parts) != base_weight.size(1):
         raise AssertionError("parts do not add up to in_features")
     m = default_precision() if mode is None else int(mode)
     if (_PARTS_ONE_LAUNCH and m == PREC_SPLIT and knots.dim() == 1 and len(parts) > 1 and not torch.compiler.is_compiling()
             and _parts_one_launch(parts, spline_weight.size(0), int(grid_size), int(spline_order), m)):
-        return _KANLinearPartsFn.apply(base_weight, spline_weight, spline_scaler, knots, int(grid_size), int(spline_order), m, *parts)
+        sk = None if skip_gradients is None or not any(k is not None and k.consumer for k in skip_gradients) else tuple(skip_gradients)
+        return _KANLinearPartsFn.apply(base_weight, spline_weight, spline_scaler, knots, int(grid_size), int(spline_order), m, sk, *parts)
     y, f0 = None, 0
     for part in parts:
         f1 = f0 + part.size(1)

@@ -350,6 +350,75 @@ def test_modules_on_a_non_current_device():
         ops.kan_linear(x.detach().to(DEV), layer.base_weight, layer.spline_weight, layer.spline_scaler, layer._knots(), 5, 3)
 
 
+# ------------------------------------------------------------------ skip-branch gradient added inside the convolution's backward
+@pytest.mark.parametrize("f", [8, 12, 64, 128, 50])
+def test_aggregation_with_an_addend_is_the_aggregation_plus_the_addend_bitwise(f):
+    """kagnn_aggregate_sum_add: the addend rides in the epilogue (hub rows: after the segment fold) -- exactly the bits of the
+    aggregation followed by a separate addition; edge-slot, row and generic kernels, hubs included"""
+    n, e = 6000, 90000
+    ei = orc.powerlaw_graph(n, e, seed=11)
+    g = ops.GraphIndex(torch.cat([ei, ei.flip(0)], dim=1).to(DEV), n)        # (both directions: hubs on either side)
+    assert g.num_hub_seg > 0 and g.num_hub_seg_t > 0
+    x = torch.randn(n, f, generator=torch.Generator().manual_seed(1)).to(DEV)
+    add = torch.randn(n, f + 4, generator=torch.Generator().manual_seed(2)).to(DEV)[:, :f]       # (a strided addend)
+    for transposed in (False, True):
+        want = ops._aggregate_raw(x, g, transposed, 1.25, None, None, None, None, False) + add
+        got = ops._aggregate_raw(x, g, transposed, 1.25, None, None, None, None, False, addend=add)
+        assert torch.equal(got, want)
+    dis = g.gcn_dis
+    bias = torch.randn(f, device=DEV)
+    want = ops._aggregate_raw(x, g, False, 1.0, None, dis, dis, bias, True) + add
+    got = ops._aggregate_raw(x, g, False, 1.0, None, dis, dis, bias, True, addend=add)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.3])
+def test_skip_gradient_handed_to_the_next_convolution_gives_the_tape_sums_bits(monkeypatch, dropout):
+    """GKAN_Nodes with skip connections on a large-graph code path: the read-out's gradient of h_l travels to conv l+1's
+    backward outside the tape (ops.SkipGradient, added in the transposed aggregation's epilogue).  Same bits as letting
+    autograd sum the two gradients -- every parameter gradient and the input gradient"""
+    from kagnn_amd import models as M
+    monkeypatch.setattr(M, "_SPLIT_READOUT_MIN_ROWS", 0)
+    n, e, f = 9000, 80000, 64
+    g = ops.GraphIndex(orc.powerlaw_graph(n, e, seed=4).to(DEV), n)
+    x = (torch.randn(n, f, generator=torch.Generator().manual_seed(3)) * 0.3).to(DEV)
+    y = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(5)).to(DEV)
+    torch.manual_seed(9)
+    model = kagnn_amd.GKAN_Nodes("gin", 3, f, f, 10, skip=True, grid_size=5, spline_order=3, hidden_layers=2, dropout=dropout).to(DEV)
+    res = []
+    for carry in (True, False):
+        monkeypatch.setattr(M, "_SKIP_GRADIENT", carry)
+        model.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        torch.manual_seed(77)                      # the dropout masks
+        out = model(xr, g)
+        assert type(out.grad_fn).__name__ == "_KANLinearPartsFnBackward"
+        ops.softmax_cross_entropy(out, y).backward()
+        res.append([out.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in model.parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # a second backward through a retained graph hands the gradients over again
+    monkeypatch.setattr(M, "_SKIP_GRADIENT", True)
+    model.zero_grad()
+    out = model(x, g)
+    loss = ops.softmax_cross_entropy(out, y)
+    loss.backward(retain_graph=True)
+    first = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    loss.backward()
+    for a, p in zip(first, model.parameters()):
+        assert torch.equal(a, p.grad)
+    # frozen convolutions: nothing is handed over, the read-out alone trains
+    for c in model.convs:
+        c.requires_grad_(False)
+    for b in model.bns:
+        b.requires_grad_(False)
+    model.zero_grad()
+    ops.softmax_cross_entropy(model(x, g), y).backward()
+    assert all(p.grad is None for c in model.convs for p in c.parameters())
+    assert model.lay_out.spline_weight.grad is not None
+
+
 # ------------------------------------------------------------------ fused layer node + bf16 gather operands (config 2)
 def test_fused_gin_kan_node_equals_the_composed_ops_bitwise(monkeypatch):
     """ops.gin_kan_layer (one tape node: aggregate + KAN chain, chain-packed weights) runs the same kernels in the same
