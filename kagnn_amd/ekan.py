@@ -133,6 +133,12 @@ class KANLinear(nn.Module):
         return ops.kan_linear(x, self.base_weight, self.spline_weight, scaler, self._knots(),
                               self.grid_size, self.spline_order, self.precision, _packed)
 
+    def read_out_blocks_in_one_launch(self, widths) -> bool:
+        """would ``forward_parts`` over fp32 blocks of these widths run as one forward launch (``kagnn_kan_fwd_parts_ok``)?"""
+        mode = self.precision if self.precision is not None else ops.default_precision()
+        return (self._knots().dim() == 1 and mode == ops.PREC_SPLIT and sum(widths) == self.in_features
+                and ops.parts_one_launch_widths_ok(tuple(int(w) for w in widths), self.out_features, self.grid_size, self.spline_order, mode))
+
     def forward_parts(self, parts, skip_gradients=None) -> torch.Tensor:
         """``forward(torch.cat(parts, dim=1))`` without the concatenation (``ops.kan_linear_parts``)."""
         knots = self._knots()

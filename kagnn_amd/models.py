@@ -59,7 +59,10 @@ class FKANLayer(FastKANLayer):
 # ---------------------------------------------------------------------------------- conv bases
 _SPLIT_READOUT = os.environ.get("KAGNN_SPLIT_READOUT", "1") != "0"
 _FUSED_LAYER = os.environ.get("KAGNN_FUSED_LAYER", "1") != "0"       # GIN + KAN chain as one autograd node (ops.gin_kan_layer)
-_SPLIT_READOUT_MIN_ROWS = 400_000
+_SPLIT_READOUT_MIN_ROWS = int(os.environ.get("KAGNN_SPLIT_READOUT_MIN_ROWS", "400000"))
+# ... from this many rows when the blocks run as ONE forward launch and hand their gradients to the convolutions
+# (ops.kan_linear_parts / ops.SkipGradient; crossover measured with tools/split_readout_probe.py: 100k rows even, 170k -6 %)
+_SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH = int(os.environ.get("KAGNN_SPLIT_READOUT_MIN_ROWS", "120000"))
 _SKIP_GRADIENT = os.environ.get("KAGNN_SKIP_GRADIENT", "1") != "0"     # skip-branch gradient added inside the next convolution's backward
 _FUSED_EPILOGUE = os.environ.get("KAGNN_FUSED_EPILOGUE", "1") != "0"  # conv -> BatchNorm1d -> dropout: statistics + mask fused
 
@@ -247,7 +250,10 @@ class _NodeModel(nn.Module):
         outs = [x if x.dtype == torch.float32 else x.float()]      # (bf16 activation storage: the read-out is fp32)
         # large graphs: read-out over [x | h1 | ... ] without concatenating (12.2 vs 13.3 ms per step at 1M nodes;
         # on a 170k-node graph the extra launches cancel the saved copies, so small graphs keep the concat)
-        split = self.skip and _SPLIT_READOUT and isinstance(self.lay_out, KANLinear) and x.size(0) >= _SPLIT_READOUT_MIN_ROWS
+        split = self.skip and _SPLIT_READOUT and isinstance(self.lay_out, KANLinear) and (
+            x.size(0) >= _SPLIT_READOUT_MIN_ROWS
+            or (x.size(0) >= _SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH and x.is_cuda and not torch.compiler.is_compiling()
+                and self.lay_out.read_out_blocks_in_one_launch([x.size(1)] + [bn.num_features for bn in self.bns])))
         # h_l feeds the next convolution and the read-out: the read-out's gradient of h_l is added inside the convolution's
         # backward instead of by the tape (ops.SkipGradient; only between the two fused nodes, everything else sums as usual)
         carry = split and _SKIP_GRADIENT and x.is_cuda and torch.is_grad_enabled() and not torch.compiler.is_compiling()

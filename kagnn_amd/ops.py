@@ -894,14 +894,8 @@ _PARTS_OK: dict = {}
 _PARTS_ONE_LAUNCH = os.environ.get("KAGNN_PARTS_ONE_LAUNCH", "1") != "0"     # 0: per-block layers summed (kept for A/B)
 
 
-def _parts_one_launch(parts, fout: int, grid_size: int, spline_order: int, mode: int) -> bool:
-    """the column blocks qualify for ``kagnn_kan_linear_fwd_parts`` (one forward launch over all of them)"""
-    p0 = parts[0]
-    if not all(t.is_cuda and t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 4 == 0
-               and t.size(1) <= t.stride(0) <= 7680 and t.size(0) == p0.size(0) and t.device == p0.device and t.data_ptr() % 16 == 0
-               for t in parts):
-        return False
-    widths = tuple(int(t.size(1)) for t in parts)
+def parts_one_launch_widths_ok(widths: tuple, fout: int, grid_size: int, spline_order: int, mode: int) -> bool:
+    """block widths ``kagnn_kan_linear_fwd_parts`` covers (asked once per shape)"""
     key = (widths, fout, grid_size, spline_order, mode)
     hit = _PARTS_OK.get(key)
     if hit is None:
@@ -909,6 +903,16 @@ def _parts_one_launch(parts, fout: int, grid_size: int, spline_order: int, mode:
                                                                     fout, grid_size, spline_order, mode))
         _PARTS_OK[key] = hit
     return hit
+
+
+def _parts_one_launch(parts, fout: int, grid_size: int, spline_order: int, mode: int) -> bool:
+    """the column blocks qualify for ``kagnn_kan_linear_fwd_parts`` (one forward launch over all of them)"""
+    p0 = parts[0]
+    if not all(t.is_cuda and t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 4 == 0
+               and t.size(1) <= t.stride(0) <= 7680 and t.size(0) == p0.size(0) and t.device == p0.device and t.data_ptr() % 16 == 0
+               for t in parts):
+        return False
+    return parts_one_launch_widths_ok(tuple(int(t.size(1)) for t in parts), fout, grid_size, spline_order, mode)
 
 
 class _KANLinearPartsFn(Function):
