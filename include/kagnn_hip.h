@@ -305,6 +305,27 @@ int kagnn_gin_kan_layer_bwd_add(const float* gy, int64_t ldgy, int64_t num_nodes
                                 float* const* g_base_weight, float* const* g_spline_weight,
                                 float* const* g_spline_scaler, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The backward of  BatchNorm1d(KAN(aggregate(x)))  in TRAINING mode -- a convolution plus the norm that follows it in every
+ * node model (reference node_classification_clean/models.py:198-200) -- given g = d loss / d (norm output) [N, widths[L]]:
+ * the norm's statistics pass (column sums -> g_bn_weight, g_bn_bias; either may be NULL), then the chain's backward with the
+ * norm's element-wise backward applied INSIDE the last layer's input-gradient kernel (cubic layers of <= 8 coefficients with
+ * 32 / 64 outputs; other shapes run the stand-alone pass), then the transposed aggregation (+ gx_addend).  y = the norm's
+ * input (= the chain's output), bn_mean / bn_rstd = the batch statistics kagnn_batchnorm_fwd saved, bn_weight NULL = no
+ * affine.  Workspace: the backward size of kagnn_gin_kan_layer_workspace_bytes PLUS
+ * kagnn_gin_kan_layer_bwd_bn_workspace_bytes(num_nodes, widths[L]).  Needs num_nodes >= 2.                             */
+int kagnn_gin_kan_layer_bwd_bn_workspace_bytes(int64_t num_nodes, int32_t out_features, size_t* bytes_host);
+int kagnn_gin_kan_layer_bwd_bn(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* bn_weight,
+                               const float* bn_mean, const float* bn_rstd, float* g_bn_weight, float* g_bn_bias,
+                               int64_t num_nodes, const int32_t* rowptr_t, const int32_t* col_t,
+                               const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
+                               int32_t num_layers, const int32_t* widths, const float* const* spline_weight,
+                               const float* const* spline_scaler, const float* knots, int32_t grid_size,
+                               int32_t spline_order, int32_t mode, const float* const* acts,
+                               const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
+                               const float* gx_addend, int64_t ld_addend, float* const* g_base_weight,
+                               float* const* g_spline_weight, float* const* g_spline_scaler, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Adaptive grids.  Replaces the device work of KANLinear.update_grid (ekan.py:164-211) and the dense
  * b_splines (:79-112).  `grid*` are whole grid buffers [in, G+2k+1] with increasing rows.

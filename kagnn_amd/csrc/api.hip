@@ -79,6 +79,9 @@ int gat_att_grad(const float*, long, const float*, const float*, long, int, int,
 size_t bn_ws_bytes(long N, int F);
 int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, const float*, const float*, float, unsigned long long, float*, long, float*, float*, void*, size_t, hipStream_t);
 int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float, unsigned long long, float*, long, float*, float*, void*, size_t, hipStream_t);
+int bn_bwd_stats(const float*, long, const float*, long, long, int, const float*, const float*, const float*, float*, float*, float*, int, void*, size_t, hipStream_t);
+bool kan_split_dx_bn_ok(long, int, int, int, int, const BnBack&, const void*);
+int kan_split_dx_bn(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const BnBack&, hipStream_t);
 int p2p_reduce_scatter(const float* const* parts, int P, int rank, long N, int out, long ld, float* y, long ldy, hipStream_t st);
 int p2p_all_gather(const float* const* shards, int P, long N, int w, long lds, float* g, long ldg, hipStream_t st);
 }  // namespace kagnn
@@ -709,24 +712,28 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
     return KAGNN_OK;
 }
 
-// gx_addend (optional, fp32 [N, widths[0]]): gx = <the layer's input gradient> + gx_addend, added inside the transposed
-// aggregation's epilogue -- the skip-concat models hand the read-out's gradient of the same activation in here instead of
-// letting the tape sum the two in a pass of its own (reference node_classification_clean/models.py:196-202)
-int kagnn_gin_kan_layer_bwd_add(const float* gy, int64_t ldgy, int64_t N, const int32_t* rowptr_t, const int32_t* col_t,
-                                const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
-                                int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
-                                const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
-                                const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
-                                const float* gx_addend, int64_t ld_addend,
-                                float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+// the BatchNorm1d (training mode) that follows the layer, for kagnn_gin_kan_layer_bwd_bn
+struct BnStage { const float* y; int64_t ldy; const float* weight; const float* mean; const float* rstd; float* g_weight; float* g_bias; };
+static size_t bn_stage_bytes(int64_t N, int out) { return al256z(bn_ws_bytes(N, out)) + al256z(4 * (size_t)((out + 63) & ~63) * sizeof(float)); }
+
+static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_t* rowptr_t, const int32_t* col_t,
+                          const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
+                          int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
+                          const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
+                          const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
+                          const float* gx_addend, int64_t ld_addend, const BnStage* bn,
+                          float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
+                          size_t workspace_bytes, void* stream, const char* fn) {
     KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && sw && acts && pack_dx && g_sw, "bad argument");
     KAGNN_CHECK_ARG(!gx_addend || (gx && gx_dtype == KAGNN_DTYPE_F32 && !bf16_gather && ld_addend >= widths[0]),
                     "gx_addend needs an fp32 gx and fp32 gather operands");
     size_t need_f = 0, need_b = 0;
     int rc = kagnn_gin_kan_layer_workspace_bytes(N, L, widths, G, K, mode, 0, num_hub_seg_t, &need_f, &need_b);
     if (rc) return rc;
-    KAGNN_CHECK_ARG(workspace && workspace_bytes >= need_b, "workspace too small (kagnn_gin_kan_layer_workspace_bytes)");
+    const size_t bn_b = bn ? bn_stage_bytes(N, widths[L]) : 0;
+    if (!(workspace && workspace_bytes >= need_b + bn_b))
+        return fail(KAGNN_ERR_ARG, bn ? "%s: workspace too small (kagnn_gin_kan_layer_workspace_bytes + kagnn_gin_kan_layer_bwd_bn_workspace_bytes)"
+                                      : "%s: workspace too small (kagnn_gin_kan_layer_workspace_bytes)", fn);
     if (N == 0) return KAGNN_OK;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     int wmax = 0;
@@ -744,8 +751,47 @@ int kagnn_gin_kan_layer_bwd_add(const float* gy, int64_t ldgy, int64_t N, const 
     long ldg = ldgy;
     int cur = 0;
     bool gh0_bf16 = false;
+    // the normalisation's backward: statistics pass (column sums -> g_weight, g_bias, the per-column table), then EITHER the
+    // last layer's input-gradient kernel applies it to the rows it loads and leaves them for the weight gradient (no pass
+    // of its own), OR -- shapes that kernel does not cover -- the stand-alone pass writes them
+    bool bn_in_dx = false;
+    BnBack bnb{};
+    if (bn) {
+        const int out = widths[L], ldt = (out + 63) & ~63;
+        KAGNN_CHECK_ARG(bn->y && bn->mean && bn->rstd && bn->ldy >= out && N >= 2, "bad BatchNorm stage");
+        unsigned char* bws = ws + need_b;
+        float* tab = reinterpret_cast<float*>(bws + al256z(bn_ws_bytes(N, out)));
+        bnb = BnBack{bn->y, (long)bn->ldy, tab, ldt, reinterpret_cast<float*>(gbuf[1]), (long)out};
+        const int in = widths[L - 1];
+        bn_in_dx = mode == KAGNN_PREC_SPLIT && use_split_dx(in, out, G, K, mode) && out <= wmax && !(L == 1 && (gx == nullptr || bf16_gather)) &&
+                   fits32(N, ldg) && kan_split_dx_bn_ok(ldg, in, out, G, K, bnb, g);
+        if (bn_in_dx) {
+            rc = bn_bwd_stats(bn->y, bn->ldy, g, ldg, N, out, bn->weight, bn->mean, bn->rstd, bn->g_weight, bn->g_bias, tab, ldt, bws,
+                              bn_ws_bytes(N, out), as_stream(stream));
+            if (rc) return rc;
+        } else {
+            // (out may exceed the chain's widest INPUT, which sizes the ping-pong matrices: then the stage's own matrix is needed)
+            if (out > wmax) return fail(KAGNN_ERR_UNSUPPORTED, "%s: a BatchNorm stage wider than every layer input is not covered", fn);
+            rc = bn_bwd(bn->y, bn->ldy, g, ldg, N, out, bn->weight, bn->mean, bn->rstd, 1, 0.0f, 0ULL, reinterpret_cast<float*>(gbuf[1]), out,
+                        bn->g_weight, bn->g_bias, bws, bn_ws_bytes(N, out), as_stream(stream));
+            if (rc) return rc;
+            g = reinterpret_cast<const float*>(gbuf[1]); ldg = out;
+        }
+    }
     for (int l = L - 1; l >= 0; --l) {
         const int in = widths[l], out = widths[l + 1];
+        const bool fused_bn = bn_in_dx && l == L - 1;
+        if (fused_bn) {            // input gradient FIRST: it produces the normalised-backward rows the weight gradient reads
+            rc = kan_split_dx_bn(acts[l], in, g, ldg, N, knots, in, out, G, K, pack_dx[l], reinterpret_cast<float*>(gbuf[0]), in, bnb,
+                                 as_stream(stream));
+            if (rc) return rc;
+            rc = kagnn_kan_linear_bwd_weight(acts[l], in, bnb.gy_out, bnb.ldo, N, knots, in, out, G, K, mode, sw[l], sc ? sc[l] : nullptr,
+                                             g_bw ? g_bw[l] : nullptr, g_sw[l], g_sc ? g_sc[l] : nullptr, ws + hub_b, dw_b, stream);
+            if (rc) return rc;
+            if (l == 0 && gx == nullptr) break;
+            g = reinterpret_cast<const float*>(gbuf[0]); ldg = in; cur = 1;
+            continue;
+        }
         rc = kagnn_kan_linear_bwd_weight(acts[l], in, g, ldg, N, knots, in, out, G, K, mode, sw[l], sc ? sc[l] : nullptr,
                                          g_bw ? g_bw[l] : nullptr, g_sw[l], g_sc ? g_sc[l] : nullptr, ws + hub_b, dw_b, stream);
         if (rc) return rc;
@@ -754,6 +800,7 @@ int kagnn_gin_kan_layer_bwd_add(const float* gy, int64_t ldgy, int64_t N, const 
         const bool b16 = l == 0 && bf16_gather && mode == KAGNN_PREC_SPLIT && K == 3 && G + K <= 8 && out <= 128 && in % 8 == 0 &&
                          in <= 512 /* the bf16 aggregation's row limit (aggregate_bf16_ok): wider first layers keep fp32 rows */ &&
                          use_split_dx(in, out, G, K, mode);
+        // (a stand-alone BatchNorm pass left its rows in gbuf[1]: the first input gradient then writes gbuf[0])
         rc = kagnn_kan_linear_bwd_input(acts[l], in, g, ldg, N, knots, in, out, G, K, mode, pack_dx[l], gbuf[cur], in,
                                         b16 ? KAGNN_DTYPE_BF16 : KAGNN_DTYPE_F32, stream);
         if (rc) return rc;
@@ -774,6 +821,50 @@ int kagnn_gin_kan_layer_bwd_add(const float* gy, int64_t ldgy, int64_t N, const 
     }
     return kagnn_aggregate_sum_add(g, ldg, static_cast<float*>(gx), ldgx, rowptr_t, col_t, nullptr, N, f0, self_scale, nullptr,
                                    nullptr, nullptr, 0, hub_seg_t, num_hub_seg_t, hub_threshold, gx_addend, ld_addend, ws, hub_b, stream);
+}
+
+// gx_addend (optional, fp32 [N, widths[0]]): gx = <the layer's input gradient> + gx_addend, added inside the transposed
+// aggregation's epilogue -- the skip-concat models hand the read-out's gradient of the same activation in here instead of
+// letting the tape sum the two in a pass of its own (reference node_classification_clean/models.py:196-202)
+int kagnn_gin_kan_layer_bwd_add(const float* gy, int64_t ldgy, int64_t N, const int32_t* rowptr_t, const int32_t* col_t,
+                                const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
+                                int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
+                                const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
+                                const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
+                                const float* gx_addend, int64_t ld_addend,
+                                float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return layer_bwd_impl(gy, ldgy, N, rowptr_t, col_t, hub_seg_t, num_hub_seg_t, hub_threshold, self_scale, L, widths, sw, sc, knots, G, K,
+                          mode, acts, pack_dx, gx, gx_dtype, ldgx, bf16_gather, gx_addend, ld_addend, nullptr, g_bw, g_sw, g_sc, workspace,
+                          workspace_bytes, stream, __func__);
+}
+
+// The backward of  BatchNorm1d(KAN(aggregate(x)))  in training mode -- the convolution plus the norm that follows it in
+// every node model (reference node_classification_clean/models.py:198-200) -- given g = d loss / d (norm output):
+// the norm's statistics pass (-> g_bn_weight, g_bn_bias), then the chain's backward with the norm's element-wise backward
+// applied INSIDE the last layer's input-gradient kernel (no normalisation-backward pass over [N, out]), then the transposed
+// aggregation (+ gx_addend).  y = the norm's input (the chain's output), bn_mean / bn_rstd = the statistics its forward saved.
+// Workspace: kagnn_gin_kan_layer_workspace_bytes' backward size + kagnn_gin_kan_layer_bwd_bn_workspace_bytes.
+int kagnn_gin_kan_layer_bwd_bn_workspace_bytes(int64_t N, int32_t out, size_t* bytes) {
+    KAGNN_CHECK_ARG(N >= 0 && out >= 1 && bytes, "bad argument");
+    *bytes = bn_stage_bytes(N, out);
+    return KAGNN_OK;
+}
+
+int kagnn_gin_kan_layer_bwd_bn(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* bn_weight,
+                               const float* bn_mean, const float* bn_rstd, float* g_bn_weight, float* g_bn_bias,
+                               int64_t N, const int32_t* rowptr_t, const int32_t* col_t,
+                               const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
+                               int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
+                               const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
+                               const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
+                               const float* gx_addend, int64_t ld_addend,
+                               float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    const BnStage bn{y, ldy, bn_weight, bn_mean, bn_rstd, g_bn_weight, g_bn_bias};
+    return layer_bwd_impl(g, ldg, N, rowptr_t, col_t, hub_seg_t, num_hub_seg_t, hub_threshold, self_scale, L, widths, sw, sc, knots, G, K,
+                          mode, acts, pack_dx, gx, gx_dtype, ldgx, bf16_gather, gx_addend, ld_addend, &bn, g_bw, g_sw, g_sc, workspace,
+                          workspace_bytes, stream, __func__);
 }
 
 int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t N, const int32_t* rowptr_t, const int32_t* col_t,

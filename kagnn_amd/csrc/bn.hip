@@ -213,14 +213,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                      ((reinterpret_cast<uintptr_t>(gx) & 15) == 0);
     const float inv_n = 1.0f / (float)N;
     for (int c = 4 * cg; c < F; c += 4 * cl) {
-        float m[4], q[4], k[4], a[4], b[4];
+        float m[4], cA[4], cB[4], cC[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ci = min(c + i, F - 1);
-            m[i] = mean[ci]; q[i] = rstd[ci];
-            k[i] = q[i] * (gamma ? gamma[ci] : 1.0f);
-            a[i] = training ? sum_gy[ci] * inv_n : 0.0f;
-            b[i] = training ? sum_gyx[ci] * inv_n : 0.0f;
+            m[i] = mean[ci];
+            if (training) bn_bwd_consts(rstd[ci], gamma ? gamma[ci] : 1.0f, sum_gy[ci], sum_gyx[ci], inv_n, cA[i], cB[i], cC[i]);
+            else { cA[i] = rstd[ci] * (gamma ? gamma[ci] : 1.0f); cB[i] = 0.0f; cC[i] = 0.0f; }
         }
         for (long n = blockIdx.x * (long)rs + slot; n < N; n += (long)gridDim.x * rs) {
             float xv[4], gv[4], o[4];
@@ -233,10 +232,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 for (int i = 0; i < 4; ++i) gv[i] *= kp[i];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = k[i] * (gv[i] - a[i] - (xv[i] - m[i]) * q[i] * b[i]);
+            for (int i = 0; i < 4; ++i) o[i] = bn_bwd_value(gv[i], xv[i], m[i], cA[i], cB[i], cC[i]);   // (the input-gradient kernel's fused form: same expression, common.h)
             st4c(gx + n * ldgx, c, F, vec, o);
         }
     }
+}
+
+// m | A | B | C per column for kernels that apply the backward to rows they load themselves (BnBack, common.h)
+__global__ void bn_bwd_table_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sum_gy, const float* __restrict__ sum_gyx, long N, int F,
+                                    float* __restrict__ tab, int ldt) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= ldt) return;
+    float A = 0.0f, B = 0.0f, C = 0.0f, m = 0.0f;
+    if (f < F) {
+        m = mean[f];
+        bn_bwd_consts(rstd[f], gamma ? gamma[f] : 1.0f, sum_gy[f], sum_gyx[f], 1.0f / (float)N, A, B, C);
+    }
+    tab[f] = m; tab[ldt + f] = A; tab[2 * ldt + f] = B; tab[3 * ldt + f] = C;
 }
 
 // rstd from a variance vector (eval mode: running_var)
@@ -354,6 +367,28 @@ int bn_fwd(const float* x, long ldx, long N, int F, const float* gamma, const fl
     }
     const int grid = (int)min(4096L, max(1L, (long)cdiv(N, s.rs)));
     bn_apply_kernel<<<grid, 256, 0, st>>>(x, ldx, N, F, save_mean, save_rstd, gamma, beta, y, ldy, s.cl, s.rs, dr);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+// the statistics half of the training backward: g_beta = sum g, g_gamma = sum g xhat, and the per-column table for a kernel
+// that applies the backward to the rows itself (kan_split_dx_kernel<..., BNB>); workspace as bn_bwd
+int bn_bwd_stats(const float* x, long ldx, const float* gy, long ldgy, long N, int F, const float* gamma, const float* save_mean,
+                 const float* save_rstd, float* g_gamma, float* g_beta, float* tab, int ldt, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ws_bytes < bn_ws_bytes(N, F)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "bn_bwd_stats");
+    const BnShape s = bn_shape(F);
+    const BnPlan p = bn_plan(N, F);
+    const DropArgs dr = drop_args(0.0f, 0);
+    float* partial = static_cast<float*>(ws);
+    float* sums = reinterpret_cast<float*>(static_cast<char*>(ws) + p.partial_bytes);
+    float* sg = g_beta ? g_beta : sums;
+    float* sgx = g_gamma ? g_gamma : sums + F;
+    const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
+    bn_colsum_kernel<1><<<p.blocks, 256, lds, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, s.cl, s.rs, p.rpb, partial, dr);
+    KAGNN_LAUNCH_CHECK();
+    bn_finish_kernel<1><<<cdiv(F, 32), 1024, 0, st>>>(partial, p.blocks, F, N, nullptr, 0.f, 0.f, sg, sgx, nullptr, nullptr);
+    KAGNN_LAUNCH_CHECK();
+    bn_bwd_table_kernel<<<cdiv(ldt, 256), 256, 0, st>>>(save_mean, save_rstd, gamma, sg, sgx, N, F, tab, ldt);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }

@@ -210,6 +210,30 @@ struct AggArgs {
                                        // second gradient of the same activation (the skip branch), saving the separate sum pass
 };
 
+// BatchNorm1d backward, training mode, as ONE expression per element of the incoming gradient g (y = the norm's input):
+//   gy = k (g - mean(g) - xhat mean(g xhat)),  xhat = (y - m) q,  k = gamma q     ==>  gy = A g + B (y - m) + C
+// with per column  A = k,  B = -k q mean(g xhat),  C = -k mean(g)  (bn_bwd_table_kernel, bn.hip).  The deviation y - m is
+// formed first, as the stand-alone pass always did (near-constant columns: |m| >> sigma).  Used by bn_bwd_apply_kernel and by
+// the input-gradient kernel that applies it to the rows it loads (kan_split_dx_kernel<..., BNB>): same bits either way.
+struct BnBack {
+    const float* y; long ldy;          // the norm's input (= the layer's output), [N, out]
+    const float* tab; int ldt;         // [4][ldt]: m | A | B | C per column
+    float* gy_out; long ldo;           // the transformed rows, for the weight-gradient kernel that runs next
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ float bn_bwd_value(float g, float y, float m, float A, float B, float C) {
+    return __builtin_fmaf(A, g, __builtin_fmaf(B, __fsub_rn(y, m), C));
+}
+// the three per-column constants from the norm's saved statistics and the two column sums of its backward
+__device__ __forceinline__ void bn_bwd_consts(float q /* rstd */, float gamma, float sum_g, float sum_gxhat, float inv_n, float& A,
+                                              float& B, float& C) {
+    const float k = __fmul_rn(q, gamma);
+    A = k;
+    B = -__fmul_rn(__fmul_rn(k, q), __fmul_rn(sum_gxhat, inv_n));
+    C = -__fmul_rn(k, __fmul_rn(sum_g, inv_n));
+}
+#endif
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace kagnn

@@ -117,13 +117,17 @@ __device__ __forceinline__ float barrel_dot(const float (&d)[8], int m, const fl
 //   PP == 2: the workgroup's waves 4..7 (the SIMD partners of waves 0..3) run one phase behind, held there by one
 //            s_barrier per phase: a SIMD always has one wave on the matrix pipe and one on the VALU
 //            (MI355X_MICROARCH.md, "Two waves per SIMD").
-template <int K, int Q2, bool GEN, int PP, bool GX16 = false>
+//   BNB: `gy` is the gradient of the BatchNorm1d that follows the layer; the norm's backward (one affine expression per
+//   element, split_common.h BnBack) is applied to the rows as they are loaded, and the transformed rows are stored for the
+//   weight-gradient kernel -- the stand-alone normalisation-backward pass (read g, read y, write gy) disappears.
+template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false>
 __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
     const unsigned char* __restrict__ pack, int resident, float* __restrict__ gx, long ldgx,
     RbfArgs rb, int sh_arg /* 1: virtual features, two 8-slot windows per input feature */, int acc_arg,
-    int ft_per_block /* feature tiles per blockIdx.y: few-row inputs spread their feature tiles over the chip */) {
+    int ft_per_block /* feature tiles per blockIdx.y: few-row inputs spread their feature tiles over the chip */, BnBack bnb) {
+    static_assert(!BNB || (K == 3 && !GEN && PP == 0 && !GX16), "the fused normalisation backward serves the lean cubic instantiation");
     // GX16: gx rows are bf16 (a compile-time variant of the lean cubic instantiation -- as a run-time flag the 2-byte
     // store path cost every launch 14 %: round 2, profiles/r02_experiments.md)
     const int sh = GEN ? sh_arg : 0;
@@ -191,6 +195,37 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     const int o0 = 32 * q + 8 * kg;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) raw[rt][q][j] = gld_s(gyb, gy_ro + min(o0 + j, out - 1) * 4, so);
+                }
+            }
+        }
+        if constexpr (BNB) {                                 // (the host only launches this with out == 32 * Q2, aligned rows)
+            const GBuf yb = gbuf_at(bnb.y, N, bnb.ldy, out, tile * 256), ob = gbuf_at(bnb.gy_out, N, bnb.ldo, out, tile * 256);
+            const unsigned ldy4 = (unsigned)bnb.ldy * 4u, ldo4 = (unsigned)bnb.ldo * 4u;
+            const unsigned yro = (unsigned)(wave * 32 + li) * ldy4 + kg * 32, oro = (unsigned)(wave * 32 + li) * ldo4 + kg * 32;
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) {
+                float cm[8], cA[8], cB[8], cC[8];
+                const float* t0 = bnb.tab + 32 * q + 8 * kg;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 a = *reinterpret_cast<const float4*>(t0 + 4 * h), b = *reinterpret_cast<const float4*>(t0 + bnb.ldt + 4 * h);
+                    const float4 c = *reinterpret_cast<const float4*>(t0 + 2 * bnb.ldt + 4 * h), d = *reinterpret_cast<const float4*>(t0 + 3 * bnb.ldt + 4 * h);
+                    cm[4 * h] = a.x; cm[4 * h + 1] = a.y; cm[4 * h + 2] = a.z; cm[4 * h + 3] = a.w;
+                    cA[4 * h] = b.x; cA[4 * h + 1] = b.y; cA[4 * h + 2] = b.z; cA[4 * h + 3] = b.w;
+                    cB[4 * h] = c.x; cB[4 * h + 1] = c.y; cB[4 * h + 2] = c.z; cB[4 * h + 3] = c.w;
+                    cC[4 * h] = d.x; cC[4 * h + 1] = d.y; cC[4 * h + 2] = d.z; cC[4 * h + 3] = d.w;
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    float yv[8];
+                    gld4_s(yb, yro, (unsigned)(16 * rt) * ldy4 + 128 * q, yv);
+                    gld4_s(yb, yro, (unsigned)(16 * rt) * ldy4 + 128 * q + 16, yv + 4);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) raw[rt][q][j] = bn_bwd_value(raw[rt][q][j], yv[j], cm[j], cA[j], cB[j], cC[j]);
+                    if (blockIdx.y == 0) {                   // (rows >= N: past the descriptor, dropped)
+                        gst4_s(ob, oro, (unsigned)(16 * rt) * ldo4 + 128 * q, raw[rt][q]);
+                        gst4_s(ob, oro, (unsigned)(16 * rt) * ldo4 + 128 * q + 16, raw[rt][q] + 4);
+                    }
                 }
             }
         }
@@ -410,10 +445,10 @@ static int dx_schedule() {
     return v;
 }
 
-template <int K, int Q2, bool GEN, int PP, bool GX16 = false>
+template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false>
 static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                         const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
-                        const RbfArgs& rb, int accumulate, hipStream_t st) {
+                        const RbfArgs& rb, int accumulate, hipStream_t st, const BnBack& bnb = BnBack{}) {
     const int sh = vshift(C), FT = cdiv(in << sh, 16);
     const size_t ft_bytes = (size_t)kCTmax * Q2 * 2 * 1024;
     const size_t budget = 160 * 1024 - kLdsHdr;
@@ -426,13 +461,13 @@ static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, lo
     const size_t lds = kLdsHdr + (resident ? fpb : 1) * ft_bytes;
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16>,
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
     }
     const dim3 grid((unsigned)min(row_blocks, 256L), (unsigned)splits);
-    kan_split_dx_kernel<K, Q2, GEN, PP, GX16><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
-                                                                      resident ? 1 : 0, gx, ldgx, rb, sh, accumulate, fpb);
+    kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
+                                                                           resident ? 1 : 0, gx, ldgx, rb, sh, accumulate, fpb, bnb);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -725,6 +760,24 @@ int kan_split_dx_any(const float* x, long ldx, const float* gy, long ldgy, long 
         if (rc) return rc;
     }
     return KAGNN_OK;
+}
+
+// the input gradient of a layer whose output feeds a BatchNorm1d, given the gradient `g` of the norm's OUTPUT: the norm's
+// backward is applied to the rows as they are loaded (BnBack: table from bn_bwd_table, y = the norm's input) and the
+// transformed rows are left in bnb.gy_out for the weight-gradient kernel.  Covered: cubic layers of <= 8 coefficients with 32
+// or 64 outputs, 16-byte aligned rows everywhere.
+bool kan_split_dx_bn_ok(long ldg, int in, int out, int G, int K, const BnBack& b, const void* g) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return K == 3 && G + K <= 8 && (out == 32 || out == 64) && !kan_dx_w2_ok(in, out, G + K, K) && ldg % 4 == 0 && b.ldy % 4 == 0 &&
+           b.ldo % 4 == 0 && b.ldt % 4 == 0 && b.ldt >= out && b.ldy <= 7680 && b.ldo <= 7680 && al(g) && al(b.y) && al(b.gy_out) && al(b.tab);
+}
+int kan_split_dx_bn(const float* x, long ldx, const float* g, long ldg, long N, const float* knots, int in, int out, int G, int K,
+                    const void* pack, float* gx, long ldgx, const BnBack& bnb, hipStream_t st) {
+    if (!kan_split_dx_bn_ok(ldg, in, out, G, K, bnb, g)) return fail(KAGNN_ERR_UNSUPPORTED, "%s: shape not covered", "kan_split_dx_bn");
+    const unsigned char* p = static_cast<const unsigned char*>(pack);
+    const int nk = G + 2 * K + 1;
+    if (out == 32) return launch_dx_pp<3, 1, false, 0, false, true>(x, ldx, g, ldg, N, in, out, G + K, knots, nk, p, gx, ldgx, RbfArgs{}, 0, st, bnb);
+    return launch_dx_pp<3, 2, false, 0, false, true>(x, ldx, g, ldg, N, in, out, G + K, knots, nk, p, gx, ldgx, RbfArgs{}, 0, st, bnb);
 }
 
 int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,

@@ -133,6 +133,12 @@ __device__ __forceinline__ void gst_s(const GBuf& b, unsigned voff, unsigned sof
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, voff, soff, 0);
 }
 
+__device__ __forceinline__ void gst4_s(const GBuf& b, unsigned voff, unsigned soff, const float* v) {
+    u32x4 t;
+    t.x = __float_as_uint(v[0]); t.y = __float_as_uint(v[1]); t.z = __float_as_uint(v[2]); t.w = __float_as_uint(v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(t, b.r, voff, soff, 0);
+}
+
 // exponent e with max|W| * 2^-e in [2^9, 2^10)
 __device__ __forceinline__ int scale_exp_from_max(float m) {
     if (!(m > 0.0f)) return 0;

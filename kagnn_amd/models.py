@@ -100,6 +100,21 @@ class _SumAggregateConv(nn.Module):
             self.__dict__.pop("_skip_gradient", None)
         return y, self.__dict__.pop("_moments", None)
 
+    def forward_fused_norm(self, x: torch.Tensor, edge_index: torch.Tensor, bn: BatchNorm1d, skip_gradient=None):
+        """``bn(self(x, edge_index))`` for a training-mode ``BatchNorm1d`` as ONE tape node (``ops._GinKanBnLayerFn``: the
+        norm's element-wise backward runs inside the chain's last input-gradient kernel), or ``None`` when the chain is
+        outside what the node covers -- nothing has been touched then.  Module hooks of the two modules do NOT run on this
+        path (their intermediate tensor is never exposed): ``conv_bn_dropout`` only takes it when neither has any."""
+        if not (_FUSED_LAYER and isinstance(self.nn, eKAN) and x.is_cuda and x.size(0) > 1):
+            return None
+        g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
+
+        def stage():
+            factor, use_running = bn.step()
+            return (bn.weight, bn.bias, bn.running_mean if use_running else None, bn.running_var if use_running else None, factor, bn.eps)
+
+        return ops.gin_kan_layer(x, g, 1.0 + self._eps(), self.nn, skip_gradient=skip_gradient, batch_norm=stage)
+
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
         if _FUSED_LAYER and isinstance(self.nn, eKAN) and x.is_cuda and x.size(0) > 0 and not torch.compiler.is_compiling():
@@ -195,6 +210,16 @@ class GIFASTKANLayer(_SumAggregateConv):
 
 
 # ---------------------------------------------------------------------------------- node models
+_FUSED_NORM_BACKWARD = os.environ.get("KAGNN_FUSED_NORM_BACKWARD", "1") != "0"    # conv + BatchNorm1d as one tape node
+
+
+def _has_hooks(m: nn.Module) -> bool:
+    mod = torch.nn.modules.module
+    return bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None)
+                or mod._global_forward_hooks or mod._global_forward_pre_hooks or mod._global_backward_hooks
+                or getattr(mod, "_global_backward_pre_hooks", None))
+
+
 def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args, skip_gradient=None):
     """The epilogue ``dropout(bn(conv(x)))`` of every message-passing layer (reference
     ``node_classification_clean/models.py:198-201``, ``graph_regression/models.py:107-119``), fused (SURVEY.md 8(f)
@@ -210,6 +235,11 @@ def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args, skip_gradient=None):
              and (bn.training or not (dropout.training and dropout.p > 0.0)))
     if not fused:
         return dropout(bn(conv(x, g, *conv_args)))
+    if (_FUSED_NORM_BACKWARD and isinstance(conv, _SumAggregateConv) and not conv_args and bn.training and bn.affine
+            and not (dropout.training and dropout.p > 0.0) and not _has_hooks(conv) and not _has_hooks(bn)):
+        h = conv.forward_fused_norm(x, g, bn, skip_gradient)      # convolution + norm as one tape node
+        if h is not None:
+            return h
     if isinstance(conv, _SumAggregateConv) and not conv_args and (bn.training or skip_gradient is not None):
         y, mom = conv.forward_with_moments(x, g, want_moments=bn.training, skip_gradient=skip_gradient)
     else:

@@ -652,6 +652,28 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
+def _gin_kan_layer_fwd_raw(xg, g, self_scale, knots, grid_size, spline_order, mode, layers, widths, moments):
+    """``kagnn_gin_kan_layer_fwd``: -> (acts [h0, ..., y], input-gradient packs per layer, column moments of y or None)"""
+    n, dev, nl = xg.size(0), xg.device, len(layers)
+    acts = [torch.empty((n, w), dtype=torch.float32, device=dev) for w in widths]
+    pfs, pds = [], []
+    for i in range(nl):
+        fb, db = _sizes("kagnn_kan_pack_bytes", widths[i], widths[i + 1], grid_size, spline_order, mode, outputs=2)
+        pfs.append(_ws(fb, dev)); pds.append(_ws(db, dev))
+    warr = (ctypes.c_int32 * (nl + 1))(*widths)
+    wf, _ = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), grid_size, spline_order, mode,
+                   g.num_hub_seg, g.num_hub_seg_t, outputs=2)
+    ws = _ws(wf, dev)
+    mom = torch.empty((2, widths[nl]), dtype=torch.float32, device=dev) if moments else None
+    _call("kagnn_gin_kan_layer_fwd", _ptr(xg), _lib.DTYPE_BF16 if xg.dtype == torch.bfloat16 else _lib.DTYPE_F32, _ld(xg), n,
+          _ptr(g.rowptr), _ptr(g.col), _ptr(g.hub_seg) if g.num_hub_seg else None, g.num_hub_seg, g.hub_threshold,
+          float(self_scale), nl, warr, _ptr_array([l[0] for l in layers]), _ptr_array([l[1] for l in layers]),
+          _ptr_array([l[2] for l in layers]), _ptr(knots), grid_size, spline_order, mode, _ptr_array(acts),
+          _ptr_array(pfs), _ptr_array(pds), _ptr(mom[0]) if moments else None, _ptr(mom[1]) if moments else None,
+          _ptr(ws), ws.numel(), _stream())
+    return acts, pds, mom
+
+
 class _GinKanLayerFn(Function):
     """One KAN-GIN convolution -- ``KAN((1 + eps) x_i + sum_{j->i} x_j)`` -- as a single tape node over
     ``kagnn_gin_kan_layer_fwd / _bwd`` (the ``gin_kan_fused_fwd / _bwd`` of SURVEY.md 8(b)): forward = aggregation + ONE
@@ -702,22 +724,7 @@ class _GinKanLayerFn(Function):
                 ctx.mark_non_differentiable(mom)
                 return h, mom
             return h
-        acts = [torch.empty((n, w), dtype=torch.float32, device=dev) for w in widths]
-        pfs, pds = [], []
-        for i in range(nl):
-            fb, db = _sizes("kagnn_kan_pack_bytes", widths[i], widths[i + 1], grid_size, spline_order, mode, outputs=2)
-            pfs.append(_ws(fb, dev)); pds.append(_ws(db, dev))
-        warr = (ctypes.c_int32 * (nl + 1))(*widths)
-        wf, _ = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), grid_size, spline_order, mode,
-                       g.num_hub_seg, g.num_hub_seg_t, outputs=2)
-        ws = _ws(wf, dev)
-        mom = torch.empty((2, widths[nl]), dtype=torch.float32, device=dev) if moments else None
-        _call("kagnn_gin_kan_layer_fwd", _ptr(xg), _lib.DTYPE_BF16 if xg.dtype == torch.bfloat16 else _lib.DTYPE_F32, _ld(xg), n,
-              _ptr(g.rowptr), _ptr(g.col), _ptr(g.hub_seg) if g.num_hub_seg else None, g.num_hub_seg, g.hub_threshold,
-              float(self_scale), nl, warr, _ptr_array([l[0] for l in layers]), _ptr_array([l[1] for l in layers]),
-              _ptr_array([l[2] for l in layers]), _ptr(knots[0]), grid_size, spline_order, mode, _ptr_array(acts),
-              _ptr_array(pfs), _ptr_array(pds), _ptr(mom[0]) if moments else None, _ptr(mom[1]) if moments else None,
-              _ptr(ws), ws.numel(), _stream())
+        acts, pds, mom = _gin_kan_layer_fwd_raw(xg, g, self_scale, knots[0], grid_size, spline_order, mode, layers, widths, moments)
         saved = []
         for i in range(nl):
             saved += [acts[i], layers[i][1], layers[i][2], pds[i]]
@@ -788,6 +795,94 @@ class _GinKanLayerFn(Function):
         return (gx, None, None, None, None, None, None, None, None, None, *grads)
 
 
+class _GinKanBnLayerFn(Function):
+    """``BatchNorm1d(KAN((1 + eps) x_i + sum_j x_j))`` in training mode -- a KAN-GIN convolution and the norm that follows it in
+    every node model (reference ``node_classification_clean/models.py:198-200``) -- as ONE tape node.  Forward:
+    ``kagnn_gin_kan_layer_fwd`` (column moments from the last kernel's epilogue) + the normalising pass.  Backward:
+    ``kagnn_gin_kan_layer_bwd_bn`` -- the norm's statistics pass, then its element-wise backward INSIDE the last layer's
+    input-gradient kernel (the rows are transformed as they are loaded and left for the weight gradient), so the separate
+    normalisation-backward pass over [N, out] is gone.  Same values as the two nodes (``_GinKanLayerFn`` -> ``_BatchNormFn``)."""
+
+    @staticmethod
+    @_on_operand_device
+    def forward(ctx, x, g, self_scale, knots, grid_size, spline_order, mode, act_bf16, skip_gradient, bn_weight, bn_bias,
+                running_mean, running_var, momentum, eps, *params):
+        _need_cuda(x, bn_weight, bn_bias, running_mean, running_var, *params)
+        nl = len(params) // 3
+        layers = [(params[3 * i].contiguous(), params[3 * i + 1].contiguous(), params[3 * i + 2].contiguous()) for i in range(nl)]
+        xg = _rows(x, allow_bf16=True)
+        if xg.size(0) != g.num_nodes:
+            raise ValueError(f"x has {xg.size(0)} rows but the graph has {g.num_nodes} nodes")
+        if act_bf16 and xg.dtype != torch.bfloat16 and xg.size(1) % 8 == 0 and xg.size(1) <= 512:
+            xg = to_bf16_rows(xg)
+        if xg.dtype == torch.bfloat16 and not _bf16_rows_ok(xg):
+            xg = xg.float()
+        widths = [layers[0][1].size(1)] + [sw.size(0) for _, sw, _ in layers]
+        ctx.meta = (g, self_scale, grid_size, spline_order, mode, act_bf16, nl, x.dtype, widths)
+        ctx.skip_gradient = None
+        if (skip_gradient is not None and x.requires_grad and x.dtype == torch.float32 and xg.dtype == torch.float32
+                and not act_bf16):
+            skip_gradient.consumer = True
+            ctx.skip_gradient = skip_gradient
+        acts, pds, mom = _gin_kan_layer_fwd_raw(xg, g, self_scale, knots[0], grid_size, spline_order, mode, layers, widths, True)
+        y = acts[nl]
+        h, mean, rstd = _batchnorm_fwd_raw(y, bn_weight, bn_bias, running_mean, running_var, True, momentum, eps, mom)
+        saved = []
+        for i in range(nl):
+            saved += [acts[i], layers[i][1], layers[i][2], pds[i]]
+        ctx.save_for_backward(*saved, knots[0], y, mean, rstd, bn_weight)
+        ctx.has_bias = bn_bias is not None
+        return h
+
+    @staticmethod
+    @once_differentiable
+    @_on_operand_device
+    def backward(ctx, gh):
+        g, self_scale, G, K, mode, act_bf16, nl, x_dtype, widths = ctx.meta
+        t = ctx.saved_tensors
+        knots, y, mean, rstd, bn_w = t[4 * nl:4 * nl + 5]
+        gh = _rows(gh)
+        need_x = ctx.needs_input_grad[0]
+        gx_dtype = torch.bfloat16 if x_dtype == torch.bfloat16 else torch.float32
+        addend = None
+        if ctx.skip_gradient is not None:
+            addend, ctx.skip_gradient.grad = ctx.skip_gradient.grad, None
+            if addend is not None:
+                addend = _rows(addend)
+                if addend.shape != (gh.size(0), widths[0]) or not need_x:
+                    raise RuntimeError("SkipGradient: the gradient handed over does not belong to this convolution's input")
+        n, dev = gh.size(0), gh.device
+        if n != g.num_nodes:
+            raise ValueError(f"the incoming gradient has {n} rows but the graph has {g.num_nodes} nodes")
+        f32 = dict(dtype=torch.float32, device=dev)
+        acts = [t[4 * i] for i in range(nl)]
+        sws, scs, pds = [t[4 * i + 1] for i in range(nl)], [t[4 * i + 2] for i in range(nl)], [t[4 * i + 3] for i in range(nl)]
+        gbw = [torch.empty((widths[i + 1], widths[i]), **f32) for i in range(nl)]
+        gsw = [torch.empty((widths[i + 1], widths[i], G + K), **f32) for i in range(nl)]
+        gsc = [torch.empty((widths[i + 1], widths[i]), **f32) for i in range(nl)]
+        gbn_w = torch.empty(widths[nl], **f32) if bn_w is not None else None
+        gbn_b = torch.empty(widths[nl], **f32) if ctx.has_bias else None
+        gx = torch.empty((n, widths[0]), dtype=gx_dtype, device=dev) if need_x else None
+        if gx is not None and gx_dtype == torch.bfloat16 and not _bf16_rows_ok(gx):
+            gx = torch.empty((n, widths[0]), **f32)
+        warr = (ctypes.c_int32 * (nl + 1))(*widths)
+        _, wb = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), G, K, mode, g.num_hub_seg,
+                       g.num_hub_seg_t, outputs=2)
+        ws = _ws(wb + _sizes("kagnn_gin_kan_layer_bwd_bn_workspace_bytes", n, widths[nl]), dev)
+        _call("kagnn_gin_kan_layer_bwd_bn", _ptr(gh), _ld(gh), _ptr(y), _ld(y), _ptr(bn_w), _ptr(mean), _ptr(rstd), _ptr(gbn_w), _ptr(gbn_b),
+              n, _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(g.hub_seg_t) if g.num_hub_seg_t else None, g.num_hub_seg_t, g.hub_threshold,
+              float(self_scale), nl, warr, _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, _ptr_array(acts), _ptr_array(pds),
+              _ptr(gx), _lib.DTYPE_BF16 if (gx is not None and gx.dtype == torch.bfloat16) else _lib.DTYPE_F32, widths[0],
+              int(bool(act_bf16) and widths[0] % 8 == 0 and widths[0] <= 512), _ptr(addend), _ld(addend) if addend is not None else 0,
+              _ptr_array(gbw), _ptr_array(gsw), _ptr_array(gsc), _ptr(ws), ws.numel(), _stream())
+        if gx is not None and gx.dtype != gx_dtype:
+            gx = gx.to(gx_dtype)
+        grads = []
+        for i in range(nl):
+            grads += [gbw[i], gsw[i], gsc[i]]
+        return (gx, None, None, None, None, None, None, None, None, gbn_w, gbn_b, None, None, None, None, *grads)
+
+
 class SkipGradient:
     """A gradient that travels from one tape node to another OUTSIDE the tape.  In the skip-concat node models an activation
     ``h_l`` feeds the next convolution AND the read-out (reference ``node_classification_clean/models.py:196-202``); autograd
@@ -820,11 +915,14 @@ def _same_knots(layers, knots) -> bool:
 
 
 def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optional[torch.dtype] = None,
-                  moments: bool = False, skip_gradient: Optional["SkipGradient"] = None):
+                  moments: bool = False, skip_gradient: Optional["SkipGradient"] = None, batch_norm=None):
     """``chain(aggregate_sum(x, g, self_scale))`` for a ``kagnn_amd.KAN`` chain as ONE autograd node, or ``None`` when the
     chain is outside what the fused node covers (adaptive grids, > 16 coefficients, mixed precisions): the caller then
     composes the ops.  ``moments=True`` -> ``(y, moments)`` with the [2, out] column moments (mean, M2) of y from the
-    last forward kernel's epilogue, for ``batch_norm(..., moments=...)``."""
+    last forward kernel's epilogue, for ``batch_norm(..., moments=...)``.
+    ``batch_norm=(weight, bias, running_mean, running_var, momentum, eps)``: the training-mode BatchNorm1d that follows the
+    convolution joins the node (``_GinKanBnLayerFn``: its element-wise backward runs inside the last input-gradient kernel)
+    and the normalised rows are returned."""
     layers = list(chain.layers)
     first = layers[0]
     mode = first.precision if first.precision is not None else default_precision()
@@ -843,6 +941,13 @@ def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optiona
     params = []
     for l in layers:
         params += [l.base_weight, l.spline_weight, l.spline_scaler]
+    if batch_norm is not None:
+        if not _LAYER_ABI or x.size(0) < 2:
+            return None
+        bw_, bb_, rm_, rv_, mom_, eps_ = batch_norm() if callable(batch_norm) else batch_norm      # (callable: evaluated only now that the node is certain -- the caller's per-call bookkeeping)
+        return _GinKanBnLayerFn.apply(x, g, float(self_scale), knots, first.grid_size, first.spline_order, int(mode),
+                                      act == torch.bfloat16 or x.dtype == torch.bfloat16, skip_gradient, bw_, bb_, rm_, rv_,
+                                      float(mom_), float(eps_), *params)
     return _GinKanLayerFn.apply(x, g, float(self_scale), knots, first.grid_size, first.spline_order, int(mode),
                                 act == torch.bfloat16 or x.dtype == torch.bfloat16, bool(moments), skip_gradient, *params)
 

@@ -419,6 +419,64 @@ def test_skip_gradient_handed_to_the_next_convolution_gives_the_tape_sums_bits(m
     assert model.lay_out.spline_weight.grad is not None
 
 
+# ------------------------------------------------------------------ convolution + BatchNorm1d as one tape node
+@pytest.mark.parametrize("f_in,hidden,layers,x_grad", [(64, 64, 2, True), (64, 64, 2, False), (48, 32, 2, True), (64, 64, 1, True),
+                                                        (64, 64, 1, False), (40, 16, 2, True), (64, 128, 2, True), (64, 64, 3, True)])
+def test_conv_and_norm_as_one_tape_node_give_the_two_nodes_bits(monkeypatch, f_in, hidden, layers, x_grad):
+    """models.conv_bn_dropout on a KAN-GIN convolution + training-mode BatchNorm1d: ONE tape node whose backward applies the
+    norm's element-wise backward inside the last input-gradient kernel (kagnn_gin_kan_layer_bwd_bn; 32 / 64 outputs) or runs
+    the stand-alone pass inside the same library call (other widths, single-layer chains without an input gradient).  Same
+    bits as the convolution node followed by the norm node: output, running statistics, every gradient"""
+    from kagnn_amd import models as M
+    n, e = 7001, 60000
+    g = ops.GraphIndex(orc.powerlaw_graph(n, e, seed=6).to(DEV), n)
+    x = (torch.randn(n, f_in, generator=torch.Generator().manual_seed(3)) * 0.4).to(DEV)
+    gh = torch.randn(n, hidden, generator=torch.Generator().manual_seed(4)).to(DEV)
+    import copy
+    torch.manual_seed(5)
+    conv0 = kagnn_amd.GIKANLayer(f_in, hidden, grid_size=5, spline_order=3, hidden_dim=hidden, nb_layers=layers).to(DEV)
+    bn0 = kagnn_amd.BatchNorm1d(hidden).to(DEV)
+    with torch.no_grad():
+        bn0.weight.uniform_(0.5, 1.5); bn0.bias.uniform_(-0.3, 0.3)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(M, "_FUSED_NORM_BACKWARD", fused)
+        conv, bn = copy.deepcopy(conv0), copy.deepcopy(bn0)      # (two constructions from one seed differ in the last bit: the init's least-squares fit)
+        drop = torch.nn.Dropout(0.0)
+        xr = x.clone().requires_grad_(x_grad)
+        h = M.conv_bn_dropout(conv, bn, drop, xr, g)
+        assert type(h.grad_fn).__name__ == ("_GinKanBnLayerFnBackward" if fused else "_BatchNormFnBackward")
+        h.backward(gh)
+        res.append([h.detach().clone(), bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()]
+                   + ([xr.grad.clone()] if x_grad else []) + [p.grad.clone() for p in list(conv.parameters()) + list(bn.parameters())])
+    names = (["h", "running_mean", "running_var", "num_batches_tracked"] + (["gx"] if x_grad else [])
+             + [k for k, _ in conv.named_parameters()] + ["bn.weight", "bn.bias"])
+    for k, a, b in zip(names, *res):
+        assert torch.equal(a, b), f"{k}: max |diff| {(a.float() - b.float()).abs().max().item():.3e} of {b.float().abs().max().item():.3e}"
+
+
+def test_conv_and_norm_node_steps_aside_for_hooks_dropout_and_eval(monkeypatch):
+    from kagnn_amd import models as M
+    n, e, f = 3000, 20000, 64
+    g = ops.GraphIndex(orc.powerlaw_graph(n, e, seed=2).to(DEV), n)
+    x = torch.randn(n, f, device=DEV).requires_grad_(True)
+    conv = kagnn_amd.GIKANLayer(f, f, grid_size=5, spline_order=3, hidden_dim=f, nb_layers=2).to(DEV)
+    bn = kagnn_amd.BatchNorm1d(f).to(DEV)
+    name = lambda h: type(h.grad_fn).__name__
+    assert name(M.conv_bn_dropout(conv, bn, torch.nn.Dropout(0.0), x, g)) == "_GinKanBnLayerFnBackward"
+    assert name(M.conv_bn_dropout(conv, bn, torch.nn.Dropout(0.5), x, g)) == "_BatchNormFnBackward"       # active dropout rides in the norm's pass
+    seen = []
+    hk = conv.register_forward_hook(lambda m, i, o: seen.append(o.shape))
+    assert name(M.conv_bn_dropout(conv, bn, torch.nn.Dropout(0.0), x, g)) == "_BatchNormFnBackward" and seen      # a hook wants the convolution's output
+    hk.remove()
+    bn.eval()
+    assert name(M.conv_bn_dropout(conv, bn, torch.nn.Dropout(0.0), x, g)) == "_BatchNormFnBackward"
+    bn.train()
+    before = int(bn.num_batches_tracked)
+    M.conv_bn_dropout(conv, bn, torch.nn.Dropout(0.0), x, g)
+    assert int(bn.num_batches_tracked) == before + 1
+
+
 # ------------------------------------------------------------------ fused layer node + bf16 gather operands (config 2)
 def test_fused_gin_kan_node_equals_the_composed_ops_bitwise(monkeypatch):
     """ops.gin_kan_layer (one tape node: aggregate + KAN chain, chain-packed weights) runs the same kernels in the same
