@@ -381,10 +381,15 @@ def _aggregate_csr(x, rowptr, col, hub, nhub, hub_threshold, self_scale, edge_we
         return out
     out = torch.empty((n, f), dtype=torch.float32, device=x.device)
     ws = _ws(_sizes("kagnn_aggregate_workspace_bytes", nhub, f), x.device) if nhub else None   # per-segment partial sums
-    _call("kagnn_aggregate_sum_add", _ptr(x), _ld(x), _ptr(out), f, _ptr(rowptr), _ptr(col),
+    if addend is None:
+        _call("kagnn_aggregate_sum", _ptr(x), _ld(x), _ptr(out), f, _ptr(rowptr), _ptr(col),
               _ptr(edge_weight), n, f, float(self_scale), _ptr(in_scale), _ptr(out_scale), _ptr(bias),
-              int(skip_self), _ptr(hub) if nhub else None, nhub, hub_threshold, _ptr(addend),
-              _ld(addend) if addend is not None else 0, _ptr(ws), ws.numel() if nhub else 0, _stream())
+              int(skip_self), _ptr(hub) if nhub else None, nhub, hub_threshold, _ptr(ws), ws.numel() if nhub else 0, _stream())
+    else:
+        _call("kagnn_aggregate_sum_add", _ptr(x), _ld(x), _ptr(out), f, _ptr(rowptr), _ptr(col),
+              _ptr(edge_weight), n, f, float(self_scale), _ptr(in_scale), _ptr(out_scale), _ptr(bias),
+              int(skip_self), _ptr(hub) if nhub else None, nhub, hub_threshold, _ptr(addend), _ld(addend), _ptr(ws),
+              ws.numel() if nhub else 0, _stream())
     return out
 
 
