@@ -522,6 +522,8 @@ def main():
             "kagnn_fastkan_bwd": ("FastKANLayer backward (input gradient through the LayerNorm, LayerNorm / spline / base weight and "
                                   "bias gradients)", 4.0 * nrows * (3 * fl + 2 * f), 2.0 * kan),
         }
+        spec["kagnn_aggregate_sum_add"] = (spec["kagnn_aggregate_sum"][0] + " + an addend row per output row",
+                                           spec["kagnn_aggregate_sum"][1] + 4.0 * n * fl, spec["kagnn_aggregate_sum"][2])
         kernels = []
         for name, (what, nbytes, flops) in spec.items():
             if name not in warm:
@@ -550,8 +552,8 @@ def main():
         elif d is not None:
             roof = {"kernel": dom, "bound": "mfma", "achieved": d["mfma_TFs_incl_split_products"], "peak": mfma_peak,
                     "unit": "TFLOP/s", "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"]}
-        else:
-            roof = {"kernel": dom, "bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        else:       # (an entry point without an algorithmic-bytes / flops figure must not end up as a silent 0 in the line)
+            raise RuntimeError(f"bench.py: the dominant entry point {dom!r} has no roofline specification (spec table above)")
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["avg_launch_ms"] = d["avg_launch_ms"] if d else None
         roof["traffic"] = None
