@@ -423,12 +423,22 @@ def test_skip_gradient_handed_to_the_next_convolution_gives_the_tape_sums_bits(m
 @pytest.mark.parametrize("f_in,hidden,layers,x_grad", [(64, 64, 2, True), (64, 64, 2, False), (48, 32, 2, True), (64, 64, 1, True),
                                                         (64, 64, 1, False), (40, 16, 2, True), (64, 128, 2, True), (64, 64, 3, True)])
 def test_conv_and_norm_as_one_tape_node_give_the_two_nodes_bits(monkeypatch, f_in, hidden, layers, x_grad):
+    _conv_and_norm_node_case(monkeypatch, f_in, hidden, layers, x_grad, 7001, 60000)
+
+
+@pytest.mark.parametrize("n,e", [(2, 3), (130, 900), (257, 2000), (3000, 1)])
+def test_conv_and_norm_as_one_tape_node_on_few_rows(monkeypatch, n, e):
+    """few rows: the input-gradient launch spreads its feature tiles over blockIdx.y (every block transforms the rows it
+    loads, block 0 stores them); two rows is the norm's minimum"""
+    _conv_and_norm_node_case(monkeypatch, 64, 64, 2, True, n, e)
+
+
+def _conv_and_norm_node_case(monkeypatch, f_in, hidden, layers, x_grad, n, e):
     """models.conv_bn_dropout on a KAN-GIN convolution + training-mode BatchNorm1d: ONE tape node whose backward applies the
     norm's element-wise backward inside the last input-gradient kernel (kagnn_gin_kan_layer_bwd_bn; 32 / 64 outputs) or runs
     the stand-alone pass inside the same library call (other widths, single-layer chains without an input gradient).  Same
     bits as the convolution node followed by the norm node: output, running statistics, every gradient"""
     from kagnn_amd import models as M
-    n, e = 7001, 60000
     g = ops.GraphIndex(orc.powerlaw_graph(n, e, seed=6).to(DEV), n)
     x = (torch.randn(n, f_in, generator=torch.Generator().manual_seed(3)) * 0.4).to(DEV)
     gh = torch.randn(n, hidden, generator=torch.Generator().manual_seed(4)).to(DEV)
