@@ -1064,19 +1064,29 @@ class _KANLinearPartsFn(Function):
         gy = _rows(gy)
         want_w = any(ctx.needs_input_grad[0:3])
         gxs, gbws, gsws, gscs, f0 = [], [], [], [], 0
-        for i, part in enumerate(parts):
+        slices = []                          # per block: contiguous (base, spline, scaler) columns, or None when nothing needs them
+        for i in range(len(parts)):
             f1 = f0 + widths[i]
+            if ctx.needs_input_grad[8 + i] or want_w:
+                slices.append((bw[:, f0:f1].contiguous(), sw[:, f0:f1].contiguous(), None if sc is None else sc[:, f0:f1].contiguous()))
+            else:
+                slices.append(None)
+            f0 = f1
+        # the input-gradient packs of all blocks that need one: ONE launch when the batch entry point covers them
+        need = [i for i in range(len(parts)) if ctx.needs_input_grad[8 + i]]
+        packs = kan_pack_chain([slices[i] for i in need], G, K, mode) if sc is not None and len(need) >= 2 else None
+        pack_of = {} if packs is None else {i: packs[k][1] for k, i in enumerate(need)}
+        for i, part in enumerate(parts):
             want_x = ctx.needs_input_grad[8 + i]
-            bwp = swp = scp = None
-            if want_x or want_w:
-                bwp, swp = bw[:, f0:f1].contiguous(), sw[:, f0:f1].contiguous()
-                scp = None if sc is None else sc[:, f0:f1].contiguous()
+            bwp, swp, scp = slices[i] if slices[i] is not None else (None, None, None)
             gx = None
             if want_x:
-                fb, db = _sizes("kagnn_kan_pack_bytes", widths[i], fout, G, K, mode, outputs=2)
-                pack_f, pack_d = _ws(fb, part.device), _ws(db, part.device)
-                _call("kagnn_kan_pack", _ptr(bwp), _ptr(swp), _ptr(scp), widths[i], fout, G, K, mode, _ptr(pack_f), _ptr(pack_d),
-                      _stream())
+                pack_d = pack_of.get(i)
+                if pack_d is None:
+                    fb, db = _sizes("kagnn_kan_pack_bytes", widths[i], fout, G, K, mode, outputs=2)
+                    pack_f, pack_d = _ws(fb, part.device), _ws(db, part.device)
+                    _call("kagnn_kan_pack", _ptr(bwp), _ptr(swp), _ptr(scp), widths[i], fout, G, K, mode, _ptr(pack_f), _ptr(pack_d),
+                          _stream())
                 gx = _kan_bwd_input_raw(part, gy, knots, pack_d, widths[i], fout, G, K, mode)
                 sk = ctx.skip_gradients[i] if ctx.skip_gradients is not None else None
                 if sk is not None and sk.consumer:         # the convolution that consumed this block adds it in its own backward
@@ -1085,7 +1095,6 @@ class _KANLinearPartsFn(Function):
             if want_w:
                 gbw, gsw, gsc = _kan_bwd_weight_raw(part, gy, knots, swp, scp, widths[i], fout, G, K, mode, True)
                 gbws.append(gbw); gsws.append(gsw); gscs.append(gsc)
-            f0 = f1
         gbw = torch.cat(gbws, dim=1) if want_w else None
         gsw = torch.cat(gsws, dim=1) if want_w else None
         gsc = torch.cat(gscs, dim=1) if want_w and sc is not None else None
