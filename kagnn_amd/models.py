@@ -236,7 +236,9 @@ def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args, skip_gradient=None):
     if not fused:
         return dropout(bn(conv(x, g, *conv_args)))
     if (_FUSED_NORM_BACKWARD and isinstance(conv, _SumAggregateConv) and not conv_args and bn.training and bn.affine
-            and not (dropout.training and dropout.p > 0.0) and not _has_hooks(conv) and not _has_hooks(bn)):
+            and not (dropout.training and dropout.p > 0.0) and not _has_hooks(conv) and not _has_hooks(bn)
+            # (a subclass with its own forward must see its forward called)
+            and type(conv).forward is _SumAggregateConv.forward and type(bn).forward is BatchNorm1d.forward):
         h = conv.forward_fused_norm(x, g, bn, skip_gradient)      # convolution + norm as one tape node
         if h is not None:
             return h

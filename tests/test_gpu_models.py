@@ -479,6 +479,12 @@ def test_conv_and_norm_node_steps_aside_for_hooks_dropout_and_eval(monkeypatch):
     hk = conv.register_forward_hook(lambda m, i, o: seen.append(o.shape))
     assert name(M.conv_bn_dropout(conv, bn, torch.nn.Dropout(0.0), x, g)) == "_BatchNormFnBackward" and seen      # a hook wants the convolution's output
     hk.remove()
+
+    class Custom(kagnn_amd.GIKANLayer):
+        def forward(self, x, edge_index):
+            return super().forward(x, edge_index) * 2.0
+    sub = Custom(f, f, grid_size=5, spline_order=3, hidden_dim=f, nb_layers=2).to(DEV)
+    assert name(M.conv_bn_dropout(sub, bn, torch.nn.Dropout(0.0), x, g)) == "_BatchNormFnBackward"      # an overriding forward is called
     bn.eval()
     assert name(M.conv_bn_dropout(conv, bn, torch.nn.Dropout(0.0), x, g)) == "_BatchNormFnBackward"
     bn.train()
