@@ -203,6 +203,17 @@ def test_size_queries_and_argument_checks_need_no_gpu():
     assert b"argument check failed" in lib.kagnn_last_error()
     assert lib.kagnn_softmax_xent_fwd(None, 4, 10, 40, None, None, 1, None, None, None, None, 0, None) != 0            # ld < classes
     assert lib.kagnn_kan_grid_refit_workspace_bytes(0, 8, 5, 3, byref(a)) != 0                                         # no rows
+    # round 3: the read-out over column blocks, the layer backward with the norm inside
+    import ctypes
+    w4 = (ctypes.c_int32 * 4)(64, 64, 64, 64)
+    assert lib.kagnn_kan_fwd_parts_ok(w4, 4, 256, 40, 5, 3, _lib.PREC_SPLIT) == 1
+    assert lib.kagnn_kan_fwd_parts_ok(w4, 4, 256, 40, 5, 3, _lib.PREC_FP32) == 0
+    assert lib.kagnn_kan_fwd_parts_ok((ctypes.c_int32 * 2)(128, 40), 2, 168, 40, 5, 3, _lib.PREC_SPLIT) == 0          # 40 is not whole chunks
+    assert lib.kagnn_kan_fwd_parts_ok((ctypes.c_int32 * 9)(*([64] * 9)), 9, 576, 40, 5, 3, _lib.PREC_SPLIT) == 0        # > 8 chunks
+    assert lib.kagnn_gin_kan_layer_bwd_bn_workspace_bytes(1_000_000, 64, byref(a)) == 0 and a.value > 0
+    assert lib.kagnn_gin_kan_layer_bwd_bn_workspace_bytes(10, 0, byref(a)) != 0
+    assert lib.kagnn_aggregate_sum_add(None, 4, None, 8, None, None, None, 10, 8, 1.0, None, None, None, 0, None, 0, 0, None, 0, None, 0,
+                                       None) != 0                                                                    # null arrays / ldx < F
 
 
 def test_hot_path_kernels_do_not_spill_registers():
