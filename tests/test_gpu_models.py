@@ -433,7 +433,12 @@ def test_conv_and_norm_as_one_tape_node_on_few_rows(monkeypatch, n, e):
     _conv_and_norm_node_case(monkeypatch, 64, 64, 2, True, n, e)
 
 
-def _conv_and_norm_node_case(monkeypatch, f_in, hidden, layers, x_grad, n, e):
+def test_conv_and_norm_as_one_tape_node_in_the_exact_fp32_mode(monkeypatch):
+    """exact-fp32 kernels: the library call runs the stand-alone normalisation backward, then the fp32 chain"""
+    _conv_and_norm_node_case(monkeypatch, 64, 64, 2, True, 5000, 40000, mode=ops.PREC_FP32)
+
+
+def _conv_and_norm_node_case(monkeypatch, f_in, hidden, layers, x_grad, n, e, mode=None):
     """models.conv_bn_dropout on a KAN-GIN convolution + training-mode BatchNorm1d: ONE tape node whose backward applies the
     norm's element-wise backward inside the last input-gradient kernel (kagnn_gin_kan_layer_bwd_bn; 32 / 64 outputs) or runs
     the stand-alone pass inside the same library call (other widths, single-layer chains without an input gradient).  Same
@@ -446,6 +451,8 @@ def _conv_and_norm_node_case(monkeypatch, f_in, hidden, layers, x_grad, n, e):
     torch.manual_seed(5)
     conv0 = kagnn_amd.GIKANLayer(f_in, hidden, grid_size=5, spline_order=3, hidden_dim=hidden, nb_layers=layers).to(DEV)
     bn0 = kagnn_amd.BatchNorm1d(hidden).to(DEV)
+    if mode is not None:
+        _set_precision(conv0, mode)
     with torch.no_grad():
         bn0.weight.uniform_(0.5, 1.5); bn0.bias.uniform_(-0.3, 0.3)
     res = []
