@@ -419,6 +419,47 @@ def test_skip_gradient_handed_to_the_next_convolution_gives_the_tape_sums_bits(m
     assert model.lay_out.spline_weight.grad is not None
 
 
+def test_node_model_folds_against_the_unfused_paths_over_random_configurations(monkeypatch):
+    """GKAN_Nodes('gin') with the three round-3 folds on (read-out over column blocks in one launch, skip gradients handed to
+    the convolutions, convolution + norm as one node) against the same model with all three off, over random widths / depths /
+    row counts / dropout: same loss and gradients (the one-launch read-out adds its chunks in a different order than the
+    per-block sums: 2e-5, everything else is bit-identical)"""
+    import copy
+    import random
+    from kagnn_amd import models as M
+    monkeypatch.setattr(M, "_SPLIT_READOUT_MIN_ROWS", 0)
+    rng = random.Random(20260929)
+    for case in range(10):
+        f_in = rng.choice([64, 128, 40, 64])
+        hidden = rng.choice([64, 32, 16, 64, 128])
+        mp, hl = rng.choice([1, 2, 3]), rng.choice([1, 2])
+        n = rng.choice([700, 3001, 9000])
+        p_drop = rng.choice([0.0, 0.0, 0.25])
+        classes = rng.choice([7, 40])
+        g = ops.GraphIndex(orc.powerlaw_graph(n, 8 * n, seed=case).to(DEV), n)
+        x = (torch.randn(n, f_in, generator=torch.Generator().manual_seed(case)) * 0.4).to(DEV)
+        y = torch.randint(0, classes, (n,), generator=torch.Generator().manual_seed(case + 1)).to(DEV)
+        torch.manual_seed(case)
+        model0 = kagnn_amd.GKAN_Nodes("gin", mp, f_in, hidden, classes, skip=True, grid_size=5, spline_order=3, hidden_layers=hl,
+                                      dropout=p_drop).to(DEV)
+        res = []
+        for on in (True, False):
+            monkeypatch.setattr(M, "_SKIP_GRADIENT", on)
+            monkeypatch.setattr(M, "_FUSED_NORM_BACKWARD", on)
+            monkeypatch.setattr(ops, "_PARTS_ONE_LAUNCH", on)
+            model = copy.deepcopy(model0)
+            xr = x.clone().requires_grad_(case % 2 == 0)
+            torch.manual_seed(1000 + case)                 # dropout masks
+            loss = ops.softmax_cross_entropy(model(xr, g), y)
+            loss.backward()
+            res.append([loss.detach().clone()] + ([xr.grad.clone()] if xr.requires_grad else [])
+                       + [p.grad.clone() for p in model.parameters()] + [b.clone() for b in model.buffers() if b.dtype.is_floating_point])
+        label = f"case {case}: f_in {f_in} hidden {hidden} mp {mp} chain {hl} n {n} dropout {p_drop}"
+        for k, (a, b) in enumerate(zip(*res)):
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-30), (label, k, float((a - b).abs().max()), scale)
+
+
 # ------------------------------------------------------------------ convolution + BatchNorm1d as one tape node
 @pytest.mark.parametrize("f_in,hidden,layers,x_grad", [(64, 64, 2, True), (64, 64, 2, False), (48, 32, 2, True), (64, 64, 1, True),
                                                         (64, 64, 1, False), (40, 16, 2, True), (64, 128, 2, True), (64, 64, 3, True)])
