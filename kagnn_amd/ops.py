@@ -947,7 +947,9 @@ def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optiona
     for l in layers:
         params += [l.base_weight, l.spline_weight, l.spline_scaler]
     if batch_norm is not None:
-        if not _LAYER_ABI or x.size(0) < 2:
+        # (the library call keeps the norm's transformed rows in the chain's ping-pong gradient matrices, which are as wide as
+        # the widest layer INPUT: a chain whose output is wider than every input stays on the two nodes)
+        if not _LAYER_ABI or x.size(0) < 2 or layers[-1].out_features > max(l.in_features for l in layers):
             return None
         bw_, bb_, rm_, rv_, mom_, eps_ = batch_norm() if callable(batch_norm) else batch_norm      # (callable: evaluated only now that the node is certain -- the caller's per-call bookkeeping)
         return _GinKanBnLayerFn.apply(x, g, float(self_scale), knots, first.grid_size, first.spline_order, int(mode),

@@ -536,6 +536,13 @@ def test_conv_and_norm_node_steps_aside_for_hooks_dropout_and_eval(monkeypatch):
     bn.eval()
     assert name(M.conv_bn_dropout(conv, bn, torch.nn.Dropout(0.0), x, g)) == "_BatchNormFnBackward"
     bn.train()
+    # a single-layer chain that widens (16 -> 64): its output is wider than every layer input -- two nodes, and they train
+    wide = kagnn_amd.GIKANLayer(16, f, grid_size=5, spline_order=3, hidden_dim=f, nb_layers=1).to(DEV)
+    x16 = torch.randn(n, 16, device=DEV).requires_grad_(True)
+    h = M.conv_bn_dropout(wide, bn, torch.nn.Dropout(0.0), x16, g)
+    assert name(h) == "_BatchNormFnBackward"
+    h.sum().backward()
+    assert x16.grad is not None and torch.isfinite(x16.grad).all()
     before = int(bn.num_batches_tracked)
     M.conv_bn_dropout(conv, bn, torch.nn.Dropout(0.0), x, g)
     assert int(bn.num_batches_tracked) == before + 1
