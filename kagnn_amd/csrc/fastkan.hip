@@ -16,6 +16,7 @@ bool kan_split_fwd_ok(int in, int out, int G, int K);
 size_t kan_split_pack_fwd_bytes(int in, int out, int C);
 size_t kan_split_pack_dx_bytes(int in, int out, int C, int K);
 size_t kan_split_dw_ws_bytes(long N, int in, int out, int C, int K);
+void kan_split_dw_slabs(long N, int in, int out, int C, int K, long* slabs, long* outP);
 int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, int, int, void*, hipStream_t);
 int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, int, void*, hipStream_t);
 int kan_split_fwd_any(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const RbfArgs&, void*, size_t, hipStream_t);
@@ -597,6 +598,11 @@ static FkBwdPlan fk_plan(long N, int in, int out, int ng, int mode) {
     p.col_blocks = (int)max(1L, min(512L, N / 256 + 1));
     p.col_rpb = (N + p.col_blocks - 1) / p.col_blocks;
     p.colpart = al256((size_t)p.col_blocks * out * 4);
+    if (p.split) {                                    // the weight-gradient kernel leaves one row of column sums per row slab
+        long slabs = 0, outP = 0;
+        kan_split_dw_slabs(N, in, out, ng, 0, &slabs, &outP);
+        p.colpart = al256((size_t)max(slabs * outP, (long)p.col_blocks * out) * 4);
+    }
     p.total = p.pack_f + p.pack_d + p.gz + p.gcat + p.slab + p.lnpart + p.colpart;
     return p;
 }
@@ -634,13 +640,21 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
             sum_partials_kernel<<<cdiv(2L * in, 32), 32 * kSumGroups, 0, st>>>(lnpart, p.ln_blocks, 2L * in, 2L * in, g_lnw, g_lnb, in);
             KAGNN_LAUNCH_CHECK();
         }
+        // the base bias gradient (column sums of gy) rides in the weight-gradient kernel, which reads gy anyway: one row of
+        // sums per row slab, folded in slab order (deterministic).  (A pass of its own over gy cost 0.08 ms per layer at 1M x 64.)
+        RbfArgs rbw = rb;
+        long slabs = 0, outP = 0;
+        kan_split_dw_slabs(N, in, out, ng, 0, &slabs, &outP);
+        rbw.colpart = (g_bb && N > 0) ? colpart : nullptr;
         { int rc = kan_split_dw_any(x, ldx, gy, ldgy, N, nullptr, in, out, ng, 0, sw, nullptr, g_bw, g_sw, nullptr,
-                                    slab, p.slab, rb, st); if (rc) return rc; }
+                                    slab, p.slab, rbw, st); if (rc) return rc; }
         if (g_bb) {
-            colsum_partial_kernel<<<p.col_blocks, 256, 0, st>>>(gy, ldgy, N, out, p.col_rpb, colpart);
-            KAGNN_LAUNCH_CHECK();
-            sum_partials_kernel<<<cdiv(out, 32), 32 * kSumGroups, 0, st>>>(colpart, p.col_blocks, out, out, g_bb, g_bb, out);
-            KAGNN_LAUNCH_CHECK();
+            if (N > 0) {
+                sum_partials_kernel<<<cdiv(out, 32), 32 * kSumGroups, 0, st>>>(colpart, slabs, outP, out, g_bb, g_bb, out);
+                KAGNN_LAUNCH_CHECK();
+            } else {
+                KAGNN_HIP(hipMemsetAsync(g_bb, 0, (size_t)out * sizeof(float), st));
+            }
         }
         return KAGNN_OK;
     }

@@ -952,6 +952,10 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
     // inside ONE iteration; only the raw rows -- direct load destinations -- cross the back edge.  With the expansion at the
     // bottom of the loop (round 2) the 104 fragment registers were loop-carried and the compiler closed every iteration with
     // ~100 v_mov copies into them (16 % of the loop's VALU instructions).
+    // (RBF layers) column sums of this slab's gy rows = its part of the base bias gradient: the wave of feature tile 0 of
+    // feature group 0 adds up the rows it loads anyway (32 adds per chunk) instead of a pass of its own over gy
+    float bsum[NTO] = {};
+    const bool bias_on = (K == 0) && rb.colpart != nullptr && fg == 0 && tile == 0;      // wave-uniform
     int T;                         // running exponent: gy is fed as gy * 2^(10 - T)
     // one chunk: expansion of `raw`, request of the chunk that will next live in `raw`, MFMAs.  false = the chunk needs a larger
     // scale (nothing was touched: rescale outside, then redo it)
@@ -988,6 +992,14 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
             const bool base32 = __any(!(smx < 60000.0f));   // wave-uniform; also catches NaN / Inf
             split_f16x2(sv, sah, sal);
             if (chunk_exp(raw) > T) return false;            // wave-uniform, rare: rescale outside, then redo this chunk
+            if constexpr (K == 0) {
+                if (bias_on) {
+#pragma unroll
+                    for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum[t] += raw.g[t][j];
+                }
+            }
             // gy side, scaled by 2^(10 - T)
             u32x4 bhi[NTO], blo[NTO];      // gy * 2^(10-T), per 16-wide output tile
             const float gs = ldexpf(1.0f, 10 - T);
@@ -1058,6 +1070,18 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
         for (; n0 < rend; n0 += 32)
             if (!step(raw)) break;
         if (n0 < rend) rescale(raw);
+    }
+    if constexpr (K == 0) {
+        if (bias_on) {                                           // rows 8*kg + j of every chunk: fold the four k-lane groups
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) {
+                float v = bsum[t];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                const long o = 16 * NTO * oc + 16 * t + li;
+                if (kg == 0 && o < outP) rb.colpart[s * outP + o] = v;
+            }
+        }
     }
     // ---- slab write: D rows <-> features 4*kg + reg, cols <-> outputs li
     const float undo = ldexpf(1.0f, T - 20), undo_b = ldexpf(1.0f, T - 14);
@@ -1364,6 +1388,12 @@ __global__ void kan_dw_unpack_v_kernel(const float* __restrict__ gcat, int in, i
     }
     if (g_sc) g_sc[of] = gs;
     if (g_bw) g_bw[of] = gcat[(8L * inP + 2 * f) * outP + o];
+}
+
+// row slabs and padded output width of the weight-gradient launch: the shape of RbfArgs::colpart ([slabs][outP])
+void kan_split_dw_slabs(long N, int in, int out, int C, int K, long* slabs, long* outP) {
+    const DwPlan p = split_dw_plan(N, in, out, C, K);
+    *slabs = p.NS; *outP = p.outP;
 }
 
 // K == 0: Gaussian RBF basis with G = num_grids; sc == nullptr and g_sw laid out [out][in][G] either way

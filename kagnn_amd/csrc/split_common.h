@@ -527,6 +527,8 @@ struct RbfArgs {
     const float* ln_w; const float* ln_b; const float* stats;   // stats[n] = (mean, rstd)
     const float* bias;        // forward: added to y (base_linear.bias), may be nullptr
     float* gz;                // input gradient: [N, in] gradient w.r.t. z when layernorm is on
+    float* colpart;           // weight gradient: [slabs][outP] column sums of gy per row slab (the base bias gradient rides in
+                              // the kernel that reads gy anyway); nullptr: not wanted
 };
 
 // ca[g] = a * c_{8*window+g} (wave-uniform; slots >= num_grids repeat the last centre -- their packed weights
