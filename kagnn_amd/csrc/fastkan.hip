@@ -109,6 +109,11 @@ static int launch_stats(const float* x, long ldx, long N, int in, float eps, flo
     return KAGNN_OK;
 }
 
+static bool fk_stats_in_fwd() {                       // KAGNN_FASTKAN_STATS_IN_FWD=0: the separate statistics pass (A/B)
+    static const bool on = [] { const char* e = getenv("KAGNN_FASTKAN_STATS_IN_FWD"); return e == nullptr || atoi(e) != 0; }();
+    return on;
+}
+
 static bool fk_split(int in, int out, int ng, int mode) { return mode == 1 && kan_split_fwd_ok(in, out, ng, 0); }
 
 static RbfArgs fk_rbf(const float* centers, int ng, float den, const float* lnw, const float* lnb,
@@ -545,11 +550,16 @@ int fastkan_fwd(const float* x, long ldx, long N, int in, int out, int ng, const
     if (ws_bytes < fastkan_fwd_ws_bytes(N, in, out, ng, mode)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "fastkan_fwd");
     if (lnw && !stats) return fail(KAGNN_ERR_ARG, "%s: row_stats is required with layernorm", "fastkan_fwd");
     if (fk_split(in, out, ng, mode)) {
-        if (lnw) { int rc = launch_stats(x, ldx, N, in, eps, stats, st); if (rc) return rc; }
+        // one-chunk layers (<= 8 centres, in <= 64 with <= 64 outputs / in <= 32 with <= 128, one output block): the forward
+        // kernel takes the row statistics from the rows it loads and stores them; anything else runs the statistics pass first
+        const int cf = cdiv(min(out, 128), 32) <= 2 ? 64 : 32;
+        const bool own_stats = lnw && ng <= 8 && in <= cf && out <= 128 && N > 0 && fk_stats_in_fwd();
+        if (lnw && !own_stats) { int rc = launch_stats(x, ldx, N, in, eps, stats, st); if (rc) return rc; }
         { int rc = kan_split_pack_fwd_noscale(bw, sw, nullptr, in, out, ng, ws, st); if (rc) return rc; }
         char* part = static_cast<char*>(ws) + al256(kan_split_pack_fwd_bytes(in, out, ng));
-        return kan_split_fwd_any(x, ldx, N, nullptr, in, out, ng, 0, ws, y, ldy,
-                                 fk_rbf(centers, ng, den, lnw, lnb, stats, bb, nullptr), part,
+        RbfArgs rb = fk_rbf(centers, ng, den, lnw, lnb, stats, bb, nullptr);
+        if (own_stats) { rb.stats_out = stats; rb.ln_eps = eps; }
+        return kan_split_fwd_any(x, ldx, N, nullptr, in, out, ng, 0, ws, y, ldy, rb, part,
                                  kan_split_fwd_ws_bytes(N, in, out, ng), st);
     }
     float* pf = (float*)ws;

@@ -193,8 +193,35 @@ __global__ __launch_bounds__(NT) void kan_split_fwd_kernel(
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
         float mean = 0.0f, rstd = 1.0f;                  // K == 0 with layernorm: this lane's row statistics
         if (K == 0 && rb.ln_w) {
-            const long rc = min(row0 + r, N - 1);
-            mean = rb.stats[2 * rc]; rstd = rb.stats[2 * rc + 1];
+            if (rb.stats_out) {
+                // one-chunk layer (in <= CF): the row's features sit in this lane and its partner half (lane ^ 32) -- two-pass
+                // mean / variance like torch, from loads that leave the row in L1 for the group pipeline below; the statistics
+                // pass over x of its own (0.058 ms per layer at 1M x 64) is gone
+                float xr[NG][8];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) load8(tile * ROWS, ch_begin, g, xr[g]);
+                float s = 0.0f;
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s += (kg * HF + 8 * g + j < in) ? xr[g][j] : 0.0f;
+                s += __shfl_xor(s, 32);
+                mean = s / (float)in;
+                float q = 0.0f;
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float d = (kg * HF + 8 * g + j < in) ? xr[g][j] - mean : 0.0f;
+                        q = fmaf(d, d, q);
+                    }
+                q += __shfl_xor(q, 32);
+                rstd = rsqrtf(q / (float)in + rb.ln_eps);
+                if (kg == 0 && row0 + r < N) { rb.stats_out[2 * (row0 + r)] = mean; rb.stats_out[2 * (row0 + r) + 1] = rstd; }
+            } else {
+                const long rc = min(row0 + r, N - 1);
+                mean = rb.stats[2 * rc]; rstd = rb.stats[2 * rc + 1];
+            }
         }
 
         for (int ch = ch_begin; ch < ch_end; ++ch) {

@@ -527,6 +527,8 @@ struct RbfArgs {
     const float* ln_w; const float* ln_b; const float* stats;   // stats[n] = (mean, rstd)
     const float* bias;        // forward: added to y (base_linear.bias), may be nullptr
     float* gz;                // input gradient: [N, in] gradient w.r.t. z when layernorm is on
+    float* stats_out;         // forward, one-chunk layers: compute the LayerNorm row statistics HERE (from the rows the kernel
+    float ln_eps;             //   loads anyway) and store them for the backward, instead of reading `stats`; nullptr: read
     float* colpart;           // weight gradient: [slabs][outP] column sums of gy per row slab (the base bias gradient rides in
                               // the kernel that reads gy anyway); nullptr: not wanted
 };
