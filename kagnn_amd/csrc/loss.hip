@@ -292,6 +292,14 @@ int xent_fwd(const float* z, long ld, long N, int C, const long* y, const unsign
     float* partial = (float*)ws;
     const int W = xent_width(C);
     int nb = N > 0 ? xent_blocks(N, W) : 0;
+    // 9..64 classes: 8 lanes per row, up to 8 classes per lane in registers, no LDS, no barriers (0.115 vs 0.175 ms forward +
+    // backward at 1M x 40 against the row-per-thread kernels over an LDS tile, which KAGNN_XENT_ROWS=1 still selects)
+    static const bool w8 = [] { const char* e = getenv("KAGNN_XENT_ROWS"); return e == nullptr || atoi(e) == 0; }();
+    if (w8 && C > 8 && C <= 64 && N > 0) {
+        nb = xent_blocks(N, 8);
+        if (C <= 40) xent_fwd_kernel<8, 5><<<nb, 256, 0, st>>>(z, ld, N, C, y, mask, pre, stats, partial);
+        else xent_fwd_kernel<8, 8><<<nb, 256, 0, st>>>(z, ld, N, C, y, mask, pre, stats, partial);
+    } else
     if (C <= 64 && N > 0) {
         nb = (int)min((long)cdiv(N, 256), 4096L);
         static bool big_lds = false;                       // 256 rows x 65 floats is just over the 64 KB default
@@ -318,6 +326,14 @@ int xent_bwd(const float* z, long ld, long N, int C, const long* y, const unsign
              const float* stats, const float* count, const float* gloss, float* gz, long ldg, hipStream_t st) {
     if (N == 0) return KAGNN_OK;
     const int W = xent_width(C), nb = xent_blocks(N, W);
+    static const bool w8 = [] { const char* e = getenv("KAGNN_XENT_ROWS"); return e == nullptr || atoi(e) == 0; }();
+    if (w8 && C > 8 && C <= 64) {
+        const int nb8 = xent_blocks(N, 8);
+        if (C <= 40) xent_bwd_kernel<8, 5><<<nb8, 256, 0, st>>>(z, ld, N, C, y, mask, pre, stats, count, gloss, gz, ldg);
+        else xent_bwd_kernel<8, 8><<<nb8, 256, 0, st>>>(z, ld, N, C, y, mask, pre, stats, count, gloss, gz, ldg);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
     if (C <= 64) {
         const int nbr = (int)min((long)cdiv(N, 256), 4096L);
         xent_bwd_rows_kernel<<<nbr, 256, (size_t)256 * (C | 1) * sizeof(float), st>>>(z, ld, N, C, y, mask, pre, stats, count, gloss, gz, ldg);
