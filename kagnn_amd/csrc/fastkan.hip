@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void fastkan_stats_kernel(const float* __restr
     if (l == 0 && row < N) { stats[2 * row] = mean; stats[2 * row + 1] = rsqrtf(v / (float)in + eps); }
 }
 
-// the same for rows of <= 64 NV features: a lane keeps its NV groups of 4 consecutive features in registers -- ONE pass
+// the same for rows of <= 64 NV features (NV <= 16): a lane keeps its NV groups of 4 consecutive features in registers -- ONE pass
 // over x, 16-byte loads when VEC (the scalar two-pass form above read every row twice: 114 us vs the 256 MB / ~4.5 TB/s
 // = 57 us of a single pass at 1M x 64).  VEC or not, the same values meet in the same order: a column slice of a wider
 // activation (unaligned) gives the bits of its contiguous copy.
@@ -102,7 +102,8 @@ static int launch_stats(const float* x, long ldx, long N, int in, float eps, flo
     const int grid = cdiv(N, 16);
 #define L(NV) do { if (vec) fastkan_stats_v4_kernel<NV, true><<<grid, 256, 0, st>>>(x, ldx, N, in, eps, stats); \
                    else fastkan_stats_v4_kernel<NV, false><<<grid, 256, 0, st>>>(x, ldx, N, in, eps, stats); } while (0)
-    if (in <= 64) L(1); else if (in <= 128) L(2); else if (in <= 256) L(4);
+    if (in <= 64) L(1); else if (in <= 128) L(2); else if (in <= 256) L(4); else if (in <= 512) L(8);
+    else if (in <= 1024) L(16);                       // (the skip read-out of the node models: 128 + 3 x 256 = 896 columns)
     else fastkan_stats_kernel<<<grid, 256, 0, st>>>(x, ldx, N, in, eps, stats);
 #undef L
     KAGNN_LAUNCH_CHECK();
