@@ -13,9 +13,12 @@ One JSON line on stdout (rank 0).  Besides the contract's fields it carries
                         its matrix-core flops -- the limiting ones are the KAN kernels, not the aggregation
   fp32_mode_ms_per_step the same step on the exact-fp32 MFMA kernels (KAGNN_PRECISION=fp32)
   cpu_baseline          the oracle (the reference's algorithm, "port") on the host cores, bounded sample
-N > 1 (one rank per GPU, RCCL): `value` is north_star's scheme (spline coefficients sharded by input feature,
-reduce-scatter / all-gather per KANLinear); the all-to-all scheme of kagnn_amd/sharded.py is timed next to it and
-reported under "alt_parallelism".  Total work is fixed => "scaling": "strong".
+The timed path is the product's default: ONE library call per convolution each way (kagnn_gin_kan_layer_fwd / _bwd); the
+dominant kernel is timed live inside it by the library's stage timer (kagnn_stage_timer_*: HIP events on the launch stream).
+N > 1 (one rank per GPU): an untimed probe runs the four combinations {feature-sharded (north_star's scheme), column/row
+transposed} x {RCCL collectives, direct peer-to-peer kernels}; `value` is the fastest one (named in config.parallelism),
+all four are listed under "multi_gpu_probe", north_star's literal scheme under "north_star_scheme".  Total work is fixed
+=> "scaling": "strong".
 """
 from __future__ import annotations
 
@@ -356,10 +359,11 @@ def main():
 
     import kagnn_amd
     from kagnn_amd import ops
-    # The product's GIKANLayer makes ONE library call each way (kagnn_gin_kan_layer_fwd / _bwd).  bench.py composes the
-    # same kernels from the per-op entry points instead, so that each of them can be bracketed by HIP events on the launch
-    # stream (roofline / roofline_kernels); bit-identical results, 0.5 % more host work (A/B: 2.483 vs 2.499 ms).
-    ops._LAYER_ABI = os.environ.get("KAGNN_BENCH_LAYER_ABI", "0") == "1"
+    # The timed path is the product's default: GIKANLayer makes ONE library call each way (kagnn_gin_kan_layer_fwd / _bwd).
+    # Per-kernel times come from the library's own stage timer (kagnn_stage_timer_*: HIP events on the launch stream around
+    # every per-operation stage INSIDE those calls), not from composing the layer out of per-op calls as rounds 1-3 did.
+    # KAGNN_BENCH_LAYER_ABI=0 restores the composed form (bit-identical results) for A/B runs.
+    ops._LAYER_ABI = os.environ.get("KAGNN_BENCH_LAYER_ABI", "1") == "1"
 
     n, e = args.nodes, args.edges
     fp32_mode = args.precision in ("fp32", "exact", "0")
@@ -373,7 +377,15 @@ def main():
         conv = kagnn_amd.GIFASTKANLayer(f, f, grid_size=grid, hidden_dim=f, nb_layers=2)
     else:
         conv = kagnn_amd.GIKANLayer(f, f, grid_size=grid, spline_order=args.order, hidden_dim=f, nb_layers=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     graph = ops.GraphIndex(ei, n)
+    torch.cuda.synchronize()
+    graph_build_first_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    graph = ops.GraphIndex(ei, n)                       # (both directions: CSR by destination and its transpose)
+    torch.cuda.synchronize()
+    graph_build_ms = (time.perf_counter() - t0) * 1e3       # one-time per edge_index (cached on its identity): NOT in the timed region
 
     def sync():
         if dist is not None:
@@ -412,8 +424,21 @@ def main():
         parallelism = "single GPU"
     else:
         from kagnn_amd.sharded import ShardedGIKANLayer, TransposedShardedGIKANLayer
+        classes = {"feature": ShardedGIKANLayer, "transposed": TransposedShardedGIKANLayer}
 
-        def make(cls):
+        def describe(scheme, comm):
+            if scheme == "feature":
+                return (f"feature-sharded x{world}: spline coefficients split by input feature, " +
+                        ("RCCL reduce-scatter (fwd) / all-gather (bwd) per KANLinear, row-chunked and overlapped (north_star's scheme)"
+                         if comm == "rccl" else
+                         "direct peer-to-peer reduce-scatter (fwd) / all-gather (bwd) kernels over hipIpc-mapped peer buffers per "
+                         "KANLinear, row-chunked and overlapped (north_star's partitioning, SURVEY 8(e)'s hand-rolled exchange)"))
+            return (f"column-sharded aggregation + row-sharded KAN chain x{world}: " +
+                    ("RCCL all-to-all both ways" if comm == "rccl" else "direct peer-to-peer pulls over hipIpc-mapped buffers both ways") +
+                    ", one flat weight-gradient all-reduce")
+
+        def make(scheme, comm):
+            cls = classes[scheme]
             sconv = (cls(conv, dist.group.WORLD, sync_in_backward=False, comm=comm) if cls is TransposedShardedGIKANLayer
                      else cls(conv, dist.group.WORLD, comm=comm)).to(dev)
             xs = sconv.shard_columns(x_full.to(dev)).requires_grad_(True)
@@ -429,56 +454,61 @@ def main():
                 if hasattr(sconv, "sync_gradients"):
                     sconv.sync_gradients()             # one flat all-reduce for all weight gradients
             return step
-        # north_star's scheme is the reported one; KAGNN_SHARDING=transposed swaps the two roles.  KAGNN_COMM=p2p runs its
-        # exchanges as direct peer-to-peer kernels over hipIpc-mapped buffers (kagnn_p2p_*) instead of RCCL collectives
-        comm = os.environ.get("KAGNN_COMM", "rccl")
-        primary = os.environ.get("KAGNN_SHARDING", "feature")
-        names = {"feature": (f"feature-sharded x{world}: spline coefficients split by input feature, RCCL reduce-scatter (fwd) / "
-                             f"all-gather (bwd) per KANLinear (north_star)") if comm == "rccl" else
-                            (f"feature-sharded x{world}: spline coefficients split by input feature, direct peer-to-peer reduce-scatter (fwd) / "
-                             f"all-gather (bwd) kernels over hipIpc-mapped peer buffers per KANLinear (KAGNN_COMM=p2p)"),
-                 "transposed": f"column-sharded aggregation + row-sharded KAN chain x{world}: " +
-                               ("RCCL all-to-all both ways" if comm == "rccl" else "direct peer-to-peer pulls over hipIpc-mapped buffers both ways (KAGNN_COMM=p2p)") +
-                               ", one flat weight-gradient all-reduce"}
-        classes = {"feature": ShardedGIKANLayer, "transposed": TransposedShardedGIKANLayer}
-        other = "transposed" if primary == "feature" else "feature"
-        step = make(classes[primary])
-        parallelism = names[primary]
 
-        def time_alt():
-            # the other scheme, timed AFTER the reported one; a failure here must not cost the run its line
-            try:
-                alt_step = make(classes[other])
-                for _ in range(args.warmup):
-                    alt_step()
-                dt_alt = timed(alt_step, args.steps)
-                return {"parallelism": names[other], "ms_per_step": dt_alt / args.steps * 1e3, "value": e / (dt_alt / args.steps)}
-            except Exception as ex:                       # noqa: BLE001 -- reported, not swallowed
-                return {"parallelism": names[other], "error": f"{type(ex).__name__}: {ex}"[:300]}
+        # Which combination is `value`?  KAGNN_SHARDING / KAGNN_COMM pin it; otherwise an UNTIMED probe runs all four
+        # ({feature, transposed} x {rccl, p2p}: short warm-up + a few steps each, max over ranks) and the fastest is then timed
+        # under the contract (W warm-up + K steps).  A combination that fails (e.g. no IPC between two devices) is listed with
+        # its error and skipped; the failure is symmetric across ranks for setup errors, which is what can go wrong here.
+        pin_s, pin_c = os.environ.get("KAGNN_SHARDING"), os.environ.get("KAGNN_COMM")
+        combos = [(sc, cm) for sc in ("feature", "transposed") for cm in ("rccl", "p2p")
+                  if (pin_s is None or sc == pin_s) and (pin_c is None or cm == pin_c)]
+        if not combos:
+            raise SystemExit("KAGNN_SHARDING must be 'feature' or 'transposed', KAGNN_COMM 'rccl' or 'p2p'")
+        probe = []
+        probe_warm, probe_steps = min(args.warmup, 2), max(2, min(args.steps, 5))
+        for sc, cm in combos:
+            entry = {"scheme": sc, "comm": cm, "parallelism": describe(sc, cm)}
+            if len(combos) > 1:
+                try:
+                    st = make(sc, cm)
+                    for _ in range(probe_warm):
+                        st()
+                    dtp = timed(st, probe_steps)
+                    entry.update(ms_per_step=dtp / probe_steps * 1e3, value=e / (dtp / probe_steps), steps=probe_steps, warmup=probe_warm)
+                    del st
+                except Exception as ex:                   # noqa: BLE001 -- reported in the line, not swallowed
+                    entry["error"] = f"{type(ex).__name__}: {ex}"[:300]
+                torch.cuda.empty_cache()
+            probe.append(entry)
+        ok = [p_ for p_ in probe if "error" not in p_]
+        if not ok:
+            raise SystemExit("bench.py: every multi-GPU combination failed: " + json.dumps(probe))
+        best = min(ok, key=lambda p_: p_.get("ms_per_step", 0.0))
+        step = make(best["scheme"], best["comm"])
+        parallelism = best["parallelism"]
+        alt = {"selected": {"scheme": best["scheme"], "comm": best["comm"]},
+               "how": ("pinned by KAGNN_SHARDING / KAGNN_COMM" if len(combos) == 1 else
+                       f"fastest of the untimed probe ({probe_warm} warm-up + {probe_steps} steps per combination, max over ranks)"),
+               "combinations": probe}
 
     for _ in range(args.warmup):
         step()
-    # per-entry-point breakdown: three extra untimed steps with HIP events around every library call.  In the
-    # timed region only the dominant entry point keeps its events (the roofline figure is measured there, live);
-    # timing all ~25 calls of a step adds ~0.07 ms of event records to a 2.7 ms step.
+    # per-stage breakdown: three extra untimed steps with the library's stage timer recording every stage (HIP events on
+    # the launch stream around each per-operation stage inside the layer calls).  In the timed region only the dominant
+    # stage keeps its events (the roofline figure is measured there, live): 2 event records per launch of that one kernel.
     PROFILE_STEPS = 3
-    warm_timer = ops.EntryPointTimer()
-    ops.set_timer(warm_timer)
     sync()
-    for _ in range(PROFILE_STEPS):
-        step()
-    sync()
-    ops.set_timer(None)
-    warm = warm_timer.summary()
+    with ops.LibraryStageTimer(None):
+        for _ in range(PROFILE_STEPS):
+            step()
+        sync()
+    warm = ops.LibraryStageTimer.collect()
     only = max(warm, key=lambda k: warm[k]["total_ms"]) if warm else None
-    timer = ops.EntryPointTimer(only=only)
-    ops.set_timer(timer)
-    dt = timed(step, args.steps)
-    ops.set_timer(None)
+    with ops.LibraryStageTimer(only):
+        dt = timed(step, args.steps)
+    prof_live = ops.LibraryStageTimer.collect()
     ms = dt / args.steps * 1e3
     value = e / (dt / args.steps)
-    if world > 1 and os.environ.get("KAGNN_BENCH_ALT", "1") != "0":
-        alt = time_alt()
 
     # N > 1: what each rank's device spent INSIDE the library (kernels, summed over the entry points of the profile steps) vs the
     # step time -- the rest is exposed waiting on the collectives (+ launch gaps): explains the driver's scaling curve
@@ -501,7 +531,7 @@ def main():
             l.precision = None
 
     if rank == 0:
-        prof = timer.summary()
+        prof = prof_live
         c = grid if fastkan else grid + args.order          # coefficients (RBF centres) per input feature
         fl = f // world if world > 1 else f
         per_step = {k: v["total_ms"] / PROFILE_STEPS for k, v in warm.items()}
@@ -522,8 +552,7 @@ def main():
             "kagnn_fastkan_bwd": ("FastKANLayer backward (input gradient through the LayerNorm, LayerNorm / spline / base weight and "
                                   "bias gradients)", 4.0 * nrows * (3 * fl + 2 * f), 2.0 * kan),
         }
-        spec["kagnn_aggregate_sum_add"] = (spec["kagnn_aggregate_sum"][0] + " + an addend row per output row",
-                                           spec["kagnn_aggregate_sum"][1] + 4.0 * n * fl, spec["kagnn_aggregate_sum"][2])
+        spec["kagnn_kan_linear_fwd_moments"] = spec["kagnn_kan_linear_fwd"]
         kernels = []
         for name, (what, nbytes, flops) in spec.items():
             if name not in warm:
@@ -534,7 +563,7 @@ def main():
             kernels.append({"entry_point": name, "what": what, "avg_launch_ms": avg * 1e3,
                             "launches_per_step": warm[name]["launches"] / PROFILE_STEPS,
                             "ms_per_step": per_step[name],
-                            "measured_in": "timed region" if name in prof else "3 untimed profile steps",
+                            "measured_in": "timed region (library stage timer)" if name in prof else "3 untimed profile steps (library stage timer)",
                             "algorithmic_bytes_per_launch": nbytes, "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
                             "algorithmic_flops_per_launch": flops,
                             "mfma_TFs_incl_split_products": tf, "mfma_frac": tf / mfma_peak if not name.startswith("kagnn_aggregate_sum") else 0.0,
@@ -555,6 +584,8 @@ def main():
         else:       # (an entry point without an algorithmic-bytes / flops figure must not end up as a silent 0 in the line)
             raise RuntimeError(f"bench.py: the dominant entry point {dom!r} has no roofline specification (spec table above)")
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # the honest whole-layer figure next to the dominant kernel's: all of B_layer over the step time
+        roof["layer_frac"] = layer_bytes(n, e, f) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         roof["avg_launch_ms"] = d["avg_launch_ms"] if d else None
         roof["traffic"] = None
         roof["note"] = ("dominant = largest device time per step; it is the kernel closest to its roofline and its bytes are "
@@ -564,7 +595,7 @@ def main():
         out = {
             "metric": "edges/sec KAN-GIN fwd+bwd, hidden=64 grid=5, 1M-node synthetic; HBM % peak",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if world > 1 else "n/a",
             "vs_baseline": None, "dtype": ("f32" if fp32_mode else "f32 (fp16 hi/lo split operands, fp32 accumulate)") +
                                           (" + bf16 gather operands (KAGNN_ACT=bf16, build-defined config-2 mode)" if args.act == "bf16" else ""),
             "data": "synthetic",
@@ -580,10 +611,21 @@ def main():
             "fp32_mode_layer_hbm_frac": (layer_bytes(n, e, f) / (fp32_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fp32_ms else None,
             "roofline": roof,
             "roofline_kernels": kernels,
-            "entry_points_ms_per_step": per_step, "entry_points_measured_in": "3 extra untimed steps after the warm-up (HIP events around every call)",
+            "entry_points_ms_per_step": per_step,
+            "entry_points_measured_in": "3 extra untimed steps after the warm-up; kagnn_stage_timer_* (HIP events on the launch stream "
+                                        "around every stage inside the library calls)",
+            "timed_path": ("product default: one library call per convolution each way (kagnn_gin_kan_layer_fwd / _bwd)" if ops._LAYER_ABI
+                           else "composed from the per-operation entry points (KAGNN_BENCH_LAYER_ABI=0)") if world == 1 and not fastkan
+                          else "per-operation entry points (sharded / FastKAN layers)",
+            # one-time per edge_index (cached on its identity); outside the timed region
+            "graph_index_build_ms": {"steady": graph_build_ms, "first_call": graph_build_first_ms,
+                                     "what": "CSR by destination + its transpose (stable radix sort, hub segments), int64 edge_index already in HBM"},
         }
         if alt is not None:
-            out["alt_parallelism"] = alt
+            out["multi_gpu_probe"] = alt
+            ns = [p_ for p_ in alt["combinations"] if p_["scheme"] == "feature" and p_["comm"] == "rccl"]
+            if ns:
+                out["north_star_scheme"] = ns[0]
         if per_rank is not None:
             out["per_rank"] = per_rank
             out["per_rank_note"] = ("library_ms_per_step: HIP-event time of this rank's kernels (3 profile steps); not_in_library: the rest of "

@@ -43,8 +43,19 @@ extern "C" {
 #define KAGNN_DTYPE_F32 0
 #define KAGNN_DTYPE_BF16 1
 
-int kagnn_version(void);          /* 210 = this header (200 + column moments / dropout arguments, kagnn_kan_linear_fwd_moments) */
+int kagnn_version(void);          /* 220 = this header (210 + the stage timer; 210 = 200 + column moments / dropout arguments) */
 const char* kagnn_last_error(void);
+
+/* Stage timer -- a measurement aid, off by default (no reference counterpart: the reference times whole epochs with
+ * time.time(), node_classification_clean/time_model.py:38-47).  While enabled, every per-operation entry point below
+ * (aggregation, weight packs, KANLinear forward / input gradient / weight gradient, FastKAN forward / backward, BatchNorm) is
+ * bracketed by HIP events recorded on the stream it launches on -- ALSO when it runs inside kagnn_gin_kan_layer_fwd / _bwd*, so
+ * a caller can time one kernel live inside the product's one-call-per-convolution path.  `only`: NULL = every stage, else the
+ * one stage name to record (e.g. "kagnn_aggregate_sum").  kagnn_stage_timer_collect waits for the recorded events, sums them by
+ * stage name into the caller's arrays (`names`: `capacity` slots of 64 chars) and clears the records. */
+int kagnn_stage_timer_enable(const char* only);
+int kagnn_stage_timer_disable(void);
+int kagnn_stage_timer_collect(char* names, int64_t* launches, double* total_ms, int32_t capacity, int32_t* n_stages);
 
 /* ------------------------------------------------------------------------------------------
  * Graph structure.  Replaces the per-call `index_select` / `scatter_add_` bookkeeping of

@@ -24,6 +24,9 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "kagnn_version": (c_int32, []),
     "kagnn_last_error": (ctypes.c_char_p, []),
+    "kagnn_stage_timer_enable": (c_int32, [ctypes.c_char_p]),
+    "kagnn_stage_timer_disable": (c_int32, []),
+    "kagnn_stage_timer_collect": (c_int32, [_P, _P, _P, c_int32, POINTER(c_int32)]),
     "kagnn_csr_workspace_bytes": (c_int32, [c_int64, c_int64, POINTER(c_size_t)]),
     "kagnn_csr_build": (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int32, _P, c_int64,
                                   POINTER(c_int64), _P, c_size_t, _P]),

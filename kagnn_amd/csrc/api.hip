@@ -88,6 +88,52 @@ int p2p_all_gather(const float* const* shards, int P, long N, int w, long lds, f
 
 using namespace kagnn;
 
+// ---------------------------------------------------------------- stage timer (measurement aid; off by default)
+// While enabled, every per-operation entry point -- ALSO when it runs inside kagnn_gin_kan_layer_fwd / _bwd* -- is bracketed by
+// HIP events recorded on the stream it launches on, so that bench.py can time the dominant kernel live inside the timed region
+// of the product's default path (one library call per convolution each way) instead of composing the layer from per-op calls.
+#include <mutex>
+#include <string>
+#include <vector>
+namespace {
+struct StageRecord { const char* name; hipEvent_t a, b; };
+struct StageTimer {
+    std::mutex mu;
+    bool on = false;
+    std::string only;                       // empty: every stage
+    std::vector<StageRecord> rec;
+    std::vector<hipEvent_t> pool;           // events of earlier sessions, reused
+} g_stage;
+thread_local int g_stage_depth = 0;         // nested entry points (fwd_moments -> fwd): only the outermost is a stage
+constexpr size_t kStageMaxRecords = 1u << 16;
+
+struct StageScope {
+    hipStream_t st;
+    const char* name;
+    hipEvent_t b = nullptr;
+    bool outer;
+    StageScope(const char* nm, void* stream) : st(as_stream(stream)), name(nm), outer(g_stage_depth++ == 0) {
+        if (!outer || !g_stage.on) return;              // (unlocked read of a flag that only bench.py toggles, between steps)
+        std::lock_guard<std::mutex> lk(g_stage.mu);
+        if (!g_stage.on || (!g_stage.only.empty() && g_stage.only != nm) || g_stage.rec.size() >= kStageMaxRecords) return;
+        hipEvent_t ev[2];
+        for (auto& e : ev) {
+            if (!g_stage.pool.empty()) { e = g_stage.pool.back(); g_stage.pool.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) return;
+        }
+        (void)hipEventRecord(ev[0], st);
+        b = ev[1];
+        g_stage.rec.push_back(StageRecord{nm, ev[0], ev[1]});
+    }
+    ~StageScope() {
+        --g_stage_depth;
+        if (b) (void)hipEventRecord(b, st);
+    }
+};
+}  // namespace
+#define KAGNN_STAGE(stream) StageScope stage_scope_(__func__, stream)
+#define KAGNN_STAGE_AS(name, stream) StageScope stage_scope_(name, stream)
+
 static int check_kan_dims(const char* fn, int in, int out, int G, int K, int mode) {
     if (in < 1 || out < 1) return fail(KAGNN_ERR_ARG, "%s: in_features/out_features must be >= 1", fn);
     if (K < 1 || K > kMaxOrder) return fail(KAGNN_ERR_UNSUPPORTED, "%s: spline_order must be 1..4", fn);
@@ -107,8 +153,52 @@ static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode 
 #pragma GCC visibility push(default)
 extern "C" {
 
-int kagnn_version(void) { return 210; }
+int kagnn_version(void) { return 220; }
 const char* kagnn_last_error(void) { return g_err; }
+
+int kagnn_stage_timer_enable(const char* only) {
+    std::lock_guard<std::mutex> lk(g_stage.mu);
+    g_stage.only = only ? only : "";
+    g_stage.on = true;
+    return KAGNN_OK;
+}
+
+int kagnn_stage_timer_disable(void) {
+    std::lock_guard<std::mutex> lk(g_stage.mu);
+    g_stage.on = false;
+    return KAGNN_OK;
+}
+
+// Aggregates the records taken so far by stage name (waits for their events), hands the events back to the pool and clears
+// the records.  names: caller's array of `capacity` char[64] slots; returns the number of distinct stages through *n_stages.
+int kagnn_stage_timer_collect(char* names, int64_t* launches, double* total_ms, int32_t capacity, int32_t* n_stages) {
+    KAGNN_CHECK_ARG(names && launches && total_ms && n_stages && capacity >= 1, "null output");
+    std::lock_guard<std::mutex> lk(g_stage.mu);
+    int n = 0;
+    for (const StageRecord& r : g_stage.rec) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) {
+            (void)hipGetLastError();
+            ms = 0.0f;
+        }
+        int k = 0;
+        while (k < n && strncmp(names + 64 * k, r.name, 63) != 0) ++k;
+        if (k == n) {
+            if (n == capacity) continue;
+            strncpy(names + 64 * n, r.name, 63);
+            names[64 * n + 63] = 0;
+            launches[n] = 0; total_ms[n] = 0.0;
+            ++n;
+        }
+        launches[k] += 1;
+        total_ms[k] += ms;
+        g_stage.pool.push_back(r.a);
+        g_stage.pool.push_back(r.b);
+    }
+    g_stage.rec.clear();
+    *n_stages = n;
+    return KAGNN_OK;
+}
 
 int kagnn_csr_workspace_bytes(int64_t E, int64_t N, size_t* bytes) {
     KAGNN_CHECK_ARG(bytes != nullptr && E >= 0 && N >= 0, "null output or negative size");
@@ -138,6 +228,7 @@ int kagnn_aggregate_sum_add(const float* x, int64_t ldx, float* out, int64_t ldo
                             const float* bias, int32_t skip_self_loops, const int32_t* hub_seg,
                             int64_t num_hub_seg, int32_t hub_threshold, const float* addend, int64_t ld_addend,
                             void* workspace, size_t workspace_bytes, void* stream) {
+    KAGNN_STAGE_AS("kagnn_aggregate_sum", stream);
     KAGNN_CHECK_ARG(N >= 0 && F >= 1, "bad shape");
     KAGNN_CHECK_ARG(N == 0 || (x && out && rowptr), "null array");
     KAGNN_CHECK_ARG(ldx >= F && ldo >= F && (!addend || ld_addend >= F), "leading dimension smaller than num_feat");
@@ -162,6 +253,7 @@ int kagnn_aggregate_sum_bf16(const void* x, int64_t ldx, void* out, int64_t ldo,
                              const float* in_scale, const float* out_scale, const float* bias, int32_t skip_self_loops,
                              const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, void* workspace,
                              size_t workspace_bytes, void* stream) {
+    KAGNN_STAGE(stream);
     KAGNN_CHECK_ARG(N >= 0 && F >= 1, "bad shape");
     KAGNN_CHECK_ARG(N == 0 || (x && out && rowptr), "null array");
     KAGNN_CHECK_ARG(ldx >= F && ldo >= F, "leading dimension smaller than num_feat");
@@ -230,6 +322,7 @@ int kagnn_kan_pack_bytes(int32_t in, int32_t out, int32_t G, int32_t K, int32_t 
 
 int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in, int32_t out,
                    int32_t G, int32_t K, int32_t mode, void* pack_fwd, void* pack_dx, void* stream) {
+    KAGNN_STAGE(stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(sw && pack_fwd && pack_dx, "null array");          // base_weight NULL = no SiLU branch
@@ -251,6 +344,7 @@ int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in
 int kagnn_kan_pack_batch(int32_t n_layers, const float* const* bw, const float* const* sw, const float* const* sc,
                          const int32_t* in, const int32_t* out, int32_t G, int32_t K, int32_t mode,
                          void* const* pack_fwd, void* const* pack_dx, void* stream) {
+    KAGNN_STAGE(stream);
     KAGNN_CHECK_ARG(n_layers >= 1 && bw && sw && in && out && pack_fwd && pack_dx, "null array");
     for (int l = 0; l < n_layers; ++l) {
         int rc = check_kan_dims(__func__, in[l], out[l], G, K, mode);
@@ -275,6 +369,7 @@ int kagnn_kan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G,
 int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* knots, int32_t in,
                          int32_t out, int32_t G, int32_t K, int32_t mode, const void* pack_fwd,
                          float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    KAGNN_STAGE(stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldy >= out, "bad shape");
@@ -300,6 +395,7 @@ int kagnn_kan_fwd_parts_ok(const int32_t* part_widths, int32_t num_parts, int32_
 int kagnn_kan_linear_fwd_parts(const float* const* x_parts, const int32_t* part_widths, const int64_t* part_ld, int32_t num_parts,
                                int64_t N, const float* knots, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
                                const void* pack_fwd, float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    KAGNN_STAGE(stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(x_parts && part_widths && part_ld && num_parts >= 1, "null block table");
@@ -332,6 +428,7 @@ int kagnn_kan_linear_fwd_moments(const float* x, int64_t ldx, int64_t N, const f
                                  int32_t out, int32_t G, int32_t K, int32_t mode, const void* pack_fwd,
                                  float* y, int64_t ldy, float* col_mean, float* col_m2, void* ws, size_t ws_bytes,
                                  void* stream) {
+    KAGNN_STAGE(stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 1 && ldx >= in && ldy >= out, "bad shape (column moments need at least one row)");
@@ -352,6 +449,7 @@ int kagnn_kan_linear_fwd_moments(const float* x, int64_t ldx, int64_t N, const f
 int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N,
                                const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
                                int32_t mode, const void* pack_dx, void* gx, int64_t ldgx, int32_t gx_dtype, void* stream) {
+    KAGNN_STAGE(stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
@@ -382,6 +480,7 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
                                 const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
                                 int32_t mode, const float* sw, const float* sc, float* g_bw,
                                 float* g_sw, float* g_sc, void* ws, size_t ws_bytes, void* stream) {
+    KAGNN_STAGE(stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out, "bad shape");
@@ -444,6 +543,7 @@ int kagnn_fastkan_fwd(const float* x, int64_t ldx, int64_t N, int32_t in, int32_
                       const float* centers, float denominator, const float* ln_w, const float* ln_b,
                       float ln_eps, const float* spline_w, const float* base_w, const float* base_b,
                       float* y, int64_t ldy, float* row_stats, int32_t mode, void* ws, size_t ws_bytes, void* stream) {
+    KAGNN_STAGE(stream);
     int rc = check_fk(__func__, in, out, ng, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldy >= out, "bad shape");
@@ -471,6 +571,7 @@ int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy
                       const float* base_w, const float* row_stats, float* gx, int64_t ldgx,
                       float* g_ln_w, float* g_ln_b, float* g_spline_w, float* g_base_w,
                       float* g_base_b, int32_t mode, void* ws, size_t ws_bytes, void* stream) {
+    KAGNN_STAGE(stream);
     int rc = check_fk(__func__, in, out, ng, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
@@ -497,6 +598,7 @@ int kagnn_batchnorm_fwd(const float* x, int64_t ldx, int64_t N, int32_t F, const
                         const float* col_mean, const float* col_m2, float dropout_p, uint64_t dropout_seed,
                         float* y, int64_t ldy, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes,
                         void* stream) {
+    KAGNN_STAGE(stream);
     KAGNN_CHECK_ARG(N >= 0 && F >= 1 && ldx >= F && ldy >= F, "bad shape");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && y && save_mean && save_rstd && ws, "null array");
@@ -513,6 +615,7 @@ int kagnn_batchnorm_bwd(const float* x, int64_t ldx, const float* gy, int64_t ld
                         float dropout_p, uint64_t dropout_seed,
                         float* gx, int64_t ldgx, float* g_weight, float* g_bias, void* ws, size_t ws_bytes,
                         void* stream) {
+    KAGNN_STAGE(stream);
     KAGNN_CHECK_ARG(N >= 0 && F >= 1 && ldx >= F && ldgy >= F && (gx == nullptr || ldgx >= F), "bad shape");
     if (N == 0) return KAGNN_OK;
     KAGNN_CHECK_ARG(x && gy && save_mean && save_rstd && ws, "null array");
@@ -601,12 +704,14 @@ int kagnn_softmax_xent_bwd(const float* logits, int64_t ld, int64_t N, int32_t C
 
 int kagnn_p2p_reduce_scatter(const float* const* parts, int32_t world, int32_t rank, int64_t N, int32_t out, int64_t ld, float* y,
                              int64_t ldy, void* stream) {
+    KAGNN_STAGE(stream);
     KAGNN_CHECK_ARG(parts && N >= 0 && out >= 1 && ld >= out && (N == 0 || y), "bad argument");
     return p2p_reduce_scatter(parts, world, rank, N, out, ld, y, ldy, as_stream(stream));
 }
 
 int kagnn_p2p_all_gather(const float* const* shards, int32_t world, int64_t N, int32_t w, int64_t lds, float* g, int64_t ldg,
                          void* stream) {
+    KAGNN_STAGE(stream);
     KAGNN_CHECK_ARG(shards && N >= 0 && w >= 1 && lds >= w && ldg >= (int64_t)w * world && (N == 0 || g), "bad argument");
     return p2p_all_gather(shards, world, N, w, lds, g, ldg, as_stream(stream));
 }
@@ -695,6 +800,7 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
     for (int l = 0; l < L; ++l) {
         if (l == 0 && fuse) {
             const size_t fw_b = need_f - 256 - hub_b - al256z(kan_sparse_fwd_agg_ws_bytes(num_hub_seg, widths[0], widths[1]));
+            KAGNN_STAGE_AS("kagnn_kan_linear_fwd+aggregate_sum (one kernel)", stream);
             rc = kan_sparse_fwd_agg(static_cast<const float*>(x), ldx, N, rowptr, col, hub_seg, num_hub_seg, hub_threshold, self_scale,
                                     knots, in_[0], out_[0], G, K, pack_fwd[0], acts[0], in_[0], acts[1], out_[0],
                                     ws + hub_b + fw_b, need_f - hub_b - fw_b, as_stream(stream));
@@ -766,12 +872,14 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
         bn_in_dx = mode == KAGNN_PREC_SPLIT && use_split_dx(in, out, G, K, mode) && out <= wmax && !(L == 1 && (gx == nullptr || bf16_gather)) &&
                    fits32(N, ldg) && kan_split_dx_bn_ok(ldg, in, out, G, K, bnb, g);
         if (bn_in_dx) {
+            KAGNN_STAGE_AS("batchnorm backward statistics (inside kagnn_gin_kan_layer_bwd_bn)", stream);
             rc = bn_bwd_stats(bn->y, bn->ldy, g, ldg, N, out, bn->weight, bn->mean, bn->rstd, bn->g_weight, bn->g_bias, tab, ldt, bws,
                               bn_ws_bytes(N, out), as_stream(stream));
             if (rc) return rc;
         } else {
             // (out may exceed the chain's widest INPUT, which sizes the ping-pong matrices: then the stage's own matrix is needed)
             if (out > wmax) return fail(KAGNN_ERR_UNSUPPORTED, "%s: a BatchNorm stage wider than every layer input is not covered", fn);
+            KAGNN_STAGE_AS("kagnn_batchnorm_bwd", stream);
             rc = bn_bwd(bn->y, bn->ldy, g, ldg, N, out, bn->weight, bn->mean, bn->rstd, 1, 0.0f, 0ULL, reinterpret_cast<float*>(gbuf[1]), out,
                         bn->g_weight, bn->g_bias, bws, bn_ws_bytes(N, out), as_stream(stream));
             if (rc) return rc;
@@ -782,8 +890,11 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
         const int in = widths[l], out = widths[l + 1];
         const bool fused_bn = bn_in_dx && l == L - 1;
         if (fused_bn) {            // input gradient FIRST: it produces the normalised-backward rows the weight gradient reads
-            rc = kan_split_dx_bn(acts[l], in, g, ldg, N, knots, in, out, G, K, pack_dx[l], reinterpret_cast<float*>(gbuf[0]), in, bnb,
-                                 as_stream(stream));
+            {
+                KAGNN_STAGE_AS("kagnn_kan_linear_bwd_input", stream);       // (+ the norm's element-wise backward on the rows it loads)
+                rc = kan_split_dx_bn(acts[l], in, g, ldg, N, knots, in, out, G, K, pack_dx[l], reinterpret_cast<float*>(gbuf[0]), in, bnb,
+                                     as_stream(stream));
+            }
             if (rc) return rc;
             rc = kagnn_kan_linear_bwd_weight(acts[l], in, bnb.gy_out, bnb.ldo, N, knots, in, out, G, K, mode, sw[l], sc ? sc[l] : nullptr,
                                              g_bw ? g_bw[l] : nullptr, g_sw[l], g_sc ? g_sc[l] : nullptr, ws + hub_b, dw_b, stream);

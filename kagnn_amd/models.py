@@ -62,7 +62,8 @@ _FUSED_LAYER = os.environ.get("KAGNN_FUSED_LAYER", "1") != "0"       # GIN + KAN
 _SPLIT_READOUT_MIN_ROWS = int(os.environ.get("KAGNN_SPLIT_READOUT_MIN_ROWS", "400000"))
 # ... from this many rows when the blocks run as ONE forward launch and hand their gradients to the convolutions
 # (ops.kan_linear_parts / ops.SkipGradient; crossover measured with tools/split_readout_probe.py: 100k rows even, 170k -6 %)
-_SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH = int(os.environ.get("KAGNN_SPLIT_READOUT_MIN_ROWS", "120000"))
+_SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH = int(os.environ.get("KAGNN_SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH",
+                                                        os.environ.get("KAGNN_SPLIT_READOUT_MIN_ROWS", "120000")))
 _SKIP_GRADIENT = os.environ.get("KAGNN_SKIP_GRADIENT", "1") != "0"     # skip-branch gradient added inside the next convolution's backward
 _FUSED_EPILOGUE = os.environ.get("KAGNN_FUSED_EPILOGUE", "1") != "0"  # conv -> BatchNorm1d -> dropout: statistics + mask fused
 

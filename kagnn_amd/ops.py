@@ -52,6 +52,37 @@ class EntryPointTimer:
         return {k: {"launches": v[0], "total_ms": v[1], "avg_ms": v[1] / v[0]} for k, v in out.items()}
 
 
+class LibraryStageTimer:
+    """Per-stage device timing INSIDE the library (``kagnn_stage_timer_*``): HIP events on the launch stream around every
+    per-operation entry point, also when it runs inside the one-call layer entry points -- what ``bench.py`` uses to time the
+    dominant kernel live on the product's default path (``KAGNN_LAYER_ABI=1``).  ``only``: record just this stage."""
+
+    def __init__(self, only: Optional[str] = None):
+        self.only = only
+
+    def __enter__(self):
+        _lib.call("kagnn_stage_timer_enable", None if self.only is None else self.only.encode())
+        return self
+
+    def __exit__(self, *exc):
+        _lib.call("kagnn_stage_timer_disable")
+        return False
+
+    @staticmethod
+    def collect(capacity: int = 64):
+        """{stage: {"launches", "total_ms", "avg_ms"}} of everything recorded since the last collect (waits for the events)"""
+        names = ctypes.create_string_buffer(64 * capacity)
+        launches = (c_int64 * capacity)()
+        total = (ctypes.c_double * capacity)()
+        n = ctypes.c_int32(0)
+        _lib.call("kagnn_stage_timer_collect", names, launches, total, capacity, byref(n))
+        out = {}
+        for i in range(n.value):
+            name = names.raw[64 * i:64 * (i + 1)].split(b"\0", 1)[0].decode()
+            out[name] = {"launches": int(launches[i]), "total_ms": float(total[i]), "avg_ms": float(total[i]) / max(1, int(launches[i]))}
+        return out
+
+
 _timer: Optional[EntryPointTimer] = None
 
 
@@ -751,7 +782,7 @@ class _GinKanLayerFn(Function):
         gx_dtype = torch.bfloat16 if x_dtype == torch.bfloat16 else torch.float32
         addend = None
         if ctx.skip_gradient is not None:
-            addend, ctx.skip_gradient.grad = ctx.skip_gradient.grad, None
+            addend = ctx.skip_gradient.take()
             if addend is not None:
                 addend = _rows(addend)
                 if addend.shape != (gy.size(0), widths[0]) or not need_x:
@@ -851,7 +882,7 @@ class _GinKanBnLayerFn(Function):
         gx_dtype = torch.bfloat16 if x_dtype == torch.bfloat16 else torch.float32
         addend = None
         if ctx.skip_gradient is not None:
-            addend, ctx.skip_gradient.grad = ctx.skip_gradient.grad, None
+            addend = ctx.skip_gradient.take()
             if addend is not None:
                 addend = _rows(addend)
                 if addend.shape != (gh.size(0), widths[0]) or not need_x:
@@ -896,11 +927,23 @@ class SkipGradient:
     (``_KANLinearPartsFn``) -- whose backward always runs first, the convolution's output feeds it -- leaves its gradient of
     ``h_l`` in ``grad`` and reports none to the tape; the convolution's backward adds it inside the transposed aggregation's
     epilogue (``kagnn_gin_kan_layer_bwd_add``).  Bit-identical to the separate sum."""
-    __slots__ = ("grad", "consumer")
+    __slots__ = ("grad", "consumer", "task")
 
     def __init__(self):
         self.grad = None
         self.consumer = False
+        self.task = -1                  # the engine run (graph task id) that parked ``grad``
+
+    def park(self, grad) -> None:
+        self.grad, self.task = grad, torch._C._current_graph_task_id()
+
+    def take(self):
+        """the parked gradient if THIS backward pass parked it, else None; always leaves the object empty.  A pass that
+        prunes the consumer (``backward(inputs=[...])``) leaves a parked gradient behind: a later pass must not add it to a
+        loss it does not belong to -- it is dropped here instead."""
+        g, t = self.grad, self.task
+        self.grad, self.task = None, -1
+        return g if t == torch._C._current_graph_task_id() else None
 
 
 _KNOTS_EQUAL: dict = {}
@@ -1092,7 +1135,8 @@ class _KANLinearPartsFn(Function):
                 gx = _kan_bwd_input_raw(part, gy, knots, pack_d, widths[i], fout, G, K, mode)
                 sk = ctx.skip_gradients[i] if ctx.skip_gradients is not None else None
                 if sk is not None and sk.consumer:         # the convolution that consumed this block adds it in its own backward
-                    sk.grad, gx = gx, None
+                    sk.park(gx)
+                    gx = None
             gxs.append(gx)
             if want_w:
                 gbw, gsw, gsc = _kan_bwd_weight_raw(part, gy, knots, swp, scp, widths[i], fout, G, K, mode, True)

@@ -48,31 +48,48 @@ class PeerBuffers:
         return self._ptrs
 
 
+_BARRIER_TOKEN: dict = {}
+
+
 def rank_barrier(group=None) -> None:
-    """every rank's device work enqueued so far is complete on all ranks after this (stream-ordered with RCCL: a one-element
-    all-reduce on the current stream; host-side with any other backend)"""
+    """every rank's device work enqueued so far on the CURRENT stream is complete on all ranks after this (stream-ordered with
+    RCCL: a one-element all-reduce on the current stream -- the token tensor is allocated once per device; host-side with any
+    other backend)"""
     if dist.get_backend(group) == "nccl":
-        t = torch.zeros(1, device=torch.device("cuda", torch.cuda.current_device()))
+        dev = torch.cuda.current_device()
+        t = _BARRIER_TOKEN.get(dev)
+        if t is None:
+            t = _BARRIER_TOKEN[dev] = torch.zeros(1, device=torch.device("cuda", dev))
         dist.all_reduce(t, group=group)
     else:
         torch.cuda.current_stream().synchronize()
         dist.barrier(group=group)
 
 
-def reduce_scatter(bufs: PeerBuffers, n: int, out: int) -> torch.Tensor:
-    """rank r's column block of the sum over ranks of the ``[n, out]`` partial matrices sitting in ``bufs``"""
+def reduce_scatter(bufs: PeerBuffers, n: int, out: int, rows=None, y: torch.Tensor = None) -> torch.Tensor:
+    """rank r's column block of the sum over ranks of the ``[n, out]`` partial matrices sitting in ``bufs``; ``rows=(r0, r1)``
+    pulls that row range only (into ``y[r0:r1]`` when ``y`` is given: the row-chunked exchange)"""
     w = out // bufs.world
-    y = torch.empty((n, w), dtype=torch.float32, device=bufs.device)
-    with ops._device_of(y):
-        ops._call("kagnn_p2p_reduce_scatter", bufs.ptr_array(), bufs.world, bufs.rank, n, out, out, ops._ptr(y), w, ops._stream())
+    r0, r1 = (0, n) if rows is None else rows
+    if y is None:
+        y = torch.empty((n, w), dtype=torch.float32, device=bufs.device)
+    if r1 > r0:
+        with ops._device_of(y):
+            ops._call("kagnn_p2p_reduce_scatter", _shifted(bufs, [r0 * out] * bufs.world), bufs.world, bufs.rank, r1 - r0, out, out,
+                      y.data_ptr() + 4 * r0 * w, w, ops._stream())
     return y
 
 
-def all_gather(bufs: PeerBuffers, n: int, w: int) -> torch.Tensor:
-    """``[n, world*w]``: the ``[n, w]`` shards sitting in ``bufs``, side by side in rank order"""
-    g = torch.empty((n, w * bufs.world), dtype=torch.float32, device=bufs.device)
-    with ops._device_of(g):
-        ops._call("kagnn_p2p_all_gather", bufs.ptr_array(), bufs.world, n, w, w, ops._ptr(g), w * bufs.world, ops._stream())
+def all_gather(bufs: PeerBuffers, n: int, w: int, rows=None, g: torch.Tensor = None) -> torch.Tensor:
+    """``[n, world*w]``: the ``[n, w]`` shards sitting in ``bufs``, side by side in rank order; ``rows=(r0, r1)`` pulls that row
+    range only (into ``g[r0:r1]`` when ``g`` is given)"""
+    r0, r1 = (0, n) if rows is None else rows
+    if g is None:
+        g = torch.empty((n, w * bufs.world), dtype=torch.float32, device=bufs.device)
+    if r1 > r0:
+        with ops._device_of(g):
+            ops._call("kagnn_p2p_all_gather", _shifted(bufs, [r0 * w] * bufs.world), bufs.world, r1 - r0, w, w,
+                      g.data_ptr() + 4 * r0 * w * bufs.world, w * bufs.world, ops._stream())
     return g
 
 

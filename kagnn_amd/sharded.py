@@ -128,42 +128,109 @@ class _Finish(Function):
         return (None, None, *pieces)
 
 
-class _P2PReduceScatter(Function):
-    """the direct peer-to-peer form of one KANLinear's exchange (``comm="p2p"``): ``partial`` already sits in this rank's
-    peer-mapped buffer (the KAN forward wrote it there); forward = rank barrier + ONE kernel that reads every peer's column
-    block and sums in rank order (``kagnn_p2p_reduce_scatter``: no rank-major staging copy, no ring); backward = this rank's
-    gradient shard into its peer-mapped buffer, rank barrier, ONE kernel that pulls all shards into the final ``[n, out]``
-    layout (``kagnn_p2p_all_gather``: no un-permute)."""
+class _P2PStep:
+    """one use of a KANLinear's peer-to-peer exchange (one forward call and the backward that belongs to it): which of the two
+    partial-sum buffers it writes, the output / gathered-gradient tensors the pull kernels fill, the row chunks and the
+    events the compute stream waits on"""
+
+    def __init__(self, xch, n, out, bounds, device):
+        self.xch, self.n, self.out, self.bounds = xch, n, out, bounds
+        self.w = out // xch.world
+        self.part = xch.part[xch.fwd_uses & 1]
+        xch.fwd_uses += 1
+        self.y = torch.empty((n, self.w), dtype=torch.float32, device=device)
+        self.g_full = None
+        self.g_ready = []
+
+
+class _P2PPullChunk(Function):
+    """rows [r0, r1) of one KANLinear's exchange in its direct peer-to-peer form (``comm="p2p"``).  The KAN forward has just
+    written this rank's partial sums of those rows into its peer-mapped buffer; on the layer's SIDE stream: wait for that
+    kernel only, rank barrier (every rank's rows are complete), ONE kernel that reads every peer's column block of the rows
+    and sums in rank order (``kagnn_p2p_reduce_scatter``: no rank-major staging copy, no ring).  The compute stream goes on
+    with the KAN kernel of the next chunk -- the pull of chunk i runs beside the compute of chunk i+1.
+    Backward: hands out the rows of the gathered gradient that ``_P2PJoin.backward`` requested ahead, after waiting for THIS
+    chunk's pull only."""
 
     @staticmethod
-    def forward(ctx, partial, xch):
+    def forward(ctx, partial, step, chunk):
         from . import p2p
-        n, out = partial.shape
-        p2p.rank_barrier(xch.group)                   # every rank's partial sums are complete
-        y = p2p.reduce_scatter(xch.part, n, out)
-        ctx.xch, ctx.n, ctx.out = xch, n, out
-        return y
+        xch = step.xch
+        r0, r1 = step.bounds[chunk]
+        ev = torch.cuda.Event()
+        ev.record()                                   # the KAN kernel that produced these rows
+        with torch.cuda.stream(xch.side):
+            xch.side.wait_event(ev)
+            p2p.rank_barrier(xch.group)
+            p2p.reduce_scatter(step.part, step.n, step.out, rows=(r0, r1), y=step.y)
+        ctx.step, ctx.chunk = step, chunk
+        return step.y[r0:r1]
 
     @staticmethod
-    def backward(ctx, g_shard):
+    def backward(ctx, _g_piece):
+        step = ctx.step
+        r0, r1 = step.bounds[ctx.chunk]
+        torch.cuda.current_stream().wait_event(step.g_ready[ctx.chunk])
+        return step.g_full[r0:r1], None, None
+
+
+class _P2PJoin(Function):
+    """forward: the compute stream waits for the pulls of all row chunks and hands out the assembled ``[n, out/P]`` shard.
+    backward (runs FIRST on the way back): this rank's gradient shard goes into one of its two peer-mapped gradient buffers,
+    then on the side stream one rank barrier and, chunk by chunk, ONE kernel that pulls all ranks' shards of the rows into
+    the final ``[rows, out]`` layout (``kagnn_p2p_all_gather``: no un-permute) -- chunk i+1 is pulled while the dX / dW
+    kernels of chunk i run."""
+
+    @staticmethod
+    def forward(ctx, step, *parts):
+        done = torch.cuda.Event()
+        done.record(step.xch.side)
+        torch.cuda.current_stream().wait_event(done)
+        ctx.step = step
+        return step.y.view_as(step.y)
+
+    @staticmethod
+    def backward(ctx, g):
         from . import p2p
-        xch, n, out = ctx.xch, ctx.n, ctx.out
-        w = out // xch.part.world
-        xch.grad.local[: n * w].view(n, w).copy_(g_shard)
-        p2p.rank_barrier(xch.group)
-        g = p2p.all_gather(xch.grad, n, w)
-        return g, None
+        step = ctx.step
+        xch, n, w = step.xch, step.n, step.w
+        buf = xch.grad[xch.bwd_uses & 1]
+        xch.bwd_uses += 1
+        buf.local[: n * w].view(n, w).copy_(g)
+        step.g_full = torch.empty((n, step.out), dtype=torch.float32, device=g.device)
+        ev = torch.cuda.Event()
+        ev.record()
+        step.g_ready = []
+        with torch.cuda.stream(xch.side):
+            xch.side.wait_event(ev)
+            p2p.rank_barrier(xch.group)
+            for r0, r1 in step.bounds:
+                p2p.all_gather(buf, n, w, rows=(r0, r1), g=step.g_full)
+                e = torch.cuda.Event()
+                e.record()
+                step.g_ready.append(e)
+        return (None, *[g[r0:r1] for r0, r1 in step.bounds])
 
 
 class _P2PExchange:
-    """the two peer-mapped buffers of one KANLinear of the feature-sharded layer: partial sums [n, out] and gradient shards
-    [n, out/P]; allocated (and their IPC handles exchanged) once per (layer, row count)"""
+    """the peer-mapped buffers of one KANLinear of the feature-sharded layer: partial sums [n, out] and gradient shards
+    [n, out/P], TWO of each, used alternately (allocated, and their IPC handles exchanged, once per (layer, row count)).
 
-    def __init__(self, n: int, out: int, device, group):
+    Why two: an exchange is  write own buffer -> rank barrier -> pull from the peers.  Nothing after the pull tells
+    a rank that its PEERS have finished reading its buffer, so writing the same buffer again is only safe after a later
+    barrier -- which a chain with ONE exchange per step (``nb_layers=1`` under ``no_grad``) does not have.  With alternating
+    buffers the next write of buffer b comes two uses later, and the use in between contains a barrier that every rank
+    enters only after its own pulls of the earlier use (same side stream, stream order) -- and this rank's compute stream
+    joins that side stream before the later write."""
+
+    def __init__(self, n: int, out: int, device, group, side):
         from . import p2p
-        self.group, self.n, self.out = group, n, out
-        self.part = p2p.PeerBuffers(n * out, device, group)
-        self.grad = p2p.PeerBuffers(n * (out // self.part.world), device, group)
+        self.group, self.n, self.out, self.side = group, n, out, side
+        self.world = dist.get_world_size(group)
+        self.part = [p2p.PeerBuffers(n * out, device, group) for _ in range(2)]
+        self.grad = [p2p.PeerBuffers(n * (out // self.world), device, group) for _ in range(2)]
+        self.fwd_uses = 0
+        self.bwd_uses = 0
 
 
 def _chunk_bounds(n: int, chunks: int):
@@ -196,9 +263,14 @@ class ShardedKANLinear(nn.Module):
         self.register_buffer("knots", full.grid[0].detach().clone())
         self.precision = full.precision
 
-    def forward(self, x_shard: torch.Tensor, local_ops) -> torch.Tensor:
+    def forward(self, x_shard: torch.Tensor, local_ops, packed=None, out=None) -> torch.Tensor:
+        kw = {}
+        if packed is not None:
+            kw["packed"] = packed                     # this step's weight packs, made once for all row chunks
+        if out is not None:
+            kw["out"] = out                           # the partial sums written straight into a (peer-mapped) buffer
         return local_ops.kan_linear(x_shard, self.base_weight, self.spline_weight, self.spline_scaler,
-                                    self.knots, self.grid_size, self.spline_order, self.precision)
+                                    self.knots, self.grid_size, self.spline_order, self.precision, **kw)
 
 
 class ShardedGIKANLayer(nn.Module):
@@ -218,36 +290,72 @@ class ShardedGIKANLayer(nn.Module):
             raise ValueError("comm must be 'rccl' or 'p2p'")
         self.comm = comm
         self._xch = {}
+        self._side = None                  # ONE side stream for all exchanges of this layer (their order is part of the buffer-reuse argument)
         self.group = group
         self.chunks = chunks
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.local_ops = _hip_ops if local_ops is None else local_ops
         self.eps = float(conv.eps)
+        if comm == "p2p":
+            # checked here, not in the middle of a forward: what the pull kernels and kan_linear(out=) need
+            if self.world > 16:
+                raise ValueError("comm='p2p' supports at most 16 ranks (kagnn_p2p_*: peer pointer table)")
+            if self.local_ops is not _hip_ops:
+                raise ValueError("comm='p2p' needs the HIP ops (kan_linear(out=) writes into the peer-mapped buffer)")
+            for l in conv.nn.layers:
+                if l.out_features % self.world or (l.out_features // self.world) % 4:
+                    raise ValueError(f"comm='p2p': out_features / world = {l.out_features}/{self.world} must be a multiple of 4 "
+                                     "(16-byte pulls); use comm='rccl' for this layer")
+                if l.grid_size + l.spline_order > 16:
+                    raise ValueError("comm='p2p': layers with more than 16 coefficients run as summed groups and cannot write "
+                                     "into a caller's buffer; use comm='rccl'")
         self.layers = nn.ModuleList(ShardedKANLinear(l, self.rank, self.world) for l in conv.nn.layers)
 
     def shard_columns(self, t: torch.Tensor) -> torch.Tensor:
         w = t.size(1) // self.world
         return t[:, self.rank * w:(self.rank + 1) * w].contiguous()
 
+    def _exchange(self, li: int, n: int, out: int, device) -> "_P2PExchange":
+        """the peer-mapped buffers of layer ``li`` at row count ``n`` (collective: every rank reaches this at the same layer and
+        row count).  One row count is kept per layer: a new one replaces the old buffers instead of piling up."""
+        hit = self._xch.get(li)
+        if hit is None or hit.n != n:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=device)
+            hit = self._xch[li] = _P2PExchange(n, out, device, self.group, self._side)
+        return hit
+
     def forward(self, x_shard: torch.Tensor, graph) -> torch.Tensor:
         h = self.local_ops.aggregate_sum(x_shard, graph, self_scale=1.0 + self.eps)
         n = h.size(0)
+        bounds = _chunk_bounds(n, self.chunks if self.chunks is not None else (4 if n >= 262144 else 1))
+        # the weight packs of the whole chain in ONE launch, shared by all row chunks (otherwise every chunk packs again)
+        packs = None
+        pack_chain = getattr(self.local_ops, "kan_pack_chain", None)
+        if pack_chain is not None and h.is_cuda:
+            first = self.layers[0]
+            mode = first.precision if first.precision is not None else self.local_ops.default_precision()
+            if all(l.spline_scaler is not None and l.grid_size == first.grid_size and l.spline_order == first.spline_order
+                   and l.precision == first.precision for l in self.layers):
+                packs = pack_chain([(l.base_weight, l.spline_weight, l.spline_scaler) for l in self.layers],
+                                   first.grid_size, first.spline_order, mode)
         if self.comm == "p2p":
             for li, layer in enumerate(self.layers):
-                key = (li, n)
-                if key not in self._xch:              # (collective: every rank reaches this at the same layer and row count)
-                    self._xch[key] = _P2PExchange(n, layer.out_features, h.device, self.group)
-                xch = self._xch[key]
-                partial = self.local_ops.kan_linear(h, layer.base_weight, layer.spline_weight, layer.spline_scaler, layer.knots,
-                                                    layer.grid_size, layer.spline_order, layer.precision,
-                                                    out=xch.part.local[: n * layer.out_features].view(n, layer.out_features))
-                h = _P2PReduceScatter.apply(partial, xch)
+                out = layer.out_features
+                step = _P2PStep(self._exchange(li, n, out, h.device), n, out, bounds, h.device)
+                rows = step.part.local[: n * out].view(n, out)
+                parts = []
+                for i, (r0, r1) in enumerate(bounds):
+                    # the KAN forward writes its partial sums STRAIGHT into the peer-mapped buffer
+                    partial = layer(h[r0:r1], self.local_ops, None if packs is None else packs[li], out=rows[r0:r1])
+                    parts.append(_P2PPullChunk.apply(partial, step, i))
+                h = _P2PJoin.apply(step, *parts)
             return h
-        bounds = _chunk_bounds(n, self.chunks if self.chunks is not None else (4 if n >= 262144 else 1))
-        for layer in self.layers:
+        for li, layer in enumerate(self.layers):
             comm = _Comm(self.group)
-            parts = [_ReduceScatterChunk.apply(layer(h[r0:r1], self.local_ops), comm, i) for i, (r0, r1) in enumerate(bounds)]
+            parts = [_ReduceScatterChunk.apply(layer(h[r0:r1], self.local_ops, None if packs is None else packs[li]), comm, i)
+                     for i, (r0, r1) in enumerate(bounds)]
             h = _Finish.apply(comm, bounds, *parts)
         return h
 
@@ -335,6 +443,9 @@ class _P2PTransposeExchange:
         self.rows = [p2p.PeerBuffers(max(self.splits) * w * world, device, group) for _ in range(2)]
 
     def run(self, x, to_rows, n, fwd):
+        # (buffer reuse: every buffer here is written once per step and the layer runs TWO exchanges per direction -- in and
+        # out, each with its rank barrier -- so a rank's next write of a buffer always follows a later barrier that its peers
+        # entered after their pulls of the previous use; no double buffering needed, unlike _P2PExchange)
         from . import p2p
         k = 0 if fwd else 1
         if to_rows:
@@ -403,7 +514,7 @@ class TransposedShardedGIKANLayer(nn.Module):
                 raise ValueError("layer widths must be divisible by the world size")
         import copy
         self.layers = nn.ModuleList(copy.deepcopy(l) for l in conv.nn.layers)      # replicated parameters
-        self._flat_pending = None          # gradients as they stood when this backward pass reached the module
+        self._flat_pending = None          # (engine run id, gradients as they stood when that backward pass reached the module)
 
     def _arm_flat_sync(self) -> None:
         """called by the first backward node of this module an engine run reaches (before any of the run's parameter
@@ -411,14 +522,20 @@ class TransposedShardedGIKANLayer(nn.Module):
         end-of-backward callback.  The callback all-reduces only what this pass added -- with gradient accumulation
         (two backward() calls without zero_grad) or the module used twice in one forward, already-synced sums must not
         be summed over the ranks again (P*S1 + S2 instead of S1 + S2)."""
-        if self._flat_pending is not None:
+        run = torch._C._current_graph_task_id()
+        if self._flat_pending is not None and self._flat_pending[0] == run:
             return                         # a later use of the module in the same pass: already armed
+        # (a latch left by ANOTHER engine run is stale: that backward raised, and the engine dropped its queued callbacks --
+        # ADVICE r03: keyed on a plain flag, every later pass returned above and the gradients silently stopped being
+        # summed over the ranks)
         from torch.autograd import Variable
-        self._flat_pending = [None if p.grad is None else p.grad.detach().clone() for p in self.parameters()]
-        Variable._execution_engine.queue_callback(self._flat_sync_delta)
+        self._flat_pending = (run, [None if p.grad is None else p.grad.detach().clone() for p in self.parameters()])
+        Variable._execution_engine.queue_callback(lambda run=run: self._flat_sync_delta(run))
 
-    def _flat_sync_delta(self) -> None:
-        prev, self._flat_pending = self._flat_pending, None
+    def _flat_sync_delta(self, run: int) -> None:
+        if self._flat_pending is None or self._flat_pending[0] != run:
+            return
+        prev, self._flat_pending = self._flat_pending[1], None
         params = [p for p in self.parameters()]
         live = [(p, b) for p, b in zip(params, prev) if p.grad is not None]
         if not live:

@@ -57,7 +57,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
         raise AssertionError(f"unclassified C parameter: {param}")
 
     def kind_py(t):
-        if t in (ctypes.c_void_p,) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
             return "ptr"
         return {ctypes.c_int64: "i64", ctypes.c_uint64: "i64", ctypes.c_size_t: "size", ctypes.c_float: "f32",
                 ctypes.c_int32: "i32"}[t]
