@@ -55,7 +55,7 @@ __global__ void split_pack_fwd_kernel(const float* __restrict__ bw, const float*
     const int SPC = CF / 2, BPC = CF / 16;
     unsigned* hdr = reinterpret_cast<unsigned*>(pack);
     __shared__ float s_m[17];
-    const float wmax = self_scale ? block_absmax_w(bw, sw, sc, in, out, C, s_m) : __uint_as_float(hdr[2]);
+    const float wmax = self_scale == 2 ? header_absmax(pack) : self_scale ? block_absmax_w(bw, sw, sc, in, out, C, s_m) : __uint_as_float(hdr[2]);
     const int e = scale_exp_from_max(wmax);
     const float wscale = ldexpf(1.0f, -e);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -389,8 +389,10 @@ int kan_split_pack_fwd_noscale(const float* bw, const float* sw, const float* sc
         const long o0 = (long)b * kOutBlk;
         unsigned char* pf = static_cast<unsigned char*>(pack_fwd) + b * stride;
         const long items = (long)(fwd_blk_bytes(in, ob, C) - kHdrBytes) / 16;
-        split_pack_fwd_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(
-            bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C, pf, 1);
+        const bool two = (long)in * ob * C >= kAbsmaxTwoLaunchMin;      // large blocks: partial maxima first (split_common.h)
+        if (two) { int rc = launch_absmax_partials(bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C, pf, st); if (rc) return rc; }
+        split_pack_fwd_kernel<<<(int)min((items + 1023) / 1024, two ? 256L : 64L), 1024, 0, st>>>(
+            bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C, pf, two ? 2 : 1);
         KAGNN_LAUNCH_CHECK();
     }
     return KAGNN_OK;

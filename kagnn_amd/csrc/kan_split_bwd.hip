@@ -14,6 +14,7 @@
 // fixed order (deterministic).
 //
 // Reference behaviour replaced: the autograd backward of node_classification_clean/ekan.py:154-162.
+#include <type_traits>
 #include "split_common.h"
 
 namespace kagnn {
@@ -45,7 +46,7 @@ __global__ void split_pack_dx_kernel(const float* __restrict__ bw, const float* 
                                      unsigned char* __restrict__ pack, int self_scale, int w2) {
     unsigned* hdr = reinterpret_cast<unsigned*>(pack);
     __shared__ float s_m[17];
-    const float wmax = self_scale ? block_absmax_w(bw, sw, sc, in, out, C, s_m) : __uint_as_float(hdr[2]);
+    const float wmax = self_scale == 2 ? header_absmax(pack) : self_scale ? block_absmax_w(bw, sw, sc, in, out, C, s_m) : __uint_as_float(hdr[2]);
     const int e = scale_exp_from_max(wmax);
     const float wscale = ldexpf(1.0f, -e);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -64,9 +65,11 @@ int kan_split_pack_dx_noscale(const float* bw, const float* sw, const float* sc,
         const int ob = min(kOutBlk, out - b * kOutBlk), Q2 = dx_q2(ob);
         const long o0 = (long)b * kOutBlk;
         const long items = (long)cdiv(inv, 16) * kCTmax * Q2 * 64;
-        split_pack_dx_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(
-            bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C, Q2,
-            static_cast<unsigned char*>(pack_dx) + b * stride, 1, w2);
+        const bool two = (long)in * ob * C >= kAbsmaxTwoLaunchMin;      // large blocks: partial maxima first (split_common.h)
+        unsigned char* pd = static_cast<unsigned char*>(pack_dx) + b * stride;
+        if (two) { int rc = launch_absmax_partials(bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C, pd, st); if (rc) return rc; }
+        split_pack_dx_kernel<<<(int)min((items + 1023) / 1024, two ? 256L : 64L), 1024, 0, st>>>(
+            bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C, Q2, pd, two ? 2 : 1, w2);
         KAGNN_LAUNCH_CHECK();
     }
     return KAGNN_OK;
@@ -1103,6 +1106,294 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
 #undef Dh
 
 // ---------------------------------------------------------------------------------------------------------------
+// Weight gradient for WIDE layers (two or more 64-output chunks: FastKAN hidden 256 = BASELINE config 5, KAN layers of
+// 128 / 256 outputs with <= 8 coefficients).  kan_split_dw_kernel gives every 64-output chunk a workgroup of its own, and
+// each of them expands the bases of the same x rows again: at 256 outputs the expansion -- span / cubic pieces or
+// LayerNorm + 8 exponentials, hi/lo split, (row, slot) transposition: ~3/4 of the kernel's VALU instructions -- ran four
+// times per scalar (config 5 spent 23 % of its epoch here).  In this kernel the SH waves that own the SH output chunks of ONE
+// 16-feature tile share the expansion through LDS: the rows go in groups of SH 32-row chunks; wave k of the team expands
+// chunk k of the group ONCE, stores the ready A fragments (8 slot planes x hi/lo + the SiLU plane: 18 x 16 B per lane,
+// already transposed, lane-contiguous: conflict-free ds_write_b128 / ds_read_b128), one workgroup barrier, and every
+// wave runs the MFMAs of all SH chunks against its own gy columns.  Two fragment buffers alternate between groups, so one
+// barrier per group is enough: a wave writes buffer b again only after the barrier of the group in between, which every
+// wave enters after its reads of b.  The accumulators, the gy side, the running power-of-two scale, the slab layout and
+// the summation order over rows are those of kan_split_dw_kernel: same slabs, bit for bit.
+constexpr int kDwShVecs = 18;                                  // u32x4 per lane and chunk: 8 planes x (hi, lo) + silu (hi, lo)
+constexpr int kDwShChunkBytes = kDwShVecs * 64 * 16;           // 18 KiB
+constexpr int kDwShFlagOff = 2304;                             // free bytes of the LDS header: base32 flags [tile][buf][chunk]
+constexpr size_t kDwShLds = kLdsHdr + 8 * (size_t)kDwShChunkBytes;   // (4/SH tiles) x 2 buffers x SH chunks = 8 chunk slots
+
+template <int K, int SH>      // K: 0 (RBF) or 3 (cubic), <= 8 coefficients; SH: 2 or 4 output chunks per feature tile
+__global__ __launch_bounds__(256, 1) void kan_split_dw_shared_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
+    int out, int C, const float* __restrict__ knots_g, int nknots, int OC, long rows_per_block,
+    long inP, long outP, float* __restrict__ slab, RbfArgs rb) {
+    constexpr int NTO = 4, TPW = 4 / SH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* s_knots = reinterpret_cast<float*>(smem);
+    unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
+    int* s_flag = reinterpret_cast<int*>(smem + kDwShFlagOff);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (K > 0 && tid < nknots) s_knots[tid] = knots_g[tid];
+    if (K > 0) build_perm_table(s_tbl, tid);
+    __syncthreads();
+    FastGeom fgeo{};
+    const int li = lane & 15, kg = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int tl = wave_u / SH, ocl = wave_u % SH;               // team (feature tile of this workgroup) and role in it
+    const int OCG = OC / SH;
+    const int tile = (blockIdx.y / OCG) * TPW + tl;               // 16-feature tile
+    const int oc = (blockIdx.y % OCG) * SH + ocl;                 // 64-output chunk
+    const int f = 16 * tile + li;
+    float ca[8] = {};
+    if constexpr (K == 0) rbf_centers(rb, ca, 0);
+    if constexpr (K > 0) fgeo = fast_geom(s_knots, nknots);
+    const bool ln_on = (K == 0) && rb.ln_w != nullptr;           // wave-uniform
+    const long s = blockIdx.x;
+    const long rbeg = blockIdx.x * rows_per_block;
+    const long rend = min(N, (blockIdx.x + 1L) * rows_per_block);
+    const long nchunks = (rend - rbeg + 31) / 32, ngroups = (nchunks + SH - 1) / SH;
+
+    f32x4 D[kCTmax][NTO];
+#define Dh D[kCTmax - 1]
+#pragma unroll
+    for (int c = 0; c < kCTmax; ++c)
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) D[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const GBuf xb = gbuf_at(x, rend, ldx, in, rbeg), gyb = gbuf_at(gy, rend, ldgy, out, rbeg);
+    const GBuf stb = gbuf_at(rb.stats, ln_on ? rend : 0, 2, 2, rbeg);
+    const float gam = ln_on ? rb.ln_w[min(f, in - 1)] : 1.0f, bet = ln_on ? rb.ln_b[min(f, in - 1)] : 0.0f;
+    const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u;
+    // the x rows this wave EXPANDS: chunk ocl of every group; the gy rows it multiplies with: every chunk
+    unsigned xo = (unsigned)(32 * ocl + 8 * kg) * ldx4 + (unsigned)min(f, in - 1) * 4u;
+    unsigned sto = (unsigned)(32 * ocl + 8 * kg) * 8u;
+    unsigned gvo[NTO];
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) gvo[t] = (unsigned)(8 * kg) * ldgy4 + (unsigned)min(64 * oc + 16 * t + li, out - 1) * 4u;
+    struct XRaw { float x[8], mu[8], rs[8]; };
+    struct GRaw { float g[NTO][8]; };
+    auto load_x = [&](XRaw& r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.x[j] = gld_s(xb, xo, (unsigned)j * ldx4);
+        if (ln_on) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { r.mu[j] = gld(stb, sto + 8u * j); r.rs[j] = gld(stb, sto + 8u * j + 4u); }
+            sto += (unsigned)(32 * SH) * 8u;
+        }
+        xo += (unsigned)(32 * SH) * ldx4;
+    };
+    auto load_g = [&](GRaw& r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) r.g[t][j] = gld_s(gyb, gvo[t], (unsigned)j * ldgy4);
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) gvo[t] += 32u * ldgy4;
+    };
+    auto chunk_exp = [&](const GRaw& r) -> int {
+        float mx = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NTO; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(r.g[t][j]));
+        return exp_for_max(wave_max_nonneg(mx));
+    };
+    u32x4* s_frag = reinterpret_cast<u32x4*>(smem + kLdsHdr);
+    auto slot = [&](int buf, int k) -> u32x4* { return s_frag + (size_t)((tl * 2 + buf) * SH + k) * (kDwShVecs * 64) + lane; };
+
+    // ---- produce: this wave's chunk of the group -> ready A fragments in LDS.  Four rows at a time (two dwords of every
+    // fragment vector, ds_write_b64): with all eight rows' windows live at once this phase set the kernel's register
+    // high-water mark (the consumers' state -- next chunk's gy rows and split fragments -- stays live across it).
+    auto produce = [&](const XRaw& raw, int buf) {
+        unsigned char* dst = reinterpret_cast<unsigned char*>(slot(buf, ocl));
+        float sv[8];
+        float smx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 pr = silu16_pair(f32x2{raw.x[j], raw.x[j + 1]});
+            sv[j] = pr.x; sv[j + 1] = pr.y;
+            smx = fmaxf(fmaxf(smx, fabsf(pr.x)), fabsf(pr.y));
+        }
+        const bool base32 = __any(!(smx < 60000.0f));
+        u32x4* dv = reinterpret_cast<u32x4*>(dst);
+        if (base32) {             // rare: silu beyond fp16 range somewhere in the chunk -- hand over the fp32 values themselves
+            dv[16 * 64] = u32x4{__float_as_uint(sv[0]), __float_as_uint(sv[1]), __float_as_uint(sv[2]), __float_as_uint(sv[3])};
+            dv[17 * 64] = u32x4{__float_as_uint(sv[4]), __float_as_uint(sv[5]), __float_as_uint(sv[6]), __float_as_uint(sv[7])};
+        } else {
+            u32x4 sah, sal;
+            split_f16x2(sv, sah, sal);
+            dv[16 * 64] = sah;
+            dv[17 * 64] = sal;
+        }
+        if (lane == 0) s_flag[(tl * 2 + buf) * SH + ocl] = base32 ? 1 : 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 rh[4], rl[4];
+            if constexpr (K == 3) {
+#pragma unroll
+                for (int j = 0; j < 4; j += 2)
+                    make_spline_frag3_pair(raw.x[4 * h + j], raw.x[4 * h + j + 1], s_tbl, fgeo, rh[j], rl[j], rh[j + 1], rl[j + 1], 0u);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * h + j;
+                    const float z = ln_on ? fmaf((raw.x[r] - raw.mu[r]) * raw.rs[r], gam, bet) : raw.x[r];
+                    make_rbf_frag(z, rb.a, ca, rh[j], rl[j]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < kCTmax - 1; ++c) {
+                const int q = c >> 1;
+                const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;
+                u32x2 ah, al;
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    ah[pp] = __builtin_amdgcn_perm(rh[2 * pp + 1][q], rh[2 * pp][q], sel);
+                    al[pp] = __builtin_amdgcn_perm(rl[2 * pp + 1][q], rl[2 * pp][q], sel);
+                }
+                *reinterpret_cast<u32x2*>(dst + (size_t)(2 * c) * 1024 + 8 * h) = ah;
+                *reinterpret_cast<u32x2*>(dst + (size_t)(2 * c + 1) * 1024 + 8 * h) = al;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    float bsum[NTO] = {};
+    const bool bias_on = (K == 0) && rb.colpart != nullptr && tile == 0;      // wave-uniform: one wave per output chunk
+    int T;
+    // ---- consume: chunk k of the group against this wave's gy columns.  false = the chunk needs a larger scale
+    auto consume = [&](GRaw& raw, int buf, int k) -> bool {
+        // ALL 18 fragment vectors of the chunk are requested up front into registers of their own (72 of the ~130 this
+        // one-wave-per-SIMD kernel has to spare): they land under the gy-side arithmetic below.  Left to itself the compiler
+        // reads each slot plane into the same 8 registers right before its 12 MFMAs and waits out the LDS latency nine
+        // times per chunk (740 -> us per launch at 169k x 256 -> 256, config 5).
+        const u32x4* src = slot(buf, k);
+        u32x4 fr[kDwShVecs];
+#pragma unroll
+        for (int v = 0; v < kDwShVecs; ++v) fr[v] = src[v * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        if (chunk_exp(raw) > T) return false;
+        if constexpr (K == 0) {
+            if (bias_on) {
+#pragma unroll
+                for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum[t] += raw.g[t][j];
+            }
+        }
+        u32x4 bhi[NTO], blo[NTO];
+        const float gs = ldexpf(1.0f, 10 - T);
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const f32x2 pr = f32x2{raw.g[t][j], raw.g[t][j + 1]} * splat2(gs);
+                v[j] = pr.x; v[j + 1] = pr.y;
+            }
+            split_f16x2(v, bhi[t], blo[t]);
+        }
+        const bool base32 = __builtin_amdgcn_readfirstlane(s_flag[(tl * 2 + buf) * SH + k]) != 0;
+        if (base32) {
+            const float gs16 = gs * 16.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sj = __uint_as_float(j < 4 ? fr[16][j & 3] : fr[17][j & 3]) * 0.0625f;
+#pragma unroll
+                for (int t = 0; t < NTO; ++t)
+                    Dh[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sj, raw.g[t][j] * gs16, Dh[t], 0, 0, 0);
+            }
+        }
+        load_g(raw);                                     // next chunk's gy rows: they land under the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < kCTmax - 1; ++c) {
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(fr[2 * c], bhi[t], D[c][t]);
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(fr[2 * c], blo[t], D[c][t]);
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(fr[2 * c + 1], bhi[t], D[c][t]);
+        }
+        if (!base32) {
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(fr[16], bhi[t], Dh[t]);
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(fr[16], blo[t], Dh[t]);
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(fr[17], bhi[t], Dh[t]);
+        }
+        return true;
+    };
+    auto rescale = [&](const GRaw& raw) {
+        const int ex = chunk_exp(raw);
+        const float dn = ldexpf(1.0f, T - ex);
+#pragma unroll
+        for (int c = 0; c < kCTmax; ++c)
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) D[c][t] *= dn;
+        T = ex;
+    };
+
+    XRaw xr;
+    load_x(xr);
+    GRaw gr;
+    load_g(gr);
+    T = chunk_exp(gr);
+    long g = 0;
+    int k = 0;
+    bool fresh = true;             // the group's fragments have not been produced yet (wave-uniform, identical in every wave:
+                                   // every wave passes exactly ONE barrier per group, whatever its rescales)
+    while (g < ngroups) {
+        bool ok = true;
+        for (; g < ngroups; ++g) {                     // hot loop: T fixed, accumulators only touched by MFMAs
+            const int buf = (int)(g & 1);
+            if (fresh) {
+                produce(xr, buf);
+                load_x(xr);                            // next group's rows: in flight under this group's MFMAs
+                __syncthreads();
+                fresh = false;
+            }
+            for (; k < SH; ++k)
+                if (!consume(gr, buf, k)) { ok = false; break; }
+            if (!ok) break;
+            k = 0;
+            fresh = true;
+        }
+        if (!ok) rescale(gr);
+    }
+    if constexpr (K == 0) {
+        if (bias_on) {
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) {
+                float v = bsum[t];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                const long o = 64 * oc + 16 * t + li;
+                if (kg == 0 && o < outP) rb.colpart[s * outP + o] = v;
+            }
+        }
+    }
+    const float undo = ldexpf(1.0f, T - 20), undo_b = ldexpf(1.0f, T - 14);
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) {
+        const long o = 64 * oc + 16 * t + li;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const long fl = 16 * tile + 4 * kg + reg;
+            if (fl < inP && o < outP) {
+#pragma unroll
+                for (int c = 0; c < kCTmax - 1; ++c)
+                    if (c < C) slab[((s * (C + 1) + c) * inP + fl) * outP + o] = D[c][t][reg] * undo;
+                slab[((s * (C + 1) + C) * inP + fl) * outP + o] = Dh[t][reg] * undo_b;
+            }
+        }
+    }
+}
+#undef Dh
+
+// ---------------------------------------------------------------------------------------------------------------
 // Weight gradient for cubic layers with 9..12 coefficients (grid 6..9; BASELINE config 3 is grid 8 => C = 11).
 // kan_split_dw_kernel runs them as 2*in virtual features: every scalar's span / cubic pieces / hi-lo split / SiLU is
 // evaluated twice (once per 8-slot window, on separate lanes) and 2 x 9 slot planes go through the matrix cores.  Here a
@@ -1431,6 +1722,27 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
     // narrow OUTPUTS (read-out layers: 40 classes, 1 regression target): only the 16-wide output tiles that exist -- at 64 the
     // wave split 64 - out columns of gy and ran their MFMAs for nothing (out = 40: 3 tiles instead of 4)
     const int nto = (!sh && out <= 48) ? cdiv(out, 16) : 4;
+    // wide layers: the SH waves that own the output chunks of one feature tile share its basis expansion through LDS
+    // (kan_split_dw_shared_kernel: same slabs, bit for bit; KAGNN_DW_SHARED=0 keeps one workgroup per output chunk for A/B)
+    const char* dw_env = getenv("KAGNN_DW_SHARED");           // (read per call: the bitwise A/B test flips it inside one process)
+    const bool dw_shared = dw_env == nullptr || atoi(dw_env) != 0;
+    if (dw_shared && !sh && (K == 0 || K == 3) && p.rs == 1 && p.OC >= 2 && p.OC % 2 == 0 && in > 32) {
+        const int SHn = p.OC % 4 == 0 ? 4 : 2;
+#define LS(KK, SS) do { \
+            static const hipError_t attr_##KK##_##SS = hipFuncSetAttribute((const void*)kan_split_dw_shared_kernel<KK, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwShLds); \
+            KAGNN_HIP(attr_##KK##_##SS); \
+            kan_split_dw_shared_kernel<KK, SS><<<grid, 256, kDwShLds, st>>>(x, ldx, gy, ldgy, N, in, out, Ck, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb); } while (0)
+        if (K == 0) { if (SHn == 4) LS(0, 4); else LS(0, 2); }
+        else        { if (SHn == 4) LS(3, 4); else LS(3, 2); }
+#undef LS
+        KAGNN_LAUNCH_CHECK();
+        const int SG = max(1, min(3, 1024 / (32 * (C + 1))));
+        kan_dw_reduce_unpack_kernel<<<dim3((unsigned)(p.outP / 32), (unsigned)in), 32 * (C + 1) * SG,
+                                      (size_t)SG * (C + 1) * 32 * sizeof(float), st>>>(
+            slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, SG);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
 #define LN(KK) if (p.rs == 4) kan_split_dw_kernel<KK, false, 4><<<grid, 256, 0, st>>>(ARGS, 0); \
                else if (p.rs == 2) kan_split_dw_kernel<KK, false, 2><<<grid, 256, 0, st>>>(ARGS, 0); \
                else if (nto == 3) kan_split_dw_kernel<KK, false, 1, 3><<<grid, 256, 0, st>>>(ARGS, 0); \

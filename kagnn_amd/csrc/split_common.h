@@ -151,16 +151,25 @@ __device__ __forceinline__ int scale_exp_from_max(float m) {
 // parameter set by itself -- cheaper than a separate reduction launch + memset -- then packs its share.
 __device__ __forceinline__ float block_absmax_w(const float* __restrict__ bw, const float* __restrict__ sw,
                                 const float* __restrict__ sc, int in, int out, int C, float* s_m /* LDS[17] */) {
+    // flat, coalesced sweeps (a maximum does not depend on the order it is taken in: same bits as any other traversal).  The
+    // (o, f)-outer / c-inner form this replaces issued C strided 4-byte loads per thread and iteration and made the pack
+    // launches of the wide FastKAN layers 53 us each (256 x 256 x 4: config 5 packs 26 times per epoch).
     float m = 0.0f;
-    const int nof = out * in;
-    for (int of = threadIdx.x; of < nof; of += blockDim.x) {
-        float v = bw ? fabsf(bw[of]) : 0.0f;
-        m = fmaxf(m, (v <= 3.0e38f) ? v : 0.0f);
-        const float scale = sc ? sc[of] : 1.0f;
-        for (int c = 0; c < C; ++c) {
-            v = fabsf(sw[(long)of * C + c] * scale);
-            m = fmaxf(m, (v <= 3.0e38f) ? v : 0.0f);
+    const unsigned nof = (unsigned)out * (unsigned)in, nsw = nof * (unsigned)C;
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    auto take = [&](float v) { v = fabsf(v); m = fmaxf(m, (v <= 3.0e38f) ? v : 0.0f); };
+    if (bw) for (unsigned i = tid; i < nof; i += nt) take(bw[i]);
+    if (!sc) {
+        if ((reinterpret_cast<uintptr_t>(sw) & 15) == 0) {
+            const unsigned n4 = nsw >> 2;
+            const float4* s4 = reinterpret_cast<const float4*>(sw);
+            for (unsigned i = tid; i < n4; i += nt) { const float4 v = s4[i]; take(v.x); take(v.y); take(v.z); take(v.w); }
+            for (unsigned i = (n4 << 2) + tid; i < nsw; i += nt) take(sw[i]);
+        } else {
+            for (unsigned i = tid; i < nsw; i += nt) take(sw[i]);
         }
+    } else {
+        for (unsigned i = tid; i < nsw; i += nt) take(sw[i] * sc[i / (unsigned)C]);
     }
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
@@ -171,6 +180,48 @@ __device__ __forceinline__ float block_absmax_w(const float* __restrict__ bw, co
     }
     __syncthreads();
     return s_m[16];
+}
+
+// Large layers (the 256 x 256 layers of BASELINE config 5: ~0.5M weights): with every pack workgroup sweeping the WHOLE parameter
+// set for the maximum, 256 workgroups read 0.5 GB out of L2 before the first pack item (47 us per pack launch).  Instead a
+// launch of <= kAbsmaxBlocks workgroups leaves one partial maximum each in the pack header (floats [8, 8 + blocks)), and the pack
+// workgroups fold those few values (self_scale == 2).  Same maximum, hence the same scale and the same packs, bit for bit.
+constexpr int kAbsmaxBlocks = 56;                 // header = 64 floats; [0..2] taken, [7] = number of partials
+constexpr long kAbsmaxTwoLaunchMin = 1L << 16;    // weights from which the two-launch form pays
+
+template <int Unused = 0>     // (a template: one definition across the translation units that include this header)
+__global__ __launch_bounds__(1024) void absmax_partials_kernel(const float* __restrict__ bw, const float* __restrict__ sw,
+                                                               const float* __restrict__ sc, int in, int out, int C,
+                                                               unsigned char* __restrict__ pack) {
+    __shared__ float s_m[17];
+    float m = 0.0f;
+    const unsigned nof = (unsigned)out * (unsigned)in, nsw = nof * (unsigned)C;
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    auto take = [&](float v) { v = fabsf(v); m = fmaxf(m, (v <= 3.0e38f) ? v : 0.0f); };
+    if (bw) for (unsigned i = tid; i < nof; i += nt) take(bw[i]);
+    if (!sc) for (unsigned i = tid; i < nsw; i += nt) take(sw[i]);
+    else for (unsigned i = tid; i < nsw; i += nt) take(sw[i] * sc[i / (unsigned)C]);
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, s_m[i]);
+        reinterpret_cast<float*>(pack)[8 + blockIdx.x] = m;
+        if (blockIdx.x == 0) reinterpret_cast<int*>(pack)[7] = (int)gridDim.x;
+    }
+}
+__device__ __forceinline__ float header_absmax(const unsigned char* pack) {
+    const int n = reinterpret_cast<const int*>(pack)[7];
+    float m = 0.0f;
+    for (int i = 0; i < n; ++i) m = fmaxf(m, reinterpret_cast<const float*>(pack)[8 + i]);
+    return m;
+}
+inline int launch_absmax_partials(const float* bw, const float* sw, const float* sc, int in, int out, int C, void* pack, hipStream_t st) {
+    const long n = (long)in * out * C;
+    const int blocks = (int)max(1L, min((long)kAbsmaxBlocks, n / 4096));
+    absmax_partials_kernel<0><<<blocks, 1024, 0, st>>>(bw, sw, sc, in, out, C, static_cast<unsigned char*>(pack));
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
 }
 
 // selector tables for v_perm_b32: entry t of window w (shift sh = t - 4 - 8w halfs) holds 4 selectors; output

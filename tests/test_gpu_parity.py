@@ -347,6 +347,56 @@ def test_fastkan_ragged_shapes_vs_oracle(shape, mode):
             assert_close(prm.grad, w64[name].grad, what="g_" + name)
 
 
+@pytest.mark.parametrize("kind,n,fi,fo,G", [("kan", 3001, 64, 128, 5), ("kan", 10000, 96, 256, 5), ("kan", 777, 72, 192, 4),
+                                            ("fastkan", 3001, 128, 256, 8), ("fastkan", 5000, 256, 256, 4),
+                                            ("fastkan", 1999, 72, 128, 8), ("kan", 70000, 64, 256, 5)])
+def test_wide_layer_weight_gradient_shares_the_expansion_bitwise_and_vs_oracle(kind, n, fi, fo, G, monkeypatch):
+    """Layers of two or more 64-output chunks: the waves owning the output chunks of one feature tile share the basis
+    expansion through LDS (kan_split_dw_shared_kernel, 2 or 4 chunks per team; ragged feature counts, row counts that are not
+    a multiple of the 32-row chunks or of the chunk groups, 192 outputs = 3 chunks stays on the per-chunk kernel).  Same
+    slabs as one workgroup per chunk, bit for bit (KAGNN_DW_SHARED=0), and every parameter gradient against the fp64 oracle."""
+    gen = torch.Generator().manual_seed(n + fi + fo)
+    x = torch.randn(n, fi, generator=gen) * 0.7
+    x[0, 0] = 7.5e4                              # one value whose SiLU leaves fp16 range: the chunk's exact-fp32 base branch
+    gy = torch.randn(n, fo, generator=gen)
+    gy[5:9] *= 3.0e4                             # a late jump in |gy|: the running power-of-two scale has to be raised mid-way
+    if kind == "kan":
+        p = orc.init_kan_linear(fi, fo, G, 3, gen)
+        layer = kagnn_amd.KANLinear(fi, fo, grid_size=G, spline_order=3)
+        layer.load_state_dict(p)
+    else:
+        torch.manual_seed(n)
+        layer = kagnn_amd.FastKANLayer(fi, fo, num_grids=G)
+        with torch.no_grad():
+            layer.layernorm.weight.uniform_(0.5, 1.5)
+            layer.layernorm.bias.uniform_(-0.3, 0.3)
+    layer = layer.to(DEV)
+    layer.precision = ops.PREC_SPLIT
+    res = []
+    for shared in ("1", "0"):
+        monkeypatch.setenv("KAGNN_DW_SHARED", shared)
+        layer.zero_grad()
+        xd = x.to(DEV).requires_grad_(True)
+        layer(xd).backward(gy.to(DEV))
+        res.append({k: v.grad.clone() for k, v in layer.named_parameters() if v.grad is not None})
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+    monkeypatch.delenv("KAGNN_DW_SHARED")
+    if kind == "kan":
+        _, _, g64 = oracle_kan_linear_fwd_bwd(x, gy, p, 3)
+        for k in KAN_KEYS:
+            if k != "grid":
+                assert_close(res[0][k], g64[k], what=f"shared dW {kind} {fi}->{fo} {k}")
+    else:
+        st = {k: v.detach().cpu().double() for k, v in layer.state_dict().items()}
+        ps = {k: (v.clone().requires_grad_(True) if k != "rbf.grid" else v) for k, v in st.items()}
+        xr = x.double().requires_grad_(True)
+        orc.fastkan_forward(xr, [ps]).backward(gy.double())
+        for k, v in ps.items():
+            if k != "rbf.grid":
+                assert_close(res[0][k], v.grad, what=f"shared dW {kind} {fi}->{fo} {k}")
+
+
 def test_gin_fastkan_layer_golden(golden):
     z, g7 = golden("g5_gin"), golden("g7_csr")
     for g in ("small", "plaw"):
