@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void kan_fwd_f32_kernel(
 // D_c[n][f] = sum_o gy[n][o] * Wcat[o][f][c]  (one 32x32 accumulator per coefficient c), then
 // gx[n][f] = sum_c D_c * dB_c/dx(x[n][f]) + D_C * silu'(x[n][f]) -- the lane that owns D[.][f]
 // owns all c for that (n,f), so the contraction over c is register-local.
-constexpr int kDxGroup = 9;   // accumulators held at once (C+1 <= 9 -> single pass)
+constexpr int kDxGroup = 3;   // accumulators held at once (48 registers; 9 -- a single pass for C+1 <= 9 -- left 112 for everything else at two waves per SIMD: up to 53 spilled)
 
 // STAGE: the W fragments of one (feature tile, coefficient group) -- [kDxGroup][Q][64 lanes] floats, 72 KB at
 // out = 64 -- are copied to LDS once per workgroup and read from there by all its waves (8 = two per SIMD, so one
@@ -198,6 +198,9 @@ __global__ __launch_bounds__(512) void kan_dx_f32_kernel(
                     }
                 }
                 gacc[i] += s;
+                // one value at a time: left free, the scheduler interleaves the 16 basis evaluations of this unrolled loop and
+                // the kernel spilled up to 53 VGPRs beside its 144 accumulators (exact-fp32 mode is the documented fallback)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (f < in) {

@@ -410,10 +410,7 @@ static FwdSplit fwd_split_plan(long N, int nchunks, int rows_per_block) {
     p.splits = cdiv(nchunks, p.cps);
     return p;
 }
-static inline int fwd_rows_per_block(int OT) {
-    static const bool narrow = getenv("KAGNN_FWD_WIDE") == nullptr;
-    return (OT <= 2 && !narrow) ? 512 : 256;
-}
+static inline int fwd_rows_per_block(int OT) { (void)OT; return 256; }       // 512 threads = 8 waves x 32 rows
 
 size_t kan_split_fwd_ws_bytes(long N, int in, int out, int C) {
     size_t worst = 0;
@@ -470,14 +467,11 @@ static int fwd_block(const float* x, long ldx, long N, const float* knots, int i
                      hipStream_t st) {
     const int sh = vshift(G + K);
     const int OT = cdiv(out, 32), nk = K ? G + 2 * K + 1 : 0, nch = cdiv(in << sh, split_cf(OT));
-    // The kernels with <= 128 VGPRs could run 4 waves per SIMD (1024 threads).  Measured on MI355X (tools/ab.sh,
-    // three boxes) that makes the forward itself 3 % faster but the whole layer step 1.3 % SLOWER: the chip is
-    // power-limited in these kernels and the denser forward costs the following kernels more clock than it
-    // gains.  Default = 2 waves per SIMD (512 threads); KAGNN_FWD_WIDE=1 selects the 4-wave launch.
-    static const bool narrow = getenv("KAGNN_FWD_WIDE") == nullptr;
+    // (The kernels with <= 128 VGPRs could run 4 waves per SIMD, 1024 threads.  Measured in round 1 on three boxes that made
+    // the forward itself 3 % faster and the whole layer step 1.3 % SLOWER -- the chip is power-limited in these kernels and the
+    // denser forward costs the following kernels more clock than it gains -- so only the 2-waves-per-SIMD launch is built.)
 #define GO(KK, TT) return launch_fwd<KK, TT, 512>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, sh, ws, ws_bytes, st)
-#define GOW(KK, TT) if (narrow) GO(KK, TT); return launch_fwd<KK, TT, 1024>(x, ldx, N, in, knots, nk, p, nch, y, ldy, out, rb, sh, ws, ws_bytes, st)
-#define BYOT(KK) switch (OT) { case 1: GOW(KK, 1); case 2: GOW(KK, 2); case 3: GO(KK, 3); case 4: GO(KK, 4); }
+#define BYOT(KK) switch (OT) { case 1: GO(KK, 1); case 2: GO(KK, 2); case 3: GO(KK, 3); case 4: GO(KK, 4); }
     switch (K) {
         case 0: BYOT(0) break;
         case 1: BYOT(1) break;
@@ -486,7 +480,6 @@ static int fwd_block(const float* x, long ldx, long N, const float* knots, int i
         case 4: BYOT(4) break;
     }
 #undef BYOT
-#undef GOW
 #undef GO
     return fail(KAGNN_ERR_UNSUPPORTED, "%s: shape not covered by the split path", "kan_split_fwd");
 }

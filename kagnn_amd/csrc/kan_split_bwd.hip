@@ -749,9 +749,9 @@ int kan_split_dx_any(const float* x, long ldx, const float* gy, long ldgy, long 
         switch (dx_q2(out)) {
             case 1: W2(1)
             case 2: W2(2)
-            default:                        // (Q2 = 4 with ONE plane happens to spill 32 VGPRs; two planes -- the second on zero weights -- do not)
-                if (G + K - 8 == 1) return W2Q(4, 2);
-                W2(4)
+            default:                        // (Q2 = 4 with ONE plane happens to spill 32 VGPRs; two planes -- the second on zero weights -- do not:
+                                            // C = 9 runs as <4, 2> and <4, 1> is not instantiated)
+                switch (G + K - 8) { case 1: case 2: return W2Q(4, 2); case 3: return W2Q(4, 3); case 4: return W2Q(4, 4); default: return W2Q(4, 8); }
         }
 #undef W2
 #undef W2Q

@@ -104,3 +104,49 @@ def oracle_node_model_fwd_bwd(x, edge_index, state, gout, arch, conv_type, mp_la
     out = orc.node_model_forward(xr, ei, st, arch, conv_type, mp_layers, spline_order, chunk=chunk)
     out.backward(gout.detach().cpu().to(dtype))
     return out.detach(), xr.grad, {k: v.grad for k, v in leaves.items()}
+
+
+# ---------------------------------------------------------------------------------- the bf16 gather mode, restated
+class _RoundRowsBf16(torch.autograd.Function):
+    """what KAGNN_ACT=bf16 does to a matrix the aggregation gathers on the way FORWARD: one round-to-nearest-even to bf16
+    (the gradient passes through unchanged: the HIP path hands the transposed aggregation's output straight to x.grad)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGradBf16(torch.autograd.Function):
+    """... and on the way BACK: d loss / d h0, the matrix the transposed aggregation gathers, is stored as bf16"""
+
+    @staticmethod
+    def forward(ctx, h):
+        return h.view_as(h)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class bf16_gather_oracle:
+    """context manager: inside it ``oracle.gin_conv`` rounds the two gathered matrices of every KAN-GIN convolution to bf16
+    exactly where the build-defined KAGNN_ACT=bf16 mode does -- everything else stays fp64.  The HIP
+    path must agree with THIS oracle at (nearly) the fp32 tolerance: that is the parity statement for the mode; its distance
+    from the unrounded oracle is a property of the mode, reported separately."""
+
+    def __enter__(self):
+        self._orig = orc.gin_conv
+
+        def gin_conv(x, edge_index, nn_fn, eps=0.0):
+            xr = _RoundRowsBf16.apply(x)
+            return nn_fn(_RoundGradBf16.apply(orc.sum_aggregate(xr, edge_index) + (1.0 + eps) * xr))
+        orc.gin_conv = gin_conv
+        return self
+
+    def __exit__(self, *exc):
+        orc.gin_conv = self._orig
+        return False

@@ -31,11 +31,13 @@ HOT = [
     (r"kan_sparse_fwd_kernel<", 0, 0),
     (r"kan_split_dx_kernel<3,[12],|kan_split_dx_kernel<3,4,(true|false),0,", 0, 0),   # 128 outputs: only the plain schedule is launched
     (r"kan_split_dw_kernel<3,", 0, 0),
-    (r"kan_split_dx_w2_kernel<(1|2),|kan_split_dx_w2_kernel<4,[2348]>", 0, 0),   # <4,1> is never launched (routed to <4,2>)
+    (r"kan_split_dx_w2_kernel<", 0, 0),
     (r"kan_split_dw_w2_kernel<", 0, 0),
     (r"kan_split_dx_kernel<0,", 0, 0),
     (r"kan_split_dw_kernel<0,", 0, 0),
-    (r"kan_split_fwd_kernel<0,\d,512>", 0, 0),        # (the 1024-thread launch is the opt-in KAGNN_FWD_WIDE experiment)
+    (r"kan_split_dw_shared_kernel<", 0, 0),            # wide layers (round 4)
+    (r"kan_split_fwd_kernel<", 0, 0),
+    (r"kan_dx_f32_kernel<|kan_dw_f32_kernel<|kan_fwd_f32_kernel<", 0, 0),   # exact-fp32 mode: the documented fallback (round 4: was up to 53 spilled)
     (r"agg_rows_v4_kernel<", 0, 0),
     (r"agg_hub", 0, 0),
     (r"agg16_", 0, 0),
