@@ -392,10 +392,17 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                         // all-zero entry (negative -> 15 through the unsigned min; beyond the last span the window holds only slots
                         // >= C, whose sums are exact zeros), so no compare / select per scalar; the derivative scale 1/(2h) is applied
                         // once to the contracted sum instead of to the four pieces
+#ifdef KAGNN_ABLATE_SHARED_EXPANSION
+                        // TIMING-ONLY ablation (wrong results): what a dX that RECEIVED span and cubic pieces from elsewhere would
+                        // still execute -- the upper bound of sharing the per-scalar expansion with dW (profiles/r04_experiments.md)
+                        m = (int)(__float_as_uint(xv) & 7u);
+                        dN[0] = xv; dN[1] = xv; dN[2] = xv; dN[3] = xv;
+#else
                         const float t = fmaf(xv, fgeo.inv_h, fgeo.c0);
                         const float u = __builtin_amdgcn_fractf(t);
                         m = (int)floorf(t);
                         cubic_dbases(u, 1.0f, dN);           // (round 3: -9 instructions per scalar, dX -4.7 %)
+#endif
                     } else {
                         float Nv[K + 1];
                         m = bspline_local<K, true>(xv, s_knots, geom, Nv, dN);

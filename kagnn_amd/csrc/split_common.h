@@ -420,6 +420,12 @@ __device__ __forceinline__ void make_spline_frag3_pair(float x0, float x1, const
                                                        const FastGeom& g, u32x4& ahi0, u32x4& alo0,
                                                        u32x4& ahi1, u32x4& alo1, unsigned woff = 0) {
     const f32x2 x = {x0, x1};
+#ifdef KAGNN_ABLATE_SHARED_EXPANSION
+    // TIMING-ONLY ablation (wrong results): span and cubic pieces "received from elsewhere" -- see kan_split_dx_kernel
+    const int m0 = (int)(__float_as_uint(x0) & 7u), m1 = (int)(__float_as_uint(x1) & 7u);
+    const f32x2 N0 = x, N1 = x, N2 = x, N3 = x;
+    (void)g;
+#else
     const f32x2 t = fma2(x, splat2(g.inv_h), splat2(g.c0));
     const f32x2 tf = {fminf(fmaxf(floorf(t.x), 0.0f), g.last_span), fminf(fmaxf(floorf(t.y), 0.0f), g.last_span)};
     const int m0 = (int)tf.x, m1 = (int)tf.y;
@@ -431,6 +437,7 @@ __device__ __forceinline__ void make_spline_frag3_pair(float x0, float x1, const
     const f32x2 N3 = uw * u2;
     const f32x2 N1 = fma2(uw, fma2(u, splat2(3.0f), splat2(-6.0f)) * u, splat2(4.0f) * w6);
     const f32x2 N2 = fma2(uw, fma2(fma2(u, splat2(-3.0f), splat2(3.0f)), u, splat2(3.0f)), w6);
+#endif
     {
         const unsigned h0 = pk_f16_rtz(N0.x, N1.x), h1 = pk_f16_rtz(N2.x, N3.x);
         const unsigned l0 = pk_f16_rtz(sub_f16lo(N0.x, h0), sub_f16hi(N1.x, h0));
