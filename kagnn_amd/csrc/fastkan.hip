@@ -381,10 +381,113 @@ __global__ __launch_bounds__(256) void fastkan_ln_bwd_kernel(
     }
 }
 
+// The same with 16-byte accesses: a lane owns T4 groups of 4 consecutive columns (column group lane + 64 t).  Rows wider than a
+// few hundred columns (the 896-wide skip read-out of the FastKAN node models) moved 2.4 GB per launch through 4-byte loads and
+// read-modify-write stores at 2.5 TB/s (955 us at 169 343 x 896); same sums in the same order per column, so same bits.
+template <int T4>
+__global__ __launch_bounds__(256) void fastkan_ln_bwd_v4_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ gz, long N, int in, LnArgs ln,
+    const float* __restrict__ stats, float* __restrict__ gx, long ldgx,
+    float* __restrict__ partial /* [blocks][2][in] */) {
+    extern __shared__ float s_part[];              // [2][in]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wid = blockIdx.x * 4L + wave, nw = gridDim.x * 4L;
+    const int q4 = in >> 2;                        // float4 groups per row
+    float4 cw[T4], cb[T4], gam[T4];
+#pragma unroll
+    for (int t = 0; t < T4; ++t) {
+        cw[t] = make_float4(0.f, 0.f, 0.f, 0.f); cb[t] = cw[t];
+        const int c4 = min(lane + 64 * t, q4 - 1);
+        gam[t] = *reinterpret_cast<const float4*>(ln.w + 4 * c4);
+    }
+    const float inv_n = 1.0f / (float)in;
+    for (long row = wid; row < N; row += nw) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        float4 zh[T4], gh[T4];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T4; ++t) {
+            const int c4 = lane + 64 * t;
+            if (c4 < q4) {
+                const float4 g = *reinterpret_cast<const float4*>(gz + row * (long)in + 4 * c4);
+                const float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + 4 * c4);
+                const float4 z = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                const float4 h = make_float4(g.x * gam[t].x, g.y * gam[t].y, g.z * gam[t].z, g.w * gam[t].w);
+                zh[t] = z; gh[t] = h;
+                cw[t].x = fmaf(g.x, z.x, cw[t].x); cw[t].y = fmaf(g.y, z.y, cw[t].y); cw[t].z = fmaf(g.z, z.z, cw[t].z); cw[t].w = fmaf(g.w, z.w, cw[t].w);
+                cb[t].x += g.x; cb[t].y += g.y; cb[t].z += g.z; cb[t].w += g.w;
+                s1 += h.x; s2 = fmaf(h.x, z.x, s2);
+                s1 += h.y; s2 = fmaf(h.y, z.y, s2);
+                s1 += h.z; s2 = fmaf(h.z, z.z, s2);
+                s1 += h.w; s2 = fmaf(h.w, z.w, s2);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+#pragma unroll
+        for (int t = 0; t < T4; ++t) {
+            const int c4 = lane + 64 * t;
+            if (c4 < q4) {
+                float4* gp = reinterpret_cast<float4*>(gx + row * ldgx + 4 * c4);
+                float4 v = *gp;
+                v.x += rstd * (gh[t].x - m1 - zh[t].x * m2); v.y += rstd * (gh[t].y - m1 - zh[t].y * m2);
+                v.z += rstd * (gh[t].z - m1 - zh[t].z * m2); v.w += rstd * (gh[t].w - m1 - zh[t].w * m2);
+                *gp = v;
+            }
+        }
+    }
+    for (int w = 1; w < 4; ++w) {                    // waves 1..3 hand their sums to wave 0, in order
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < T4; ++t) {
+                const int c4 = lane + 64 * t;
+                if (c4 < q4) { *reinterpret_cast<float4*>(s_part + 4 * c4) = cw[t]; *reinterpret_cast<float4*>(s_part + in + 4 * c4) = cb[t]; }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < T4; ++t) {
+                const int c4 = lane + 64 * t;
+                if (c4 < q4) {
+                    const float4 a = *reinterpret_cast<const float4*>(s_part + 4 * c4), b = *reinterpret_cast<const float4*>(s_part + in + 4 * c4);
+                    cw[t].x += a.x; cw[t].y += a.y; cw[t].z += a.z; cw[t].w += a.w;
+                    cb[t].x += b.x; cb[t].y += b.y; cb[t].z += b.z; cb[t].w += b.w;
+                }
+            }
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < T4; ++t) {
+            const int c4 = lane + 64 * t;
+            if (c4 < q4) {
+                *reinterpret_cast<float4*>(partial + (blockIdx.x * 2L + 0) * in + 4 * c4) = cw[t];
+                *reinterpret_cast<float4*>(partial + (blockIdx.x * 2L + 1) * in + 4 * c4) = cb[t];
+            }
+        }
+    }
+}
+
 static int launch_ln_bwd(int blocks, const float* x, long ldx, const float* gz, long N, int in, LnArgs ln,
                          const float* stats, float* gx, long ldgx, float* partial, hipStream_t st) {
     const int T = cdiv(in, 64);
     const size_t lds = 2 * (size_t)in * sizeof(float);
+    // wide rows, 16-byte accesses (the row sums s1 / s2 are taken in another order than the 4-byte form: results agree to
+    // rounding, each form is deterministic)
+    const bool v4 = in > 256 && in <= 2048 && (in & 3) == 0 && (ldx & 3) == 0 && (ldgx & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gz) | reinterpret_cast<uintptr_t>(gx) |
+                      reinterpret_cast<uintptr_t>(ln.w) | reinterpret_cast<uintptr_t>(partial)) & 15) == 0;
+    if (v4) {
+        const int T4 = cdiv(in, 256);
+#define LV(TT) fastkan_ln_bwd_v4_kernel<TT><<<blocks, 256, lds, st>>>(x, ldx, gz, N, in, ln, stats, gx, ldgx, partial)
+        if (T4 <= 2) LV(2); else if (T4 <= 4) LV(4); else LV(8);
+#undef LV
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
 #define L(TT, RR) fastkan_ln_bwd_kernel<TT, RR><<<blocks, 256, lds, st>>>(x, ldx, gz, N, in, ln, stats, gx, ldgx, partial)
     // measured on MI355X: many single-row waves beat fewer multi-row ones (only very narrow rows take two)
     if (T <= 1) L(1, 2); else if (T <= 2) L(2, 2); else if (T <= 4) L(4, 1); else if (T <= 8) L(8, 1);
