@@ -168,6 +168,13 @@ __device__ __forceinline__ float block_absmax_w(const float* __restrict__ bw, co
         } else {
             for (unsigned i = tid; i < nsw; i += nt) take(sw[i]);
         }
+    } else if (nsw <= 65536u) {
+        // small layers (the 64 x 64 x 8 layers of every hidden-64 model: one (o, f) pair per thread and trip, C strided loads that
+        // all hit L2 -- cheaper here than an integer division per element: fused_pack_batch_kernel 19.5 vs 24.6 us)
+        for (unsigned of = tid; of < nof; of += nt) {
+            const float scale = sc[of];
+            for (int c = 0; c < C; ++c) take(sw[of * (unsigned)C + c] * scale);
+        }
     } else {
         for (unsigned i = tid; i < nsw; i += nt) take(sw[i] * sc[i / (unsigned)C]);
     }

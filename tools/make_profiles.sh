@@ -29,5 +29,8 @@ KAGNN_ACT=bf16 python tools/configs_sweep.py 2 2>/dev/null | grep "cfg2 " > $OUT
 python bench.py --act bf16 --no-cpu-baseline --no-extras --no-fp32 2>/dev/null | tail -1 > $OUT/${TAG}_bench_bf16_gather.json
 python bench.py --workload config3 --no-cpu-baseline --no-extras --no-traffic 2>/dev/null | tail -1 > $OUT/${TAG}_bench_config3.json
 python bench.py --workload fastkan 2>/dev/null | tail -1 > $OUT/${TAG}_bench_fastkan.json
+tools/prof_fastkan.sh ${TAG}_fk 40 > $OUT/${TAG}_fastkan_layer_kernel_trace.txt 2>&1
+python tools/shard_plan_probe.py --link-gbs=50 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_shard_plan.txt; cp gpurun_out/shard_plan.json $OUT/${TAG}_shard_plan.json
+python tools/kernel_resources.py > $OUT/${TAG}_kernel_resources.txt 2>&1
 rm -rf $R/gpurun_out/prof_${TAG}* 
 ls -la $OUT
