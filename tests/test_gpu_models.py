@@ -689,6 +689,39 @@ def test_fused_gin_kan_node_equals_the_composed_ops_bitwise(monkeypatch):
     assert_close(res[0][1], gx64, what="3-layer ragged chain gx")
 
 
+def test_library_stage_timer_sees_the_kernels_inside_the_layer_calls():
+    """kagnn_stage_timer_* (what bench.py reads its per-kernel times from on the product's one-call-per-convolution path):
+    while enabled every stage INSIDE kagnn_gin_kan_layer_fwd / _bwd is bracketed by HIP events; `only` restricts the records
+    to one stage; disabled (the default) nothing is recorded."""
+    n, e, f = 20000, 150000, 64
+    ei = orc.powerlaw_graph(n, e, seed=8)
+    g = ops.GraphIndex(ei.to(DEV), n)
+    torch.manual_seed(5)
+    conv = kagnn_amd.GIKANLayer(f, f, grid_size=5, spline_order=3, hidden_dim=f, nb_layers=2).to(DEV)
+    x = (torch.randn(n, f, generator=torch.Generator().manual_seed(3)) * 0.3).to(DEV).requires_grad_(True)
+    gy = torch.randn(n, f, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def step():
+        x.grad = None
+        conv.zero_grad()
+        conv(x, g).backward(gy)
+    step()
+    assert ops.LibraryStageTimer.collect() == {}                    # off by default
+    with ops.LibraryStageTimer(None):
+        step()
+        step()
+    got = ops.LibraryStageTimer.collect()
+    assert {k: v["launches"] for k, v in got.items()} == {"kagnn_aggregate_sum": 4, "kagnn_kan_pack_batch": 2, "kagnn_kan_linear_fwd": 4,
+                                                           "kagnn_kan_linear_bwd_weight": 4, "kagnn_kan_linear_bwd_input": 4}, got
+    assert all(v["total_ms"] > 0.0 and abs(v["avg_ms"] * v["launches"] - v["total_ms"]) < 1e-9 for v in got.values())
+    with ops.LibraryStageTimer("kagnn_aggregate_sum"):
+        step()
+    only = ops.LibraryStageTimer.collect()
+    assert list(only) == ["kagnn_aggregate_sum"] and only["kagnn_aggregate_sum"]["launches"] == 2
+    step()
+    assert ops.LibraryStageTimer.collect() == {}
+
+
 @pytest.mark.parametrize("f", [64, 128, 8, 24, 256, 12, 40])
 def test_bf16_aggregation_vs_oracle_on_the_rounded_rows(f):
     """kagnn_aggregate_sum_bf16: fp32 accumulation of bf16 rows is EXACT arithmetic on the rounded inputs up to fp32
