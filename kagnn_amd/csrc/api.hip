@@ -872,7 +872,7 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
         bn_in_dx = mode == KAGNN_PREC_SPLIT && use_split_dx(in, out, G, K, mode) && out <= wmax && !(L == 1 && (gx == nullptr || bf16_gather)) &&
                    fits32(N, ldg) && kan_split_dx_bn_ok(ldg, in, out, G, K, bnb, g);
         if (bn_in_dx) {
-            KAGNN_STAGE_AS("batchnorm backward statistics (inside kagnn_gin_kan_layer_bwd_bn)", stream);
+            KAGNN_STAGE_AS("kagnn_batchnorm_bwd statistics (in ..._layer_bwd_bn)", stream);
             rc = bn_bwd_stats(bn->y, bn->ldy, g, ldg, N, out, bn->weight, bn->mean, bn->rstd, bn->g_weight, bn->g_bias, tab, ldt, bws,
                               bn_ws_bytes(N, out), as_stream(stream));
             if (rc) return rc;

@@ -919,6 +919,15 @@ class _GinKanBnLayerFn(Function):
         return (gx, None, None, None, None, None, None, None, None, gbn_w, gbn_b, None, None, None, None, *grads)
 
 
+_GRAPH_TASK_ID = getattr(torch._C, "_current_graph_task_id", None)
+
+
+def graph_task_id() -> int:
+    """id of the autograd engine run this is called from (-1 outside a backward pass; always -1 on a torch build without the
+    hook: the tags below then compare equal and the objects behave as before they were tagged)"""
+    return _GRAPH_TASK_ID() if _GRAPH_TASK_ID is not None else -1
+
+
 class SkipGradient:
     """A gradient that travels from one tape node to another OUTSIDE the tape.  In the skip-concat node models an activation
     ``h_l`` feeds the next convolution AND the read-out (reference ``node_classification_clean/models.py:196-202``); autograd
@@ -935,7 +944,7 @@ class SkipGradient:
         self.task = -1                  # the engine run (graph task id) that parked ``grad``
 
     def park(self, grad) -> None:
-        self.grad, self.task = grad, torch._C._current_graph_task_id()
+        self.grad, self.task = grad, graph_task_id()
 
     def take(self):
         """the parked gradient if THIS backward pass parked it, else None; always leaves the object empty.  A pass that
@@ -943,7 +952,7 @@ class SkipGradient:
         loss it does not belong to -- it is dropped here instead."""
         g, t = self.grad, self.task
         self.grad, self.task = None, -1
-        return g if t == torch._C._current_graph_task_id() else None
+        return g if t == graph_task_id() else None
 
 
 _KNOTS_EQUAL: dict = {}

@@ -522,7 +522,7 @@ class TransposedShardedGIKANLayer(nn.Module):
         end-of-backward callback.  The callback all-reduces only what this pass added -- with gradient accumulation
         (two backward() calls without zero_grad) or the module used twice in one forward, already-synced sums must not
         be summed over the ranks again (P*S1 + S2 instead of S1 + S2)."""
-        run = torch._C._current_graph_task_id()
+        run = _hip_ops.graph_task_id()
         if self._flat_pending is not None and self._flat_pending[0] == run:
             return                         # a later use of the module in the same pass: already armed
         # (a latch left by ANOTHER engine run is stale: that backward raised, and the engine dropped its queued callbacks --
