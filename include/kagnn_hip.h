@@ -43,7 +43,7 @@ extern "C" {
 #define KAGNN_DTYPE_F32 0
 #define KAGNN_DTYPE_BF16 1
 
-int kagnn_version(void);          /* 220 = this header (210 + the stage timer; 210 = 200 + column moments / dropout arguments) */
+int kagnn_version(void);          /* 230 = this header (220 + the *_affine entry points of a folded BatchNorm1d; 220 = 210 + the stage timer) */
 const char* kagnn_last_error(void);
 
 /* Stage timer -- a measurement aid, off by default (no reference counterpart: the reference times whole epochs with
@@ -501,6 +501,50 @@ int kagnn_p2p_reduce_scatter(const float* const* parts, int32_t world, int32_t r
                              int64_t ld, float* y, int64_t ldy, void* stream);
 int kagnn_p2p_all_gather(const float* const* shards, int32_t world, int64_t num_rows, int32_t shard_width, int64_t lds,
                          float* g, int64_t ldg, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm1d folded into its consumers (round 4).  Reference: node_classification_clean/models.py:198-203 --
+ * `x = self.bns[i](self.convs[i](x, edge_index))` feeds the next GINConv and the skip read-out `lay_out(torch.cat(l, dim=1))`.
+ * In training mode without dropout the normalised matrix need not exist: kagnn_batchnorm_stats_affine turns the column
+ * moments the convolution's last forward kernel produced into (save_mean, save_rstd, running statistics, per-column affine
+ * a = gamma * rstd, b = beta - mean * a), and every consumer reads the convolution's raw output y as  a * y + b:
+ *   - the next convolution's aggregation: kagnn_aggregate_sum_affine / kagnn_gin_kan_layer_fwd_affine
+ *       out_i = a * (self_scale * y_i + sum_{j->i} y_j) + (self_scale + deg_i) * b      (unit edge weights)
+ *   - the read-out: kagnn_kan_linear_fwd_parts_affine (per column block), kagnn_kan_linear_bwd_input_affine,
+ *     kagnn_kan_linear_bwd_weight_affine (cubic layers, <= 8 coefficients, <= 64 outputs, split precision).
+ * Gradients are taken with respect to the NORMALISED input; the norm's own backward (kagnn_gin_kan_layer_bwd_bn,
+ * kagnn_batchnorm_bwd) goes on from there, so nothing else changes.  `affine` arrays: 2 * width floats, scales then shifts,
+ * 16-byte aligned.
+ */
+int kagnn_batchnorm_stats_affine(const float* col_mean, const float* col_m2, int64_t num_rows, int32_t num_feat,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* save_mean, float* save_rstd, float* affine, void* stream);
+int kagnn_aggregate_sum_affine(const float* x, int64_t ldx, float* out, int64_t ldo, const int32_t* rowptr, const int32_t* col,
+                               int64_t num_nodes, int32_t num_feat, float self_scale, const float* col_scale,
+                               const float* col_shift, const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold,
+                               const float* addend, int64_t ld_addend, void* workspace, size_t workspace_bytes, void* stream);
+int kagnn_gin_kan_layer_fwd_affine(const float* x, int64_t ldx, int64_t num_nodes, const int32_t* rowptr, const int32_t* col,
+                                   const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, float self_scale,
+                                   const float* in_col_scale, const float* in_col_shift,
+                                   int32_t num_layers, const int32_t* widths, const float* const* base_weight,
+                                   const float* const* spline_weight, const float* const* spline_scaler, const float* knots,
+                                   int32_t grid_size, int32_t spline_order, int32_t mode, float* const* acts,
+                                   void* const* pack_fwd, void* const* pack_dx, float* col_mean, float* col_m2,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+int kagnn_kan_linear_fwd_parts_affine(const float* const* x_parts, const int32_t* part_widths, const int64_t* part_ld,
+                                      const float* const* part_affine, int32_t num_parts, int64_t num_rows, const float* knots,
+                                      int32_t in_features, int32_t out_features, int32_t grid_size, int32_t spline_order,
+                                      int32_t mode, const void* pack_fwd, float* y, int64_t ldy, void* workspace,
+                                      size_t workspace_bytes, void* stream);
+int kagnn_kan_linear_bwd_input_affine(const float* x, int64_t ldx, const float* x_affine, const float* gy, int64_t ldgy,
+                                      int64_t num_rows, const float* knots, int32_t in_features, int32_t out_features,
+                                      int32_t grid_size, int32_t spline_order, int32_t mode, const void* pack_dx, void* gx,
+                                      int64_t ldgx, int32_t gx_dtype, void* stream);
+int kagnn_kan_linear_bwd_weight_affine(const float* x, int64_t ldx, const float* x_affine, const float* gy, int64_t ldgy,
+                                       int64_t num_rows, const float* knots, int32_t in_features, int32_t out_features,
+                                       int32_t grid_size, int32_t spline_order, int32_t mode, const float* spline_weight,
+                                       const float* spline_scaler, float* g_base_weight, float* g_spline_weight,
+                                       float* g_spline_scaler, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,17 @@ _SIGNATURES = {
                                 c_int32, _P]),
     "kagnn_gat_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                 _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int32, _P]),
+    "kagnn_batchnorm_stats_affine": (c_int32, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
+    "kagnn_aggregate_sum_affine": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int32, c_float, _P, _P, _P, c_int64, c_int32,
+                                             _P, c_int64, _P, c_size_t, _P]),
+    "kagnn_gin_kan_layer_fwd_affine": (c_int32, [_P, c_int64, c_int64, _P, _P, _P, c_int64, c_int32, c_float, _P, _P, c_int32, _P,
+                                                 _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "kagnn_kan_linear_fwd_parts_affine": (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P, c_int32, c_int32, c_int32, c_int32,
+                                                    c_int32, _P, _P, c_int64, _P, c_size_t, _P]),
+    "kagnn_kan_linear_bwd_input_affine": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int64, _P, c_int32, c_int32,
+                                                    c_int32, c_int32, c_int32, _P, _P, c_int64, c_int32, _P]),
+    "kagnn_kan_linear_bwd_weight_affine": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int64, _P, c_int32, c_int32,
+                                                     c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "kagnn_batchnorm_workspace_bytes": (c_int32, [c_int64, c_int32, POINTER(c_size_t)]),
     "kagnn_batchnorm_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_float, c_float, c_int32,
                                       _P, _P, c_float, c_uint64, _P, c_int64, _P, _P, _P, c_size_t, _P]),

@@ -56,6 +56,13 @@ __global__ __launch_bounds__(256) void agg_rows_v4_kernel(AggArgs a) {
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias) b = ld4(a.bias + c4);
     float4 o = make_float4(fmaf(os, acc.x, b.x), fmaf(os, acc.y, b.y), fmaf(os, acc.z, b.z), fmaf(os, acc.w, b.w));
+    if (a.col_scale) {                         // gathered rows = col_scale * x + col_shift (see AggArgs); unit edge weights only.
+        // Hub rows: `o` holds the self term, the shift is added here for ALL t - s edges, the merge kernel scales the segment sums
+        const float4 cs = ld4(a.col_scale + c4), ch = ld4(a.col_shift + c4);
+        const float cnt = (float)(t - s) + a.self_scale;
+        o.x = fmaf(cs.x, o.x, cnt * ch.x); o.y = fmaf(cs.y, o.y, cnt * ch.y);
+        o.z = fmaf(cs.z, o.z, cnt * ch.z); o.w = fmaf(cs.w, o.w, cnt * ch.w);
+    }
     if (a.addend && !hub) {                    // (hub rows: agg_hub_merge_kernel adds it after the segments -- the order of the separate sum)
         const float4 d = ld4(a.addend + gid * a.lda + c4);
         o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
@@ -106,6 +113,12 @@ __global__ __launch_bounds__(256) void agg_rows_ep_kernel(AggArgs a) {
         if (a.bias) b = ld4(a.bias + c4);
         float4 o = make_float4(fmaf(os, fmaf(sw, xs.x, acc.x), b.x), fmaf(os, fmaf(sw, xs.y, acc.y), b.y),
                                fmaf(os, fmaf(sw, xs.z, acc.z), b.z), fmaf(os, fmaf(sw, xs.w, acc.w), b.w));
+        if (a.col_scale) {
+            const float4 cs = ld4(a.col_scale + c4), ch = ld4(a.col_shift + c4);
+            const float cnt = (float)(t - s) + a.self_scale;
+            o.x = fmaf(cs.x, o.x, cnt * ch.x); o.y = fmaf(cs.y, o.y, cnt * ch.y);
+            o.z = fmaf(cs.z, o.z, cnt * ch.z); o.w = fmaf(cs.w, o.w, cnt * ch.w);
+        }
         if (a.addend && !hub) {
             const float4 d = ld4(a.addend + row * a.lda + c4);
             o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
@@ -175,6 +188,10 @@ __global__ __launch_bounds__(256) void agg_hub_merge_kernel(AggArgs a, const int
         const float os = a.out_scale ? a.out_scale[row] : 1.0f;
         float4* o = reinterpret_cast<float4*>(a.out + (long)row * a.ldo + c4);
         float4 v = *o;
+        if (a.col_scale) {                     // (the row kernel added the shift for every edge of the row)
+            const float4 cs = ld4(a.col_scale + c4);
+            acc.x *= cs.x; acc.y *= cs.y; acc.z *= cs.z; acc.w *= cs.w;
+        }
         v.x = fmaf(os, acc.x, v.x); v.y = fmaf(os, acc.y, v.y); v.z = fmaf(os, acc.z, v.z); v.w = fmaf(os, acc.w, v.w);
         if (a.addend) {
             const float4 d = ld4(a.addend + (long)row * a.lda + c4);
@@ -196,7 +213,8 @@ __global__ __launch_bounds__(256) void agg_rows_generic_kernel(AggArgs a) {
         acc = fmaf(edge_w(a, e, j, i), a.x[(long)j * a.ldx + f], acc);
     }
     const float os = a.out_scale ? a.out_scale[i] : 1.0f;
-    const float o = fmaf(os, acc, a.bias ? a.bias[f] : 0.0f);
+    float o = fmaf(os, acc, a.bias ? a.bias[f] : 0.0f);
+    if (a.col_scale) o = fmaf(a.col_scale[f], o, ((float)(t - s) + a.self_scale) * a.col_shift[f]);
     a.out[i * a.ldo + f] = a.addend ? o + a.addend[i * a.lda + f] : o;
 }
 
@@ -294,7 +312,8 @@ __global__ __launch_bounds__(256) void segment_bcast_kernel(const float* __restr
 static bool vec4_ok(const AggArgs& a) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return a.F % 4 == 0 && a.F <= 256 && a.ldx % 4 == 0 && a.ldo % 4 == 0 && al(a.x) && al(a.out) &&
-           (!a.bias || al(a.bias)) && (!a.addend || (al(a.addend) && a.lda % 4 == 0));
+           (!a.bias || al(a.bias)) && (!a.addend || (al(a.addend) && a.lda % 4 == 0)) &&
+           (!a.col_scale || (al(a.col_scale) && al(a.col_shift)));
 }
 
 size_t aggregate_ws_bytes(long num_hub_seg, int F) { return (size_t)num_hub_seg * (size_t)((F + 3) & ~3) * sizeof(float); }

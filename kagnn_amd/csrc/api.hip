@@ -41,9 +41,9 @@ int kan_split_pack_fwd_noscale(const float*, const float*, const float*, int, in
 int kan_split_pack_dx_noscale(const float*, const float*, const float*, int, int, int, int, void*, hipStream_t);
 int kan_split_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t);
 size_t kan_split_fwd_ws_bytes(long N, int in, int out, int C);
-int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t, int gx16);
+int kan_split_dx(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t, int gx16, const float* x_affine);
 size_t kan_split_dw_ws_bytes(long N, int in, int out, int C, int K);
-int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t);
+int kan_split_dw(const float*, long, const float*, long, long, const float*, int, int, int, int, const float*, const float*, float*, float*, float*, float*, size_t, hipStream_t, const float* x_affine);
 bool kan_split_fwd_ok(int in, int out, int G, int K);
 bool kan_sparse_fwd_ok(int in, int out, int G, int K);
 bool kan_fused_pack_ok(int in, int out, int C);
@@ -54,7 +54,7 @@ int kan_sparse_pack_fwd(const float*, const float*, const float*, int, int, int,
 size_t kan_sparse_fwd_ws_bytes(long N, int in, int out, int C);
 int kan_sparse_fwd(const float*, long, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, float*, float*, hipStream_t);
 bool kan_sparse_fwd_parts_ok(const int*, int, int, int, int, int);
-int kan_sparse_fwd_parts(const float* const*, const int*, const long*, int, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t);
+int kan_sparse_fwd_parts(const float* const*, const int*, const long*, int, long, const float*, int, int, int, int, const void*, float*, long, void*, size_t, hipStream_t, const float* const*);
 bool kan_sparse_fwd_moments_ok(long N, int in, int out, int G, int K);
 size_t kan_sparse_fwd_moments_ws_bytes(long N, int out);
 int col_moments(const float*, long, long, int, float*, float*, void*, size_t, hipStream_t);
@@ -80,6 +80,7 @@ size_t bn_ws_bytes(long N, int F);
 int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, const float*, const float*, float, unsigned long long, float*, long, float*, float*, void*, size_t, hipStream_t);
 int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float, unsigned long long, float*, long, float*, float*, void*, size_t, hipStream_t);
 int bn_bwd_stats(const float*, long, const float*, long, long, int, const float*, const float*, const float*, float*, float*, float*, int, void*, size_t, hipStream_t);
+int bn_stats_affine(const float*, const float*, long, int, const float*, const float*, float*, float*, float, float, float*, float*, float*, hipStream_t);
 bool kan_split_dx_bn_ok(long, int, int, int, int, const BnBack&, const void*);
 int kan_split_dx_bn(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const BnBack&, hipStream_t);
 int p2p_reduce_scatter(const float* const* parts, int P, int rank, long N, int out, long ld, float* y, long ldy, hipStream_t st);
@@ -153,7 +154,7 @@ static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode 
 #pragma GCC visibility push(default)
 extern "C" {
 
-int kagnn_version(void) { return 220; }
+int kagnn_version(void) { return 230; }
 const char* kagnn_last_error(void) { return g_err; }
 
 int kagnn_stage_timer_enable(const char* only) {
@@ -246,6 +247,27 @@ int kagnn_aggregate_sum(const float* x, int64_t ldx, float* out, int64_t ldo, co
                         void* stream) {
     return kagnn_aggregate_sum_add(x, ldx, out, ldo, rowptr, col, edge_weight, N, F, self_scale, in_scale, out_scale, bias,
                                    skip_self_loops, hub_seg, num_hub_seg, hub_threshold, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+// GIN-form aggregation of a matrix that exists only as  col_scale[c] * x[.][c] + col_shift[c]  -- the output of a training-mode
+// BatchNorm1d whose normalising pass is folded into the aggregation that gathers it (reference node_classification_clean/
+// models.py:198-200, `x = self.bns[i](self.convs[i](x, edge_index))` feeding the next GINConv):
+//   out_i = col_scale * (self_scale * x_i + sum_{j->i} x_j) + (self_scale + deg_i) * col_shift   [+ addend_i]
+// Unit edge weights (no edge_weight / in_scale / out_scale / bias / skip_self_loops).  col_scale / col_shift: F floats each.
+int kagnn_aggregate_sum_affine(const float* x, int64_t ldx, float* out, int64_t ldo, const int32_t* rowptr, const int32_t* col,
+                               int64_t N, int32_t F, float self_scale, const float* col_scale, const float* col_shift,
+                               const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, const float* addend,
+                               int64_t ld_addend, void* workspace, size_t workspace_bytes, void* stream) {
+    KAGNN_STAGE_AS("kagnn_aggregate_sum", stream);
+    KAGNN_CHECK_ARG(N >= 0 && F >= 1, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (x && out && rowptr), "null array");
+    KAGNN_CHECK_ARG(ldx >= F && ldo >= F && (!addend || ld_addend >= F), "leading dimension smaller than num_feat");
+    KAGNN_CHECK_ARG(x != out, "in-place aggregation is not supported");
+    KAGNN_CHECK_ARG((col_scale == nullptr) == (col_shift == nullptr), "col_scale and col_shift must both be given or both be null");
+    AggArgs a{x, ldx, out, ldo, rowptr, col, nullptr, N, F, self_scale, nullptr, nullptr, nullptr,
+              0, hub_threshold > 0 ? hub_threshold : 0x7fffffff, addend, ld_addend};
+    a.col_scale = col_scale; a.col_shift = col_shift;
+    return aggregate_sum(a, hub_seg, num_hub_seg, static_cast<float*>(workspace), workspace_bytes, as_stream(stream));
 }
 
 int kagnn_aggregate_sum_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t out_dtype, const int32_t* rowptr,
@@ -395,7 +417,18 @@ int kagnn_kan_fwd_parts_ok(const int32_t* part_widths, int32_t num_parts, int32_
 int kagnn_kan_linear_fwd_parts(const float* const* x_parts, const int32_t* part_widths, const int64_t* part_ld, int32_t num_parts,
                                int64_t N, const float* knots, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
                                const void* pack_fwd, float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
-    KAGNN_STAGE(stream);
+    return kagnn_kan_linear_fwd_parts_affine(x_parts, part_widths, part_ld, nullptr, num_parts, N, knots, in, out, G, K, mode, pack_fwd, y, ldy,
+                                             ws, ws_bytes, stream);
+}
+
+// part_affine (NULL, or per block NULL / 2 * width floats: the block's column scales, then its column shifts): the block is
+// read as  scale * x + shift  -- a BatchNorm1d output that was never written (the skip read-out of the node models over
+// normalised layer outputs, reference node_classification_clean/models.py:198-203).
+int kagnn_kan_linear_fwd_parts_affine(const float* const* x_parts, const int32_t* part_widths, const int64_t* part_ld,
+                                      const float* const* part_affine, int32_t num_parts,
+                                      int64_t N, const float* knots, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
+                                      const void* pack_fwd, float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    KAGNN_STAGE_AS("kagnn_kan_linear_fwd_parts", stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(x_parts && part_widths && part_ld && num_parts >= 1, "null block table");
@@ -406,7 +439,7 @@ int kagnn_kan_linear_fwd_parts(const float* const* x_parts, const int32_t* part_
     KAGNN_CHECK_ARG(knots && pack_fwd && y, "null array");
     if (!fits32(N, ldy)) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats", __func__);
     static_assert(sizeof(long) == sizeof(int64_t), "LP64");
-    return kan_sparse_fwd_parts(x_parts, part_widths, reinterpret_cast<const long*>(part_ld), num_parts, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream));
+    return kan_sparse_fwd_parts(x_parts, part_widths, reinterpret_cast<const long*>(part_ld), num_parts, N, knots, in, out, G, K, pack_fwd, y, ldy, ws, ws_bytes, as_stream(stream), part_affine);
 }
 
 // forward + column moments of its output (the statistics of the BatchNorm1d that follows a convolution)
@@ -449,7 +482,16 @@ int kagnn_kan_linear_fwd_moments(const float* x, int64_t ldx, int64_t N, const f
 int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N,
                                const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
                                int32_t mode, const void* pack_dx, void* gx, int64_t ldgx, int32_t gx_dtype, void* stream) {
-    KAGNN_STAGE(stream);
+    return kagnn_kan_linear_bwd_input_affine(x, ldx, nullptr, gy, ldgy, N, knots, in, out, G, K, mode, pack_dx, gx, ldgx, gx_dtype, stream);
+}
+
+// x_affine (NULL, or 2 * in floats: column scales, then column shifts): the layer input is  scale * x + shift  -- a BatchNorm1d
+// output that was never written; gx is the gradient with respect to THAT input (the norm's own backward takes it from there).
+// Covered: split precision, cubic layers of <= 8 coefficients and <= 64 outputs (the read-out of the node models).
+int kagnn_kan_linear_bwd_input_affine(const float* x, int64_t ldx, const float* x_affine, const float* gy, int64_t ldgy, int64_t N,
+                                      const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
+                                      int32_t mode, const void* pack_dx, void* gx, int64_t ldgx, int32_t gx_dtype, void* stream) {
+    KAGNN_STAGE_AS("kagnn_kan_linear_bwd_input", stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
@@ -459,8 +501,9 @@ int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int
     if (use_split_dx(in, out, G, K, mode)) {
         if (!(fits32(N, ldx) && fits32(N, ldgy) && fits32(N, ldgx))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
         return kan_split_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack_dx, static_cast<float*>(gx), ldgx, as_stream(stream),
-                            gx_dtype == KAGNN_DTYPE_BF16);
+                            gx_dtype == KAGNN_DTYPE_BF16, x_affine);
     }
+    if (x_affine) return fail(KAGNN_ERR_UNSUPPORTED, "%s: an input affine is applied by the split-precision kernels only", __func__);
     if (gx_dtype != KAGNN_DTYPE_F32) return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 gradient rows are produced by the split-precision kernels only", __func__);
     float* gxf = static_cast<float*>(gx);
     return kan_f32_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, (const float*)pack_dx, gxf, ldgx, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
@@ -480,7 +523,15 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
                                 const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
                                 int32_t mode, const float* sw, const float* sc, float* g_bw,
                                 float* g_sw, float* g_sc, void* ws, size_t ws_bytes, void* stream) {
-    KAGNN_STAGE(stream);
+    return kagnn_kan_linear_bwd_weight_affine(x, ldx, nullptr, gy, ldgy, N, knots, in, out, G, K, mode, sw, sc, g_bw, g_sw, g_sc, ws, ws_bytes, stream);
+}
+
+// x_affine: as kagnn_kan_linear_bwd_input_affine (the weight gradient of a layer whose input is a folded BatchNorm1d output)
+int kagnn_kan_linear_bwd_weight_affine(const float* x, int64_t ldx, const float* x_affine, const float* gy, int64_t ldgy, int64_t N,
+                                       const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
+                                       int32_t mode, const float* sw, const float* sc, float* g_bw,
+                                       float* g_sw, float* g_sc, void* ws, size_t ws_bytes, void* stream) {
+    KAGNN_STAGE_AS("kagnn_kan_linear_bwd_weight", stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out, "bad shape");
@@ -489,8 +540,9 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
     KAGNN_CHECK_ARG((sc == nullptr) == (g_sc == nullptr), "spline_scaler and its gradient must both be given or both be null");
     if (use_split_dw(in, out, G, K, mode)) {
         if (!(fits32(N, ldx) && fits32(N, ldgy))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
-        return kan_split_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream));
+        return kan_split_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, as_stream(stream), x_affine);
     }
+    if (x_affine) return fail(KAGNN_ERR_UNSUPPORTED, "%s: an input affine is applied by the split-precision kernels only", __func__);
     return kan_f32_dw(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, (float*)ws, ws_bytes, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
 }
 
@@ -608,6 +660,20 @@ int kagnn_batchnorm_fwd(const float* x, int64_t ldx, int64_t N, int32_t F, const
     KAGNN_CHECK_ARG(dropout_p >= 0.0f && dropout_p <= 1.0f, "dropout_p outside [0, 1]");
     return bn_fwd(x, ldx, N, F, weight, bias, running_mean, running_var, momentum, eps, training, col_mean, col_m2, dropout_p,
                   dropout_seed, y, ldy, save_mean, save_rstd, ws, ws_bytes, as_stream(stream));
+}
+
+// The statistics half of a training-mode BatchNorm1d forward whose normalising pass is folded into the kernels that read its
+// output (round 4; reference node_classification_clean/models.py:198-200): from the column moments (mean, M2) the producing
+// kernel left behind -> save_mean, save_rstd (for the backward), the running statistics update, and the per-column affine
+//   affine[0][c] = gamma[c] * rstd[c],   affine[1][c] = beta[c] - mean[c] * affine[0][c]
+// that kagnn_aggregate_sum_affine / kagnn_gin_kan_layer_fwd_affine / kagnn_kan_linear_*_affine apply to the rows they load.
+int kagnn_batchnorm_stats_affine(const float* col_mean, const float* col_m2, int64_t N, int32_t F, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                                 float* save_rstd, float* affine, void* stream) {
+    KAGNN_CHECK_ARG(N >= 1 && F >= 1 && col_mean && col_m2 && save_mean && save_rstd && affine, "bad argument");
+    KAGNN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var must both be given or both be null");
+    return bn_stats_affine(col_mean, col_m2, N, F, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd, affine,
+                           as_stream(stream));
 }
 
 int kagnn_batchnorm_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N, int32_t F,
@@ -744,13 +810,17 @@ int kagnn_gin_kan_layer_workspace_bytes(int64_t N, int32_t L, const int32_t* wid
     return KAGNN_OK;
 }
 
-int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t N, const int32_t* rowptr, const int32_t* col,
-                            const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, float self_scale,
-                            int32_t L, const int32_t* widths, const float* const* bw, const float* const* sw,
-                            const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
-                            float* const* acts, void* const* pack_fwd, void* const* pack_dx, float* col_mean,
-                            float* col_m2, void* workspace, size_t workspace_bytes, void* stream) {
+static int layer_fwd_impl(const void* x, int32_t x_dtype, int64_t ldx, int64_t N, const int32_t* rowptr, const int32_t* col,
+                          const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, float self_scale,
+                          const float* in_col_scale, const float* in_col_shift,
+                          int32_t L, const int32_t* widths, const float* const* bw, const float* const* sw,
+                          const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
+                          float* const* acts, void* const* pack_fwd, void* const* pack_dx, float* col_mean,
+                          float* col_m2, void* workspace, size_t workspace_bytes, void* stream, const char* fn) {
+    (void)fn;
     KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && bw && sw && acts && pack_fwd && pack_dx, "bad argument");
+    KAGNN_CHECK_ARG((in_col_scale == nullptr) == (in_col_shift == nullptr), "in_col_scale and in_col_shift must both be given or both be null");
+    KAGNN_CHECK_ARG(!in_col_scale || x_dtype == KAGNN_DTYPE_F32, "the column affine of the gathered matrix needs fp32 rows");
     KAGNN_CHECK_ARG((col_mean == nullptr) == (col_m2 == nullptr), "col_mean and col_m2 must both be given or both be null");
     size_t need_f = 0, need_b = 0;
     int rc = kagnn_gin_kan_layer_workspace_bytes(N, L, widths, G, K, mode, num_hub_seg, 0, &need_f, &need_b);
@@ -766,7 +836,7 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
     // layer forward: 0.60 vs 0.56 ms at 8 input features, 1.06 vs 0.62 at 32; profiles/r03_experiments.md).
     const char* fuse_e = getenv("KAGNN_FUSE_AGG");
     const bool fuse_env = fuse_e != nullptr && atoi(fuse_e) != 0;
-    const bool fuse = fuse_env && x_dtype == KAGNN_DTYPE_F32 && mode == KAGNN_PREC_SPLIT && !(L == 1 && col_mean) &&
+    const bool fuse = fuse_env && !in_col_scale && x_dtype == KAGNN_DTYPE_F32 && mode == KAGNN_PREC_SPLIT && !(L == 1 && col_mean) &&
                       use_sparse_fwd(widths[0], widths[1], G, K, mode) &&
                       kan_sparse_fwd_agg_ok(static_cast<const float*>(x), ldx, N, widths[0], widths[1], G, K);
     // 1. h0 = self_scale * x_i + sum_{j -> i} x_j
@@ -775,6 +845,9 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
     else if (x_dtype == KAGNN_DTYPE_BF16)
         rc = kagnn_aggregate_sum_bf16(x, ldx, acts[0], widths[0], KAGNN_DTYPE_F32, rowptr, col, nullptr, N, widths[0], self_scale,
                                       nullptr, nullptr, nullptr, 0, hub_seg, num_hub_seg, hub_threshold, ws, hub_b, stream);
+    else if (in_col_scale)
+        rc = kagnn_aggregate_sum_affine(static_cast<const float*>(x), ldx, acts[0], widths[0], rowptr, col, N, widths[0], self_scale,
+                                        in_col_scale, in_col_shift, hub_seg, num_hub_seg, hub_threshold, nullptr, 0, ws, hub_b, stream);
     else
         rc = kagnn_aggregate_sum(static_cast<const float*>(x), ldx, acts[0], widths[0], rowptr, col, nullptr, N, widths[0],
                                  self_scale, nullptr, nullptr, nullptr, 0, hub_seg, num_hub_seg, hub_threshold, ws, hub_b, stream);
@@ -816,6 +889,30 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
         if (rc) return rc;
     }
     return KAGNN_OK;
+}
+
+int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t N, const int32_t* rowptr, const int32_t* col,
+                            const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, float self_scale,
+                            int32_t L, const int32_t* widths, const float* const* bw, const float* const* sw,
+                            const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
+                            float* const* acts, void* const* pack_fwd, void* const* pack_dx, float* col_mean,
+                            float* col_m2, void* workspace, size_t workspace_bytes, void* stream) {
+    return layer_fwd_impl(x, x_dtype, ldx, N, rowptr, col, hub_seg, num_hub_seg, hub_threshold, self_scale, nullptr, nullptr, L, widths,
+                          bw, sw, sc, knots, G, K, mode, acts, pack_fwd, pack_dx, col_mean, col_m2, workspace, workspace_bytes, stream, __func__);
+}
+
+// The same on an input that exists only as  in_col_scale * x + in_col_shift  (the previous layer's BatchNorm1d, folded into this
+// layer's aggregation: kagnn_aggregate_sum_affine); acts[0] receives the aggregate of the NORMALISED rows, as before.
+int kagnn_gin_kan_layer_fwd_affine(const float* x, int64_t ldx, int64_t N, const int32_t* rowptr, const int32_t* col,
+                                   const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, float self_scale,
+                                   const float* in_col_scale, const float* in_col_shift,
+                                   int32_t L, const int32_t* widths, const float* const* bw, const float* const* sw,
+                                   const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
+                                   float* const* acts, void* const* pack_fwd, void* const* pack_dx, float* col_mean,
+                                   float* col_m2, void* workspace, size_t workspace_bytes, void* stream) {
+    return layer_fwd_impl(x, KAGNN_DTYPE_F32, ldx, N, rowptr, col, hub_seg, num_hub_seg, hub_threshold, self_scale, in_col_scale,
+                          in_col_shift, L, widths, bw, sw, sc, knots, G, K, mode, acts, pack_fwd, pack_dx, col_mean, col_m2, workspace,
+                          workspace_bytes, stream, __func__);
 }
 
 // the BatchNorm1d (training mode) that follows the layer, for kagnn_gin_kan_layer_bwd_bn

@@ -275,6 +275,17 @@ __global__ void bn_from_moments_kernel(const float* __restrict__ col_mean, const
     }
 }
 
+// ... plus the per-column affine of the normalisation, for consumers that apply it to the rows they load instead of reading a
+// normalised matrix (bn_stats_affine): a = gamma * rstd, b = beta - mean * a  -- the expressions of bn_apply_kernel
+__global__ void bn_affine_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, int F, float* __restrict__ affine) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float sc = rstd[f] * (gamma ? gamma[f] : 1.0f);
+    affine[f] = sc;
+    affine[F + f] = fmaf(-mean[f], sc, beta ? beta[f] : 0.0f);
+}
+
 // (count, mean, M2) of two disjoint row sets -> of their union (Chan et al.); b is folded into a
 __device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
     if (nb <= 0.0f) return;
@@ -367,6 +378,16 @@ int bn_fwd(const float* x, long ldx, long N, int F, const float* gamma, const fl
     }
     const int grid = (int)min(4096L, max(1L, (long)cdiv(N, s.rs)));
     bn_apply_kernel<<<grid, 256, 0, st>>>(x, ldx, N, F, save_mean, save_rstd, gamma, beta, y, ldy, s.cl, s.rs, dr);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int bn_stats_affine(const float* col_mean, const float* col_m2, long N, int F, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* save_mean, float* save_rstd,
+                    float* affine, hipStream_t st) {
+    bn_from_moments_kernel<<<cdiv(F, 256), 256, 0, st>>>(col_mean, col_m2, N, F, eps, momentum, save_mean, save_rstd, running_mean, running_var);
+    KAGNN_LAUNCH_CHECK();
+    bn_affine_kernel<<<cdiv(F, 256), 256, 0, st>>>(save_mean, save_rstd, gamma, beta, F, affine);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }

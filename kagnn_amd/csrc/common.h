@@ -209,6 +209,11 @@ struct AggArgs {
     int skip_self; int hub_threshold;
     const float* addend; long lda;     // optional [N, F] matrix added to the result row by row, LAST (after scale and bias): e.g. a
                                        // second gradient of the same activation (the skip branch), saving the separate sum pass
+    // optional per-COLUMN affine of the GATHERED matrix (round 4): the rows being gathered are a[c] * x[.][c] + b[c] without that
+    // matrix existing -- the output of a training-mode BatchNorm1d whose normalising pass is folded into this aggregation
+    // (reference node_classification_clean/models.py:198-200: x = bns[i](convs[i](x)) feeding the next GINConv):
+    //   out_i = a * (self * x_i + sum_j w_ij x_j) + (self + sum_j w_ij) * b        (GIN form: unit weights => count = deg_i + self)
+    const float* col_scale = nullptr; const float* col_shift = nullptr;
 };
 
 // BatchNorm1d backward, training mode, as ONE expression per element of the incoming gradient g (y = the norm's input):

@@ -206,7 +206,9 @@ __device__ __forceinline__ float4 spagg_ld4(const float* p) { return *reinterpre
 // PARTS: the input is the column concatenation of up to 8 row-major blocks that live in different buffers (the skip-concat
 // read-out of the node models: [x | h1 | h2 | ...] is never built).  Every block is a whole number of 64-feature chunks wide,
 // so chunk ch reads from p[ch] with leading dimension ld[ch] (the host resolves the blocks to per-chunk entries).
-struct SpParts { const float* p[8]; int ld[8]; };
+struct SpParts { const float* p[8]; int ld[8];
+                 const float* sc[8]; const float* sh[8]; };     // per chunk: NULL, or the 64 column scales / shifts of a block that
+                                                                // exists only as scale * x + shift (a folded BatchNorm1d, round 4)
 
 template <int OT, bool SH, bool MOM, bool NARROW = false, int AGG = -1, bool PARTS = false>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
 __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
@@ -272,6 +274,18 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
             const unsigned ro = (unsigned)(wave * 32 + r) * ((unsigned)ldc * 4u) + kg * HF * 4;
             gld4_s(xb, ro, (unsigned)(8 * g) * 4u, v);
             gld4_s(xb, ro, (unsigned)(8 * g) * 4u + 16, v + 4);
+            const float* as = xp.sc[0];
+            const float* ah = xp.sh[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) { as = ch == i ? xp.sc[i] : as; ah = ch == i ? xp.sh[i] : ah; }
+            if (as != nullptr) {                          // wave-uniform: this block is  scale * x + shift  (a folded BatchNorm1d; rows >= N
+                                                          // are never stored).  Applied here: carried with the prefetched rows to the
+                                                          // point of use instead (16 more live registers) the kernel was 3 % slower
+                const float4 s0 = *reinterpret_cast<const float4*>(as + kg * HF + 8 * g), s1 = *reinterpret_cast<const float4*>(as + kg * HF + 8 * g + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(ah + kg * HF + 8 * g), h1 = *reinterpret_cast<const float4*>(ah + kg * HF + 8 * g + 4);
+                v[0] = fmaf(v[0], s0.x, h0.x); v[1] = fmaf(v[1], s0.y, h0.y); v[2] = fmaf(v[2], s0.z, h0.z); v[3] = fmaf(v[3], s0.w, h0.w);
+                v[4] = fmaf(v[4], s1.x, h1.x); v[5] = fmaf(v[5], s1.y, h1.y); v[6] = fmaf(v[6], s1.z, h1.z); v[7] = fmaf(v[7], s1.w, h1.w);
+            }
             return;
         }
         const GBuf xb = gbuf_at(x, N, ldx, in, tile0);
@@ -969,7 +983,8 @@ static int launch_sparse_parts(const SpParts& xp, long N, int in, const float* k
 }
 
 int kan_sparse_fwd_parts(const float* const* parts, const int* widths, const long* lds, int nparts, long N, const float* knots, int in, int out,
-                         int G, int K, const void* pack, float* y, long ldy, void* ws, size_t ws_bytes, hipStream_t st) {
+                         int G, int K, const void* pack, float* y, long ldy, void* ws, size_t ws_bytes, hipStream_t st,
+                         const float* const* part_affine /* NULL, or per block NULL / [2][width]: scales then shifts */) {
     if (!kan_sparse_fwd_parts_ok(widths, nparts, in, out, G, K))
         return fail(KAGNN_ERR_UNSUPPORTED, "%s: blocks not covered (kagnn_kan_fwd_parts_ok)", "kan_sparse_fwd_parts");
     SpParts xp{};
@@ -977,9 +992,17 @@ int kan_sparse_fwd_parts(const float* const* parts, const int* widths, const lon
     for (int i = 0; i < nparts; ++i) {
         if (!parts[i] || (reinterpret_cast<uintptr_t>(parts[i]) & 15) || lds[i] % 4 || lds[i] < widths[i] || lds[i] > 7680)
             return fail(KAGNN_ERR_ARG, "%s: block %d is null, not 16-byte aligned, or its leading dimension is not a multiple of 4 in [width, 7680]", "kan_sparse_fwd_parts", i);
-        for (int k = 0; k < widths[i] / kSpCF; ++k) { xp.p[c] = parts[i] + (long)k * kSpCF; xp.ld[c++] = (int)lds[i]; }
+        const float* af = part_affine ? part_affine[i] : nullptr;
+        if (af && (reinterpret_cast<uintptr_t>(af) & 15))
+            return fail(KAGNN_ERR_ARG, "%s: the affine of block %d is not 16-byte aligned", "kan_sparse_fwd_parts", i);
+        for (int k = 0; k < widths[i] / kSpCF; ++k) {
+            xp.p[c] = parts[i] + (long)k * kSpCF; xp.ld[c] = (int)lds[i];
+            xp.sc[c] = af ? af + (long)k * kSpCF : nullptr;
+            xp.sh[c] = af ? af + widths[i] + (long)k * kSpCF : nullptr;
+            ++c;
+        }
     }
-    for (; c < 8; ++c) { xp.p[c] = xp.p[0]; xp.ld[c] = xp.ld[0]; }
+    for (; c < 8; ++c) { xp.p[c] = xp.p[0]; xp.ld[c] = xp.ld[0]; xp.sc[c] = nullptr; xp.sh[c] = nullptr; }
     const int nk = G + 2 * K + 1;
     const size_t stride = sp_blk_bytes(in, in, min(out, kSpOutBlk));
     for (int b = 0; b * kSpOutBlk < out; ++b) {

@@ -123,7 +123,7 @@ __device__ __forceinline__ float barrel_dot(const float (&d)[8], int m, const fl
 //   BNB: `gy` is the gradient of the BatchNorm1d that follows the layer; the norm's backward (one affine expression per
 //   element, split_common.h BnBack) is applied to the rows as they are loaded, and the transformed rows are stored for the
 //   weight-gradient kernel -- the stand-alone normalisation-backward pass (read g, read y, write gy) disappears.
-template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false>
+template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false>
 __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     RbfArgs rb, int sh_arg /* 1: virtual features, two 8-slot windows per input feature */, int acc_arg,
     int ft_per_block /* feature tiles per blockIdx.y: few-row inputs spread their feature tiles over the chip */, BnBack bnb) {
     static_assert(!BNB || (K == 3 && !GEN && PP == 0 && !GX16), "the fused normalisation backward serves the lean cubic instantiation");
+    static_assert(!XAFF || (K == 3 && !GEN && !GX16 && !BNB), "the input affine serves the lean cubic instantiation (the read-out of the node models)");
     // GX16: gx rows are bf16 (a compile-time variant of the lean cubic instantiation -- as a run-time flag the 2-byte
     // store path cost every launch 14 %: round 2, profiles/r02_experiments.md)
     const int sh = GEN ? sh_arg : 0;
@@ -308,6 +309,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             const unsigned gx_ro = gx_rb + (unsigned)min(fr, in - 1) * gxes, gz_ro = gz_rb + fcol;
             float gam = 1.0f, bet = 0.0f;
             if (ln_on) { gam = rb.ln_w[min(fr, in - 1)]; bet = rb.ln_b[min(fr, in - 1)]; }
+            float xa = 1.0f, xs = 0.0f;                  // XAFF: the input is  xa * x + xs  (a folded BatchNorm1d)
+            if constexpr (XAFF) { xa = rb.x_affine[min(fr, in - 1)]; xs = rb.x_affine[in + min(fr, in - 1)]; }
             float xq[2][4];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const float xv = xq[rt][reg];
+                    const float xv = XAFF ? fmaf(xq[rt][reg], xa, xs) : xq[rt][reg];
                     if constexpr (K == 0) {
                         // Gaussian RBF: gz = k2 * sum_g D_g * phi_g(z) * t_g   (gradient w.r.t. z), gb = D_base * silu'(x)
                         const float z = ln_on ? fmaf((xv - mu[rt][reg]) * rs[rt][reg], gam, bet) : xv;
@@ -455,7 +458,7 @@ static int dx_schedule() {
     return v;
 }
 
-template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false>
+template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false>
 static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                         const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
                         const RbfArgs& rb, int accumulate, hipStream_t st, const BnBack& bnb = BnBack{}) {
@@ -471,12 +474,12 @@ static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, lo
     const size_t lds = kLdsHdr + (resident ? fpb : 1) * ft_bytes;
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB>,
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
     }
     const dim3 grid((unsigned)min(row_blocks, 256L), (unsigned)splits);
-    kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
+    kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
                                                                            resident ? 1 : 0, gx, ldgx, rb, sh, accumulate, fpb, bnb);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
@@ -493,6 +496,10 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
         if (gx16) return launch_dx_pp<K, Q2, GEN, 0, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
         return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
     } else if constexpr (K == 3 && !GEN) {
+        if (rb.x_affine) {                               // the input is a folded BatchNorm1d output (read-out of the node models)
+            if (gx16) return fail(KAGNN_ERR_UNSUPPORTED, "%s: an input affine and bf16 gradient rows do not combine", "kan_split_dx");
+            return launch_dx_pp<K, Q2, GEN, 1, false, false, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
+        }
         if (gx16) return launch_dx_pp<K, Q2, GEN, 1, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
         switch (dx_schedule()) {
             case 0: return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
@@ -501,6 +508,7 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
         }
     }
     if (gx16) return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 gradient rows need a cubic layer with <= 8 coefficients", "kan_split_dx");
+    if (rb.x_affine) return fail(KAGNN_ERR_UNSUPPORTED, "%s: an input affine needs a cubic layer with <= 8 coefficients and <= 64 outputs", "kan_split_dx");
     return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
 }
 
@@ -791,8 +799,12 @@ int kan_split_dx_bn(const float* x, long ldx, const float* g, long ldg, long N, 
 }
 
 int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
-                 int out, int G, int K, const void* pack, float* gx, long ldgx, hipStream_t st, int gx16) {
-    return kan_split_dx_any(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack, gx, ldgx, RbfArgs{}, st, gx16);
+                 int out, int G, int K, const void* pack, float* gx, long ldgx, hipStream_t st, int gx16, const float* x_affine) {
+    RbfArgs rb{};
+    rb.x_affine = x_affine;
+    if (x_affine && (kan_dx_w2_ok(in, out, G + K, K) || out > 64))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: an input affine needs a cubic layer with <= 8 coefficients and <= 64 outputs", "kan_split_dx");
+    return kan_split_dx_any(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack, gx, ldgx, rb, st, gx16);
 }
 
 // ====================================================================== weight gradient
@@ -865,7 +877,8 @@ template <int NTO> struct DwRaw { float x[8]; float g[NTO][8]; float mu[8], rs[8
 // (16 x 32 outputs, 72 accumulators, 198 registers: TWO waves per SIMD) was measured in round 3 and is not instantiated: the
 // basis expansion runs twice and the pair gains nothing from sharing the SIMD -- 0.769 vs 0.604 ms per step
 // (profiles/r03_experiments.md)
-template <int K, bool GEN, int RS = 1, int NTO = 4>      // GEN == false: <= 8 coefficients, no virtual-feature code (see kan_split_dx_kernel)
+template <int K, bool GEN, int RS = 1, int NTO = 4, bool XAFF = false>      // GEN == false: <= 8 coefficients, no virtual-feature code (see kan_split_dx_kernel)
+                                                                             // XAFF: the input is rb.x_affine's scale * x + shift (a folded BatchNorm1d)
 __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots, int OC, long rows_per_block,
@@ -921,6 +934,8 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
     const GBuf xb = gbuf_at(x, rend, ldx, in, rbeg), gyb = gbuf_at(gy, rend, ldgy, out, rbeg);
     const GBuf stb = gbuf_at(rb.stats, ln_on ? rend : 0, 2, 2, rbeg);   // rows >= N: (0, 0) -> z = beta, finite; their gy is 0
     const float gam = ln_on ? rb.ln_w[min(f, in - 1)] : 1.0f, bet = ln_on ? rb.ln_b[min(f, in - 1)] : 0.0f;
+    float xa = 1.0f, xs = 0.0f;
+    if constexpr (XAFF) { xa = rb.x_affine[min(f, in - 1)]; xs = rb.x_affine[in + min(f, in - 1)]; }
     unsigned sto = (unsigned)(8 * kg) * 8u;
     const unsigned ldx4 = (unsigned)ldx * 4u, ldgy4 = (unsigned)ldgy * 4u;
     // per-lane byte offsets of the chunk being fetched; rows advance by 32 per call.  Unconditional buffer
@@ -975,19 +990,24 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
             // to arrive
             u32x4 rh[8], rl[8];            // per row: 8-slot windows (hi / lo) of this lane's feature
             u32x4 sah, sal;                // silu(x) * 2^4 over the 8 rows, hi / lo
+            float xr[8];                   // this chunk's x values (XAFF: the folded BatchNorm1d applied; rows >= rend become the
+                                           // shift -- their gy rows read as 0, the products vanish).  A copy: `raw` must stay as it
+                                           // was loaded, the chunk is redone when its scale turns out too small
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[j] = XAFF ? fmaf(raw.x[j], xa, xs) : raw.x[j];
             if constexpr (K == 3) {
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    make_spline_frag3_pair(raw.x[j], raw.x[j + 1], s_tbl, fgeo, rh[j], rl[j], rh[j + 1], rl[j + 1], woff);
+                    make_spline_frag3_pair(xr[j], xr[j + 1], s_tbl, fgeo, rh[j], rl[j], rh[j + 1], rl[j + 1], woff);
                 }
             } else
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if constexpr (K == 0) {
-                    const float z = ln_on ? fmaf((raw.x[j] - raw.mu[j]) * raw.rs[j], gam, bet) : raw.x[j];
+                    const float z = ln_on ? fmaf((xr[j] - raw.mu[j]) * raw.rs[j], gam, bet) : xr[j];
                     make_rbf_frag(z, rb.a, ca, rh[j], rl[j]);
                 } else {
-                    spline_frag<K>(raw.x[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j], woff);
+                    spline_frag<K>(xr[j], s_knots, s_tbl, geom, fgeo, rh[j], rl[j], woff);
                 }
             }
             // ---- SiLU branch: fp16 hi/lo at scale 2^4 (|silu| < 4094); larger values take the fp32 MFMA
@@ -995,7 +1015,7 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
             float smx = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {                 // packed fp32, two rows per instruction (bit-identical to siluf(x) * 16)
-                const f32x2 pr = silu16_pair(f32x2{raw.x[j], raw.x[j + 1]});
+                const f32x2 pr = silu16_pair(f32x2{xr[j], xr[j + 1]});
                 sv[j] = pr.x; sv[j + 1] = pr.y;
                 smx = fmaxf(fmaxf(smx, fabsf(pr.x)), fabsf(pr.y));
             }
@@ -1733,7 +1753,7 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
     // (kan_split_dw_shared_kernel: same slabs, bit for bit; KAGNN_DW_SHARED=0 keeps one workgroup per output chunk for A/B)
     const char* dw_env = getenv("KAGNN_DW_SHARED");           // (read per call: the bitwise A/B test flips it inside one process)
     const bool dw_shared = dw_env == nullptr || atoi(dw_env) != 0;
-    if (dw_shared && !sh && (K == 0 || K == 3) && p.rs == 1 && p.OC >= 2 && p.OC % 2 == 0 && in > 32) {
+    if (dw_shared && !rb.x_affine && !sh && (K == 0 || K == 3) && p.rs == 1 && p.OC >= 2 && p.OC % 2 == 0 && in > 32) {
         const int SHn = p.OC % 4 == 0 ? 4 : 2;
 #define LS(KK, SS) do { \
             static const hipError_t attr_##KK##_##SS = hipFuncSetAttribute((const void*)kan_split_dw_shared_kernel<KK, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwShLds); \
@@ -1756,6 +1776,13 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
                else if (nto == 2) kan_split_dw_kernel<KK, false, 1, 2><<<grid, 256, 0, st>>>(ARGS, 0); \
                else if (nto == 1) kan_split_dw_kernel<KK, false, 1, 1><<<grid, 256, 0, st>>>(ARGS, 0); \
                else { L(KK); }
+    if (rb.x_affine) {                                   // the input is a folded BatchNorm1d output (read-out of the node models)
+        if (K != 3 || sh || p.rs != 1) return fail(KAGNN_ERR_UNSUPPORTED, "%s: an input affine needs a cubic layer with <= 8 coefficients and more than 32 inputs", "kan_split_dw");
+        if (nto == 3) kan_split_dw_kernel<3, false, 1, 3, true><<<grid, 256, 0, st>>>(ARGS, 0);
+        else if (nto == 2) kan_split_dw_kernel<3, false, 1, 2, true><<<grid, 256, 0, st>>>(ARGS, 0);
+        else if (nto == 1) kan_split_dw_kernel<3, false, 1, 1, true><<<grid, 256, 0, st>>>(ARGS, 0);
+        else kan_split_dw_kernel<3, false, 1, 4, true><<<grid, 256, 0, st>>>(ARGS, 0);
+    } else
     switch (K) {
         case 0: LN(0); break;
         case 1: L(1); break;
@@ -1787,8 +1814,12 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
 
 int kan_split_dw(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,
                  int out, int G, int K, const float* sw, const float* sc, float* g_bw, float* g_sw,
-                 float* g_sc, float* ws, size_t ws_bytes, hipStream_t st) {
-    return kan_split_dw_any(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, ws, ws_bytes, RbfArgs{}, st);
+                 float* g_sc, float* ws, size_t ws_bytes, hipStream_t st, const float* x_affine) {
+    RbfArgs rb{};
+    rb.x_affine = x_affine;
+    if (x_affine && (kan_dw_w2_ok(in, out, G + K, K) || out > 64))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: an input affine needs a cubic layer with <= 8 coefficients and <= 64 outputs", "kan_split_dw");
+    return kan_split_dw_any(x, ldx, gy, ldgy, N, knots, in, out, G, K, sw, sc, g_bw, g_sw, g_sc, ws, ws_bytes, rb, st);
 }
 
 }  // namespace kagnn

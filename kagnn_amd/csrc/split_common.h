@@ -168,15 +168,14 @@ __device__ __forceinline__ float block_absmax_w(const float* __restrict__ bw, co
         } else {
             for (unsigned i = tid; i < nsw; i += nt) take(sw[i]);
         }
-    } else if (nsw <= 65536u) {
-        // small layers (the 64 x 64 x 8 layers of every hidden-64 model: one (o, f) pair per thread and trip, C strided loads that
-        // all hit L2 -- cheaper here than an integer division per element: fused_pack_batch_kernel 19.5 vs 24.6 us)
+    } else {
+        // with a spline_scaler: one (o, f) pair per thread and trip, C strided loads that all hit L2 -- cheaper than a flat sweep
+        // with an integer division per element (measured both ways: fused_pack_batch_kernel at 64 x 64 x 8 19.5 vs 24.6 us,
+        // fused_pack_kernel at 40 x 256 x 8 31 vs 53 us)
         for (unsigned of = tid; of < nof; of += nt) {
             const float scale = sc[of];
             for (int c = 0; c < C; ++c) take(sw[of * (unsigned)C + c] * scale);
         }
-    } else {
-        for (unsigned i = tid; i < nsw; i += nt) take(sw[i] * sc[i / (unsigned)C]);
     }
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
@@ -207,7 +206,10 @@ __global__ __launch_bounds__(1024) void absmax_partials_kernel(const float* __re
     auto take = [&](float v) { v = fabsf(v); m = fmaxf(m, (v <= 3.0e38f) ? v : 0.0f); };
     if (bw) for (unsigned i = tid; i < nof; i += nt) take(bw[i]);
     if (!sc) for (unsigned i = tid; i < nsw; i += nt) take(sw[i]);
-    else for (unsigned i = tid; i < nsw; i += nt) take(sw[i] * sc[i / (unsigned)C]);
+    else for (unsigned of = tid; of < nof; of += nt) {
+        const float scale = sc[of];
+        for (int c = 0; c < C; ++c) take(sw[of * (unsigned)C + c] * scale);
+    }
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -596,6 +598,10 @@ struct RbfArgs {
     float ln_eps;             //   loads anyway) and store them for the backward, instead of reading `stats`; nullptr: read
     float* colpart;           // weight gradient: [slabs][outP] column sums of gy per row slab (the base bias gradient rides in
                               // the kernel that reads gy anyway); nullptr: not wanted
+    // (B-spline layers too, round 4) the layer input exists only as  x_affine[f] * x[.][f] + x_affine[in + f]  -- a BatchNorm1d
+    // output that was never written: the XAFF instantiations of the input- and weight-gradient kernels apply it to the rows
+    // they load
+    const float* x_affine = nullptr;
 };
 
 // ca[g] = a * c_{8*window+g} (wave-uniform; slots >= num_grids repeat the last centre -- their packed weights

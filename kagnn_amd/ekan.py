@@ -143,7 +143,7 @@ class KANLinear(nn.Module):
         """``forward(torch.cat(parts, dim=1))`` without the concatenation (``ops.kan_linear_parts``)."""
         knots = self._knots()
         if knots.dim() != 1:                             # adaptive grid: per-feature knot rows, keep it simple
-            return self.forward(ops.concat_columns(list(parts)))
+            return self.forward(ops.concat_columns([t.materialise() if isinstance(t, ops.AffineRows) else t for t in parts]))
         scaler = self.spline_scaler if self.enable_standalone_scale_spline else None
         return ops.kan_linear_parts(parts, self.base_weight, self.spline_weight, scaler, knots, self.grid_size,
                                     self.spline_order, self.precision, skip_gradients)

@@ -66,6 +66,7 @@ _SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH = int(os.environ.get("KAGNN_SPLIT_READOUT_MIN
                                                         os.environ.get("KAGNN_SPLIT_READOUT_MIN_ROWS", "120000")))
 _SKIP_GRADIENT = os.environ.get("KAGNN_SKIP_GRADIENT", "1") != "0"     # skip-branch gradient added inside the next convolution's backward
 _FUSED_EPILOGUE = os.environ.get("KAGNN_FUSED_EPILOGUE", "1") != "0"  # conv -> BatchNorm1d -> dropout: statistics + mask fused
+_LAZY_NORM = os.environ.get("KAGNN_LAZY_NORM", "1") != "0"             # the norm's forward pass folded into its consumers (ops.AffineRows)
 
 
 class _SumAggregateConv(nn.Module):
@@ -101,11 +102,14 @@ class _SumAggregateConv(nn.Module):
             self.__dict__.pop("_skip_gradient", None)
         return y, self.__dict__.pop("_moments", None)
 
-    def forward_fused_norm(self, x: torch.Tensor, edge_index: torch.Tensor, bn: BatchNorm1d, skip_gradient=None):
+    def forward_fused_norm(self, x, edge_index: torch.Tensor, bn: BatchNorm1d, skip_gradient=None, lazy: bool = False):
         """``bn(self(x, edge_index))`` for a training-mode ``BatchNorm1d`` as ONE tape node (``ops._GinKanBnLayerFn``: the
         norm's element-wise backward runs inside the chain's last input-gradient kernel), or ``None`` when the chain is
         outside what the node covers -- nothing has been touched then.  Module hooks of the two modules do NOT run on this
         path (their intermediate tensor is never exposed): ``conv_bn_dropout`` only takes it when neither has any."""
+        in_affine = None
+        if isinstance(x, ops.AffineRows):                 # the previous layer's norm, to be folded into this aggregation
+            x, in_affine = x.y, x.affine
         if not (_FUSED_LAYER and isinstance(self.nn, eKAN) and x.is_cuda and x.size(0) > 1):
             return None
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
@@ -114,7 +118,8 @@ class _SumAggregateConv(nn.Module):
             factor, use_running = bn.step()
             return (bn.weight, bn.bias, bn.running_mean if use_running else None, bn.running_var if use_running else None, factor, bn.eps)
 
-        return ops.gin_kan_layer(x, g, 1.0 + self._eps(), self.nn, skip_gradient=skip_gradient, batch_norm=stage)
+        return ops.gin_kan_layer(x, g, 1.0 + self._eps(), self.nn, skip_gradient=skip_gradient, batch_norm=stage,
+                                 in_affine=in_affine, lazy_norm=lazy)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
@@ -221,13 +226,27 @@ def _has_hooks(m: nn.Module) -> bool:
                 or getattr(mod, "_global_backward_pre_hooks", None))
 
 
-def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args, skip_gradient=None):
+def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args, skip_gradient=None, lazy=False):
     """The epilogue ``dropout(bn(conv(x)))`` of every message-passing layer (reference
     ``node_classification_clean/models.py:198-201``, ``graph_regression/models.py:107-119``), fused (SURVEY.md 8(f)
     rank 1): the batch statistics come out of the convolution's last forward kernel (``_SumAggregateConv`` over a KAN
     chain) and the dropout mask is applied inside the normalising pass and regenerated in the backward
     (``ops.batch_norm``).  Stock modules under torch.compile and, with dropout on, during stream capture (a captured
     seed would repeat the mask on every replay)."""
+    # ``lazy`` (only _NodeModel.forward asks): return an ops.AffineRows -- the convolution's raw output plus the norm's per-column
+    # affine -- instead of the normalised rows, when the one-node form below runs; ``x`` may itself be one (the previous layer's)
+    x_in = x
+    if isinstance(x, ops.AffineRows):
+        ok = (_FUSED_EPILOGUE and _FUSED_NORM_BACKWARD and not torch.compiler.is_compiling() and type(dropout) is nn.Dropout
+              and isinstance(bn, BatchNorm1d) and isinstance(conv, _SumAggregateConv) and not conv_args and bn.training and bn.affine
+              and not (dropout.training and dropout.p > 0.0) and not _has_hooks(conv) and not _has_hooks(bn)
+              and type(conv).forward is _SumAggregateConv.forward and type(bn).forward is BatchNorm1d.forward
+              and ops.default_activation_dtype() == torch.float32)
+        if ok:
+            h = conv.forward_fused_norm(x, g, bn, skip_gradient, lazy=lazy)
+            if h is not None:
+                return h
+        x = x_in.materialise()                            # a consumer that cannot fold the affine: write the rows out
     fused = (_FUSED_EPILOGUE and x.is_cuda and not torch.compiler.is_compiling() and type(dropout) is nn.Dropout
              and isinstance(bn, BatchNorm1d)
              and not (dropout.p > 0.0 and dropout.training and torch.cuda.is_current_stream_capturing())
@@ -240,7 +259,8 @@ def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args, skip_gradient=None):
             and not (dropout.training and dropout.p > 0.0) and not _has_hooks(conv) and not _has_hooks(bn)
             # (a subclass with its own forward must see its forward called)
             and type(conv).forward is _SumAggregateConv.forward and type(bn).forward is BatchNorm1d.forward):
-        h = conv.forward_fused_norm(x, g, bn, skip_gradient)      # convolution + norm as one tape node
+        h = conv.forward_fused_norm(x, g, bn, skip_gradient,      # convolution + norm as one tape node
+                                    lazy=lazy and ops.default_activation_dtype() == torch.float32 and x.dtype == torch.float32)
         if h is not None:
             return h
     if isinstance(conv, _SumAggregateConv) and not conv_args and (bn.training or skip_gradient is not None):
@@ -290,11 +310,21 @@ class _NodeModel(nn.Module):
         # h_l feeds the next convolution and the read-out: the read-out's gradient of h_l is added inside the convolution's
         # backward instead of by the tape (ops.SkipGradient; only between the two fused nodes, everything else sums as usual)
         carry = split and _SKIP_GRADIENT and x.is_cuda and torch.is_grad_enabled() and not torch.compiler.is_compiling()
+        # the norm's normalising pass folded into its consumers: every layer output then
+        # travels as an ops.AffineRows -- raw convolution output + per-column affine -- which the next convolution's aggregation
+        # and the read-out's three kernels apply to the rows they load.  Only where every consumer can: the one-launch skip
+        # read-out on the split-precision cubic kernels, <= 64 classes, blocks wider than 32 columns, dropout off (the
+        # per-layer conditions -- training-mode norm, no hooks, fp32 rows -- are checked by conv_bn_dropout)
+        lazy = (_LAZY_NORM and split and x.is_cuda and not torch.compiler.is_compiling() and isinstance(self.lay_out, KANLinear) and self.lay_out.spline_order == 3
+                and self.lay_out.grid_size + 3 <= 8 and self.lay_out.out_features <= 64 and not (self.dropout.training and self.dropout.p > 0.0)
+                and all(bn.num_features > 32 for bn in self.bns)
+                and (self.lay_out.precision if self.lay_out.precision is not None else ops.default_precision()) == ops.PREC_SPLIT)
         skips = []
         for conv, bn in zip(self.convs, self.bns):
-            sk = ops.SkipGradient() if carry and x.requires_grad else None
+            grad_in = x.y.requires_grad if isinstance(x, ops.AffineRows) else x.requires_grad
+            sk = ops.SkipGradient() if carry and grad_in else None
             skips.append(sk)
-            x = conv_bn_dropout(conv, bn, self.dropout, x, g, skip_gradient=sk)
+            x = conv_bn_dropout(conv, bn, self.dropout, x, g, skip_gradient=sk, lazy=lazy)
             outs.append(x)
         if self.skip:
             if split:

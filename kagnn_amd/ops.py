@@ -377,6 +377,23 @@ def _aggregate_raw(x, g: GraphIndex, transposed, self_scale, edge_weight, in_sca
                           skip_self, out_dtype, addend)
 
 
+def aggregate_sum_affine(x, g: GraphIndex, self_scale: float, affine: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """``aggregate_sum(x * affine[0] + affine[1], g, self_scale)`` without that matrix (``kagnn_aggregate_sum_affine``: the affine is
+    applied to the row sums -- ``a * (self * x_i + sum_j x_j) + (self + deg_i) * b``).  Forward only (no autograd): inside the
+    fused convolution node the library makes this call itself; this wrapper serves tests and the C-ABI documentation."""
+    _need_cuda(x, affine)
+    x = _rows(x.detach())
+    rowptr, col, _, hub, nhub = g.side(transposed)
+    n, f = x.shape
+    out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    ws = _ws(_sizes("kagnn_aggregate_workspace_bytes", nhub, f), x.device) if nhub else None
+    with _device_of(x):
+        _call("kagnn_aggregate_sum_affine", _ptr(x), _ld(x), _ptr(out), f, _ptr(rowptr), _ptr(col), n, f, float(self_scale),
+              _ptr(affine[0]), _ptr(affine[1]), _ptr(hub) if nhub else None, nhub, g.hub_threshold, None, 0,
+              _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+    return out
+
+
 def _bf16_rows_ok(t: torch.Tensor) -> bool:
     return t.size(1) % 8 == 0 and t.size(1) <= 512 and _ld(t) % 8 == 0 and t.data_ptr() % 16 == 0
 
@@ -613,20 +630,28 @@ def _kan_fwd_raw(x, bw, sw, sc, knots, grid_size, spline_order, mode, packed=Non
     return y, pack_d
 
 
-def _kan_bwd_input_raw(x, gy, knots, pack_d, fin, fout, G, K, mode, bf16_out=False):
+def _kan_bwd_input_raw(x, gy, knots, pack_d, fin, fout, G, K, mode, bf16_out=False, x_affine=None):
     n = x.size(0)
     gx = torch.empty((n, fin), dtype=torch.bfloat16 if bf16_out else torch.float32, device=x.device)
+    if x_affine is not None:           # the layer input is x_affine[0] * x + x_affine[1] (AffineRows); gx is w.r.t. that input
+        _call("kagnn_kan_linear_bwd_input_affine", _ptr(x), _ld(x), _ptr(x_affine), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
+              fout, G, K, mode, _ptr(pack_d), _ptr(gx), fin, _lib.DTYPE_F32, _stream())
+        return gx
     _call("kagnn_kan_linear_bwd_input", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
           fout, G, K, mode, _ptr(pack_d), _ptr(gx), fin, _lib.DTYPE_BF16 if bf16_out else _lib.DTYPE_F32, _stream())
     return gx
 
 
-def _kan_bwd_weight_raw(x, gy, knots, sw, sc, fin, fout, G, K, mode, has_base):
+def _kan_bwd_weight_raw(x, gy, knots, sw, sc, fin, fout, G, K, mode, has_base, x_affine=None):
     n = x.size(0)
     ws = _ws(_sizes("kagnn_kan_bwd_weight_workspace_bytes", n, fin, fout, G, K, mode), x.device)
     gbw = torch.empty((fout, fin), dtype=torch.float32, device=x.device) if has_base else None
     gsw = torch.empty((fout, fin, G + K), dtype=torch.float32, device=x.device)
     gsc = None if sc is None else torch.empty((fout, fin), dtype=torch.float32, device=x.device)
+    if x_affine is not None:
+        _call("kagnn_kan_linear_bwd_weight_affine", _ptr(x), _ld(x), _ptr(x_affine), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
+              fout, G, K, mode, _ptr(sw), _ptr(sc), _ptr(gbw), _ptr(gsw), _ptr(gsc), _ptr(ws), ws.numel(), _stream())
+        return gbw, gsw, gsc
     _call("kagnn_kan_linear_bwd_weight", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, _ptr(knots), fin,
           fout, G, K, mode, _ptr(sw), _ptr(sc), _ptr(gbw), _ptr(gsw), _ptr(gsc), _ptr(ws),
           ws.numel(), _stream())
@@ -688,7 +713,7 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
-def _gin_kan_layer_fwd_raw(xg, g, self_scale, knots, grid_size, spline_order, mode, layers, widths, moments):
+def _gin_kan_layer_fwd_raw(xg, g, self_scale, knots, grid_size, spline_order, mode, layers, widths, moments, in_affine=None):
     """``kagnn_gin_kan_layer_fwd``: -> (acts [h0, ..., y], input-gradient packs per layer, column moments of y or None)"""
     n, dev, nl = xg.size(0), xg.device, len(layers)
     acts = [torch.empty((n, w), dtype=torch.float32, device=dev) for w in widths]
@@ -701,6 +726,14 @@ def _gin_kan_layer_fwd_raw(xg, g, self_scale, knots, grid_size, spline_order, mo
                    g.num_hub_seg, g.num_hub_seg_t, outputs=2)
     ws = _ws(wf, dev)
     mom = torch.empty((2, widths[nl]), dtype=torch.float32, device=dev) if moments else None
+    if in_affine is not None:          # the gathered rows are in_affine[0] * xg + in_affine[1]: a folded BatchNorm1d (AffineRows)
+        _call("kagnn_gin_kan_layer_fwd_affine", _ptr(xg), _ld(xg), n,
+              _ptr(g.rowptr), _ptr(g.col), _ptr(g.hub_seg) if g.num_hub_seg else None, g.num_hub_seg, g.hub_threshold,
+              float(self_scale), _ptr(in_affine[0]), _ptr(in_affine[1]), nl, warr, _ptr_array([l[0] for l in layers]),
+              _ptr_array([l[1] for l in layers]), _ptr_array([l[2] for l in layers]), _ptr(knots), grid_size, spline_order, mode,
+              _ptr_array(acts), _ptr_array(pfs), _ptr_array(pds), _ptr(mom[0]) if moments else None,
+              _ptr(mom[1]) if moments else None, _ptr(ws), ws.numel(), _stream())
+        return acts, pds, mom
     _call("kagnn_gin_kan_layer_fwd", _ptr(xg), _lib.DTYPE_BF16 if xg.dtype == torch.bfloat16 else _lib.DTYPE_F32, _ld(xg), n,
           _ptr(g.rowptr), _ptr(g.col), _ptr(g.hub_seg) if g.num_hub_seg else None, g.num_hub_seg, g.hub_threshold,
           float(self_scale), nl, warr, _ptr_array([l[0] for l in layers]), _ptr_array([l[1] for l in layers]),
@@ -708,6 +741,37 @@ def _gin_kan_layer_fwd_raw(xg, g, self_scale, knots, grid_size, spline_order, mo
           _ptr_array(pfs), _ptr_array(pds), _ptr(mom[0]) if moments else None, _ptr(mom[1]) if moments else None,
           _ptr(ws), ws.numel(), _stream())
     return acts, pds, mom
+
+
+class AffineRows:
+    """A matrix that exists only as ``y * affine[0] + affine[1]`` (per-column scale and shift) -- the output of a training-mode
+    ``BatchNorm1d`` whose normalising pass is folded into the kernels that read it (reference
+    ``node_classification_clean/models.py:198-203``).  ``y`` is the convolution's raw output, on the tape; ``affine`` is a [2, F]
+    fp32 tensor outside it.  CONVENTION: whoever consumes this object treats ``y``'s gradient slot as the gradient with respect
+    to the NORMALISED rows -- the producing node (``_GinKanBnLayerFn`` in lazy mode) runs the norm's backward from there.  Only
+    ``kagnn_amd.models._NodeModel.forward`` builds these, and only between nodes that follow the convention."""
+    __slots__ = ("y", "affine")
+
+    def __init__(self, y: torch.Tensor, affine: torch.Tensor):
+        self.y, self.affine = y, affine
+
+    def size(self, d):
+        return self.y.size(d)
+
+    def materialise(self) -> torch.Tensor:
+        """the normalised rows as an ordinary tensor (for consumers that cannot fold the affine); the gradient passes through
+        unchanged, as the convention above requires"""
+        return _MaterialiseAffineFn.apply(self.y, self.affine)
+
+
+class _MaterialiseAffineFn(Function):
+    @staticmethod
+    def forward(ctx, y, affine):
+        return torch.addcmul(affine[1], y, affine[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
 
 
 class _GinKanLayerFn(Function):
@@ -841,9 +905,11 @@ class _GinKanBnLayerFn(Function):
 
     @staticmethod
     @_on_operand_device
-    def forward(ctx, x, g, self_scale, knots, grid_size, spline_order, mode, act_bf16, skip_gradient, bn_weight, bn_bias,
+    def forward(ctx, x, g, self_scale, knots, grid_size, spline_order, mode, act_bf16, skip_gradient, in_affine, lazy, bn_weight, bn_bias,
                 running_mean, running_var, momentum, eps, *params):
-        _need_cuda(x, bn_weight, bn_bias, running_mean, running_var, *params)
+        """``in_affine``: the input is an ``AffineRows`` (``x`` = its y): the aggregation folds the previous layer's norm.
+        ``lazy``: do not write the normalised rows -- return ``(y, affine)`` for an ``AffineRows`` (see its convention)."""
+        _need_cuda(x, bn_weight, bn_bias, running_mean, running_var, in_affine, *params)
         nl = len(params) // 3
         layers = [(params[3 * i].contiguous(), params[3 * i + 1].contiguous(), params[3 * i + 2].contiguous()) for i in range(nl)]
         xg = _rows(x, allow_bf16=True)
@@ -860,20 +926,33 @@ class _GinKanBnLayerFn(Function):
                 and not act_bf16):
             skip_gradient.consumer = True
             ctx.skip_gradient = skip_gradient
-        acts, pds, mom = _gin_kan_layer_fwd_raw(xg, g, self_scale, knots[0], grid_size, spline_order, mode, layers, widths, True)
+        acts, pds, mom = _gin_kan_layer_fwd_raw(xg, g, self_scale, knots[0], grid_size, spline_order, mode, layers, widths, True,
+                                                in_affine=in_affine)
         y = acts[nl]
-        h, mean, rstd = _batchnorm_fwd_raw(y, bn_weight, bn_bias, running_mean, running_var, True, momentum, eps, mom)
+        affine = None
+        if lazy:
+            f = widths[nl]
+            mean = torch.empty(f, dtype=torch.float32, device=y.device)
+            rstd = torch.empty(f, dtype=torch.float32, device=y.device)
+            affine = torch.empty((2, f), dtype=torch.float32, device=y.device)
+            _call("kagnn_batchnorm_stats_affine", _ptr(mom[0]), _ptr(mom[1]), y.size(0), f, _ptr(bn_weight), _ptr(bn_bias),
+                  _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), _ptr(mean), _ptr(rstd), _ptr(affine), _stream())
+        else:
+            h, mean, rstd = _batchnorm_fwd_raw(y, bn_weight, bn_bias, running_mean, running_var, True, momentum, eps, mom)
         saved = []
         for i in range(nl):
             saved += [acts[i], layers[i][1], layers[i][2], pds[i]]
         ctx.save_for_backward(*saved, knots[0], y, mean, rstd, bn_weight)
         ctx.has_bias = bn_bias is not None
+        if lazy:
+            ctx.mark_non_differentiable(affine)
+            return y, affine
         return h
 
     @staticmethod
     @once_differentiable
     @_on_operand_device
-    def backward(ctx, gh):
+    def backward(ctx, gh, _g_affine=None):
         g, self_scale, G, K, mode, act_bf16, nl, x_dtype, widths = ctx.meta
         t = ctx.saved_tensors
         knots, y, mean, rstd, bn_w = t[4 * nl:4 * nl + 5]
@@ -916,7 +995,7 @@ class _GinKanBnLayerFn(Function):
         grads = []
         for i in range(nl):
             grads += [gbw[i], gsw[i], gsc[i]]
-        return (gx, None, None, None, None, None, None, None, None, gbn_w, gbn_b, None, None, None, None, *grads)
+        return (gx, None, None, None, None, None, None, None, None, None, None, gbn_w, gbn_b, None, None, None, None, *grads)
 
 
 _GRAPH_TASK_ID = getattr(torch._C, "_current_graph_task_id", None)
@@ -972,7 +1051,8 @@ def _same_knots(layers, knots) -> bool:
 
 
 def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optional[torch.dtype] = None,
-                  moments: bool = False, skip_gradient: Optional["SkipGradient"] = None, batch_norm=None):
+                  moments: bool = False, skip_gradient: Optional["SkipGradient"] = None, batch_norm=None,
+                  in_affine: Optional[torch.Tensor] = None, lazy_norm: bool = False):
     """``chain(aggregate_sum(x, g, self_scale))`` for a ``kagnn_amd.KAN`` chain as ONE autograd node, or ``None`` when the
     chain is outside what the fused node covers (adaptive grids, > 16 coefficients, mixed precisions): the caller then
     composes the ops.  ``moments=True`` -> ``(y, moments)`` with the [2, out] column moments (mean, M2) of y from the
@@ -1004,9 +1084,10 @@ def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optiona
         if not _LAYER_ABI or x.size(0) < 2 or layers[-1].out_features > max(l.in_features for l in layers):
             return None
         bw_, bb_, rm_, rv_, mom_, eps_ = batch_norm() if callable(batch_norm) else batch_norm      # (callable: evaluated only now that the node is certain -- the caller's per-call bookkeeping)
-        return _GinKanBnLayerFn.apply(x, g, float(self_scale), knots, first.grid_size, first.spline_order, int(mode),
-                                      act == torch.bfloat16 or x.dtype == torch.bfloat16, skip_gradient, bw_, bb_, rm_, rv_,
-                                      float(mom_), float(eps_), *params)
+        out = _GinKanBnLayerFn.apply(x, g, float(self_scale), knots, first.grid_size, first.spline_order, int(mode),
+                                     act == torch.bfloat16 or x.dtype == torch.bfloat16, skip_gradient, in_affine, bool(lazy_norm),
+                                     bw_, bb_, rm_, rv_, float(mom_), float(eps_), *params)
+        return AffineRows(out[0], out[1]) if lazy_norm else out
     return _GinKanLayerFn.apply(x, g, float(self_scale), knots, first.grid_size, first.spline_order, int(mode),
                                 act == torch.bfloat16 or x.dtype == torch.bfloat16, bool(moments), skip_gradient, *params)
 
@@ -1087,9 +1168,12 @@ class _KANLinearPartsFn(Function):
 
     @staticmethod
     @_on_operand_device
-    def forward(ctx, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, skip_gradients, *parts):
+    def forward(ctx, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, skip_gradients, affines, *parts):
+        """``affines``: ``None`` or per block ``None`` / a [2, width] tensor -- the block is read as scale * x + shift
+        (``AffineRows``: a BatchNorm1d output that was never written)"""
         _need_cuda(base_weight, spline_weight, spline_scaler, knots, *parts)
         ctx.skip_gradients = skip_gradients
+        ctx.affines = affines
         n, fout = parts[0].size(0), spline_weight.size(0)
         widths = [int(t.size(1)) for t in parts]
         fin = sum(widths)
@@ -1102,9 +1186,9 @@ class _KANLinearPartsFn(Function):
         y = torch.empty((n, fout), dtype=torch.float32, device=bw.device)
         wb = _sizes("kagnn_kan_fwd_workspace_bytes", n, fin, fout, grid_size, spline_order, mode)
         ws = _ws(wb, bw.device) if wb else None
-        _call("kagnn_kan_linear_fwd_parts", _ptr_array(parts), (ctypes.c_int32 * len(widths))(*widths),
-              (ctypes.c_int64 * len(widths))(*[_ld(t) for t in parts]), len(widths), n,
-              _ptr(knots), fin, fout, grid_size, spline_order, mode, _ptr(pack_f), _ptr(y), fout, _ptr(ws), wb, _stream())
+        _call("kagnn_kan_linear_fwd_parts_affine", _ptr_array(parts), (ctypes.c_int32 * len(widths))(*widths),
+              (ctypes.c_int64 * len(widths))(*[_ld(t) for t in parts]), None if affines is None else _ptr_array(list(affines)),
+              len(widths), n, _ptr(knots), fin, fout, grid_size, spline_order, mode, _ptr(pack_f), _ptr(y), fout, _ptr(ws), wb, _stream())
         ctx.save_for_backward(bw, sw, sc, knots, *parts)
         ctx.dims = (widths, fout, grid_size, spline_order, mode)
         return y
@@ -1121,17 +1205,18 @@ class _KANLinearPartsFn(Function):
         slices = []                          # per block: contiguous (base, spline, scaler) columns, or None when nothing needs them
         for i in range(len(parts)):
             f1 = f0 + widths[i]
-            if ctx.needs_input_grad[8 + i] or want_w:
+            if ctx.needs_input_grad[9 + i] or want_w:
                 slices.append((bw[:, f0:f1].contiguous(), sw[:, f0:f1].contiguous(), None if sc is None else sc[:, f0:f1].contiguous()))
             else:
                 slices.append(None)
             f0 = f1
         # the input-gradient packs of all blocks that need one: ONE launch when the batch entry point covers them
-        need = [i for i in range(len(parts)) if ctx.needs_input_grad[8 + i]]
+        need = [i for i in range(len(parts)) if ctx.needs_input_grad[9 + i]]
         packs = kan_pack_chain([slices[i] for i in need], G, K, mode) if sc is not None and len(need) >= 2 else None
         pack_of = {} if packs is None else {i: packs[k][1] for k, i in enumerate(need)}
         for i, part in enumerate(parts):
-            want_x = ctx.needs_input_grad[8 + i]
+            want_x = ctx.needs_input_grad[9 + i]
+            aff = None if ctx.affines is None else ctx.affines[i]
             bwp, swp, scp = slices[i] if slices[i] is not None else (None, None, None)
             gx = None
             if want_x:
@@ -1141,19 +1226,27 @@ class _KANLinearPartsFn(Function):
                     pack_f, pack_d = _ws(fb, part.device), _ws(db, part.device)
                     _call("kagnn_kan_pack", _ptr(bwp), _ptr(swp), _ptr(scp), widths[i], fout, G, K, mode, _ptr(pack_f), _ptr(pack_d),
                           _stream())
-                gx = _kan_bwd_input_raw(part, gy, knots, pack_d, widths[i], fout, G, K, mode)
+                gx = _kan_bwd_input_raw(part, gy, knots, pack_d, widths[i], fout, G, K, mode, x_affine=aff)
                 sk = ctx.skip_gradients[i] if ctx.skip_gradients is not None else None
                 if sk is not None and sk.consumer:         # the convolution that consumed this block adds it in its own backward
                     sk.park(gx)
                     gx = None
             gxs.append(gx)
             if want_w:
-                gbw, gsw, gsc = _kan_bwd_weight_raw(part, gy, knots, swp, scp, widths[i], fout, G, K, mode, True)
+                gbw, gsw, gsc = _kan_bwd_weight_raw(part, gy, knots, swp, scp, widths[i], fout, G, K, mode, True, x_affine=aff)
                 gbws.append(gbw); gsws.append(gsw); gscs.append(gsc)
         gbw = torch.cat(gbws, dim=1) if want_w else None
         gsw = torch.cat(gsws, dim=1) if want_w else None
         gsc = torch.cat(gscs, dim=1) if want_w and sc is not None else None
-        return (gbw, gsw, gsc, None, None, None, None, None, *gxs)
+        return (gbw, gsw, gsc, None, None, None, None, None, None, *gxs)
+
+
+def parts_affine_ok(fout: int, grid_size: int, spline_order: int, parts, lazy) -> bool:
+    """can the read-out kernels apply a folded BatchNorm1d to these blocks?  (``kagnn_kan_linear_*_affine``: cubic layers of
+    <= 8 coefficients and <= 64 outputs; the weight-gradient kernel needs blocks wider than 32 columns)"""
+    if spline_order != 3 or grid_size + spline_order > 8 or fout > 64:
+        return False
+    return all(not z or int(t.size(1)) > 32 for t, z in zip(parts, lazy))
 
 
 def kan_linear_parts(parts, base_weight, spline_weight, spline_scaler, knots, grid_size: int, spline_order: int,
@@ -1169,10 +1262,16 @@ def kan_linear_parts(parts, base_weight, spline_weight, spline_scaler, knots, gr
     if sum(int(t.size(1)) for t in parts) != base_weight.size(1):
         raise AssertionError("parts do not add up to in_features")
     m = default_precision() if mode is None else int(mode)
+    lazy = [isinstance(t, AffineRows) for t in parts]
+    raw = [t.y if z else t for t, z in zip(parts, lazy)]
     if (_PARTS_ONE_LAUNCH and m == PREC_SPLIT and knots.dim() == 1 and len(parts) > 1 and not torch.compiler.is_compiling()
-            and _parts_one_launch(parts, spline_weight.size(0), int(grid_size), int(spline_order), m)):
+            and _parts_one_launch(raw, spline_weight.size(0), int(grid_size), int(spline_order), m)
+            and (not any(lazy) or parts_affine_ok(spline_weight.size(0), int(grid_size), int(spline_order), raw, lazy))):
         sk = None if skip_gradients is None or not any(k is not None and k.consumer for k in skip_gradients) else tuple(skip_gradients)
-        return _KANLinearPartsFn.apply(base_weight, spline_weight, spline_scaler, knots, int(grid_size), int(spline_order), m, sk, *parts)
+        affines = tuple(t.affine if z else None for t, z in zip(parts, lazy)) if any(lazy) else None
+        return _KANLinearPartsFn.apply(base_weight, spline_weight, spline_scaler, knots, int(grid_size), int(spline_order), m, sk,
+                                       affines, *raw)
+    parts = [t.materialise() if z else t for t, z in zip(parts, lazy)]        # (blocks no kernel folds: write them out)
     y, f0 = None, 0
     for part in parts:
         f1 = f0 + part.size(1)

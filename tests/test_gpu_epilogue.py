@@ -269,3 +269,155 @@ def test_node_model_trains_with_fused_dropout():
     assert losses[-1] < losses[0] - 0.4 and all(np.isfinite(losses)), losses
     model.eval()
     assert torch.equal(model(x, ei), model(x, ei))
+
+
+# ------------------------------------------------------------------ the norm's forward pass folded into its consumers (round 4)
+@pytest.mark.parametrize("f", [64, 128, 32, 8, 40])
+def test_aggregation_of_a_folded_norm_equals_the_aggregation_of_the_normalised_rows(f):
+    """kagnn_aggregate_sum_affine: a * (self * x_i + sum_j x_j) + (self + deg_i) * b  against the aggregation of the matrix
+    a * x + b written out -- hub rows (segment partial sums scaled in the merge), isolated rows (deg 0: self term only), both
+    directions"""
+    n, e = 20011, 150000
+    ei = orc.powerlaw_graph(n, e, seed=10)
+    g = ops.GraphIndex(ei.to(DEV), n)
+    assert g.num_hub_seg > 0
+    gen = torch.Generator().manual_seed(f)
+    x = (torch.randn(n, f, generator=gen) * 3.0 + 5.0).to(DEV)
+    aff = torch.stack([torch.rand(f, generator=gen) + 0.5, torch.randn(f, generator=gen)]).to(DEV)
+    h = torch.addcmul(aff[1], x, aff[0])
+    for tr in (False, True):
+        want = ops._aggregate_raw(h, g, tr, 1.0, None, None, None, None, False)
+        got = ops.aggregate_sum_affine(x, g, 1.0, aff, transposed=tr)
+        assert_close(got, want.double().cpu(), 2e-6, what=f"folded-norm aggregation F={f} transposed={tr}")
+    want64 = orc.sum_aggregate(h.double().cpu(), ei) + 1.5 * h.double().cpu()
+    assert_close(ops.aggregate_sum_affine(x, g, 1.5, aff), want64, 2e-6, what=f"folded-norm aggregation vs oracle F={f}")
+
+
+def test_read_out_over_folded_norm_blocks_equals_the_materialised_blocks():
+    """kagnn_kan_linear_fwd_parts_affine / _bwd_input_affine / _bwd_weight_affine: the skip read-out over blocks that exist
+    only as (y, per-column affine) against the same layer over the blocks written out -- output, the gradient with respect to
+    the NORMALISED block (ops.AffineRows' convention) and every parameter gradient"""
+    n, out = 5003, 40
+    gen = torch.Generator().manual_seed(7)
+    torch.manual_seed(7)
+    layer = kagnn_amd.KANLinear(192, out, grid_size=5, spline_order=3).to(DEV)
+    x0 = (torch.randn(n, 64, generator=gen) * 0.5).to(DEV)
+    ys = [(torch.randn(n, 64, generator=gen) * 2.0 + 1.0).to(DEV) for _ in range(2)]
+    affs = [torch.stack([torch.rand(64, generator=gen) * 0.5 + 0.2, torch.randn(64, generator=gen) * 0.3]).to(DEV) for _ in range(2)]
+    gy = torch.randn(n, out, generator=gen).to(DEV)
+    # reference: the blocks written out
+    hs = [torch.addcmul(a[1], y, a[0]).requires_grad_(True) for y, a in zip(ys, affs)]
+    x0a = x0.clone().requires_grad_(True)
+    ref = layer.forward_parts([x0a] + hs)
+    ref.backward(gy)
+    want = [ref.detach().clone(), x0a.grad.clone()] + [h.grad.clone() for h in hs] + [p.grad.clone() for p in layer.parameters()]
+    layer.zero_grad()
+    yr = [y.clone().requires_grad_(True) for y in ys]
+    x0b = x0.clone().requires_grad_(True)
+    timer = ops.EntryPointTimer()
+    ops.set_timer(timer)
+    try:
+        got_y = layer.forward_parts([x0b] + [ops.AffineRows(y, a) for y, a in zip(yr, affs)])
+        got_y.backward(gy)
+    finally:
+        ops.set_timer(None)
+    names = [r[0] for r in timer.records]
+    assert "kagnn_kan_linear_fwd_parts_affine" in names and names.count("kagnn_kan_linear_bwd_input_affine") == 2 \
+        and names.count("kagnn_kan_linear_bwd_weight_affine") == 2, names
+    got = [got_y.detach(), x0b.grad] + [y.grad for y in yr] + [p.grad for p in layer.parameters()]
+    for a, b, what in zip(got, want, ["y", "gx0", "g_h1 (w.r.t. the normalised block)", "g_h2", "g_base", "g_spline", "g_scaler"]):
+        assert_close(a, b.double().cpu(), 4e-6, what="folded-norm read-out: " + what)
+
+
+def test_node_model_with_folded_norms_equals_the_model_with_normalising_passes(monkeypatch):
+    """GKAN_Nodes (3 x KAN-GIN hidden 64, skip read-out, 40 classes) on a graph large enough for the one-launch read-out: with
+    the norms folded into their consumers (default: no normalised matrix is written, no bn_apply pass) against
+    KAGNN_LAZY_NORM=0 -- logits, input gradient, every parameter gradient, the running statistics"""
+    from kagnn_amd import models as M
+    n, e = 131072 + 5, 900000
+    ei = orc.powerlaw_graph(n, e, seed=2).to(DEV)
+    g = ops.GraphIndex(ei, n)
+    x = (torch.randn(n, 64, generator=torch.Generator().manual_seed(1)) * 0.5).to(DEV)
+    gout = (torch.randn(n, 40, generator=torch.Generator().manual_seed(2)) / n).to(DEV)
+    torch.manual_seed(3)
+    model = kagnn_amd.GKAN_Nodes("gin", 3, 64, 64, 40, skip=True, grid_size=5, spline_order=3, hidden_layers=2).to(DEV).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    res = []
+    for lazy in (True, False):
+        monkeypatch.setattr(M, "_LAZY_NORM", lazy)
+        model.load_state_dict(state)
+        model.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        timer = ops.EntryPointTimer()
+        ops.set_timer(timer)
+        try:
+            out = model(xr, g)
+            out.backward(gout)
+        finally:
+            ops.set_timer(None)
+        names = [r[0] for r in timer.records]
+        assert names.count("kagnn_batchnorm_stats_affine") == (3 if lazy else 0), names
+        assert names.count("kagnn_batchnorm_fwd") == (0 if lazy else 3), names
+        assert names.count("kagnn_gin_kan_layer_fwd_affine") == (2 if lazy else 0), names
+        res.append(([out.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None],
+                    {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    names = ["logits", "gx"] + [k for k, p in model.named_parameters() if p.grad is not None]
+    for a, b, what in zip(res[0][0], res[1][0], names):
+        scale = max(1e-30, float(b.abs().max()))
+        # (2e-5 of the largest element; the norms' bias gradients are cancelling sums over 131k rows of terms ~1e3 times their
+        # result -- both forms carry that noise: 1e-4)
+        tol = 1e-4 if what.startswith("bns.") else 2e-5
+        assert float((a - b).abs().max()) <= tol * scale, (what, float((a - b).abs().max()) / scale)
+    for k in res[0][1]:                                           # running statistics (layers > 0 see inputs that differ by rounding)
+        a, b = res[0][1][k].float(), res[1][1][k].float()
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), k
+
+
+def test_folded_norms_over_random_model_configurations(monkeypatch):
+    """the same comparison (norms folded into their consumers vs normalising passes) over random widths / depths / row counts /
+    class counts / chain lengths, incl. configurations the fold does not cover (narrow hidden widths, > 64 classes, dropout
+    on: the model must fall back per layer or as a whole and still agree).  Tolerance: 1e-4 of each tensor's largest element
+    with a floor at 1e-6 of the largest gradient in the model (cancelling sums such as the norms' bias gradients)."""
+    import copy
+    import random
+    from kagnn_amd import models as M
+    monkeypatch.setattr(M, "_SPLIT_READOUT_MIN_ROWS", 0)
+    monkeypatch.setattr(M, "_SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH", 0)
+    rng = random.Random(4)
+    folded = 0
+    for case in range(10):
+        f_in = rng.choice([64, 128])
+        hidden = rng.choice([64, 64, 128, 32])
+        mp, hl = rng.choice([1, 2, 3]), rng.choice([1, 2])
+        n = rng.choice([700, 3001, 9000])
+        p_drop = rng.choice([0.0, 0.0, 0.0, 0.25])
+        classes = rng.choice([7, 40, 64, 70])
+        g = ops.GraphIndex(orc.powerlaw_graph(n, 8 * n, seed=case).to(DEV), n)
+        x = (torch.randn(n, f_in, generator=torch.Generator().manual_seed(case)) * 0.4).to(DEV)
+        y = torch.randint(0, classes, (n,), generator=torch.Generator().manual_seed(case + 1)).to(DEV)
+        torch.manual_seed(case)
+        model0 = kagnn_amd.GKAN_Nodes("gin", mp, f_in, hidden, classes, skip=True, grid_size=5, spline_order=3, hidden_layers=hl,
+                                      dropout=p_drop).to(DEV)
+        res = []
+        for lazy in (True, False):
+            monkeypatch.setattr(M, "_LAZY_NORM", lazy)
+            model = copy.deepcopy(model0)
+            xr = x.clone().requires_grad_(case % 2 == 0)
+            torch.manual_seed(1000 + case)
+            timer = ops.EntryPointTimer()
+            ops.set_timer(timer)
+            try:
+                loss = ops.softmax_cross_entropy(model(xr, g), y)
+                loss.backward()
+            finally:
+                ops.set_timer(None)
+            if lazy:
+                folded += sum(1 for r in timer.records if r[0] == "kagnn_batchnorm_stats_affine")
+            res.append([loss.detach().clone()] + ([xr.grad.clone()] if xr.requires_grad else [])
+                       + [p.grad.clone() for p in model.parameters()] + [b.clone() for b in model.buffers() if b.dtype.is_floating_point])
+        label = f"case {case}: f_in {f_in} hidden {hidden} mp {mp} chain {hl} n {n} dropout {p_drop} classes {classes}"
+        floor = 1e-6 * max(float(t.abs().max()) for t in res[1][1:])
+        for k, (a, b) in enumerate(zip(*res)):
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= max(1e-4 * scale, floor), (label, k, float((a - b).abs().max()), scale)
+    assert folded >= 5                                  # (the covered configurations really took the folded path)

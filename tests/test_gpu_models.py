@@ -431,6 +431,8 @@ def test_skip_gradient_handed_to_the_next_convolution_gives_the_tape_sums_bits(m
     autograd sum the two gradients -- every parameter gradient and the input gradient"""
     from kagnn_amd import models as M
     monkeypatch.setattr(M, "_SPLIT_READOUT_MIN_ROWS", 0)
+    monkeypatch.setattr(M, "_LAZY_NORM", False)        # (the composed node of the third variant cannot fold the norms: compare like with like;
+                                                       # the folded form has its own test in test_gpu_epilogue.py)
     n, e, f = 9000, 80000, 64
     g = ops.GraphIndex(orc.powerlaw_graph(n, e, seed=4).to(DEV), n)
     x = (torch.randn(n, f, generator=torch.Generator().manual_seed(3)) * 0.3).to(DEV)
@@ -483,6 +485,8 @@ def test_node_model_folds_against_the_unfused_paths_over_random_configurations(m
     import random
     from kagnn_amd import models as M
     monkeypatch.setattr(M, "_SPLIT_READOUT_MIN_ROWS", 0)
+    monkeypatch.setattr(M, "_LAZY_NORM", False)        # (round 4's fold changes the rounding of every layer input: its own test
+                                                       # over random configurations is in test_gpu_epilogue.py, at its own tolerance)
     rng = random.Random(20260929)
     for case in range(10):
         f_in = rng.choice([64, 128, 40, 64])
