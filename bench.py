@@ -15,10 +15,15 @@ One JSON line on stdout (rank 0).  Besides the contract's fields it carries
   cpu_baseline          the oracle (the reference's algorithm, "port") on the host cores, bounded sample
 The timed path is the product's default: ONE library call per convolution each way (kagnn_gin_kan_layer_fwd / _bwd); the
 dominant kernel is timed live inside it by the library's stage timer (kagnn_stage_timer_*: HIP events on the launch stream).
-N > 1 (one rank per GPU): an untimed probe runs the four combinations {feature-sharded (north_star's scheme), column/row
-transposed} x {RCCL collectives, direct peer-to-peer kernels}; `value` is the fastest one (named in config.parallelism),
-all four are listed under "multi_gpu_probe", north_star's literal scheme under "north_star_scheme".  Total work is fixed
-=> "scaling": "strong".
+N > 1 (one rank per GPU): a probe runs the combinations {feature-sharded (north_star's scheme), column/row transposed} x
+{RCCL through torch.distributed, direct peer-to-peer kernels} + the feature-sharded layer on the library's own RCCL entry
+points (include/kagnn_rccl.h), each under the full contract (W warm-up + K timed steps, max over ranks), plain RCCL first;
+`value` is the fastest one (named in config.parallelism), re-timed with the stage timer on; all are listed under
+"multi_gpu_probe", north_star's literal scheme under "north_star_scheme".  Total work is fixed => "scaling": "strong".
+The line survives a transport that hangs or kills a rank (none of the N > 1 paths has ever run on more than one device):
+rank 0's line travels through a forked reporter process that prints the LAST line it was handed when rank 0 ends -- the
+complete one, or the interim one written after the last combination that finished -- and every phase runs under a
+watchdog (KAGNN_BENCH_PHASE_TIMEOUT seconds, default 90; 300 for the first, which includes RCCL's start-up).
 """
 from __future__ import annotations
 
@@ -302,6 +307,66 @@ def other_layer_figures(dev, graph, n, e, steps=10):
 
 
 # ---------------------------------------------------------------------------------------------- main
+class _Reporter:
+    """N > 1 only.  Rank 0 hands every candidate for THE line (interim after each finished combination, complete at the end) to a
+    child forked before HIP is initialised; the child prints the last one it received when the pipe closes -- i.e. when rank 0
+    ends, however it ends (normal return, watchdog exit, SIGKILL from the launcher after another rank died, a GPU fault).
+    Exactly one line reaches stdout."""
+
+    def __init__(self):
+        import signal
+        r, w = os.pipe()
+        self.pid = os.fork()
+        if self.pid == 0:
+            os.close(w)
+            for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+                signal.signal(sig, signal.SIG_IGN)       # the launcher's clean-up must not take the reporter with it
+            last = b""
+            with os.fdopen(r, "rb") as f:
+                for line in f:
+                    if line.endswith(b"\n"):            # (a torn last line -- rank 0 died mid-write -- is dropped)
+                        last = line
+            if last:
+                os.write(1, last)
+            os._exit(0)
+        os.close(r)
+        self.w = os.fdopen(w, "wb", buffering=0)
+
+    def offer(self, obj) -> None:
+        self.w.write((json.dumps(obj) + "\n").encode())
+
+    def close(self) -> None:
+        self.w.close()
+        os.waitpid(self.pid, 0)
+
+
+class _Watchdog:
+    """every phase of the N > 1 run has a deadline; a rank that overruns it leaves (exit code 0: the reporter prints what rank 0
+    last offered).  All ranks enter a phase together (barrier), so they all leave within a second of each other."""
+
+    def __init__(self, rank: int):
+        import threading
+        self.rank, self.deadline, self.name = rank, None, ""
+        self.default = float(os.environ.get("KAGNN_BENCH_PHASE_TIMEOUT", "90"))
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def phase(self, name: str, seconds: float = None) -> None:
+        self.name, self.deadline = name, time.monotonic() + (self.default if seconds is None else seconds)
+
+    def clear(self) -> None:
+        self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            d = self.deadline
+            if d is not None and time.monotonic() > d:
+                sys.stderr.write(f"bench.py: rank {self.rank}: phase {self.name!r} overran its deadline -- leaving; rank 0's reporter "
+                                 "prints the last complete result\n")
+                sys.stderr.flush()
+                os._exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -337,6 +402,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # (forked before the first HIP call of this process: the child only reads a pipe and writes one line)
+    reporter = _Reporter() if (world > 1 and rank == 0 and os.environ.get("KAGNN_BENCH_REPORTER", "1") == "1") else None
+    dog = _Watchdog(rank) if world > 1 else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     # debugging aid for boxes with fewer GPUs than ranks: KAGNN_BENCH_BACKEND=gloo puts every rank on cuda:0 and
@@ -405,6 +473,23 @@ def main():
             dt = float(t)
         return dt
 
+    def contract_fields(value_, ms_, parallelism_):
+        """the contract's part of the JSON line (everything else is added by the rank-0 block at the end)"""
+        return {
+            "metric": "edges/sec KAN-GIN fwd+bwd, hidden=64 grid=5, 1M-node synthetic; HBM % peak",
+            "value": value_, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_, "higher_is_better": True, "scaling": "strong" if world > 1 else "n/a",
+            "vs_baseline": None, "dtype": ("f32" if fp32_mode else "f32 (fp16 hi/lo split operands, fp32 accumulate)") +
+                                          (" + bf16 gather operands (KAGNN_ACT=bf16, build-defined config-2 mode)" if args.act == "bf16" else ""),
+            "data": "synthetic",
+            "config": {"workload": (f"{args.workload}: FastKAN-GIN conv layer fwd+bwd (aggregate + FastKAN([{f},{f},{f}]) num_grids={grid}), "
+                                    if fastkan else
+                                    f"{args.workload}: KAN-GIN conv layer fwd+bwd (aggregate + KAN([{f},{f},{f}]) grid={grid} order={args.order}), ")
+                                   + f"power-law graph N={n} E={e} seed 0 (SURVEY 8(d))",
+                       "nodes": n, "edges": e, "hidden": f, "grid_size": grid, "spline_order": args.order,
+                       "precision": args.precision, "activation_storage": args.act, "parallelism": parallelism_},
+        }
+
     alt = None
     if world == 1:
         conv = conv.to(dev)
@@ -431,13 +516,26 @@ def main():
                 return (f"feature-sharded x{world}: spline coefficients split by input feature, " +
                         ("RCCL reduce-scatter (fwd) / all-gather (bwd) per KANLinear, row-chunked and overlapped (north_star's scheme)"
                          if comm == "rccl" else
+                         "the same RCCL exchange as ONE library call per KANLinear each way on the layer's own ncclComm_t "
+                         "(kagnn_sharded_kan_linear_fwd / _bwd, include/kagnn_rccl.h; north_star's scheme)"
+                         if comm == "rccl_c" else
                          "direct peer-to-peer reduce-scatter (fwd) / all-gather (bwd) kernels over hipIpc-mapped peer buffers per "
                          "KANLinear, row-chunked and overlapped (north_star's partitioning, SURVEY 8(e)'s hand-rolled exchange)"))
             return (f"column-sharded aggregation + row-sharded KAN chain x{world}: " +
                     ("RCCL all-to-all both ways" if comm == "rccl" else "direct peer-to-peer pulls over hipIpc-mapped buffers both ways") +
                     ", one flat weight-gradient all-reduce")
 
+        # test aid for the safety net above (tests/test_sharded_gloo.py): KAGNN_BENCH_FAULT="<scheme>/<comm>:hang|kill[:rank]"
+        # makes that combination hang on / kill the given rank (default 1) -- what a broken transport would do
+        fault = os.environ.get("KAGNN_BENCH_FAULT", "")
+
         def make(scheme, comm):
+            if fault.startswith(f"{scheme}/{comm}:"):
+                how, _, who = fault.split(":", 1)[1].partition(":")
+                if rank == int(who or 1):
+                    if how == "kill":
+                        os.kill(os.getpid(), 9)
+                    time.sleep(1e6)
             cls = classes[scheme]
             sconv = (cls(conv, dist.group.WORLD, sync_in_backward=False, comm=comm) if cls is TransposedShardedGIKANLayer
                      else cls(conv, dist.group.WORLD, comm=comm)).to(dev)
@@ -455,40 +553,56 @@ def main():
                     sconv.sync_gradients()             # one flat all-reduce for all weight gradients
             return step
 
-        # Which combination is `value`?  KAGNN_SHARDING / KAGNN_COMM pin it; otherwise an UNTIMED probe runs all four
-        # ({feature, transposed} x {rccl, p2p}: short warm-up + a few steps each, max over ranks) and the fastest is then timed
-        # under the contract (W warm-up + K steps).  A combination that fails (e.g. no IPC between two devices) is listed with
-        # its error and skipped; the failure is symmetric across ranks for setup errors, which is what can go wrong here.
+        # Which combination is `value`?  KAGNN_SHARDING / KAGNN_COMM pin it; otherwise every combination runs under the full
+        # contract (W warm-up + K timed steps, max over ranks) and the fastest is reported (re-timed below with the stage timer
+        # on).  Order = least exotic first: plain RCCL through torch.distributed, then the direct peer-to-peer kernels, then the
+        # library's own RCCL entry points -- after every combination that finishes, rank 0 hands an interim line to the reporter,
+        # so a later transport that hangs (watchdog) or kills a rank still leaves a measured line.  A combination that raises is
+        # listed with its error and skipped (setup errors are symmetric across ranks; an asymmetric one ends in the watchdog).
         pin_s, pin_c = os.environ.get("KAGNN_SHARDING"), os.environ.get("KAGNN_COMM")
-        combos = [(sc, cm) for sc in ("feature", "transposed") for cm in ("rccl", "p2p")
-                  if (pin_s is None or sc == pin_s) and (pin_c is None or cm == pin_c)]
+        order = [("feature", "rccl"), ("transposed", "rccl"), ("feature", "p2p"), ("transposed", "p2p"), ("feature", "rccl_c")]
+        combos = [(sc, cm) for sc, cm in order if (pin_s is None or sc == pin_s) and (pin_c is None or cm == pin_c)]
         if not combos:
-            raise SystemExit("KAGNN_SHARDING must be 'feature' or 'transposed', KAGNN_COMM 'rccl' or 'p2p'")
+            raise SystemExit("KAGNN_SHARDING must be 'feature' or 'transposed', KAGNN_COMM 'rccl', 'rccl_c' (feature only) or 'p2p'")
         probe = []
-        probe_warm, probe_steps = min(args.warmup, 2), max(2, min(args.steps, 5))
-        for sc, cm in combos:
+
+        def selection(entries):
+            ok_ = [p_ for p_ in entries if "error" not in p_]
+            return min(ok_, key=lambda p_: p_["ms_per_step"]) if ok_ else None
+
+        for ci, (sc, cm) in enumerate(combos):
             entry = {"scheme": sc, "comm": cm, "parallelism": describe(sc, cm)}
-            if len(combos) > 1:
-                try:
-                    st = make(sc, cm)
-                    for _ in range(probe_warm):
-                        st()
-                    dtp = timed(st, probe_steps)
-                    entry.update(ms_per_step=dtp / probe_steps * 1e3, value=e / (dtp / probe_steps), steps=probe_steps, warmup=probe_warm)
-                    del st
-                except Exception as ex:                   # noqa: BLE001 -- reported in the line, not swallowed
-                    entry["error"] = f"{type(ex).__name__}: {ex}"[:300]
-                torch.cuda.empty_cache()
+            dog.phase(f"combination {sc}/{cm}", 300.0 if ci == 0 else None)      # (the first one includes RCCL's start-up)
+            try:
+                st = make(sc, cm)
+                for _ in range(args.warmup):
+                    st()
+                dtp = timed(st, args.steps)
+                entry.update(ms_per_step=dtp / args.steps * 1e3, value=e / (dtp / args.steps), steps=args.steps, warmup=args.warmup)
+                del st
+            except Exception as ex:                       # noqa: BLE001 -- reported in the line, not swallowed
+                entry["error"] = f"{type(ex).__name__}: {ex}"[:300]
+            dog.clear()
+            torch.cuda.empty_cache()
             probe.append(entry)
-        ok = [p_ for p_ in probe if "error" not in p_]
-        if not ok:
+            best = selection(probe)
+            if reporter is not None and best is not None:
+                line = contract_fields(best["value"], best["ms_per_step"], best["parallelism"])
+                line["multi_gpu_probe"] = {"selected": {"scheme": best["scheme"], "comm": best["comm"]}, "combinations": list(probe),
+                                           "not_run": [f"{a}/{b}" for a, b in combos[ci + 1:]]}
+                line["interim"] = ("this line was written after the last combination that finished; a later phase of the run hung or "
+                                   "lost a rank (stderr names it)")
+                reporter.offer(line)
+        best = selection(probe)
+        if best is None:
             raise SystemExit("bench.py: every multi-GPU combination failed: " + json.dumps(probe))
-        best = min(ok, key=lambda p_: p_.get("ms_per_step", 0.0))
+        dog.phase("final timing of the selected combination", 180.0)
         step = make(best["scheme"], best["comm"])
         parallelism = best["parallelism"]
         alt = {"selected": {"scheme": best["scheme"], "comm": best["comm"]},
                "how": ("pinned by KAGNN_SHARDING / KAGNN_COMM" if len(combos) == 1 else
-                       f"fastest of the untimed probe ({probe_warm} warm-up + {probe_steps} steps per combination, max over ranks)"),
+                       f"fastest of the combinations, each run under the contract ({args.warmup} warm-up + {args.steps} timed steps, max over "
+                       "ranks); `value` is its re-run with the stage timer on the dominant kernel"),
                "combinations": probe}
 
     for _ in range(args.warmup):
@@ -512,6 +626,8 @@ def main():
     with ops.LibraryStageTimer(only):
         dt = timed(step, args.steps)
     prof_live = ops.LibraryStageTimer.collect()
+    if dog is not None:
+        dog.phase("per-rank gather", 60.0)
     ms = dt / args.steps * 1e3
     value = e / (dt / args.steps)
 
@@ -523,6 +639,8 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         per_rank = [dict(g, not_in_library_ms_per_step=max(0.0, ms - g["library_ms_per_step"])) for g in gathered]
+    if dog is not None:
+        dog.clear()
 
     fp32_ms = None
     if not args.no_fp32 and not fp32_mode and world == 1:
@@ -597,19 +715,8 @@ def main():
                         "mostly served by the Infinity Cache (served_from) -- the limiting kernels are in roofline_kernels, and "
                         "the honest headline figure is layer_hbm_frac")
         layer_gbs = layer_bytes(n, e, f) / (ms * 1e-3) / 1e9
-        out = {
-            "metric": "edges/sec KAN-GIN fwd+bwd, hidden=64 grid=5, 1M-node synthetic; HBM % peak",
-            "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if world > 1 else "n/a",
-            "vs_baseline": None, "dtype": ("f32" if fp32_mode else "f32 (fp16 hi/lo split operands, fp32 accumulate)") +
-                                          (" + bf16 gather operands (KAGNN_ACT=bf16, build-defined config-2 mode)" if args.act == "bf16" else ""),
-            "data": "synthetic",
-            "config": {"workload": (f"{args.workload}: FastKAN-GIN conv layer fwd+bwd (aggregate + FastKAN([{f},{f},{f}]) num_grids={grid}), "
-                                    if fastkan else
-                                    f"{args.workload}: KAN-GIN conv layer fwd+bwd (aggregate + KAN([{f},{f},{f}]) grid={grid} order={args.order}), ")
-                                   + f"power-law graph N={n} E={e} seed 0 (SURVEY 8(d))",
-                       "nodes": n, "edges": e, "hidden": f, "grid_size": grid, "spline_order": args.order,
-                       "precision": args.precision, "activation_storage": args.act, "parallelism": parallelism},
+        out = contract_fields(value, ms, parallelism)
+        out.update({
             "layer_algorithmic_bytes": layer_bytes(n, e, f),
             "layer_hbm_GBs": layer_gbs, "layer_hbm_frac": layer_gbs / HBM_PEAK_GBS,
             "fp32_mode_ms_per_step": fp32_ms,
@@ -625,12 +732,12 @@ def main():
             # one-time per edge_index (cached on its identity); outside the timed region
             "graph_index_build_ms": {"steady": graph_build_ms, "first_call": graph_build_first_ms,
                                      "what": "CSR by destination + its transpose (stable radix sort, hub segments), int64 edge_index already in HBM"},
-        }
+        })
         if alt is not None:
             out["multi_gpu_probe"] = alt
-            ns = [p_ for p_ in alt["combinations"] if p_["scheme"] == "feature" and p_["comm"] == "rccl"]
-            if ns:
-                out["north_star_scheme"] = ns[0]
+            ns = [p_ for p_ in alt["combinations"] if p_["scheme"] == "feature" and p_["comm"] in ("rccl", "rccl_c")]
+            if ns:                                        # (spline coefficients sharded by input feature + RCCL: the faster of its two hosts)
+                out["north_star_scheme"] = min(ns, key=lambda p_: p_.get("ms_per_step", float("inf")))
         if per_rank is not None:
             out["per_rank"] = per_rank
             out["per_rank_note"] = ("library_ms_per_step: HIP-event time of this rank's kernels (3 profile steps); not_in_library: the rest of "
@@ -673,9 +780,16 @@ def main():
                                                    arch="fastkan" if fastkan else "kan")
                 out["cpu_baseline"]["selected"] = ("1/10-size sample (--cpu-sample-only)" if args.cpu_sample_only
                                                    else f"1/10-size sample (MemAvailable {mem:.0f} GB < 48 GB)")
-        print(json.dumps(out), flush=True)
+        if reporter is not None:
+            reporter.offer(out)                          # (the reporter prints it when this process ends)
+        else:
+            print(json.dumps(out), flush=True)
+    if dog is not None:
+        dog.phase("shutdown", 60.0)
     if dist is not None:
         dist.destroy_process_group()
+    if reporter is not None:
+        reporter.close()
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
 """Build libkagnn_hip.so (gfx950) in-tree with hipcc.  No torch involved: the library is a plain
-C-ABI shared object (include/kagnn_hip.h)."""
+C-ABI shared object (include/kagnn_hip.h).  libkagnn_rccl.so (include/kagnn_rccl.h: the sharded KANLinear on a caller-owned
+ncclComm_t) is a second shared object next to it, linking librccl and libkagnn_hip.so."""
 from __future__ import annotations
 
 import os
@@ -12,6 +13,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIBPATH = os.path.join(LIBDIR, "libkagnn_hip.so")
+RCCL_LIBPATH = os.path.join(LIBDIR, "libkagnn_rccl.so")
+RCCL_SOURCE = "rccl_sharded.hip"
+ROCM_LIB = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
 SOURCES = ["api.hip", "csr.hip", "aggregate.hip", "aggregate_bf16.hip", "kan_fp32.hip", "kan_split.hip", "kan_sparse_fwd.hip", "kan_split_bwd.hip", "kan_grid.hip", "fastkan.hip", "bn.hip", "gat.hip", "loss.hip", "p2p.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wno-unused-result", "-DNDEBUG"]
@@ -38,6 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(PKG), "include", "kagnn_hip.h"))
+    headers.append(os.path.join(os.path.dirname(PKG), "include", "kagnn_rccl.h"))
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
@@ -50,9 +55,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return o
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+        objs = list(ex.map(compile_one, SOURCES + [RCCL_SOURCE]))
+    rccl_obj = objs.pop()
     if force or _stale(LIBPATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    if force or _stale(RCCL_LIBPATH, [rccl_obj, LIBPATH]):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", RCCL_LIBPATH, rccl_obj,
+               "-L" + LIBDIR, "-lkagnn_hip", "-L" + ROCM_LIB, "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + ROCM_LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -284,11 +284,15 @@ class ShardedGIKANLayer(nn.Module):
         overlapped.  ``comm="p2p"``: the direct form of SURVEY.md 8(e) -- every rank maps its peers' exchange buffers
         (hipIpc, ``kagnn_amd/p2p.py``) and ONE kernel per exchange pulls the column blocks over xGMI
         (``kagnn_p2p_reduce_scatter`` / ``kagnn_p2p_all_gather``); the KAN forward writes its partial sums straight into the
-        peer-mapped buffer and the gathered gradient lands in its final layout: no staging passes, no ring."""
+        peer-mapped buffer and the gathered gradient lands in its final layout: no staging passes, no ring.
+        ``comm="rccl_c"``: the RCCL form with the whole exchange inside the library -- one call per KANLinear each way
+        (``kagnn_sharded_kan_linear_fwd / _bwd`` of include/kagnn_rccl.h on an ``ncclComm_t`` of this layer's own): the same
+        row chunks and overlap, no Python between the chunks, ONE weight-gradient pass over all rows."""
         super().__init__()
-        if comm not in ("rccl", "p2p"):
-            raise ValueError("comm must be 'rccl' or 'p2p'")
+        if comm not in ("rccl", "rccl_c", "p2p"):
+            raise ValueError("comm must be 'rccl', 'rccl_c' or 'p2p'")
         self.comm = comm
+        self._ccomm = None                 # comm="rccl_c": this layer's own ncclComm_t (kagnn_amd/rccl.py), made on first use
         self._xch = {}
         self._side = None                  # ONE side stream for all exchanges of this layer (their order is part of the buffer-reuse argument)
         self.group = group
@@ -340,6 +344,17 @@ class ShardedGIKANLayer(nn.Module):
                    and l.precision == first.precision for l in self.layers):
                 packs = pack_chain([(l.base_weight, l.spline_weight, l.spline_scaler) for l in self.layers],
                                    first.grid_size, first.spline_order, mode)
+        if self.comm == "rccl_c":
+            from . import rccl
+            if self.local_ops is not _hip_ops:
+                raise ValueError("comm='rccl_c' needs the HIP ops (the exchange is a library call)")
+            if self._ccomm is None:
+                self._ccomm = rccl.Communicator.from_group(self.group, h.device)
+            for li, layer in enumerate(self.layers):
+                h = rccl.sharded_kan_linear(h, layer.base_weight, layer.spline_weight, layer.spline_scaler, layer.knots,
+                                            layer.grid_size, layer.spline_order, layer.precision, self._ccomm,
+                                            row_chunks=len(bounds), packed=None if packs is None else packs[li])
+            return h
         if self.comm == "p2p":
             for li, layer in enumerate(self.layers):
                 out = layer.out_features

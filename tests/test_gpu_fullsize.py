@@ -160,6 +160,82 @@ def test_sharded_layer_world1_nccl():
             dist.destroy_process_group()
 
 
+def test_rccl_c_entry_points_world1_vs_oracle_and_plain_ops():
+    """libkagnn_rccl.so (include/kagnn_rccl.h): kagnn_sharded_kan_linear_fwd / _bwd on an ncclComm_t of one rank -- the
+    staging kernels, ncclReduceScatter / ncclAllGather on the side stream, the row chunks, ONE weight-gradient pass.
+    With one rank the exchange is the identity, so every output must equal the plain KANLinear ops BIT FOR BIT (rows are
+    independent in y and gx; the weight gradient is the same single launch); the whole sharded layer (comm="rccl_c") is
+    then checked against the fp64 oracle.  More than one rank needs more than one GPU (RCCL refuses two ranks on a device)."""
+    import os
+    import torch.distributed as dist
+    from kagnn_amd import rccl
+    comm = rccl.Communicator(rccl.Communicator.unique_id(), 1, 0, torch.device(DEV))
+    try:
+        for n, fin, fout, grid, chunks in ((5000, 64, 64, 5, 1), (5000, 64, 64, 5, 3), (4097, 24, 40, 5, 2),
+                                           (300_000, 64, 64, 5, 4), (70_001, 128, 128, 8, 3), (7, 16, 16, 3, 4)):
+            torch.manual_seed(n + fin)
+            layer = kagnn_amd.KANLinear(fin, fout, grid_size=grid, spline_order=3).to(DEV)
+            gen = torch.Generator(device=DEV).manual_seed(n)
+            x = (torch.randn(n, fin, device=DEV, generator=gen) * 0.4)
+            gy = torch.randn(n, fout, device=DEV, generator=gen)
+            xa = x.clone().requires_grad_(True)
+            ya = layer(xa)
+            ya.backward(gy)
+            want = {k: p.grad.clone() for k, p in layer.named_parameters()}
+            layer.zero_grad()
+            xb = x.clone().requires_grad_(True)
+            yb = rccl.sharded_kan_linear(xb, layer.base_weight, layer.spline_weight, layer.spline_scaler, layer._knots(),
+                                         grid, 3, None, comm, row_chunks=chunks)
+            yb.backward(gy)
+            torch.cuda.synchronize()
+            tag = f"n={n} {fin}->{fout} grid {grid} chunks {chunks}"
+            if fin <= 64:
+                assert torch.equal(ya, yb), tag
+                assert torch.equal(xa.grad, xb.grad), tag
+                for k, p in layer.named_parameters():
+                    assert torch.equal(want[k], p.grad), (tag, k)
+            else:       # wider inputs: the forward splits its feature loop by ROW COUNT (few rows -> more splits), so a row chunk
+                        # may sum in another order than the whole matrix -- same values to rounding
+                assert_close(yb, ya.detach(), tol=2e-6, what=tag + " y")
+                assert_close(xb.grad, xa.grad, tol=2e-6, what=tag + " gx")
+                for k, p in layer.named_parameters():
+                    assert_close(p.grad, want[k], tol=2e-6, what=tag + " " + k)
+        # the sharded layer on that transport, against the oracle
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        created = not dist.is_initialized()
+        if created:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        try:
+            from kagnn_amd.sharded import ShardedGIKANLayer
+            n, e, f = 20000, 200000, 64
+            ei = orc.powerlaw_graph(n, e, seed=6)
+            gen = torch.Generator().manual_seed(6)
+            x = torch.randn(n, f, generator=gen) * 0.25
+            gy = torch.randn(n, f, generator=gen)
+            conv = kagnn_amd.GIKANLayer(f, f, grid_size=5, spline_order=3, hidden_dim=f, nb_layers=2)
+            layers = [{k: v.detach().clone() for k, v in l.state_dict().items()} for l in conv.nn.layers]
+            y_ref, gx_ref, g_ref = orc.kan_gin_layer_fwd_bwd(x, ei, layers, 3, gy)
+            graph = ops.GraphIndex(ei.to(DEV), n)
+            for chunks in (1, 3):
+                s = ShardedGIKANLayer(conv, None, chunks=chunks, comm="rccl_c").to(DEV)
+                for _ in range(2):                       # twice: the communicator and its side stream are reused
+                    s.zero_grad()
+                    xs = x.to(DEV).requires_grad_(True)
+                    y = s(xs, graph)
+                    y.backward(gy.to(DEV))
+                assert_close(y, y_ref, what=f"rccl_c sharded y (chunks={chunks})")
+                assert_close(xs.grad, gx_ref, what=f"rccl_c sharded gx (chunks={chunks})")
+                for li, layer in enumerate(s.layers):
+                    for k in ("base_weight", "spline_weight", "spline_scaler"):
+                        assert_close(getattr(layer, k).grad, g_ref[li][k], what=f"rccl_c L{li}.{k} (chunks={chunks})")
+        finally:
+            if created:
+                dist.destroy_process_group()
+    finally:
+        comm.close()
+
+
 def test_activations_beyond_4gib_stay_on_the_split_kernels():
     """x [20M, 64] fp32 is 5.1 GB: byte offsets no longer fit 32 bits.  The split kernels re-open their buffer windows
     per workgroup tile, so the layer must (a) not fall back to the fp32 kernels and (b) treat the far rows exactly

@@ -9,36 +9,40 @@ import pytest
 import torch
 
 import kagnn_amd
-from kagnn_amd import _lib
+from kagnn_amd import _lib, rccl
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the two C-ABI libraries: header, ctypes host module, minimum number of entry points
+ABIS = [("kagnn_hip.h", _lib, 20), ("kagnn_rccl.h", rccl, 8)]
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "kagnn_hip.h")).read()
+def _declared_symbols(header="kagnn_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(kagnn_[a-z0-9_]+)\s*\(", src)))
 
 
-def test_library_exports_every_declared_symbol():
-    if not os.path.exists(_lib.LIB_PATH):
+@pytest.mark.parametrize("header,mod,least", ABIS, ids=[a[0] for a in ABIS])
+def test_library_exports_every_declared_symbol(header, mod, least):
+    if not os.path.exists(mod.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
-    lib = _lib.load()
-    declared = _declared_symbols()
-    assert len(declared) >= 20
+    lib = mod.load()
+    declared = _declared_symbols(header)
+    assert len(declared) >= least
     for name in declared:
-        assert hasattr(lib, name), f"{name} is declared in include/kagnn_hip.h but not exported"
-    assert sorted(_lib.EXPORTED) == declared, "ctypes signature table and header disagree"
-    assert lib.kagnn_version() >= 100
+        assert hasattr(lib, name), f"{name} is declared in include/{header} but not exported"
+    assert sorted(mod.EXPORTED) == declared, "ctypes signature table and header disagree"
+    assert (lib.kagnn_version() if mod is _lib else lib.kagnn_rccl_version()) >= 100
 
 
-def test_ctypes_signatures_match_the_header_prototypes():
-    """every prototype of include/kagnn_hip.h against the ctypes table of kagnn_amd/_lib.py: number of parameters, and per
-    parameter pointer / 64-bit integer / 32-bit integer / float / size_t -- a drifted signature would otherwise only show up
-    as garbage arguments on the GPU box"""
+@pytest.mark.parametrize("header,mod,least", ABIS, ids=[a[0] for a in ABIS])
+def test_ctypes_signatures_match_the_header_prototypes(header, mod, least):
+    """every prototype of include/kagnn_hip.h (kagnn_rccl.h) against the ctypes table of kagnn_amd/_lib.py (rccl.py): number of
+    parameters, and per parameter pointer / 64-bit integer / 32-bit integer / float / size_t -- a drifted signature would
+    otherwise only show up as garbage arguments on the GPU box"""
     import ctypes
-    src = open(os.path.join(ROOT, "include", "kagnn_hip.h")).read()
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = dict(re.findall(r"\b(kagnn_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
 
@@ -64,7 +68,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
 
     sizes = {"i64": 8, "size": ctypes.sizeof(ctypes.c_size_t), "ptr": ctypes.sizeof(ctypes.c_void_p)}
     checked = 0
-    for name, (_res, argtypes) in _lib._SIGNATURES.items():
+    for name, (_res, argtypes) in mod._SIGNATURES.items():
         params = protos[name].strip()
         c_kinds = [] if params in ("", "void") else [kind_c(q) for q in params.split(",")]
         py_kinds = [kind_py(t) for t in argtypes]
@@ -72,7 +76,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
         for i, (a, b) in enumerate(zip(c_kinds, py_kinds)):
             assert a == b or sizes.get(a, 4) == sizes.get(b, 4) and {a, b} <= {"i64", "size"}, f"{name}: parameter {i}: header {a}, ctypes {b}"
         checked += 1
-    assert checked == len(protos) >= 20
+    assert checked == len(protos) >= least
 
 
 def test_state_dict_surface_matches_reference_names():
@@ -214,6 +218,31 @@ def test_size_queries_and_argument_checks_need_no_gpu():
     assert lib.kagnn_gin_kan_layer_bwd_bn_workspace_bytes(10, 0, byref(a)) != 0
     assert lib.kagnn_aggregate_sum_add(None, 4, None, 8, None, None, None, 10, 8, 1.0, None, None, None, 0, None, 0, 0, None, 0, None, 0,
                                        None) != 0                                                                    # null arrays / ldx < F
+
+
+def test_rccl_library_size_query_and_argument_checks_need_no_gpu():
+    """libkagnn_rccl.so (include/kagnn_rccl.h): the workspace query is host arithmetic on top of libkagnn_hip's own queries and
+    bad arguments are refused before any HIP / RCCL call"""
+    from ctypes import byref, c_size_t
+    lib = rccl.load()
+    f, b = c_size_t(0), c_size_t(0)
+    n, out = 1_000_000, 64
+    assert lib.kagnn_sharded_kan_linear_workspace_bytes(n, 8, out, 5, 3, _lib.PREC_SPLIT, 8, 4, byref(f), byref(b)) == 0
+    mat = n * out * 4
+    assert 2 * mat <= f.value < 2 * mat + (1 << 20)                  # partial sums + rank-major blocks (tall input: no kernel scratch)
+    assert 2 * mat < b.value < 2 * mat + (1 << 30)                   # gathered blocks + gathered gradient + weight-gradient slabs
+    assert lib.kagnn_sharded_kan_linear_workspace_bytes(n, 8, 60, 5, 3, _lib.PREC_SPLIT, 8, 4, byref(f), byref(b)) != 0     # 60 % 8
+    assert b"divisible" in lib.kagnn_rccl_last_error()
+    assert lib.kagnn_sharded_kan_linear_workspace_bytes(n, 8, out, 5, 3, _lib.PREC_SPLIT, 8, 0, byref(f), byref(b)) != 0    # 0 chunks
+    assert lib.kagnn_sharded_kan_linear_workspace_bytes(n, 8, out, 5, 7, _lib.PREC_SPLIT, 8, 1, byref(f), byref(b)) != 0    # order 7
+    assert b"spline_order" in lib.kagnn_rccl_last_error()           # (libkagnn_hip's message is carried through)
+    assert lib.kagnn_sharded_kan_linear_fwd(None, 8, 10, None, 8, out, 5, 3, _lib.PREC_SPLIT, None, None, None, 8, 0, 1, None, 0,
+                                            None, None) != 0         # no communicator
+    assert b"comm is NULL" in lib.kagnn_rccl_last_error()
+    assert lib.kagnn_rccl_comm_init(None, 2, 0, None) != 0
+    assert lib.kagnn_rccl_comm_destroy(None) == 0
+    with pytest.raises(ValueError):
+        rccl.Communicator(b"short", 1, 0, torch.device("cpu"))
 
 
 def test_hot_path_kernels_do_not_spill_registers():

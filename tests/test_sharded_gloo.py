@@ -236,3 +236,51 @@ def test_sharded_layers_two_ranks_one_gpu(tmp_path):
         port = s.getsockname()[1]
     mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), both ranks on cuda:0 with
+# the collectives on gloo (KAGNN_BENCH_BACKEND=gloo: numbers meaningless, control flow real): the combination loop, the
+# reporter process that owns THE line, and the watchdog -- none of the N > 1 transports has ever run on two devices, so
+# the line must survive one that hangs and one that takes a rank down (KAGNN_BENCH_FAULT)
+def _run_bench_two_ranks(extra_env, timeout=420):
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, KAGNN_BENCH_BACKEND="gloo", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--nodes", "20000", "--edges", "200000"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    return r.returncode, json.loads(lines[0]), r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_prints_one_line_even_when_a_transport_hangs_or_kills_a_rank():
+    rc, line, err = _run_bench_two_ranks({})
+    assert rc == 0, err[-3000:]
+    combos = {(c["scheme"], c["comm"]): c for c in line["multi_gpu_probe"]["combinations"]}
+    assert set(combos) == {("feature", "rccl"), ("transposed", "rccl"), ("feature", "p2p"), ("transposed", "p2p"), ("feature", "rccl_c")}
+    for k in (("feature", "rccl"), ("transposed", "rccl"), ("feature", "p2p"), ("transposed", "p2p")):
+        assert "error" not in combos[k] and combos[k]["ms_per_step"] > 0, combos[k]
+    # two ranks on one device: RCCL itself refuses (the library entry points need one GPU per rank) -- listed, not fatal
+    assert "error" in combos[("feature", "rccl_c")], combos[("feature", "rccl_c")]
+    assert "interim" not in line and line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["north_star_scheme"]["scheme"] == "feature" and "per_rank" in line and line["roofline"]["frac"] > 0
+    sel = line["multi_gpu_probe"]["selected"]
+    assert (sel["scheme"], sel["comm"]) in combos and "error" not in combos[(sel["scheme"], sel["comm"])]
+
+    # a transport that hangs on one rank: the watchdog ends the run, the line is the interim one of what had finished
+    rc, line, err = _run_bench_two_ranks({"KAGNN_BENCH_FAULT": "feature/p2p:hang", "KAGNN_BENCH_PHASE_TIMEOUT": "25"})
+    assert "interim" in line and line["value"] > 0 and "overran its deadline" in err
+    done = [(c["scheme"], c["comm"]) for c in line["multi_gpu_probe"]["combinations"]]
+    assert done == [("feature", "rccl"), ("transposed", "rccl")]
+    assert line["multi_gpu_probe"]["not_run"] == ["transposed/p2p", "feature/rccl_c"]
+
+    # a transport that takes rank 0 itself down (SIGKILL): the reporter still prints what rank 0 had handed it
+    rc, line, err = _run_bench_two_ranks({"KAGNN_BENCH_FAULT": "transposed/p2p:kill:0", "KAGNN_BENCH_PHASE_TIMEOUT": "25"})
+    assert "interim" in line and len(line["multi_gpu_probe"]["combinations"]) == 3 and line["ms_per_step"] > 0
