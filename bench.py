@@ -589,7 +589,7 @@ def main():
             if reporter is not None and best is not None:
                 line = contract_fields(best["value"], best["ms_per_step"], best["parallelism"])
                 line["multi_gpu_probe"] = {"selected": {"scheme": best["scheme"], "comm": best["comm"]}, "combinations": list(probe),
-                                           "not_run": [f"{a}/{b}" for a, b in combos[ci + 1:]]}
+                                           "not_finished": [f"{a}/{b}" for a, b in combos[ci + 1:]]}
                 line["interim"] = ("this line was written after the last combination that finished; a later phase of the run hung or "
                                    "lost a rank (stderr names it)")
                 reporter.offer(line)

@@ -279,7 +279,7 @@ def test_bench_two_ranks_prints_one_line_even_when_a_transport_hangs_or_kills_a_
     assert "interim" in line and line["value"] > 0 and "overran its deadline" in err
     done = [(c["scheme"], c["comm"]) for c in line["multi_gpu_probe"]["combinations"]]
     assert done == [("feature", "rccl"), ("transposed", "rccl")]
-    assert line["multi_gpu_probe"]["not_run"] == ["transposed/p2p", "feature/rccl_c"]
+    assert line["multi_gpu_probe"]["not_finished"] == ["feature/p2p", "transposed/p2p", "feature/rccl_c"]
 
     # a transport that takes rank 0 itself down (SIGKILL): the reporter still prints what rank 0 had handed it
     rc, line, err = _run_bench_two_ranks({"KAGNN_BENCH_FAULT": "transposed/p2p:kill:0", "KAGNN_BENCH_PHASE_TIMEOUT": "25"})
