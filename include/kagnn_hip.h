@@ -43,7 +43,7 @@ extern "C" {
 #define KAGNN_DTYPE_F32 0
 #define KAGNN_DTYPE_BF16 1
 
-int kagnn_version(void);          /* 230 = this header (220 + the *_affine entry points of a folded BatchNorm1d; 220 = 210 + the stage timer) */
+int kagnn_version(void);          /* 240 = this header (230 + kagnn_gin_kan_layer_bwd_bn_sums; 230 = 220 + the *_affine entry points of a folded BatchNorm1d; 220 = 210 + the stage timer) */
 const char* kagnn_last_error(void);
 
 /* Stage timer -- a measurement aid, off by default (no reference counterpart: the reference times whole epochs with
@@ -336,6 +336,35 @@ int kagnn_gin_kan_layer_bwd_bn(const float* g, int64_t ldg, const float* y, int6
                                const float* gx_addend, int64_t ld_addend, float* const* g_base_weight,
                                float* const* g_spline_weight, float* const* g_spline_scaler, void* workspace,
                                size_t workspace_bytes, void* stream);
+
+/* kagnn_gin_kan_layer_bwd_bn with the norms' backward STATISTICS travelling with the gradients (round 4; reference
+ * node_classification_clean/models.py:198-200 -- in the node models the gradient g arriving at layer l's norm is what layer
+ * l+1's transposed aggregation produces, plus the skip gradient added there):
+ *   prev_y [N, widths[0]] (ld_prev_y), prev_mean, prev_rstd, prev_sums -- all four or none: this call's transposed aggregation
+ *     ALSO leaves prev_sums[0][widths[0]] = sum_n gx, prev_sums[1][widths[0]] = sum_n gx * xhat, xhat = (prev_y - prev_mean) *
+ *     prev_rstd, where prev_y is the PREVIOUS norm's input (this convolution's input before the folded affine): the two column
+ *     sums that norm's backward starts from.  Partial sums in the row kernel's epilogue (one row pair per workgroup, hub rows
+ *     from the merge kernel), folded in a fixed order: deterministic.  Needs an fp32 gx, 17..256 input features (a multiple of
+ *     4), 16-byte aligned rows; otherwise KAGNN_ERR_UNSUPPORTED.
+ *   bn_sums [2][widths[L]] or NULL: the same two sums for THIS norm, made by the next layer's call -- the statistics pass over
+ *     g and y is skipped when the norm's element-wise backward runs inside the input-gradient kernel (ignored otherwise).
+ * Workspace: kagnn_gin_kan_layer_bwd_bn's, plus kagnn_gin_kan_layer_bwd_bn_sums_workspace_bytes when prev_sums is given.  */
+int kagnn_gin_kan_layer_bwd_bn_sums_workspace_bytes(int64_t num_nodes, int32_t in_features, int64_t num_hub_seg_t,
+                                                    size_t* bytes_host);
+int kagnn_gin_kan_layer_bwd_bn_sums(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* bn_weight,
+                                    const float* bn_mean, const float* bn_rstd, float* g_bn_weight, float* g_bn_bias,
+                                    const float* bn_sums,
+                                    const float* prev_y, int64_t ld_prev_y, const float* prev_mean, const float* prev_rstd,
+                                    float* prev_sums,
+                                    int64_t num_nodes, const int32_t* rowptr_t, const int32_t* col_t,
+                                    const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
+                                    int32_t num_layers, const int32_t* widths, const float* const* spline_weight,
+                                    const float* const* spline_scaler, const float* knots, int32_t grid_size,
+                                    int32_t spline_order, int32_t mode, const float* const* acts,
+                                    const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
+                                    const float* gx_addend, int64_t ld_addend, float* const* g_base_weight,
+                                    float* const* g_spline_weight, float* const* g_spline_scaler, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Adaptive grids.  Replaces the device work of KANLinear.update_grid (ekan.py:164-211) and the dense

@@ -84,6 +84,12 @@ _SIGNATURES = {
                                              c_int64, _P, _P, _P, c_int64, c_int32, c_float, c_int32, _P, _P, _P,
                                              _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P, c_int64,
                                              _P, _P, _P, _P, c_size_t, _P]),
+    "kagnn_gin_kan_layer_bwd_bn_sums_workspace_bytes": (c_int32, [c_int64, c_int32, c_int64, POINTER(c_size_t)]),
+    "kagnn_gin_kan_layer_bwd_bn_sums": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P,
+                                                  _P, _P, c_int64, _P, _P, _P,
+                                                  c_int64, _P, _P, _P, c_int64, c_int32, c_float, c_int32, _P, _P, _P,
+                                                  _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P, c_int64,
+                                                  _P, _P, _P, _P, c_size_t, _P]),
     "kagnn_kan_bsplines": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
     "kagnn_kan_grid_refit_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "kagnn_kan_grid_refit": (c_int32, [_P, c_int64, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P,

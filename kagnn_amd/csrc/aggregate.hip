@@ -24,50 +24,81 @@ __device__ __forceinline__ float edge_w(const AggArgs& a, int e, int j, long i) 
     return w;
 }
 
-template <int LPR>
+// the statistics side of a stored row (AggArgs::st_*): o and o * xhat for this lane's four columns
+__device__ __forceinline__ void stats_products(const AggArgs& a, long row, int c4, const float4& o, float4& pa, float4& pb) {
+    const float4 y = ld4(a.st_y + row * a.st_ldy + c4), m = ld4(a.st_mean + c4), q = ld4(a.st_rstd + c4);
+    pa = o;
+    pb = make_float4(o.x * ((y.x - m.x) * q.x), o.y * ((y.y - m.y) * q.y), o.z * ((y.z - m.z) * q.z), o.w * ((y.w - m.w) * q.w));
+}
+
+// STATS: also leave the workgroup's column sums of the rows it stores (and of their products with xhat) in
+// a.st_partial[blockIdx.x][2][F] -- rows of one workgroup meet in LDS and are added in row order (deterministic); hub rows
+// contribute nothing here (their final value exists only in agg_hub_merge_kernel, which adds their share)
+template <int LPR, bool STATS = false>
 __global__ __launch_bounds__(256) void agg_rows_v4_kernel(AggArgs a) {
     const long gid = (blockIdx.x * 256L + threadIdx.x) / LPR;
     const int c4 = (threadIdx.x % LPR) * 4;
-    if (gid >= a.N || c4 >= a.F) return;
-    const int s = a.rowptr[gid], t = a.rowptr[gid + 1];
-    const bool hub = (t - s) > a.hub_threshold;
-    float4 acc = ld4(a.x + gid * a.ldx + c4);
-    const float sw = a.self_scale * (a.in_scale ? a.in_scale[gid] : 1.0f);
-    acc.x *= sw; acc.y *= sw; acc.z *= sw; acc.w *= sw;
-    if (!hub) {
-        int e = s;
-        for (; e + 4 <= t; e += 4) {
-            const int j0 = a.col[e], j1 = a.col[e + 1], j2 = a.col[e + 2], j3 = a.col[e + 3];
-            const float4 v0 = ld4(a.x + (long)j0 * a.ldx + c4);
-            const float4 v1 = ld4(a.x + (long)j1 * a.ldx + c4);
-            const float4 v2 = ld4(a.x + (long)j2 * a.ldx + c4);
-            const float4 v3 = ld4(a.x + (long)j3 * a.ldx + c4);
-            fma4(acc, edge_w(a, e, j0, gid), v0);
-            fma4(acc, edge_w(a, e + 1, j1, gid), v1);
-            fma4(acc, edge_w(a, e + 2, j2, gid), v2);
-            fma4(acc, edge_w(a, e + 3, j3, gid), v3);
+    const bool live = gid < a.N && c4 < a.F;
+    if (!STATS && !live) return;
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+    if (live) {
+        const int s = a.rowptr[gid], t = a.rowptr[gid + 1];
+        const bool hub = (t - s) > a.hub_threshold;
+        float4 acc = ld4(a.x + gid * a.ldx + c4);
+        const float sw = a.self_scale * (a.in_scale ? a.in_scale[gid] : 1.0f);
+        acc.x *= sw; acc.y *= sw; acc.z *= sw; acc.w *= sw;
+        if (!hub) {
+            int e = s;
+            for (; e + 4 <= t; e += 4) {
+                const int j0 = a.col[e], j1 = a.col[e + 1], j2 = a.col[e + 2], j3 = a.col[e + 3];
+                const float4 v0 = ld4(a.x + (long)j0 * a.ldx + c4);
+                const float4 v1 = ld4(a.x + (long)j1 * a.ldx + c4);
+                const float4 v2 = ld4(a.x + (long)j2 * a.ldx + c4);
+                const float4 v3 = ld4(a.x + (long)j3 * a.ldx + c4);
+                fma4(acc, edge_w(a, e, j0, gid), v0);
+                fma4(acc, edge_w(a, e + 1, j1, gid), v1);
+                fma4(acc, edge_w(a, e + 2, j2, gid), v2);
+                fma4(acc, edge_w(a, e + 3, j3, gid), v3);
+            }
+            for (; e < t; ++e) {
+                const int j = a.col[e];
+                fma4(acc, edge_w(a, e, j, gid), ld4(a.x + (long)j * a.ldx + c4));
+            }
         }
-        for (; e < t; ++e) {
-            const int j = a.col[e];
-            fma4(acc, edge_w(a, e, j, gid), ld4(a.x + (long)j * a.ldx + c4));
+        const float os = a.out_scale ? a.out_scale[gid] : 1.0f;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) b = ld4(a.bias + c4);
+        float4 o = make_float4(fmaf(os, acc.x, b.x), fmaf(os, acc.y, b.y), fmaf(os, acc.z, b.z), fmaf(os, acc.w, b.w));
+        if (a.col_scale) {                         // gathered rows = col_scale * x + col_shift (see AggArgs); unit edge weights only.
+            // Hub rows: `o` holds the self term, the shift is added here for ALL t - s edges, the merge kernel scales the segment sums
+            const float4 cs = ld4(a.col_scale + c4), ch = ld4(a.col_shift + c4);
+            const float cnt = (float)(t - s) + a.self_scale;
+            o.x = fmaf(cs.x, o.x, cnt * ch.x); o.y = fmaf(cs.y, o.y, cnt * ch.y);
+            o.z = fmaf(cs.z, o.z, cnt * ch.z); o.w = fmaf(cs.w, o.w, cnt * ch.w);
+        }
+        if (a.addend && !hub) {                    // (hub rows: agg_hub_merge_kernel adds it after the segments -- the order of the separate sum)
+            const float4 d = ld4(a.addend + gid * a.lda + c4);
+            o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+        }
+        *reinterpret_cast<float4*>(a.out + gid * a.ldo + c4) = o;
+        if (STATS && !hub) stats_products(a, gid, c4, o, pa, pb);
+    }
+    if constexpr (STATS) {
+        __shared__ float4 s_a[256], s_b[256];
+        s_a[threadIdx.x] = pa; s_b[threadIdx.x] = pb;
+        __syncthreads();
+        if (threadIdx.x < LPR && c4 < a.F) {
+            constexpr int R = 256 / LPR;
+#pragma unroll 4
+            for (int k = 1; k < R; ++k) {          // rows of the workgroup, in order
+                const float4 u = s_a[k * LPR + threadIdx.x], v = s_b[k * LPR + threadIdx.x];
+                pa.x += u.x; pa.y += u.y; pa.z += u.z; pa.w += u.w;
+                pb.x += v.x; pb.y += v.y; pb.z += v.z; pb.w += v.w;
+            }
+            *reinterpret_cast<float4*>(a.st_partial + (blockIdx.x * 2L + 0) * a.F + c4) = pa;
+            *reinterpret_cast<float4*>(a.st_partial + (blockIdx.x * 2L + 1) * a.F + c4) = pb;
         }
     }
-    const float os = a.out_scale ? a.out_scale[gid] : 1.0f;
-    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias) b = ld4(a.bias + c4);
-    float4 o = make_float4(fmaf(os, acc.x, b.x), fmaf(os, acc.y, b.y), fmaf(os, acc.z, b.z), fmaf(os, acc.w, b.w));
-    if (a.col_scale) {                         // gathered rows = col_scale * x + col_shift (see AggArgs); unit edge weights only.
-        // Hub rows: `o` holds the self term, the shift is added here for ALL t - s edges, the merge kernel scales the segment sums
-        const float4 cs = ld4(a.col_scale + c4), ch = ld4(a.col_shift + c4);
-        const float cnt = (float)(t - s) + a.self_scale;
-        o.x = fmaf(cs.x, o.x, cnt * ch.x); o.y = fmaf(cs.y, o.y, cnt * ch.y);
-        o.z = fmaf(cs.z, o.z, cnt * ch.z); o.w = fmaf(cs.w, o.w, cnt * ch.w);
-    }
-    if (a.addend && !hub) {                    // (hub rows: agg_hub_merge_kernel adds it after the segments -- the order of the separate sum)
-        const float4 d = ld4(a.addend + gid * a.lda + c4);
-        o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
-    }
-    *reinterpret_cast<float4*>(a.out + gid * a.ldo + c4) = o;
 }
 
 // Narrow rows (F <= 16): with LPR = F/4 lanes per row a wave would own 64/LPR rows and run as long as the
@@ -161,15 +192,24 @@ __global__ __launch_bounds__(256) void agg_hub_v4_kernel(AggArgs a, const int* _
 // consecutive segments (csr.hip lists them in edge order) round-robin, then the partial sums meet in LDS in a fixed
 // order and are added, scaled, onto what the row kernel wrote (self term + bias).  A fixed association order is all
 // bit-reproducibility needs; walking the ~80 segments of a 10^4-degree hub with ONE lane group took 28 us per launch.
-template <int LPR>
+// STATS (AggArgs::st_*): the hub row's share of the column statistics goes to partial row `st_row0 + segment index` (the
+// workgroups of a row's later segments leave zeros there)
+template <int LPR, bool STATS = false>
 __global__ __launch_bounds__(256) void agg_hub_merge_kernel(AggArgs a, const int* __restrict__ seg, long nseg,
-                                                            const float* __restrict__ part, int ldp) {
+                                                            const float* __restrict__ part, int ldp, long st_row0 = 0) {
     __shared__ float4 s_part[256];
     const long sidx = blockIdx.x;
     const int row = seg[3 * sidx];
-    if (sidx > 0 && seg[3 * (sidx - 1)] == row) return;          // workgroup-uniform
     constexpr int G = 256 / LPR;
     const int g = threadIdx.x / LPR, lg = threadIdx.x % LPR, c4 = lg * 4;
+    if (sidx > 0 && seg[3 * (sidx - 1)] == row) {                // workgroup-uniform
+        if (STATS && g == 0 && c4 < a.F) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(a.st_partial + ((st_row0 + sidx) * 2 + 0) * a.F + c4) = z;
+            *reinterpret_cast<float4*>(a.st_partial + ((st_row0 + sidx) * 2 + 1) * a.F + c4) = z;
+        }
+        return;
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < a.F) {
         for (long k = sidx + g; k < nseg && seg[3 * k] == row; k += G) {
@@ -198,6 +238,12 @@ __global__ __launch_bounds__(256) void agg_hub_merge_kernel(AggArgs a, const int
             v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
         }
         *o = v;
+        if constexpr (STATS) {
+            float4 pa, pb;
+            stats_products(a, row, c4, v, pa, pb);
+            *reinterpret_cast<float4*>(a.st_partial + ((st_row0 + sidx) * 2 + 0) * a.F + c4) = pa;
+            *reinterpret_cast<float4*>(a.st_partial + ((st_row0 + sidx) * 2 + 1) * a.F + c4) = pb;
+        }
     }
 }
 
@@ -337,8 +383,20 @@ int aggregate_hub_rows(const AggArgs& a, const int* hub_seg, long num_hub_seg, f
     return KAGNN_OK;
 }
 
+// column statistics of the result (AggArgs::st_*): which shapes the row kernels cover, and how many partial row pairs
+// [2][F] they leave in st_partial (row workgroups first, then one slot per hub segment)
+static int stats_lpr(int F) { return F <= 32 ? 8 : F <= 64 ? 16 : F <= 128 ? 32 : 64; }
+bool aggregate_stats_ok(const AggArgs& a) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return vec4_ok(a) && a.F > 16 && a.st_y && a.st_mean && a.st_rstd && a.st_partial && a.st_ldy % 4 == 0 && al(a.st_y) &&
+           al(a.st_mean) && al(a.st_rstd) && al(a.st_partial);
+}
+long aggregate_stats_rows(long N, int F, long num_hub_seg) { return (long)cdiv(N * stats_lpr(F), 256) + (num_hub_seg > 0 ? num_hub_seg : 0); }
+
 int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, float* ws, size_t ws_bytes, hipStream_t st) {
     if (a.N == 0) return KAGNN_OK;
+    const bool stats = a.st_partial != nullptr;
+    if (stats && !aggregate_stats_ok(a)) return fail(KAGNN_ERR_UNSUPPORTED, "%s: column statistics need 16-byte aligned fp32 rows of 17..256 columns", "aggregate_sum");
     if (!vec4_ok(a)) {
         AggArgs b = a;
         b.hub_threshold = 0x7fffffff;
@@ -352,24 +410,30 @@ int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, float*
     const int ldp = (a.F + 3) & ~3;
     if (b.hub_threshold != 0x7fffffff && (ws == nullptr || ws_bytes < aggregate_ws_bytes(num_hub_seg, a.F)))
         return fail(KAGNN_ERR_ARG, "%s: workspace too small for the hub segments (see kagnn_aggregate_workspace_bytes)", "aggregate_sum");
-#define HUBS(LPR)                                                                                   \
+#define HUBS(LPR, ST)                                                                               \
     if (b.hub_threshold != 0x7fffffff) {                                                            \
         agg_hub_v4_kernel<LPR><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg, ws, ldp);         \
         KAGNN_LAUNCH_CHECK();                                                                       \
-        agg_hub_merge_kernel<LPR><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg, num_hub_seg, ws, ldp); \
+        agg_hub_merge_kernel<LPR, ST><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg, num_hub_seg, ws, ldp, (long)cdiv(a.N * LPR, 256)); \
         KAGNN_LAUNCH_CHECK();                                                                       \
     }
 #define ROWS(LPR)                                                                     \
     {                                                                                 \
-        agg_rows_v4_kernel<LPR><<<cdiv(a.N * LPR, 256), 256, 0, st>>>(b);             \
-        KAGNN_LAUNCH_CHECK();                                                         \
-        HUBS(LPR)                                                                     \
+        if (stats) {                                                                  \
+            agg_rows_v4_kernel<LPR, true><<<cdiv(a.N * LPR, 256), 256, 0, st>>>(b);   \
+            KAGNN_LAUNCH_CHECK();                                                     \
+            HUBS(LPR, true)                                                           \
+        } else {                                                                      \
+            agg_rows_v4_kernel<LPR><<<cdiv(a.N * LPR, 256), 256, 0, st>>>(b);         \
+            KAGNN_LAUNCH_CHECK();                                                     \
+            HUBS(LPR, false)                                                          \
+        }                                                                             \
     }
 #define ROWS_EP(LPR)                                                                  \
     {                                                                                 \
         agg_rows_ep_kernel<LPR><<<cdiv(a.N * 16, 256), 256, 0, st>>>(b);              \
         KAGNN_LAUNCH_CHECK();                                                         \
-        HUBS(LPR)                                                                     \
+        HUBS(LPR, false)                                                              \
     }
     // measured at N=1M / E=10M: edge-parallel wins for F <= 16 (0.19 vs 0.23 ms at F=8), loses slightly at F=32
     if (a.F <= 4) ROWS_EP(1) else if (a.F <= 8) ROWS_EP(2) else if (a.F <= 16) ROWS_EP(4) else if (a.F <= 32) ROWS(8)

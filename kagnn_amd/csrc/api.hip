@@ -19,6 +19,11 @@ int kan_sparse_fwd_agg(const float* x, long ldx, long N, const int* rowptr, cons
                        int hub_threshold, float self_scale, const float* knots, int in, int out, int G, int K, const void* pack,
                        float* h0, long ldh, float* y, long ldy, void* ws, size_t ws_bytes, hipStream_t st);
 int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, float* ws, size_t ws_bytes, hipStream_t st);
+bool aggregate_stats_ok(const AggArgs& a);
+long aggregate_stats_rows(long N, int F, long num_hub_seg);
+size_t bn_stats_fold_bytes(long B, int F);
+int bn_sums_from_partials(float* ws, long B, int F, float* sums, hipStream_t st);
+int bn_bwd_stats_given(const float*, long, int, const float*, const float*, const float*, float*, float*, float*, int, hipStream_t);
 int gcn_deg_inv_sqrt(const int* rowptr, const int* col, long N, float* dis, hipStream_t st);
 int gine_fwd(const float*, long, const float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
 int gine_bwd(const float*, long, const float*, long, const float*, long, float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
@@ -154,7 +159,7 @@ static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode 
 #pragma GCC visibility push(default)
 extern "C" {
 
-int kagnn_version(void) { return 230; }
+int kagnn_version(void) { return 240; }
 const char* kagnn_last_error(void) { return g_err; }
 
 int kagnn_stage_timer_enable(const char* only) {
@@ -918,6 +923,10 @@ int kagnn_gin_kan_layer_fwd_affine(const float* x, int64_t ldx, int64_t N, const
 // the BatchNorm1d (training mode) that follows the layer, for kagnn_gin_kan_layer_bwd_bn
 struct BnStage { const float* y; int64_t ldy; const float* weight; const float* mean; const float* rstd; float* g_weight; float* g_bias; };
 static size_t bn_stage_bytes(int64_t N, int out) { return al256z(bn_ws_bytes(N, out)) + al256z(4 * (size_t)((out + 63) & ~63) * sizeof(float)); }
+// the statistics of the PREVIOUS norm's backward, produced by this layer's transposed aggregation (kagnn_gin_kan_layer_bwd_bn_sums):
+// prev_y = that norm's input (this convolution's forward input before the folded affine), its saved mean / rstd, sums = out [2][in]
+struct StatsOut { const float* y; int64_t ldy; const float* mean; const float* rstd; float* sums; };
+static size_t stats_out_bytes(int64_t N, int f0, int64_t num_hub_seg_t) { return al256z(bn_stats_fold_bytes(aggregate_stats_rows(N, f0, num_hub_seg_t), f0)); }
 
 static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_t* rowptr_t, const int32_t* col_t,
                           const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
@@ -926,7 +935,8 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
                           const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
                           const float* gx_addend, int64_t ld_addend, const BnStage* bn,
                           float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
-                          size_t workspace_bytes, void* stream, const char* fn) {
+                          size_t workspace_bytes, void* stream, const char* fn,
+                          const float* bn_sums_in = nullptr, const StatsOut* so = nullptr) {
     KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && sw && acts && pack_dx && g_sw, "bad argument");
     KAGNN_CHECK_ARG(!gx_addend || (gx && gx_dtype == KAGNN_DTYPE_F32 && !bf16_gather && ld_addend >= widths[0]),
                     "gx_addend needs an fp32 gx and fp32 gather operands");
@@ -934,7 +944,11 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
     int rc = kagnn_gin_kan_layer_workspace_bytes(N, L, widths, G, K, mode, 0, num_hub_seg_t, &need_f, &need_b);
     if (rc) return rc;
     const size_t bn_b = bn ? bn_stage_bytes(N, widths[L]) : 0;
-    if (!(workspace && workspace_bytes >= need_b + bn_b))
+    const size_t so_b = so ? stats_out_bytes(N, widths[0], num_hub_seg_t) : 0;
+    KAGNN_CHECK_ARG(!so || (so->y && so->mean && so->rstd && so->sums && so->ldy >= widths[0] && gx && gx_dtype == KAGNN_DTYPE_F32 && !bf16_gather),
+                    "the previous norm's statistics need its input, mean, rstd and an fp32 gx");
+    KAGNN_CHECK_ARG(!bn_sums_in || bn, "bn_sums belongs to the BatchNorm stage");
+    if (!(workspace && workspace_bytes >= need_b + bn_b + so_b))
         return fail(KAGNN_ERR_ARG, bn ? "%s: workspace too small (kagnn_gin_kan_layer_workspace_bytes + kagnn_gin_kan_layer_bwd_bn_workspace_bytes)"
                                       : "%s: workspace too small (kagnn_gin_kan_layer_workspace_bytes)", fn);
     if (N == 0) return KAGNN_OK;
@@ -968,7 +982,11 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
         const int in = widths[L - 1];
         bn_in_dx = mode == KAGNN_PREC_SPLIT && use_split_dx(in, out, G, K, mode) && out <= wmax && !(L == 1 && (gx == nullptr || bf16_gather)) &&
                    fits32(N, ldg) && kan_split_dx_bn_ok(ldg, in, out, G, K, bnb, g);
-        if (bn_in_dx) {
+        if (bn_in_dx && bn_sums_in) {        // the column sums came with the gradient (the aggregation that produced g left them)
+            KAGNN_STAGE_AS("kagnn_batchnorm_bwd statistics given (in ..._layer_bwd_bn)", stream);
+            rc = bn_bwd_stats_given(bn_sums_in, N, out, bn->weight, bn->mean, bn->rstd, bn->g_weight, bn->g_bias, tab, ldt, as_stream(stream));
+            if (rc) return rc;
+        } else if (bn_in_dx) {
             KAGNN_STAGE_AS("kagnn_batchnorm_bwd statistics (in ..._layer_bwd_bn)", stream);
             rc = bn_bwd_stats(bn->y, bn->ldy, g, ldg, N, out, bn->weight, bn->mean, bn->rstd, bn->g_weight, bn->g_bias, tab, ldt, bws,
                               bn_ws_bytes(N, out), as_stream(stream));
@@ -1027,6 +1045,22 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
         return kagnn_aggregate_sum_bf16(src, f0, gx, ldgx, gx_dtype, rowptr_t, col_t, nullptr, N, f0, self_scale, nullptr, nullptr,
                                         nullptr, 0, hub_seg_t, num_hub_seg_t, hub_threshold, ws, hub_b, stream);
     }
+    if (so) {       // the transposed aggregation also leaves the column statistics of gx for the previous norm's backward
+        AggArgs a{g, ldg, static_cast<float*>(gx), ldgx, rowptr_t, col_t, nullptr, N, f0, self_scale, nullptr, nullptr, nullptr,
+                  0, hub_threshold > 0 ? hub_threshold : 0x7fffffff, gx_addend, ld_addend};
+        float* partial = reinterpret_cast<float*>(ws + need_b + bn_b);
+        a.st_y = so->y; a.st_ldy = so->ldy; a.st_mean = so->mean; a.st_rstd = so->rstd; a.st_partial = partial;
+        KAGNN_CHECK_ARG(ldg >= f0 && ldgx >= f0 && (!gx_addend || ld_addend >= f0), "leading dimension smaller than num_feat");
+        if (!aggregate_stats_ok(a)) return fail(KAGNN_ERR_UNSUPPORTED, "%s: the previous norm's statistics need 17..256 input features in 16-byte aligned fp32 rows", fn);
+        {
+            KAGNN_STAGE_AS("kagnn_aggregate_sum", stream);
+            rc = aggregate_sum(a, hub_seg_t, num_hub_seg_t, reinterpret_cast<float*>(ws), hub_b, as_stream(stream));
+            if (rc) return rc;
+        }
+        KAGNN_STAGE_AS("kagnn_batchnorm_bwd statistics fold", stream);
+        const bool hubs = num_hub_seg_t > 0 && hub_seg_t != nullptr && hub_threshold > 0;
+        return bn_sums_from_partials(partial, aggregate_stats_rows(N, f0, hubs ? num_hub_seg_t : 0), f0, so->sums, as_stream(stream));
+    }
     return kagnn_aggregate_sum_add(g, ldg, static_cast<float*>(gx), ldgx, rowptr_t, col_t, nullptr, N, f0, self_scale, nullptr,
                                    nullptr, nullptr, 0, hub_seg_t, num_hub_seg_t, hub_threshold, gx_addend, ld_addend, ws, hub_b, stream);
 }
@@ -1073,6 +1107,42 @@ int kagnn_gin_kan_layer_bwd_bn(const float* g, int64_t ldg, const float* y, int6
     return layer_bwd_impl(g, ldg, N, rowptr_t, col_t, hub_seg_t, num_hub_seg_t, hub_threshold, self_scale, L, widths, sw, sc, knots, G, K,
                           mode, acts, pack_dx, gx, gx_dtype, ldgx, bf16_gather, gx_addend, ld_addend, &bn, g_bw, g_sw, g_sc, workspace,
                           workspace_bytes, stream, __func__);
+}
+
+// kagnn_gin_kan_layer_bwd_bn with the norms' backward STATISTICS travelling with the gradients (round 4): in the node models the
+// gradient g arriving at layer l's norm is produced by layer l+1's transposed aggregation (+ the skip gradient it adds), so
+//   * prev_y / prev_mean / prev_rstd / prev_sums (all or none): this call's transposed aggregation ALSO leaves
+//     prev_sums[0][in] = sum_n gx, prev_sums[1][in] = sum_n gx * xhat_prev  (xhat_prev = (prev_y - prev_mean) * prev_rstd; prev_y is
+//     the previous norm's input = this convolution's input before the folded affine) -- from partial sums in the row kernel's
+//     epilogue, folded in a fixed order;
+//   * bn_sums (or NULL): [2][out] sums for THIS norm made that way by the next layer's call -- the statistics pass over g and y is
+//     skipped (only when the norm's element-wise backward runs inside the input-gradient kernel; otherwise ignored).
+// Extra workspace behind kagnn_gin_kan_layer_bwd_bn's: kagnn_gin_kan_layer_bwd_bn_sums_workspace_bytes (0 without prev_sums).
+int kagnn_gin_kan_layer_bwd_bn_sums_workspace_bytes(int64_t N, int32_t in_features, int64_t num_hub_seg_t, size_t* bytes) {
+    KAGNN_CHECK_ARG(N >= 0 && in_features >= 1 && num_hub_seg_t >= 0 && bytes, "bad argument");
+    *bytes = stats_out_bytes(N, in_features, num_hub_seg_t);
+    return KAGNN_OK;
+}
+
+int kagnn_gin_kan_layer_bwd_bn_sums(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* bn_weight,
+                                    const float* bn_mean, const float* bn_rstd, float* g_bn_weight, float* g_bn_bias,
+                                    const float* bn_sums,
+                                    const float* prev_y, int64_t ld_prev_y, const float* prev_mean, const float* prev_rstd,
+                                    float* prev_sums,
+                                    int64_t N, const int32_t* rowptr_t, const int32_t* col_t,
+                                    const int32_t* hub_seg_t, int64_t num_hub_seg_t, int32_t hub_threshold, float self_scale,
+                                    int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
+                                    const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
+                                    const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
+                                    const float* gx_addend, int64_t ld_addend,
+                                    float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    const BnStage bn{y, ldy, bn_weight, bn_mean, bn_rstd, g_bn_weight, g_bn_bias};
+    const StatsOut so{prev_y, ld_prev_y, prev_mean, prev_rstd, prev_sums};
+    KAGNN_CHECK_ARG((prev_sums == nullptr) == (prev_y == nullptr), "prev_y and prev_sums come together");
+    return layer_bwd_impl(g, ldg, N, rowptr_t, col_t, hub_seg_t, num_hub_seg_t, hub_threshold, self_scale, L, widths, sw, sc, knots, G, K,
+                          mode, acts, pack_dx, gx, gx_dtype, ldgx, bf16_gather, gx_addend, ld_addend, &bn, g_bw, g_sw, g_sc, workspace,
+                          workspace_bytes, stream, __func__, bn_sums, prev_sums ? &so : nullptr);
 }
 
 int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t N, const int32_t* rowptr_t, const int32_t* col_t,

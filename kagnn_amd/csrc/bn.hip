@@ -414,6 +414,59 @@ int bn_bwd_stats(const float* x, long ldx, const float* gy, long ldgy, long N, i
     return KAGNN_OK;
 }
 
+// ---- the norm's backward statistics arriving from ELSEWHERE (round 4): the aggregation that produced the incoming gradient g
+// left partial row pairs [B][2][F] of sum g and sum g * xhat (aggregate.hip, AggArgs::st_*).  Two launches fold them in a fixed
+// order: kStatsFold workgroups each add a contiguous range of the B rows (32 MB at 1M rows: one row pair per 16 rows), then
+// bn_finish_kernel<1> adds those kStatsFold rows.
+constexpr int kStatsFold = 256;
+__global__ __launch_bounds__(256) void stats_fold_kernel(const float* __restrict__ partial, long B, int F2 /* 2 * F */,
+                                                         float* __restrict__ stage) {
+    __shared__ float s_red[256];
+    const long per = (B + gridDim.x - 1) / gridDim.x, b0 = blockIdx.x * per, b1 = min(B, b0 + per);
+    for (int c0 = 0; c0 < F2; c0 += 64) {                 // 64 columns x 4 row slots per pass (uniform trip count: barriers inside)
+        const int c = c0 + (threadIdx.x & 63), slot = threadIdx.x >> 6;
+        float acc = 0.0f;
+        if (c < F2)
+            for (long b = b0 + slot; b < b1; b += 4) acc += partial[b * F2 + c];
+        s_red[threadIdx.x] = acc;
+        __syncthreads();
+        if (slot == 0 && c < F2) stage[(long)blockIdx.x * F2 + c] = (s_red[threadIdx.x] + s_red[threadIdx.x + 64]) + (s_red[threadIdx.x + 128] + s_red[threadIdx.x + 192]);
+        __syncthreads();
+    }
+}
+
+size_t bn_stats_fold_bytes(long B, int F) { return ((size_t)B + kStatsFold) * 2 * F * sizeof(float); }    // partial rows | fold stage
+
+// partial [B][2][F] (at ws) -> sums[0][F] = sum g, sums[1][F] = sum g * xhat
+int bn_sums_from_partials(float* ws, long B, int F, float* sums, hipStream_t st) {
+    float* stage = ws + (size_t)B * 2 * F;
+    const int nb = (int)min((long)kStatsFold, max(1L, B));
+    stats_fold_kernel<<<nb, 256, 0, st>>>(ws, B, 2 * F, stage);
+    KAGNN_LAUNCH_CHECK();
+    bn_finish_kernel<1><<<cdiv(F, 32), 1024, 0, st>>>(stage, nb, F, 0, nullptr, 0.f, 0.f, sums, sums + F, nullptr, nullptr);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+__global__ void bn_sums_out_kernel(const float* __restrict__ sums, int F, float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    if (g_beta) g_beta[f] = sums[f];
+    if (g_gamma) g_gamma[f] = sums[F + f];
+}
+
+// bn_bwd_stats with the two column sums given (sums[0] = sum g, sums[1] = sum g * xhat) instead of a pass over g and x
+int bn_bwd_stats_given(const float* sums, long N, int F, const float* gamma, const float* save_mean, const float* save_rstd,
+                       float* g_gamma, float* g_beta, float* tab, int ldt, hipStream_t st) {
+    if (g_gamma || g_beta) {
+        bn_sums_out_kernel<<<cdiv(F, 256), 256, 0, st>>>(sums, F, g_gamma, g_beta);
+        KAGNN_LAUNCH_CHECK();
+    }
+    bn_bwd_table_kernel<<<cdiv(ldt, 256), 256, 0, st>>>(save_mean, save_rstd, gamma, sums, sums + F, N, F, tab, ldt);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 int bn_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, int F, const float* gamma,
            const float* save_mean, const float* save_rstd, int training, float dropout_p,
            unsigned long long dropout_seed, float* gx, long ldgx, float* g_gamma,

@@ -214,6 +214,14 @@ struct AggArgs {
     // (reference node_classification_clean/models.py:198-200: x = bns[i](convs[i](x)) feeding the next GINConv):
     //   out_i = a * (self * x_i + sum_j w_ij x_j) + (self + sum_j w_ij) * b        (GIN form: unit weights => count = deg_i + self)
     const float* col_scale = nullptr; const float* col_shift = nullptr;
+    // optional COLUMN STATISTICS of the result (round 4): when the result is the gradient g arriving at a training-mode
+    // BatchNorm1d (the transposed aggregation of the NEXT convolution's backward produces it, reference models.py:198-200), the
+    // norm's backward needs sum_n g and sum_n g * xhat, xhat = (st_y - st_mean) * st_rstd, st_y = the norm's input.  The row
+    // kernel forms both products on the row it is about to store and leaves one partial row pair per workgroup (hub rows: per
+    // hub segment slot, from the merge kernel) in st_partial[.][2][F]; bn.hip folds them in a fixed order.  Saves the norm's
+    // own statistics pass over g and y.
+    const float* st_y = nullptr; long st_ldy = 0; const float* st_mean = nullptr; const float* st_rstd = nullptr;
+    float* st_partial = nullptr;
 };
 
 // BatchNorm1d backward, training mode, as ONE expression per element of the incoming gradient g (y = the norm's input):

@@ -107,9 +107,9 @@ class _SumAggregateConv(nn.Module):
         norm's element-wise backward runs inside the chain's last input-gradient kernel), or ``None`` when the chain is
         outside what the node covers -- nothing has been touched then.  Module hooks of the two modules do NOT run on this
         path (their intermediate tensor is never exposed): ``conv_bn_dropout`` only takes it when neither has any."""
-        in_affine = None
+        in_affine = in_stats = None
         if isinstance(x, ops.AffineRows):                 # the previous layer's norm, to be folded into this aggregation
-            x, in_affine = x.y, x.affine
+            x, in_affine, in_stats = x.y, x.affine, x.stats
         if not (_FUSED_LAYER and isinstance(self.nn, eKAN) and x.is_cuda and x.size(0) > 1):
             return None
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
@@ -119,7 +119,7 @@ class _SumAggregateConv(nn.Module):
             return (bn.weight, bn.bias, bn.running_mean if use_running else None, bn.running_var if use_running else None, factor, bn.eps)
 
         return ops.gin_kan_layer(x, g, 1.0 + self._eps(), self.nn, skip_gradient=skip_gradient, batch_norm=stage,
-                                 in_affine=in_affine, lazy_norm=lazy)
+                                 in_affine=in_affine, lazy_norm=lazy, in_stats=in_stats)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))

@@ -750,10 +750,10 @@ class AffineRows:
     fp32 tensor outside it.  CONVENTION: whoever consumes this object treats ``y``'s gradient slot as the gradient with respect
     to the NORMALISED rows -- the producing node (``_GinKanBnLayerFn`` in lazy mode) runs the norm's backward from there.  Only
     ``kagnn_amd.models._NodeModel.forward`` builds these, and only between nodes that follow the convention."""
-    __slots__ = ("y", "affine")
+    __slots__ = ("y", "affine", "stats")
 
-    def __init__(self, y: torch.Tensor, affine: torch.Tensor):
-        self.y, self.affine = y, affine
+    def __init__(self, y: torch.Tensor, affine: torch.Tensor, stats: Optional["NormSums"] = None):
+        self.y, self.affine, self.stats = y, affine, stats     # stats: the producing norm's NormSums (or None)
 
     def size(self, d):
         return self.y.size(d)
@@ -762,6 +762,38 @@ class AffineRows:
         """the normalised rows as an ordinary tensor (for consumers that cannot fold the affine); the gradient passes through
         unchanged, as the convention above requires"""
         return _MaterialiseAffineFn.apply(self.y, self.affine)
+
+
+class NormSums:
+    """Side channel between two fused convolution + norm nodes (``_GinKanBnLayerFn``), outside the tape like ``SkipGradient``:
+    the backward of layer l's norm starts from two column sums of its incoming gradient g -- ``sum g`` and ``sum g * xhat`` -- which
+    used to take a pass over g and the norm's input.  In the node models g is exactly what layer l+1's transposed aggregation
+    writes (reference ``node_classification_clean/models.py:198-200``), so that kernel forms the sums in its epilogue
+    (``kagnn_gin_kan_layer_bwd_bn_sums``).  The PRODUCING node (layer l) creates this object in its forward and fills ``mean`` /
+    ``rstd``; the CONSUMING node (layer l+1) gets it with the ``AffineRows``, parks ``sums`` for the gradient tensor it returns;
+    layer l's backward takes them only if the gradient it receives IS that tensor (same storage, same engine run) -- any other
+    consumer of the activation makes autograd sum into a new tensor and the statistics pass runs as before."""
+    __slots__ = ("mean", "rstd", "sums", "grad", "task")
+
+    def __init__(self):
+        self.mean = self.rstd = self.sums = self.grad = None
+        self.task = -1
+
+    def park(self, sums: torch.Tensor, grad: torch.Tensor) -> None:
+        self.sums, self.grad, self.task = sums, grad, graph_task_id()      # (holding ``grad`` keeps its storage from being reused)
+
+    def take(self, grad: torch.Tensor):
+        sums, parked, t = self.sums, self.grad, self.task
+        self.sums = self.grad = None
+        self.task = -1
+        if sums is None or t != graph_task_id() or parked is None:
+            return None
+        same = (parked.data_ptr() == grad.data_ptr() and parked.shape == grad.shape and parked.stride() == grad.stride()
+                and parked.dtype == grad.dtype and parked.device == grad.device)
+        return sums if same else None
+
+
+_FOLD_NORM_STATS = os.environ.get("KAGNN_FOLD_NORM_STATS", "1") != "0"
 
 
 class _MaterialiseAffineFn(Function):
@@ -905,10 +937,11 @@ class _GinKanBnLayerFn(Function):
 
     @staticmethod
     @_on_operand_device
-    def forward(ctx, x, g, self_scale, knots, grid_size, spline_order, mode, act_bf16, skip_gradient, in_affine, lazy, bn_weight, bn_bias,
-                running_mean, running_var, momentum, eps, *params):
+    def forward(ctx, x, g, self_scale, knots, grid_size, spline_order, mode, act_bf16, skip_gradient, in_affine, lazy, in_stats, out_stats,
+                bn_weight, bn_bias, running_mean, running_var, momentum, eps, *params):
         """``in_affine``: the input is an ``AffineRows`` (``x`` = its y): the aggregation folds the previous layer's norm.
-        ``lazy``: do not write the normalised rows -- return ``(y, affine)`` for an ``AffineRows`` (see its convention)."""
+        ``lazy``: do not write the normalised rows -- return ``(y, affine)`` for an ``AffineRows`` (see its convention).
+        ``in_stats`` / ``out_stats``: the ``NormSums`` of the input ``AffineRows`` / a fresh one for the output (lazy mode)."""
         _need_cuda(x, bn_weight, bn_bias, running_mean, running_var, in_affine, *params)
         nl = len(params) // 3
         layers = [(params[3 * i].contiguous(), params[3 * i + 1].contiguous(), params[3 * i + 2].contiguous()) for i in range(nl)]
@@ -942,7 +975,19 @@ class _GinKanBnLayerFn(Function):
         saved = []
         for i in range(nl):
             saved += [acts[i], layers[i][1], layers[i][2], pds[i]]
-        ctx.save_for_backward(*saved, knots[0], y, mean, rstd, bn_weight)
+        # the norms' backward statistics travel with the gradients (NormSums): this node's own, and the previous norm's that
+        # this node's transposed aggregation can produce -- fp32 rows of 17..256 columns (a multiple of 4), gradient wanted
+        ctx.out_stats = ctx.in_stats = None
+        if _FOLD_NORM_STATS and lazy and out_stats is not None:
+            out_stats.mean, out_stats.rstd = mean, rstd
+            ctx.out_stats = out_stats
+        extra = []
+        if (_FOLD_NORM_STATS and in_affine is not None and in_stats is not None and in_stats.mean is not None and x.requires_grad
+                and x.dtype == torch.float32 and xg is x and not act_bf16 and 16 < widths[0] <= 256 and widths[0] % 4 == 0
+                and x.data_ptr() % 16 == 0 and _ld(x) % 4 == 0):
+            ctx.in_stats = in_stats
+            extra = [x]                                   # x = the previous norm's input
+        ctx.save_for_backward(*saved, knots[0], y, mean, rstd, bn_weight, *extra)
         ctx.has_bias = bn_bias is not None
         if lazy:
             ctx.mark_non_differentiable(affine)
@@ -956,6 +1001,7 @@ class _GinKanBnLayerFn(Function):
         g, self_scale, G, K, mode, act_bf16, nl, x_dtype, widths = ctx.meta
         t = ctx.saved_tensors
         knots, y, mean, rstd, bn_w = t[4 * nl:4 * nl + 5]
+        gh_in = gh
         gh = _rows(gh)
         need_x = ctx.needs_input_grad[0]
         gx_dtype = torch.bfloat16 if x_dtype == torch.bfloat16 else torch.float32
@@ -983,19 +1029,40 @@ class _GinKanBnLayerFn(Function):
         warr = (ctypes.c_int32 * (nl + 1))(*widths)
         _, wb = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), G, K, mode, g.num_hub_seg,
                        g.num_hub_seg_t, outputs=2)
-        ws = _ws(wb + _sizes("kagnn_gin_kan_layer_bwd_bn_workspace_bytes", n, widths[nl]), dev)
-        _call("kagnn_gin_kan_layer_bwd_bn", _ptr(gh), _ld(gh), _ptr(y), _ld(y), _ptr(bn_w), _ptr(mean), _ptr(rstd), _ptr(gbn_w), _ptr(gbn_b),
-              n, _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(g.hub_seg_t) if g.num_hub_seg_t else None, g.num_hub_seg_t, g.hub_threshold,
-              float(self_scale), nl, warr, _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, _ptr_array(acts), _ptr_array(pds),
-              _ptr(gx), _lib.DTYPE_BF16 if (gx is not None and gx.dtype == torch.bfloat16) else _lib.DTYPE_F32, widths[0],
-              int(bool(act_bf16) and widths[0] % 8 == 0 and widths[0] <= 512), _ptr(addend), _ld(addend) if addend is not None else 0,
-              _ptr_array(gbw), _ptr_array(gsw), _ptr_array(gsc), _ptr(ws), ws.numel(), _stream())
+        # statistics that came with the gradient (the next layer's aggregation made them for exactly this tensor), and the ones
+        # this call makes for the previous norm
+        my_sums = ctx.out_stats.take(gh_in) if ctx.out_stats is not None else None
+        prev = ctx.in_stats if (ctx.in_stats is not None and gx is not None and gx.dtype == torch.float32) else None
+        tail = (n, _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(g.hub_seg_t) if g.num_hub_seg_t else None, g.num_hub_seg_t, g.hub_threshold,
+                float(self_scale), nl, warr, _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, _ptr_array(acts), _ptr_array(pds),
+                _ptr(gx), _lib.DTYPE_BF16 if (gx is not None and gx.dtype == torch.bfloat16) else _lib.DTYPE_F32, widths[0],
+                int(bool(act_bf16) and widths[0] % 8 == 0 and widths[0] <= 512), _ptr(addend), _ld(addend) if addend is not None else 0,
+                _ptr_array(gbw), _ptr_array(gsw), _ptr_array(gsc))
+        wbn = _sizes("kagnn_gin_kan_layer_bwd_bn_workspace_bytes", n, widths[nl])
+        if my_sums is None and prev is None:
+            ws = _ws(wb + wbn, dev)
+            _call("kagnn_gin_kan_layer_bwd_bn", _ptr(gh), _ld(gh), _ptr(y), _ld(y), _ptr(bn_w), _ptr(mean), _ptr(rstd), _ptr(gbn_w),
+                  _ptr(gbn_b), *tail, _ptr(ws), ws.numel(), _stream())
+        else:
+            prev_sums = prev_y = None
+            wst = 0
+            if prev is not None:
+                prev_y = t[4 * nl + 5]
+                prev_sums = torch.empty((2, widths[0]), **f32)
+                wst = _sizes("kagnn_gin_kan_layer_bwd_bn_sums_workspace_bytes", n, widths[0], g.num_hub_seg_t)
+            ws = _ws(wb + wbn + wst, dev)
+            _call("kagnn_gin_kan_layer_bwd_bn_sums", _ptr(gh), _ld(gh), _ptr(y), _ld(y), _ptr(bn_w), _ptr(mean), _ptr(rstd), _ptr(gbn_w),
+                  _ptr(gbn_b), _ptr(my_sums), _ptr(prev_y), _ld(prev_y) if prev_y is not None else 0,
+                  _ptr(prev.mean) if prev is not None else None, _ptr(prev.rstd) if prev is not None else None, _ptr(prev_sums),
+                  *tail, _ptr(ws), ws.numel(), _stream())
+            if prev is not None:
+                prev.park(prev_sums, gx)
         if gx is not None and gx.dtype != gx_dtype:
             gx = gx.to(gx_dtype)
         grads = []
         for i in range(nl):
             grads += [gbw[i], gsw[i], gsc[i]]
-        return (gx, None, None, None, None, None, None, None, None, None, None, gbn_w, gbn_b, None, None, None, None, *grads)
+        return (gx, None, None, None, None, None, None, None, None, None, None, None, None, gbn_w, gbn_b, None, None, None, None, *grads)
 
 
 _GRAPH_TASK_ID = getattr(torch._C, "_current_graph_task_id", None)
@@ -1052,7 +1119,7 @@ def _same_knots(layers, knots) -> bool:
 
 def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optional[torch.dtype] = None,
                   moments: bool = False, skip_gradient: Optional["SkipGradient"] = None, batch_norm=None,
-                  in_affine: Optional[torch.Tensor] = None, lazy_norm: bool = False):
+                  in_affine: Optional[torch.Tensor] = None, lazy_norm: bool = False, in_stats: Optional["NormSums"] = None):
     """``chain(aggregate_sum(x, g, self_scale))`` for a ``kagnn_amd.KAN`` chain as ONE autograd node, or ``None`` when the
     chain is outside what the fused node covers (adaptive grids, > 16 coefficients, mixed precisions): the caller then
     composes the ops.  ``moments=True`` -> ``(y, moments)`` with the [2, out] column moments (mean, M2) of y from the
@@ -1084,10 +1151,11 @@ def gin_kan_layer(x, g: GraphIndex, self_scale: float, chain, act_dtype: Optiona
         if not _LAYER_ABI or x.size(0) < 2 or layers[-1].out_features > max(l.in_features for l in layers):
             return None
         bw_, bb_, rm_, rv_, mom_, eps_ = batch_norm() if callable(batch_norm) else batch_norm      # (callable: evaluated only now that the node is certain -- the caller's per-call bookkeeping)
+        out_stats = NormSums() if lazy_norm else None
         out = _GinKanBnLayerFn.apply(x, g, float(self_scale), knots, first.grid_size, first.spline_order, int(mode),
                                      act == torch.bfloat16 or x.dtype == torch.bfloat16, skip_gradient, in_affine, bool(lazy_norm),
-                                     bw_, bb_, rm_, rv_, float(mom_), float(eps_), *params)
-        return AffineRows(out[0], out[1]) if lazy_norm else out
+                                     in_stats, out_stats, bw_, bb_, rm_, rv_, float(mom_), float(eps_), *params)
+        return AffineRows(out[0], out[1], out_stats) if lazy_norm else out
     return _GinKanLayerFn.apply(x, g, float(self_scale), knots, first.grid_size, first.spline_order, int(mode),
                                 act == torch.bfloat16 or x.dtype == torch.bfloat16, bool(moments), skip_gradient, *params)
 

@@ -421,3 +421,87 @@ def test_folded_norms_over_random_model_configurations(monkeypatch):
             scale = float(b.abs().max())
             assert float((a - b).abs().max()) <= max(1e-4 * scale, floor), (label, k, float((a - b).abs().max()), scale)
     assert folded >= 5                                  # (the covered configurations really took the folded path)
+
+
+# ------------------------------------------------------------------ the norm's backward statistics travelling with the gradient
+def _node_model_grads(model, x, g, gout, state):
+    model.load_state_dict(state)
+    model.zero_grad()
+    xr = x.clone().requires_grad_(True)
+    timer = ops.EntryPointTimer()
+    ops.set_timer(timer)
+    try:
+        with ops.LibraryStageTimer(None):
+            out = model(xr, g)
+            out.backward(gout)
+            torch.cuda.synchronize()
+        stages = ops.LibraryStageTimer.collect()
+    finally:
+        ops.set_timer(None)
+    names = [r[0] for r in timer.records]
+    tensors = [out.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    return tensors, names, stages
+
+
+def test_norm_backward_statistics_come_with_the_gradient_from_the_next_layers_aggregation(monkeypatch):
+    """GKAN_Nodes (3 x KAN-GIN hidden 64, skip read-out) with the norms folded: the gradient arriving at layer l's norm is
+    written by layer l+1's transposed aggregation (+ the skip gradient), whose epilogue now also leaves sum g and sum g * xhat
+    (kagnn_gin_kan_layer_bwd_bn_sums; hub rows from the merge kernel) -- so two of the three norms skip their statistics pass.
+    Against KAGNN_FOLD_NORM_STATS=0 (the pass over g and y): every gradient, on a power-law graph with hub rows and a row count
+    that is not a multiple of the 16-row workgroups."""
+    n, e = 131072 + 13, 650_000
+    ei = orc.powerlaw_graph(n, e, seed=7)
+    ei = torch.cat([ei, ei.flip(0)], dim=1).to(DEV)              # both directions power-law: the TRANSPOSED structure has hub rows too
+    g = ops.GraphIndex(ei, n)
+    assert g.num_hub_seg_t > 0 and g.num_hub_seg > 0
+    x = (torch.randn(n, 64, generator=torch.Generator().manual_seed(1)) * 0.5).to(DEV)
+    gout = (torch.randn(n, 40, generator=torch.Generator().manual_seed(2)) / n).to(DEV)
+    torch.manual_seed(5)
+    model = kagnn_amd.GKAN_Nodes("gin", 3, 64, 64, 40, skip=True, grid_size=5, spline_order=3, hidden_layers=2).to(DEV).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    GIVEN, PASS = "kagnn_batchnorm_bwd statistics given (in ..._layer_bwd_bn)", "kagnn_batchnorm_bwd statistics (in ..._layer_bwd_bn)"
+    res = {}
+    for fold in (True, False):
+        monkeypatch.setattr(ops, "_FOLD_NORM_STATS", fold)
+        tensors, names, stages = _node_model_grads(model, x, g, gout, state)
+        launches = {k: v["launches"] for k, v in stages.items()}
+        if fold:
+            assert names.count("kagnn_gin_kan_layer_bwd_bn_sums") == 3 and names.count("kagnn_gin_kan_layer_bwd_bn") == 0, names
+            assert launches.get(GIVEN) == 2 and launches.get(PASS) == 1, launches       # (the last norm's gradient comes from the read-out)
+            assert launches.get("kagnn_batchnorm_bwd statistics fold") == 2, launches
+        else:
+            assert names.count("kagnn_gin_kan_layer_bwd_bn") == 3 and GIVEN not in launches and launches.get(PASS) == 3, (names, launches)
+        res[fold] = tensors
+    names = ["logits", "gx"] + [k for k, p in model.named_parameters() if p.grad is not None]
+    for a, b, what in zip(res[True], res[False], names):
+        scale = max(1e-30, float(b.abs().max()))
+        tol = 1e-4 if what.startswith("bns.") else 2e-5          # (cancelling sums over 131k rows: see the folded-norm test above)
+        assert float((a - b).abs().max()) <= tol * scale, (what, float((a - b).abs().max()) / scale)
+    assert torch.equal(res[True][0], res[False][0])               # the forward does not change
+
+
+def test_norm_backward_statistics_are_not_taken_when_the_gradient_is_not_the_parked_tensor(monkeypatch):
+    """the side channel only applies when the gradient a norm receives IS the tensor the next layer's aggregation wrote.  With
+    the skip gradients travelling on the tape (KAGNN_SKIP_GRADIENT off) autograd sums the read-out's and the convolution's
+    gradients of h_l into a NEW tensor: the parked sums describe only one addend and must be dropped -- same results as without
+    the fold, and the statistics pass runs for every norm."""
+    from kagnn_amd import models as M
+    n, e = 20011, 180000
+    g = ops.GraphIndex(orc.powerlaw_graph(n, e, seed=8).to(DEV), n)
+    x = (torch.randn(n, 64, generator=torch.Generator().manual_seed(3)) * 0.5).to(DEV)
+    gout = (torch.randn(n, 40, generator=torch.Generator().manual_seed(4)) / n).to(DEV)
+    monkeypatch.setattr(M, "_SPLIT_READOUT_MIN_ROWS", 0)
+    monkeypatch.setattr(M, "_SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH", 0)
+    monkeypatch.setattr(M, "_SKIP_GRADIENT", False)
+    torch.manual_seed(6)
+    model = kagnn_amd.GKAN_Nodes("gin", 3, 64, 64, 40, skip=True, grid_size=5, spline_order=3, hidden_layers=2).to(DEV).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    PASS = "kagnn_batchnorm_bwd statistics (in ..._layer_bwd_bn)"
+    res = {}
+    for fold in (True, False):
+        monkeypatch.setattr(ops, "_FOLD_NORM_STATS", fold)
+        tensors, names, stages = _node_model_grads(model, x, g, gout, state)
+        assert stages[PASS]["launches"] == 3, stages.keys()
+        res[fold] = tensors
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)                                  # (the aggregation's result rows do not depend on the statistics side)

@@ -266,7 +266,8 @@ def test_hot_path_kernels_do_not_spill_registers():
                  "kan_sparse_fwd_kernel<2,false,false,false,-1,true>",
                  "kan_split_dw_kernel<3,false,1,4,false>", "kan_split_dx_kernel<3,2,false,1,false,false,false>",
                  "kan_split_dx_kernel<3,2,false,0,false,true,false>", "kan_split_dw_w2_kernel<3,1>",
-                 "kan_split_dx_w2_kernel<4,3>", "kan_split_dw_kernel<0,false,1,4,false>", "agg_rows_v4_kernel<16>",
+                 "kan_split_dx_w2_kernel<4,3>", "kan_split_dw_kernel<0,false,1,4,false>", "agg_rows_v4_kernel<16,false>",
+                     "agg_rows_v4_kernel<16,true>", "agg_hub_merge_kernel<16,true>",      # (with the column statistics of the result: the norm backward fold)
                  # round 4: the wide-layer weight gradient and the read-out kernels that apply a folded BatchNorm1d to their rows
                  "kan_split_dw_shared_kernel<0,4>", "kan_split_dw_kernel<3,false,1,3,true>", "kan_split_dx_kernel<3,2,false,1,false,false,true>"):
         assert must in names, f"{must} is not covered by the spill gate: {sorted(names)[:5]}..."

@@ -15,7 +15,7 @@ txt = open("$OUT/${TAG}_bench_kernel_trace_and_pmc.txt").read()
 out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 3 (tools/prof.sh); per-launch "
                "averages; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- the x2 on FETCH_SIZE is the gfx950 correction of "
                "MI355X_MICROARCH.md (HBM) for 16 B/lane reads, which is what agg_rows_v4_kernel issues; WRITE_SIZE uncalibrated"}
-m = re.search(r"\nagg_rows_v4_kernel<16>\n(.*)", txt)
+m = re.search(r"\nagg_rows_v4_kernel<16(?:, false)?>\n(.*)", txt)
 if m:
     vals = dict(kv.split("=") for kv in m.group(1).split())
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
