@@ -505,3 +505,36 @@ def test_norm_backward_statistics_are_not_taken_when_the_gradient_is_not_the_par
         res[fold] = tensors
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)                                  # (the aggregation's result rows do not depend on the statistics side)
+
+
+@pytest.mark.parametrize("hidden", [40, 128, 200])
+def test_norm_backward_statistics_fold_at_other_widths(hidden, monkeypatch):
+    """the statistics side of the aggregation at 40 / 128 / 200 columns (lane groups of 16 / 32 / 64 per row, partly idle lanes),
+    hub rows in both directions, few rows: fold on vs off, every gradient"""
+    from kagnn_amd import models as M
+    monkeypatch.setattr(M, "_SPLIT_READOUT_MIN_ROWS", 0)
+    monkeypatch.setattr(M, "_SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH", 0)
+    n, e = 5003, 40000
+    ei = orc.powerlaw_graph(n, e, seed=hidden)
+    g = ops.GraphIndex(torch.cat([ei, ei.flip(0)], dim=1).to(DEV), n)
+    assert g.num_hub_seg_t > 0
+    x = (torch.randn(n, 64, generator=torch.Generator().manual_seed(hidden)) * 0.5).to(DEV)
+    gout = (torch.randn(n, 10, generator=torch.Generator().manual_seed(hidden + 1)) / n).to(DEV)
+    torch.manual_seed(hidden)
+    model = kagnn_amd.GKAN_Nodes("gin", 3, 64, hidden, 10, skip=True, grid_size=5, spline_order=3, hidden_layers=1).to(DEV).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    res = {}
+    for fold in (True, False):
+        monkeypatch.setattr(ops, "_FOLD_NORM_STATS", fold)
+        tensors, names, stages = _node_model_grads(model, x, g, gout, state)
+        if fold:
+            # (hidden > 64: the first convolution's output is wider than its inputs, it stays on two tape nodes -- one fold fewer)
+            want = 2 if hidden <= 64 else 1
+            assert names.count("kagnn_gin_kan_layer_bwd_bn_sums") >= want, names
+            assert stages.get("kagnn_batchnorm_bwd statistics fold", {}).get("launches") == want, stages.keys()
+        res[fold] = tensors
+    names = ["logits", "gx"] + [k for k, p in model.named_parameters() if p.grad is not None]
+    floor = 1e-6 * max(float(t.abs().max()) for t in res[False][1:])
+    for a, b, what in zip(res[True], res[False], names):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= max(1e-4 * scale, floor), (what, float((a - b).abs().max()), scale)
