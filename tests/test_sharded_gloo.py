@@ -135,17 +135,23 @@ def test_sharded_layer_world2_gloo(tmp_path):
 # ---------------------------------------------------------------------------------------------------------
 # the same two sharded layers with the PRODUCT's local ops (HIP kernels): two ranks share cuda:0, collectives
 # over gloo -- checks the sharding algebra end to end against the unsharded layer on the same device
-def _gpu_worker(rank, world, port, out_dir):
+def _gpu_worker(rank, world, port, out_dir, backend="gloo"):
+    """backend "gloo": both ranks on cuda:0 (what a 1-GPU box can run); "nccl": one device per rank over RCCL -- the real thing,
+    including the library's own RCCL entry points (comm="rccl_c") and the barrier's RCCL branch; needs >= 2 GPUs"""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import kagnn_amd
         from kagnn_amd import ops
         from kagnn_amd.sharded import ShardedGIKANLayer, TransposedShardedGIKANLayer
         from oracle import kan_oracle as orc
-        dev = torch.device("cuda", 0)
         n, e, f = 3001, 30000, 16
         ei = orc.powerlaw_graph(n, e, seed=3).to(dev)
         gen = torch.Generator().manual_seed(3)
@@ -165,8 +171,11 @@ def _gpu_worker(rank, world, port, out_dir):
             assert err <= 1e-4, (what, err)
 
         # comm="p2p": hipIpc peer-mapped exchange buffers + kagnn_p2p_reduce_scatter / _all_gather (two processes, one GPU)
-        for cls, kw in ((ShardedGIKANLayer, {}), (ShardedGIKANLayer, {"chunks": 3}), (ShardedGIKANLayer, {"comm": "p2p"}),
-                        (ShardedGIKANLayer, {"comm": "p2p", "chunks": 3}), (TransposedShardedGIKANLayer, {}), (TransposedShardedGIKANLayer, {"comm": "p2p"})):
+        combos = [(ShardedGIKANLayer, {}), (ShardedGIKANLayer, {"chunks": 3}), (ShardedGIKANLayer, {"comm": "p2p"}),
+                  (ShardedGIKANLayer, {"comm": "p2p", "chunks": 3}), (TransposedShardedGIKANLayer, {}), (TransposedShardedGIKANLayer, {"comm": "p2p"})]
+        if backend == "nccl":              # (RCCL refuses two ranks on one device: only with a GPU per rank)
+            combos += [(ShardedGIKANLayer, {"comm": "rccl_c"}), (ShardedGIKANLayer, {"comm": "rccl_c", "chunks": 3})]
+        for cls, kw in combos:
             sconv = cls(conv, None, **kw).to(dev)
             xs = sconv.shard_columns(x).requires_grad_(True)
             y = sconv(xs, graph)
@@ -209,7 +218,7 @@ def _gpu_worker(rank, world, port, out_dir):
             yb.backward(gyb)
             wb = fb // world
             slb = slice(rank * wb, (rank + 1) * wb)
-            for kw in ({}, {"comm": "p2p"}):
+            for kw in ({}, {"comm": "p2p"}) + (({"comm": "rccl_c"},) if backend == "nccl" else ()):
                 sb = ShardedGIKANLayer(convb, None, **kw).to(dev)
                 for step in range(2):                  # twice: both buffers of the p2p exchange
                     xs = sb.shard_columns(xb).requires_grad_(True)
@@ -235,6 +244,18 @@ def test_sharded_layers_two_ranks_one_gpu(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one rank per device over RCCL / xGMI")
+def test_sharded_layers_two_ranks_two_gpus_rccl(tmp_path):
+    """the same checks with one DEVICE per rank: collectives over RCCL, peer pulls over xGMI, the barrier's RCCL branch, and the
+    library's own RCCL entry points (comm="rccl_c") -- skipped on the 1-GPU boxes every round of this build has had"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
