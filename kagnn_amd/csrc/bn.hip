@@ -416,18 +416,24 @@ int bn_bwd_stats(const float* x, long ldx, const float* gy, long ldgy, long N, i
 
 // ---- the norm's backward statistics arriving from ELSEWHERE (round 4): the aggregation that produced the incoming gradient g
 // left partial row pairs [B][2][F] of sum g and sum g * xhat (aggregate.hip, AggArgs::st_*).  Two launches fold them in a fixed
-// order: kStatsFold workgroups each add a contiguous range of the B rows (32 MB at 1M rows: one row pair per 16 rows), then
-// bn_finish_kernel<1> adds those kStatsFold rows.
-constexpr int kStatsFold = 256;
+// order: one workgroup per 64 partial row pairs adds them (32 MB at 1M rows: one row pair per 16 rows; 977 workgroups), then
+// bn_finish_kernel<1> adds those 977 rows.
+constexpr int kStatsFoldRows = 64;               // partial rows per workgroup of the first folding launch
 __global__ __launch_bounds__(256) void stats_fold_kernel(const float* __restrict__ partial, long B, int F2 /* 2 * F */,
                                                          float* __restrict__ stage) {
     __shared__ float s_red[256];
-    const long per = (B + gridDim.x - 1) / gridDim.x, b0 = blockIdx.x * per, b1 = min(B, b0 + per);
+    const long b0 = (long)blockIdx.x * kStatsFoldRows, b1 = min(B, b0 + kStatsFoldRows);
     for (int c0 = 0; c0 < F2; c0 += 64) {                 // 64 columns x 4 row slots per pass (uniform trip count: barriers inside)
         const int c = c0 + (threadIdx.x & 63), slot = threadIdx.x >> 6;
+        float v[kStatsFoldRows / 4];
+#pragma unroll
+        for (int k = 0; k < kStatsFoldRows / 4; ++k) {    // all 16 loads of a thread in flight, then added in row order
+            const long b = b0 + slot + 4 * k;
+            v[k] = (c < F2 && b < b1) ? partial[b * F2 + c] : 0.0f;
+        }
         float acc = 0.0f;
-        if (c < F2)
-            for (long b = b0 + slot; b < b1; b += 4) acc += partial[b * F2 + c];
+#pragma unroll
+        for (int k = 0; k < kStatsFoldRows / 4; ++k) acc += v[k];
         s_red[threadIdx.x] = acc;
         __syncthreads();
         if (slot == 0 && c < F2) stage[(long)blockIdx.x * F2 + c] = (s_red[threadIdx.x] + s_red[threadIdx.x + 64]) + (s_red[threadIdx.x + 128] + s_red[threadIdx.x + 192]);
@@ -435,13 +441,14 @@ __global__ __launch_bounds__(256) void stats_fold_kernel(const float* __restrict
     }
 }
 
-size_t bn_stats_fold_bytes(long B, int F) { return ((size_t)B + kStatsFold) * 2 * F * sizeof(float); }    // partial rows | fold stage
+static long stats_fold_blocks(long B) { return max(1L, (B + kStatsFoldRows - 1) / kStatsFoldRows); }
+size_t bn_stats_fold_bytes(long B, int F) { return ((size_t)B + stats_fold_blocks(B)) * 2 * F * sizeof(float); }    // partial rows | fold stage
 
 // partial [B][2][F] (at ws) -> sums[0][F] = sum g, sums[1][F] = sum g * xhat
 int bn_sums_from_partials(float* ws, long B, int F, float* sums, hipStream_t st) {
     float* stage = ws + (size_t)B * 2 * F;
-    const int nb = (int)min((long)kStatsFold, max(1L, B));
-    stats_fold_kernel<<<nb, 256, 0, st>>>(ws, B, 2 * F, stage);
+    const long nb = stats_fold_blocks(B);
+    stats_fold_kernel<<<(unsigned)nb, 256, 0, st>>>(ws, B, 2 * F, stage);
     KAGNN_LAUNCH_CHECK();
     bn_finish_kernel<1><<<cdiv(F, 32), 1024, 0, st>>>(stage, nb, F, 0, nullptr, 0.f, 0.f, sums, sums + F, nullptr, nullptr);
     KAGNN_LAUNCH_CHECK();
