@@ -10,6 +10,8 @@ node_classification_clean/models.py:198-201 -- through the C ABI:
 * the node models with the fused epilogue on and off agree, and train with dropout.
 """
 import numpy as np
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -95,7 +97,19 @@ def test_forward_moments_when_the_mean_dwarfs_the_spread():
     rm = torch.zeros(64, device=DEV)
     out = ops.batch_norm(y, None, None, rm, rv, True, 0.1, 1e-5, moments=mom)
     want = F.batch_norm(y.double().cpu(), None, None, None, None, True, 0.1, 1e-5)
-    assert_close(out, want, 2e-3, what="bn of a near-constant column", elementwise=False)   # rstd ~ 1e2 amplifies fp32 ulps of y
+    # Tolerance DERIVED, not fitted: the normalised value is (y - mean) * rstd with y ~ 48 and rstd ~ 1e2, so what shows is the fp32
+    # rounding of the column MEAN times rstd.  The mean is a chain of pairwise merges (Chan) -- ceil(n / 256) workgroup rows folded
+    # one after the other in the finish kernel, each fold rounding to half an ulp of the mean: a random walk of sqrt(merges) / 2 ulps
+    # (sum / sum-of-squares statistics would be off by whole units here).  Allowed: exactly that estimate; observed: about a fifth
+    # of it (the folds are hierarchical -- wave, workgroup, finish -- so fewer of them are sequential than the estimate assumes)
+    yd = y.double()
+    mean_abs = float(yd.mean(0).abs().max())
+    rstd_max = float((yd.var(0, unbiased=False) + 1e-5).rsqrt().max())
+    merges = -(-y.size(0) // 256)
+    ulp = 2.0 ** (math.floor(math.log2(mean_abs)) - 23)
+    bound = rstd_max * ulp * 0.5 * math.sqrt(merges)
+    scale = max(1.0, float(want.abs().max()))
+    assert_close(out, want, bound / scale, what="bn of a near-constant column", elementwise=False)
 
 
 @pytest.mark.parametrize("n,f", [(5000, 64), (100003, 64), (777, 40), (30000, 128)])
