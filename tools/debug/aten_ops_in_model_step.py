@@ -1,0 +1,55 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch, bench, kagnn_amd
+from kagnn_amd import harness, ops
+from torch.profiler import profile, ProfilerActivity
+dev = torch.device("cuda", 0)
+n, e, f = 1_000_000, 10_000_000, 64
+graph = ops.GraphIndex(bench.powerlaw_graph(n, e, 0).to(dev), n)
+x = (torch.randn(n, f, generator=torch.Generator().manual_seed(0)) * 0.25).to(dev)
+torch.manual_seed(0)
+model = kagnn_amd.GKAN_Nodes("gin", 3, f, f, 40, skip=True, grid_size=5, spline_order=3, hidden_layers=2).to(dev)
+y = torch.randint(0, 40, (n,), generator=torch.Generator().manual_seed(2)).to(dev)
+mask = torch.ones(n, dtype=torch.bool, device=dev)
+import inspect
+src = inspect.getsource(harness.time_model)
+print(src[:3000])
+opt = torch.optim.Adam(model.parameters(), lr=0.001, fused=True)
+def step():
+    opt.zero_grad()
+    out = model(x, graph)
+    loss = ops.softmax_cross_entropy(out, y, mask)
+    loss.backward()
+    opt.step()
+for _ in range(3): step()
+torch.cuda.synchronize()
+# who makes a tensor contiguous by COPYING it (one small kernel each)?
+import traceback, collections
+sites = collections.Counter()
+_orig = torch.Tensor.contiguous
+def _spy(self, *a, **k):
+    if not self.is_contiguous():
+        fr = [f for f in traceback.extract_stack()[:-1] if "kagnn_amd" in f.filename or "harness" in f.filename]
+        sites[(tuple(self.shape), tuple(self.stride()), " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in fr[-3:]))] += 1
+    return _orig(self, *a, **k)
+torch.Tensor.contiguous = _spy
+for name in ("zeros", "cat", "ones_like"):
+    def mk(name):
+        o = getattr(torch, name)
+        def spy(*a, **k):
+            fr = [f for f in traceback.extract_stack()[:-1] if "kagnn_amd" in f.filename or "harness" in f.filename]
+            sites[(name, " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in fr[-3:]))] += 1
+            return o(*a, **k)
+        return spy
+    setattr(torch, name, mk(name))
+step(); torch.cuda.synchronize()
+torch.Tensor.contiguous = _orig
+for k, v in sites.most_common(): print(v, k)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    step(); torch.cuda.synchronize()
+rows = []
+for ev in prof.key_averages(group_by_stack_n=6):
+    if ev.key.startswith("aten::") and ev.device_time_total > 0 and ev.key not in ("aten::to",):
+        rows.append((ev.key, ev.count, ev.device_time_total, [s for s in ev.stack if "kagnn_amd" in s or "harness" in s][:3]))
+rows.sort(key=lambda r: -r[2])
+for r in rows[:40]: print(r)
