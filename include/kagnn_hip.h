@@ -366,6 +366,22 @@ int kagnn_gin_kan_layer_bwd_bn_sums(const float* g, int64_t ldg, const float* y,
                                     float* const* g_spline_weight, float* const* g_spline_scaler, void* workspace,
                                     size_t workspace_bytes, void* stream);
 
+/* kagnn_kan_linear_bwd_input_affine that ALSO leaves the two column sums the backward of the folded BatchNorm1d starts from (round 4):
+ * sums[0][in] = sum_n gx, sums[1][in] = sum_n gx * xhat, xhat = (x - bn_mean) * bn_rstd on the raw rows x (= that norm's input).
+ * The read-out's gradient of the LAST convolution's output in the node models (node_classification_clean/models.py:198-203): that
+ * norm's incoming gradient IS this gx, so its statistics pass goes away (hand `sums` to kagnn_gin_kan_layer_bwd_bn_sums as bn_sums).
+ * Per workgroup one partial row pair (lanes add their 8 rows, the row groups meet by shuffles, the waves in LDS in order), folded by
+ * one launch: deterministic.  Covered (kagnn_kan_bwd_input_sums_ok == 1): split precision, cubic layers of <= 8 coefficients,
+ * <= 64 inputs (a multiple of 4) and outputs, >= 32768 rows; else KAGNN_ERR_UNSUPPORTED.                                        */
+int kagnn_kan_bwd_input_sums_ok(int64_t num_rows, int32_t in_features, int32_t out_features, int32_t grid_size, int32_t spline_order,
+                                int32_t mode);
+int kagnn_kan_bwd_input_sums_workspace_bytes(int64_t num_rows, int32_t in_features, size_t* bytes_host);
+int kagnn_kan_linear_bwd_input_affine_sums(const float* x, int64_t ldx, const float* x_affine, const float* bn_mean,
+                                           const float* bn_rstd, const float* gy, int64_t ldgy, int64_t num_rows, const float* knots,
+                                           int32_t in_features, int32_t out_features, int32_t grid_size, int32_t spline_order,
+                                           int32_t mode, const void* pack_dx, float* gx, int64_t ldgx, float* sums,
+                                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Adaptive grids.  Replaces the device work of KANLinear.update_grid (ekan.py:164-211) and the dense
  * b_splines (:79-112).  `grid*` are whole grid buffers [in, G+2k+1] with increasing rows.

@@ -90,6 +90,10 @@ _SIGNATURES = {
                                                   c_int64, _P, _P, _P, c_int64, c_int32, c_float, c_int32, _P, _P, _P,
                                                   _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P, c_int64,
                                                   _P, _P, _P, _P, c_size_t, _P]),
+    "kagnn_kan_bwd_input_sums_ok": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "kagnn_kan_bwd_input_sums_workspace_bytes": (c_int32, [c_int64, c_int32, POINTER(c_size_t)]),
+    "kagnn_kan_linear_bwd_input_affine_sums": (c_int32, [_P, c_int64, _P, _P, _P, _P, c_int64, c_int64, _P, c_int32, c_int32,
+                                                         c_int32, c_int32, c_int32, _P, _P, c_int64, _P, _P, c_size_t, _P]),
     "kagnn_kan_bsplines": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
     "kagnn_kan_grid_refit_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
     "kagnn_kan_grid_refit": (c_int32, [_P, c_int64, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P,

@@ -23,6 +23,7 @@ bool aggregate_stats_ok(const AggArgs& a);
 long aggregate_stats_rows(long N, int F, long num_hub_seg);
 size_t bn_stats_fold_bytes(long B, int F);
 int bn_sums_from_partials(float* ws, long B, int F, float* sums, hipStream_t st);
+int bn_finish_partials(const float* partial, long B, int F, float* sums, hipStream_t st);
 int bn_bwd_stats_given(const float*, long, int, const float*, const float*, const float*, float*, float*, float*, int, hipStream_t);
 int gcn_deg_inv_sqrt(const int* rowptr, const int* col, long N, float* dis, hipStream_t st);
 int gine_fwd(const float*, long, const float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
@@ -64,6 +65,10 @@ bool kan_sparse_fwd_moments_ok(long N, int in, int out, int G, int K);
 size_t kan_sparse_fwd_moments_ws_bytes(long N, int out);
 int col_moments(const float*, long, long, int, float*, float*, void*, size_t, hipStream_t);
 bool kan_split_dx_ok(int in, int out, int G, int K);
+int kan_split_dx_stats_blocks(long N);
+bool kan_split_dx_stats_ok(long N, int in, int out, int G, int K);
+int kan_split_dx_stats(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, hipStream_t,
+                       const float*, const float*, const float*, float*);
 bool kan_split_dw_ok(int in, int out, int G, int K);
 
 int fastkan_fwd(const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, void*, size_t, int, hipStream_t);
@@ -512,6 +517,41 @@ int kagnn_kan_linear_bwd_input_affine(const float* x, int64_t ldx, const float* 
     if (gx_dtype != KAGNN_DTYPE_F32) return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 gradient rows are produced by the split-precision kernels only", __func__);
     float* gxf = static_cast<float*>(gx);
     return kan_f32_dx(x, ldx, gy, ldgy, N, knots, in, out, G, K, (const float*)pack_dx, gxf, ldgx, mode == KAGNN_PREC_FP32_GRID, as_stream(stream));
+}
+
+// kagnn_kan_linear_bwd_input_affine that ALSO leaves the two column sums the backward of the folded BatchNorm1d starts from:
+// sums[0][in] = sum_n gx, sums[1][in] = sum_n gx * xhat, xhat = (x - bn_mean) * bn_rstd on the raw rows (x = the norm's input).
+// The read-out's gradient of the LAST convolution's output in the node models (reference node_classification_clean/models.py:198-203):
+// that norm's incoming gradient is exactly this gx, so its statistics pass over (gx, x) goes away.  Covered (kagnn_kan_bwd_input_sums_ok):
+// split precision, cubic layers of <= 8 coefficients, <= 64 inputs (a multiple of 4) and outputs, >= 32768 rows.
+int kagnn_kan_bwd_input_sums_ok(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode) {
+    return mode == KAGNN_PREC_SPLIT && use_split_dx(in, out, G, K, mode) && kan_split_dx_stats_ok(N, in, out, G, K) ? 1 : 0;
+}
+int kagnn_kan_bwd_input_sums_workspace_bytes(int64_t N, int32_t in, size_t* bytes) {
+    KAGNN_CHECK_ARG(N >= 0 && in >= 1 && bytes, "bad argument");
+    *bytes = ((size_t)kan_split_dx_stats_blocks(N) + 1) * 2 * in * sizeof(float);
+    return KAGNN_OK;
+}
+int kagnn_kan_linear_bwd_input_affine_sums(const float* x, int64_t ldx, const float* x_affine, const float* bn_mean, const float* bn_rstd,
+                                           const float* gy, int64_t ldgy, int64_t N, const float* knots, int32_t in, int32_t out,
+                                           int32_t G, int32_t K, int32_t mode, const void* pack_dx, float* gx, int64_t ldgx,
+                                           float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_kan_dims(__func__, in, out, G, K, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 1 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
+    KAGNN_CHECK_ARG(x && x_affine && bn_mean && bn_rstd && gy && knots && pack_dx && gx && sums && workspace, "null array");
+    if (!kagnn_kan_bwd_input_sums_ok(N, in, out, G, K, mode)) return fail(KAGNN_ERR_UNSUPPORTED, "%s: shape not covered (kagnn_kan_bwd_input_sums_ok)", __func__);
+    if (!(fits32(N, ldx) && fits32(N, ldgy) && fits32(N, ldgx))) return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats", __func__);
+    const int B = kan_split_dx_stats_blocks(N);
+    KAGNN_CHECK_ARG(workspace_bytes >= ((size_t)B + 1) * 2 * in * sizeof(float), "workspace too small (kagnn_kan_bwd_input_sums_workspace_bytes)");
+    float* partial = static_cast<float*>(workspace);
+    {
+        KAGNN_STAGE_AS("kagnn_kan_linear_bwd_input", stream);
+        rc = kan_split_dx_stats(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack_dx, gx, ldgx, as_stream(stream), x_affine, bn_mean, bn_rstd, partial);
+        if (rc) return rc;
+    }
+    KAGNN_STAGE_AS("kagnn_batchnorm_bwd statistics fold", stream);
+    return bn_finish_partials(partial, B, in, sums, as_stream(stream));
 }
 
 int kagnn_kan_bwd_weight_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K,

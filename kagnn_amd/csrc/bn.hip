@@ -455,6 +455,13 @@ int bn_sums_from_partials(float* ws, long B, int F, float* sums, hipStream_t st)
     return KAGNN_OK;
 }
 
+// few partial row pairs [B][2][F] (one per workgroup of a persistent kernel): the finish launch alone
+int bn_finish_partials(const float* partial, long B, int F, float* sums, hipStream_t st) {
+    bn_finish_kernel<1><<<cdiv(F, 32), 1024, 0, st>>>(partial, B, F, 0, nullptr, 0.f, 0.f, sums, sums + F, nullptr, nullptr);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 __global__ void bn_sums_out_kernel(const float* __restrict__ sums, int F, float* __restrict__ g_gamma, float* __restrict__ g_beta) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;

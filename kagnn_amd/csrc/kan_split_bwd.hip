@@ -123,7 +123,12 @@ __device__ __forceinline__ float barrel_dot(const float (&d)[8], int m, const fl
 //   BNB: `gy` is the gradient of the BatchNorm1d that follows the layer; the norm's backward (one affine expression per
 //   element, split_common.h BnBack) is applied to the rows as they are loaded, and the transformed rows are stored for the
 //   weight-gradient kernel -- the stand-alone normalisation-backward pass (read g, read y, write gy) disappears.
-template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false>
+// XST (with XAFF; the read-out's gradient of the LAST convolution's output): also leave the column sums of the stored gradient rows
+// and of their products with xhat (RbfArgs::st_*) -- the two sums the backward of the norm whose folded output this layer read
+// starts from.  Per feature tile a lane adds its 8 rows, the four row groups of a wave meet by two shuffles, and the wave adds the
+// tile's 16 columns into its own LDS slots behind the W tiles; the 8 waves are added in order at the end: one partial row pair
+// per workgroup, deterministic.  Needs <= 4 feature tiles per workgroup (in <= 64, no split over blockIdx.y).
+template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false, bool XST = false>
 __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     int ft_per_block /* feature tiles per blockIdx.y: few-row inputs spread their feature tiles over the chip */, BnBack bnb) {
     static_assert(!BNB || (K == 3 && !GEN && PP == 0 && !GX16), "the fused normalisation backward serves the lean cubic instantiation");
     static_assert(!XAFF || (K == 3 && !GEN && !GX16 && !BNB), "the input affine serves the lean cubic instantiation (the read-out of the node models)");
+    static_assert(!XST || XAFF, "the column statistics ride in the read-out instantiation");
     // GX16: gx rows are bf16 (a compile-time variant of the lean cubic instantiation -- as a run-time flag the 2-byte
     // store path cost every launch 14 %: round 2, profiles/r02_experiments.md)
     const int sh = GEN ? sh_arg : 0;
@@ -281,13 +287,18 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
         }
     };
 
+    // XST: [wave 8][stat 2][feature 64] floats behind the (resident) W tiles
+    float* s_stat = reinterpret_cast<float*>(s_w + (size_t)(ft_end - ft_begin) * FT_BYTES) + wave * 128;
+    if constexpr (XST) { s_stat[lane] = 0.0f; s_stat[64 + lane] = 0.0f; }   // (each wave touches only its own slice until the end)
     float graw[2][Q2][8];
     long tile = blockIdx.x;
-    if (tile * 256 >= N) return;                                 // (workgroup-uniform; the grid never over-covers)
+    if (!XST && tile * 256 >= N) return;                         // (workgroup-uniform; the grid never over-covers)
+    if (!XST || tile * 256 < N) {
     load_gy(tile, graw);
     load_stats(tile);
     split_gy(graw);
     if (PP >= 1 && (tile + gridDim.x) * 256 < N) load_gy(tile + gridDim.x, graw);
+    }
     if (pingpong && wave >= 4) __builtin_amdgcn_s_barrier();     // the partner half starts one phase late
 
     for (; tile * 256 < N; tile += gridDim.x) {
@@ -317,6 +328,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
             if (ln_on) { gam = rb.ln_w[min(fr, in - 1)]; bet = rb.ln_b[min(fr, in - 1)]; }
             float xa = 1.0f, xs = 0.0f;                  // XAFF: the input is  xa * x + xs  (a folded BatchNorm1d)
             if constexpr (XAFF) { xa = rb.x_affine[min(fr, in - 1)]; xs = rb.x_affine[in + min(fr, in - 1)]; }
+            float st_m = 0.0f, st_q = 0.0f, st_g = 0.0f, st_gx = 0.0f;
+            if constexpr (XST) { st_m = rb.st_mean[min(fr, in - 1)]; st_q = rb.st_rstd[min(fr, in - 1)]; }
             float xq[2][4];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -431,6 +444,10 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     }
                     float s = fmaf(D[kCTmax - 1][rt][reg], silu_gradf(xv), bar) * rinv[rt][reg];
                     if (sh) s += __shfl_xor(s, 1);                       // the two windows of one input feature (wave-uniform branch)
+                    if constexpr (XST) {                                 // (rows >= N: gy reads as 0 there, so s == 0)
+                        st_g += s;
+                        st_gx = fmaf(s, (xq[rt][reg] - st_m) * st_q, st_gx);
+                    }
                     if (f < inv && win == 0) {
                         const unsigned so_x = (unsigned)(16 * rt + reg) * ldgx4;
                         if (ACC) s += gld_s(gxb, gx_ro, so_x);                          // second and later output blocks
@@ -439,6 +456,11 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                     }
                     }
                 }
+            }
+            if constexpr (XST) {                           // this tile's 16 columns: the four row groups, then the wave's LDS slots
+                st_g += __shfl_xor(st_g, 16); st_gx += __shfl_xor(st_gx, 16);
+                st_g += __shfl_xor(st_g, 32); st_gx += __shfl_xor(st_gx, 32);
+                if (kg == 0 && f < in) { s_stat[f] += st_g; s_stat[64 + f] += st_gx; }
             }
             if (PP >= 1 && ft + 1 == ft_end && more) {
                 // fragments of the next row tile (its rows arrived long ago), and the request for the one after
@@ -450,6 +472,17 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
         }
     }
     if (pingpong && wave < 4) __builtin_amdgcn_s_barrier();      // balance the partner half's initial barrier
+    if constexpr (XST) {
+        __syncthreads();
+        if (tid < 128) {                                         // (stat, feature): the 8 waves in order
+            const float* base = reinterpret_cast<const float*>(s_w + (size_t)(ft_end - ft_begin) * FT_BYTES);
+            float a = 0.0f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) a += base[w8 * 128 + tid];
+            const int stat = tid >> 6, col = tid & 63;
+            if (col < in) rb.st_partial[((long)blockIdx.x * 2 + stat) * in + col] = a;
+        }
+    }
 }
 
 // KAGNN_DX_SCHEDULE = 0 plain | 1 gy prefetch (default) | 2 prefetch + phase ping-pong.  Measured round 2
@@ -464,7 +497,7 @@ static int dx_schedule() {
     return v;
 }
 
-template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false>
+template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false, bool XST = false>
 static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                         const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
                         const RbfArgs& rb, int accumulate, hipStream_t st, const BnBack& bnb = BnBack{}) {
@@ -477,15 +510,17 @@ static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, lo
     const int fpb = cdiv(FT, splits);
     splits = cdiv(FT, fpb);
     const bool resident = (size_t)fpb * ft_bytes <= budget;
-    const size_t lds = kLdsHdr + (resident ? fpb : 1) * ft_bytes;
+    if (XST && !(resident && splits == 1 && in <= 64 && (size_t)fpb * ft_bytes + 8 * 128 * sizeof(float) <= budget))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: column statistics need <= 64 input features, resident weights and >= 32768 rows", "kan_split_dx");
+    const size_t lds = kLdsHdr + (resident ? fpb : 1) * ft_bytes + (XST ? 8 * 128 * sizeof(float) : 0);
     static bool configured = false;
     if (!configured) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF>,
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF, XST>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
     }
     const dim3 grid((unsigned)min(row_blocks, 256L), (unsigned)splits);
-    kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
+    kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF, XST><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
                                                                            resident ? 1 : 0, gx, ldgx, rb, sh, accumulate, fpb, bnb);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
@@ -504,6 +539,11 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
     } else if constexpr (K == 3 && !GEN) {
         if (rb.x_affine) {                               // the input is a folded BatchNorm1d output (read-out of the node models)
             if (gx16) return fail(KAGNN_ERR_UNSUPPORTED, "%s: an input affine and bf16 gradient rows do not combine", "kan_split_dx");
+            if (rb.st_partial) {
+                if constexpr (Q2 <= 2)
+                    return launch_dx_pp<K, Q2, GEN, 1, false, false, true, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
+                return fail(KAGNN_ERR_UNSUPPORTED, "%s: column statistics need <= 64 outputs", "kan_split_dx");
+            }
             return launch_dx_pp<K, Q2, GEN, 1, false, false, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
         }
         if (gx16) return launch_dx_pp<K, Q2, GEN, 1, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
@@ -802,6 +842,21 @@ int kan_split_dx_bn(const float* x, long ldx, const float* g, long ldg, long N, 
     const int nk = G + 2 * K + 1;
     if (out == 32) return launch_dx_pp<3, 1, false, 0, false, true>(x, ldx, g, ldg, N, in, out, G + K, knots, nk, p, gx, ldgx, RbfArgs{}, 0, st, bnb);
     return launch_dx_pp<3, 2, false, 0, false, true>(x, ldx, g, ldg, N, in, out, G + K, knots, nk, p, gx, ldgx, RbfArgs{}, 0, st, bnb);
+}
+
+// (statistics variant: st_partial[min(cdiv(N, 256), 256)][2][in], see kan_split_dx_kernel<..., XST>)
+int kan_split_dx_stats_blocks(long N) { return (int)min((long)cdiv(N, 256), 256L); }
+bool kan_split_dx_stats_ok(long N, int in, int out, int G, int K) {
+    return K == 3 && G + K <= 8 && in <= 64 && in % 4 == 0 && out <= 64 && cdiv(N, 256) >= 128;
+}
+int kan_split_dx_stats(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in, int out, int G, int K,
+                       const void* pack, float* gx, long ldgx, hipStream_t st, const float* x_affine, const float* st_mean,
+                       const float* st_rstd, float* st_partial) {
+    if (!kan_split_dx_stats_ok(N, in, out, G, K) || !x_affine)
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: column statistics need a folded input, a cubic layer of <= 8 coefficients, <= 64 inputs / outputs and >= 32768 rows", "kan_split_dx");
+    RbfArgs rb{};
+    rb.x_affine = x_affine; rb.st_mean = st_mean; rb.st_rstd = st_rstd; rb.st_partial = st_partial;
+    return kan_split_dx_any(x, ldx, gy, ldgy, N, knots, in, out, G, K, pack, gx, ldgx, rb, st, 0);
 }
 
 int kan_split_dx(const float* x, long ldx, const float* gy, long ldgy, long N, const float* knots, int in,

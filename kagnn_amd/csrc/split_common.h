@@ -602,6 +602,10 @@ struct RbfArgs {
     // output that was never written: the XAFF instantiations of the input- and weight-gradient kernels apply it to the rows
     // they load
     const float* x_affine = nullptr;
+    // (input-gradient kernel, XST instantiation, round 4) the column statistics of the gradient rows it stores, for the backward of
+    // the BatchNorm1d whose folded output this layer read: st_partial[workgroup][2][in] receives sum gx and sum gx * xhat over
+    // the workgroup's rows, xhat = (x - st_mean) * st_rstd on the RAW rows the kernel loads (x = that norm's input)
+    const float* st_mean = nullptr; const float* st_rstd = nullptr; float* st_partial = nullptr;
 };
 
 // ca[g] = a * c_{8*window+g} (wave-uniform; slots >= num_grids repeat the last centre -- their packed weights

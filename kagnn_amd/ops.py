@@ -642,6 +642,18 @@ def _kan_bwd_input_raw(x, gy, knots, pack_d, fin, fout, G, K, mode, bf16_out=Fal
     return gx
 
 
+def _kan_bwd_input_sums_raw(x, gy, knots, pack_d, fin, fout, G, K, mode, x_affine, ns):
+    """``_kan_bwd_input_raw(x_affine=)`` + the two column sums of gx the folded norm's backward starts from (``ns``: its NormSums)"""
+    n = x.size(0)
+    gx = torch.empty((n, fin), dtype=torch.float32, device=x.device)
+    sums = torch.empty((2, fin), dtype=torch.float32, device=x.device)
+    wb = _sizes("kagnn_kan_bwd_input_sums_workspace_bytes", n, fin)
+    ws = _ws(wb, x.device)
+    _call("kagnn_kan_linear_bwd_input_affine_sums", _ptr(x), _ld(x), _ptr(x_affine), _ptr(ns.mean), _ptr(ns.rstd), _ptr(gy), _ld(gy), n,
+          _ptr(knots), fin, fout, G, K, mode, _ptr(pack_d), _ptr(gx), fin, _ptr(sums), _ptr(ws), ws.numel(), _stream())
+    return gx, sums
+
+
 def _kan_bwd_weight_raw(x, gy, knots, sw, sc, fin, fout, G, K, mode, has_base, x_affine=None):
     n = x.size(0)
     ws = _ws(_sizes("kagnn_kan_bwd_weight_workspace_bytes", n, fin, fout, G, K, mode), x.device)
@@ -1239,12 +1251,15 @@ class _KANLinearPartsFn(Function):
 
     @staticmethod
     @_on_operand_device
-    def forward(ctx, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, skip_gradients, affines, *parts):
+    def forward(ctx, base_weight, spline_weight, spline_scaler, knots, grid_size, spline_order, mode, skip_gradients, affines, norm_stats,
+                *parts):
         """``affines``: ``None`` or per block ``None`` / a [2, width] tensor -- the block is read as scale * x + shift
-        (``AffineRows``: a BatchNorm1d output that was never written)"""
+        (``AffineRows``: a BatchNorm1d output that was never written); ``norm_stats``: ``None`` or per block ``None`` / the
+        ``NormSums`` of that norm (its backward statistics can then come out of this node's input-gradient kernel)"""
         _need_cuda(base_weight, spline_weight, spline_scaler, knots, *parts)
         ctx.skip_gradients = skip_gradients
         ctx.affines = affines
+        ctx.norm_stats = norm_stats
         n, fout = parts[0].size(0), spline_weight.size(0)
         widths = [int(t.size(1)) for t in parts]
         fin = sum(widths)
@@ -1275,7 +1290,7 @@ class _KANLinearPartsFn(Function):
         gxs, gbws, gsws, gscs, f0 = [], [], [], [], 0
         slices = []                          # per block: contiguous (base, spline, scaler) columns, or None when nothing needs them
         npart, w0 = len(parts), widths[0]
-        if npart > 1 and all(w == w0 for w in widths) and (want_w or all(ctx.needs_input_grad[9:9 + npart])):
+        if npart > 1 and all(w == w0 for w in widths) and (want_w or all(ctx.needs_input_grad[10:10 + npart])):
             # equal blocks (the node models on hidden-wide inputs): ONE strided copy per parameter tensor -- [out, P, w(, C)] ->
             # [P, out, w(, C)] -- instead of one per block and tensor (12 four-microsecond launches per read-out backward)
             out_f = bw.size(0)
@@ -1286,17 +1301,17 @@ class _KANLinearPartsFn(Function):
         else:
             for i in range(npart):
                 f1 = f0 + widths[i]
-                if ctx.needs_input_grad[9 + i] or want_w:
+                if ctx.needs_input_grad[10 + i] or want_w:
                     slices.append((bw[:, f0:f1].contiguous(), sw[:, f0:f1].contiguous(), None if sc is None else sc[:, f0:f1].contiguous()))
                 else:
                     slices.append(None)
                 f0 = f1
         # the input-gradient packs of all blocks that need one: ONE launch when the batch entry point covers them
-        need = [i for i in range(len(parts)) if ctx.needs_input_grad[9 + i]]
+        need = [i for i in range(len(parts)) if ctx.needs_input_grad[10 + i]]
         packs = kan_pack_chain([slices[i] for i in need], G, K, mode) if sc is not None and len(need) >= 2 else None
         pack_of = {} if packs is None else {i: packs[k][1] for k, i in enumerate(need)}
         for i, part in enumerate(parts):
-            want_x = ctx.needs_input_grad[9 + i]
+            want_x = ctx.needs_input_grad[10 + i]
             aff = None if ctx.affines is None else ctx.affines[i]
             bwp, swp, scp = slices[i] if slices[i] is not None else (None, None, None)
             gx = None
@@ -1307,9 +1322,18 @@ class _KANLinearPartsFn(Function):
                     pack_f, pack_d = _ws(fb, part.device), _ws(db, part.device)
                     _call("kagnn_kan_pack", _ptr(bwp), _ptr(swp), _ptr(scp), widths[i], fout, G, K, mode, _ptr(pack_f), _ptr(pack_d),
                           _stream())
-                gx = _kan_bwd_input_raw(part, gy, knots, pack_d, widths[i], fout, G, K, mode, x_affine=aff)
                 sk = ctx.skip_gradients[i] if ctx.skip_gradients is not None else None
-                if sk is not None and sk.consumer:         # the convolution that consumed this block adds it in its own backward
+                handed = sk is not None and sk.consumer    # the convolution that consumed this block adds it in its own backward
+                ns = None if (ctx.norm_stats is None or handed or aff is None) else ctx.norm_stats[i]
+                if (ns is not None and ns.mean is not None and _FOLD_NORM_STATS and part.data_ptr() % 16 == 0
+                        and getattr(_lib.load(), "kagnn_kan_bwd_input_sums_ok")(part.size(0), widths[i], fout, G, K, mode)):
+                    # this gradient goes STRAIGHT to the norm whose folded output the block is (the last convolution's): the
+                    # kernel also leaves the two column sums that norm's backward starts from (no statistics pass there)
+                    gx, sums = _kan_bwd_input_sums_raw(part, gy, knots, pack_d, widths[i], fout, G, K, mode, aff, ns)
+                    ns.park(sums, gx)
+                else:
+                    gx = _kan_bwd_input_raw(part, gy, knots, pack_d, widths[i], fout, G, K, mode, x_affine=aff)
+                if handed:
                     sk.park(gx)
                     gx = None
             gxs.append(gx)
@@ -1319,7 +1343,7 @@ class _KANLinearPartsFn(Function):
         gbw = torch.cat(gbws, dim=1) if want_w else None
         gsw = torch.cat(gsws, dim=1) if want_w else None
         gsc = torch.cat(gscs, dim=1) if want_w and sc is not None else None
-        return (gbw, gsw, gsc, None, None, None, None, None, None, *gxs)
+        return (gbw, gsw, gsc, None, None, None, None, None, None, None, *gxs)
 
 
 def parts_affine_ok(fout: int, grid_size: int, spline_order: int, parts, lazy) -> bool:
@@ -1350,8 +1374,9 @@ def kan_linear_parts(parts, base_weight, spline_weight, spline_scaler, knots, gr
             and (not any(lazy) or parts_affine_ok(spline_weight.size(0), int(grid_size), int(spline_order), raw, lazy))):
         sk = None if skip_gradients is None or not any(k is not None and k.consumer for k in skip_gradients) else tuple(skip_gradients)
         affines = tuple(t.affine if z else None for t, z in zip(parts, lazy)) if any(lazy) else None
+        stats = tuple(t.stats if z else None for t, z in zip(parts, lazy)) if any(lazy) else None
         return _KANLinearPartsFn.apply(base_weight, spline_weight, spline_scaler, knots, int(grid_size), int(spline_order), m, sk,
-                                       affines, *raw)
+                                       affines, stats, *raw)
     parts = [t.materialise() if z else t for t, z in zip(parts, lazy)]        # (blocks no kernel folds: write them out)
     y, f0 = None, 0
     for part in parts:
