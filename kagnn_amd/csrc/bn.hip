@@ -286,6 +286,26 @@ __global__ void bn_affine_kernel(const float* __restrict__ mean, const float* __
     affine[F + f] = fmaf(-mean[f], sc, beta ? beta[f] : 0.0f);
 }
 
+__global__ void bn_from_moments_affine_kernel(const float* __restrict__ col_mean, const float* __restrict__ col_m2, long N, int F,
+                                              float eps, float momentum, float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ affine) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float mean = col_mean[f], var = fmaxf(col_m2[f] / (float)N, 0.0f);
+    const float rstd = rsqrtf(var + eps);
+    save_mean[f] = mean;
+    save_rstd[f] = rstd;
+    if (running_mean) {
+        const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+        running_mean[f] = fmaf(momentum, mean - running_mean[f], running_mean[f]);
+        running_var[f] = fmaf(momentum, unb - running_var[f], running_var[f]);
+    }
+    const float sc = rstd * (gamma ? gamma[f] : 1.0f);
+    affine[f] = sc;
+    affine[F + f] = fmaf(-mean, sc, beta ? beta[f] : 0.0f);
+}
+
 // (count, mean, M2) of two disjoint row sets -> of their union (Chan et al.); b is folded into a
 __device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
     if (nb <= 0.0f) return;
@@ -385,9 +405,9 @@ int bn_fwd(const float* x, long ldx, long N, int F, const float* gamma, const fl
 int bn_stats_affine(const float* col_mean, const float* col_m2, long N, int F, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* save_mean, float* save_rstd,
                     float* affine, hipStream_t st) {
-    bn_from_moments_kernel<<<cdiv(F, 256), 256, 0, st>>>(col_mean, col_m2, N, F, eps, momentum, save_mean, save_rstd, running_mean, running_var);
-    KAGNN_LAUNCH_CHECK();
-    bn_affine_kernel<<<cdiv(F, 256), 256, 0, st>>>(save_mean, save_rstd, gamma, beta, F, affine);
+    // (one launch: the same expressions as bn_from_moments_kernel followed by bn_affine_kernel, on values still in registers)
+    bn_from_moments_affine_kernel<<<cdiv(F, 256), 256, 0, st>>>(col_mean, col_m2, N, F, eps, momentum, save_mean, save_rstd, running_mean,
+                                                                running_var, gamma, beta, affine);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -462,21 +482,27 @@ int bn_finish_partials(const float* partial, long B, int F, float* sums, hipStre
     return KAGNN_OK;
 }
 
-__global__ void bn_sums_out_kernel(const float* __restrict__ sums, int F, float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+// bn_bwd_table_kernel + the two gradient outputs in one launch (the sums are given: nothing else to do before the table)
+__global__ void bn_bwd_table_given_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                          const float* __restrict__ sums, long N, int F, float* __restrict__ tab, int ldt,
+                                          float* __restrict__ g_gamma, float* __restrict__ g_beta) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    if (g_beta) g_beta[f] = sums[f];
-    if (g_gamma) g_gamma[f] = sums[F + f];
+    if (f >= ldt) return;
+    float A = 0.0f, B = 0.0f, C = 0.0f, m = 0.0f;
+    if (f < F) {
+        const float sg = sums[f], sgx = sums[F + f];
+        m = mean[f];
+        bn_bwd_consts(rstd[f], gamma ? gamma[f] : 1.0f, sg, sgx, 1.0f / (float)N, A, B, C);
+        if (g_beta) g_beta[f] = sg;
+        if (g_gamma) g_gamma[f] = sgx;
+    }
+    tab[f] = m; tab[ldt + f] = A; tab[2 * ldt + f] = B; tab[3 * ldt + f] = C;
 }
 
 // bn_bwd_stats with the two column sums given (sums[0] = sum g, sums[1] = sum g * xhat) instead of a pass over g and x
 int bn_bwd_stats_given(const float* sums, long N, int F, const float* gamma, const float* save_mean, const float* save_rstd,
                        float* g_gamma, float* g_beta, float* tab, int ldt, hipStream_t st) {
-    if (g_gamma || g_beta) {
-        bn_sums_out_kernel<<<cdiv(F, 256), 256, 0, st>>>(sums, F, g_gamma, g_beta);
-        KAGNN_LAUNCH_CHECK();
-    }
-    bn_bwd_table_kernel<<<cdiv(ldt, 256), 256, 0, st>>>(save_mean, save_rstd, gamma, sums, sums + F, N, F, tab, ldt);
+    bn_bwd_table_given_kernel<<<cdiv(ldt, 256), 256, 0, st>>>(save_mean, save_rstd, gamma, sums, N, F, tab, ldt, g_gamma, g_beta);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
