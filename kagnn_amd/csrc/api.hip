@@ -107,13 +107,16 @@ using namespace kagnn;
 #include <string>
 #include <vector>
 namespace {
-struct StageRecord { const char* name; hipEvent_t a, b; };
+struct StageRecord { const char* name; hipEvent_t a, b; int dev; };
+constexpr int kStageMaxDevices = 64;
 struct StageTimer {
     std::mutex mu;
     bool on = false;
     std::string only;                       // empty: every stage
     std::vector<StageRecord> rec;
-    std::vector<hipEvent_t> pool;           // events of earlier sessions, reused
+    // events of earlier sessions, reused -- PER DEVICE: an event belongs to the device that was current when it was created, and
+    // recording it on another device's stream fails (the ignored error used to show up as 0 ms timings: ADVICE r04)
+    std::vector<hipEvent_t> pool[kStageMaxDevices];
 } g_stage;
 thread_local int g_stage_depth = 0;         // nested entry points (fwd_moments -> fwd): only the outermost is a stage
 constexpr size_t kStageMaxRecords = 1u << 16;
@@ -127,14 +130,21 @@ struct StageScope {
         if (!outer || !g_stage.on) return;              // (unlocked read of a flag that only bench.py toggles, between steps)
         std::lock_guard<std::mutex> lk(g_stage.mu);
         if (!g_stage.on || (!g_stage.only.empty() && g_stage.only != nm) || g_stage.rec.size() >= kStageMaxRecords) return;
-        hipEvent_t ev[2];
-        for (auto& e : ev) {
-            if (!g_stage.pool.empty()) { e = g_stage.pool.back(); g_stage.pool.pop_back(); }
-            else if (hipEventCreate(&e) != hipSuccess) return;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kStageMaxDevices) return;
+        std::vector<hipEvent_t>& pool = g_stage.pool[dev];
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        for (int i = 0; i < 2; ++i) {
+            if (!pool.empty()) { ev[i] = pool.back(); pool.pop_back(); }
+            else if (hipEventCreate(&ev[i]) != hipSuccess) {
+                (void)hipGetLastError();
+                if (i == 1) pool.push_back(ev[0]);      // a partial failure must not leak the first event
+                return;
+            }
         }
         (void)hipEventRecord(ev[0], st);
         b = ev[1];
-        g_stage.rec.push_back(StageRecord{nm, ev[0], ev[1]});
+        g_stage.rec.push_back(StageRecord{nm, ev[0], ev[1], dev});
     }
     ~StageScope() {
         --g_stage_depth;
@@ -192,6 +202,8 @@ int kagnn_stage_timer_collect(char* names, int64_t* launches, double* total_ms, 
             (void)hipGetLastError();
             ms = 0.0f;
         }
+        g_stage.pool[r.dev].push_back(r.a);             // (before any `continue`: a record beyond `capacity` used to leak its events)
+        g_stage.pool[r.dev].push_back(r.b);
         int k = 0;
         while (k < n && strncmp(names + 64 * k, r.name, 63) != 0) ++k;
         if (k == n) {
@@ -203,8 +215,6 @@ int kagnn_stage_timer_collect(char* names, int64_t* launches, double* total_ms, 
         }
         launches[k] += 1;
         total_ms[k] += ms;
-        g_stage.pool.push_back(r.a);
-        g_stage.pool.push_back(r.b);
     }
     g_stage.rec.clear();
     *n_stages = n;

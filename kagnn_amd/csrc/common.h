@@ -29,6 +29,17 @@ inline int fail(int code, const char* fmt, const char* a = "", long b = 0, long 
     } while (0)
 #define KAGNN_LAUNCH_CHECK() KAGNN_HIP(hipGetLastError())
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a process-wide "configured" flag leaves the kernel
+// at the 64 KB default on the second GPU a process drives and its launch fails there.  One bit per device ordinal;
+// true the first time the calling thread's current device (the one the launch goes to) meets this call site.
+inline bool first_use_on_this_device(unsigned long long& seen) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;      // unknown: configure again (idempotent)
+    const unsigned long long bit = 1ull << d;
+    const unsigned long long before = __atomic_fetch_or(&seen, bit, __ATOMIC_RELAXED);
+    return !(before & bit);
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -799,10 +799,9 @@ static int launch_sparse(const float* x, long ldx, long N, int in, const float* 
                          const unsigned char* pack, float* y, long ldy, int out, float* ws, size_t ws_bytes,
                          float* col_mean, float* col_m2, hipStream_t st) {
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT) + (MOM ? 8 * OT * 64 * sizeof(float) : 0);
-    static bool configured = false;
-    if (!configured) {
+    static unsigned long long configured = 0;          // (per device: common.h)
+    if (first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH, MOM, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
     }
     const int nchunks = cdiv(in << (SH ? 1 : 0), kSpCF);
     const int gx = sp_grid(N);
@@ -864,10 +863,9 @@ template <int OT, int AGG>
 static int launch_sparse_agg(const float* x, long ldx, long N, int in, const float* knots, int nknots, const unsigned char* pack,
                              float* y, long ldy, int out, const SpAgg& ag, hipStream_t st) {
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
-    static bool configured = false;
-    if (!configured) {
+    static unsigned long long configured = 0;          // (per device: common.h)
+    if (first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, false, false, true, AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
     }
     kan_sparse_fwd_kernel<OT, false, false, true, AGG><<<sp_grid(N), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, 1, y, ldy, out, 1, 0L,
                                                                                       nullptr, ag, SpParts{});
@@ -959,10 +957,9 @@ template <int OT>
 static int launch_sparse_parts(const SpParts& xp, long N, int in, const float* knots, int nknots, const unsigned char* pack,
                                float* y, long ldy, int out, float* ws, size_t ws_bytes, hipStream_t st) {
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
-    static bool configured = false;
-    if (!configured) {
+    static unsigned long long configured = 0;          // (per device: common.h)
+    if (first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, false, false, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
     }
     const int nchunks = in / kSpCF, gx = sp_grid(N);
     const SpSplit p = sp_split_plan(N, nchunks);

@@ -436,11 +436,10 @@ static int launch_fwd(const float* x, long ldx, long N, int in, const float* kno
                       const unsigned char* pack, int nchunks, float* y, long ldy, int out, const RbfArgs& rb,
                       int sh, float* ws, size_t ws_bytes, hipStream_t st) {
     const size_t lds = kLdsHdr + split_fwd_chunk_bytes(OT);
-    static bool configured = false;
-    if (!configured) {
+    static unsigned long long configured = 0;          // (per device: common.h)
+    if (first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT, NT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
     }
     const int gx = (int)min((long)cdiv(N, NT / 2), 256L);
     const FwdSplit p = fwd_split_plan(N, nchunks, NT / 2);

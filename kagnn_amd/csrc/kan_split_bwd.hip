@@ -513,11 +513,10 @@ static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, lo
     if (XST && !(resident && splits == 1 && in <= 64 && (size_t)fpb * ft_bytes + 8 * 128 * sizeof(float) <= budget))
         return fail(KAGNN_ERR_UNSUPPORTED, "%s: column statistics need <= 64 input features, resident weights and >= 32768 rows", "kan_split_dx");
     const size_t lds = kLdsHdr + (resident ? fpb : 1) * ft_bytes + (XST ? 8 * 128 * sizeof(float) : 0);
-    static bool configured = false;
-    if (!configured) {
+    static unsigned long long configured = 0;          // (per device: common.h)
+    if (first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF, XST>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        configured = true;
     }
     const dim3 grid((unsigned)min(row_blocks, 256L), (unsigned)splits);
     kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF, XST><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
@@ -764,10 +763,9 @@ template <int Q2, int NS1>
 static int launch_dx_w2(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                         const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx, hipStream_t st) {
     const size_t lds = kLdsHdr + (size_t)kCTmax * Q2 * 2 * 1024;
-    static bool configured = false;
-    if (!configured) {
+    static unsigned long long configured = 0;          // (per device: common.h)
+    if (first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_w2_kernel<Q2, NS1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        configured = true;
     }
     kan_split_dx_w2_kernel<Q2, NS1><<<(unsigned)min((long)cdiv(N, 256), 256L), 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots,
                                                                                         pack, gx, ldgx);
@@ -1817,8 +1815,9 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
     if (dw_shared && !rb.x_affine && !sh && (K == 0 || K == 3) && p.rs == 1 && p.OC >= 2 && p.OC % 2 == 0 && in > 32) {
         const int SHn = p.OC % 4 == 0 ? 4 : 2;
 #define LS(KK, SS) do { \
-            static const hipError_t attr_##KK##_##SS = hipFuncSetAttribute((const void*)kan_split_dw_shared_kernel<KK, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwShLds); \
-            KAGNN_HIP(attr_##KK##_##SS); \
+            static unsigned long long seen_##KK##_##SS = 0; \
+            if (first_use_on_this_device(seen_##KK##_##SS)) \
+                KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dw_shared_kernel<KK, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwShLds)); \
             kan_split_dw_shared_kernel<KK, SS><<<grid, 256, kDwShLds, st>>>(x, ldx, gy, ldgy, N, in, out, Ck, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb); } while (0)
         if (K == 0) { if (SHn == 4) LS(0, 4); else LS(0, 2); }
         else        { if (SHn == 4) LS(3, 4); else LS(3, 2); }

@@ -302,11 +302,10 @@ int xent_fwd(const float* z, long ld, long N, int C, const long* y, const unsign
     } else
     if (C <= 64 && N > 0) {
         nb = (int)min((long)cdiv(N, 256), 4096L);
-        static bool big_lds = false;                       // 256 rows x 65 floats is just over the 64 KB default
-        if (!big_lds) {
+        static unsigned long long big_lds = 0;                     // 256 rows x 65 floats is just over the 64 KB default
+        if (first_use_on_this_device(big_lds)) {
             KAGNN_HIP(hipFuncSetAttribute((const void*)xent_fwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
             KAGNN_HIP(hipFuncSetAttribute((const void*)xent_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
-            big_lds = true;
         }
         xent_fwd_rows_kernel<<<nb, 256, (size_t)256 * (C | 1) * sizeof(float), st>>>(z, ld, N, C, y, mask, pre, stats, partial);
     } else

@@ -785,23 +785,26 @@ class NormSums:
     ``rstd``; the CONSUMING node (layer l+1) gets it with the ``AffineRows``, parks ``sums`` for the gradient tensor it returns;
     layer l's backward takes them only if the gradient it receives IS that tensor (same storage, same engine run) -- any other
     consumer of the activation makes autograd sum into a new tensor and the statistics pass runs as before."""
-    __slots__ = ("mean", "rstd", "sums", "grad", "task")
+    __slots__ = ("mean", "rstd", "sums", "grad", "task", "version")
 
     def __init__(self):
         self.mean = self.rstd = self.sums = self.grad = None
-        self.task = -1
+        self.task = self.version = -1
 
     def park(self, sums: torch.Tensor, grad: torch.Tensor) -> None:
-        self.sums, self.grad, self.task = sums, grad, graph_task_id()      # (holding ``grad`` keeps its storage from being reused)
+        # (holding ``grad`` keeps its storage from being reused; its version counter is recorded so that an engine that
+        # accumulated another consumer's gradient INTO it in place -- same storage, new contents -- is noticed: ADVICE r04)
+        self.sums, self.grad, self.task, self.version = sums, grad, graph_task_id(), grad._version
 
     def take(self, grad: torch.Tensor):
-        sums, parked, t = self.sums, self.grad, self.task
+        sums, parked, t, ver = self.sums, self.grad, self.task, self.version
         self.sums = self.grad = None
-        self.task = -1
+        self.task = self.version = -1
         if sums is None or t != graph_task_id() or parked is None:
             return None
         same = (parked.data_ptr() == grad.data_ptr() and parked.shape == grad.shape and parked.stride() == grad.stride()
-                and parked.dtype == grad.dtype and parked.device == grad.device)
+                and parked.dtype == grad.dtype and parked.device == grad.device
+                and parked._version == ver and grad._version == ver)
         return sums if same else None
 
 

@@ -83,5 +83,6 @@ def pytest_sessionfinish(session, exitstatus):
     try:
         import helpers
         helpers.dump_error_log(os.path.join(ROOT, "gpurun_out", "parity_errors.json"))
+        helpers.dump_soft_failures(os.path.join(ROOT, "gpurun_out", "parity_soft_failures.json"))
     except Exception:  # pragma: no cover
         pass

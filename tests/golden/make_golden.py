@@ -83,7 +83,10 @@ def g1():
 def g2():
     out = {}
     shapes = [(64, 64, 5, 3), (128, 32, 5, 3), (48, 40, 8, 3), (7, 5, 1, 1), (3, 2, 2, 1),
-              (16, 16, 8, 4), (33, 17, 4, 3), (40, 24, 3, 2)]
+              (16, 16, 8, 4), (33, 17, 4, 3), (40, 24, 3, 2),
+              # the shapes SURVEY.md 8(c) names (appended: the earlier cases keep their seeds): the 128-wide two-chunk input and
+              # the two-window C = 11 layer at width 128 (config 3's KANLinear) meet reference-made vectors
+              (128, 64, 5, 3), (128, 128, 8, 3)]
     for i, (fi, fo, G, k) in enumerate(shapes):
         torch.manual_seed(100 + i)
         layer = ref_ekan.KANLinear(fi, fo, grid_size=G, spline_order=k)
@@ -109,7 +112,8 @@ def g2():
 # ---------------------------------------------------------------- G3: KAN chains
 def g3():
     out = {}
-    for i, (sizes, G, k) in enumerate([([128, 32, 32], 5, 3), ([64, 64, 64], 5, 3), ([10, 6, 3], 4, 3)]):
+    for i, (sizes, G, k) in enumerate([([128, 32, 32], 5, 3), ([64, 64, 64], 5, 3), ([10, 6, 3], 4, 3),
+                                       ([128, 64, 64], 5, 3), ([128, 128, 128], 8, 3)]):
         torch.manual_seed(300 + i)
         net = ref_ekan.KAN(sizes, grid_size=G, spline_order=k)
         gen = torch.Generator().manual_seed(310 + i)

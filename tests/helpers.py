@@ -1,12 +1,20 @@
 """Shared helpers of the parity tests: tolerances, state loading, oracle drivers.
 
 Tolerances.  BASELINE.json's contract is "within 1e-4 fp32" (``CONTRACT``).  The tests pin an order of magnitude
-tighter: ``TOL`` = 2e-5 relative to ``max(1, max|reference|)`` for every element -- about 10x the error both
-precision modes actually show on the layer-level cases (``profiles/r02_parity_errors.json``), so a regression of the
-fp16 hi/lo split path (a dropped product, a wrong scale exponent: >= 2^-11) cannot hide behind the contract figure.
-On top of the max-norm bound every element at or above ``REL_FLOOR`` x scale must agree to ``CONTRACT`` RELATIVE to
-its own magnitude.  Tests that need more room (errors compounded through BatchNorm / several layers / Adam) pass an
-explicit ``tol`` and say why.
+tighter: ``TOL`` = 2e-5 relative to the tensor's OWN magnitude ``max|reference|`` for every element -- about 10x the
+error both precision modes actually show on the layer-level cases (``profiles/r02_parity_errors.json``), so a regression
+of the fp16 hi/lo split path (a dropped product, a wrong scale exponent: >= 2^-11) cannot hide behind the contract
+figure.  Round 5: the scale used to be ``max(1, max|reference|)``, which made the bound ABSOLUTE for
+small tensors -- with a mean-type loss gradient (``gout / n``) the arxiv-shaped model tests accepted all-zero input
+gradients.  The scale is now the reference tensor's own maximum, floored only by an explicit ``noise`` estimate the
+caller passes and justifies (the rounding noise of a cancelling fp32 sum: ``eps32 x sum|terms|``); an all-zero reference
+without a noise estimate must be matched exactly.  ``tests/test_gpu_models.py`` holds the mutation guards (zeroed and
+1e-3-perturbed gradients MUST fail).  On top of the max-norm bound every element at or above ``REL_FLOOR`` x scale must
+agree to ``CONTRACT`` RELATIVE to its own magnitude.  Tests that need more room (errors compounded through BatchNorm /
+several layers / Adam) pass an explicit ``tol`` and say why.
+
+``KAGNN_TEST_SOFT=1`` (a survey aid, never the driver's mode): violations are recorded in ``SOFT_FAILURES`` and written to
+``gpurun_out/parity_soft_failures.json`` instead of raised, so ONE run of the suite lists every check a rule change moves.
 """
 import json
 import os
@@ -31,7 +39,26 @@ def T(a, device=None):
     return t if device is None else t.to(device)
 
 
-def assert_close(got, want, tol=TOL, what="", elementwise=True):
+SOFT = os.environ.get("KAGNN_TEST_SOFT", "0") == "1"
+SOFT_FAILURES = []
+
+
+def _fail(what, msg, **info):
+    if SOFT:
+        SOFT_FAILURES.append(dict(what=what, msg=msg, **info))
+        return
+    raise AssertionError(msg)
+
+
+def check(cond, what, info=None):
+    """a plain assertion that KAGNN_TEST_SOFT=1 records instead of raising (for checks that do not go through assert_close)"""
+    if not cond:
+        _fail(what, f"{what}: {info}", info=repr(info))
+
+
+def assert_close(got, want, tol=TOL, what="", elementwise=True, noise=0.0):
+    """max-norm: ``max|got - want| <= tol * max(max|want|, noise)``; element-wise: see the module docstring.  ``noise`` is an
+    ABSOLUTE magnitude below which the reference itself is rounding noise (state where it comes from at the call site)."""
     got = got.detach().double().cpu()
     want = T(want).double() if not torch.is_tensor(want) else want.detach().double().cpu()
     assert got.shape == want.shape, (what, got.shape, want.shape)
@@ -39,16 +66,52 @@ def assert_close(got, want, tol=TOL, what="", elementwise=True):
     if not want.numel():
         return 0.0
     g, w = torch.nan_to_num(got), torch.nan_to_num(want)
-    scale = max(1.0, float(w.abs().max()))
+    own = float(w.abs().max())
+    scale = max(own, float(noise))
     diff = (g - w).abs()
     err = float(diff.max())
+    if scale == 0.0:                       # an identically zero reference and no noise estimate: exact match
+        ERROR_LOG.append((what, 0.0 if err == 0.0 else float("inf"), tol))
+        if err != 0.0:
+            _fail(what, f"{what}: reference is identically zero, got max |value| {err:.3e}", err=err, scale=0.0, tol=tol)
+        return 0.0
     ERROR_LOG.append((what, err / scale, tol))
-    assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.0e} * {scale:.3g}"
+    if err > tol * scale:
+        _fail(what, f"{what}: max abs err {err:.3e} > {tol:.0e} * {scale:.3g}", err=err, scale=scale, tol=tol,
+              old_rule_ok=bool(err <= tol * max(1.0, own)))
     big = w.abs() >= REL_FLOOR * scale
     if elementwise and bool(big.any()):
         rel = float((diff[big] / w.abs()[big]).max())
-        assert rel <= max(CONTRACT, 5 * tol), f"{what}: element-wise relative error {rel:.3e} on a large element"
+        if rel > max(CONTRACT, 5 * tol):
+            _fail(what, f"{what}: element-wise relative error {rel:.3e} on a large element", rel=rel, scale=scale, tol=tol)
     return err / scale
+
+
+def must_fail(got, want, tol=TOL, what="", **kw):
+    """mutation guard: the SAME assertion the test just passed has to reject this ``got`` (with the old
+    ``max(1, .)`` scale an all-zero input gradient passed the arxiv-shaped model tests)"""
+    if SOFT:
+        before = len(SOFT_FAILURES)
+        assert_close(got, want, tol, what=what + " [mutant]", **kw)
+        caught = len(SOFT_FAILURES) > before
+        del SOFT_FAILURES[before:]
+    else:
+        try:
+            assert_close(got, want, tol, what=what + " [mutant]", **kw)
+            caught = False
+        except AssertionError:
+            caught = True
+    while ERROR_LOG and ERROR_LOG[-1][0].endswith("[mutant]"):
+        ERROR_LOG.pop()
+    assert caught, f"{what}: the check accepted a mutated tensor -- it cannot fail"
+
+
+def dump_soft_failures(path):
+    if not SOFT:
+        return
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump(SOFT_FAILURES, f, indent=1)
 
 
 def dump_error_log(path):
@@ -61,7 +124,8 @@ def dump_error_log(path):
             worst[key] = (err, tol)
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
-        json.dump({"n_checks": len(ERROR_LOG), "max_ratio_to_tol": max(e / t for _, e, t in ERROR_LOG if t > 0),
+        json.dump({"n_checks": len(ERROR_LOG), "scale_rule": "max|reference| of the tensor itself, floored only by an explicit noise estimate",
+                   "max_ratio_to_tol": max(e / t for _, e, t in ERROR_LOG if t > 0),
                    "worst_per_label": {k: {"err": v[0], "tol": v[1]} for k, v in sorted(worst.items(), key=lambda kv: -kv[1][0])[:200]}},
                   f, indent=1)
 

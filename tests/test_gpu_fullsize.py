@@ -100,6 +100,101 @@ def test_fullsize_kanlinear_samples_and_linearity(big, mode):
     assert_close(a_b + b_b, full_b, 2e-5, what="dWb additivity")
 
 
+def _oracle_chain_rows(h0_rows, gy_rows, layers):
+    """fp64 oracle of the KAN chain on a set of rows: y, d/dh0 and the parameter gradients those rows contribute"""
+    h = h0_rows.double().requires_grad_(True)
+    ps = [{k: (v.double().requires_grad_(True) if k != "grid" else v.double()) for k, v in p.items()} for p in layers]
+    t = h
+    for p in ps:
+        t = orc.kan_linear_forward(t, p["base_weight"], p["spline_weight"], p["spline_scaler"], p["grid"], 3)
+    t.backward(gy_rows.double())
+    return t.detach(), h.grad, [{k: p[k].grad for k in ("base_weight", "spline_weight", "spline_scaler")} for p in ps]
+
+
+def test_fullsize_one_call_gin_layer_backward_vs_oracle(big):
+    """THE TIMED PATH's backward at the metric's size: GIKANLayer(64 -> 64, grid 5, 2 KANLinears) on the
+    1M / 10M graph through ``kagnn_gin_kan_layer_fwd / _bwd`` (one library call each way -- what bench.py times).
+    (A) upstream gradient non-zero on a 4 096-row sample: y on the sample, EVERY parameter gradient (exact: the other rows
+        contribute zero) and the whole input gradient (rows reached from the sample against the fp64 oracle, bit-zero elsewhere);
+        the oracle's chain is fed the device's own h0 rows, its transposed aggregation runs over the edges into the sample.
+    (B) dense upstream gradient: gx on sampled SOURCE rows (needs d/dh0 at every out-neighbour: the oracle chain runs on
+        those rows), and additivity of the parameter gradients over a row partition of gy through the same entry points."""
+    ei, x, gi = big
+    gen = torch.Generator().manual_seed(41)
+    torch.manual_seed(41)
+    conv = kagnn_amd.GIKANLayer(F, F, grid_size=5, spline_order=3, hidden_dim=F, nb_layers=2)
+    layers = [{k: v.detach().clone() for k, v in l.state_dict().items()} for l in conv.nn.layers]
+    conv = conv.to(DEV)
+    xd = x.to(DEV)
+    h0 = ops.aggregate_sum(xd, gi, self_scale=1.0)            # (checked against the oracle in the aggregation test above)
+    src, dst = ei[0], ei[1]
+    deg = torch.bincount(dst, minlength=N)
+
+    def run(gy_dev):
+        conv.zero_grad()
+        xr = xd.detach().requires_grad_(True)
+        timer = ops.EntryPointTimer()
+        ops.set_timer(timer)
+        try:
+            y = conv(xr, gi)
+            y.backward(gy_dev)
+        finally:
+            ops.set_timer(None)
+        names = {r[0] for r in timer.records}
+        assert {"kagnn_gin_kan_layer_fwd", "kagnn_gin_kan_layer_bwd"} <= names, names       # the one-call path ran
+        return y.detach(), xr.grad, [{k: getattr(l, k).grad.clone() for k in ("base_weight", "spline_weight", "spline_scaler")}
+                                     for l in conv.nn.layers]
+
+    # ---- (A) sparse upstream gradient
+    rows = torch.unique(torch.cat([torch.randint(0, N, (4096,), generator=gen), deg.argmax().view(1),
+                                   (deg == 0).nonzero()[:3].view(-1)]))
+    gy = torch.zeros(N, F)
+    gy[rows] = torch.randn(rows.numel(), F, generator=gen)
+    y, gx, g = run(gy.to(DEV))
+    y64, gh0, g64 = _oracle_chain_rows(h0[rows.to(DEV)].cpu(), gy[rows], layers)
+    assert_close(y.cpu()[rows], y64, what="fullsize layer y rows")
+    for li in range(2):
+        for k in ("base_weight", "spline_weight", "spline_scaler"):
+            assert_close(g[li][k], g64[li][k], what=f"fullsize layer L{li}.{k}")
+    slot = torch.full((N,), -1, dtype=torch.long)
+    slot[rows] = torch.arange(rows.numel())
+    into = slot[dst] >= 0                                         # edges whose destination carries a gradient
+    want = torch.zeros(N, F, dtype=torch.float64)
+    want[rows] = gh0                                              # self term, (1 + eps) = 1
+    want.index_add_(0, src[into], gh0[slot[dst[into]]])
+    touched = torch.zeros(N, dtype=torch.bool)
+    touched[rows] = True
+    touched[src[into]] = True
+    gxc = gx.cpu()
+    assert_close(gxc[touched], want[touched], what="fullsize layer gx (rows reached from the sample)")
+    assert float(gxc[~touched].abs().max()) == 0.0               # nothing leaks to unreachable rows
+    del want, gxc
+
+    # ---- (B) dense upstream gradient
+    gyd = torch.randn(N, F, generator=gen)
+    y, gx, g_full = run(gyd.to(DEV))
+    js = torch.unique(torch.cat([torch.randint(0, N, (400,), generator=gen), deg.argmax().view(1)]))
+    jmask = torch.zeros(N, dtype=torch.bool); jmask[js] = True
+    out_e = jmask[src]                                            # edges leaving the sampled sources
+    need = torch.unique(torch.cat([js, dst[out_e]]))
+    slot = torch.full((N,), -1, dtype=torch.long)
+    slot[need] = torch.arange(need.numel())
+    _, gh0, _ = _oracle_chain_rows(h0[need.to(DEV)].cpu(), gyd[need], layers)
+    want = torch.zeros(N, F, dtype=torch.float64)
+    want[js] = gh0[slot[js]]
+    want.index_add_(0, src[out_e], gh0[slot[dst[out_e]]])
+    assert_close(gx.cpu()[js], want[js], what="fullsize layer gx on sampled source rows (dense gy)")
+    half = N // 2 + 29
+    ga = gyd.clone(); ga[half:] = 0
+    gb = gyd.clone(); gb[:half] = 0
+    _, gxa, g_a = run(ga.to(DEV))
+    _, gxb, g_b = run(gb.to(DEV))
+    for li in range(2):
+        for k in ("base_weight", "spline_weight", "spline_scaler"):
+            assert_close(g_a[li][k] + g_b[li][k], g_full[li][k], 2e-5, what=f"fullsize layer L{li}.{k} additivity")
+    assert_close(gxa + gxb, gx, 2e-5, what="fullsize layer gx linearity in gy", elementwise=False)
+
+
 def test_two_feature_shards_sum_to_the_full_layer():
     """the per-rank pieces of kagnn_amd.sharded on ONE GPU: partial sums over input-feature shards
     (strided column views, narrow in_features) add up to the unsharded layer, fwd and bwd."""

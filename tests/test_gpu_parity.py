@@ -160,7 +160,7 @@ def test_kanlinear_golden_fwd_bwd(golden, mode):
         assert_close(layer.spline_weight.grad, z[f"{tag}.g_spline_weight"], what=tag + ".g_spline_weight")
         assert_close(layer.spline_scaler.grad, z[f"{tag}.g_spline_scaler"], what=tag + ".g_spline_scaler")
         i += 1
-    assert i == 8
+    assert i == 10
 
 
 @pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
@@ -185,7 +185,7 @@ def test_kan_chain_golden(golden, mode):
         for name, p in net.named_parameters():
             assert_close(p.grad, z[f"{tag}.grad.{name}"], what=f"{tag}.grad.{name}")
         i += 1
-    assert i == 3
+    assert i == 5
 
 
 @pytest.mark.parametrize("mode", MODES, ids=MODE_IDS)
@@ -553,10 +553,16 @@ def test_zinc_shaped_batch_regression_models_golden(golden, kind, mode, monkeypa
     # KAN flavour 1e-6 in both modes and 7e-6 for the reference; FastKAN flavour exact-fp32 mode 5e-6, split mode 1.6e-3,
     # the reference's own fp32 run 1.6e-3).  A gradient may be off by 1e-4, or by twice what the reference itself is off.
     checked = 0
+    gmax = max(float(st[name].grad.abs().max()) for name, p_ in m.named_parameters() if p_.requires_grad and st[name].grad is not None)
     for name, p_ in m.named_parameters():
         if p_.requires_grad and st[name].grad is not None:
             g, w64, w32 = p_.grad.double().cpu(), st[name].grad, T(z[f"{kind}.grad.{name}"]).double()
-            scale = max(1.0, float(w64.abs().max()))
+            scale = float(w64.abs().max())            # the gradient's own magnitude (round 5: was max(1, .))
+            if scale <= 1e-12 * gmax:
+                # a bias in front of a training-mode BatchNorm: identically zero gradient; fp32 (here and in the reference's
+                # fixture) holds the rounding noise of a cancelling sum over the batch's rows -- bound the noise
+                assert float(g.abs().max()) <= 1e-5 * gmax, (name, float(g.abs().max()), gmax)
+                continue
             e64, eref = float((g - w64).abs().max()) / scale, float((w32 - w64).abs().max()) / scale
             assert e64 <= max(1e-4, 2.0 * eref), f"zinc {kind} grad.{name}: {e64:.2e} from the fp64 oracle (the reference's fp32 gradient: {eref:.2e})"
             checked += 1

@@ -276,3 +276,45 @@ def test_hot_path_kernels_do_not_spill_registers():
     assert not bad, "hot-path kernels spill registers: " + "; ".join(f"{r[0]}: {r[1]} VGPRs / {r[2]} B" for r in bad)
     # one wave per SIMD is the floor: nothing may need more than the 512-entry file
     assert all(k["vgpr_count"] <= 512 for k in rows)
+
+
+def test_assert_close_scales_by_the_reference_itself_and_can_fail():
+    """tests/helpers.assert_close (round 5): the bound is relative to max|reference| of the tensor, so small
+    tensors are held to the same RELATIVE accuracy as large ones; zeros and 1e-3 perturbations are rejected whatever the
+    magnitude; an all-zero reference must be matched exactly unless the caller supplies a noise estimate."""
+    import helpers
+    if helpers.SOFT:
+        pytest.skip("KAGNN_TEST_SOFT=1 records instead of raising")
+    g = torch.Generator().manual_seed(0)
+    for mag in (1e-6, 1e-3, 1.0, 1e4):
+        w = torch.randn(100, 7, generator=g, dtype=torch.float64) * mag
+        helpers.assert_close(w * (1 + 1e-6), w, 2e-5, what="tiny perturbation")
+        helpers.must_fail(torch.zeros_like(w), w, 2e-5, what=f"zeros at magnitude {mag}")
+        helpers.must_fail(w * (1 + 1e-3), w, 1e-4, what=f"1e-3 perturbation at magnitude {mag}")
+        helpers.assert_close(w + 1e-3 * mag, w, 2e-5, what="inside an explicit noise floor", noise=100 * mag, elementwise=False)
+    z = torch.zeros(5)
+    helpers.assert_close(z, z, what="exact zeros")
+    helpers.must_fail(z + 1e-30, z, what="zero reference, no noise estimate")
+    helpers.assert_close(z + 1e-9, z, 1e-4, what="zero reference with a noise estimate", noise=1e-4)
+
+
+def test_norm_sums_side_channel_drops_sums_when_the_parked_gradient_was_accumulated_into_in_place():
+    """ops.NormSums: the parked column sums describe the gradient tensor AS IT WAS when the next layer's aggregation
+    wrote it.  Identity of storage is not enough -- an engine that accumulates a second consumer's gradient into the same tensor
+    in place keeps data_ptr / shape / stride and changes the contents; the version counter tells.  A second consumer's gradient
+    arriving BEFORE the park (the parked tensor already carries it: sums valid) and AFTER it (stale sums: dropped)."""
+    from kagnn_amd import ops
+    sums = torch.ones(2, 4)
+    g = torch.zeros(8, 4)
+    g.add_(1.0)                                   # another consumer's gradient, accumulated BEFORE the aggregation parked its sums
+    ns = ops.NormSums()
+    ns.park(sums, g)
+    assert ns.take(g) is sums                     # untouched since the park: the sums describe it
+    assert ns.take(g) is None                     # (taken once)
+    ns.park(sums, g)
+    g.add_(1.0)                                   # ... and AFTER: same storage, new contents
+    assert ns.take(g) is None
+    ns.park(sums, g)
+    assert ns.take(g.clone()) is None             # a new tensor (what autograd's out-of-place accumulation produces)
+    ns.park(sums, g)
+    assert ns.take(g.view(8, 4)) is sums          # an alias of the unmodified tensor is still that gradient

@@ -12,7 +12,7 @@ T = lambda a: torch.from_numpy(np.asarray(a))
 
 def close(a, b, tol=1e-6):
     a, b = T(a).double(), T(b).double()
-    scale = max(1.0, float(b.abs().max()))
+    scale = max(1e-300, float(b.abs().max()))
     assert a.shape == b.shape
     assert float((a - b).abs().max()) <= tol * scale, float((a - b).abs().max())
 
@@ -49,7 +49,7 @@ def test_g2_kanlinear_fwd_bwd(golden):
         close(ps["spline_weight"].grad, z[f"{tag}.g_spline_weight"])
         close(ps["spline_scaler"].grad, z[f"{tag}.g_spline_scaler"])
         i += 1
-    assert i == 8
+    assert i == 10
 
 
 def test_g3_kan_chain(golden):
@@ -75,7 +75,7 @@ def test_g3_kan_chain(golden):
             for n in ("base_weight", "spline_weight", "spline_scaler"):
                 close(L[n].grad, z[f"{tag}.grad.layers.{li}.{n}"], 2e-6)
         i += 1
-    assert i == 3
+    assert i == 5
 
 
 FK_KEYS = ("layernorm.weight", "layernorm.bias", "rbf.grid", "spline_linear.weight",
@@ -319,9 +319,19 @@ def test_g8b_zinc_batch_whole_model_restatement(golden, kind):
     pred64 = orc.graph_regression_forward(x, ei, ea, batch, 256, st, kind, 3)
     close(pred64.detach(), z[f"{kind}.pred"], 5e-5)
     (pred64.squeeze() - y.double()).abs().mean().backward()
-    checked = 0
-    for k in z.files:
-        if k.startswith(f"{kind}.grad."):
-            close(st[k[len(kind) + 6:]].grad, z[k], 5e-3)
-            checked += 1
-    assert checked >= 20
+    checked = zero = 0
+    names = [k for k in z.files if k.startswith(f"{kind}.grad.")]
+    gmax = max(float(st[k[len(kind) + 6:]].grad.abs().max()) for k in names)
+    for k in names:
+        g64 = st[k[len(kind) + 6:]].grad
+        if float(g64.abs().max()) <= 1e-12 * gmax:
+            # a bias in front of a training-mode BatchNorm: the gradient is IDENTICALLY zero (the batch mean is subtracted), fp64
+            # leaves 1e-17, and what the reference's fp32 run stored is the rounding noise of a cancelling sum over 5 932 rows --
+            # bound the noise (1e-5 of the model's largest gradient) instead of comparing it with zero (round 5: `close` scales
+            # by the reference's own maximum, so this case no longer hides behind max(1, .))
+            assert float(np.abs(z[k]).max()) <= 1e-5 * gmax, k
+            zero += 1
+            continue
+        close(g64, z[k], 5e-3)
+        checked += 1
+    assert checked >= 20 and zero <= 4, (checked, zero)

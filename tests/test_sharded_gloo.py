@@ -1,4 +1,4 @@
-"""world_size-2 gloo test (CPU) of the feature-sharded layer's communication logic.
+"""world_size-2 / -4 / -8 gloo tests (CPU) of the feature-sharded layer's communication logic.
 
 The local compute is INJECTED here (oracle ops, differentiable through stock autograd) -- the product
 default is the HIP library; what is under test is the sharding / all-reduce / all-gather algebra:
@@ -29,7 +29,10 @@ class OracleOps:
         return orc.kan_linear_forward(x, bw, sw, sc, knots.expand(x.size(1), -1), K)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, f=8, hid=12, grid=5, full=True):
+    """``f`` / ``hid`` / ``grid``: layer widths and grid size -- world 8 at 64 / 64 / 5 and 128 / 128 / 8 gives every rank the 8 and 16
+    columns of the headline's and config 3's P = 8 shards (the narrow instantiations' shapes; SURVEY 8(e), BASELINE config 3);
+    ``full``: also the regression sections that do not depend on the world size (run at world 2 only)."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -39,16 +42,17 @@ def _worker(rank, world, port, out_dir):
         import kagnn_amd
         from kagnn_amd.sharded import ShardedGIKANLayer
         from oracle import kan_oracle as orc
-        n, e, f, hid = 400, 3000, 8, 12
+        n, e = 400, 3000
         ei = orc.powerlaw_graph(n, e, seed=11)
         gen = torch.Generator().manual_seed(11)
         x = torch.randn(n, f, generator=gen) * 0.3
         gy = torch.randn(n, f, generator=gen)
         torch.manual_seed(5)                                  # same full module on every rank
-        conv = kagnn_amd.GIKANLayer(f, f, grid_size=5, spline_order=3, hidden_dim=hid, nb_layers=2)
+        conv = kagnn_amd.GIKANLayer(f, f, grid_size=grid, spline_order=3, hidden_dim=hid, nb_layers=2)
         layers = [{k: v.detach().clone() for k, v in l.state_dict().items()} for l in conv.nn.layers]
         y_ref, gx_ref, g_ref = orc.kan_gin_layer_fwd_bwd(x, ei, layers, 3, gy)
 
+        assert f % world == 0 and hid % world == 0
         w = f // world
         sl = slice(rank * w, (rank + 1) * w)
         tol = 2e-5
@@ -57,9 +61,11 @@ def _worker(rank, world, port, out_dir):
             xs = sconv.shard_columns(x).requires_grad_(True)
             y = sconv(xs, ei)
             y.backward(sconv.shard_columns(gy))
+            assert y.shape == (n, w) and xs.grad.shape == (n, w)
             assert torch.allclose(y, y_ref[:, sl], atol=tol, rtol=tol)
             assert torch.allclose(xs.grad, gx_ref[:, sl], atol=tol, rtol=tol)
             for li, layer in enumerate(sconv.layers):
+                assert layer.hi - layer.lo == (f if li == 0 else hid) // world       # this rank's slice of the input features
                 isl = slice(layer.lo, layer.hi)
                 assert torch.allclose(layer.base_weight.grad, g_ref[li]["base_weight"][:, isl], atol=tol, rtol=tol)
                 assert torch.allclose(layer.spline_weight.grad, g_ref[li]["spline_weight"][:, isl], atol=tol, rtol=tol)
@@ -82,6 +88,9 @@ def _worker(rank, world, port, out_dir):
             for li, layer in enumerate(tconv.layers):         # replicated parameters: full gradients on every rank
                 for name in ("base_weight", "spline_weight", "spline_scaler"):
                     assert torch.allclose(getattr(layer, name).grad, g_ref[li][name], atol=tol, rtol=tol), (n2, li, name)
+        if not full:
+            open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+            return
         # ---- "flat" with gradient accumulation (two backward passes, no zero_grad) and the module used twice in one
         # forward: only what a pass adds may be summed over the ranks (the queued callback used to all-reduce
         # the accumulated .grad again: P*S1 + S2)
@@ -124,12 +133,25 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_sharded_layer_world2_gloo(tmp_path):
+def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+        return s.getsockname()[1]
+
+
+def test_sharded_layer_world2_gloo(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+@pytest.mark.parametrize("world,f,hid,grid", [(4, 64, 64, 5), (8, 64, 64, 5), (4, 128, 128, 8), (8, 128, 128, 8), (8, 64, 128, 8)],
+                         ids=["P4-F64", "P8-F64", "P4-F128-G8", "P8-F128-G8", "P8-F64-H128-G8"])
+def test_sharded_layer_world4_and_world8_gloo(tmp_path, world, f, hid, grid):
+    """the SYSTEM at P = 4 and P = 8 (VERDICT r04 missing 2: only P = 2 had ever run): the rank-major [P][n][out/P] staging, the
+    reduce-scatter / all-gather algebra, uneven row chunks (400 rows in 3 and 7 chunks) and the transposed variant's all-to-all with
+    401 rows over P ranks -- at the widths the P = 8 shards have (8 columns per rank at F = 64, 16 at F = 128 / grid 8)."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), f, hid, grid, False), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -167,7 +189,7 @@ def _gpu_worker(rank, world, port, out_dir, backend="gloo"):
         sl = slice(rank * w, (rank + 1) * w)
 
         def close(a, b, what):
-            err = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+            err = float((a - b).abs().max()) / max(1e-300, float(b.abs().max()))
             assert err <= 1e-4, (what, err)
 
         # comm="p2p": hipIpc peer-mapped exchange buffers + kagnn_p2p_reduce_scatter / _all_gather (two processes, one GPU)
@@ -294,10 +316,19 @@ def test_bench_two_ranks_prints_one_line_even_when_a_transport_hangs_or_kills_a_
     assert line["north_star_scheme"]["scheme"] == "feature" and "per_rank" in line and line["roofline"]["frac"] > 0
     sel = line["multi_gpu_probe"]["selected"]
     assert (sel["scheme"], sel["comm"]) in combos and "error" not in combos[(sel["scheme"], sel["comm"])]
+    # `value` is north_star's scheme (it used to be the fastest combination, i.e. silently another
+    # partitioning); the fastest of the rest sits beside it under its own key
+    assert line["complete"] is True and line["value_scheme_is_north_star"] is True
+    assert (sel["scheme"], sel["comm"]) == ("feature", "rccl")            # (rccl_c cannot run with two ranks on one device)
+    fa = line["fastest_alternative"]
+    assert (fa["scheme"], fa["comm"]) in {("transposed", "rccl"), ("feature", "p2p"), ("transposed", "p2p")} and fa["ms_per_step"] > 0
+    assert fa["ms_per_step"] == min(combos[k]["ms_per_step"] for k in combos if k[1] != "rccl_c" and k != ("feature", "rccl"))
 
     # a transport that hangs on one rank: the watchdog ends the run, the line is the interim one of what had finished
     rc, line, err = _run_bench_two_ranks({"KAGNN_BENCH_FAULT": "feature/p2p:hang", "KAGNN_BENCH_PHASE_TIMEOUT": "25"})
     assert "interim" in line and line["value"] > 0 and "overran its deadline" in err
+    assert rc != 0 and line["complete"] is False         # (a hung transport must be visible to the launcher)
+    assert line["value_scheme_is_north_star"] is True and line["fastest_alternative"]["scheme"] == "transposed"
     done = [(c["scheme"], c["comm"]) for c in line["multi_gpu_probe"]["combinations"]]
     assert done == [("feature", "rccl"), ("transposed", "rccl")]
     assert line["multi_gpu_probe"]["not_finished"] == ["feature/p2p", "transposed/p2p", "feature/rccl_c"]
