@@ -439,6 +439,7 @@ def main():
 
     n, e = args.nodes, args.edges
     fp32_mode = args.precision in ("fp32", "exact", "0")
+    half_mode = args.precision in ("half", "fp16", "3")
     ei = powerlaw_graph(n, e, seed=0).to(dev)
     gen = torch.Generator().manual_seed(0)
     x_full = torch.randn(n, f, generator=gen) * 0.25
@@ -483,7 +484,9 @@ def main():
             "metric": "edges/sec KAN-GIN fwd+bwd, hidden=64 grid=5, 1M-node synthetic; HBM % peak",
             "value": value_, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_, "higher_is_better": True, "scaling": "strong" if world > 1 else "n/a",
-            "vs_baseline": None, "dtype": ("f32" if fp32_mode else "f32 (fp16 hi/lo split operands, fp32 accumulate)") +
+            "vs_baseline": None, "dtype": ("f32" if fp32_mode else
+                                          "f16 operands rounded once, fp32 accumulate (KAGNN_PRECISION=half: build-defined config-2 mode, NOT the headline)"
+                                          if half_mode else "f32 (fp16 hi/lo split operands, fp32 accumulate)") +
                                           (" + bf16 gather operands (KAGNN_ACT=bf16, build-defined config-2 mode)" if args.act == "bf16" else ""),
             "data": "synthetic",
             "config": {"workload": (f"{args.workload}: FastKAN-GIN conv layer fwd+bwd (aggregate + FastKAN([{f},{f},{f}]) num_grids={grid}), "
@@ -678,7 +681,7 @@ def main():
         per_step = {k: v["total_ms"] / PROFILE_STEPS for k, v in warm.items()}
         dom = only if only in prof else max((k for k in per_step if k in ROOFLINE_STAGES), key=per_step.get)
         mfma_peak = FP32_MFMA_PEAK_TF if fp32_mode else F16_MFMA_PEAK_TF
-        products = 1.0 if fp32_mode else 3.0            # split mode: hi*hi + hi*lo + lo*hi on the fp16 matrix cores
+        products = 1.0 if (fp32_mode or half_mode) else 3.0            # split mode: hi*hi + hi*lo + lo*hi on the fp16 matrix cores (half: one)
         nrows = n if world == 1 else n                  # (feature sharding keeps all rows on every rank)
         kan = kan_flops(nrows, fl, f, c)
         spec = {   # entry point -> (what, algorithmic bytes per launch, algorithmic flops per launch)

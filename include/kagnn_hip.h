@@ -38,12 +38,18 @@ extern "C" {
 #define KAGNN_PREC_SPLIT 1      /* fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate */
 #define KAGNN_PREC_FP32_GRID 2  /* exact fp32, and `knots` is the whole [in, G+2k+1] grid buffer: per-feature,
                                  * non-uniform knot rows (what KANLinear.update_grid leaves behind)       */
+#define KAGNN_PREC_HALF 3       /* BUILD-DEFINED reduced precision (BASELINE config 2 "bf16"; the reference is fp32 only, ekan.py:154-162):
+                                 * KAGNN_PREC_SPLIT's kernels with ONE fp16 product per fp32 product -- bases, SiLU, gy and the packed
+                                 * weights are evaluated in fp32 and rounded once (RNE, 11 significant bits) after the same exact
+                                 * power-of-two scaling, fp32 accumulate: a third of the matrix-core work, ~5e-4 from the fp32 result.
+                                 * Cubic layers of <= 8 coefficients; any other shape runs the three-product kernels (more accurate).
+                                 * Takes the same packs as KAGNN_PREC_SPLIT.  Never the headline.                              */
 
 /* element type of an activation / gradient matrix where an entry point accepts more than fp32 */
 #define KAGNN_DTYPE_F32 0
 #define KAGNN_DTYPE_BF16 1
 
-int kagnn_version(void);          /* 240 = this header (230 + kagnn_gin_kan_layer_bwd_bn_sums; 230 = 220 + the *_affine entry points of a folded BatchNorm1d; 220 = 210 + the stage timer) */
+int kagnn_version(void);          /* 250 = this header (240 + KAGNN_PREC_HALF; 240 = 230 + kagnn_gin_kan_layer_bwd_bn_sums; 230 = 220 + the *_affine entry points of a folded BatchNorm1d; 220 = 210 + the stage timer) */
 const char* kagnn_last_error(void);
 
 /* Stage timer -- a measurement aid, off by default (no reference counterpart: the reference times whole epochs with
@@ -79,6 +85,19 @@ int kagnn_csr_build(const int64_t* key, const int64_t* val, int64_t num_edges, i
                     int32_t hub_threshold, int32_t* hub_seg, int64_t hub_seg_capacity,
                     int64_t* num_hub_seg_host,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Small graphs (1 <= E, N <= 65 536; kagnn_csr_small_ok == 1) -- the mini-batches of the graph-level models, whose CSR is rebuilt
+ * per batch (reference graph_regression/optuna_zinc.py:56-66 -> torch_geometric's propagate bookkeeping): BOTH structures in ONE
+ * launch and with NO host synchronisation.  src / dst = edge_index[0] / edge_index[1] (int64); (rowptr, col, perm) by destination as
+ * kagnn_csr_build(key = dst, val = src) makes them, (rowptr_t, col_t, perm_t) by source; same stable order, bit for bit.  Node ids
+ * outside [0, num_nodes) are clamped to 0 (no out-of-bounds access follows) and reported in the DEVICE array flags[2] (bit 0: a key,
+ * bit 1: a value; [0] destination side, [1] source side), which the caller reads when convenient.  No hub segments.
+ * Workspace: kagnn_csr_small_workspace_bytes(E).                                                                                */
+int kagnn_csr_small_ok(int64_t num_edges, int64_t num_nodes);
+int kagnn_csr_small_workspace_bytes(int64_t num_edges, size_t* bytes_host);
+int kagnn_csr_build_small(const int64_t* src, const int64_t* dst, int64_t num_edges, int64_t num_nodes, int32_t* rowptr,
+                          int32_t* col, int32_t* perm, int32_t* rowptr_t, int32_t* col_t, int32_t* perm_t, int32_t* flags,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* in-degree normalisation of GCN (torch_geometric gcn_norm as used by KAGCNConv,
  * node_classification_clean/models.py:31-37): dis[i] = (1 + #non-loop in-edges of i)^-1/2.
@@ -365,6 +384,91 @@ int kagnn_gin_kan_layer_bwd_bn_sums(const float* g, int64_t ldg, const float* y,
                                     const float* gx_addend, int64_t ld_addend, float* const* g_base_weight,
                                     float* const* g_spline_weight, float* const* g_spline_scaler, void* workspace,
                                     size_t workspace_bytes, void* stream);
+
+/* Embedding-table encoders of the graph-level models (reference graph_regression/models.py:244-281, AtomEncoder / BondEncoder:
+ * out = sum over the integer feature columns of one table lookup each), one launch per column each way:
+ *   fwd: out[i, :] (+)= table[index[i * index_stride], :]      (accumulate != 0: add to out -- the 2nd, 3rd, ... column)
+ *   bwd: g_table[v, :] = sum_{i : index[i * index_stride] == v} g[i, :]   rows in order inside blocks of 128, blocks in order:
+ *        deterministic (no atomics)
+ * index: int64 (a column of the [N, columns] feature matrix: index_stride = columns); table / g_table: [V, F] contiguous.  An index
+ * outside [0, V) -- a device-side assert in torch.nn.functional.embedding -- gives a NaN row in fwd and is skipped in bwd.          */
+int kagnn_embedding_fwd(const int64_t* index, int64_t index_stride, int64_t num_rows, const float* table, int32_t num_embeddings,
+                        int32_t num_feat, float* out, int64_t ldo, int32_t accumulate, void* stream);
+int kagnn_embedding_bwd_workspace_bytes(int64_t num_rows, int32_t num_embeddings, int32_t num_feat, size_t* bytes_host);
+int kagnn_embedding_bwd(const int64_t* index, int64_t index_stride, int64_t num_rows, const float* g, int64_t ldg,
+                        int32_t num_embeddings, int32_t num_feat, float* g_table, void* workspace, size_t workspace_bytes,
+                        void* stream);      /* num_embeddings <= 512; two launches: per-row-block partial tables, then their sum in block order */
+
+/* ---- one library call per GINE convolution each way (round 5; BASELINE config 4 -- the ZINC-shaped mini-batch step is launch- and
+ * host-bound).  Replaces: torch_geometric GINEConv around ekan.KAN + the BatchNorm1d that follows it, reference
+ * graph_regression/models.py:98,107-119 (called per mini-batch from optuna_zinc.py:56-66).
+ * Forward:  acts[0] = self_scale * x_i + sum_{j->i} relu(x_j + edge_attr[perm[e]]) (kagnn_aggregate_gine), ONE pack launch for the
+ *   chain, the chain's KANLinear forwards into acts[1..L]; col_mean / col_m2 (both or NULL): the column moments of acts[L] from the
+ *   last kernel's epilogue, for kagnn_batchnorm_fwd(col_mean, col_m2).
+ * Backward: g = gradient of the chain's output -- or, with bn_y != NULL, of the training-mode BatchNorm1d that follows (bn_y = the
+ *   norm's input = acts[L], bn_mean / bn_rstd as saved by its forward; g_bn_weight / g_bn_bias receive its parameter gradients):
+ *   statistics pass, then the norm's element-wise backward inside the last layer's input-gradient kernel where the shape allows it
+ *   (kagnn_gin_kan_layer_bwd_bn), dW / dX per layer, then kagnn_aggregate_gine_bwd on the TRANSPOSED structure: gx [N, widths[0]]
+ *   (required) and g_edge_attr [E, widths[0]] in original edge order (may be NULL).
+ * Same kernels and summation orders as the per-operation entry points: bit-identical results.  fp32 rows, no hub segments (mini-batches
+ * of small graphs).  Workspace: kagnn_gin_kan_layer_workspace_bytes(..., num_hub_seg = 0, num_hub_seg_t = 0) forward / backward sizes,
+ * the backward plus kagnn_gin_kan_layer_bwd_bn_workspace_bytes(num_nodes, widths[L]) when bn_y is given.                              */
+int kagnn_gine_kan_layer_fwd(const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int64_t num_nodes,
+                             const int32_t* rowptr, const int32_t* col, const int32_t* perm, float self_scale,
+                             int32_t num_layers, const int32_t* widths, const float* const* base_weight,
+                             const float* const* spline_weight, const float* const* spline_scaler, const float* knots,
+                             int32_t grid_size, int32_t spline_order, int32_t mode, float* const* acts,
+                             void* const* pack_fwd, void* const* pack_dx, float* col_mean, float* col_m2,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int kagnn_gine_kan_layer_bwd(const float* g, int64_t ldg, const float* bn_y, int64_t ld_bn_y, const float* bn_weight,
+                             const float* bn_mean, const float* bn_rstd, float* g_bn_weight, float* g_bn_bias,
+                             const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int64_t num_nodes,
+                             const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t, float self_scale,
+                             int32_t num_layers, const int32_t* widths, const float* const* spline_weight,
+                             const float* const* spline_scaler, const float* knots, int32_t grid_size,
+                             int32_t spline_order, int32_t mode, const float* const* acts, const void* const* pack_dx,
+                             float* gx, int64_t ldgx, float* g_edge_attr, int64_t ldge, float* const* g_base_weight,
+                             float* const* g_spline_weight, float* const* g_spline_scaler, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* ---- the WHOLE message-passing stack of a graph-level model in one call each way (round 5):  num_convs x { GINE convolution around a KAN
+ * chain of num_layers layers -> training-mode BatchNorm1d }, every chain hidden -> ... -> hidden with the same `widths` (widths[0] ==
+ * widths[num_layers]).  Replaces the loop of reference graph_regression/models.py:107-119
+ * (`for i in range(n_layers): x = self.bn[i](self.conv[i](x, edge_index, edge_attr))`, dropout 0) as called per mini-batch from
+ * optuna_zinc.py:56-66: on a 256-molecule batch a convolution is ~100 us of device work, and as one tape node per convolution the host
+ * spent about as long per node each way on argument marshalling -- the step was host-bound at twice its device time.
+ * Forward: ONE pack launch for all layers of all convolutions, then per convolution kagnn_aggregate_gine, the chain (column moments
+ * from the last kernel) and the normalising pass -> h[i] (the next convolution's input).  Backward: g = gradient of h[num_convs - 1];
+ * per convolution, last first: the norm's statistics pass, its element-wise backward inside the last input-gradient kernel, dW / dX,
+ * kagnn_aggregate_gine_bwd -> the previous convolution's g; gx = gradient of x; the edge-attribute gradients of all convolutions add
+ * up in g_edge_attr [E, widths[0]] (may be NULL).  Same kernels and summation orders as num_convs calls of
+ * kagnn_gine_kan_layer_fwd / _bwd: bit-identical.
+ * Arrays: per layer, convolution-major [num_convs * num_layers]: base_weight, spline_weight, spline_scaler, pack_fwd, pack_dx, g_*;
+ * acts [num_convs * (num_layers + 1)] (acts[i * (L + 1)] = the aggregated input, ... + L = the chain's output = the norm's input);
+ * per convolution [num_convs]: self_scale, momentum, eps (HOST floats); bn_weight, bn_bias, running_mean, running_var (the last two
+ * arrays or entries may be NULL), h, save_mean, save_rstd, g_bn_weight, g_bn_bias (device).  num_nodes >= 2.                          */
+int kagnn_gine_kan_stack_workspace_bytes(int64_t num_nodes, int32_t num_convs, int32_t num_layers, const int32_t* widths,
+                                         int32_t grid_size, int32_t spline_order, int32_t mode, size_t* fwd_bytes_host,
+                                         size_t* bwd_bytes_host);
+int kagnn_gine_kan_stack_fwd(const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int64_t num_nodes,
+                             const int32_t* rowptr, const int32_t* col, const int32_t* perm, const float* self_scale,
+                             int32_t num_convs, int32_t num_layers, const int32_t* widths, const float* const* base_weight,
+                             const float* const* spline_weight, const float* const* spline_scaler, const float* knots,
+                             int32_t grid_size, int32_t spline_order, int32_t mode, float* const* acts, void* const* pack_fwd,
+                             void* const* pack_dx, const float* const* bn_weight, const float* const* bn_bias,
+                             float* const* running_mean, float* const* running_var, const float* momentum, const float* eps,
+                             float* const* h, float* const* save_mean, float* const* save_rstd, void* workspace,
+                             size_t workspace_bytes, void* stream);
+int kagnn_gine_kan_stack_bwd(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* edge_attr, int64_t lde,
+                             int64_t num_nodes, const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t,
+                             const float* self_scale, int32_t num_convs, int32_t num_layers, const int32_t* widths,
+                             const float* const* spline_weight, const float* const* spline_scaler, const float* knots,
+                             int32_t grid_size, int32_t spline_order, int32_t mode, const float* const* acts,
+                             const void* const* pack_dx, const float* const* h, const float* const* bn_weight,
+                             const float* const* save_mean, const float* const* save_rstd, float* gx, int64_t ldgx,
+                             float* g_edge_attr, int64_t ldge, float* const* g_bn_weight, float* const* g_bn_bias,
+                             float* const* g_base_weight, float* const* g_spline_weight, float* const* g_spline_scaler,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* kagnn_kan_linear_bwd_input_affine that ALSO leaves the two column sums the backward of the folded BatchNorm1d starts from (round 4):
  * sums[0][in] = sum_n gx, sums[1][in] = sum_n gx * xhat, xhat = (x - bn_mean) * bn_rstd on the raw rows x (= that norm's input).

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("KAGNN_LIB") or os.path.join(_HERE, "lib", "libkagnn_h
 PREC_FP32 = 0
 PREC_SPLIT = 1
 PREC_FP32_GRID = 2      # exact fp32 on per-feature, non-uniform knot rows (after update_grid)
+PREC_HALF = 3           # build-defined reduced precision: the split kernels with ONE fp16 product per fp32 product (kagnn_hip.h)
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 _P = c_void_p
@@ -30,6 +31,9 @@ _SIGNATURES = {
     "kagnn_csr_workspace_bytes": (c_int32, [c_int64, c_int64, POINTER(c_size_t)]),
     "kagnn_csr_build": (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, c_int32, _P, c_int64,
                                   POINTER(c_int64), _P, c_size_t, _P]),
+    "kagnn_csr_small_ok": (c_int32, [c_int64, c_int64]),
+    "kagnn_csr_small_workspace_bytes": (c_int32, [c_int64, POINTER(c_size_t)]),
+    "kagnn_csr_build_small": (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "kagnn_gcn_deg_inv_sqrt": (c_int32, [_P, _P, c_int64, _P, _P]),
     "kagnn_aggregate_workspace_bytes": (c_int32, [c_int64, c_int32, POINTER(c_size_t)]),
     "kagnn_aggregate_sum": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int32, c_float,
@@ -47,6 +51,9 @@ _SIGNATURES = {
     "kagnn_segment_broadcast": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, _P]),
     "kagnn_p2p_reduce_scatter": (c_int32, [_P, c_int32, c_int32, c_int64, c_int32, c_int64, _P, c_int64, _P]),
     "kagnn_p2p_all_gather": (c_int32, [_P, c_int32, c_int64, c_int32, c_int64, _P, c_int64, _P]),
+    "kagnn_embedding_fwd": (c_int32, [_P, c_int64, c_int64, _P, c_int32, c_int32, _P, c_int64, c_int32, _P]),
+    "kagnn_embedding_bwd_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, POINTER(c_size_t)]),
+    "kagnn_embedding_bwd": (c_int32, [_P, c_int64, c_int64, _P, c_int64, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "kagnn_kan_pack_bytes": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32,
                                        POINTER(c_size_t), POINTER(c_size_t)]),
     "kagnn_kan_pack": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
@@ -90,6 +97,21 @@ _SIGNATURES = {
                                                   c_int64, _P, _P, _P, c_int64, c_int32, c_float, c_int32, _P, _P, _P,
                                                   _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P, c_int64,
                                                   _P, _P, _P, _P, c_size_t, _P]),
+    # x ldx ea lde N rowptr col perm self L widths bw sw sc knots G K mode acts pf pd cmean cm2 ws bytes stream
+    "kagnn_gine_kan_layer_fwd": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, _P, _P, c_float, c_int32, _P, _P, _P, _P, _P,
+                                           c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    # g ldg bn_y ld bn_w mean rstd g_w g_b x ldx ea lde N rowptr_t col_t perm_t self L widths sw sc knots G K mode acts pd gx ldgx gea ldge gbw gsw gsc ws bytes stream
+    "kagnn_gine_kan_layer_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P, _P,
+                                           c_float, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, c_int64,
+                                           _P, _P, _P, _P, c_size_t, _P]),
+    "kagnn_gine_kan_stack_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, _P, c_int32, c_int32, c_int32, POINTER(c_size_t), POINTER(c_size_t)]),
+    # x ldx ea lde N rowptr col perm self nconv L widths bw sw sc knots G K mode acts pf pd bnw bnb rm rv mom eps h mean rstd ws bytes stream
+    "kagnn_gine_kan_stack_fwd": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P, _P,
+                                           c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    # g ldg x ldx ea lde N rowptr_t col_t perm_t self nconv L widths sw sc knots G K mode acts pd h bnw mean rstd gx ldgx gea ldge gbnw gbnb gbw gsw gsc ws bytes stream
+    "kagnn_gine_kan_stack_bwd": (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P,
+                                           c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P,
+                                           _P, c_size_t, _P]),
     "kagnn_kan_bwd_input_sums_ok": (c_int32, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "kagnn_kan_bwd_input_sums_workspace_bytes": (c_int32, [c_int64, c_int32, POINTER(c_size_t)]),
     "kagnn_kan_linear_bwd_input_affine_sums": (c_int32, [_P, c_int64, _P, _P, _P, _P, c_int64, c_int64, _P, c_int32, c_int32,

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void gine_bwd_kernel(const float* __restrict__
                                                        const int* __restrict__ rowptr,
                                                        const int* __restrict__ col,
                                                        const int* __restrict__ perm, long N, int F,
-                                                       float self_scale) {
+                                                       float self_scale, int gea_accumulate) {
     const long j = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (j >= N) return;
     const int lane = threadIdx.x & 63;
@@ -316,7 +316,9 @@ __global__ __launch_bounds__(256) void gine_bwd_kernel(const float* __restrict__
         for (int e = s; e < t; ++e) {
             const long pe = perm[e];
             const float g = (xj + ea[pe * lde + f] > 0.0f) ? gout[(long)col[e] * ldg + f] : 0.0f;
-            if (gea) gea[pe * ldge + f] = g;
+            // (every edge sits in exactly one source row: a plain read-modify-write, no atomics; accumulate = the edge attributes
+            // feed several convolutions and their gradients add up in place -- kagnn_gine_kan_stack_bwd)
+            if (gea) gea[pe * ldge + f] = gea_accumulate ? gea[pe * ldge + f] + g : g;
             acc += g;
         }
         gx[j * ldgx + f] = acc;
@@ -352,6 +354,88 @@ __global__ __launch_bounds__(256) void segment_bcast_kernel(const float* __restr
         const float v = g[b * ldg + f] * inv;
         for (int i = s; i < t; ++i) gx[(long)i * ldgx + f] = v;
     }
+}
+
+// ------------------------------------------------------------------ embedding-table encoders of the graph-level models
+// (reference graph_regression/models.py:244-281: AtomEncoder / BondEncoder -- out = sum over the integer feature columns of one table
+// lookup each).  One launch per column each way instead of aten's gather (forward) and its sort-based embedding_dense_backward
+// (~12 launches per table and step: radix sort, segment offsets, partial sums, scatter) -- on a 256-molecule mini-batch the two
+// tables' backward was ~25 launches and ~170 us of a ~1.1 ms step.  The tables are tiny (21 atom / 4 bond types for ZINC, <= 119
+// rows for OGB molecules), so the backward is one workgroup per (table row, 64-column chunk) scanning the index column: the rows that
+// hit it are added in row order by four waves (rows w, w + 4, ...), the four partial sums in wave order -- deterministic.
+// An index outside [0, V) (aten: a device-side assert) gives a NaN row in the forward and is skipped in the backward.
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ idx, long stride, long N,
+                                                            const float* __restrict__ table, int V, int F,
+                                                            float* __restrict__ out, long ldo, int accumulate) {
+    const long i = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t v = idx[i * stride];
+    const bool ok = v >= 0 && v < V;
+    for (int f = lane; f < F; f += 64) {
+        const float t = ok ? table[v * F + f] : __builtin_nanf("");
+        out[i * ldo + f] = accumulate ? out[i * ldo + f] + t : t;
+    }
+}
+
+// backward, phase 1: one wave per (block of kEmbRows rows, 64-column chunk) walks its rows IN ORDER and adds each gradient row into the
+// LDS copy of the table row it hit (the index is wave-uniform: one LDS row per step, lane = column, no conflicts); the block's
+// table goes to partial[block][V][F].  Phase 2 adds the blocks in block order: deterministic, no atomics.  (A first version had
+// one workgroup per table row scan the whole index column -- a serial chain of dependent loads: 0.5 ms for 12.7k edges.)
+constexpr int kEmbRows = 128;
+__global__ __launch_bounds__(64) void embedding_bwd_partial_kernel(const int64_t* __restrict__ idx, long stride, long N,
+                                                                   const float* __restrict__ g, long ldg, int V, int F,
+                                                                   float* __restrict__ partial) {
+    extern __shared__ float s_acc[];                    // [V][64]
+    const int lane = threadIdx.x, f = blockIdx.y * 64 + lane;
+    for (int k = lane; k < V * 64; k += 64) s_acc[k] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    const long r0 = (long)blockIdx.x * kEmbRows, r1 = min(N, r0 + kEmbRows);
+    for (long i = r0; i < r1; ++i) {
+        const int64_t v = idx[i * stride];
+        if (v >= 0 && v < V && f < F) s_acc[v * 64 + lane] += g[i * ldg + f];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (f < F)
+        for (int v = 0; v < V; ++v) partial[((long)blockIdx.x * V + v) * F + f] = s_acc[v * 64 + lane];
+}
+
+__global__ __launch_bounds__(256) void embedding_bwd_reduce_kernel(const float* __restrict__ partial, int nb, int V, int F,
+                                                                   float* __restrict__ g_table) {
+    const long k = blockIdx.x * 256L + threadIdx.x;
+    if (k >= (long)V * F) return;
+    float a = 0.0f;
+    for (int b = 0; b < nb; ++b) a += partial[(long)b * V * F + k];
+    g_table[k] = a;
+}
+
+int embedding_fwd(const int64_t* idx, long stride, long N, const float* table, int V, int F, float* out, long ldo, int accumulate,
+                  hipStream_t st) {
+    if (N == 0) return KAGNN_OK;
+    embedding_fwd_kernel<<<cdiv(N, 4), 256, 0, st>>>(idx, stride, N, table, V, F, out, ldo, accumulate);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+size_t embedding_bwd_ws_bytes(long N, int V, int F) { return (size_t)cdiv(max(N, 1L), kEmbRows) * V * F * sizeof(float); }
+
+int embedding_bwd(const int64_t* idx, long stride, long N, const float* g, long ldg, int V, int F, float* g_table, float* ws,
+                  size_t ws_bytes, hipStream_t st) {
+    if (V == 0) return KAGNN_OK;
+    if (V > 512) return fail(KAGNN_ERR_UNSUPPORTED, "%s: tables of at most 512 rows (the categorical encoders of the graph-level models)", "embedding_bwd");
+    if (ws_bytes < embedding_bwd_ws_bytes(N, V, F)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "embedding_bwd");
+    const int nb = cdiv(max(N, 1L), kEmbRows);
+    const size_t lds = (size_t)V * 64 * sizeof(float);
+    if (lds > 64 * 1024) {
+        static unsigned long long configured = 0;
+        if (first_use_on_this_device(configured))
+            KAGNN_HIP(hipFuncSetAttribute((const void*)embedding_bwd_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 1024));
+    }
+    embedding_bwd_partial_kernel<<<dim3((unsigned)nb, (unsigned)cdiv(F, 64)), 64, lds, st>>>(idx, stride, N, g, ldg, V, F, ws);
+    KAGNN_LAUNCH_CHECK();
+    embedding_bwd_reduce_kernel<<<cdiv((long)V * F, 256), 256, 0, st>>>(ws, nb, V, F, g_table);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
 }
 
 // ------------------------------------------------------------------ launchers
@@ -463,9 +547,9 @@ int gine_fwd(const float* x, long ldx, const float* ea, long lde, float* out, lo
 
 int gine_bwd(const float* x, long ldx, const float* ea, long lde, const float* gout, long ldg,
              float* gx, long ldgx, float* gea, long ldge, const int* rowptr, const int* col,
-             const int* perm, long N, int F, float self_scale, hipStream_t st) {
+             const int* perm, long N, int F, float self_scale, hipStream_t st, int gea_accumulate) {
     if (N == 0) return KAGNN_OK;
-    gine_bwd_kernel<<<cdiv(N, 4), 256, 0, st>>>(x, ldx, ea, lde, gout, ldg, gx, ldgx, gea, ldge, rowptr, col, perm, N, F, self_scale);
+    gine_bwd_kernel<<<cdiv(N, 4), 256, 0, st>>>(x, ldx, ea, lde, gout, ldg, gx, ldgx, gea, ldge, rowptr, col, perm, N, F, self_scale, gea_accumulate);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }

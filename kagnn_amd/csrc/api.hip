@@ -4,6 +4,7 @@
 
 namespace kagnn {
 thread_local char g_err[512] = "";
+thread_local bool g_half_products = false;      // KAGNN_PREC_HALF for the duration of an entry-point call (split_common.h)
 
 size_t aggregate_ws_bytes(long num_hub_seg, int F);
 size_t aggregate_bf16_ws_bytes(long num_hub_seg, int F);
@@ -27,11 +28,17 @@ int bn_finish_partials(const float* partial, long B, int F, float* sums, hipStre
 int bn_bwd_stats_given(const float*, long, int, const float*, const float*, const float*, float*, float*, float*, int, hipStream_t);
 int gcn_deg_inv_sqrt(const int* rowptr, const int* col, long N, float* dis, hipStream_t st);
 int gine_fwd(const float*, long, const float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
-int gine_bwd(const float*, long, const float*, long, const float*, long, float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t);
+int gine_bwd(const float*, long, const float*, long, const float*, long, float*, long, float*, long, const int*, const int*, const int*, long, int, float, hipStream_t, int gea_accumulate = 0);
 int segment_pool(const float*, long, float*, long, const int*, long, int, int, hipStream_t);
 int segment_bcast(const float*, long, float*, long, const int*, long, int, int, hipStream_t);
+int embedding_fwd(const int64_t*, long, long, const float*, int, int, float*, long, int, hipStream_t);
+int embedding_bwd(const int64_t*, long, long, const float*, long, int, int, float*, float*, size_t, hipStream_t);
+size_t embedding_bwd_ws_bytes(long N, int V, int F);
 int csr_workspace_bytes(long E, long N, size_t* bytes);
 int csr_build(const int64_t*, const int64_t*, long, long, int*, int*, int*, int, int*, long, int64_t*, void*, size_t, hipStream_t);
+bool csr_small_ok(long E, long N);
+size_t csr_small_workspace_bytes(long E);
+int csr_build_small(const int64_t*, const int64_t*, long, long, int*, int*, int*, int*, int*, int*, int*, void*, size_t, hipStream_t);
 
 size_t kan_f32_pack_fwd_bytes(int in, int out, int C);
 size_t kan_f32_pack_dx_bytes(int in, int out, int C);
@@ -152,6 +159,17 @@ struct StageScope {
     }
 };
 }  // namespace
+// KAGNN_PREC_HALF is KAGNN_PREC_SPLIT with ONE product per fp32 product: every routing decision below is the split mode's, the
+// launchers of the three KAN kernels pick their HALF instantiation while the flag is up (shapes without one run the
+// three-product kernels: more accurate, never less).  Entry points call each other with the rewritten mode, so a nested scope
+// sees KAGNN_PREC_SPLIT and leaves the flag alone.
+struct ModeScope {
+    bool prev;
+    explicit ModeScope(int32_t& mode) : prev(kagnn::g_half_products) {
+        if (mode == KAGNN_PREC_HALF) { kagnn::g_half_products = true; mode = KAGNN_PREC_SPLIT; }
+    }
+    ~ModeScope() { kagnn::g_half_products = prev; }
+};
 #define KAGNN_STAGE(stream) StageScope stage_scope_(__func__, stream)
 #define KAGNN_STAGE_AS(name, stream) StageScope stage_scope_(name, stream)
 
@@ -174,7 +192,7 @@ static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode 
 #pragma GCC visibility push(default)
 extern "C" {
 
-int kagnn_version(void) { return 240; }
+int kagnn_version(void) { return 250; }
 const char* kagnn_last_error(void) { return g_err; }
 
 int kagnn_stage_timer_enable(const char* only) {
@@ -236,6 +254,20 @@ int kagnn_csr_build(const int64_t* key, const int64_t* val, int64_t E, int64_t N
     KAGNN_CHECK_ARG(E == 0 || (key && val && col && perm && ws), "null array");
     return csr_build(key, val, E, N, rowptr, col, perm, hub_threshold, hub_seg, hub_seg_capacity,
                      num_hub_seg_host, ws, ws_bytes, as_stream(stream));
+}
+
+int kagnn_csr_small_ok(int64_t E, int64_t N) { return csr_small_ok(E, N) ? 1 : 0; }
+
+int kagnn_csr_small_workspace_bytes(int64_t E, size_t* bytes) {
+    KAGNN_CHECK_ARG(bytes != nullptr && E >= 0, "null output or negative size");
+    *bytes = csr_small_workspace_bytes(E);
+    return KAGNN_OK;
+}
+
+int kagnn_csr_build_small(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr, int32_t* col, int32_t* perm,
+                          int32_t* rowptr_t, int32_t* col_t, int32_t* perm_t, int32_t* flags, void* ws, size_t ws_bytes, void* stream) {
+    KAGNN_CHECK_ARG(src && dst && rowptr && col && perm && rowptr_t && col_t && perm_t && flags && ws, "null array");
+    return csr_build_small(src, dst, E, N, rowptr, col, perm, rowptr_t, col_t, perm_t, flags, ws, ws_bytes, as_stream(stream));
 }
 
 int kagnn_gcn_deg_inv_sqrt(const int32_t* rowptr, const int32_t* col, int64_t N, float* dis, void* stream) {
@@ -351,8 +383,29 @@ int kagnn_segment_broadcast(const float* g, int64_t ldg, float* gx, int64_t ldgx
 }
 
 // ---------------------------------------------------------------- efficient-KAN
+int kagnn_embedding_fwd(const int64_t* index, int64_t index_stride, int64_t N, const float* table, int32_t V, int32_t F, float* out,
+                        int64_t ldo, int32_t accumulate, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && V >= 1 && F >= 1 && index_stride >= 1 && ldo >= F, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (index && table && out), "null array");
+    return embedding_fwd(index, index_stride, N, table, V, F, out, ldo, accumulate, as_stream(stream));
+}
+
+int kagnn_embedding_bwd_workspace_bytes(int64_t N, int32_t V, int32_t F, size_t* bytes) {
+    KAGNN_CHECK_ARG(N >= 0 && V >= 1 && F >= 1 && bytes, "bad argument");
+    *bytes = embedding_bwd_ws_bytes(N, V, F);
+    return KAGNN_OK;
+}
+
+int kagnn_embedding_bwd(const int64_t* index, int64_t index_stride, int64_t N, const float* g, int64_t ldg, int32_t V, int32_t F,
+                        float* g_table, void* workspace, size_t workspace_bytes, void* stream) {
+    KAGNN_CHECK_ARG(N >= 0 && V >= 1 && F >= 1 && index_stride >= 1 && ldg >= F && g_table && workspace, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (index && g), "null array");
+    return embedding_bwd(index, index_stride, N, g, ldg, V, F, g_table, static_cast<float*>(workspace), workspace_bytes, as_stream(stream));
+}
+
 int kagnn_kan_pack_bytes(int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
                          size_t* fwd_bytes, size_t* dx_bytes) {
+    ModeScope mode_scope_(mode);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(fwd_bytes && dx_bytes, "null output");
@@ -364,6 +417,7 @@ int kagnn_kan_pack_bytes(int32_t in, int32_t out, int32_t G, int32_t K, int32_t 
 
 int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in, int32_t out,
                    int32_t G, int32_t K, int32_t mode, void* pack_fwd, void* pack_dx, void* stream) {
+    ModeScope mode_scope_(mode);
     KAGNN_STAGE(stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
@@ -386,6 +440,7 @@ int kagnn_kan_pack(const float* bw, const float* sw, const float* sc, int32_t in
 int kagnn_kan_pack_batch(int32_t n_layers, const float* const* bw, const float* const* sw, const float* const* sc,
                          const int32_t* in, const int32_t* out, int32_t G, int32_t K, int32_t mode,
                          void* const* pack_fwd, void* const* pack_dx, void* stream) {
+    ModeScope mode_scope_(mode);
     KAGNN_STAGE(stream);
     KAGNN_CHECK_ARG(n_layers >= 1 && bw && sw && in && out && pack_fwd && pack_dx, "null array");
     for (int l = 0; l < n_layers; ++l) {
@@ -400,6 +455,7 @@ int kagnn_kan_pack_batch(int32_t n_layers, const float* const* bw, const float* 
 
 int kagnn_kan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
                                   size_t* bytes) {
+    ModeScope mode_scope_(mode);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
@@ -411,6 +467,7 @@ int kagnn_kan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G,
 int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* knots, int32_t in,
                          int32_t out, int32_t G, int32_t K, int32_t mode, const void* pack_fwd,
                          float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     KAGNN_STAGE(stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
@@ -430,6 +487,7 @@ int kagnn_kan_linear_fwd(const float* x, int64_t ldx, int64_t N, const float* kn
 // skip-concat read-out of the node models (reference node_classification_clean/models.py:202 `torch.cat(l, dim=1)` feeding
 // `lay_out`) without building the concatenation, one launch, one write of y.  pack_fwd is the pack of the WHOLE layer.
 int kagnn_kan_fwd_parts_ok(const int32_t* part_widths, int32_t num_parts, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode) {
+    ModeScope mode_scope_(mode);
     if (!part_widths || check_kan_dims(__func__, in, out, G, K, mode)) return 0;
     return use_sparse_fwd(in, out, G, K, mode) && kan_sparse_fwd_parts_ok(part_widths, num_parts, in, out, G, K) ? 1 : 0;
 }
@@ -437,6 +495,7 @@ int kagnn_kan_fwd_parts_ok(const int32_t* part_widths, int32_t num_parts, int32_
 int kagnn_kan_linear_fwd_parts(const float* const* x_parts, const int32_t* part_widths, const int64_t* part_ld, int32_t num_parts,
                                int64_t N, const float* knots, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
                                const void* pack_fwd, float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     return kagnn_kan_linear_fwd_parts_affine(x_parts, part_widths, part_ld, nullptr, num_parts, N, knots, in, out, G, K, mode, pack_fwd, y, ldy,
                                              ws, ws_bytes, stream);
 }
@@ -448,6 +507,7 @@ int kagnn_kan_linear_fwd_parts_affine(const float* const* x_parts, const int32_t
                                       const float* const* part_affine, int32_t num_parts,
                                       int64_t N, const float* knots, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
                                       const void* pack_fwd, float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     KAGNN_STAGE_AS("kagnn_kan_linear_fwd_parts", stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
@@ -469,6 +529,7 @@ static bool fused_moments(int64_t N, int32_t in, int32_t out, int32_t G, int32_t
 
 int kagnn_kan_fwd_moments_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode,
                                           size_t* bytes) {
+    ModeScope mode_scope_(mode);
     size_t b = 0;
     int rc = kagnn_kan_fwd_workspace_bytes(N, in, out, G, K, mode, &b);
     if (rc) return rc;
@@ -481,6 +542,7 @@ int kagnn_kan_linear_fwd_moments(const float* x, int64_t ldx, int64_t N, const f
                                  int32_t out, int32_t G, int32_t K, int32_t mode, const void* pack_fwd,
                                  float* y, int64_t ldy, float* col_mean, float* col_m2, void* ws, size_t ws_bytes,
                                  void* stream) {
+    ModeScope mode_scope_(mode);
     KAGNN_STAGE(stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
@@ -502,6 +564,7 @@ int kagnn_kan_linear_fwd_moments(const float* x, int64_t ldx, int64_t N, const f
 int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N,
                                const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
                                int32_t mode, const void* pack_dx, void* gx, int64_t ldgx, int32_t gx_dtype, void* stream) {
+    ModeScope mode_scope_(mode);
     return kagnn_kan_linear_bwd_input_affine(x, ldx, nullptr, gy, ldgy, N, knots, in, out, G, K, mode, pack_dx, gx, ldgx, gx_dtype, stream);
 }
 
@@ -511,6 +574,7 @@ int kagnn_kan_linear_bwd_input(const float* x, int64_t ldx, const float* gy, int
 int kagnn_kan_linear_bwd_input_affine(const float* x, int64_t ldx, const float* x_affine, const float* gy, int64_t ldgy, int64_t N,
                                       const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
                                       int32_t mode, const void* pack_dx, void* gx, int64_t ldgx, int32_t gx_dtype, void* stream) {
+    ModeScope mode_scope_(mode);
     KAGNN_STAGE_AS("kagnn_kan_linear_bwd_input", stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
@@ -535,6 +599,7 @@ int kagnn_kan_linear_bwd_input_affine(const float* x, int64_t ldx, const float* 
 // that norm's incoming gradient is exactly this gx, so its statistics pass over (gx, x) goes away.  Covered (kagnn_kan_bwd_input_sums_ok):
 // split precision, cubic layers of <= 8 coefficients, <= 64 inputs (a multiple of 4) and outputs, >= 32768 rows.
 int kagnn_kan_bwd_input_sums_ok(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K, int32_t mode) {
+    ModeScope mode_scope_(mode);
     return mode == KAGNN_PREC_SPLIT && use_split_dx(in, out, G, K, mode) && kan_split_dx_stats_ok(N, in, out, G, K) ? 1 : 0;
 }
 int kagnn_kan_bwd_input_sums_workspace_bytes(int64_t N, int32_t in, size_t* bytes) {
@@ -546,6 +611,7 @@ int kagnn_kan_linear_bwd_input_affine_sums(const float* x, int64_t ldx, const fl
                                            const float* gy, int64_t ldgy, int64_t N, const float* knots, int32_t in, int32_t out,
                                            int32_t G, int32_t K, int32_t mode, const void* pack_dx, float* gx, int64_t ldgx,
                                            float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(N >= 1 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
@@ -566,6 +632,7 @@ int kagnn_kan_linear_bwd_input_affine_sums(const float* x, int64_t ldx, const fl
 
 int kagnn_kan_bwd_weight_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t G, int32_t K,
                                          int32_t mode, size_t* bytes) {
+    ModeScope mode_scope_(mode);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
@@ -578,6 +645,7 @@ int kagnn_kan_linear_bwd_weight(const float* x, int64_t ldx, const float* gy, in
                                 const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
                                 int32_t mode, const float* sw, const float* sc, float* g_bw,
                                 float* g_sw, float* g_sc, void* ws, size_t ws_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     return kagnn_kan_linear_bwd_weight_affine(x, ldx, nullptr, gy, ldgy, N, knots, in, out, G, K, mode, sw, sc, g_bw, g_sw, g_sc, ws, ws_bytes, stream);
 }
 
@@ -586,6 +654,7 @@ int kagnn_kan_linear_bwd_weight_affine(const float* x, int64_t ldx, const float*
                                        const float* knots, int32_t in, int32_t out, int32_t G, int32_t K,
                                        int32_t mode, const float* sw, const float* sc, float* g_bw,
                                        float* g_sw, float* g_sc, void* ws, size_t ws_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     KAGNN_STAGE_AS("kagnn_kan_linear_bwd_weight", stream);
     int rc = check_kan_dims(__func__, in, out, G, K, mode);
     if (rc) return rc;
@@ -639,6 +708,7 @@ int kagnn_kan_grid_refit(const float* x, int64_t ldx, int64_t N, const float* gr
 }
 
 int kagnn_fastkan_fwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t ng, int32_t mode, size_t* bytes) {
+    ModeScope mode_scope_(mode);
     int rc = check_fk(__func__, in, out, ng, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
@@ -650,6 +720,7 @@ int kagnn_fastkan_fwd(const float* x, int64_t ldx, int64_t N, int32_t in, int32_
                       const float* centers, float denominator, const float* ln_w, const float* ln_b,
                       float ln_eps, const float* spline_w, const float* base_w, const float* base_b,
                       float* y, int64_t ldy, float* row_stats, int32_t mode, void* ws, size_t ws_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     KAGNN_STAGE(stream);
     int rc = check_fk(__func__, in, out, ng, mode);
     if (rc) return rc;
@@ -665,6 +736,7 @@ int kagnn_fastkan_fwd(const float* x, int64_t ldx, int64_t N, int32_t in, int32_
 }
 
 int kagnn_fastkan_bwd_workspace_bytes(int64_t N, int32_t in, int32_t out, int32_t ng, int32_t mode, size_t* bytes) {
+    ModeScope mode_scope_(mode);
     int rc = check_fk(__func__, in, out, ng, mode);
     if (rc) return rc;
     KAGNN_CHECK_ARG(bytes && N >= 0, "bad argument");
@@ -678,6 +750,7 @@ int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy
                       const float* base_w, const float* row_stats, float* gx, int64_t ldgx,
                       float* g_ln_w, float* g_ln_b, float* g_spline_w, float* g_base_w,
                       float* g_base_b, int32_t mode, void* ws, size_t ws_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     KAGNN_STAGE(stream);
     int rc = check_fk(__func__, in, out, ng, mode);
     if (rc) return rc;
@@ -842,6 +915,7 @@ static size_t al256z(size_t b) { return (b + 255) & ~(size_t)255; }
 
 int kagnn_gin_kan_layer_workspace_bytes(int64_t N, int32_t L, const int32_t* widths, int32_t G, int32_t K, int32_t mode,
                                         int64_t num_hub_seg, int64_t num_hub_seg_t, size_t* fwd_bytes, size_t* bwd_bytes) {
+    ModeScope mode_scope_(mode);
     KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && fwd_bytes && bwd_bytes, "bad argument");
     size_t fw = 0, dw = 0;
     int wmax = 0;
@@ -865,13 +939,24 @@ int kagnn_gin_kan_layer_workspace_bytes(int64_t N, int32_t L, const int32_t* wid
     return KAGNN_OK;
 }
 
+// GINE message passing around the same chain (reference graph_regression/models.py:98,107-119: GINEConv(KAN)): the aggregation of
+// the forward is kagnn_aggregate_gine (relu(x_j + e_ij) messages, edge attributes in ORIGINAL edge order through `perm`), the last
+// step of the backward kagnn_aggregate_gine_bwd on the transposed structure (also the edge-attribute gradient)
+struct GineStage {
+    const float* x; int64_t ldx; const float* ea; int64_t lde; const int32_t* perm;      // forward: perm of the CSR; backward: of its transpose
+    float* g_ea; int64_t ldge;                                                           // backward only (g_ea may be null)
+    int accumulate_g_ea = 0;                                                             // backward: g_ea += (the stack's later convolutions)
+    int prepacked = 0;                                                                   // forward: the packs were made by the caller (one launch for a whole stack)
+};
+
 static int layer_fwd_impl(const void* x, int32_t x_dtype, int64_t ldx, int64_t N, const int32_t* rowptr, const int32_t* col,
                           const int32_t* hub_seg, int64_t num_hub_seg, int32_t hub_threshold, float self_scale,
                           const float* in_col_scale, const float* in_col_shift,
                           int32_t L, const int32_t* widths, const float* const* bw, const float* const* sw,
                           const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
                           float* const* acts, void* const* pack_fwd, void* const* pack_dx, float* col_mean,
-                          float* col_m2, void* workspace, size_t workspace_bytes, void* stream, const char* fn) {
+                          float* col_m2, void* workspace, size_t workspace_bytes, void* stream, const char* fn,
+                          const GineStage* gine = nullptr) {
     (void)fn;
     KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && bw && sw && acts && pack_fwd && pack_dx, "bad argument");
     KAGNN_CHECK_ARG((in_col_scale == nullptr) == (in_col_shift == nullptr), "in_col_scale and in_col_shift must both be given or both be null");
@@ -891,11 +976,14 @@ static int layer_fwd_impl(const void* x, int32_t x_dtype, int64_t ldx, int64_t N
     // layer forward: 0.60 vs 0.56 ms at 8 input features, 1.06 vs 0.62 at 32; profiles/r03_experiments.md).
     const char* fuse_e = getenv("KAGNN_FUSE_AGG");
     const bool fuse_env = fuse_e != nullptr && atoi(fuse_e) != 0;
-    const bool fuse = fuse_env && !in_col_scale && x_dtype == KAGNN_DTYPE_F32 && mode == KAGNN_PREC_SPLIT && !(L == 1 && col_mean) &&
+    const bool fuse = fuse_env && !gine && !in_col_scale && x_dtype == KAGNN_DTYPE_F32 && mode == KAGNN_PREC_SPLIT && !(L == 1 && col_mean) &&
                       use_sparse_fwd(widths[0], widths[1], G, K, mode) &&
                       kan_sparse_fwd_agg_ok(static_cast<const float*>(x), ldx, N, widths[0], widths[1], G, K);
-    // 1. h0 = self_scale * x_i + sum_{j -> i} x_j
-    if (fuse)
+    // 1. h0 = self_scale * x_i + sum_{j -> i} x_j      (GINE: sum_{j -> i} relu(x_j + e_ij))
+    if (gine)
+        rc = kagnn_aggregate_gine(static_cast<const float*>(x), ldx, gine->ea, gine->lde, acts[0], widths[0], rowptr, col, gine->perm, N,
+                                  widths[0], self_scale, stream);
+    else if (fuse)
         rc = KAGNN_OK;                       // (produced by the first forward kernel, step 3)
     else if (x_dtype == KAGNN_DTYPE_BF16)
         rc = kagnn_aggregate_sum_bf16(x, ldx, acts[0], widths[0], KAGNN_DTYPE_F32, rowptr, col, nullptr, N, widths[0], self_scale,
@@ -908,7 +996,8 @@ static int layer_fwd_impl(const void* x, int32_t x_dtype, int64_t ldx, int64_t N
                                  self_scale, nullptr, nullptr, nullptr, 0, hub_seg, num_hub_seg, hub_threshold, ws, hub_b, stream);
     if (rc) return rc;
     // 2. weight packs: one launch for the whole chain where the shapes allow it
-    bool batched = L >= 2;
+    const bool prepacked = gine && gine->prepacked;
+    bool batched = L >= 2 && !prepacked;
     int in_[8], out_[8];
     for (int l = 0; l < L; ++l) {
         in_[l] = widths[l]; out_[l] = widths[l + 1];
@@ -918,7 +1007,7 @@ static int layer_fwd_impl(const void* x, int32_t x_dtype, int64_t ldx, int64_t N
     if (batched) {
         rc = kagnn_kan_pack_batch(L, bw, sw, sc, in_, out_, G, K, mode, pack_fwd, pack_dx, stream);
         if (rc) return rc;
-    } else {
+    } else if (!prepacked) {
         for (int l = 0; l < L; ++l) {
             rc = kagnn_kan_pack(bw[l], sw[l], sc ? sc[l] : nullptr, in_[l], out_[l], G, K, mode, pack_fwd[l], pack_dx[l], stream);
             if (rc) return rc;
@@ -952,6 +1041,7 @@ int kagnn_gin_kan_layer_fwd(const void* x, int32_t x_dtype, int64_t ldx, int64_t
                             const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
                             float* const* acts, void* const* pack_fwd, void* const* pack_dx, float* col_mean,
                             float* col_m2, void* workspace, size_t workspace_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     return layer_fwd_impl(x, x_dtype, ldx, N, rowptr, col, hub_seg, num_hub_seg, hub_threshold, self_scale, nullptr, nullptr, L, widths,
                           bw, sw, sc, knots, G, K, mode, acts, pack_fwd, pack_dx, col_mean, col_m2, workspace, workspace_bytes, stream, __func__);
 }
@@ -965,6 +1055,7 @@ int kagnn_gin_kan_layer_fwd_affine(const float* x, int64_t ldx, int64_t N, const
                                    const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
                                    float* const* acts, void* const* pack_fwd, void* const* pack_dx, float* col_mean,
                                    float* col_m2, void* workspace, size_t workspace_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     return layer_fwd_impl(x, KAGNN_DTYPE_F32, ldx, N, rowptr, col, hub_seg, num_hub_seg, hub_threshold, self_scale, in_col_scale,
                           in_col_shift, L, widths, bw, sw, sc, knots, G, K, mode, acts, pack_fwd, pack_dx, col_mean, col_m2, workspace,
                           workspace_bytes, stream, __func__);
@@ -986,7 +1077,7 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
                           const float* gx_addend, int64_t ld_addend, const BnStage* bn,
                           float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
                           size_t workspace_bytes, void* stream, const char* fn,
-                          const float* bn_sums_in = nullptr, const StatsOut* so = nullptr) {
+                          const float* bn_sums_in = nullptr, const StatsOut* so = nullptr, const GineStage* gine = nullptr) {
     KAGNN_CHECK_ARG(N >= 0 && L >= 1 && L <= 8 && widths && sw && acts && pack_dx && g_sw, "bad argument");
     KAGNN_CHECK_ARG(!gx_addend || (gx && gx_dtype == KAGNN_DTYPE_F32 && !bf16_gather && ld_addend >= widths[0]),
                     "gx_addend needs an fp32 gx and fp32 gather operands");
@@ -1085,6 +1176,9 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
     }
     if (gx == nullptr) return KAGNN_OK;
     const int f0 = widths[0];
+    if (gine)        // GINE: gradient of the relu(x_j + e_ij) messages on the transposed structure -> gx and the edge-attribute gradient
+        return gine_bwd(gine->x, gine->ldx, gine->ea, gine->lde, g, ldg, static_cast<float*>(gx), ldgx, gine->g_ea, gine->ldge,
+                        rowptr_t, col_t, gine->perm, N, f0, self_scale, as_stream(stream), gine->accumulate_g_ea);
     if (gh0_bf16 || gx_dtype == KAGNN_DTYPE_BF16) {
         const void* src = g;
         if (!gh0_bf16) {                          // fp32 d loss / d h0 but a bf16 result wanted: convert, then the bf16 kernel
@@ -1126,6 +1220,7 @@ int kagnn_gin_kan_layer_bwd_add(const float* gy, int64_t ldgy, int64_t N, const 
                                 const float* gx_addend, int64_t ld_addend,
                                 float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
                                 size_t workspace_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     return layer_bwd_impl(gy, ldgy, N, rowptr_t, col_t, hub_seg_t, num_hub_seg_t, hub_threshold, self_scale, L, widths, sw, sc, knots, G, K,
                           mode, acts, pack_dx, gx, gx_dtype, ldgx, bf16_gather, gx_addend, ld_addend, nullptr, g_bw, g_sw, g_sc, workspace,
                           workspace_bytes, stream, __func__);
@@ -1153,6 +1248,7 @@ int kagnn_gin_kan_layer_bwd_bn(const float* g, int64_t ldg, const float* y, int6
                                const float* gx_addend, int64_t ld_addend,
                                float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
                                size_t workspace_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     const BnStage bn{y, ldy, bn_weight, bn_mean, bn_rstd, g_bn_weight, g_bn_bias};
     return layer_bwd_impl(g, ldg, N, rowptr_t, col_t, hub_seg_t, num_hub_seg_t, hub_threshold, self_scale, L, widths, sw, sc, knots, G, K,
                           mode, acts, pack_dx, gx, gx_dtype, ldgx, bf16_gather, gx_addend, ld_addend, &bn, g_bw, g_sw, g_sc, workspace,
@@ -1187,6 +1283,7 @@ int kagnn_gin_kan_layer_bwd_bn_sums(const float* g, int64_t ldg, const float* y,
                                     const float* gx_addend, int64_t ld_addend,
                                     float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
                                     size_t workspace_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     const BnStage bn{y, ldy, bn_weight, bn_mean, bn_rstd, g_bn_weight, g_bn_bias};
     const StatsOut so{prev_y, ld_prev_y, prev_mean, prev_rstd, prev_sums};
     KAGNN_CHECK_ARG((prev_sums == nullptr) == (prev_y == nullptr), "prev_y and prev_sums come together");
@@ -1202,9 +1299,170 @@ int kagnn_gin_kan_layer_bwd(const float* gy, int64_t ldgy, int64_t N, const int3
                             const void* const* pack_dx, void* gx, int32_t gx_dtype, int64_t ldgx, int32_t bf16_gather,
                             float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
                             size_t workspace_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
     return kagnn_gin_kan_layer_bwd_add(gy, ldgy, N, rowptr_t, col_t, hub_seg_t, num_hub_seg_t, hub_threshold, self_scale, L, widths, sw,
                                        sc, knots, G, K, mode, acts, pack_dx, gx, gx_dtype, ldgx, bf16_gather, nullptr, 0, g_bw, g_sw,
                                        g_sc, workspace, workspace_bytes, stream);
+}
+
+// ---- the same ONE call per convolution each way around GINE message passing (BASELINE config 4: the ZINC-shaped mini-batch step is
+// host- and launch-bound, graph_regression/models.py:107-119, optuna_zinc.py:56-66).  Forward = kagnn_aggregate_gine + one pack
+// launch + the chain (column moments of the output for the BatchNorm1d that follows, when col_mean is given); backward = [the norm's
+// statistics pass and its element-wise backward inside the last input-gradient kernel, when bn_y is given] + the chain's
+// dW / dX + kagnn_aggregate_gine_bwd.  Same kernels, same order, same bits as the per-operation composition.  fp32 rows; the
+// structure arrays are those of kagnn_csr_build (forward: by destination; backward: by source), small graphs: no hub segments.
+// Workspace: kagnn_gin_kan_layer_workspace_bytes (num_hub_seg = 0) [+ kagnn_gin_kan_layer_bwd_bn_workspace_bytes].
+int kagnn_gine_kan_layer_fwd(const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int64_t N, const int32_t* rowptr,
+                             const int32_t* col, const int32_t* perm, float self_scale,
+                             int32_t L, const int32_t* widths, const float* const* bw, const float* const* sw,
+                             const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
+                             float* const* acts, void* const* pack_fwd, void* const* pack_dx, float* col_mean,
+                             float* col_m2, void* workspace, size_t workspace_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
+    KAGNN_CHECK_ARG(N == 0 || (x && edge_attr && perm && widths && ldx >= widths[0] && lde >= widths[0]), "null array or short leading dimension");
+    const GineStage gs{x, ldx, edge_attr, lde, perm, nullptr, 0};
+    return layer_fwd_impl(x, KAGNN_DTYPE_F32, ldx, N, rowptr, col, nullptr, 0, 0, self_scale, nullptr, nullptr, L, widths, bw, sw, sc,
+                          knots, G, K, mode, acts, pack_fwd, pack_dx, col_mean, col_m2, workspace, workspace_bytes, stream, __func__, &gs);
+}
+
+int kagnn_gine_kan_layer_bwd(const float* g, int64_t ldg, const float* bn_y, int64_t ld_bn_y, const float* bn_weight,
+                             const float* bn_mean, const float* bn_rstd, float* g_bn_weight, float* g_bn_bias,
+                             const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int64_t N,
+                             const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t, float self_scale,
+                             int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
+                             const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
+                             const void* const* pack_dx, float* gx, int64_t ldgx, float* g_edge_attr, int64_t ldge,
+                             float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
+    KAGNN_CHECK_ARG(N == 0 || (x && edge_attr && perm_t && gx && widths && ldx >= widths[0] && lde >= widths[0] && ldgx >= widths[0]),
+                    "null array or short leading dimension (gx is required: the edge-attribute gradient comes out of the same kernel)");
+    KAGNN_CHECK_ARG(!g_edge_attr || ldge >= widths[0], "short leading dimension of g_edge_attr");
+    const GineStage gs{x, ldx, edge_attr, lde, perm_t, g_edge_attr, ldge};
+    const BnStage bn{bn_y, ld_bn_y, bn_weight, bn_mean, bn_rstd, g_bn_weight, g_bn_bias};
+    return layer_bwd_impl(g, ldg, N, rowptr_t, col_t, nullptr, 0, 0, self_scale, L, widths, sw, sc, knots, G, K, mode, acts, pack_dx,
+                          gx, KAGNN_DTYPE_F32, ldgx, 0, nullptr, 0, bn_y ? &bn : nullptr, g_bw, g_sw, g_sc, workspace, workspace_bytes,
+                          stream, __func__, nullptr, nullptr, &gs);
+}
+
+// ---- the WHOLE message-passing stack of a graph-level model in one call each way (round 5): nconv x {GINE convolution around a KAN
+// chain of L layers -> training-mode BatchNorm1d}, every chain hidden -> ... -> hidden with the same widths (reference
+// graph_regression/models.py:107-119: `for i in range(n_layers): x = self.bn[i](self.conv[i](x, edge_index, edge_attr))`).  On a
+// 256-molecule mini-batch a convolution is ~100 us of device work; as one tape node per convolution the HOST spent ~100 us per node
+// each way on argument marshalling and allocations -- the step was host-bound at twice its device time.  Forward: ONE pack launch for
+// all nconv * L layers, then per convolution kagnn_aggregate_gine, the chain (column moments from the last kernel) and the
+// normalising pass -> h[i].  Backward: per convolution (last first) the norm's statistics pass, its element-wise backward inside
+// the last input-gradient kernel, dW / dX, kagnn_aggregate_gine_bwd; the edge-attribute gradients of the nconv convolutions add
+// up in g_edge_attr in place.  Same kernels and orders as nconv calls of kagnn_gine_kan_layer_fwd / _bwd: same bits.
+// Array arguments: widths [L + 1] (widths[0] == widths[L]); per layer, convolution-major [nconv * L]: base_weight, spline_weight,
+// spline_scaler, pack_fwd, pack_dx, g_*; acts [nconv * (L + 1)]; per convolution [nconv]: self_scale / momentum / eps (HOST floats),
+// bn_weight, bn_bias, running_mean, running_var (device; the last two NULL arrays or NULL entries: no running statistics), h,
+// save_mean, save_rstd, g_bn_weight, g_bn_bias.  Workspace: kagnn_gine_kan_stack_workspace_bytes.
+int kagnn_gine_kan_stack_workspace_bytes(int64_t N, int32_t nconv, int32_t L, const int32_t* widths, int32_t G, int32_t K, int32_t mode,
+                                         size_t* fwd_bytes, size_t* bwd_bytes) {
+    ModeScope mode_scope_(mode);
+    KAGNN_CHECK_ARG(N >= 0 && nconv >= 1 && L >= 1 && L <= 8 && widths && fwd_bytes && bwd_bytes, "bad argument");
+    KAGNN_CHECK_ARG(widths[0] == widths[L], "every convolution of the stack maps hidden -> hidden");
+    size_t f = 0, b = 0, bn = 0, bw = 0;
+    int rc = kagnn_gin_kan_layer_workspace_bytes(N, L, widths, G, K, mode, 0, 0, &f, &b);
+    if (rc) return rc;
+    rc = kagnn_batchnorm_workspace_bytes(N, widths[L], &bn); if (rc) return rc;
+    rc = kagnn_gin_kan_layer_bwd_bn_workspace_bytes(N, widths[L], &bw); if (rc) return rc;
+    *fwd_bytes = al256z(f) + al256z(bn) + al256z(2 * (size_t)widths[L] * sizeof(float)) + 256;
+    *bwd_bytes = al256z(b + bw) + 2 * al256z((size_t)N * widths[0] * sizeof(float)) + 256;
+    return KAGNN_OK;
+}
+
+int kagnn_gine_kan_stack_fwd(const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int64_t N, const int32_t* rowptr,
+                             const int32_t* col, const int32_t* perm, const float* self_scale, int32_t nconv,
+                             int32_t L, const int32_t* widths, const float* const* bw, const float* const* sw,
+                             const float* const* sc, const float* knots, int32_t G, int32_t K, int32_t mode,
+                             float* const* acts, void* const* pack_fwd, void* const* pack_dx,
+                             const float* const* bn_weight, const float* const* bn_bias, float* const* running_mean,
+                             float* const* running_var, const float* momentum, const float* eps,
+                             float* const* h, float* const* save_mean, float* const* save_rstd,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
+    KAGNN_CHECK_ARG(nconv >= 1 && L >= 1 && L <= 8 && widths && self_scale && bw && sw && acts && pack_fwd && pack_dx && bn_weight && bn_bias &&
+                    momentum && eps && h && save_mean && save_rstd, "null array");
+    KAGNN_CHECK_ARG(widths[0] == widths[L] && N >= 2, "hidden -> hidden chains, at least two rows (batch statistics)");
+    size_t need_f = 0, need_b = 0, lf = 0, lb = 0, bnb = 0;
+    int rc = kagnn_gine_kan_stack_workspace_bytes(N, nconv, L, widths, G, K, mode, &need_f, &need_b);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(workspace && workspace_bytes >= need_f, "workspace too small (kagnn_gine_kan_stack_workspace_bytes)");
+    rc = kagnn_gin_kan_layer_workspace_bytes(N, L, widths, G, K, mode, 0, 0, &lf, &lb); if (rc) return rc;
+    rc = kagnn_batchnorm_workspace_bytes(N, widths[L], &bnb); if (rc) return rc;
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    unsigned char* ws_bn = ws + al256z(lf);
+    float* mom = reinterpret_cast<float*>(ws_bn + al256z(bnb));
+    const int H = widths[L];
+    // one pack launch for the whole stack where the shapes allow it (<= 16 layers on the sparse-forward / split path)
+    int in_[16], out_[16];
+    bool batch = nconv * L <= 16;
+    for (int k = 0; k < nconv * L && batch; ++k) {
+        in_[k] = widths[k % L]; out_[k] = widths[k % L + 1];
+        batch = use_split_dx(in_[k], out_[k], G, K, mode) && use_sparse_fwd(in_[k], out_[k], G, K, mode) && kan_fused_pack_ok(in_[k], out_[k], G + K);
+    }
+    if (batch) { rc = kagnn_kan_pack_batch(nconv * L, bw, sw, sc, in_, out_, G, K, mode, pack_fwd, pack_dx, stream); if (rc) return rc; }
+    const float* in = x;
+    int64_t ldin = ldx;
+    for (int i = 0; i < nconv; ++i) {
+        GineStage gs{in, ldin, edge_attr, lde, perm, nullptr, 0};
+        gs.prepacked = batch ? 1 : 0;
+        rc = layer_fwd_impl(in, KAGNN_DTYPE_F32, ldin, N, rowptr, col, nullptr, 0, 0, self_scale[i], nullptr, nullptr, L, widths, bw + i * L,
+                            sw + i * L, sc ? sc + i * L : nullptr, knots, G, K, mode, acts + i * (L + 1), pack_fwd + i * L, pack_dx + i * L,
+                            mom, mom + H, ws, al256z(lf), stream, __func__, &gs);
+        if (rc) return rc;
+        rc = kagnn_batchnorm_fwd(acts[i * (L + 1) + L], H, N, H, bn_weight[i], bn_bias[i], running_mean ? running_mean[i] : nullptr,
+                                 running_var ? running_var[i] : nullptr, momentum[i], eps[i], 1, mom, mom + H, 0.0f, 0ULL, h[i], H,
+                                 save_mean[i], save_rstd[i], ws_bn, bnb, stream);
+        if (rc) return rc;
+        in = h[i]; ldin = H;
+    }
+    return KAGNN_OK;
+}
+
+int kagnn_gine_kan_stack_bwd(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int64_t N,
+                             const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t, const float* self_scale,
+                             int32_t nconv, int32_t L, const int32_t* widths, const float* const* sw, const float* const* sc,
+                             const float* knots, int32_t G, int32_t K, int32_t mode, const float* const* acts,
+                             const void* const* pack_dx, const float* const* h, const float* const* bn_weight,
+                             const float* const* save_mean, const float* const* save_rstd,
+                             float* gx, int64_t ldgx, float* g_edge_attr, int64_t ldge, float* const* g_bn_weight, float* const* g_bn_bias,
+                             float* const* g_bw, float* const* g_sw, float* const* g_sc, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    ModeScope mode_scope_(mode);
+    KAGNN_CHECK_ARG(nconv >= 1 && L >= 1 && L <= 8 && widths && self_scale && sw && acts && pack_dx && h && bn_weight && save_mean && save_rstd &&
+                    g_bn_weight && g_bn_bias && g_sw && gx && x && edge_attr, "null array");
+    KAGNN_CHECK_ARG(widths[0] == widths[L] && N >= 2 && ldgx >= widths[0], "hidden -> hidden chains, at least two rows");
+    size_t need_f = 0, need_b = 0, lf = 0, lb = 0, bwb = 0;
+    int rc = kagnn_gine_kan_stack_workspace_bytes(N, nconv, L, widths, G, K, mode, &need_f, &need_b);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(workspace && workspace_bytes >= need_b, "workspace too small (kagnn_gine_kan_stack_workspace_bytes)");
+    rc = kagnn_gin_kan_layer_workspace_bytes(N, L, widths, G, K, mode, 0, 0, &lf, &lb); if (rc) return rc;
+    rc = kagnn_gin_kan_layer_bwd_bn_workspace_bytes(N, widths[L], &bwb); if (rc) return rc;
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    const int H = widths[0];
+    const size_t gbytes = al256z((size_t)N * H * sizeof(float));
+    float* pp[2] = {reinterpret_cast<float*>(ws + al256z(lb + bwb)), reinterpret_cast<float*>(ws + al256z(lb + bwb) + gbytes)};
+    const float* gcur = g;
+    int64_t ldcur = ldg;
+    for (int i = nconv - 1; i >= 0; --i) {
+        const float* in = i == 0 ? x : h[i - 1];
+        const int64_t ldin = i == 0 ? ldx : H;
+        float* gout = i == 0 ? gx : pp[i & 1];
+        const int64_t ldo = i == 0 ? ldgx : H;
+        GineStage gs{in, ldin, edge_attr, lde, perm_t, g_edge_attr, ldge};
+        gs.accumulate_g_ea = i < nconv - 1 ? 1 : 0;
+        const BnStage bn{acts[i * (L + 1) + L], H, bn_weight[i], save_mean[i], save_rstd[i], g_bn_weight[i], g_bn_bias[i]};
+        rc = layer_bwd_impl(gcur, ldcur, N, rowptr_t, col_t, nullptr, 0, 0, self_scale[i], L, widths, sw + i * L, sc ? sc + i * L : nullptr, knots,
+                            G, K, mode, acts + i * (L + 1), pack_dx + i * L, gout, KAGNN_DTYPE_F32, ldo, 0, nullptr, 0, &bn,
+                            g_bw ? g_bw + i * L : nullptr, g_sw + i * L, g_sc ? g_sc + i * L : nullptr, ws, al256z(lb + bwb), stream, __func__,
+                            nullptr, nullptr, &gs);
+        if (rc) return rc;
+        gcur = gout; ldcur = ldo;
+    }
+    return KAGNN_OK;
 }
 
 }  // extern "C"

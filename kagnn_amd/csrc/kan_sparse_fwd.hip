@@ -210,13 +210,16 @@ struct SpParts { const float* p[8]; int ld[8];
                  const float* sc[8]; const float* sh[8]; };     // per chunk: NULL, or the 64 column scales / shifts of a block that
                                                                 // exists only as scale * x + shift (a folded BatchNorm1d, round 4)
 
-template <int OT, bool SH, bool MOM, bool NARROW = false, int AGG = -1, bool PARTS = false>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
+// HALF (KAGNN_PREC_HALF, split_common.h): one fp16 product per fp32 product -- bases and SiLU rounded once (RNE), only the hi
+// fragments of the packed weights are read: one sparse MFMA per step and tile instead of three, no lo payloads / placements
+template <int OT, bool SH, bool MOM, bool NARROW = false, int AGG = -1, bool PARTS = false, bool HALF = false>      // SH: 9..16 coefficients as 2*in virtual features (two 8-slot windows per input feature)
 __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     const float* __restrict__ x, long ldx, long N, int in, const float* __restrict__ knots_g, int nknots,
     const unsigned char* __restrict__ pack, int nchunks, float* __restrict__ y, long ldy, int out,
     int chunks_per_split, long part_stride, float* __restrict__ mom_partial, SpAgg ag, SpParts xp) {
     static_assert(AGG < 0 || (NARROW && !SH && !MOM), "the fused aggregation serves plain narrow layers");
     static_assert(!PARTS || (!NARROW && !SH && !MOM && AGG < 0), "column blocks: plain wide layers");
+    static_assert(!HALF || (!SH && AGG < 0), "single-product mode: layers of <= 8 coefficients, no fused aggregation");
     constexpr int NT = 512, CF = kSpCF, BPC = CF / 16, NG = CF / 16, ROWS = (NT / 64) * 32;
     const int HF = NARROW ? sp_hf(in << (SH ? 1 : 0)) : CF / 2;    // features per lane half: CF / 2, or 16 / 8 in narrow layers
     constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 2 * 1024;
@@ -484,9 +487,11 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     // the other buffer -- which the half after this one now streams into
                     lds_dma_wait();
                     __syncthreads();
+#ifndef KAGNN_ABLATE_FWD_NO_REFILL        // TIMING-ONLY ablation (wrong results): what the streamed forward costs without its L2 -> LDS refills
                     if (g == 0) dma_half(ch, 1);
                     else if (ch + 1 < ch_end) dma_half(ch + 1, 0);
                     else if ((tile + gridDim.x) * ROWS < N) dma_half(ch_begin, 0);
+#endif
                 }
                 float xv[8];
 #pragma unroll
@@ -518,12 +523,19 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     const unsigned char* wp = hb + (size_t)((4 * (g & 1) + s) * OT) * 2 * 2048 + lane * 16;
 #pragma unroll
                     for (int i = 0; i < 2 * OT; ++i) {      // [ot][hi|lo] x two 16-byte halves, a KiB apart
+                        if (HALF && (i & 1)) continue;      // (single-product mode: the hi fragments only)
                         w[2 * i] = *reinterpret_cast<const u32x4*>(wp + i * 2048);
                         w[2 * i + 1] = *reinterpret_cast<const u32x4*>(wp + i * 2048 + 1024);
                     }
                 };
                 auto build = [&](int s, const u32x4& e0, const u32x4& e1, float u0, float u1, u32x4& hi, u32x4& lo, int& idx) {
-                    unsigned a0, a1, a2, a3, b0, b1, b2, b3, h0, h1, l0, l1;
+                    unsigned a0, a1, a2, a3, b0 = 0, b1 = 0, b2 = 0, b3 = 0, h0, h1, l0, l1;
+                    if constexpr (HALF) {            // rounded once: hi payloads and placements only
+                        unsigned ph[2][2];
+                        frag3_payload_pair_h(u0, u1, ph);
+                        a0 = __builtin_amdgcn_perm(ph[0][1], ph[0][0], e0[0]); a1 = __builtin_amdgcn_perm(ph[0][1], ph[0][0], e0[1]);
+                        a2 = __builtin_amdgcn_perm(ph[1][1], ph[1][0], e1[0]); a3 = __builtin_amdgcn_perm(ph[1][1], ph[1][0], e1[1]);
+                    } else
                     if constexpr (!SH) {             // the step's two scalars on packed fp32 (forward 0.399 -> 0.388 ms per step)
                         unsigned ph[2][2], pl[2][2];
                         frag3_payload_pair(u0, u1, ph, pl);
@@ -552,16 +564,18 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     if (s < 3) prep_reads(s + 1, e0, e1, u0, u1, nbw);
 #pragma unroll
                     for (int t = 0; t < OT; ++t) acc[t] = smfmac(ahi, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
+                    if constexpr (!HALF) {
 #pragma unroll
-                    for (int t = 0; t < OT; ++t) acc[t] = smfmac(ahi, bw[4 * t + 2], bw[4 * t + 3], acc[t], aidx);
+                        for (int t = 0; t < OT; ++t) acc[t] = smfmac(ahi, bw[4 * t + 2], bw[4 * t + 3], acc[t], aidx);
 #pragma unroll
-                    for (int t = 0; t < OT; ++t) acc[t] = smfmac(alo, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
+                        for (int t = 0; t < OT; ++t) acc[t] = smfmac(alo, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
+                    }
                     if (s < 3) {
                         u32x4 nhi, nlo; int nidx;
                         build(s + 1, e0, e1, u0, u1, nhi, nlo, nidx);
                         ahi = nhi; alo = nlo; aidx = nidx;
 #pragma unroll
-                        for (int i = 0; i < 4 * OT; ++i) bw[i] = nbw[i];
+                        for (int i = 0; i < 4 * OT; ++i) { if (HALF && ((i >> 1) & 1)) continue; bw[i] = nbw[i]; }
                     } else {
                         float smx = 0.0f;
 #pragma unroll
@@ -573,7 +587,8 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                         }
                         big = __any(!(smx < 60000.0f) || sv[0] != sv[0] || sv[1] != sv[1] || sv[2] != sv[2] || sv[3] != sv[3] ||
                                     sv[4] != sv[4] || sv[5] != sv[5] || sv[6] != sv[6] || sv[7] != sv[7]);   // wave-uniform
-                        split_f16x2(sv, sh_hi, sh_lo);
+                        if constexpr (HALF) { round_f16x2(sv, sh_hi); sh_lo = sh_hi; }
+                        else split_f16x2(sv, sh_hi, sh_lo);
                     }
                 }
                 if (!big) {
@@ -581,10 +596,12 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
 #pragma unroll
                     for (int t = 0; t < OT; ++t) {
                         const u32x4 wh = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 0) * 1024);
-                        const u32x4 wl = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 1) * 1024);
                         acc_b[t] = mfma_f16(sh_hi, wh, acc_b[t]);
-                        acc_b[t] = mfma_f16(sh_hi, wl, acc_b[t]);
-                        acc_b[t] = mfma_f16(sh_lo, wh, acc_b[t]);
+                        if constexpr (!HALF) {
+                            const u32x4 wl = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 1) * 1024);
+                            acc_b[t] = mfma_f16(sh_hi, wl, acc_b[t]);
+                            acc_b[t] = mfma_f16(sh_lo, wh, acc_b[t]);
+                        }
                     }
                 } else {
                     // values beyond fp16 range (|x| > ~3700) or non-finite: this group's SiLU branch in exact fp32,
@@ -717,7 +734,7 @@ int kan_fused_pack(const float* bw, const float* sw, const float* sc, int in, in
 
 // the same for up to kPackBatch layers of a chain in ONE launch (each ~22 us pack launch is latency, not work:
 // a two-layer chain saves one of them per step)
-constexpr int kPackBatch = 8;
+constexpr int kPackBatch = 16;          // (round 5: the whole GINE stack of a graph-level model packs in one launch: 4 convs x 2 layers + ...)
 struct PackBatch {
     const float* bw[kPackBatch]; const float* sw[kPackBatch]; const float* sc[kPackBatch];
     unsigned char* pf[kPackBatch]; unsigned char* pd[kPackBatch];
@@ -743,7 +760,7 @@ __global__ void fused_pack_batch_kernel(PackBatch b) {
 
 int kan_fused_pack_batch(int n, const float* const* bw, const float* const* sw, const float* const* sc, const int* in,
                          const int* out, int C, void* const* pack_fwd, void* const* pack_dx, hipStream_t st) {
-    if (n < 1 || n > kPackBatch) return fail(KAGNN_ERR_UNSUPPORTED, "%s: 1..8 layers per batch", "kan_fused_pack_batch");
+    if (n < 1 || n > kPackBatch) return fail(KAGNN_ERR_UNSUPPORTED, "%s: 1..16 layers per batch", "kan_fused_pack_batch");
     PackBatch b{};
     b.n = n; b.C = C; b.blk0[0] = 0;
     for (int l = 0; l < n; ++l) {
@@ -794,14 +811,18 @@ bool kan_sparse_fwd_moments_ok(long N, int in, int out, int G, int K) {
 }
 size_t kan_sparse_fwd_moments_ws_bytes(long N, int out) { return (size_t)sp_grid(N) * 3 * min(out, kSpOutBlk) * sizeof(float); }
 
-template <int OT, bool SH, bool MOM, bool NARROW>
+template <int OT, bool SH, bool MOM, bool NARROW, bool HALF = false>
 static int launch_sparse(const float* x, long ldx, long N, int in, const float* knots, int nknots,
                          const unsigned char* pack, float* y, long ldy, int out, float* ws, size_t ws_bytes,
                          float* col_mean, float* col_m2, hipStream_t st) {
+    if constexpr (!HALF && !SH && !NARROW) {          // single-product mode (thread-local, set by the entry point): its instantiation
+        if (g_half_products)
+            return launch_sparse<OT, SH, MOM, NARROW, true>(x, ldx, N, in, knots, nknots, pack, y, ldy, out, ws, ws_bytes, col_mean, col_m2, st);
+    }
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT) + (MOM ? 8 * OT * 64 * sizeof(float) : 0);
     static unsigned long long configured = 0;          // (per device: common.h)
     if (first_use_on_this_device(configured)) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH, MOM, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH, MOM, NARROW, -1, false, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int nchunks = cdiv(in << (SH ? 1 : 0), kSpCF);
     const int gx = sp_grid(N);
@@ -810,21 +831,21 @@ static int launch_sparse(const float* x, long ldx, long N, int in, const float* 
         if (p.splits > 1) return fail(KAGNN_ERR_UNSUPPORTED, "%s: no column moments from a launch split over the chunks", "kan_sparse_fwd");
         if (!ws || ws_bytes < (size_t)gx * 3 * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small for the column moments", "kan_sparse_fwd");
-        kan_sparse_fwd_kernel<OT, SH, true, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, ws, SpAgg{}, SpParts{});
+        kan_sparse_fwd_kernel<OT, SH, true, NARROW, -1, false, HALF><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, ws, SpAgg{}, SpParts{});
         KAGNN_LAUNCH_CHECK();
         return moments_finish(ws, gx, out, col_mean, col_m2, st);
     }
     if (p.splits > 1) {
         if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_sparse_fwd");
-        kan_sparse_fwd_kernel<OT, SH, false, NARROW><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
+        kan_sparse_fwd_kernel<OT, SH, false, NARROW, -1, false, HALF><<<dim3(gx, p.splits), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, ws, out, out,
                                                                                 p.cps, N * (long)out, nullptr, SpAgg{}, SpParts{});
         KAGNN_LAUNCH_CHECK();
         sparse_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
         KAGNN_LAUNCH_CHECK();
         return KAGNN_OK;
     }
-    kan_sparse_fwd_kernel<OT, SH, false, NARROW><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, nullptr, SpAgg{}, SpParts{});
+    kan_sparse_fwd_kernel<OT, SH, false, NARROW, -1, false, HALF><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, nullptr, SpAgg{}, SpParts{});
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -953,27 +974,30 @@ bool kan_sparse_fwd_parts_ok(const int* widths, int nparts, int in, int out, int
     return sum == in;
 }
 
-template <int OT>
+template <int OT, bool HALF = false>
 static int launch_sparse_parts(const SpParts& xp, long N, int in, const float* knots, int nknots, const unsigned char* pack,
                                float* y, long ldy, int out, float* ws, size_t ws_bytes, hipStream_t st) {
+    if constexpr (!HALF) {
+        if (g_half_products) return launch_sparse_parts<OT, true>(xp, N, in, knots, nknots, pack, y, ldy, out, ws, ws_bytes, st);
+    }
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
     static unsigned long long configured = 0;          // (per device: common.h)
     if (first_use_on_this_device(configured)) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, false, false, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, false, false, false, -1, true, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int nchunks = in / kSpCF, gx = sp_grid(N);
     const SpSplit p = sp_split_plan(N, nchunks);
     if (p.splits > 1) {
         if (!ws || ws_bytes < (size_t)p.splits * N * out * sizeof(float))
             return fail(KAGNN_ERR_ARG, "%s: workspace too small (see kagnn_kan_fwd_workspace_bytes)", "kan_sparse_fwd_parts");
-        kan_sparse_fwd_kernel<OT, false, false, false, -1, true><<<dim3(gx, p.splits), 512, lds, st>>>(
+        kan_sparse_fwd_kernel<OT, false, false, false, -1, true, HALF><<<dim3(gx, p.splits), 512, lds, st>>>(
             xp.p[0], xp.ld[0], N, in, knots, nknots, pack, nchunks, ws, out, out, p.cps, N * (long)out, nullptr, SpAgg{}, xp);
         KAGNN_LAUNCH_CHECK();
         sparse_sum_splits_kernel<<<cdiv(N * out, 256), 256, 0, st>>>(ws, p.splits, N, out, y, ldy);
         KAGNN_LAUNCH_CHECK();
         return KAGNN_OK;
     }
-    kan_sparse_fwd_kernel<OT, false, false, false, -1, true><<<gx, 512, lds, st>>>(xp.p[0], xp.ld[0], N, in, knots, nknots, pack, nchunks, y, ldy,
+    kan_sparse_fwd_kernel<OT, false, false, false, -1, true, HALF><<<gx, 512, lds, st>>>(xp.p[0], xp.ld[0], N, in, knots, nknots, pack, nchunks, y, ldy,
                                                                                     out, nchunks, 0L, nullptr, SpAgg{}, xp);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;

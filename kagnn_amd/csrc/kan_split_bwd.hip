@@ -128,7 +128,9 @@ __device__ __forceinline__ float barrel_dot(const float (&d)[8], int m, const fl
 // starts from.  Per feature tile a lane adds its 8 rows, the four row groups of a wave meet by two shuffles, and the wave adds the
 // tile's 16 columns into its own LDS slots behind the W tiles; the 8 waves are added in order at the end: one partial row pair
 // per workgroup, deterministic.  Needs <= 4 feature tiles per workgroup (in <= 64, no split over blockIdx.y).
-template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false, bool XST = false>
+// HALF (KAGNN_PREC_HALF, split_common.h): gy rounded once per row scale, only the hi W^T fragments are staged and read: 2 MFMAs per
+// (slot, k-step) instead of 6; the V phase (basis derivatives, contraction, SiLU') stays fp32.
+template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false, bool XST = false, bool HALF = false>
 __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
     int out, int C, const float* __restrict__ knots_g, int nknots,
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     static_assert(!BNB || (K == 3 && !GEN && PP == 0 && !GX16), "the fused normalisation backward serves the lean cubic instantiation");
     static_assert(!XAFF || (K == 3 && !GEN && !GX16 && !BNB), "the input affine serves the lean cubic instantiation (the read-out of the node models)");
     static_assert(!XST || XAFF, "the column statistics ride in the read-out instantiation");
+    static_assert(!HALF || (K == 3 && !GEN), "single-product mode: the lean cubic instantiation");
     // GX16: gx rows are bf16 (a compile-time variant of the lean cubic instantiation -- as a run-time flag the 2-byte
     // store path cost every launch 14 %: round 2, profiles/r02_experiments.md)
     const int sh = GEN ? sh_arg : 0;
@@ -159,6 +162,10 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     auto stage = [&](int ft0, int nft) {
         const unsigned char* src = gw + (size_t)ft0 * FT_BYTES;
         const int nblk = nft * (FT_BYTES / 1024);
+        if constexpr (HALF) {                                // [c][q][hi|lo] KiB blocks: the even ones
+            for (int blk = 2 * wave; blk < nblk; blk += 16)
+                lds_dma_1k(src + (size_t)blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_w + blk * 1024));
+        } else
         for (int blk = wave; blk < nblk; blk += 8)
             lds_dma_1k(src + (size_t)blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_w + blk * 1024));
         lds_dma_wait();
@@ -266,7 +273,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = raw[rt][q][j] * sc;
-                split_f16x2_asm(v, ahi[rt][q], alo[rt][q]);
+                if constexpr (HALF) round_f16x2(v, ahi[rt][q]);
+                else split_f16x2_asm(v, ahi[rt][q], alo[rt][q]);
             }
             const float mine = ldexpf(1.0f, e_w + rexp - 10);      // undo factor of this lane's row
 #pragma unroll
@@ -354,23 +362,26 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
 #pragma unroll
                 for (int g = 0; g < RD; ++g) {
                     bh[g] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * g + 0) * 1024);
-                    bl[g] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * g + 1) * 1024);
+                    if constexpr (!HALF) bl[g] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * g + 1) * 1024);
                 }
 #pragma unroll
                 for (int g = 0; g < NGRP; ++g) {
                     const int c = g / Q2, q = g % Q2;      // LDS order is [c][q][hi|lo], i.e. group g at 2g KiB
                     if (g + RD < NGRP) {
                         bh[(g + RD) % (RD + 1)] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * (g + RD) + 0) * 1024);
-                        bl[(g + RD) % (RD + 1)] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * (g + RD) + 1) * 1024);
+                        if constexpr (!HALF) bl[(g + RD) % (RD + 1)] = *reinterpret_cast<const u32x4*>(wft + (size_t)(2 * (g + RD) + 1) * 1024);
                     }
                     __builtin_amdgcn_sched_barrier(0);     // pin: hipcc otherwise sinks the reads back to their first use
-                    const u32x4 bhi = bh[g % (RD + 1)], blo = bl[g % (RD + 1)];
+                    const u32x4 bhi = bh[g % (RD + 1)];
                     D[c][0] = mfma16_f16(ahi[0][q], bhi, D[c][0]);
                     D[c][1] = mfma16_f16(ahi[1][q], bhi, D[c][1]);
-                    D[c][0] = mfma16_f16(ahi[0][q], blo, D[c][0]);
-                    D[c][1] = mfma16_f16(ahi[1][q], blo, D[c][1]);
-                    D[c][0] = mfma16_f16(alo[0][q], bhi, D[c][0]);
-                    D[c][1] = mfma16_f16(alo[1][q], bhi, D[c][1]);
+                    if constexpr (!HALF) {
+                        const u32x4 blo = bl[g % (RD + 1)];
+                        D[c][0] = mfma16_f16(ahi[0][q], blo, D[c][0]);
+                        D[c][1] = mfma16_f16(ahi[1][q], blo, D[c][1]);
+                        D[c][0] = mfma16_f16(alo[0][q], bhi, D[c][0]);
+                        D[c][1] = mfma16_f16(alo[1][q], bhi, D[c][1]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -497,10 +508,14 @@ static int dx_schedule() {
     return v;
 }
 
-template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false, bool XST = false>
+template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false, bool XST = false, bool HALF = false>
 static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                         const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
                         const RbfArgs& rb, int accumulate, hipStream_t st, const BnBack& bnb = BnBack{}) {
+    if constexpr (!HALF && K == 3 && !GEN && Q2 <= 2 && PP != 2) {      // single-product mode (thread-local, set by the entry point)
+        if (g_half_products)
+            return launch_dx_pp<K, Q2, GEN, PP, GX16, BNB, XAFF, XST, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st, bnb);
+    }
     const int sh = vshift(C), FT = cdiv(in << sh, 16);
     const size_t ft_bytes = (size_t)kCTmax * Q2 * 2 * 1024;
     const size_t budget = 160 * 1024 - kLdsHdr;
@@ -515,11 +530,11 @@ static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, lo
     const size_t lds = kLdsHdr + (resident ? fpb : 1) * ft_bytes + (XST ? 8 * 128 * sizeof(float) : 0);
     static unsigned long long configured = 0;          // (per device: common.h)
     if (first_use_on_this_device(configured)) {
-        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF, XST>,
+        KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF, XST, HALF>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     }
     const dim3 grid((unsigned)min(row_blocks, 256L), (unsigned)splits);
-    kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF, XST><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
+    kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF, XST, HALF><<<grid, 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack,
                                                                            resident ? 1 : 0, gx, ldgx, rb, sh, accumulate, fpb, bnb);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
@@ -658,9 +673,14 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
                 for (int reg = 0; reg < 4; ++reg) xq[rt][reg] = gld_s(xb, x_rb + fcol, (unsigned)(16 * rt + reg) * ldx4);
             f32x4 D[kCTmax][2];
             // ================= window 0: slots 0..7 + base
+#ifdef KAGNN_ABLATE_DXW2_NO_STAGE          // TIMING-ONLY ablation (wrong results): no re-staging of W^T, 1 = barriers kept, 2 = barriers dropped too
+            if (KAGNN_ABLATE_DXW2_NO_STAGE == 1) { __syncthreads(); __syncthreads(); }
+            if (tile == (long)blockIdx.x && t == 0) { stage(0, kCTmax); __syncthreads(); }
+#else
             __syncthreads();
             stage(2 * t, kCTmax);
             __syncthreads();
+#endif
 #pragma unroll
             for (int c = 0; c < kCTmax; ++c) { D[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             {
@@ -712,9 +732,13 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
                 }
             }
             // ================= window 1: its C - 8 live slots only
+#ifdef KAGNN_ABLATE_DXW2_NO_STAGE
+            if (KAGNN_ABLATE_DXW2_NO_STAGE == 1) { __syncthreads(); __syncthreads(); }
+#else
             __syncthreads();
             stage(2 * t + 1, ns1);
             __syncthreads();
+#endif
             f32x4 D1[NS1][2];
 #pragma unroll
             for (int c = 0; c < NS1; ++c) { D1[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D1[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -936,7 +960,9 @@ template <int NTO> struct DwRaw { float x[8]; float g[NTO][8]; float mu[8], rs[8
 // (16 x 32 outputs, 72 accumulators, 198 registers: TWO waves per SIMD) was measured in round 3 and is not instantiated: the
 // basis expansion runs twice and the pair gains nothing from sharing the SIMD -- 0.769 vs 0.604 ms per step
 // (profiles/r03_experiments.md)
-template <int K, bool GEN, int RS = 1, int NTO = 4, bool XAFF = false>      // GEN == false: <= 8 coefficients, no virtual-feature code (see kan_split_dx_kernel)
+// HALF (KAGNN_PREC_HALF, split_common.h): bases, SiLU and gy rounded once -- no lo fragments, no lo transposition, one MFMA
+// per (slot plane, output tile) instead of three
+template <int K, bool GEN, int RS = 1, int NTO = 4, bool XAFF = false, bool HALF = false>      // GEN == false: <= 8 coefficients, no virtual-feature code (see kan_split_dx_kernel)
                                                                              // XAFF: the input is rb.x_affine's scale * x + shift (a folded BatchNorm1d)
 __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gy, long ldgy, long N, int in,
@@ -1057,7 +1083,8 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
             if constexpr (K == 3) {
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    make_spline_frag3_pair(xr[j], xr[j + 1], s_tbl, fgeo, rh[j], rl[j], rh[j + 1], rl[j + 1], woff);
+                    if constexpr (HALF) make_spline_frag3_pair_h(xr[j], xr[j + 1], s_tbl, fgeo, rh[j], rh[j + 1], woff);
+                    else make_spline_frag3_pair(xr[j], xr[j + 1], s_tbl, fgeo, rh[j], rl[j], rh[j + 1], rl[j + 1], woff);
                 }
             } else
 #pragma unroll
@@ -1079,7 +1106,7 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
                 smx = fmaxf(fmaxf(smx, fabsf(pr.x)), fabsf(pr.y));
             }
             const bool base32 = __any(!(smx < 60000.0f));   // wave-uniform; also catches NaN / Inf
-            split_f16x2(sv, sah, sal);
+            if constexpr (HALF) round_f16x2(sv, sah); else split_f16x2(sv, sah, sal);
             if (chunk_exp(raw) > T) return false;            // wave-uniform, rare: rescale outside, then redo this chunk
             if constexpr (K == 0) {
                 if (bias_on) {
@@ -1100,7 +1127,7 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
                     const f32x2 pr = f32x2{raw.g[t][j], raw.g[t][j + 1]} * splat2(gs);
                     v[j] = pr.x; v[j + 1] = pr.y;
                 }
-                split_f16x2(v, bhi[t], blo[t]);
+                if constexpr (HALF) round_f16x2(v, bhi[t]); else split_f16x2(v, bhi[t], blo[t]);
             }
             if (base32) {                                    // rare: this chunk's base branch in exact fp32, at Dh's scale
                 const float gs16 = gs * 16.0f;               // (4 rows per MFMA, k-lane kg <-> row 8*kg + j)
@@ -1121,22 +1148,26 @@ __global__ __launch_bounds__(256, NTO == 4 ? 1 : 2) void kan_split_dw_kernel(
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     ah[p] = __builtin_amdgcn_perm(rh[2 * p + 1][q], rh[2 * p][q], sel);
-                    al[p] = __builtin_amdgcn_perm(rl[2 * p + 1][q], rl[2 * p][q], sel);
+                    if constexpr (!HALF) al[p] = __builtin_amdgcn_perm(rl[2 * p + 1][q], rl[2 * p][q], sel);
                 }
 #pragma unroll
                 for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(ah, bhi[t], D[c][t]);
+                if constexpr (!HALF) {
 #pragma unroll
-                for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(ah, blo[t], D[c][t]);
+                    for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(ah, blo[t], D[c][t]);
 #pragma unroll
-                for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(al, bhi[t], D[c][t]);
+                    for (int t = 0; t < NTO; ++t) D[c][t] = mfma16_f16(al, bhi[t], D[c][t]);
+                }
             }
             if (!base32) {
 #pragma unroll
                 for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(sah, bhi[t], Dh[t]);
+                if constexpr (!HALF) {
 #pragma unroll
-                for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(sah, blo[t], Dh[t]);
+                    for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(sah, blo[t], Dh[t]);
 #pragma unroll
-                for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(sal, bhi[t], Dh[t]);
+                    for (int t = 0; t < NTO; ++t) Dh[t] = mfma16_f16(sal, bhi[t], Dh[t]);
+                }
             }
         return true;
     };
@@ -1812,7 +1843,7 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
     // (kan_split_dw_shared_kernel: same slabs, bit for bit; KAGNN_DW_SHARED=0 keeps one workgroup per output chunk for A/B)
     const char* dw_env = getenv("KAGNN_DW_SHARED");           // (read per call: the bitwise A/B test flips it inside one process)
     const bool dw_shared = dw_env == nullptr || atoi(dw_env) != 0;
-    if (dw_shared && !rb.x_affine && !sh && (K == 0 || K == 3) && p.rs == 1 && p.OC >= 2 && p.OC % 2 == 0 && in > 32) {
+    if (dw_shared && !(g_half_products && K == 3) && !rb.x_affine && !sh && (K == 0 || K == 3) && p.rs == 1 && p.OC >= 2 && p.OC % 2 == 0 && in > 32) {
         const int SHn = p.OC % 4 == 0 ? 4 : 2;
 #define LS(KK, SS) do { \
             static unsigned long long seen_##KK##_##SS = 0; \
@@ -1830,6 +1861,9 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
         KAGNN_LAUNCH_CHECK();
         return KAGNN_OK;
     }
+    // single-product mode (thread-local, set by the entry point): the cubic, <= 8-coefficient instantiations
+    const bool half = g_half_products && K == 3 && !sh;
+#define LH(RR, NN, XX) kan_split_dw_kernel<3, false, RR, NN, XX, true><<<grid, 256, 0, st>>>(ARGS, 0)
 #define LN(KK) if (p.rs == 4) kan_split_dw_kernel<KK, false, 4><<<grid, 256, 0, st>>>(ARGS, 0); \
                else if (p.rs == 2) kan_split_dw_kernel<KK, false, 2><<<grid, 256, 0, st>>>(ARGS, 0); \
                else if (nto == 3) kan_split_dw_kernel<KK, false, 1, 3><<<grid, 256, 0, st>>>(ARGS, 0); \
@@ -1838,10 +1872,14 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
                else { L(KK); }
     if (rb.x_affine) {                                   // the input is a folded BatchNorm1d output (read-out of the node models)
         if (K != 3 || sh || p.rs != 1) return fail(KAGNN_ERR_UNSUPPORTED, "%s: an input affine needs a cubic layer with <= 8 coefficients and more than 32 inputs", "kan_split_dw");
-        if (nto == 3) kan_split_dw_kernel<3, false, 1, 3, true><<<grid, 256, 0, st>>>(ARGS, 0);
+        if (half) { if (nto == 3) LH(1, 3, true); else if (nto == 2) LH(1, 2, true); else if (nto == 1) LH(1, 1, true); else LH(1, 4, true); }
+        else if (nto == 3) kan_split_dw_kernel<3, false, 1, 3, true><<<grid, 256, 0, st>>>(ARGS, 0);
         else if (nto == 2) kan_split_dw_kernel<3, false, 1, 2, true><<<grid, 256, 0, st>>>(ARGS, 0);
         else if (nto == 1) kan_split_dw_kernel<3, false, 1, 1, true><<<grid, 256, 0, st>>>(ARGS, 0);
         else kan_split_dw_kernel<3, false, 1, 4, true><<<grid, 256, 0, st>>>(ARGS, 0);
+    } else if (half) {
+        if (p.rs == 4) LH(4, 4, false); else if (p.rs == 2) LH(2, 4, false);
+        else if (nto == 3) LH(1, 3, false); else if (nto == 2) LH(1, 2, false); else if (nto == 1) LH(1, 1, false); else LH(1, 4, false);
     } else
     switch (K) {
         case 0: LN(0); break;
@@ -1853,6 +1891,7 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
     }
 #undef L
 #undef LN
+#undef LH
 #undef ARGS
     KAGNN_LAUNCH_CHECK();
     if (!sh) {

@@ -318,6 +318,25 @@ __device__ __forceinline__ void split_f16x2_asm(const float (&v)[8], u32x4& hi, 
     }
 }
 
+// ---- KAGNN_PREC_HALF (round 5; build-defined reduced-precision mode for BASELINE config 2): ONE fp16 product per fp32 product.
+// Every operand is evaluated in fp32 and rounded ONCE, to nearest even (v_cvt_pk_f16_f32: gfx950 has the packed RNE
+// conversion), after the same exact power-of-two pre-scale as the hi part of the split mode -- no `lo` operands, so a third of
+// the matrix-core work and about half of the conversion / placement VALU work.  fp32 accumulation as before.  The HALF
+// instantiations of the three KAN kernels read only the `hi` fragments of the split mode's weight packs (the packs' hi parts
+// are already RNE roundings of w * 2^-e).  The thread-local flag is set by the C entry points (api.hip: ModeScope) for the
+// duration of a call with mode == KAGNN_PREC_HALF; the launchers below pick the HALF instantiation where one exists and the
+// three-product kernels (more accurate, never less) elsewhere.
+extern thread_local bool g_half_products;
+__device__ __forceinline__ unsigned pk_f16_rne(float a, float b) {
+    const f16x2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+// 8 fp32 values (already scaled into fp16 range) -> ONE fp16 fragment, round to nearest even
+__device__ __forceinline__ void round_f16x2(const float (&v)[8], u32x4& hi) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hi[q] = pk_f16_rne(v[2 * q], v[2 * q + 1]);
+}
+
 // drop a 4-half payload {p1:p0} (hi and lo parts) into an 8-slot window with the selectors of one table entry
 __device__ __forceinline__ void frag3_place_fwd(const u32x4& sel, unsigned h0, unsigned h1, unsigned l0,
                                                 unsigned l1, u32x4& ahi, u32x4& alo) {
@@ -463,6 +482,35 @@ __device__ __forceinline__ void make_spline_frag3_pair(float x0, float x1, const
     }
 }
 
+// HALF: the same two scalars, rounded once -- hi fragments only
+__device__ __forceinline__ void make_spline_frag3_pair_h(float x0, float x1, const unsigned* __restrict__ tbl,
+                                                         const FastGeom& g, u32x4& ahi0, u32x4& ahi1, unsigned woff = 0) {
+    const f32x2 x = {x0, x1};
+    const f32x2 t = fma2(x, splat2(g.inv_h), splat2(g.c0));
+    const f32x2 tf = {fminf(fmaxf(floorf(t.x), 0.0f), g.last_span), fminf(fmaxf(floorf(t.y), 0.0f), g.last_span)};
+    const int m0 = (int)tf.x, m1 = (int)tf.y;
+    const f32x2 u = t - tf;
+    const f32x2 w6 = {(x0 >= g.k_first && x0 < g.k_last) ? kAScale / 6.0f : 0.0f,
+                      (x1 >= g.k_first && x1 < g.k_last) ? kAScale / 6.0f : 0.0f};
+    const f32x2 u2 = u * u, om = splat2(1.0f) - u, uw = u * w6, ow = om * w6;
+    const f32x2 N0 = ow * (om * om);
+    const f32x2 N3 = uw * u2;
+    const f32x2 N1 = fma2(uw, fma2(u, splat2(3.0f), splat2(-6.0f)) * u, splat2(4.0f) * w6);
+    const f32x2 N2 = fma2(uw, fma2(fma2(u, splat2(-3.0f), splat2(3.0f)), u, splat2(3.0f)), w6);
+    {
+        const unsigned h0 = pk_f16_rne(N0.x, N1.x), h1 = pk_f16_rne(N2.x, N3.x);
+        const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + woff + 16 * (m0 + 1));
+        ahi0[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi0[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
+        ahi0[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi0[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
+    }
+    {
+        const unsigned h0 = pk_f16_rne(N0.y, N1.y), h1 = pk_f16_rne(N2.y, N3.y);
+        const u32x4 sel = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(tbl) + woff + 16 * (m1 + 1));
+        ahi1[0] = __builtin_amdgcn_perm(h1, h0, sel[0]); ahi1[1] = __builtin_amdgcn_perm(h1, h0, sel[1]);
+        ahi1[2] = __builtin_amdgcn_perm(h1, h0, sel[2]); ahi1[3] = __builtin_amdgcn_perm(h1, h0, sel[3]);
+    }
+}
+
 // ---- the same K == 3 expansion in three pieces, so a caller can software-pipeline it under MFMAs:
 //   frag3_index   : table index of the span (needs only t)           -> issue the LDS table read early
 //   frag3_payload : cubic pieces, fp16 hi/lo payloads (pure VALU)     -> overlaps the MFMAs in flight
@@ -541,6 +589,17 @@ __device__ __forceinline__ void frag3_payload_pair(float u0, float u1, unsigned 
     h[1][0] = pk_f16_rtz(N0.y, N1.y); h[1][1] = pk_f16_rtz(N2.y, N3.y);
     l[1][0] = pk_f16_rtz(sub_f16lo(N0.y, h[1][0]), sub_f16hi(N1.y, h[1][0]));
     l[1][1] = pk_f16_rtz(sub_f16lo(N2.y, h[1][1]), sub_f16hi(N3.y, h[1][1]));
+}
+// HALF: the payloads of two scalars, rounded once (no lo parts)
+__device__ __forceinline__ void frag3_payload_pair_h(float u0, float u1, unsigned (&h)[2][2]) {
+    const f32x2 u = {u0, u1}, w6 = splat2(kAScale / 6.0f);
+    const f32x2 u2 = u * u, om = splat2(1.0f) - u, uw = u * w6, ow = om * w6;
+    const f32x2 N0 = ow * (om * om);
+    const f32x2 N3 = uw * u2;
+    const f32x2 N1 = fma2(uw, fma2(u, splat2(3.0f), splat2(-6.0f)) * u, splat2(4.0f) * w6);
+    const f32x2 N2 = fma2(uw, fma2(fma2(u, splat2(-3.0f), splat2(3.0f)), u, splat2(3.0f)), w6);
+    h[0][0] = pk_f16_rne(N0.x, N1.x); h[0][1] = pk_f16_rne(N2.x, N3.x);
+    h[1][0] = pk_f16_rne(N0.y, N1.y); h[1][1] = pk_f16_rne(N2.y, N3.y);
 }
 __device__ __forceinline__ void frag3_place(const u32x4& sel, unsigned h0, unsigned h1, unsigned l0,
                                             unsigned l1, u32x4& ahi, u32x4& alo) {

@@ -136,7 +136,7 @@ class KANLinear(nn.Module):
     def read_out_blocks_in_one_launch(self, widths) -> bool:
         """would ``forward_parts`` over fp32 blocks of these widths run as one forward launch (``kagnn_kan_fwd_parts_ok``)?"""
         mode = self.precision if self.precision is not None else ops.default_precision()
-        return (self._knots().dim() == 1 and mode == ops.PREC_SPLIT and sum(widths) == self.in_features
+        return (self._knots().dim() == 1 and ops.split_like(mode) and sum(widths) == self.in_features
                 and ops.parts_one_launch_widths_ok(tuple(int(w) for w in widths), self.out_features, self.grid_size, self.spline_order, mode))
 
     def forward_parts(self, parts, skip_gradients=None) -> torch.Tensor:
@@ -216,7 +216,7 @@ class KAN(nn.Module):
         """all layers' weight packs in one launch when the chain runs on the sparse-forward / split kernels"""
         first = self.layers[0]
         mode = first.precision if first.precision is not None else ops.default_precision()
-        if mode != ops.PREC_SPLIT or any(l.precision != first.precision or l._knots().dim() != 1 for l in self.layers):
+        if not ops.split_like(mode) or any(l.precision != first.precision or l._knots().dim() != 1 for l in self.layers):
             return None
         if x.size(0) == 0 or not ops._fits32(x, 1):
             return None

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .models import (FASTKAGATConv, FASTKAGCNConv, GIFASTKANLayer, GIKANLayer, KAGATConv, KAGCNConv, conv_bn_dropout,
+from .models import (FASTKAGATConv, FASTKAGCNConv, GIFASTKANLayer, GIKANLayer, KAGATConv, KAGCNConv, _has_hooks, conv_bn_dropout,
                      make_fastkan, make_kan)
 from .norm import BatchNorm1d
 
@@ -45,6 +45,11 @@ class _SumOfEmbeddings(nn.Module):
 
     def forward(self, x):
         tables = getattr(self, self._list_name)
+        if (x.is_cuda and x.dtype == torch.int64 and x.dim() == 2 and x.size(1) <= len(tables) and not torch.compiler.is_compiling()
+                and all(type(t) is nn.Embedding and t.padding_idx is None and t.max_norm is None and not t.sparse
+                        and not t.scale_grad_by_freq and t.weight.dtype == torch.float32 and t.num_embeddings <= 512 for t in tables)):
+            # one launch per feature column each way (ops._EmbeddingSumFn) instead of gather + add / aten's sort-based backward
+            return ops.embedding_sum(x, [tables[i].weight for i in range(x.shape[1])])
         out = 0
         for i in range(x.shape[1]):
             out = out + tables[i](x[:, i])
@@ -70,6 +75,15 @@ def _num_graphs(data) -> int:
     return int(n) if n is not None else int(data.batch.max()) + 1
 
 
+def _segment_ptr(data) -> torch.Tensor:
+    """node offsets of the batch's graphs: torch_geometric's ``Batch.ptr`` when the loader supplies it (int64 -> int32, one cast),
+    else one binary search over the sorted ``batch`` vector"""
+    ptr = getattr(data, "ptr", None)
+    if ptr is not None and ptr.numel() == _num_graphs(data) + 1:
+        return ptr.to(torch.int32)
+    return ops.segment_ptr(data.batch, _num_graphs(data))
+
+
 # the reference's graph-level files name their convolution layers differently from the node-level file
 # (graph_classification/models.py:157-172,... `KAGCN_Layer(GCNConv)`, `KAGAT_Layer(GATConv)`): same layers, same
 # constructor arguments
@@ -81,12 +95,18 @@ FASTKAGAT_Layer = FASTKAGATConv
 
 class _GraphLevel(nn.Module):
     def _message_passing(self, x, g, edge_attr=None):
+        # GINE stacks (graph_regression/models.py:107-119): all convolutions + norms as ONE tape node where the shapes allow it
+        if (edge_attr is not None and self.training and not (self.dropout.p > 0.0) and all(isinstance(c, GINEKANLayer) for c in self.conv)
+                and all(type(b) is BatchNorm1d for b in self.bn) and not any(_has_hooks(m) for m in list(self.conv) + list(self.bn))):
+            h = ops.gine_kan_stack(x, edge_attr, g, list(self.conv), list(self.bn))
+            if h is not None:
+                return h
         for conv, bn in zip(self.conv, self.bn):
             x = conv_bn_dropout(conv, bn, self.dropout, x, g, *(() if edge_attr is None else (edge_attr,)))
         return x
 
     def _pool(self, x, data):
-        return ops.segment_pool(x, ops.segment_ptr(data.batch, _num_graphs(data)))
+        return ops.segment_pool(x, _segment_ptr(data))
 
 
 class KAGIN(_GraphLevel):
@@ -135,12 +155,24 @@ class GINEKANLayer(nn.Module):
         self.register_buffer("eps", torch.full((1,), float(eps)))
         self._eps_key, self._eps_val = None, float(eps)
 
-    def forward(self, x, edge_index, edge_attr):
+    def _eps(self) -> float:
         key = (self.eps.data_ptr(), self.eps._version)
-        if key != self._eps_key:
+        if key != self._eps_key:                  # one host read per change of the buffer, not per call
             self._eps_val, self._eps_key = float(self.eps), key
+        return self._eps_val
+
+    def forward_fused_norm(self, x, edge_index, edge_attr, bn):
+        """``bn(self(x, edge_index, edge_attr))`` for a training-mode BatchNorm1d as ONE tape node (``ops._GineKanLayerFn``: one
+        library call each way), or ``None`` when the chain is outside what the node covers -- nothing has been touched then."""
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
-        return self.nn(ops.aggregate_gine(x, edge_attr, g, self_scale=1.0 + self._eps_val))
+        return ops.gine_kan_layer(x, edge_attr, g, 1.0 + self._eps(), self.nn, batch_norm=bn)
+
+    def forward(self, x, edge_index, edge_attr):
+        g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
+        y = ops.gine_kan_layer(x, edge_attr, g, 1.0 + self._eps(), self.nn)          # one tape node: aggregate + KAN chain
+        if y is not None:
+            return y
+        return self.nn(ops.aggregate_gine(x, edge_attr, g, self_scale=1.0 + self._eps()))
 
 
 class KAGINRegression(_GraphLevel):
@@ -214,7 +246,7 @@ class KAGCN(_ConvSiluStack):
 
     def forward(self, data):
         x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0), cache=False))
-        ptr = ops.segment_ptr(data.batch, _num_graphs(data))
+        ptr = _segment_ptr(data)
         return F.log_softmax(self.readout(ops.segment_pool(x, ptr, mean=True)), dim=1)
 
 
@@ -248,7 +280,7 @@ class FASTKAGCN(_ConvSiluStack):
 
     def forward(self, data):
         x = self._stack(data.x, ops.graph_index(data.edge_index, data.x.size(0), cache=False))
-        ptr = ops.segment_ptr(data.batch, _num_graphs(data))
+        ptr = _segment_ptr(data)
         return F.log_softmax(self.readout(ops.segment_pool(x, ptr, mean=True)), dim=1)
 
 

@@ -263,6 +263,13 @@ def conv_bn_dropout(conv, bn, dropout, x, g, *conv_args, skip_gradient=None, laz
                                     lazy=lazy and ops.default_activation_dtype() == torch.float32 and x.dtype == torch.float32)
         if h is not None:
             return h
+    # GINE message passing (graph_regression/models.py:107-119): convolution + norm as one tape node, one library call each way
+    if (_FUSED_NORM_BACKWARD and len(conv_args) == 1 and hasattr(conv, "forward_fused_norm") and not isinstance(conv, _SumAggregateConv)
+            and bn.training and bn.affine and not (dropout.training and dropout.p > 0.0) and not _has_hooks(conv) and not _has_hooks(bn)
+            and type(bn).forward is BatchNorm1d.forward and x.size(0) > 1):
+        h = conv.forward_fused_norm(x, g, conv_args[0], bn)
+        if h is not None:
+            return h
     if isinstance(conv, _SumAggregateConv) and not conv_args and (bn.training or skip_gradient is not None):
         y, mom = conv.forward_with_moments(x, g, want_moments=bn.training, skip_gradient=skip_gradient)
     else:
@@ -318,7 +325,7 @@ class _NodeModel(nn.Module):
         lazy = (_LAZY_NORM and split and x.is_cuda and not torch.compiler.is_compiling() and isinstance(self.lay_out, KANLinear) and self.lay_out.spline_order == 3
                 and self.lay_out.grid_size + 3 <= 8 and self.lay_out.out_features <= 64 and not (self.dropout.training and self.dropout.p > 0.0)
                 and all(bn.num_features > 32 for bn in self.bns)
-                and (self.lay_out.precision if self.lay_out.precision is not None else ops.default_precision()) == ops.PREC_SPLIT)
+                and ops.split_like(self.lay_out.precision if self.lay_out.precision is not None else ops.default_precision()))
         skips = []
         for conv, bn in zip(self.convs, self.bns):
             grad_in = x.y.requires_grad if isinstance(x, ops.AffineRows) else x.requires_grad

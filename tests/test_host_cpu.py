@@ -262,15 +262,21 @@ def test_hot_path_kernels_do_not_spill_registers():
     report = kr.hot_path_report(rows)
     names = [r[0] for r in report]
     # the gate really covers the kernels bench.py times (a renamed kernel must not silently drop out of it)
-    for must in ("kan_sparse_fwd_kernel<2,false,false,false,-1,false>", "kan_sparse_fwd_kernel<2,false,true,false,-1,false>", "kan_sparse_fwd_kernel<2,false,false,true,8,false>",
-                 "kan_sparse_fwd_kernel<2,false,false,false,-1,true>",
-                 "kan_split_dw_kernel<3,false,1,4,false>", "kan_split_dx_kernel<3,2,false,1,false,false,false,false>",
-                 "kan_split_dx_kernel<3,2,false,0,false,true,false,false>", "kan_split_dw_w2_kernel<3,1>",
-                 "kan_split_dx_w2_kernel<4,3>", "kan_split_dw_kernel<0,false,1,4,false>", "agg_rows_v4_kernel<16,false>",
+    for must in ("kan_sparse_fwd_kernel<2,false,false,false,-1,false,false>", "kan_sparse_fwd_kernel<2,false,true,false,-1,false,false>",
+                 "kan_sparse_fwd_kernel<2,false,false,true,8,false,false>", "kan_sparse_fwd_kernel<2,false,false,false,-1,true,false>",
+                 "kan_split_dw_kernel<3,false,1,4,false,false>", "kan_split_dx_kernel<3,2,false,1,false,false,false,false,false>",
+                 "kan_split_dx_kernel<3,2,false,0,false,true,false,false,false>", "kan_split_dw_w2_kernel<3,1>",
+                 "kan_split_dx_w2_kernel<4,3>", "kan_split_dw_kernel<0,false,1,4,false,false>", "agg_rows_v4_kernel<16,false>",
                      "agg_rows_v4_kernel<16,true>", "agg_hub_merge_kernel<16,true>",      # (with the column statistics of the result: the norm backward fold)
                  # round 4: the wide-layer weight gradient and the read-out kernels that apply a folded BatchNorm1d to their rows
-                 "kan_split_dw_shared_kernel<0,4>", "kan_split_dw_kernel<3,false,1,3,true>", "kan_split_dx_kernel<3,2,false,1,false,false,true,false>",
-                     "kan_split_dx_kernel<3,2,false,1,false,false,true,true>"):      # (+ the column statistics of the stored gradient rows)
+                 "kan_split_dw_shared_kernel<0,4>", "kan_split_dw_kernel<3,false,1,3,true,false>", "kan_split_dx_kernel<3,2,false,1,false,false,true,false,false>",
+                     "kan_split_dx_kernel<3,2,false,1,false,false,true,true,false>",      # (+ the column statistics of the stored gradient rows)
+                 # round 5: the single-product (KAGNN_PREC_HALF) instantiations of the config-2 model's kernels
+                 "kan_sparse_fwd_kernel<2,false,false,false,-1,false,true>", "kan_sparse_fwd_kernel<2,false,true,false,-1,false,true>",
+                 "kan_sparse_fwd_kernel<2,false,false,false,-1,true,true>", "kan_split_dw_kernel<3,false,1,4,false,true>",
+                 "kan_split_dw_kernel<3,false,1,3,true,true>", "kan_split_dx_kernel<3,2,false,1,false,false,false,false,true>",
+                 "kan_split_dx_kernel<3,2,false,0,false,true,false,false,true>", "kan_split_dx_kernel<3,2,false,1,true,false,false,false,true>",
+                 "kan_split_dx_kernel<3,2,false,1,false,false,true,true,true>"):
         assert must in names, f"{must} is not covered by the spill gate: {sorted(names)[:5]}..."
     bad = [r for r in report if r[1] > r[3] or r[2] > r[4]]
     assert not bad, "hot-path kernels spill registers: " + "; ".join(f"{r[0]}: {r[1]} VGPRs / {r[2]} B" for r in bad)

@@ -9,6 +9,7 @@ T=$(mktemp -d)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result -DNDEBUG $FLAGS -c kagnn_amd/csrc/$TU -o $T/v.o
 OBJS=""
 for o in kagnn_amd/lib/obj/*.o; do
+  if [ "$(basename $o .o)" == "rccl_sharded" ]; then continue; fi      # (libkagnn_rccl.so's object, not part of the core library)
   if [ "$(basename $o .o)" == "$(basename $TU .hip)" ]; then OBJS="$OBJS $T/v.o"; else OBJS="$OBJS $o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o kagnn_amd/lib/libkagnn_hip_$NAME.so $OBJS

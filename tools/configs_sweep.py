@@ -80,3 +80,26 @@ if 4 in WANT:
     def zstep():
         opt.zero_grad(); (m(d) - tgt).abs().mean().backward(); opt.step()
     run("cfg4 ZINC-like batch 256 graphs KAGIN(GINE) 4 layers hidden 64: step", zstep, 20)
+    # the same through the package's loop (kagnn_amd.harness.train_graph_batches = optuna_zinc.py:56-66: fused Adam, loss read per epoch)
+    # over 8 DIFFERENT batches (each with its own edge_index: the CSR is rebuilt per batch, as in training), OGB-style embedding encoders
+    from kagnn_amd.harness import train_graph_batches
+    batches = []
+    for k in range(8):
+        g = torch.Generator().manual_seed(100 + k)
+        sizes = torch.randint(18, 29, (B,), generator=g)
+        N = int(sizes.sum()); off = torch.cumsum(sizes, 0) - sizes
+        src, dst, batch = [], [], []
+        for b in range(B):
+            nb = int(sizes[b]); eb = 2 * nb + 4
+            src.append(torch.randint(0, nb, (eb,), generator=g) + off[b]); dst.append(torch.randint(0, nb, (eb,), generator=g) + off[b])
+            batch.append(torch.full((nb,), b))
+        E = sum(len(s_) for s_ in src)
+        batches.append(SimpleNamespace(x=torch.randint(0, 21, (N, 1), generator=g).to(dev), edge_index=torch.stack([torch.cat(src), torch.cat(dst)]).to(dev),
+                                       edge_attr=torch.randint(0, 4, (E,), generator=g).to(dev), batch=torch.cat(batch).to(dev), num_graphs=B,
+                                       y=torch.randn(B, generator=g).to(dev)))
+    m = kagnn_amd.KAGINRegression(1, 1, 4, 64, 2, 4, 3, 1, 0.0, True)
+    m.atom_encoder = kagnn_amd.graph_models.AtomEncoder(64, [21])
+    m.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, 64)])
+    m = m.to(dev)
+    t, means = train_graph_batches(m, batches, nb_epochs=5, warmup=2)
+    print(f"cfg4 harness (ZINC-style embedding encoders, 8 distinct batches, fused Adam): {t * 1e3:.2f} ms/step, loss {means[-1]:.4f}", flush=True)

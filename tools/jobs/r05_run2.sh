@@ -1,0 +1,9 @@
+set -x
+cd ${GRAFT_REPO_ROOT:-.}
+mkdir -p gpurun_out
+KAGNN_TEST_SOFT=1 timeout 1500 python -m pytest tests/test_gpu_half.py "tests/test_gpu_fullsize.py::test_fullsize_one_call_gin_layer_backward_vs_oracle" tests/test_gpu_parity.py tests/test_gpu_models.py -k "half or one_call or harness or gfastkan_nodes or kanlinear or g2 or g3 or chain or gine or zinc" -q --durations=8 > gpurun_out/run2_tests.log 2>&1; tail -25 gpurun_out/run2_tests.log
+cp gpurun_out/parity_soft_failures.json gpurun_out/run2_soft_failures.json
+rm -f gpurun_out/ab.log
+tools/run_ab_libs.sh "cur fwdnorefill dxw2nostage1 dxw2nostage2" 2 --workload config3
+cp gpurun_out/ab.log gpurun_out/run2_ab_config3.log
+for i in 1 2 3; do KAGNN_GINE_LAYER_ABI=1 python tools/configs_sweep.py 4 2>&1 | tail -1; KAGNN_GINE_LAYER_ABI=0 python tools/configs_sweep.py 4 2>&1 | tail -1; done | tee gpurun_out/run2_configs.log
