@@ -673,6 +673,18 @@ def main():
         fp32_ms = timed(step, k32) / k32 * 1e3
         for l in conv.nn.layers:
             l.precision = None
+    # the build-defined reduced-precision mode of BASELINE config 2 (KAGNN_PRECISION=half: one fp16 product per fp32 product) on
+    # the same layer, measured after the timed region like the exact-fp32 figure -- reported beside the headline, never as it
+    half_ms = None
+    if not args.no_fp32 and not fp32_mode and not half_mode and world == 1 and not fastkan:
+        for l in conv.nn.layers:
+            l.precision = ops.PREC_HALF
+        for _ in range(2):
+            step()
+        kh = max(3, min(args.steps, 10))
+        half_ms = timed(step, kh) / kh * 1e3
+        for l in conv.nn.layers:
+            l.precision = None
 
     if rank == 0:
         prof = prof_live
@@ -741,6 +753,7 @@ def main():
             "layer_algorithmic_bytes": layer_bytes(n, e, f),
             "layer_hbm_GBs": layer_gbs, "layer_hbm_frac": layer_gbs / HBM_PEAK_GBS,
             "fp32_mode_ms_per_step": fp32_ms,
+            "half_mode_ms_per_step": half_ms,      # KAGNN_PRECISION=half on the same layer (build-defined config-2 mode; ~3e-4 from fp32)
             "fp32_mode_layer_hbm_frac": (layer_bytes(n, e, f) / (fp32_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fp32_ms else None,
             "roofline": roof,
             "roofline_kernels": kernels,

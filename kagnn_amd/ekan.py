@@ -21,7 +21,7 @@ from torch import nn
 from . import ops
 
 
-_PACK_CHAIN = os.environ.get("KAGNN_PACK_CHAIN", "1") != "0"     # all layers of a chain packed in one launch
+_PACK_CHAIN = True      # all layers of a chain packed in one launch (a module attribute for the bitwise A/B tests, no longer an environment switch)
 
 
 def _init_bases(points: torch.Tensor, knots: torch.Tensor, order: int) -> torch.Tensor:

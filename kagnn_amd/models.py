@@ -57,13 +57,12 @@ class FKANLayer(FastKANLayer):
 
 
 # ---------------------------------------------------------------------------------- conv bases
-_SPLIT_READOUT = os.environ.get("KAGNN_SPLIT_READOUT", "1") != "0"
+_SPLIT_READOUT = True       # (module attributes: tests and tools/fuzz_models.py move them; no longer environment switches)
 _FUSED_LAYER = os.environ.get("KAGNN_FUSED_LAYER", "1") != "0"       # GIN + KAN chain as one autograd node (ops.gin_kan_layer)
-_SPLIT_READOUT_MIN_ROWS = int(os.environ.get("KAGNN_SPLIT_READOUT_MIN_ROWS", "400000"))
+_SPLIT_READOUT_MIN_ROWS = 400000
 # ... from this many rows when the blocks run as ONE forward launch and hand their gradients to the convolutions
-# (ops.kan_linear_parts / ops.SkipGradient; crossover measured with tools/split_readout_probe.py: 100k rows even, 170k -6 %)
-_SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH = int(os.environ.get("KAGNN_SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH",
-                                                        os.environ.get("KAGNN_SPLIT_READOUT_MIN_ROWS", "120000")))
+# (ops.kan_linear_parts / ops.SkipGradient; crossover measured in round 3, profiles/r03_experiments.md: 100k rows even, 170k -6 %)
+_SPLIT_READOUT_MIN_ROWS_ONE_LAUNCH = 120000
 _SKIP_GRADIENT = os.environ.get("KAGNN_SKIP_GRADIENT", "1") != "0"     # skip-branch gradient added inside the next convolution's backward
 _FUSED_EPILOGUE = os.environ.get("KAGNN_FUSED_EPILOGUE", "1") != "0"  # conv -> BatchNorm1d -> dropout: statistics + mask fused
 _LAZY_NORM = os.environ.get("KAGNN_LAZY_NORM", "1") != "0"             # the norm's forward pass folded into its consumers (ops.AffineRows)

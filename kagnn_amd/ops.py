@@ -1609,7 +1609,7 @@ def kan_linear(x, base_weight, spline_weight, spline_scaler, knots, grid_size: i
 
 
 _PARTS_OK: dict = {}
-_PARTS_ONE_LAUNCH = os.environ.get("KAGNN_PARTS_ONE_LAUNCH", "1") != "0"     # 0: per-block layers summed (kept for A/B)
+_PARTS_ONE_LAUNCH = True      # False: per-block layers summed (a module attribute for the bitwise A/B tests, no longer an environment switch)
 
 
 def parts_one_launch_widths_ok(widths: tuple, fout: int, grid_size: int, spline_order: int, mode: int) -> bool:

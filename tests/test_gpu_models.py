@@ -8,6 +8,9 @@ configs at their real shapes, determinism, and the precision report.
   tests/test_oracle_golden.py pins to the reference-made G9 / G11 logits).
 * config 3's layer (hidden 128, grid 8) at full size: sampled rows vs the oracle + additivity.
 """
+import os
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -1092,3 +1095,19 @@ def test_precision_report_split_vs_fp32_vs_reference_fp32():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump(report, open(os.path.join(out, "precision_report.json"), "w"), indent=1)
+
+
+# ------------------------------------------------------------------ folds on vs off over random model configurations
+def test_fuzz_models_folds_on_vs_off():
+    """tools/fuzz_models.py as part of the suite: 40 random GKAN_Nodes configurations (widths 32..128, 1-4 layers, 700..70 001 rows,
+    dropout, skip on / off, hubs both ways), the default path (norms folded, statistics travelling with the gradients, one-launch
+    read-out) against every fold switched off -- loss, input gradient, every parameter gradient and buffer.  This is the defence of
+    the switch surface: a fold that only an A/B flag used to exercise is exercised here."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_models.py"), "40", "0"], cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    tail = r.stdout[-3000:]
+    assert r.returncode == 0 and "failures: 0" in r.stdout, tail + r.stderr[-2000:]
+    m = re.search(r"folded norms: (\d+), statistics made by producers: (\d+)", r.stdout)
+    assert m and int(m.group(1)) >= 20 and int(m.group(2)) >= 20, tail       # the folds really ran

@@ -157,7 +157,7 @@ def test_sharded_layer_world4_and_world8_gloo(tmp_path, world, f, hid, grid):
 # ---------------------------------------------------------------------------------------------------------
 # the same two sharded layers with the PRODUCT's local ops (HIP kernels): two ranks share cuda:0, collectives
 # over gloo -- checks the sharding algebra end to end against the unsharded layer on the same device
-def _gpu_worker(rank, world, port, out_dir, backend="gloo"):
+def _gpu_worker(rank, world, port, out_dir, backend="gloo", f=16, big=True):
     """backend "gloo": both ranks on cuda:0 (what a 1-GPU box can run); "nccl": one device per rank over RCCL -- the real thing,
     including the library's own RCCL entry points (comm="rccl_c") and the barrier's RCCL branch; needs >= 2 GPUs"""
     sys.path.insert(0, ROOT)
@@ -174,7 +174,7 @@ def _gpu_worker(rank, world, port, out_dir, backend="gloo"):
         from kagnn_amd import ops
         from kagnn_amd.sharded import ShardedGIKANLayer, TransposedShardedGIKANLayer
         from oracle import kan_oracle as orc
-        n, e, f = 3001, 30000, 16
+        n, e = 3001, 30000
         ei = orc.powerlaw_graph(n, e, seed=3).to(dev)
         gen = torch.Generator().manual_seed(3)
         x = (torch.randn(n, f, generator=gen) * 0.3).to(dev)
@@ -226,6 +226,9 @@ def _gpu_worker(rank, world, port, out_dir, backend="gloo"):
         assert s1._xch[0].fwd_uses == 6 and s1._xch[0].bwd_uses == 0
         # ---- the row-CHUNKED exchanges on the HIP kernels (>= 262 144 rows => 4 chunks by default): the headline width
         # (64, grid 5) and config 3's (128, grid 8: two-window kernels), RCCL-free collectives (gloo) and p2p pulls
+        if not big:
+            open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+            return
         nb, eb = 262144 + 77, 1_500_000
         eib = orc.powerlaw_graph(nb, eb, seed=4).to(dev)
         gb = ops.GraphIndex(eib, nb)
@@ -267,6 +270,24 @@ def test_sharded_layers_two_ranks_one_gpu(tmp_path):
         port = s.getsockname()[1]
     mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+@pytest.mark.gpu
+def test_sharded_layers_four_ranks_one_gpu(tmp_path):
+    """P = 4 as a SYSTEM on the HIP kernels (VERDICT r04 missing 2): four PROCESSES sharing cuda:0, 32 features = 8 columns per
+    rank (the narrow instantiations of the P = 8 headline shard), collectives over gloo and -- comm="p2p" -- kagnn_p2p_reduce_scatter /
+    _all_gather pulling from three other processes' hipIpc-mapped buffers, rank-ordered sums, both p2p schemes, chunked and not,
+    the two-buffer reuse across steps and forward-only calls."""
+    mp.spawn(_gpu_worker, args=(4, _free_port(), str(tmp_path), "gloo", 32, False), nprocs=4, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(4))
+
+
+@pytest.mark.gpu
+def test_sharded_layers_four_ranks_one_gpu_chunked_headline_widths(tmp_path):
+    """the same four processes on the row-CHUNKED exchanges at the headline's and config 3's widths (64 / grid 5 -> 16 columns per
+    rank; 128 / grid 8 -> 32 columns per rank, two-window kernels): 262 221 rows => 4 chunks, gloo collectives and p2p pulls"""
+    mp.spawn(_gpu_worker, args=(4, _free_port(), str(tmp_path), "gloo", 16, True), nprocs=4, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(4))
 
 
 @pytest.mark.gpu

@@ -26,6 +26,12 @@ PY
 for k in 2 3 5 1 4; do tools/prof_cfg.sh $k ${TAG}_cfg$k 40 > $OUT/${TAG}_config${k}_kernel_trace.txt 2>&1; done
 tools/prof_model.sh > $OUT/${TAG}_model_step_kernel_trace.txt 2>&1
 KAGNN_ACT=bf16 python tools/configs_sweep.py 2 2>/dev/null | grep "cfg2 " > $OUT/${TAG}_config2_bf16.txt
+# BASELINE config 2's build-defined modes side by side: fp32 storage / bf16 gathers x split (three products) / half (one product)
+for a in fp32 bf16; do for p in split half; do
+  echo "KAGNN_ACT=$a KAGNN_PRECISION=$p: $(KAGNN_ACT=$a KAGNN_PRECISION=$p python tools/configs_sweep.py 2 2>/dev/null | grep 'cfg2 ')"
+done; done > $OUT/${TAG}_config2_modes.txt
+python bench.py --precision half --no-cpu-baseline --no-extras --no-traffic 2>/dev/null | tail -1 > $OUT/${TAG}_bench_half.json
+python bench.py --precision half --act bf16 --no-cpu-baseline --no-extras --no-traffic 2>/dev/null | tail -1 > $OUT/${TAG}_bench_half_bf16_gather.json
 python bench.py --act bf16 --no-cpu-baseline --no-extras --no-fp32 2>/dev/null | tail -1 > $OUT/${TAG}_bench_bf16_gather.json
 python bench.py --workload config3 --no-cpu-baseline --no-extras --no-traffic 2>/dev/null | tail -1 > $OUT/${TAG}_bench_config3.json
 python bench.py --workload fastkan 2>/dev/null | tail -1 > $OUT/${TAG}_bench_fastkan.json
