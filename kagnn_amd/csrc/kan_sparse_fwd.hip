@@ -530,6 +530,14 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                 };
                 auto build = [&](int s, const u32x4& e0, const u32x4& e1, float u0, float u1, u32x4& hi, u32x4& lo, int& idx) {
                     unsigned a0, a1, a2, a3, b0 = 0, b1 = 0, b2 = 0, b3 = 0, h0, h1, l0, l1;
+#ifdef KAGNN_ABLATE_FWD_NO_EXPAND          // TIMING-ONLY ablation (wrong results): the A operand "received from elsewhere" -- what is left is the
+                                           // weight-fragment reads and the matrix-core work: the share of a launch that a 128-output forward would
+                                           // NOT repeat per 64-output block
+                    hi = u32x4{__float_as_uint(u0), __float_as_uint(u1), e0[0], e1[0]};
+                    lo = u32x4{e0[1], e1[1], __float_as_uint(u1), __float_as_uint(u0)};
+                    idx = (int)(e0[2] | (e1[2] << 8));
+                    return;
+#endif
                     if constexpr (HALF) {            // rounded once: hi payloads and placements only
                         unsigned ph[2][2];
                         frag3_payload_pair_h(u0, u1, ph);

@@ -605,14 +605,23 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
     // were 23 % of this kernel at 128 -> 128.  (A double-buffered, overlapped form -- as in kan_sparse_fwd.hip -- costs
     // ~50 more registers than this kernel has: profiles/r02_experiments.md.)
     const unsigned lds_w = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)s_w);
-    auto stage = [&](int tile, int nslots) {                     // [c][q][hi|lo] order: the first nslots slots are a prefix
+    // Round 5: the two windows live in TWO LDS regions (window 0: 9 slots at s_w, window 1: its NS1 live slots behind them), and the
+    // copy of window 0 -- 72 of the 96 KB a feature tile stages at Q2 = 4 -- is issued one phase ahead: window 0 of the next
+    // (feature tile, or row tile) streams in under the MFMAs and the V phase of window 1, so its phase starts with a wait for a
+    // copy issued a whole section earlier and ONE barrier (it was barrier / copy + wait / barrier: the timing-only ablation of
+    // profiles/r05_experiments.md section 2 put the exposed staging at 16 % of this kernel at 128 -> 128).  The copy is issued
+    // AFTER the barrier that ends the last use of its region.  Window 1 keeps the exposed form: issuing ITS copy ahead (before or
+    // after the M phase of window 0) makes hipcc spill 46-48 VGPRs at Q2 = 4 in every placement tried (round 2 saw the same).
+    auto stage_issue = [&](int tile, int nslots, unsigned dst_off) {      // [c][q][hi|lo] order: the first nslots slots are a prefix
         const unsigned char* src = gw + (size_t)tile * FT_BYTES;
         const int nblk = nslots * Q2 * 2;
         for (int blk = wave; blk < nblk; blk += 8)
-            lds_dma_1k(src + blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_w + blk * 1024));
-        lds_dma_wait();
+            lds_dma_1k(src + blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_w + dst_off + blk * 1024));
     };
+    // (Q2 = 4 with exactly four live slots in the second window -- C = 12 at 128 outputs -- spills one VGPR in the ahead form: exposed there)
+    constexpr bool AHEAD = !(Q2 == 4 && NS1 == 4);
     __syncthreads();
+    if (AHEAD && (long)blockIdx.x * 256 < N) stage_issue(0, kCTmax, 0u);
     const FastGeom fgeo = fast_geom(s_knots, nknots);
     const float wd = 0.5f * fgeo.inv_h;
     const int li = lane & 15, kg = lane >> 4;
@@ -622,6 +631,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
     const unsigned x_rb = (unsigned)(wave * 32 + 4 * kg) * ldx4;
     const unsigned gx_rb = (unsigned)(wave * 32 + 4 * kg) * ldgx4;
     const unsigned char* wl = s_w + lane * 16;
+    const unsigned char* wl1 = wl + FT_BYTES;                     // window 1's region
 
     for (long tile = blockIdx.x; tile * 256 < N; tile += gridDim.x) {
         const GBuf gyb = gbuf_at(gy, N, ldgy, out, tile * 256);
@@ -673,14 +683,14 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
                 for (int reg = 0; reg < 4; ++reg) xq[rt][reg] = gld_s(xb, x_rb + fcol, (unsigned)(16 * rt + reg) * ldx4);
             f32x4 D[kCTmax][2];
             // ================= window 0: slots 0..7 + base
-#ifdef KAGNN_ABLATE_DXW2_NO_STAGE          // TIMING-ONLY ablation (wrong results): no re-staging of W^T, 1 = barriers kept, 2 = barriers dropped too
-            if (KAGNN_ABLATE_DXW2_NO_STAGE == 1) { __syncthreads(); __syncthreads(); }
-            if (tile == (long)blockIdx.x && t == 0) { stage(0, kCTmax); __syncthreads(); }
-#else
-            __syncthreads();
-            stage(2 * t, kCTmax);
-            __syncthreads();
-#endif
+            if constexpr (AHEAD) {
+                lds_dma_wait();              // this wave's blocks of window 0 (issued a phase ago) have landed ...
+                __syncthreads();             // ... so have everyone's; and everyone is done with window 1 of the previous tile
+            } else {
+                __syncthreads();
+                stage_issue(2 * t, kCTmax, 0u); lds_dma_wait();
+                __syncthreads();
+            }
 #pragma unroll
             for (int c = 0; c < kCTmax; ++c) { D[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             {
@@ -732,13 +742,13 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
                 }
             }
             // ================= window 1: its C - 8 live slots only
-#ifdef KAGNN_ABLATE_DXW2_NO_STAGE
-            if (KAGNN_ABLATE_DXW2_NO_STAGE == 1) { __syncthreads(); __syncthreads(); }
-#else
             __syncthreads();
-            stage(2 * t + 1, ns1);
+            stage_issue(2 * t + 1, ns1, (unsigned)FT_BYTES); lds_dma_wait();
             __syncthreads();
-#endif
+            if constexpr (AHEAD) {
+                if (t + 1 < T) stage_issue(2 * (t + 1), kCTmax, 0u);
+                else if ((tile + gridDim.x) * 256 < N) stage_issue(0, kCTmax, 0u);
+            }
             f32x4 D1[NS1][2];
 #pragma unroll
             for (int c = 0; c < NS1; ++c) { D1[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D1[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -746,8 +756,8 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
             for (int c = 0; c < NS1; ++c) {
 #pragma unroll
                 for (int q = 0; q < Q2; ++q) {
-                    const u32x4 bhi = *reinterpret_cast<const u32x4*>(wl + (size_t)(2 * (c * Q2 + q) + 0) * 1024);
-                    const u32x4 blo = *reinterpret_cast<const u32x4*>(wl + (size_t)(2 * (c * Q2 + q) + 1) * 1024);
+                    const u32x4 bhi = *reinterpret_cast<const u32x4*>(wl1 + (size_t)(2 * (c * Q2 + q) + 0) * 1024);
+                    const u32x4 blo = *reinterpret_cast<const u32x4*>(wl1 + (size_t)(2 * (c * Q2 + q) + 1) * 1024);
                     D1[c][0] = mfma16_f16(ahi[0][q], bhi, D1[c][0]);
                     D1[c][1] = mfma16_f16(ahi[1][q], bhi, D1[c][1]);
                     D1[c][0] = mfma16_f16(ahi[0][q], blo, D1[c][0]);
@@ -786,7 +796,7 @@ __global__ __launch_bounds__(512) void kan_split_dx_w2_kernel(
 template <int Q2, int NS1>
 static int launch_dx_w2(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                         const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx, hipStream_t st) {
-    const size_t lds = kLdsHdr + (size_t)kCTmax * Q2 * 2 * 1024;
+    const size_t lds = kLdsHdr + (size_t)(kCTmax + NS1) * Q2 * 2 * 1024;       // window 0's 9 slots + window 1's NS1 (two regions)
     static unsigned long long configured = 0;          // (per device: common.h)
     if (first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_w2_kernel<Q2, NS1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));

@@ -7,6 +7,7 @@ T=$(mktemp -d)
 git archive $REV kagnn_amd/csrc include | tar -x -C $T
 OBJS=""
 for f in $T/kagnn_amd/csrc/*.hip; do
+  if [ "$(basename $f)" == "rccl_sharded.hip" ]; then continue; fi      # (libkagnn_rccl.so's source, not part of the core library)
   o=$T/$(basename $f .hip).o
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result -DNDEBUG -c $f -o $o &
   OBJS="$OBJS $o"
