@@ -25,6 +25,7 @@ typedef _Float16 f16x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kSpCF = 64;                 // features per LDS chunk
 constexpr int kSpOutBlk = 64;             // output columns per launch (2 accumulator tiles: the 64-feature chunk of packed W is 152 KB)
+constexpr int kSpOutBlkWide = 128;        // ... of the WIDE instantiation (OT = 4, round 5: see kan_sparse_fwd_kernel)
 constexpr int kSpSteps = kSpCF / 4;       // sparse MFMA steps per chunk: 2 features per lane half and step
 __host__ __device__ inline size_t sparse_fwd_chunk_bytes(int OT) {
     return (size_t)kSpSteps * OT * 2 * 2048 + (size_t)(kSpCF / 16) * OT * 2 * 1024;
@@ -39,7 +40,21 @@ __host__ __device__ inline int sp_sh(int C) { return C > 8 ? 1 : 0; }
 // `inv` = number of (virtual) features = in << sp_sh(C)
 static size_t sp_chunks_bytes(int inv, int ob) { return (size_t)cdiv(inv, kSpCF) * sparse_fwd_chunk_bytes(cdiv(ob, 32)); }
 static size_t sp_blk_bytes(int in, int inv, int ob) { return kHdrBytes + sp_chunks_bytes(inv, ob) + (((size_t)ob * in * 4 + 255) & ~(size_t)255); }
-size_t kan_sparse_pack_fwd_bytes(int in, int out, int C) { return (size_t)cdiv(out, kSpOutBlk) * sp_blk_bytes(in, in << sp_sh(C), min(out, kSpOutBlk)); }
+// Output block width of a layer.  Layers whose output count is a multiple of 128 (on more than 32 virtual features: BASELINE config 3's
+// 128 -> 128 layers) run the WIDE instantiation: one launch covers 128 outputs, so every scalar is expanded once per 128 outputs
+// instead of once per 64 -- the expansion (span, cubic pieces, hi/lo split, placement), not the matrix cores, bounds this kernel.
+// KAGNN_FWD_WIDE=0 keeps the 64-wide blocks (A/B timing).  The pack layout follows the block width: read once per process.
+static bool sp_wide_enabled() {
+    static const bool on = [] { const char* e = getenv("KAGNN_FWD_WIDE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static int sp_out_blk(int inv /* virtual features */, int out) {
+    return (sp_wide_enabled() && out % kSpOutBlkWide == 0 && inv > 32) ? kSpOutBlkWide : kSpOutBlk;
+}
+size_t kan_sparse_pack_fwd_bytes(int in, int out, int C) {
+    const int inv = in << sp_sh(C), blk = sp_out_blk(inv, out);
+    return (size_t)cdiv(out, blk) * sp_blk_bytes(in, inv, min(out, blk));
+}
 
 // A lane half of the sparse MFMA's K owns `hf` consecutive (virtual) features of a chunk, 8 per group.  Layers of <= 32
 // features use BOTH halves all the same: hf = 16 (two groups) up to 32 features, 8 (one group) up to 16 -- with hf fixed
@@ -220,12 +235,24 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     static_assert(AGG < 0 || (NARROW && !SH && !MOM), "the fused aggregation serves plain narrow layers");
     static_assert(!PARTS || (!NARROW && !SH && !MOM && AGG < 0), "column blocks: plain wide layers");
     static_assert(!HALF || (!SH && AGG < 0), "single-product mode: layers of <= 8 coefficients, no fused aggregation");
-    constexpr int NT = 512, CF = kSpCF, BPC = CF / 16, NG = CF / 16, ROWS = (NT / 64) * 32;
+    static_assert(OT != 4 || (!NARROW && AGG < 0 && !PARTS && !HALF), "the wide instantiation serves plain layers");
+    // OT == 4 (WIDE, round 5): 128 outputs per launch at the SAME two waves per SIMD and 256-row tiles as the 64-wide blocks --
+    // round 4's OT = 4 ran one wave per SIMD on 128-row tiles and lost to the doubled weight stream (r04_experiments.md 8).  What
+    // makes it fit 256 registers: (i) MERGED -- the SiLU branch is fed at the bases' scale 2^10 (not 2^4) and accumulates into
+    // the spline accumulator, no second tile set (|silu| < 58 instead of < 3660 before a group takes the exact-fp32 fallback,
+    // which accumulates at the same scale); (ii) the weight fragments of a step are read where they are used instead of one
+    // step ahead into a second register set.  The packed chunk (288 KB) streams through the two LDS buffers in FOUR pieces.
+    constexpr bool MERGED = OT == 4;
+    constexpr int NT = 512, NW = NT / 64, CF = kSpCF, BPC = CF / 16, NG = CF / 16, ROWS = (NT / 64) * 32;
     const int HF = NARROW ? sp_hf(in << (SH ? 1 : 0)) : CF / 2;    // features per lane half: CF / 2, or 16 / 8 in narrow layers
     constexpr int CHUNK_BYTES = kSpSteps * OT * 2 * 2048 + BPC * OT * 2 * 1024;
     constexpr int SPL_BYTES = kSpSteps * OT * 2 * 2048;
-    constexpr int HALF_SPL = SPL_BYTES / 2, HALF_BASE = (BPC / 2) * OT * 2 * 1024, HALF_BYTES = HALF_SPL + HALF_BASE;
-    static_assert(2 * HALF_BYTES == CHUNK_BYTES && NG == 4 && kSpSteps == 16, "two halves of 2 groups x 4 steps");
+    // a chunk streams through the two LDS buffers in PPC pieces of GPP feature groups (4 sparse steps + 1 SiLU group per group)
+    constexpr int PPC = OT == 4 ? 4 : 2, GPP = NG / PPC;
+    constexpr int HALF_SPL = SPL_BYTES / PPC, HALF_BASE = (BPC / PPC) * OT * 2 * 1024, HALF_BYTES = HALF_SPL + HALF_BASE;
+    constexpr int BUF_BYTES = 2 * HALF_BYTES;             // both LDS buffers (== CHUNK_BYTES unless wide)
+    static_assert(PPC * HALF_BYTES == CHUNK_BYTES && NG == 4 && kSpSteps == 16, "PPC pieces of GPP groups x 4 steps");
+    static_assert((HALF_SPL / 1024) % NW == 0, "spline blocks of a piece divide over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* s_knots = reinterpret_cast<float*>(smem);
     unsigned* s_tbl = reinterpret_cast<unsigned*>(smem + 256);
@@ -236,29 +263,35 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     if (tid < nknots) s_knots[tid] = knots_g[tid];
     build_sparse_table(s_tbl, tid, nknots);
     const float post = reinterpret_cast<const float*>(pack)[0];
-    const float post_b = post * 64.0f;                  // the SiLU branch is fed at scale 2^4 instead of 2^10
+    const float post_b = post * 64.0f;                  // the SiLU branch is fed at scale 2^4 instead of 2^10 (not MERGED)
     // exact-fp32 SiLU groups (values beyond fp16 range) accumulate into the SAME acc_b: their base weights are scaled by
     // 2^(4 - e) so the products sit at acc_b's scale (an accumulator tile of their own cost 16 OT registers the kernel does
     // not have: the column-moments instantiation spilled 53 VGPRs around its MFMA loop -- profiles/r03_kernel_resources.txt)
-    const float wsc16 = ldexpf(1.0f, 4 - reinterpret_cast<const int*>(pack)[1]);
+    const float wsc16 = ldexpf(1.0f, (MERGED ? 10 : 4) - reinterpret_cast<const int*>(pack)[1]);
     const float* base_w = reinterpret_cast<const float*>(pack + kHdrBytes + (size_t)nchunks * CHUNK_BYTES);   // [out][in] fp32
     const unsigned char* gw = pack + kHdrBytes;
     // half h (0 / 1) of chunk ch -> LDS buffer h: 32 OT one-KiB pieces of sparse-step fragments + 4 OT of SiLU fragments
     const unsigned lds_w = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)s_w);
+    // piece h (0 .. PPC-1) of chunk ch -> LDS buffer h & 1: one-KiB blocks of sparse-step fragments, then of SiLU fragments
     auto dma_half = [&](int ch, int h) {
         const unsigned char* src = gw + (size_t)ch * CHUNK_BYTES;
-        const unsigned dst = lds_w + h * HALF_BYTES;
+        const unsigned dst = lds_w + (h & 1) * HALF_BYTES;
+        constexpr int SPB = HALF_SPL / 1024 / NW, BB = HALF_BASE / 1024;      // spline blocks per wave; SiLU blocks of the piece
 #pragma unroll
-        for (int k = 0; k < 4 * OT; ++k) {
-            const int blk = wave * (4 * OT) + k;
+        for (int k = 0; k < SPB; ++k) {
+            const int blk = wave * SPB + k;
             lds_dma_1k(src + h * HALF_SPL + blk * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(dst + blk * 1024));
         }
-        if (wave < 4 * OT)
-            lds_dma_1k(src + SPL_BYTES + h * HALF_BASE + wave * 1024 + lane * 16,
-                       __builtin_amdgcn_readfirstlane(dst + HALF_SPL + wave * 1024));
+#pragma unroll
+        for (int k = 0; k < (BB + NW - 1) / NW; ++k) {
+            const int blk = wave + k * NW;
+            if (blk < BB)
+                lds_dma_1k(src + SPL_BYTES + h * HALF_BASE + blk * 1024 + lane * 16,
+                           __builtin_amdgcn_readfirstlane(dst + HALF_SPL + blk * 1024));
+        }
     };
     const int ch_begin = blockIdx.y * chunks_per_split, ch_end = min(nchunks, ch_begin + chunks_per_split);
-    const bool resident = (ch_end - ch_begin) == 1;
+    const bool resident = PPC == 2 && (ch_end - ch_begin) == 1;      // (a wide chunk never fits: it always streams)
     dma_half(ch_begin, 0);
     if (resident) { if (AGG < 0) dma_half(ch_begin, 1); lds_dma_wait(); }      // (AGG: the second half buffer is the gather's staging area)
     y += (long)blockIdx.y * part_stride;
@@ -453,7 +486,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     // weight chunk ([wave][t][mean | M2][32 columns], 4 KiB at OT = 2), not in registers: four more live VGPRs through the
     // MFMA loop were what tipped the 256-register instantiation into scratch
     float mom_n = 0.0f;
-    float* s_momw = reinterpret_cast<float*>(s_w + CHUNK_BYTES) + wave * (OT * 64);
+    float* s_momw = reinterpret_cast<float*>(s_w + BUF_BYTES) + wave * (OT * 64);
     if constexpr (MOM) {
 #pragma unroll
         for (int t = 0; t < OT; ++t) s_momw[64 * t + lane] = 0.0f;      // (each wave touches only its own slice: no barrier)
@@ -471,24 +504,25 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
         // rare groups whose values do not fit that, exact fp32 MFMAs on the fp32 weights brought to the same scale
         // (round 2 kept a third tile `acc_f` for them: 16 OT more registers; with the packed-fp32 payloads the leaner kernel is as
         // fast -- 0.393 vs 0.394 ms per step, same-box A/B -- and nothing spills)
-        f32x16 acc[OT], acc_b[OT];
+        f32x16 acc[OT], acc_b[MERGED ? 1 : OT];
 #pragma unroll
         for (int t = 0; t < OT; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc[t][i] = 0.0f; acc_b[t][i] = 0.0f; }
+            for (int i = 0; i < 16; ++i) { acc[t][i] = 0.0f; if constexpr (!MERGED) acc_b[t][i] = 0.0f; }
 
         for (int ch = ch_begin; ch < ch_end; ++ch) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if (g >= ng_live) continue;                                // narrow layer: nothing but zero weights left
-                const unsigned char* hb = s_w + (g >> 1) * HALF_BYTES;     // this group's half buffer
-                if (!resident && (g & 1) == 0) {
-                    // my pieces of this half have landed; after the barrier so have everyone's, and everyone is done with
-                    // the other buffer -- which the half after this one now streams into
+                const int q = g / GPP, gq = g % GPP;                       // piece of the chunk, group inside the piece
+                const unsigned char* hb = s_w + (q & 1) * HALF_BYTES;      // this piece's buffer
+                if (!resident && gq == 0) {
+                    // my blocks of this piece have landed; after the barrier so have everyone's, and everyone is done with
+                    // the other buffer -- which the piece after this one now streams into
                     lds_dma_wait();
                     __syncthreads();
 #ifndef KAGNN_ABLATE_FWD_NO_REFILL        // TIMING-ONLY ablation (wrong results): what the streamed forward costs without its L2 -> LDS refills
-                    if (g == 0) dma_half(ch, 1);
+                    if (q + 1 < PPC) dma_half(ch, q + 1);
                     else if (ch + 1 < ch_end) dma_half(ch + 1, 0);
                     else if ((tile + gridDim.x) * ROWS < N) dma_half(ch_begin, 0);
 #endif
@@ -520,10 +554,19 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     else frag3_index<false>(xv[2 * s + 1], f3geo, u1, o1);
                     e0 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + o0);
                     e1 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(s_tbl) + o1);
-                    const unsigned char* wp = hb + (size_t)((4 * (g & 1) + s) * OT) * 2 * 2048 + lane * 16;
+                    if constexpr (MERGED) return;           // (wide: the weight fragments are read where they are used -- read_w)
+                    const unsigned char* wp = hb + (size_t)((4 * gq + s) * OT) * 2 * 2048 + lane * 16;
 #pragma unroll
                     for (int i = 0; i < 2 * OT; ++i) {      // [ot][hi|lo] x two 16-byte halves, a KiB apart
                         if (HALF && (i & 1)) continue;      // (single-product mode: the hi fragments only)
+                        w[2 * i] = *reinterpret_cast<const u32x4*>(wp + i * 2048);
+                        w[2 * i + 1] = *reinterpret_cast<const u32x4*>(wp + i * 2048 + 1024);
+                    }
+                };
+                auto read_w = [&](int s, u32x4 (&w)[4 * OT]) {
+                    const unsigned char* wp = hb + (size_t)((4 * gq + s) * OT) * 2 * 2048 + lane * 16;
+#pragma unroll
+                    for (int i = 0; i < 2 * OT; ++i) {
                         w[2 * i] = *reinterpret_cast<const u32x4*>(wp + i * 2048);
                         w[2 * i + 1] = *reinterpret_cast<const u32x4*>(wp + i * 2048 + 1024);
                     }
@@ -558,57 +601,37 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     lo = u32x4{b0, b1, b2, b3};
                     idx = (int)(e0[2] | (e1[2] << 8));
                 };
-                {
-                    u32x4 e0, e1; float u0, u1;
-                    prep_reads(0, e0, e1, u0, u1, bw);
-                    build(0, e0, e1, u0, u1, ahi, alo, aidx);
-                }
                 u32x4 sh_hi, sh_lo;                        // SiLU fragments, prepared under the last step's MFMAs
                 float sv[8];
                 bool big = false;
+                auto silu_prep = [&]() {
+                    float smx = 0.0f;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    u32x4 e0, e1, nbw[4 * OT]; float u0, u1;
-                    if (s < 3) prep_reads(s + 1, e0, e1, u0, u1, nbw);
-#pragma unroll
-                    for (int t = 0; t < OT; ++t) acc[t] = smfmac(ahi, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
-                    if constexpr (!HALF) {
-#pragma unroll
-                        for (int t = 0; t < OT; ++t) acc[t] = smfmac(ahi, bw[4 * t + 2], bw[4 * t + 3], acc[t], aidx);
-#pragma unroll
-                        for (int t = 0; t < OT; ++t) acc[t] = smfmac(alo, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
+                    for (int i = 0; i < 8; i += 2) {     // packed fp32, two scalars per instruction
+                        const f32x2 xp = {xv[i], xv[i + 1]};
+                        f32x2 pr = silu16_pair(xp) + (xp - xp) * splat2(16.0f);      // +-Inf -> NaN like the reference
+                        if constexpr (MERGED) pr = pr * splat2(64.0f);                      // the bases' scale: 2^10
+                        sv[i] = pr.x; sv[i + 1] = pr.y;
+                        smx = fmaxf(fmaxf(smx, fabsf(pr.x)), fabsf(pr.y));
                     }
-                    if (s < 3) {
-                        u32x4 nhi, nlo; int nidx;
-                        build(s + 1, e0, e1, u0, u1, nhi, nlo, nidx);
-                        ahi = nhi; alo = nlo; aidx = nidx;
-#pragma unroll
-                        for (int i = 0; i < 4 * OT; ++i) { if (HALF && ((i >> 1) & 1)) continue; bw[i] = nbw[i]; }
-                    } else {
-                        float smx = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 8; i += 2) {     // packed fp32, two scalars per instruction
-                            const f32x2 xp = {xv[i], xv[i + 1]};
-                            const f32x2 pr = silu16_pair(xp) + (xp - xp) * splat2(16.0f);      // +-Inf -> NaN like the reference
-                            sv[i] = pr.x; sv[i + 1] = pr.y;
-                            smx = fmaxf(fmaxf(smx, fabsf(pr.x)), fabsf(pr.y));
-                        }
-                        big = __any(!(smx < 60000.0f) || sv[0] != sv[0] || sv[1] != sv[1] || sv[2] != sv[2] || sv[3] != sv[3] ||
-                                    sv[4] != sv[4] || sv[5] != sv[5] || sv[6] != sv[6] || sv[7] != sv[7]);   // wave-uniform
-                        if constexpr (HALF) { round_f16x2(sv, sh_hi); sh_lo = sh_hi; }
-                        else split_f16x2(sv, sh_hi, sh_lo);
-                    }
-                }
+                    big = __any(!(smx < 60000.0f) || sv[0] != sv[0] || sv[1] != sv[1] || sv[2] != sv[2] || sv[3] != sv[3] ||
+                                sv[4] != sv[4] || sv[5] != sv[5] || sv[6] != sv[6] || sv[7] != sv[7]);   // wave-uniform
+                    if constexpr (HALF) { round_f16x2(sv, sh_hi); sh_lo = sh_hi; }
+                    else split_f16x2(sv, sh_hi, sh_lo);
+                };
+                auto base_branch = [&]() {
                 if (!big) {
-                    const unsigned char* wp = hb + HALF_SPL + (size_t)((g & 1) * OT) * 2 * 1024 + lane * 16;
+
+                    const unsigned char* wp = hb + HALF_SPL + (size_t)(gq * OT) * 2 * 1024 + lane * 16;
 #pragma unroll
                     for (int t = 0; t < OT; ++t) {
+                        f32x16& ab = MERGED ? acc[t] : acc_b[MERGED ? 0 : t];
                         const u32x4 wh = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 0) * 1024);
-                        acc_b[t] = mfma_f16(sh_hi, wh, acc_b[t]);
+                        ab = mfma_f16(sh_hi, wh, ab);
                         if constexpr (!HALF) {
                             const u32x4 wl = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 1) * 1024);
-                            acc_b[t] = mfma_f16(sh_hi, wl, acc_b[t]);
-                            acc_b[t] = mfma_f16(sh_lo, wh, acc_b[t]);
+                            ab = mfma_f16(sh_hi, wl, ab);
+                            ab = mfma_f16(sh_lo, wh, ab);
                         }
                     }
                 } else {
@@ -622,9 +645,91 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                             const int o = 32 * t + r;
                             const int fr = SH ? (f0 + j) >> 1 : f0 + j;          // SH: only the first window carries the base weight
                             const float w = (o < out && fr < in && !(SH && (j & 1))) ? base_w[(long)o * in + fr] : 0.0f;
-                            acc_b[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j] * 0.0625f, w * wsc16, acc_b[t], 0, 0, 0);
+                            f32x16& ab = MERGED ? acc[t] : acc_b[MERGED ? 0 : t];
+                            ab = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j] * (MERGED ? 0.0009765625f : 0.0625f), w * wsc16, ab, 0, 0, 0);
                         }
                     }
+                }
+                };
+                // wide (MERGED): the SiLU branch FIRST -- its fragments are dead before the sparse steps start and the x values die step by
+                // step, instead of x, 16 SiLU values / fragments and the step's operands all being live under the last step (the
+                // instantiation spilled 2-15 VGPRs that way); same sums, another order inside the accumulator
+                if constexpr (MERGED) { silu_prep(); base_branch(); }
+                {
+                    u32x4 e0, e1; float u0, u1;
+                    prep_reads(0, e0, e1, u0, u1, bw);
+                    build(0, e0, e1, u0, u1, ahi, alo, aidx);
+                    if constexpr (MERGED) read_w(0, bw);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    u32x4 e0, e1, nbw[MERGED ? 1 : 4 * OT]; float u0, u1;
+                    if constexpr (MERGED) { if (s < 3) prep_reads(s + 1, e0, e1, u0, u1, bw); }      // (index + table reads only)
+                    else if (s < 3) prep_reads(s + 1, e0, e1, u0, u1, reinterpret_cast<u32x4 (&)[4 * OT]>(nbw));
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) acc[t] = smfmac(ahi, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
+                    if constexpr (!HALF) {
+#pragma unroll
+                        for (int t = 0; t < OT; ++t) acc[t] = smfmac(ahi, bw[4 * t + 2], bw[4 * t + 3], acc[t], aidx);
+#pragma unroll
+                        for (int t = 0; t < OT; ++t) acc[t] = smfmac(alo, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
+                    }
+                    if (s < 3) {
+                        u32x4 nhi, nlo; int nidx;
+                        build(s + 1, e0, e1, u0, u1, nhi, nlo, nidx);
+                        ahi = nhi; alo = nlo; aidx = nidx;
+                        if constexpr (MERGED) read_w(s + 1, bw);
+                        else {
+#pragma unroll
+                            for (int i = 0; i < 4 * OT; ++i) { if (HALF && ((i >> 1) & 1)) continue; bw[i] = nbw[i]; }
+                        }
+                    } else if constexpr (!MERGED) {        // (inline, not through the lambda: the 64-wide instantiations keep the code they were tuned with)
+                        float smx = 0.0f;
+    #pragma unroll
+                        for (int i = 0; i < 8; i += 2) {     // packed fp32, two scalars per instruction
+                            const f32x2 xp = {xv[i], xv[i + 1]};
+                            f32x2 pr = silu16_pair(xp) + (xp - xp) * splat2(16.0f);      // +-Inf -> NaN like the reference
+                            if constexpr (MERGED) pr = pr * splat2(64.0f);                      // the bases' scale: 2^10
+                            sv[i] = pr.x; sv[i + 1] = pr.y;
+                            smx = fmaxf(fmaxf(smx, fabsf(pr.x)), fabsf(pr.y));
+                        }
+                        big = __any(!(smx < 60000.0f) || sv[0] != sv[0] || sv[1] != sv[1] || sv[2] != sv[2] || sv[3] != sv[3] ||
+                                    sv[4] != sv[4] || sv[5] != sv[5] || sv[6] != sv[6] || sv[7] != sv[7]);   // wave-uniform
+                        if constexpr (HALF) { round_f16x2(sv, sh_hi); sh_lo = sh_hi; }
+                        else split_f16x2(sv, sh_hi, sh_lo);
+                    }
+                }
+                if constexpr (!MERGED) {
+                if (!big) {
+
+                    const unsigned char* wp = hb + HALF_SPL + (size_t)(gq * OT) * 2 * 1024 + lane * 16;
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) {
+                        f32x16& ab = MERGED ? acc[t] : acc_b[MERGED ? 0 : t];
+                        const u32x4 wh = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 0) * 1024);
+                        ab = mfma_f16(sh_hi, wh, ab);
+                        if constexpr (!HALF) {
+                            const u32x4 wl = *reinterpret_cast<const u32x4*>(wp + (t * 2 + 1) * 1024);
+                            ab = mfma_f16(sh_hi, wl, ab);
+                            ab = mfma_f16(sh_lo, wh, ab);
+                        }
+                    }
+                } else {
+                    // values beyond fp16 range (|x| > ~3700) or non-finite: this group's SiLU branch in exact fp32,
+                    // v_mfma_f32_32x32x2_f32 with k = lane half <-> this lane's own feature, weights straight from HBM
+                    const int f0 = ch * CF + kg * HF + 8 * g;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                        for (int t = 0; t < OT; ++t) {
+                            const int o = 32 * t + r;
+                            const int fr = SH ? (f0 + j) >> 1 : f0 + j;          // SH: only the first window carries the base weight
+                            const float w = (o < out && fr < in && !(SH && (j & 1))) ? base_w[(long)o * in + fr] : 0.0f;
+                            f32x16& ab = MERGED ? acc[t] : acc_b[MERGED ? 0 : t];
+                            ab = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j] * (MERGED ? 0.0009765625f : 0.0625f), w * wsc16, ab, 0, 0, 0);
+                        }
+                    }
+                }
                 }
             }
         }
@@ -639,7 +744,7 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
             const unsigned base = (unsigned)(wave * 32 + 4 * kg) * ldy4 + col * 4;
             float v[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = fmaf(acc[t][i], post, acc_b[t][i] * post_b);
+            for (int i = 0; i < 16; ++i) v[i] = MERGED ? acc[t][i] * post : fmaf(acc[t][i], post, acc_b[MERGED ? 0 : t][i] * post_b);
             if (col < out) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)               // rows >= N fall past the descriptor: dropped
@@ -684,14 +789,14 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
     if constexpr (MOM) {
         // the 8 waves' moments already sit in LDS; merged in wave order
         __syncthreads();
-        const float* s_mom = reinterpret_cast<const float*>(s_w + CHUNK_BYTES);   // [wave 8][t][mean | M2][32]
+        const float* s_mom = reinterpret_cast<const float*>(s_w + BUF_BYTES);     // [wave 8][t][mean | M2][32]
         float* s_cnt = reinterpret_cast<float*>(s_w);                              // (the weight chunk is dead)
         // (lane / wave ids taken afresh: the prologue's copies would otherwise stay live -- in scratch -- across the MFMA loop)
         const int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         if (lane2 == 0) s_cnt[wave] = mom_n;
         __syncthreads();
-        if (wave == 0 && lane2 < OT * 32 && lane2 < out) {
-            const int tid = lane2;
+        if (wave == 0)
+        for (int tid = lane2; tid < OT * 32 && tid < out; tid += 64) {        // (wide blocks: 128 columns, two per lane)
             float n = 0.0f, m = 0.0f, q = 0.0f;
             for (int w8 = 0; w8 < NT / 64; ++w8) {
                 const float nb = s_cnt[w8];
@@ -713,11 +818,11 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
 // ------------------------------------------------------------------ host side
 int kan_sparse_pack_fwd(const float* bw, const float* sw, const float* sc, int in, int out, int C, void* pack_fwd,
                         hipStream_t st) {
-    const int inv = in << sp_sh(C);
-    const size_t stride = sp_blk_bytes(in, inv, min(out, kSpOutBlk));
-    for (int b = 0; b * kSpOutBlk < out; ++b) {
-        const int ob = min(kSpOutBlk, out - b * kSpOutBlk);
-        const long o0 = (long)b * kSpOutBlk;
+    const int inv = in << sp_sh(C), blk = sp_out_blk(inv, out);
+    const size_t stride = sp_blk_bytes(in, inv, min(out, blk));
+    for (int b = 0; b * blk < out; ++b) {
+        const int ob = min(blk, out - b * blk);
+        const long o0 = (long)b * blk;
         const long items = (long)sp_chunks_bytes(inv, ob) / 16;
         sparse_pack_fwd_kernel<<<(int)min((items + 1023) / 1024, 64L), 1024, 0, st>>>(
             bw ? bw + o0 * in : nullptr, sw + o0 * in * C, sc ? sc + o0 * in : nullptr, in, ob, C,
@@ -798,7 +903,7 @@ static SpSplit sp_split_plan(long N, int nchunks) {        // same policy as kan
 
 size_t kan_sparse_fwd_ws_bytes(long N, int in, int out, int C) {
     const SpSplit p = sp_split_plan(N, cdiv(in << sp_sh(C), kSpCF));
-    return p.splits > 1 ? (size_t)p.splits * N * min(out, kSpOutBlk) * sizeof(float) : 0;
+    return p.splits > 1 ? (size_t)p.splits * N * min(out, sp_out_blk(in << sp_sh(C), out)) * sizeof(float) : 0;
 }
 
 __global__ void sparse_sum_splits_kernel(const float* __restrict__ part, int splits, long N, int out,
@@ -815,19 +920,23 @@ int moments_finish(const float* partial, int P, int F, float* col_mean, float* c
 static int sp_grid(long N) { return (int)min((long)cdiv(N, 256), 256L); }
 // column moments in the epilogue: whenever the launch is not split over the chunks (few-row inputs)
 bool kan_sparse_fwd_moments_ok(long N, int in, int out, int G, int K) {
+    // (wide 128-output blocks of layers with <= 8 coefficients: the column-moments instantiation <4, false, true> spills 7 VGPRs --
+    // eight distinct x values per group where the two-window layers have four; those layers take the stand-alone moments pass)
+    if (sp_out_blk(in << sp_sh(G + K), out) == kSpOutBlkWide && !sp_sh(G + K)) return false;
     return kan_sparse_fwd_ok(in, out, G, K) && sp_split_plan(N, cdiv(in << sp_sh(G + K), kSpCF)).splits == 1;
 }
-size_t kan_sparse_fwd_moments_ws_bytes(long N, int out) { return (size_t)sp_grid(N) * 3 * min(out, kSpOutBlk) * sizeof(float); }
+size_t kan_sparse_fwd_moments_ws_bytes(long N, int out) { return (size_t)sp_grid(N) * 3 * min(out, kSpOutBlkWide) * sizeof(float); }   // (either block width)
 
 template <int OT, bool SH, bool MOM, bool NARROW, bool HALF = false>
 static int launch_sparse(const float* x, long ldx, long N, int in, const float* knots, int nknots,
                          const unsigned char* pack, float* y, long ldy, int out, float* ws, size_t ws_bytes,
                          float* col_mean, float* col_m2, hipStream_t st) {
-    if constexpr (!HALF && !SH && !NARROW) {          // single-product mode (thread-local, set by the entry point): its instantiation
+    if constexpr (!HALF && !SH && !NARROW && OT != 4) {          // single-product mode (thread-local, set by the entry point): its instantiation
         if (g_half_products)
             return launch_sparse<OT, SH, MOM, NARROW, true>(x, ldx, N, in, knots, nknots, pack, y, ldy, out, ws, ws_bytes, col_mean, col_m2, st);
     }
-    const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT) + (MOM ? 8 * OT * 64 * sizeof(float) : 0);
+    // (wide, OT = 4: two LDS buffers of a QUARTER chunk each)
+    const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT) / (OT == 4 ? 2 : 1) + (MOM ? 8 * OT * 64 * sizeof(float) : 0);
     static unsigned long long configured = 0;          // (per device: common.h)
     if (first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH, MOM, NARROW, -1, false, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -943,16 +1052,24 @@ int kan_sparse_fwd_agg(const float* x, long ldx, long N, const int* rowptr, cons
 int kan_sparse_fwd(const float* x, long ldx, long N, const float* knots, int in, int out, int G, int K,
                    const void* pack, float* y, long ldy, void* ws, size_t ws_bytes, float* col_mean, float* col_m2,
                    hipStream_t st) {
-    const int nk = G + 2 * K + 1, sh = sp_sh(G + K);
-    const size_t stride = sp_blk_bytes(in, in << sh, min(out, kSpOutBlk));
-    for (int b = 0; b * kSpOutBlk < out; ++b) {
-        const int ob = min(kSpOutBlk, out - b * kSpOutBlk), OT = cdiv(ob, 32);
+    const int nk = G + 2 * K + 1, sh = sp_sh(G + K), blk = sp_out_blk(in << sh, out);
+    const size_t stride = sp_blk_bytes(in, in << sh, min(out, blk));
+    for (int b = 0; b * blk < out; ++b) {
+        const int ob = min(blk, out - b * blk), OT = cdiv(ob, 32);
         const unsigned char* p = static_cast<const unsigned char*>(pack) + b * stride;
-        float* yb = y + b * kSpOutBlk;
+        float* yb = y + b * blk;
         int rc;
-        float* cm = col_mean ? col_mean + b * kSpOutBlk : nullptr;
-        float* cq = col_mean ? col_m2 + b * kSpOutBlk : nullptr;
+        float* cm = col_mean ? col_mean + b * blk : nullptr;
+        float* cq = col_mean ? col_m2 + b * blk : nullptr;
         const bool narrow = (in << sh) <= 32;
+        if (OT == 4) {                                     // wide block (sp_out_blk: whole 128-output blocks, never narrow)
+#define LW(SS, MM) launch_sparse<4, SS, MM, false>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, cm, cq, st)
+            if (col_mean && !sh) return fail(KAGNN_ERR_UNSUPPORTED, "%s: no column moments from the wide block of a <= 8-coefficient layer (kan_sparse_fwd_moments_ok)", "kan_sparse_fwd");
+            rc = col_mean ? LW(true, true) : (sh ? LW(true, false) : LW(false, false));
+#undef LW
+            if (rc) return rc;
+            continue;
+        }
 #define LL(OO, SS, MM, NN) launch_sparse<OO, SS, MM, NN>(x, ldx, N, in, knots, nk, p, yb, ldy, ob, static_cast<float*>(ws), ws_bytes, cm, cq, st)
 #define L(OO, SS, MM) (narrow ? LL(OO, SS, MM, true) : LL(OO, SS, MM, false))
         if (col_mean) {
@@ -974,6 +1091,7 @@ int kan_sparse_fwd(const float* x, long ldx, long N, const float* knots, int in,
 // 16-byte aligned rows (leading dimensions: multiples of 4, <= 7680)
 bool kan_sparse_fwd_parts_ok(const int* widths, int nparts, int in, int out, int G, int K) {
     if (!kan_sparse_fwd_ok(in, out, G, K) || sp_sh(G + K) || nparts < 1 || nparts > 8 || in > 8 * kSpCF) return false;
+    if (sp_out_blk(in, out) != kSpOutBlk) return false;     // (a wide layer's pack has 128-output blocks; read-outs are narrow)
     int sum = 0;
     for (int i = 0; i < nparts; ++i) {
         if (widths[i] <= 0 || widths[i] % kSpCF) return false;
