@@ -496,18 +496,9 @@ __global__ __launch_bounds__(512) void kan_split_dx_kernel(
     }
 }
 
-// KAGNN_DX_SCHEDULE = 0 plain | 1 gy prefetch (default) | 2 prefetch + phase ping-pong.  Measured round 2
-// (profiles/r02_experiments.md): 0.565 / 0.561 / 0.555 ms per step -- the schedule is not what limits this kernel.
-static int dx_schedule() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("KAGNN_DX_SCHEDULE");
-        v = e ? atoi(e) : 1;
-        if (v < 0 || v > 2) v = 1;
-    }
-    return v;
-}
-
+// Schedule: the gy rows of the next row tile are requested a tile ahead (PP = 1).  The plain schedule (PP = 0) serves the instantiations
+// that cannot afford the prefetched rows' registers; the phase ping-pong of SIMD partners (PP = 2) measured 0.555 vs 0.561 ms per step in
+// round 2 -- the schedule is not what limits this kernel -- and is no longer instantiated (its environment switch went in round 5).
 template <int K, int Q2, bool GEN, int PP, bool GX16 = false, bool BNB = false, bool XAFF = false, bool XST = false, bool HALF = false>
 static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, long N, int in, int out, int C,
                         const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx,
@@ -561,11 +552,7 @@ static int launch_dx(const float* x, long ldx, const float* gy, long ldgy, long 
             return launch_dx_pp<K, Q2, GEN, 1, false, false, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
         }
         if (gx16) return launch_dx_pp<K, Q2, GEN, 1, true>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
-        switch (dx_schedule()) {
-            case 0: return launch_dx_pp<K, Q2, GEN, 0>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
-            case 2: return launch_dx_pp<K, Q2, GEN, 2>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
-            default: return launch_dx_pp<K, Q2, GEN, 1>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
-        }
+        return launch_dx_pp<K, Q2, GEN, 1>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots, pack, gx, ldgx, rb, accumulate, st);
     }
     if (gx16) return fail(KAGNN_ERR_UNSUPPORTED, "%s: bf16 gradient rows need a cubic layer with <= 8 coefficients", "kan_split_dx");
     if (rb.x_affine) return fail(KAGNN_ERR_UNSUPPORTED, "%s: an input affine needs a cubic layer with <= 8 coefficients and <= 64 outputs", "kan_split_dx");

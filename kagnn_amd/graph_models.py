@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import graph_ops, ops
 from .models import (FASTKAGATConv, FASTKAGCNConv, GIFASTKANLayer, GIKANLayer, KAGATConv, KAGCNConv, _has_hooks, conv_bn_dropout,
                      make_fastkan, make_kan)
 from .norm import BatchNorm1d
@@ -48,8 +48,8 @@ class _SumOfEmbeddings(nn.Module):
         if (x.is_cuda and x.dtype == torch.int64 and x.dim() == 2 and x.size(1) <= len(tables) and not torch.compiler.is_compiling()
                 and all(type(t) is nn.Embedding and t.padding_idx is None and t.max_norm is None and not t.sparse
                         and not t.scale_grad_by_freq and t.weight.dtype == torch.float32 and t.num_embeddings <= 512 for t in tables)):
-            # one launch per feature column each way (ops._EmbeddingSumFn) instead of gather + add / aten's sort-based backward
-            return ops.embedding_sum(x, [tables[i].weight for i in range(x.shape[1])])
+            # one launch per feature column each way (graph_ops._EmbeddingSumFn) instead of gather + add / aten's sort-based backward
+            return graph_ops.embedding_sum(x, [tables[i].weight for i in range(x.shape[1])])
         out = 0
         for i in range(x.shape[1]):
             out = out + tables[i](x[:, i])
@@ -98,7 +98,7 @@ class _GraphLevel(nn.Module):
         # GINE stacks (graph_regression/models.py:107-119): all convolutions + norms as ONE tape node where the shapes allow it
         if (edge_attr is not None and self.training and not (self.dropout.p > 0.0) and all(isinstance(c, GINEKANLayer) for c in self.conv)
                 and all(type(b) is BatchNorm1d for b in self.bn) and not any(_has_hooks(m) for m in list(self.conv) + list(self.bn))):
-            h = ops.gine_kan_stack(x, edge_attr, g, list(self.conv), list(self.bn))
+            h = graph_ops.gine_kan_stack(x, edge_attr, g, list(self.conv), list(self.bn))
             if h is not None:
                 return h
         for conv, bn in zip(self.conv, self.bn):
@@ -162,14 +162,14 @@ class GINEKANLayer(nn.Module):
         return self._eps_val
 
     def forward_fused_norm(self, x, edge_index, edge_attr, bn):
-        """``bn(self(x, edge_index, edge_attr))`` for a training-mode BatchNorm1d as ONE tape node (``ops._GineKanLayerFn``: one
+        """``bn(self(x, edge_index, edge_attr))`` for a training-mode BatchNorm1d as ONE tape node (``graph_ops._GineKanLayerFn``: one
         library call each way), or ``None`` when the chain is outside what the node covers -- nothing has been touched then."""
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
-        return ops.gine_kan_layer(x, edge_attr, g, 1.0 + self._eps(), self.nn, batch_norm=bn)
+        return graph_ops.gine_kan_layer(x, edge_attr, g, 1.0 + self._eps(), self.nn, batch_norm=bn)
 
     def forward(self, x, edge_index, edge_attr):
         g = edge_index if isinstance(edge_index, ops.GraphIndex) else ops.graph_index(edge_index, x.size(0))
-        y = ops.gine_kan_layer(x, edge_attr, g, 1.0 + self._eps(), self.nn)          # one tape node: aggregate + KAN chain
+        y = graph_ops.gine_kan_layer(x, edge_attr, g, 1.0 + self._eps(), self.nn)          # one tape node: aggregate + KAN chain
         if y is not None:
             return y
         return self.nn(ops.aggregate_gine(x, edge_attr, g, self_scale=1.0 + self._eps()))

@@ -318,7 +318,7 @@ class GraphIndex:
         return self.rowptr, self.col, self.perm, self.hub_seg, self.num_hub_seg
 
 
-_SMALL_CSR = os.environ.get("KAGNN_SMALL_CSR", "1") != "0"      # 0: always the rocPRIM build (A/B; bit-identical arrays)
+_SMALL_CSR = True      # False: always the rocPRIM build (a module attribute for the bitwise tests; identical arrays)
 _pending_checks: "dict[int, list]" = {}
 
 
@@ -598,53 +598,6 @@ def aggregate_gine(x, edge_attr, g: GraphIndex, self_scale: float = 1.0) -> torc
     return _GineFn.apply(x, edge_attr, g, float(self_scale))
 
 
-# ======================================================================== embedding-table encoders
-class _EmbeddingSumFn(Function):
-    """``sum_c tables[c][x[:, c]]`` (the OGB-style Atom / BondEncoder of the graph-level models, reference
-    ``graph_regression/models.py:244-281``): one launch per feature column each way (``kagnn_embedding_fwd / _bwd``) instead of a
-    gather + add per column forward and aten's sort-based ``embedding_dense_backward`` (~12 launches per table) backward."""
-
-    @staticmethod
-    @_on_operand_device
-    def forward(ctx, x, *tables):
-        _need_cuda(x, *tables)
-        if x.dtype != torch.int64 or x.dim() != 2 or x.size(1) != len(tables):
-            raise ValueError("x must be an int64 [N, columns] matrix with one table per column")
-        x = x.contiguous()
-        n, cols, f = x.size(0), x.size(1), tables[0].size(1)
-        out = torch.empty((n, f), dtype=torch.float32, device=x.device)
-        tabs = [t.contiguous() for t in tables]
-        for c, t in enumerate(tabs):
-            if t.dtype != torch.float32 or t.size(1) != f:
-                raise ValueError("embedding tables must be fp32 [V, F] with one F")
-            _call("kagnn_embedding_fwd", x.data_ptr() + 8 * c, cols, n, _ptr(t), t.size(0), f, _ptr(out), f, int(c > 0), _stream())
-        ctx.save_for_backward(x)
-        ctx.shapes = [tuple(t.shape) for t in tabs]
-        return out
-
-    @staticmethod
-    @once_differentiable
-    @_on_operand_device
-    def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        g = _rows(g)
-        n, cols = x.shape
-        grads = []
-        for c, (v, f) in enumerate(ctx.shapes):
-            if not ctx.needs_input_grad[1 + c]:
-                grads.append(None)
-                continue
-            gt = torch.empty((v, f), dtype=torch.float32, device=g.device)
-            ws = _ws(_sizes("kagnn_embedding_bwd_workspace_bytes", n, v, f), g.device)
-            _call("kagnn_embedding_bwd", x.data_ptr() + 8 * c, cols, n, _ptr(g), _ld(g), v, f, _ptr(gt), _ptr(ws), ws.numel(), _stream())
-            grads.append(gt)
-        return (None, *grads)
-
-
-def embedding_sum(x: torch.Tensor, tables) -> torch.Tensor:
-    return _EmbeddingSumFn.apply(x, *tables)
-
-
 # ======================================================================== pooling
 def segment_ptr(batch: torch.Tensor, num_graphs: int) -> torch.Tensor:
     """Offsets of a SORTED batch vector (torch_geometric's DataLoader emits it sorted): ptr[b] = the first node of graph b.
@@ -879,267 +832,6 @@ def _gin_kan_layer_fwd_raw(xg, g, self_scale, knots, grid_size, spline_order, mo
           _ptr_array(pfs), _ptr_array(pds), _ptr(mom[0]) if moments else None, _ptr(mom[1]) if moments else None,
           _ptr(ws), ws.numel(), _stream())
     return acts, pds, mom
-
-
-class _GineKanLayerFn(Function):
-    """One KAN-GINE convolution -- ``KAN((1 + eps) x_i + sum_{j->i} relu(x_j + e_ij))`` -- and, optionally, the training-mode
-    ``BatchNorm1d`` that follows it (reference ``graph_regression/models.py:98,107-119``) as ONE tape node over
-    ``kagnn_gine_kan_layer_fwd / _bwd``: one library call each way (round 5; BASELINE config 4's mini-batch step is launch- and
-    host-bound -- a conv used to be ~7 calls forward and ~10 backward).  Forward: aggregation + one pack launch + the chain, the
-    norm's batch statistics from the last kernel's epilogue, then the normalising pass; backward: the norm's statistics pass, its
-    element-wise backward inside the last input-gradient kernel, dW / dX per layer, the transposed GINE aggregation (``gx`` and the
-    edge-attribute gradient from the same kernel).  Same kernels and summation orders as the composition: same bits."""
-
-    @staticmethod
-    @_on_operand_device
-    def forward(ctx, x, edge_attr, g, self_scale, knots, grid_size, spline_order, mode, bn_w, bn_b, rm, rv, momentum, eps, *params):
-        """``bn_w`` .. ``eps``: the training-mode BatchNorm1d (affine) that follows the convolution, or ``bn_w is None``: none"""
-        _need_cuda(x, edge_attr, bn_w, bn_b, rm, rv, *params)
-        bn = None if bn_w is None else True
-        nl = len(params) // 3
-        layers = [(params[3 * i].contiguous(), params[3 * i + 1].contiguous(), params[3 * i + 2].contiguous()) for i in range(nl)]
-        xg, ea = _rows(x), _rows(edge_attr)
-        n, dev = xg.size(0), xg.device
-        widths = [layers[0][1].size(1)] + [sw.size(0) for _, sw, _ in layers]
-        if n != g.num_nodes or ea.shape != (g.num_edges, widths[0]) or xg.size(1) != widths[0]:
-            raise ValueError("x must be [N, F] and edge_attr [E, F] with F the chain's input width, N / E those of the graph")
-        acts = [torch.empty((n, w), dtype=torch.float32, device=dev) for w in widths]
-        pfs, pds = [], []
-        for i in range(nl):
-            fb, db = _sizes("kagnn_kan_pack_bytes", widths[i], widths[i + 1], grid_size, spline_order, mode, outputs=2)
-            pfs.append(_ws(fb, dev)); pds.append(_ws(db, dev))
-        warr = (ctypes.c_int32 * (nl + 1))(*widths)
-        wf, _ = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), grid_size, spline_order, mode, 0, 0, outputs=2)
-        ws = _ws(wf, dev)
-        mom = torch.empty((2, widths[nl]), dtype=torch.float32, device=dev) if bn is not None else None
-        _call("kagnn_gine_kan_layer_fwd", _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm),
-              float(self_scale), nl, warr, _ptr_array([l[0] for l in layers]), _ptr_array([l[1] for l in layers]),
-              _ptr_array([l[2] for l in layers]), _ptr(knots), grid_size, spline_order, mode, _ptr_array(acts), _ptr_array(pfs),
-              _ptr_array(pds), _ptr(mom[0]) if mom is not None else None, _ptr(mom[1]) if mom is not None else None,
-              _ptr(ws), ws.numel(), _stream())
-        y = acts[nl]
-        saved = [xg, ea]
-        for i in range(nl):
-            saved += [acts[i], layers[i][1], layers[i][2], pds[i]]
-        ctx.meta = (g, self_scale, grid_size, spline_order, mode, nl, widths, bn is not None)
-        if bn is None:
-            ctx.save_for_backward(*saved, knots)
-            return y
-        h, mean, rstd = _batchnorm_fwd_raw(y, bn_w, bn_b, rm, rv, True, momentum, eps, mom)
-        ctx.save_for_backward(*saved, knots, y, bn_w, mean, rstd)
-        return h
-
-    @staticmethod
-    @once_differentiable
-    @_on_operand_device
-    def backward(ctx, gh):
-        g, self_scale, G, K, mode, nl, widths, has_bn = ctx.meta
-        t = ctx.saved_tensors
-        xg, ea = t[0], t[1]
-        knots = t[2 + 4 * nl]
-        gh = _rows(gh)
-        n, dev = gh.size(0), gh.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        acts = [t[2 + 4 * i] for i in range(nl)]
-        sws, scs, pds = [t[3 + 4 * i] for i in range(nl)], [t[4 + 4 * i] for i in range(nl)], [t[5 + 4 * i] for i in range(nl)]
-        gbw = [torch.empty((widths[i + 1], widths[i]), **f32) for i in range(nl)]
-        gsw = [torch.empty((widths[i + 1], widths[i], G + K), **f32) for i in range(nl)]
-        gsc = [torch.empty((widths[i + 1], widths[i]), **f32) for i in range(nl)]
-        gx = torch.empty((n, widths[0]), **f32)
-        gea = torch.empty((g.num_edges, widths[0]), **f32) if ctx.needs_input_grad[1] else None
-        _, wb = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), G, K, mode, 0, 0, outputs=2)
-        y = bn_w = mean = rstd = g_bnw = g_bnb = None
-        if has_bn:
-            y, bn_w, mean, rstd = t[3 + 4 * nl:7 + 4 * nl]
-            wb += _sizes("kagnn_gin_kan_layer_bwd_bn_workspace_bytes", n, widths[nl])
-            g_bnw, g_bnb = torch.empty(widths[nl], **f32), torch.empty(widths[nl], **f32)
-        ws = _ws(wb, dev)
-        warr = (ctypes.c_int32 * (nl + 1))(*widths)
-        _call("kagnn_gine_kan_layer_bwd", _ptr(gh), _ld(gh), _ptr(y), _ld(y) if y is not None else 0, _ptr(bn_w), _ptr(mean), _ptr(rstd),
-              _ptr(g_bnw), _ptr(g_bnb), _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(g.perm_t),
-              float(self_scale), nl, warr, _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, _ptr_array(acts), _ptr_array(pds),
-              _ptr(gx), widths[0], _ptr(gea), widths[0], _ptr_array(gbw), _ptr_array(gsw), _ptr_array(gsc), _ptr(ws), ws.numel(), _stream())
-        grads = []
-        for i in range(nl):
-            grads += [gbw[i], gsw[i], gsc[i]]
-        return (gx, gea, None, None, None, None, None, None, g_bnw, g_bnb, None, None, None, None, *grads)
-
-
-class _GineKanStackFn(Function):
-    """The whole message-passing stack of a graph-level model -- ``nconv x {GINE convolution around a KAN chain -> training-mode
-    BatchNorm1d}``, all chains hidden -> ... -> hidden (reference ``graph_regression/models.py:107-119``) -- as ONE tape node over
-    ``kagnn_gine_kan_stack_fwd / _bwd`` (round 5; see include/kagnn_hip.h: on a 256-molecule batch the per-convolution nodes cost the
-    host as much as the device).  Everything a step allocates comes from a handful of tensors (activations, normalised outputs,
-    statistics, gradients) that the per-layer pointers index into."""
-
-    @staticmethod
-    @_on_operand_device
-    def forward(ctx, x, edge_attr, g, self_scales, knots, grid_size, spline_order, mode, running, momentum, eps, nconv, nl, *params):
-        """``params``: per convolution ``bn_weight, bn_bias`` then per layer ``base_weight, spline_weight, spline_scaler``;
-        ``running``: per convolution ``(running_mean, running_var)`` or ``(None, None)``"""
-        _need_cuda(x, edge_attr, *params)
-        xg, ea = _rows(x), _rows(edge_attr)
-        n, dev, H = xg.size(0), xg.device, xg.size(1)
-        per = 2 + 3 * nl
-        bnw = [params[i * per].contiguous() for i in range(nconv)]
-        bnb = [params[i * per + 1].contiguous() for i in range(nconv)]
-        bws, sws, scs = [], [], []
-        for i in range(nconv):
-            for l in range(nl):
-                b, w, c = params[i * per + 2 + 3 * l:i * per + 5 + 3 * l]
-                bws.append(b.contiguous()); sws.append(w.contiguous()); scs.append(c.contiguous())
-        if n != g.num_nodes or ea.shape != (g.num_edges, H):
-            raise ValueError("x must be [N, H] and edge_attr [E, H] with N / E those of the graph")
-        f32 = dict(dtype=torch.float32, device=dev)
-        acts_all = torch.empty((nconv, nl + 1, n, H), **f32)
-        h_all = torch.empty((nconv, n, H), **f32)
-        stats = torch.empty((nconv, 2, H), **f32)
-        fb, db = _sizes("kagnn_kan_pack_bytes", H, H, grid_size, spline_order, mode, outputs=2)
-        fb, db = (fb + 255) & ~255, (db + 255) & ~255
-        packs = torch.empty(nconv * nl * (fb + db), dtype=torch.uint8, device=dev)
-        pf_ptr = [packs.data_ptr() + k * fb for k in range(nconv * nl)]
-        pd_ptr = [packs.data_ptr() + nconv * nl * fb + k * db for k in range(nconv * nl)]
-        widths = (H,) * (nl + 1)
-        warr = (ctypes.c_int32 * (nl + 1))(*widths)
-        wf, _ = _sizes("kagnn_gine_kan_stack_workspace_bytes", n, nconv, nl, widths, grid_size, spline_order, mode, outputs=2)
-        ws = _ws(wf, dev)
-        VP, FA = ctypes.c_void_p * (nconv * nl), ctypes.c_float * nconv
-        VC = ctypes.c_void_p * nconv
-        a0, hs = acts_all.data_ptr(), n * H * 4
-        acts_ptr = (ctypes.c_void_p * (nconv * (nl + 1)))(*[a0 + k * hs for k in range(nconv * (nl + 1))])
-        h_ptr = VC(*[h_all.data_ptr() + i * hs for i in range(nconv)])
-        mean_ptr = VC(*[stats.data_ptr() + (2 * i) * H * 4 for i in range(nconv)])
-        rstd_ptr = VC(*[stats.data_ptr() + (2 * i + 1) * H * 4 for i in range(nconv)])
-        scale_arr = FA(*[float(v) for v in self_scales])
-        _call("kagnn_gine_kan_stack_fwd", _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm), scale_arr,
-              nconv, nl, warr, _ptr_array(bws), _ptr_array(sws), _ptr_array(scs), _ptr(knots), grid_size, spline_order, mode, acts_ptr,
-              VP(*pf_ptr), VP(*pd_ptr), _ptr_array(bnw), _ptr_array(bnb), _ptr_array([r[0] for r in running]),
-              _ptr_array([r[1] for r in running]), FA(*[float(v) for v in momentum]), FA(*[float(v) for v in eps]), h_ptr, mean_ptr,
-              rstd_ptr, _ptr(ws), ws.numel(), _stream())
-        ctx.meta = (g, tuple(float(v) for v in self_scales), grid_size, spline_order, mode, nconv, nl, H, fb, db)
-        ctx.save_for_backward(xg, ea, acts_all, h_all, stats, packs, knots, *bnw, *sws, *scs)
-        return h_all[nconv - 1]
-
-    @staticmethod
-    @once_differentiable
-    @_on_operand_device
-    def backward(ctx, gh):
-        g, self_scales, G, K, mode, nconv, nl, H, fb, db = ctx.meta
-        t = ctx.saved_tensors
-        xg, ea, acts_all, h_all, stats, packs, knots = t[:7]
-        bnw = t[7:7 + nconv]
-        sws = t[7 + nconv:7 + nconv + nconv * nl]
-        scs = t[7 + nconv + nconv * nl:7 + nconv + 2 * nconv * nl]
-        gh = _rows(gh)
-        n, dev = gh.size(0), gh.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        C = G + K
-        gx = torch.empty((n, H), **f32)
-        gea = torch.empty((g.num_edges, H), **f32) if ctx.needs_input_grad[1] else None
-        g_bn = torch.empty((nconv, 2, H), **f32)
-        g_bw = torch.empty((nconv * nl, H, H), **f32)
-        g_sw = torch.empty((nconv * nl, H, H, C), **f32)
-        g_sc = torch.empty((nconv * nl, H, H), **f32)
-        widths = (H,) * (nl + 1)
-        warr = (ctypes.c_int32 * (nl + 1))(*widths)
-        _, wb = _sizes("kagnn_gine_kan_stack_workspace_bytes", n, nconv, nl, widths, G, K, mode, outputs=2)
-        ws = _ws(wb, dev)
-        VP, FA, VC = ctypes.c_void_p * (nconv * nl), ctypes.c_float * nconv, ctypes.c_void_p * nconv
-        a0, hs = acts_all.data_ptr(), n * H * 4
-        acts_ptr = (ctypes.c_void_p * (nconv * (nl + 1)))(*[a0 + k * hs for k in range(nconv * (nl + 1))])
-        pd_ptr = VP(*[packs.data_ptr() + nconv * nl * fb + k * db for k in range(nconv * nl)])
-        _call("kagnn_gine_kan_stack_bwd", _ptr(gh), _ld(gh), _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr_t), _ptr(g.col_t),
-              _ptr(g.perm_t), FA(*self_scales), nconv, nl, warr, _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, acts_ptr, pd_ptr,
-              VC(*[h_all.data_ptr() + i * hs for i in range(nconv)]), _ptr_array(bnw),
-              VC(*[stats.data_ptr() + (2 * i) * H * 4 for i in range(nconv)]), VC(*[stats.data_ptr() + (2 * i + 1) * H * 4 for i in range(nconv)]),
-              _ptr(gx), H, _ptr(gea), H, VC(*[g_bn.data_ptr() + (2 * i) * H * 4 for i in range(nconv)]),
-              VC(*[g_bn.data_ptr() + (2 * i + 1) * H * 4 for i in range(nconv)]),
-              VP(*[g_bw.data_ptr() + k * H * H * 4 for k in range(nconv * nl)]), VP(*[g_sw.data_ptr() + k * H * H * C * 4 for k in range(nconv * nl)]),
-              VP(*[g_sc.data_ptr() + k * H * H * 4 for k in range(nconv * nl)]), _ptr(ws), ws.numel(), _stream())
-        grads = []
-        for i in range(nconv):
-            grads += [g_bn[i, 0], g_bn[i, 1]]
-            for l in range(nl):
-                k = i * nl + l
-                grads += [g_bw[k], g_sw[k], g_sc[k]]
-        return (gx, gea, None, None, None, None, None, None, None, None, None, None, None, *grads)
-
-
-_GINE_STACK_ABI = os.environ.get("KAGNN_GINE_STACK_ABI", "1") != "0"     # 0: one tape node per convolution (A/B, bit-identical)
-
-
-def gine_kan_stack(x, edge_attr, g: "GraphIndex", convs, bns):
-    """``for conv, bn in zip(convs, bns): x = bn(conv(x, g, edge_attr))`` as ONE tape node (``_GineKanStackFn``), or ``None`` when the
-    stack is outside what the node covers (the caller then runs the loop): GINE convolutions around KAN chains of identical
-    hidden -> ... -> hidden widths (<= 64: one pack launch for the stack), one uniform grid and precision for all of them, a
-    split-like mode, training-mode affine BatchNorm1d modules, fp32 CUDA rows, at most 16 KANLinears in all, not under torch.compile."""
-    if (not _GINE_STACK_ABI or not _GINE_LAYER_ABI or torch.compiler.is_compiling() or not x.is_cuda or x.dtype != torch.float32
-            or x.size(0) < 2 or len(convs) < 2):
-        return None
-    H = x.size(1)
-    first = None
-    params, scales, running, momentum, eps = [], [], [], [], []
-    nl = None
-    for conv, bn in zip(convs, bns):
-        layers = list(getattr(conv.nn, "layers", []))
-        if nl is None:
-            nl = len(layers)
-        if not (1 <= len(layers) == nl) or any(type(l).__name__ != "KANLinear" for l in layers):
-            return None
-        if first is None:
-            first = layers[0]
-        for l in layers:
-            if (l.in_features != H or l.out_features != H or l.precision != first.precision or l.grid_size != first.grid_size
-                    or l.spline_order != first.spline_order or l._knots().dim() != 1):
-                return None
-        if not (bn.training and bn.affine and bn.num_features == H):
-            return None
-    mode = first.precision if first.precision is not None else default_precision()
-    if not split_like(mode) or first.spline_order != 3 or first.grid_size + first.spline_order > 8 or H > 64 or len(convs) * nl > 16:
-        return None
-    for conv, bn in zip(convs, bns):
-        factor, use_running = bn.step()
-        params += [bn.weight, bn.bias]
-        for l in conv.nn.layers:
-            params += [l.base_weight, l.spline_weight, l.spline_scaler]
-        scales.append(1.0 + conv._eps())
-        running.append((bn.running_mean, bn.running_var) if use_running else (None, None))
-        momentum.append(factor); eps.append(bn.eps)
-    return _GineKanStackFn.apply(x, edge_attr, g, tuple(scales), first._knots(), first.grid_size, first.spline_order, mode, tuple(running),
-                                 tuple(momentum), tuple(eps), len(convs), nl, *params)
-
-
-_GINE_LAYER_ABI = os.environ.get("KAGNN_GINE_LAYER_ABI", "1") != "0"     # 0: the per-operation composition (A/B, bit-identical)
-
-
-def gine_kan_layer(x, edge_attr, g: "GraphIndex", self_scale: float, net, batch_norm=None):
-    """``net(aggregate_gine(x, edge_attr))`` -- and ``bn(.)`` of it when ``batch_norm`` (a training-mode ``kagnn_amd.BatchNorm1d``
-    with affine parameters) is given -- as one tape node (``_GineKanLayerFn``), or ``None`` when the chain is outside what the
-    node covers (the caller then composes the operations): a KAN chain of uniform grids, one precision, split-like mode, <= 8
-    layers, fp32 CUDA rows, not under torch.compile."""
-    if not _GINE_LAYER_ABI or torch.compiler.is_compiling() or not x.is_cuda or x.dtype != torch.float32 or x.size(0) < 2:
-        return None
-    layers = list(getattr(net, "layers", []))
-    if not (1 <= len(layers) <= 8) or any(type(l).__name__ != "KANLinear" for l in layers):
-        return None
-    first = layers[0]
-    mode = first.precision if first.precision is not None else default_precision()
-    if not split_like(mode) or first.grid_size + first.spline_order > 16:
-        return None
-    if any(l.precision != first.precision or l.grid_size != first.grid_size or l.spline_order != first.spline_order
-           or l._knots().dim() != 1 for l in layers):
-        return None
-    if max(max(l.in_features, l.out_features) for l in layers) > 7680:
-        return None
-    params = []
-    for l in layers:
-        params += [l.base_weight, l.spline_weight, l.spline_scaler]
-    bn = (None, None, None, None, 0.0, 0.0)
-    if batch_norm is not None:
-        factor, use_running = batch_norm.step()
-        bn = (batch_norm.weight, batch_norm.bias, batch_norm.running_mean if use_running else None,
-              batch_norm.running_var if use_running else None, factor, batch_norm.eps)
-    return _GineKanLayerFn.apply(x, edge_attr, g, float(self_scale), first._knots(), first.grid_size, first.spline_order, mode, *bn, *params)
 
 
 class AffineRows:

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import kagnn_amd
-from kagnn_amd import ops
+from kagnn_amd import graph_ops, ops
 from oracle import kan_oracle as orc
 from helpers import FK_KEYS, KAN_KEYS, T, TOL, assert_close, oracle_kan_linear_fwd_bwd, prenorm_bias_noise
 
@@ -711,8 +711,8 @@ def test_gine_conv_one_library_call_each_way_matches_the_composition(golden, mon
     state = {k[len(pre):]: T(z[k], DEV) for k in z.files if k.startswith(pre)}
     res = {}
     for how in ("stack", "layer", "ops"):
-        monkeypatch.setattr(ops, "_GINE_STACK_ABI", how == "stack")
-        monkeypatch.setattr(ops, "_GINE_LAYER_ABI", how != "ops")
+        monkeypatch.setattr(graph_ops, "_GINE_STACK_ABI", how == "stack")
+        monkeypatch.setattr(graph_ops, "_GINE_LAYER_ABI", how != "ops")
         m.load_state_dict(state, strict=True)
         m = m.to(DEV).train()
         m.zero_grad()

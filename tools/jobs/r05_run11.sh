@@ -1,0 +1,6 @@
+cd ${GRAFT_REPO_ROOT:-.}
+mkdir -p gpurun_out
+KAGNN_TEST_SOFT=1 timeout 900 python -m pytest tests/test_gpu_half.py -q > gpurun_out/run11_half.log 2>&1; tail -4 gpurun_out/run11_half.log
+cp gpurun_out/parity_soft_failures.json gpurun_out/run11_soft.json
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_epilogue.py tests/test_gpu_fullsize.py -q -k "not 4gib" > gpurun_out/run11_tests.log 2>&1; tail -5 gpurun_out/run11_tests.log
+python tools/configs_sweep.py 4 2>&1 | tail -1
