@@ -307,15 +307,15 @@ def test_sharded_layers_two_ranks_two_gpus_rccl(tmp_path):
 # the collectives on gloo (KAGNN_BENCH_BACKEND=gloo: numbers meaningless, control flow real): the combination loop, the
 # reporter process that owns THE line, and the watchdog -- none of the N > 1 transports has ever run on two devices, so
 # the line must survive one that hangs and one that takes a rank down (KAGNN_BENCH_FAULT)
-def _run_bench_two_ranks(extra_env, timeout=420):
+def _run_bench_two_ranks(extra_env, timeout=420, nproc=2):
     import json
     import subprocess
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, KAGNN_BENCH_BACKEND="gloo", **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
            "--nodes", "20000", "--edges", "200000"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -357,3 +357,15 @@ def test_bench_two_ranks_prints_one_line_even_when_a_transport_hangs_or_kills_a_
     # a transport that takes rank 0 itself down (SIGKILL): the reporter still prints what rank 0 had handed it
     rc, line, err = _run_bench_two_ranks({"KAGNN_BENCH_FAULT": "transposed/p2p:kill:0", "KAGNN_BENCH_PHASE_TIMEOUT": "25"})
     assert "interim" in line and len(line["multi_gpu_probe"]["combinations"]) == 3 and line["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_one_gpu_runs_every_combination():
+    """bench.py --gpus 4 as the driver launches it (four ranks on cuda:0, collectives on gloo): the probe, the selection of north_star's
+    scheme and the per-rank gather at P = 4 -- 16 columns per rank at the headline width"""
+    rc, line, err = _run_bench_two_ranks({}, nproc=4)
+    assert rc == 0, err[-3000:]
+    combos = {(c["scheme"], c["comm"]): c for c in line["multi_gpu_probe"]["combinations"]}
+    for k in (("feature", "rccl"), ("transposed", "rccl"), ("feature", "p2p"), ("transposed", "p2p")):
+        assert "error" not in combos[k] and combos[k]["ms_per_step"] > 0, combos[k]
+    assert line["n_gpus"] == 4 and line["complete"] is True and line["value_scheme_is_north_star"] is True and len(line["per_rank"]) == 4

@@ -1,0 +1,91 @@
+"""Is the graph-level training step run-to-run reproducible, and does the host running ahead of the device change it?
+Runs the reference's mini-batch loop (optuna_zinc.py:56-66) on the same seeded model several ways and prints per-epoch
+mean losses (fp64 accumulation on the host from per-step fp32 losses kept on the device) plus whether final parameters
+are bit-identical.  Diagnostic only."""
+import os, sys
+from types import SimpleNamespace
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import kagnn_amd
+DEV = "cuda:0"
+B, H, EPOCHS = 32, 32, int(os.environ.get("EPOCHS", "8"))
+
+
+def make_batches():
+    batches = []
+    for k in range(4):
+        g = torch.Generator().manual_seed(50 + k)
+        sizes = torch.randint(10, 30, (B,), generator=g)
+        n = int(sizes.sum()); off = torch.cumsum(sizes, 0) - sizes
+        src, dst, batch = [], [], []
+        for b in range(B):
+            nb = int(sizes[b]); eb = 2 * nb + 3
+            src.append(torch.randint(0, nb, (eb,), generator=g) + off[b]); dst.append(torch.randint(0, nb, (eb,), generator=g) + off[b])
+            batch.append(torch.full((nb,), b))
+        e = sum(len(s_) for s_ in src)
+        x = torch.randint(0, 21, (n, 1), generator=g)
+        batches.append(SimpleNamespace(x=x.to(DEV), edge_index=torch.stack([torch.cat(src), torch.cat(dst)]).to(DEV),
+                                       edge_attr=torch.randint(0, 4, (e,), generator=g).to(DEV), batch=torch.cat(batch).to(DEV), num_graphs=B,
+                                       y=(x.float().mean() + torch.randn(B, generator=g) * 0.1).to(DEV)))
+    return batches
+
+
+_INITIAL = None
+
+
+def make():
+    """The same initial model every time: a seeded CONSTRUCTION is not bit-reproducible (the spline-weight init is a CPU
+    `torch.linalg.lstsq`, as in the reference's curve2coeff, and LAPACK's result depends on buffer alignment: two seeded
+    constructions differ in the last bit of some spline weights) -- so the first one's state_dict is reused."""
+    global _INITIAL
+    torch.manual_seed(3)
+    m = kagnn_amd.KAGINRegression(1, 1, 3, H, 2, 4, 3, 1, 0.0, True)
+    m.atom_encoder = kagnn_amd.graph_models.AtomEncoder(H, [21])
+    m.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, H)])
+    if _INITIAL is None:
+        _INITIAL = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(_INITIAL)
+    return m.to(DEV)
+
+
+def run(batches, sync_each_step, fused=True):
+    m = make()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3, fused=fused)
+    m.train()
+    losses = []
+    for _ in range(EPOCHS):
+        for d in batches:
+            opt.zero_grad()
+            loss = torch.nn.L1Loss()(m(d).squeeze(), d.y)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+            if sync_each_step:
+                torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    l = np.array([float(x) for x in losses], dtype=np.float64).reshape(EPOCHS, len(batches))
+    return l, [p.detach().clone() for p in m.parameters()]
+
+
+def same(a, b):
+    return all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def first_diff(la, lb):
+    d = np.argwhere(la != lb)
+    return None if len(d) == 0 else (int(d[0][0]), int(d[0][1]), float(la[tuple(d[0])]), float(lb[tuple(d[0])]))
+
+
+if __name__ == "__main__":
+    batches = make_batches()
+    runs = {}
+    for name, kw in [("sync_a", dict(sync_each_step=True)), ("sync_b", dict(sync_each_step=True)),
+                     ("async_a", dict(sync_each_step=False)), ("async_b", dict(sync_each_step=False)),
+                     ("sync_unfused_adam", dict(sync_each_step=True, fused=False))]:
+        runs[name] = run(batches, **kw)
+        print(name, "epoch means", [f"{v:.9f}" for v in runs[name][0].mean(axis=1)], flush=True)
+    ref = runs["sync_a"]
+    for name, (l, p) in runs.items():
+        print(f"{name} vs sync_a: params identical {same(p, ref[1])}; first differing (epoch, step, got, want) {first_diff(l, ref[0])}")
+    print("async_a vs async_b: params identical", same(runs["async_a"][1], runs["async_b"][1]), first_diff(runs["async_a"][0], runs["async_b"][0]))
