@@ -378,35 +378,81 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __res
     }
 }
 
-// backward, phase 1: one wave per (block of kEmbRows rows, 64-column chunk) walks its rows IN ORDER and adds each gradient row into the
-// LDS copy of the table row it hit (the index is wave-uniform: one LDS row per step, lane = column, no conflicts); the block's
-// table goes to partial[block][V][F].  Phase 2 adds the blocks in block order: deterministic, no atomics.  (A first version had
-// one workgroup per table row scan the whole index column -- a serial chain of dependent loads: 0.5 ms for 12.7k edges.)
+// backward, phase 1: a workgroup of WAVES waves per (block of kEmbRows rows, 64-column chunk); every wave walks ITS kEmbRows / WAVES
+// rows IN ORDER and adds each gradient row into its own LDS copy of the table row it hit (the index is wave-uniform: one LDS row
+// per step, lane = column, no conflicts), then the waves' tables are added in wave order -> partial[block][V][F].  Phase 2 adds the
+// blocks in block order: deterministic, no atomics.  The rows are fetched 16 at a time with UNCONDITIONAL loads (16 index + 16
+// gradient loads in flight; the first form -- `if (ok) s_acc[v] += g[i]` per row -- compiled to a branch and a wait on the index
+// load per row: 43 us for 12.7k edges x 64 columns, whatever the row count), and the adds are plain LDS read-modify-writes:
+// `ds_add_f32` runs at ~150 ns per wave instruction on gfx950 (tools/experiments/embedding_bwd_scaling.py: 128 rows = 20 us, and
+// four waves of a CU take twice that), slower than the round trip it was meant to avoid.
+// (The very first version had one workgroup per table row scan the whole index column: 0.5 ms.)
 constexpr int kEmbRows = 128;
-__global__ __launch_bounds__(64) void embedding_bwd_partial_kernel(const int64_t* __restrict__ idx, long stride, long N,
-                                                                   const float* __restrict__ g, long ldg, int V, int F,
-                                                                   float* __restrict__ partial) {
-    extern __shared__ float s_acc[];                    // [V][64]
-    const int lane = threadIdx.x, f = blockIdx.y * 64 + lane;
-    for (int k = lane; k < V * 64; k += 64) s_acc[k] = 0.0f;
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void embedding_bwd_partial_kernel(const int64_t* __restrict__ idx, long stride, long N,
+                                                                           const float* __restrict__ g, long ldg, int V, int F,
+                                                                           float* __restrict__ partial) {
+    extern __shared__ float s_acc[];                    // [WAVES][V][64]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = blockIdx.y * 64 + lane;
+    float* acc = s_acc + (size_t)wave * V * 64;
+    for (int k = lane; k < V * 64; k += 64) acc[k] = 0.0f;
     __builtin_amdgcn_wave_barrier();
-    const long r0 = (long)blockIdx.x * kEmbRows, r1 = min(N, r0 + kEmbRows);
-    for (long i = r0; i < r1; ++i) {
-        const int64_t v = idx[i * stride];
-        if (v >= 0 && v < V && f < F) s_acc[v * 64 + lane] += g[i * ldg + f];
+    constexpr int RPW = kEmbRows / WAVES;               // rows per wave: a workgroup covers kEmbRows rows either way
+    const long r0 = ((long)blockIdx.x * WAVES + wave) * RPW, r1 = min(N, r0 + RPW);
+    const bool col_ok = f < F;
+    const int fc = min(f, F - 1);                       // (unconditional loads: a predicated one costs a branch and a wait per row)
+    for (long i0 = r0; i0 < r1; i0 += 16) {
+        int64_t iv[16];
+        float gv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) iv[u] = idx[min(i0 + u, r1 - 1) * stride];      // (clamped: the tail repeats the last row, masked below)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) gv[u] = g[min(i0 + u, r1 - 1) * ldg + fc];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const bool hit = i0 + u < r1 && iv[u] >= 0 && iv[u] < V;                   // wave-uniform
+            const float val = col_ok ? gv[u] : 0.0f;
+            if (hit) acc[(int)iv[u] * 64 + lane] += val;
+        }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (f < F)
-        for (int v = 0; v < V; ++v) partial[((long)blockIdx.x * V + v) * F + f] = s_acc[v * 64 + lane];
+    __syncthreads();
+    for (int k = threadIdx.x; k < V * 64; k += 64 * WAVES) {
+        const int v = k >> 6, ff = blockIdx.y * 64 + (k & 63);
+        float a = s_acc[k];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) a += s_acc[(size_t)w * V * 64 + k];
+        if (ff < F) partial[((long)blockIdx.x * V + v) * F + ff] = a;
+    }
 }
 
+// phase 2: 32 table elements x 8 contiguous ranges of blocks per workgroup; a thread adds its range in block order (eight loads in
+// flight), the eight range sums meet in LDS and are added in range order
 __global__ __launch_bounds__(256) void embedding_bwd_reduce_kernel(const float* __restrict__ partial, int nb, int V, int F,
                                                                    float* __restrict__ g_table) {
-    const long k = blockIdx.x * 256L + threadIdx.x;
-    if (k >= (long)V * F) return;
+    __shared__ float s_part[8][32];
+    const int e = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    const long per = (long)V * F, k = blockIdx.x * 32L + e;
+    const int chunk = (nb + 7) / 8, b0 = sub * chunk, b1 = min(nb, b0 + chunk);
     float a = 0.0f;
-    for (int b = 0; b < nb; ++b) a += partial[(long)b * V * F + k];
-    g_table[k] = a;
+    if (k < per) {
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = partial[(b + u) * per + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += t[u];
+        }
+        for (; b < b1; ++b) a += partial[b * per + k];
+    }
+    s_part[sub][e] = a;
+    __syncthreads();
+    if (sub == 0 && k < per) {
+        float t = s_part[0][e];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += s_part[q][e];
+        g_table[k] = t;
+    }
 }
 
 int embedding_fwd(const int64_t* idx, long stride, long N, const float* table, int V, int F, float* out, long ldo, int accumulate,
@@ -424,16 +470,25 @@ int embedding_bwd(const int64_t* idx, long stride, long N, const float* g, long 
     if (V == 0) return KAGNN_OK;
     if (V > 512) return fail(KAGNN_ERR_UNSUPPORTED, "%s: tables of at most 512 rows (the categorical encoders of the graph-level models)", "embedding_bwd");
     if (ws_bytes < embedding_bwd_ws_bytes(N, V, F)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "embedding_bwd");
-    const int nb = cdiv(max(N, 1L), kEmbRows);
-    const size_t lds = (size_t)V * 64 * sizeof(float);
+    // four waves per workgroup (four LDS tables, 32 rows each) while they fit, then two, then one.  Either way
+    // cdiv(N, kEmbRows) partial tables (what embedding_bwd_ws_bytes sizes)
+    const size_t tbl = (size_t)V * 64 * sizeof(float);
+    const int waves = 4 * tbl <= 64 * 1024 ? 4 : 2 * tbl <= 128 * 1024 ? 2 : 1;
+    const int nb = cdiv(max(N, 1L), (long)kEmbRows);
+    const size_t lds = waves * tbl;
     if (lds > 64 * 1024) {
         static unsigned long long configured = 0;
-        if (first_use_on_this_device(configured))
-            KAGNN_HIP(hipFuncSetAttribute((const void*)embedding_bwd_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 1024));
+        if (first_use_on_this_device(configured)) {
+            KAGNN_HIP(hipFuncSetAttribute((const void*)embedding_bwd_partial_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 1024));
+            KAGNN_HIP(hipFuncSetAttribute((const void*)embedding_bwd_partial_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 1024));
+        }
     }
-    embedding_bwd_partial_kernel<<<dim3((unsigned)nb, (unsigned)cdiv(F, 64)), 64, lds, st>>>(idx, stride, N, g, ldg, V, F, ws);
+    const dim3 grid((unsigned)nb, (unsigned)cdiv(F, 64));
+    if (waves == 4) embedding_bwd_partial_kernel<4><<<grid, 256, lds, st>>>(idx, stride, N, g, ldg, V, F, ws);
+    else if (waves == 2) embedding_bwd_partial_kernel<2><<<grid, 128, lds, st>>>(idx, stride, N, g, ldg, V, F, ws);
+    else embedding_bwd_partial_kernel<1><<<grid, 64, lds, st>>>(idx, stride, N, g, ldg, V, F, ws);
     KAGNN_LAUNCH_CHECK();
-    embedding_bwd_reduce_kernel<<<cdiv((long)V * F, 256), 256, 0, st>>>(ws, nb, V, F, g_table);
+    embedding_bwd_reduce_kernel<<<cdiv((long)V * F, 32), 256, 0, st>>>(ws, nb, V, F, g_table);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }

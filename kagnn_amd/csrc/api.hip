@@ -5,6 +5,7 @@
 namespace kagnn {
 thread_local char g_err[512] = "";
 thread_local bool g_half_products = false;      // KAGNN_PREC_HALF for the duration of an entry-point call (split_common.h)
+thread_local DwDefer* g_dw_defer = nullptr;       // deferred weight-gradient slab reductions of a stack call (common.h)
 
 size_t aggregate_ws_bytes(long num_hub_seg, int F);
 size_t aggregate_bf16_ws_bytes(long num_hub_seg, int F);
@@ -1105,6 +1106,17 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
     const size_t hub_b = al256z(aggregate_bf16_ws_bytes(num_hub_seg_t, widths[0])), dw_b = al256z(dwb);
     const size_t g_b = al256z((size_t)N * wmax * sizeof(float));
     unsigned char* gbuf[2] = {ws + hub_b + dw_b, ws + hub_b + dw_b + g_b};
+    // where layer l's weight gradient keeps its row slabs: the shared area -- or, inside a stack call that reduces the slabs of all
+    // its layers in one launch at the end (DwDefer, common.h), a piece of that call's arena
+    auto dw_area = [&](int l, unsigned char*& area, size_t& bytes) {
+        area = ws + hub_b; bytes = dw_b;
+        kagnn::DwDefer* d = kagnn::g_dw_defer;
+        if (d == nullptr) return;
+        size_t b = 0;
+        if (kagnn_kan_bwd_weight_workspace_bytes(N, widths[l], widths[l + 1], G, K, mode, &b) != KAGNN_OK) return;
+        b = al256z(b);
+        if (d->used + b <= d->arena_bytes) { area = d->arena + d->used; bytes = b; d->used += b; }
+    };
     const float* g = gy;
     long ldg = ldgy;
     int cur = 0;
@@ -1152,15 +1164,19 @@ static int layer_bwd_impl(const float* gy, int64_t ldgy, int64_t N, const int32_
                                      as_stream(stream));
             }
             if (rc) return rc;
+            unsigned char* dwa; size_t dwn;
+            dw_area(l, dwa, dwn);
             rc = kagnn_kan_linear_bwd_weight(acts[l], in, bnb.gy_out, bnb.ldo, N, knots, in, out, G, K, mode, sw[l], sc ? sc[l] : nullptr,
-                                             g_bw ? g_bw[l] : nullptr, g_sw[l], g_sc ? g_sc[l] : nullptr, ws + hub_b, dw_b, stream);
+                                             g_bw ? g_bw[l] : nullptr, g_sw[l], g_sc ? g_sc[l] : nullptr, dwa, dwn, stream);
             if (rc) return rc;
             if (l == 0 && gx == nullptr) break;
             g = reinterpret_cast<const float*>(gbuf[0]); ldg = in; cur = 1;
             continue;
         }
+        unsigned char* dwa; size_t dwn;
+        dw_area(l, dwa, dwn);
         rc = kagnn_kan_linear_bwd_weight(acts[l], in, g, ldg, N, knots, in, out, G, K, mode, sw[l], sc ? sc[l] : nullptr,
-                                         g_bw ? g_bw[l] : nullptr, g_sw[l], g_sc ? g_sc[l] : nullptr, ws + hub_b, dw_b, stream);
+                                         g_bw ? g_bw[l] : nullptr, g_sw[l], g_sc ? g_sc[l] : nullptr, dwa, dwn, stream);
         if (rc) return rc;
         if (l == 0 && gx == nullptr) break;
         // the gathered matrix of the transposed aggregation leaves the dX kernel as bf16 when the mode asks for it
@@ -1358,6 +1374,18 @@ int kagnn_gine_kan_layer_bwd(const float* g, int64_t ldg, const float* bn_y, int
 // spline_scaler, pack_fwd, pack_dx, g_*; acts [nconv * (L + 1)]; per convolution [nconv]: self_scale / momentum / eps (HOST floats),
 // bn_weight, bn_bias, running_mean, running_var (device; the last two NULL arrays or NULL entries: no running statistics), h,
 // save_mean, save_rstd, g_bn_weight, g_bn_bias.  Workspace: kagnn_gine_kan_stack_workspace_bytes.
+// the backward's arena of weight-gradient row slabs: one area per layer of the stack, reduced in ONE launch at the end of the call
+static size_t gine_stack_dw_arena_bytes(int64_t N, int nconv, int L, const int32_t* widths, int G, int K, int mode) {
+    if (nconv * L > kagnn::kDwDeferMax) return 0;
+    size_t a = 0;
+    for (int l = 0; l < L; ++l) {
+        size_t b = 0;
+        if (kagnn_kan_bwd_weight_workspace_bytes(N, widths[l], widths[l + 1], G, K, mode, &b) != KAGNN_OK) return 0;
+        a += al256z(b);
+    }
+    return a * (size_t)nconv;
+}
+
 int kagnn_gine_kan_stack_workspace_bytes(int64_t N, int32_t nconv, int32_t L, const int32_t* widths, int32_t G, int32_t K, int32_t mode,
                                          size_t* fwd_bytes, size_t* bwd_bytes) {
     ModeScope mode_scope_(mode);
@@ -1369,7 +1397,7 @@ int kagnn_gine_kan_stack_workspace_bytes(int64_t N, int32_t nconv, int32_t L, co
     rc = kagnn_batchnorm_workspace_bytes(N, widths[L], &bn); if (rc) return rc;
     rc = kagnn_gin_kan_layer_bwd_bn_workspace_bytes(N, widths[L], &bw); if (rc) return rc;
     *fwd_bytes = al256z(f) + al256z(bn) + al256z(2 * (size_t)widths[L] * sizeof(float)) + 256;
-    *bwd_bytes = al256z(b + bw) + 2 * al256z((size_t)N * widths[0] * sizeof(float)) + 256;
+    *bwd_bytes = al256z(b + bw) + 2 * al256z((size_t)N * widths[0] * sizeof(float)) + gine_stack_dw_arena_bytes(N, nconv, L, widths, G, K, mode) + 256;
     return KAGNN_OK;
 }
 
@@ -1445,6 +1473,15 @@ int kagnn_gine_kan_stack_bwd(const float* g, int64_t ldg, const float* x, int64_
     const int H = widths[0];
     const size_t gbytes = al256z((size_t)N * H * sizeof(float));
     float* pp[2] = {reinterpret_cast<float*>(ws + al256z(lb + bwb)), reinterpret_cast<float*>(ws + al256z(lb + bwb) + gbytes)};
+    // every layer's row slabs in an area of their own, all nconv * L slab reductions in one launch after the last convolution
+    kagnn::DwDefer defer{};
+    defer.arena = ws + al256z(lb + bwb) + 2 * gbytes;
+    defer.arena_bytes = gine_stack_dw_arena_bytes(N, nconv, L, widths, G, K, mode);
+    struct DeferScope {
+        kagnn::DwDefer* prev;
+        explicit DeferScope(kagnn::DwDefer* d) : prev(kagnn::g_dw_defer) { kagnn::g_dw_defer = d; }
+        ~DeferScope() { kagnn::g_dw_defer = prev; }
+    } defer_scope_(defer.arena_bytes ? &defer : nullptr);
     const float* gcur = g;
     int64_t ldcur = ldg;
     for (int i = nconv - 1; i >= 0; --i) {
@@ -1462,7 +1499,10 @@ int kagnn_gine_kan_stack_bwd(const float* g, int64_t ldg, const float* x, int64_
         if (rc) return rc;
         gcur = gout; ldcur = ldo;
     }
-    return KAGNN_OK;
+    {
+        KAGNN_STAGE_AS("kagnn_kan_linear_bwd_weight (slab reductions of the stack)", stream);
+        return kagnn::dw_defer_flush(as_stream(stream));
+    }
 }
 
 }  // extern "C"

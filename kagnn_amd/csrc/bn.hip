@@ -197,6 +197,57 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
+// statistics from a producer's column moments + bn_apply_kernel in one launch (round 5: the graph-level mini-batches are launch-bound;
+// two launches until then): every thread derives mean / rstd of its columns from the moments (mean, M2 / N biased), then applies
+// bn_apply_kernel's expressions; workgroup 0's first row slot also stores save_mean / save_rstd and updates the running statistics (one
+// thread per column).  Same bits as the two launches.
+__global__ __launch_bounds__(256) void bn_apply_from_moments_kernel(const float* __restrict__ x, long ldx, long N, int F,
+                                                                    const float* __restrict__ col_mean, const float* __restrict__ col_m2,
+                                                                    float eps, float momentum, float* __restrict__ save_mean,
+                                                                    float* __restrict__ save_rstd, float* __restrict__ running_mean,
+                                                                    float* __restrict__ running_var,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    float* __restrict__ y, long ldy, int cl, int rs, DropArgs dr) {
+    const int cg = threadIdx.x % cl, slot = threadIdx.x / cl;
+    if (slot >= rs) return;
+    const bool vec = ((F & 3) == 0) && ((ldx & 3) == 0) && ((ldy & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    const bool writer = blockIdx.x == 0 && slot == 0;
+    for (int c = 4 * cg; c < F; c += 4 * cl) {
+        float sc[4], sh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = min(c + i, F - 1);
+            const float mean = col_mean[ci], var = fmaxf(col_m2[ci] / (float)N, 0.0f);
+            const float rstd = rsqrtf(var + eps);
+            if (writer && c + i < F) {
+                save_mean[ci] = mean;
+                save_rstd[ci] = rstd;
+                if (running_mean) {
+                    const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+                    running_mean[ci] = fmaf(momentum, mean - running_mean[ci], running_mean[ci]);
+                    running_var[ci] = fmaf(momentum, unb - running_var[ci], running_var[ci]);
+                }
+            }
+            sc[i] = rstd * (gamma ? gamma[ci] : 1.0f);
+            sh[i] = fmaf(-mean, sc[i], beta ? beta[ci] : 0.0f);
+        }
+        for (long n = blockIdx.x * (long)rs + slot; n < N; n += (long)gridDim.x * rs) {
+            float v[4];
+            ld4c(x + n * ldx, c, F, vec, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+            if (dr.thr < 65536u) {
+                float k[4];
+                keep4(dr, n, c, k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= k[i];
+            }
+            st4c(y + n * ldy, c, F, vec, v);
+        }
+    }
+}
+
 // training: gx = gamma*rstd * (gy - sum_gy/N - xhat * sum_gy_xhat/N);   eval: gx = gamma*rstd*gy
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, long ldx,
                                                            const float* __restrict__ gy, long ldgy, long N, int F,
@@ -238,18 +289,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
-// m | A | B | C per column for kernels that apply the backward to rows they load themselves (BnBack, common.h)
-__global__ void bn_bwd_table_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sum_gy, const float* __restrict__ sum_gyx, long N, int F,
-                                    float* __restrict__ tab, int ldt) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= ldt) return;
-    float A = 0.0f, B = 0.0f, C = 0.0f, m = 0.0f;
-    if (f < F) {
-        m = mean[f];
-        bn_bwd_consts(rstd[f], gamma ? gamma[f] : 1.0f, sum_gy[f], sum_gyx[f], 1.0f / (float)N, A, B, C);
+// bn_finish_kernel<1> + the table m | A | B | C per column for kernels that apply the backward to rows they load themselves (BnBack,
+// common.h) in one launch: the thread that finishes column f's two sums also writes its table entries (until round 5 a launch of
+// its own reading the sums back: same expressions on the same values, same bits); columns F .. ldt - 1 of the table are zero.
+// Grid: cdiv(ldt, 32).
+__global__ __launch_bounds__(1024) void bn_finish_table_kernel(const float* __restrict__ partial, long B, int F, long N,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, float* __restrict__ sum_gy,
+                                                              float* __restrict__ sum_gyx, float* __restrict__ tab, int ldt) {
+    __shared__ float s_p[32][2][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;       // 32 columns x 32 row groups
+    const int f = blockIdx.x * 32 + c;
+    float a = 0.0f, b = 0.0f;
+    if (f < F)
+        for (long w = rg; w < B; w += 32) { a += partial[(w * 2 + 0) * F + f]; b += partial[(w * 2 + 1) * F + f]; }
+    s_p[rg][0][c] = a; s_p[rg][1][c] = b;
+    __syncthreads();
+    if (rg == 0 && f < ldt) {
+        float A = 0.0f, Bc = 0.0f, C = 0.0f, m = 0.0f;
+        if (f < F) {
+            float ta = 0.f, tb = 0.f;
+#pragma unroll
+            for (int g = 0; g < 32; ++g) { ta += s_p[g][0][c]; tb += s_p[g][1][c]; }
+            sum_gy[f] = ta;        // g_bias
+            sum_gyx[f] = tb;       // g_weight
+            m = mean[f];
+            bn_bwd_consts(rstd[f], gamma ? gamma[f] : 1.0f, ta, tb, 1.0f / (float)N, A, Bc, C);
+        }
+        tab[f] = m; tab[ldt + f] = A; tab[2 * ldt + f] = Bc; tab[3 * ldt + f] = C;
     }
-    tab[f] = m; tab[ldt + f] = A; tab[2 * ldt + f] = B; tab[3 * ldt + f] = C;
 }
 
 // rstd from a variance vector (eval mode: running_var)
@@ -258,23 +326,8 @@ __global__ void bn_rstd_kernel(const float* __restrict__ var, int F, float eps, 
     if (f < F) rstd[f] = rsqrtf(var[f] + eps);
 }
 
-// training statistics from column moments (mean, M2 = sum of squared deviations) a producer kernel left behind
-__global__ void bn_from_moments_kernel(const float* __restrict__ col_mean, const float* __restrict__ col_m2, long N, int F,
-                                       float eps, float momentum, float* __restrict__ save_mean,
-                                       float* __restrict__ save_rstd, float* __restrict__ running_mean,
-                                       float* __restrict__ running_var) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    const float mean = col_mean[f], var = fmaxf(col_m2[f] / (float)N, 0.0f);
-    save_mean[f] = mean;
-    save_rstd[f] = rsqrtf(var + eps);
-    if (running_mean) {
-        const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
-        running_mean[f] = fmaf(momentum, mean - running_mean[f], running_mean[f]);
-        running_var[f] = fmaf(momentum, unb - running_var[f], running_var[f]);
-    }
-}
-
+// training statistics from column moments (mean, M2 = sum of squared deviations) a producer kernel left behind: inside
+// bn_apply_from_moments_kernel (above), and ...
 // ... plus the per-column affine of the normalisation, for consumers that apply it to the rows they load instead of reading a
 // normalised matrix (bn_stats_affine): a = gamma * rstd, b = beta - mean * a  -- the expressions of bn_apply_kernel
 __global__ void bn_affine_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -379,10 +432,12 @@ int bn_fwd(const float* x, long ldx, long N, int F, const float* gamma, const fl
     const BnShape s = bn_shape(F);
     const BnPlan p = bn_plan(N, F);
     const DropArgs dr = drop_args(training ? dropout_p : 0.0f, dropout_seed);
-    if (training && col_mean) {
-        bn_from_moments_kernel<<<cdiv(F, 256), 256, 0, st>>>(col_mean, col_m2, N, F, eps, momentum, save_mean, save_rstd,
-                                                            running_mean, running_var);
+    if (training && col_mean) {          // statistics and normalisation in one launch
+        const int grid = (int)min(4096L, max(1L, (long)cdiv(N, s.rs)));
+        bn_apply_from_moments_kernel<<<grid, 256, 0, st>>>(x, ldx, N, F, col_mean, col_m2, eps, momentum, save_mean, save_rstd, running_mean,
+                                                          running_var, gamma, beta, y, ldy, s.cl, s.rs, dr);
         KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
     } else if (training) {
         float* partial = static_cast<float*>(ws);
         const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
@@ -405,7 +460,7 @@ int bn_fwd(const float* x, long ldx, long N, int F, const float* gamma, const fl
 int bn_stats_affine(const float* col_mean, const float* col_m2, long N, int F, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* save_mean, float* save_rstd,
                     float* affine, hipStream_t st) {
-    // (one launch: the same expressions as bn_from_moments_kernel followed by bn_affine_kernel, on values still in registers)
+    // (one launch: the statistics expressions of bn_apply_from_moments_kernel followed by bn_affine_kernel's, on values still in registers)
     bn_from_moments_affine_kernel<<<cdiv(F, 256), 256, 0, st>>>(col_mean, col_m2, N, F, eps, momentum, save_mean, save_rstd, running_mean,
                                                                 running_var, gamma, beta, affine);
     KAGNN_LAUNCH_CHECK();
@@ -427,9 +482,7 @@ int bn_bwd_stats(const float* x, long ldx, const float* gy, long ldgy, long N, i
     const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
     bn_colsum_kernel<1><<<p.blocks, 256, lds, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, s.cl, s.rs, p.rpb, partial, dr);
     KAGNN_LAUNCH_CHECK();
-    bn_finish_kernel<1><<<cdiv(F, 32), 1024, 0, st>>>(partial, p.blocks, F, N, nullptr, 0.f, 0.f, sg, sgx, nullptr, nullptr);
-    KAGNN_LAUNCH_CHECK();
-    bn_bwd_table_kernel<<<cdiv(ldt, 256), 256, 0, st>>>(save_mean, save_rstd, gamma, sg, sgx, N, F, tab, ldt);
+    bn_finish_table_kernel<<<cdiv(ldt, 32), 1024, 0, st>>>(partial, p.blocks, F, N, save_mean, save_rstd, gamma, sg, sgx, tab, ldt);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
 }
@@ -482,7 +535,7 @@ int bn_finish_partials(const float* partial, long B, int F, float* sums, hipStre
     return KAGNN_OK;
 }
 
-// bn_bwd_table_kernel + the two gradient outputs in one launch (the sums are given: nothing else to do before the table)
+// the table of bn_finish_table_kernel + the two gradient outputs in one launch (the sums are given: nothing else to do before the table)
 __global__ void bn_bwd_table_given_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                           const float* __restrict__ sums, long N, int F, float* __restrict__ tab, int ldt,
                                           float* __restrict__ g_gamma, float* __restrict__ g_beta) {

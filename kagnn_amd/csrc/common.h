@@ -29,6 +29,24 @@ inline int fail(int code, const char* fmt, const char* a = "", long b = 0, long 
     } while (0)
 #define KAGNN_LAUNCH_CHECK() KAGNN_HIP(hipGetLastError())
 
+// Deferred slab reductions of the weight gradient (kan_split_bwd.hip).  A weight-gradient call is {row-slab kernel, slab
+// reduction + unpack}; the second is a ~8 us launch per KANLinear, and the message-passing stack of a graph-level model runs
+// nconv * L of them per step on a mini-batch whose whole step is ~1 ms.  An entry point that owns a workspace ARENA for the slabs of
+// several layers sets g_dw_defer for its duration: a weight-gradient call whose slab lies inside the arena records its reduction
+// instead of launching it, and dw_defer_flush runs all recorded ones in ONE launch (same per-element code path: same bits).
+struct DwReduceItem {
+    const float* slab; long NS; int in, out, C, SG; long inP, outP;
+    const float* sw; const float* sc; float* g_bw; float* g_sw; float* g_sc;
+};
+constexpr int kDwDeferMax = 16;
+struct DwDefer {
+    unsigned char* arena; size_t arena_bytes, used;
+    int n;
+    DwReduceItem item[kDwDeferMax];
+};
+extern thread_local DwDefer* g_dw_defer;
+int dw_defer_flush(hipStream_t st);                 // launches what g_dw_defer holds (no-op when empty) and empties it
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a process-wide "configured" flag leaves the kernel
 // at the 64 KB default on the second GPU a process drives and its launch fails there.  One bit per device ordinal;
 // true the first time the calling thread's current device (the one the launch goes to) meets this call site.
@@ -237,7 +255,7 @@ struct AggArgs {
 
 // BatchNorm1d backward, training mode, as ONE expression per element of the incoming gradient g (y = the norm's input):
 //   gy = k (g - mean(g) - xhat mean(g xhat)),  xhat = (y - m) q,  k = gamma q     ==>  gy = A g + B (y - m) + C
-// with per column  A = k,  B = -k q mean(g xhat),  C = -k mean(g)  (bn_bwd_table_kernel, bn.hip).  The deviation y - m is
+// with per column  A = k,  B = -k q mean(g xhat),  C = -k mean(g)  (bn_finish_table_kernel, bn.hip).  The deviation y - m is
 // formed first, as the stand-alone pass always did (near-constant columns: |m| >> sigma).  Used by bn_bwd_apply_kernel and by
 // the input-gradient kernel that applies it to the rows it loads (kan_split_dx_kernel<..., BNB>): same bits either way.
 struct BnBack {

@@ -198,7 +198,7 @@ __device__ __forceinline__ f32x16 smfmac(const u32x4& a, const u32x4& b0, const 
 // MOM: the epilogue also accumulates the COLUMN MOMENTS of y (count, mean, sum of squared deviations; per wave over its
 // row tiles, merged pairwise in a fixed order -- Chan et al., no cancellation) and leaves one (mean, M2, count) row per
 // workgroup in mom_partial[gridDim.x][3][out]: the BatchNorm1d that follows the convolution (reference
-// models.py:198-200) then needs no statistics pass over y (bn.hip: moments_finish, bn_from_moments_kernel).
+// models.py:198-200) then needs no statistics pass over y (bn.hip: moments_finish, bn_apply_from_moments_kernel).
 // NARROW: a layer of <= 32 (virtual) features, laid over both lane halves (sp_hf); a template flag because the lane-half width
 // as a runtime value cost the 64-feature forward 1.7 %
 // AGG (>= 0, narrow layers only): the kernel's input is NOT read from memory but produced in place -- the GIN neighbour

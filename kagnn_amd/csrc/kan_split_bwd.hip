@@ -1728,16 +1728,16 @@ __global__ __launch_bounds__(256) void kan_split_dw_w2_kernel(
 // slab reduction and unpack in one launch (the non-virtual layout): thread (o, plane c) of workgroup (o-tile, f)
 // sums slab[.][c][f][o] in a fixed order, writes g_spline_weight (chain rule through spline_scaler), and the
 // planes of one (f, o) meet in LDS for g_spline_scaler = sum_c gW * spline_weight (fixed order, deterministic)
-__global__ void kan_dw_reduce_unpack_kernel(const float* __restrict__ slab, long NS, int in, int out, int C,
-                                            long inP, long outP, const float* __restrict__ sw,
-                                            const float* __restrict__ sc, float* __restrict__ g_bw,
-                                            float* __restrict__ g_sw, float* __restrict__ g_sc, int SG) {
+__device__ __forceinline__ void dw_reduce_unpack_body(const float* __restrict__ slab, long NS, int in, int out, int C,
+                                                      long inP, long outP, const float* __restrict__ sw,
+                                                      const float* __restrict__ sc, float* __restrict__ g_bw,
+                                                      float* __restrict__ g_sw, float* __restrict__ g_sc, int SG, int bx, int by) {
     // thread = (output ol of 32, plane c of C+1, slab group sg of SG): the slab sum is split over SG groups (shorter
     // dependent load chains), combined through LDS in group order -- still a fixed summation order
     extern __shared__ float s_red[];                 // [SG][C+1][32] partial sums, then [C][32] products
     const int ol = threadIdx.x & 31, pc = threadIdx.x >> 5;
     const int c = pc % (C + 1), sg = pc / (C + 1);
-    const int f = blockIdx.y, o = blockIdx.x * 32 + ol;
+    const int f = by, o = bx * 32 + ol;
     const long per = (long)(C + 1) * inP * outP;
     const long i = ((long)c * inP + f) * outP + o;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -1772,6 +1772,57 @@ __global__ void kan_dw_reduce_unpack_kernel(const float* __restrict__ slab, long
         for (int k = 0; k < C; ++k) gs += s_red[k * 32 + ol];
         g_sc[of] = gs;
     }
+}
+
+__global__ void kan_dw_reduce_unpack_kernel(const float* __restrict__ slab, long NS, int in, int out, int C,
+                                            long inP, long outP, const float* __restrict__ sw,
+                                            const float* __restrict__ sc, float* __restrict__ g_bw,
+                                            float* __restrict__ g_sw, float* __restrict__ g_sc, int SG) {
+    dw_reduce_unpack_body(slab, NS, in, out, C, inP, outP, sw, sc, g_bw, g_sw, g_sc, SG, blockIdx.x, blockIdx.y);
+}
+
+// the same for up to kDwDeferMax layers in one launch (DwDefer, common.h): blockIdx.z = the layer; all of them have the same
+// C and SG (one block shape), the grid covers the largest (outP / 32, in) and a workgroup outside its layer's range leaves
+struct DwReduceBatch { DwReduceItem item[kDwDeferMax]; };
+__global__ void kan_dw_reduce_unpack_batch_kernel(const DwReduceBatch b) {
+    const DwReduceItem& it = b.item[blockIdx.z];
+    if ((long)blockIdx.x * 32 >= it.outP || (int)blockIdx.y >= it.in) return;
+    dw_reduce_unpack_body(it.slab, it.NS, it.in, it.out, it.C, it.inP, it.outP, it.sw, it.sc, it.g_bw, it.g_sw, it.g_sc, it.SG, blockIdx.x,
+                          blockIdx.y);
+}
+
+int dw_defer_flush(hipStream_t st) {
+    DwDefer* d = g_dw_defer;
+    if (d == nullptr || d->n == 0) return KAGNN_OK;
+    DwReduceBatch b{};
+    unsigned gx = 1, gy = 1;
+    for (int k = 0; k < d->n; ++k) {
+        b.item[k] = d->item[k];
+        gx = max(gx, (unsigned)(d->item[k].outP / 32));
+        gy = max(gy, (unsigned)d->item[k].in);
+    }
+    const int C = d->item[0].C, SG = d->item[0].SG;
+    kan_dw_reduce_unpack_batch_kernel<<<dim3(gx, gy, (unsigned)d->n), 32 * (C + 1) * SG, (size_t)SG * (C + 1) * 32 * sizeof(float), st>>>(b);
+    d->n = 0;
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+// the slab reduction + unpack of one layer: launched now, or recorded when the slab lives in the caller's arena (DwDefer)
+static int dw_reduce_unpack(const float* slab, long NS, int in, int out, int C, long inP, long outP, const float* sw, const float* sc,
+                            float* g_bw, float* g_sw, float* g_sc, hipStream_t st) {
+    const int SG = max(1, min(3, 1024 / (32 * (C + 1))));
+    DwDefer* d = g_dw_defer;
+    const unsigned char* sp = reinterpret_cast<const unsigned char*>(slab);
+    if (d != nullptr && sp >= d->arena && sp < d->arena + d->arena_bytes) {
+        if (d->n > 0 && (d->item[0].C != C || d->n == kDwDeferMax)) { int rc = dw_defer_flush(st); if (rc) return rc; }
+        d->item[d->n++] = DwReduceItem{slab, NS, in, out, C, SG, inP, outP, sw, sc, g_bw, g_sw, g_sc};
+        return KAGNN_OK;
+    }
+    kan_dw_reduce_unpack_kernel<<<dim3((unsigned)(outP / 32), (unsigned)in), 32 * (C + 1) * SG, (size_t)SG * (C + 1) * 32 * sizeof(float), st>>>(
+        slab, NS, in, out, C, inP, outP, sw, sc, g_bw, g_sw, g_sc, SG);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
 }
 
 // virtual-feature layout (sh == 1) back to the parameter layout, with the spline_scaler chain rule of
@@ -1817,12 +1868,7 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
 #undef W2N
 #undef W2
         KAGNN_LAUNCH_CHECK();
-        const int SG = max(1, min(3, 1024 / (32 * (C + 1))));
-        kan_dw_reduce_unpack_kernel<<<dim3((unsigned)(p.outP / 32), (unsigned)in), 32 * (C + 1) * SG,
-                                      (size_t)SG * (C + 1) * 32 * sizeof(float), st>>>(
-            slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, SG);
-        KAGNN_LAUNCH_CHECK();
-        return KAGNN_OK;
+        return dw_reduce_unpack(slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, st);
     }
     const int sh = C > 8 ? 1 : 0, Ck = sh ? 8 : C;          // slots per (virtual) feature the kernel stores
     const DwPlan p = split_dw_plan(N, in, out, C, K);
@@ -1851,12 +1897,7 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
         else        { if (SHn == 4) LS(3, 4); else LS(3, 2); }
 #undef LS
         KAGNN_LAUNCH_CHECK();
-        const int SG = max(1, min(3, 1024 / (32 * (C + 1))));
-        kan_dw_reduce_unpack_kernel<<<dim3((unsigned)(p.outP / 32), (unsigned)in), 32 * (C + 1) * SG,
-                                      (size_t)SG * (C + 1) * 32 * sizeof(float), st>>>(
-            slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, SG);
-        KAGNN_LAUNCH_CHECK();
-        return KAGNN_OK;
+        return dw_reduce_unpack(slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, st);
     }
     // single-product mode (thread-local, set by the entry point): the cubic, <= 8-coefficient instantiations
     const bool half = g_half_products && K == 3 && !sh;
@@ -1892,12 +1933,7 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
 #undef ARGS
     KAGNN_LAUNCH_CHECK();
     if (!sh) {
-        const int SG = max(1, min(3, 1024 / (32 * (C + 1))));
-        kan_dw_reduce_unpack_kernel<<<dim3((unsigned)(p.outP / 32), (unsigned)in), 32 * (C + 1) * SG,
-                                      (size_t)SG * (C + 1) * 32 * sizeof(float), st>>>(
-            slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, SG);
-        KAGNN_LAUNCH_CHECK();
-        return KAGNN_OK;
+        return dw_reduce_unpack(slab, p.NS, in, out, C, p.inP, p.outP, sw, sc, g_bw, g_sw, g_sc, st);
     }
     { int rc = kan_dw_reduce(slab, p.NS, p.per, gcat, st); if (rc) return rc; }
     if (sh) {

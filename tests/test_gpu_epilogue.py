@@ -269,7 +269,7 @@ def test_node_model_trains_with_fused_dropout():
         torch.cuda.synchronize()
     names = [ev.key for ev in prof.key_averages()]
     assert not any("dropout" in k.lower() or "bernoulli" in k.lower() for k in names), names
-    assert any("bn_apply_kernel" in k for k in names) and not any("bn_colsum_kernel<0>" in k for k in names), names
+    assert any("bn_apply_from_moments_kernel" in k for k in names) and not any("bn_colsum_kernel<0>" in k for k in names), names
     b = model(x, ei)
     assert not torch.equal(a, b)
     opt = torch.optim.Adam(model.parameters(), lr=0.01)

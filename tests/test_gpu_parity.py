@@ -655,7 +655,8 @@ def test_embedding_table_encoders_match_torch():
     from kagnn_amd.graph_models import AtomEncoder, BondEncoder
     torch.manual_seed(0)
     for enc, dims, n in ((AtomEncoder(64), kagnn_amd.graph_models.ATOM_FEATURE_DIMS, 5932), (BondEncoder(40), kagnn_amd.graph_models.BOND_FEATURE_DIMS, 12670),
-                         (AtomEncoder(32, [21]), [21], 777)):
+                         (AtomEncoder(32, [21]), [21], 777), (AtomEncoder(16, [400, 3]), [400, 3], 33), (AtomEncoder(70, [130, 2]), [130, 2], 1),
+                         (AtomEncoder(64, [200]), [200], 3000)):      # (tables of <= 64 / <= 128 / more rows: 4 / 2 / 1 waves per row block)
         enc = enc.to(DEV)
         gen = torch.Generator().manual_seed(n)
         x = torch.stack([torch.randint(0, d, (n,), generator=gen) for d in dims], dim=1).to(DEV)

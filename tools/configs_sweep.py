@@ -1,7 +1,8 @@
 """Sanity/perf sweep over the BASELINE.json configs (synthetic shapes).
 usage: python tools/configs_sweep.py [config numbers ...]   (default: all)"""
 import sys, time, torch
-WANT = {int(a) for a in sys.argv[1:]} or {1, 2, 3, 4, 5}
+HARNESS_ONLY = "4h" in sys.argv[1:]          # config 4 through train_graph_batches only (clean launch counts per step)
+WANT = {int(a) for a in sys.argv[1:] if a != "4h"} or ({4} if HARNESS_ONLY else {1, 2, 3, 4, 5})
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kagnn_amd
@@ -79,7 +80,8 @@ if 4 in WANT:
     tgt = torch.randn(B, 1).to(dev)
     def zstep():
         opt.zero_grad(); (m(d) - tgt).abs().mean().backward(); opt.step()
-    run("cfg4 ZINC-like batch 256 graphs KAGIN(GINE) 4 layers hidden 64: step", zstep, 20)
+    if not HARNESS_ONLY:
+        run("cfg4 ZINC-like batch 256 graphs KAGIN(GINE) 4 layers hidden 64: step", zstep, 20)
     # the same through the package's loop (kagnn_amd.harness.train_graph_batches = optuna_zinc.py:56-66: fused Adam, loss read per epoch)
     # over 8 DIFFERENT batches (each with its own edge_index: the CSR is rebuilt per batch, as in training), OGB-style embedding encoders
     from kagnn_amd.harness import train_graph_batches
@@ -102,4 +104,5 @@ if 4 in WANT:
     m.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, 64)])
     m = m.to(dev)
     t, means = train_graph_batches(m, batches, nb_epochs=5, warmup=2)
+    print(f"cfg4 harness steps run (incl. warm-up): {7 * len(batches)}")
     print(f"cfg4 harness (ZINC-style embedding encoders, 8 distinct batches, fused Adam): {t * 1e3:.2f} ms/step, loss {means[-1]:.4f}", flush=True)
