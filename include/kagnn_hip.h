@@ -637,6 +637,12 @@ int kagnn_softmax_xent_bwd(const float* logits, int64_t ld, int64_t num_rows, in
                            const float* row_stats, const float* count, const float* g_loss,
                            float* g_logits, int64_t ldg, void* stream);
 
+/* Loss of the graph-regression scripts (graph_regression/optuna_zinc.py:58: torch.nn.L1Loss()(model(data).squeeze(), data.y)):
+ *   loss = mean |pred - target| over n contiguous fp32 elements; g_pred = (g_loss / n) * sign(pred - target).
+ * loss / g_loss: device scalars; one launch each way, deterministic (fixed summation order), no host sync. */
+int kagnn_l1_loss_fwd(const float* pred, const float* target, int64_t n, float* loss, void* stream);
+int kagnn_l1_loss_bwd(const float* pred, const float* target, int64_t n, const float* g_loss, float* g_pred, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Direct peer-to-peer exchange steps of the feature-sharded layer (no reference counterpart: the reference has no
  * multi-GPU code; contract = BASELINE.json north_star, SURVEY.md 8(b)/(e): "sharded variants", "hand-rolled

@@ -132,6 +132,8 @@ _SIGNATURES = {
     "kagnn_softmax_xent_workspace_bytes": (c_int32, [c_int64, POINTER(c_size_t)]),
     "kagnn_softmax_xent_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, c_int32, _P, _P, _P, _P, c_size_t, _P]),
     "kagnn_softmax_xent_bwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, c_int32, _P, _P, _P, _P, c_int64, _P]),
+    "kagnn_l1_loss_fwd": (c_int32, [_P, _P, c_int64, _P, _P]),
+    "kagnn_l1_loss_bwd": (c_int32, [_P, _P, c_int64, _P, _P, _P]),
     "kagnn_gat_logits": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "kagnn_gat_fwd": (c_int32, [_P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P, c_int64,
                                 c_int32, _P]),

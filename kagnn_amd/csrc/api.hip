@@ -92,6 +92,8 @@ int kan_grid_refit(const float*, long, long, const float*, const float*, int, in
 size_t xent_ws_bytes(long N);
 int xent_fwd(const float*, long, long, int, const long*, const unsigned char*, int, float*, float*, float*, void*, size_t, hipStream_t);
 int xent_bwd(const float*, long, long, int, const long*, const unsigned char*, int, const float*, const float*, const float*, float*, long, hipStream_t);
+int l1_loss_fwd(const float* p, const float* t, long n, float* loss, hipStream_t st);
+int l1_loss_bwd(const float* p, const float* t, long n, const float* g_loss, float* g_p, hipStream_t st);
 size_t gat_att_grad_ws_bytes(long N, int H, int C);
 int gat_att_grad(const float*, long, const float*, const float*, long, int, int, float*, float*, void*, size_t, hipStream_t);
 size_t bn_ws_bytes(long N, int F);
@@ -193,7 +195,7 @@ static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode 
 #pragma GCC visibility push(default)
 extern "C" {
 
-int kagnn_version(void) { return 250; }
+int kagnn_version(void) { return 251; }
 const char* kagnn_last_error(void) { return g_err; }
 
 int kagnn_stage_timer_enable(const char* only) {
@@ -892,6 +894,19 @@ int kagnn_softmax_xent_bwd(const float* logits, int64_t ld, int64_t N, int32_t C
     KAGNN_CHECK_ARG(N == 0 || (logits && labels && row_stats && count && g_loss && g_logits), "null array");
     return xent_bwd(logits, ld, N, C, (const long*)labels, mask, pre_softmax, row_stats, count, g_loss, g_logits, ldg,
                     as_stream(stream));
+}
+
+// mean absolute error of two contiguous fp32 vectors (torch.nn.L1Loss, reduction = "mean"): graph_regression/optuna_zinc.py:58
+int kagnn_l1_loss_fwd(const float* pred, const float* target, int64_t n, float* loss, void* stream) {
+    KAGNN_STAGE(stream);
+    KAGNN_CHECK_ARG(n >= 0 && loss && (n == 0 || (pred && target)), "null array or negative size");
+    return l1_loss_fwd(pred, target, n, loss, as_stream(stream));
+}
+
+int kagnn_l1_loss_bwd(const float* pred, const float* target, int64_t n, const float* g_loss, float* g_pred, void* stream) {
+    KAGNN_STAGE(stream);
+    KAGNN_CHECK_ARG(n >= 0 && (n == 0 || (pred && target && g_loss && g_pred)), "null array or negative size");
+    return l1_loss_bwd(pred, target, n, g_loss, g_pred, as_stream(stream));
 }
 
 

@@ -349,4 +349,46 @@ int xent_bwd(const float* z, long ld, long N, int C, const long* y, const unsign
     return KAGNN_OK;
 }
 
+// ------------------------------------------------------------------ mean absolute error (the graph-regression scripts' loss:
+// graph_regression/optuna_zinc.py:58 `torch.nn.L1Loss()(model(data).squeeze(), data.y)`), one launch each way instead of aten's
+// sub / abs / mean and sign / expand / mul -- on a 256-molecule mini-batch the loss is 256 numbers and six launches.
+// forward: loss = (1/n) sum |p_i - t_i|, one workgroup: thread j adds elements j, j + 1024, ... in order, the 1024 partial sums
+// fold pairwise through LDS (fixed order: deterministic).  Meant for the [graphs] / [graphs, targets] predictions of a mini-batch;
+// a million elements still work, at one workgroup's bandwidth.
+__global__ __launch_bounds__(1024) void l1_loss_fwd_kernel(const float* __restrict__ p, const float* __restrict__ t, long n,
+                                                           float* __restrict__ loss) {
+    __shared__ float s_a[1024];
+    float a = 0.0f;
+    for (long i = threadIdx.x; i < n; i += 1024) a += fabsf(p[i] - t[i]);
+    s_a[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) s_a[threadIdx.x] += s_a[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = s_a[0] / (float)n;
+}
+
+// backward: g_p[i] = (g_loss * (1 / n)) * sign(p_i - t_i)   (sign(0) = sign(NaN) = 0, as aten's sign: `(0 < d) - (d < 0)`)
+__global__ __launch_bounds__(256) void l1_loss_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, long n,
+                                                          const float* __restrict__ g_loss, float* __restrict__ g_p) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n) return;
+    const float d = p[i] - t[i], g = g_loss[0] * (1.0f / (float)n);      // (aten divides by a host scalar as a multiplication by its reciprocal)
+    g_p[i] = d > 0.0f ? g : d < 0.0f ? -g : g * 0.0f;
+}
+
+int l1_loss_fwd(const float* p, const float* t, long n, float* loss, hipStream_t st) {
+    l1_loss_fwd_kernel<<<1, 1024, 0, st>>>(p, t, n, loss);        // n == 0: 0 / 0 = NaN, as aten's mean of an empty tensor
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int l1_loss_bwd(const float* p, const float* t, long n, const float* g_loss, float* g_p, hipStream_t st) {
+    if (n == 0) return KAGNN_OK;
+    l1_loss_bwd_kernel<<<cdiv(n, 256), 256, 0, st>>>(p, t, n, g_loss, g_p);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 }  // namespace kagnn

@@ -1617,6 +1617,38 @@ def softmax_cross_entropy(logits, labels, mask=None, pre_softmax: bool = False) 
     return _SoftmaxXentFn.apply(logits, labels, mask, bool(pre_softmax))
 
 
+class _L1LossFn(Function):
+    @staticmethod
+    @_on_operand_device
+    def forward(ctx, pred, target):
+        _need_cuda(pred, target)
+        p = pred.to(torch.float32).contiguous()
+        t = target.to(torch.float32).contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=p.device)
+        _call("kagnn_l1_loss_fwd", _ptr(p), _ptr(t), p.numel(), _ptr(out), _stream())
+        ctx.save_for_backward(p, t)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    @_on_operand_device
+    def backward(ctx, gloss):
+        p, t = ctx.saved_tensors
+        g = gloss.to(torch.float32).contiguous()
+        gp = torch.empty_like(p)
+        _call("kagnn_l1_loss_bwd", _ptr(p), _ptr(t), p.numel(), _ptr(g), _ptr(gp), _stream())
+        return gp, None
+
+
+def l1_loss(pred, target) -> torch.Tensor:
+    """``torch.nn.L1Loss()(pred, target)`` (mean absolute error; the loss of the reference's graph-regression scripts,
+    ``graph_regression/optuna_zinc.py:58``) as one kernel each way; same shapes required (no broadcasting -- L1Loss warns about it
+    and the scripts squeeze the prediction for that reason); the target gets no gradient."""
+    if pred.shape != target.shape:
+        raise ValueError(f"l1_loss: prediction {tuple(pred.shape)} and target {tuple(target.shape)} must have the same shape")
+    return _L1LossFn.apply(pred, target)
+
+
 # ======================================================================== GAT attention aggregation
 class _GatFn(Function):
     @staticmethod

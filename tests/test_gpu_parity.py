@@ -689,6 +689,40 @@ def test_embedding_table_encoders_match_torch():
     assert bool(torch.isnan(out[1]).all()) and not bool(torch.isnan(out[[0, 2]]).any())     # out-of-range index: a NaN row, loudly
 
 
+def test_l1_loss_is_torch_l1loss():
+    """ops.l1_loss = torch.nn.L1Loss() (graph_regression/optuna_zinc.py:58) in one launch each way: the mean to rounding (another
+    summation order), the gradient sign(d) * (g / n) to the bit (sign(0) = sign(NaN) = 0 as aten's), a NaN makes the loss NaN, no gradient for the target"""
+    gen = torch.Generator().manual_seed(3)
+    for n in (1, 2, 3, 7, 31, 100, 256, 1000, 4096, 5932, 100_003):
+        p = torch.randn(n, generator=gen).to(DEV).requires_grad_(True)
+        t = torch.randn(n, generator=gen).to(DEV)
+        with torch.no_grad():
+            if n >= 31:
+                p[3] = t[3]                                            # an exact zero difference
+        want = torch.nn.L1Loss()(p, t)
+        (gw,) = torch.autograd.grad(want * 1.7, p)
+        got = ops.l1_loss(p, t)
+        (gg,) = torch.autograd.grad(got * 1.7, p)
+        assert abs(float(got) - float(want)) <= 2e-6 * float(want), (n, float(got), float(want))
+        assert torch.equal(gg, gw), (n, float((gg - gw).abs().max()))
+        ref64 = float((p.detach().double() - t.double()).abs().mean())
+        assert abs(float(got) - ref64) <= 1e-6 * ref64
+    p2 = torch.randn(64, 3, generator=gen).to(DEV)
+    t2 = torch.randn(64, 3, generator=gen).to(DEV)
+    assert abs(float(ops.l1_loss(p2.t(), t2.t())) - float(torch.nn.L1Loss()(p2, t2))) <= 1e-6       # non-contiguous operands
+    bad = p2.clone(); bad[5, 1] = float("nan")
+    bad.requires_grad_(True)
+    l = ops.l1_loss(bad, t2)
+    l.backward()
+    bad2 = bad.detach().clone().requires_grad_(True)
+    torch.nn.L1Loss()(bad2, t2).backward()
+    assert bool(torch.isnan(l)) and torch.equal(bad.grad, bad2.grad) and float(bad.grad[5, 1]) == 0.0     # aten: sign(NaN) = 0
+    with pytest.raises(ValueError, match="same shape"):
+        ops.l1_loss(p2, t2[:, :1])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.l1_loss(p2.cpu(), t2.cpu())
+
+
 def test_gine_conv_one_library_call_each_way_matches_the_composition(golden, monkeypatch):
     """Round 5 (BASELINE config 4): the whole GINE stack as ONE tape node (kagnn_gine_kan_stack_fwd / _bwd), ``GINEKANLayer`` + the
     BatchNorm1d behind it as one node per convolution (kagnn_gine_kan_layer_fwd / _bwd; KAGNN_GINE_STACK_ABI=0), both
