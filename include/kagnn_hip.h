@@ -643,6 +643,13 @@ int kagnn_softmax_xent_bwd(const float* logits, int64_t ld, int64_t num_rows, in
 int kagnn_l1_loss_fwd(const float* pred, const float* target, int64_t n, float* loss, void* stream);
 int kagnn_l1_loss_bwd(const float* pred, const float* target, int64_t n, const float* g_loss, float* g_pred, void* stream);
 
+/* Optimiser of the same scripts (optuna_zinc.py:49,62: torch.optim.Adam(model.parameters(), lr), optimizer.step() per batch): one
+ * update of `count` fp32 tensors in one launch per 32 tensors.  HOST arrays of device pointers / element counts; `step` = 1, 2, ...
+ * (bias corrections 1 - beta^step are computed on the host in double).  torch's rule without amsgrad:
+ *   g += weight_decay * p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps) */
+int kagnn_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const int64_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Direct peer-to-peer exchange steps of the feature-sharded layer (no reference counterpart: the reference has no
  * multi-GPU code; contract = BASELINE.json north_star, SURVEY.md 8(b)/(e): "sharded variants", "hand-rolled

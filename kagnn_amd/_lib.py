@@ -134,6 +134,7 @@ _SIGNATURES = {
     "kagnn_softmax_xent_bwd": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, c_int32, _P, _P, _P, _P, c_int64, _P]),
     "kagnn_l1_loss_fwd": (c_int32, [_P, _P, c_int64, _P, _P]),
     "kagnn_l1_loss_bwd": (c_int32, [_P, _P, c_int64, _P, _P, _P]),
+    "kagnn_adam_step": (c_int32, [c_int32, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int64, _P]),
     "kagnn_gat_logits": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "kagnn_gat_fwd": (c_int32, [_P, c_int64, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P, c_int64,
                                 c_int32, _P]),

@@ -94,6 +94,8 @@ int xent_fwd(const float*, long, long, int, const long*, const unsigned char*, i
 int xent_bwd(const float*, long, long, int, const long*, const unsigned char*, int, const float*, const float*, const float*, float*, long, hipStream_t);
 int l1_loss_fwd(const float* p, const float* t, long n, float* loss, hipStream_t st);
 int l1_loss_bwd(const float* p, const float* t, long n, const float* g_loss, float* g_p, hipStream_t st);
+int adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+              const long* numel, float lr, float beta1, float beta2, float eps, float weight_decay, long step, hipStream_t st);
 size_t gat_att_grad_ws_bytes(long N, int H, int C);
 int gat_att_grad(const float*, long, const float*, const float*, long, int, int, float*, float*, void*, size_t, hipStream_t);
 size_t bn_ws_bytes(long N, int F);
@@ -195,7 +197,7 @@ static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode 
 #pragma GCC visibility push(default)
 extern "C" {
 
-int kagnn_version(void) { return 251; }
+int kagnn_version(void) { return 252; }
 const char* kagnn_last_error(void) { return g_err; }
 
 int kagnn_stage_timer_enable(const char* only) {
@@ -907,6 +909,20 @@ int kagnn_l1_loss_bwd(const float* pred, const float* target, int64_t n, const f
     KAGNN_STAGE(stream);
     KAGNN_CHECK_ARG(n >= 0 && (n == 0 || (pred && target && g_loss && g_pred)), "null array or negative size");
     return l1_loss_bwd(pred, target, n, g_loss, g_pred, as_stream(stream));
+}
+
+// one Adam update of `count` fp32 parameter tensors (HOST arrays of device pointers and element counts; step = 1, 2, ...: the
+// number of this update, for the bias corrections): torch.optim.Adam's rule without amsgrad, one launch per 32 tensors
+int kagnn_adam_step(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const int64_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream) {
+    KAGNN_STAGE(stream);
+    KAGNN_CHECK_ARG(count >= 0 && step >= 1 && (count == 0 || (params && grads && exp_avg && exp_avg_sq && numel)), "null array or bad count / step");
+    KAGNN_CHECK_ARG(lr >= 0.0f && beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f && eps >= 0.0f, "bad hyper-parameter");
+    for (int k = 0; k < count; ++k)
+        KAGNN_CHECK_ARG(numel[k] >= 0 && (numel[k] == 0 || (params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k])), "null tensor");
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+    return adam_step(count, params, grads, exp_avg, exp_avg_sq, reinterpret_cast<const long*>(numel), lr, beta1, beta2, eps, weight_decay,
+                     (long)step, as_stream(stream));
 }
 
 

@@ -96,21 +96,89 @@ def time_model(model, x, edge_index, y, mask, nb_epochs: int = 20, warmup: int =
     return float(np.round(dt, 6)), [float(l.detach()) for l in losses]
 
 
+class Adam:
+    """``torch.optim.Adam(params, lr, betas, eps, weight_decay)`` (no amsgrad) for fp32 device parameters as ONE library call per
+    step (``kagnn_adam_step``: one launch per 32 tensors) -- the optimiser of the reference's graph-regression scripts
+    (``graph_regression/optuna_zinc.py:49,62``).  Same update rule in fp32; what it removes is torch.optim's per-step Python (state
+    dictionaries, tensor grouping, step counters kept as tensors: 0.2-0.3 ms of host time per step, fused or not -- a quarter of a
+    256-molecule mini-batch's step).  ``step()`` / ``zero_grad()`` / ``state_dict()``-free by design: a training-loop helper, not a
+    torch.optim subclass (schedulers and checkpoints want the real one: pass it to ``train_graph_batches(optimizer=...)``)."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        import ctypes
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params or any((not p.is_cuda) or p.dtype != torch.float32 or not p.is_contiguous() for p in self.params):
+            raise TypeError("kagnn_amd.harness.Adam takes contiguous fp32 parameters on the GPU (there is no CPU path)")
+        if len({p.device for p in self.params}) != 1:
+            raise ValueError("kagnn_amd.harness.Adam: all parameters on one device")
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.steps = 0
+        total = sum(p.numel() for p in self.params)
+        self._m = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+        self._v = torch.zeros_like(self._m)
+        off, moff = 0, []
+        for p in self.params:
+            moff.append(off); off += p.numel()
+        n = len(self.params)
+        self._VP, self._I64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+        self._m_ptr = [self._m.data_ptr() + 4 * o for o in moff]
+        self._v_ptr = [self._v.data_ptr() + 4 * o for o in moff]
+        self._numel = [p.numel() for p in self.params]
+        self._p_ptr = [p.data_ptr() for p in self.params]            # (parameters are updated in place: their storage stays)
+        self._p_tab, self._m_tab, self._v_tab = self._VP(*self._p_ptr), self._VP(*self._m_ptr), self._VP(*self._v_ptr)
+        self._n_tab = self._I64(*self._numel)
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if set_to_none or p.grad is None:
+                p.grad = None
+            else:
+                p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        from . import ops
+        self.steps += 1
+        f32 = torch.float32
+        ptrs = [p.data_ptr() for p in self.params]
+        if ptrs != self._p_ptr:                                       # a parameter's storage was replaced (p.data = ...): follow it
+            self._p_ptr, self._p_tab = ptrs, self._VP(*ptrs)
+        gs = [p.grad for p in self.params]
+        if not all(g is not None and g.dtype is f32 and g.is_contiguous() for g in gs):     # rare: a subset, or gradients to convert
+            # (`None in gs` would compare every TENSOR with None through torch's dispatcher: 10 us each)
+            keep = [k for k, g in enumerate(gs) if g is not None]
+            if not keep:
+                return
+            gs = [gs[k] if gs[k].dtype is f32 and gs[k].is_contiguous() else gs[k].to(f32).contiguous() for k in keep]
+            pp, mp, vp, nn_ = ([a[k] for k in keep] for a in (self._p_ptr, self._m_ptr, self._v_ptr, self._numel))
+            VP, I64 = _ctypes_arrays(len(keep))
+            tables = (VP(*pp), VP(*[g.data_ptr() for g in gs]), VP(*mp), VP(*vp), I64(*nn_))
+        else:
+            tables = (self._p_tab, self._VP(*[g.data_ptr() for g in gs]), self._m_tab, self._v_tab, self._n_tab)
+        with ops._device_of(self.params[0]):
+            ops._call("kagnn_adam_step", len(gs), *tables, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps,
+                      ops._stream())
+
+
+def _ctypes_arrays(n: int):
+    import ctypes
+    return ctypes.c_void_p * n, ctypes.c_int64 * n
+
+
 def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr: float = 1e-3, optimizer=None):
-    """The mini-batch training loop of the reference's graph-regression scripts (``graph_regression/optuna_zinc.py:56-66``:
-    Adam, L1 loss, ``{zero_grad, loss(model(data).squeeze(), data.y), backward, step}`` per batch) over ``batches`` -- objects with
+    """The mini-batch training loop of the reference's graph-regression scripts (``graph_regression/optuna_zinc.py:56-66``: Adam,
+    L1 loss, ``{zero_grad, loss(model(data).squeeze(), data.y), backward, step}`` per batch) over ``batches`` -- objects with
     ``x, edge_index, edge_attr, batch, y`` (``num_graphs`` / ``ptr`` when the loader supplies them) already on the device.
-    Returns ``(seconds per step, mean training loss per epoch)``.  Differences from the script, none of them in the mathematics: the
-    optimiser's update runs as one fused launch (same rule), the loss is ``ops.l1_loss`` (the same mean absolute error and the same
-    gradient ``sign(d) * (g / n)``; its forward sum runs in another order than aten's), and the running loss is accumulated ON THE DEVICE and read once per
-    epoch -- the script's ``loss.item()`` per batch drains the stream every step, which on a step of ~1 ms of device work is the
-    difference between the host running ahead of the GPU and waiting for it."""
-    import os
+    Returns ``(seconds per step, mean training loss per epoch)``.  Differences from the script, none of them in the mathematics:
+    * the optimiser is ``kagnn_amd.harness.Adam`` unless one is passed (torch.optim.Adam's rule in fp32 as one library call;
+      torch's own kernels round differently -- its fused one mixes double arithmetic -- so trajectories agree to rounding, not
+      to the bit; with ``optimizer=torch.optim.Adam(..., fused=True)`` the loop IS the script's, bit for bit);
+    * the loss is ``ops.l1_loss`` (the same mean absolute error, the same gradient bits; its forward sum runs in another order);
+    * the running loss is accumulated ON THE DEVICE and read once per epoch -- the script's ``loss.item()`` per batch drains the
+      stream every step, which on a step of ~1 ms of device work is the difference between the host running ahead of the GPU
+      and waiting for it."""
     if optimizer is None:
-        try:
-            optimizer = torch.optim.Adam(model.parameters(), lr=lr, fused=os.environ.get("KAGNN_FUSED_ADAM", "1") != "0")
-        except (TypeError, RuntimeError):
-            optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+        optimizer = Adam(model.parameters(), lr=lr)            # torch.optim.Adam's rule, one library call per step
     from . import ops
     loss_fn = ops.l1_loss              # = torch.nn.L1Loss() (mean |p - t|), one launch each way instead of six
     model.train()

@@ -1113,12 +1113,42 @@ def test_fuzz_models_folds_on_vs_off():
     assert m and int(m.group(1)) >= 20 and int(m.group(2)) >= 20, tail       # the folds really ran
 
 
+# ------------------------------------------------------------------ the harness optimiser (optuna_zinc.py:49,62: torch.optim.Adam)
+@pytest.mark.parametrize("weight_decay", [0.0, 0.01])
+def test_harness_adam_is_torch_adam(weight_decay):
+    """kagnn_amd.harness.Adam (kagnn_adam_step: one launch per 32 tensors) against torch.optim.Adam run in float64 on the same
+    gradients: 40 tensors of 1 .. 100 003 elements (two launches), 6 steps, a tensor without a gradient is left alone"""
+    from kagnn_amd.harness import Adam
+    gen = torch.Generator().manual_seed(9)
+    sizes = [1, 2, 63, 64, 65, 4096, 100_003] + [int(v) for v in torch.randint(1, 5000, (33,), generator=gen)]
+    ps = [torch.nn.Parameter(torch.randn(n, generator=gen).to(DEV)) for n in sizes]
+    ps[5] = torch.nn.Parameter(torch.randn(64, 64, generator=gen).to(DEV))
+    ref = [torch.nn.Parameter(p.detach().double().clone()) for p in ps]
+    frozen = 11
+    mine = Adam(ps, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=weight_decay)
+    theirs = torch.optim.Adam(ref, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=weight_decay)
+    for step in range(6):
+        mine.zero_grad(); theirs.zero_grad()
+        for k, (p, r) in enumerate(zip(ps, ref)):
+            if k == frozen:
+                continue
+            g = torch.randn(p.shape, generator=gen).to(DEV) * (10.0 ** float(torch.randint(-6, 2, (1,), generator=gen)))
+            p.grad = g
+            r.grad = g.double()
+        mine.step(); theirs.step()
+        for k, (p, r) in enumerate(zip(ps, ref)):
+            assert_close(p.detach(), r.detach(), 2e-6, what=f"adam step {step} tensor {k}", elementwise=False)
+    assert torch.equal(ps[frozen].detach().double(), ref[frozen].detach())
+    with pytest.raises(TypeError, match="no CPU path"):
+        Adam([torch.nn.Parameter(torch.zeros(3))])
+
+
 # ------------------------------------------------------------------ the graph-level training loop (optuna_zinc.py:56-66)
 def test_train_graph_batches_is_the_reference_loop():
     """harness.train_graph_batches = `for data in loader: zero_grad; loss = L1(model(data).squeeze(), data.y); backward; step` with
     Adam (graph_regression/optuna_zinc.py:56-66) over distinct mini-batches (a CSR per batch, the GINE stack as one tape node,
-    embedding encoders): the same losses and the same final parameters as that loop written out by hand with the same optimiser
-    settings, bit for bit; the loss goes down."""
+    embedding encoders): with torch's fused Adam passed in, the same losses and the same final parameters as that loop written out
+    by hand, bit for bit; with the package's own Adam (the default) the same trajectory to rounding; the loss goes down."""
     from types import SimpleNamespace
     from kagnn_amd.harness import train_graph_batches
     B, H = 32, 32
@@ -1148,8 +1178,13 @@ def test_train_graph_batches_is_the_reference_loop():
     # (a second seeded construction is NOT the same model to the bit: the spline-weight init is a CPU lstsq, as in the reference's
     # curve2coeff, whose last bit depends on buffer alignment -- tools/experiments/train_determinism.py; the copy below is)
     initial = {k: v.clone() for k, v in m1.state_dict().items()}
-    t, means = train_graph_batches(m1, batches, nb_epochs=6, warmup=0, lr=2e-3)
+    t, means = train_graph_batches(m1, batches, nb_epochs=6, warmup=0, lr=2e-3, optimizer=torch.optim.Adam(m1.parameters(), lr=2e-3, fused=True))
     assert t > 0 and all(np.isfinite(means)) and means[-1] < means[0], means
+    # the default optimiser (kagnn_amd.harness.Adam: the same rule, one library call) follows the same trajectory to rounding
+    m3 = make()
+    m3.load_state_dict(initial)
+    _, means3 = train_graph_batches(m3, batches, nb_epochs=6, warmup=0, lr=2e-3)
+    assert np.allclose(means3[:3], means[:3], rtol=1e-4, atol=0) and np.allclose(means3, means, rtol=2e-2, atol=0), (means3, means)
     m2 = make()
     m2.load_state_dict(initial)
     opt = torch.optim.Adam(m2.parameters(), lr=2e-3, fused=True)

@@ -105,4 +105,4 @@ if 4 in WANT:
     m = m.to(dev)
     t, means = train_graph_batches(m, batches, nb_epochs=5, warmup=2)
     print(f"cfg4 harness steps run (incl. warm-up): {7 * len(batches)}")
-    print(f"cfg4 harness (ZINC-style embedding encoders, 8 distinct batches, fused Adam): {t * 1e3:.2f} ms/step, loss {means[-1]:.4f}", flush=True)
+    print(f"cfg4 harness (ZINC-style embedding encoders, 8 distinct batches, one-call Adam + L1): {t * 1e3:.2f} ms/step, loss {means[-1]:.4f}", flush=True)

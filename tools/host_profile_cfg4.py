@@ -31,19 +31,21 @@ wall = (time.perf_counter() - t0) / 80
 print(f"host issue time {host * 1e3:.3f} ms/step, wall {wall * 1e3:.3f} ms/step (device-bound if wall >> host)")
 # host issue time per phase (no synchronisation inside the loop: what the Python side costs when the device keeps up)
 from kagnn_amd import ops
-ph = {"zero_grad": 0.0, "forward": 0.0, "loss": 0.0, "backward": 0.0, "optimizer": 0.0}
-for _ in range(10):
-    for d in batches:
-        t = [time.perf_counter()]
-        opt.zero_grad(set_to_none=True); t.append(time.perf_counter())
-        out = m(d); t.append(time.perf_counter())
-        loss = ops.l1_loss(out.squeeze(), d.y.squeeze()); t.append(time.perf_counter())
-        loss.backward(); t.append(time.perf_counter())
-        opt.step(); t.append(time.perf_counter())
-        for k, (a, b) in zip(ph, zip(t, t[1:])):
-            ph[k] += b - a
-torch.cuda.synchronize()
-print("host issue time per phase, us/step:", {k: round(v / 80 * 1e6, 1) for k, v in ph.items()}, "sum", round(sum(ph.values()) / 80 * 1e6, 1))
+from kagnn_amd.harness import Adam
+for label, opt in (("torch.optim.Adam(fused=True)", opt), ("kagnn_amd.harness.Adam", Adam(m.parameters(), lr=1e-3)), ("torch.optim.Adam(fused=True) again", opt)):
+  ph = {"zero_grad": 0.0, "forward": 0.0, "loss": 0.0, "backward": 0.0, "optimizer": 0.0}
+  for _ in range(10):
+      for d in batches:
+          t = [time.perf_counter()]
+          opt.zero_grad(set_to_none=True); t.append(time.perf_counter())
+          out = m(d); t.append(time.perf_counter())
+          loss = ops.l1_loss(out.squeeze(), d.y.squeeze()); t.append(time.perf_counter())
+          loss.backward(); t.append(time.perf_counter())
+          opt.step(); t.append(time.perf_counter())
+          for k, (a, b) in zip(ph, zip(t, t[1:])):
+              ph[k] += b - a
+  torch.cuda.synchronize()
+  print(label, "-- host issue time per phase, us/step:", {k: round(v / 80 * 1e6, 1) for k, v in ph.items()}, "sum", round(sum(ph.values()) / 80 * 1e6, 1))
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10):
     for d in batches: step(d)
