@@ -43,13 +43,21 @@ class _SumOfEmbeddings(nn.Module):
         setattr(self, list_name, tables)
         self._list_name = list_name
 
-    def forward(self, x):
+    def _fast_tables(self, x):
+        """the tables' weights when ``x`` takes the embedding kernels (``kagnn_embedding_fwd / _bwd``), else ``None``"""
         tables = getattr(self, self._list_name)
-        if (x.is_cuda and x.dtype == torch.int64 and x.dim() == 2 and x.size(1) <= len(tables) and not torch.compiler.is_compiling()
+        if (x.is_cuda and x.dtype == torch.int64 and x.dim() == 2 and 1 <= x.size(1) <= len(tables) and not torch.compiler.is_compiling()
                 and all(type(t) is nn.Embedding and t.padding_idx is None and t.max_norm is None and not t.sparse
                         and not t.scale_grad_by_freq and t.weight.dtype == torch.float32 and t.num_embeddings <= 512 for t in tables)):
+            return [tables[i].weight for i in range(x.shape[1])]
+        return None
+
+    def forward(self, x):
+        tables = getattr(self, self._list_name)
+        weights = self._fast_tables(x)
+        if weights is not None:
             # one launch per feature column each way (graph_ops._EmbeddingSumFn) instead of gather + add / aten's sort-based backward
-            return graph_ops.embedding_sum(x, [tables[i].weight for i in range(x.shape[1])])
+            return graph_ops.embedding_sum(x, weights)
         out = 0
         for i in range(x.shape[1]):
             out = out + tables[i](x[:, i])
@@ -194,6 +202,10 @@ class KAGINRegression(_GraphLevel):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, data):
+        if type(self) is KAGINRegression:                 # the whole forward as ONE tape node where the model and the batch allow it
+            out = graph_ops.kagin_regression_forward(self, data)
+            if out is not None:
+                return out
         x, edge_attr = data.x, data.edge_attr
         if edge_attr.dim() == 1:
             edge_attr = edge_attr.unsqueeze(1)

@@ -11,8 +11,9 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from .ops import (GraphIndex, _batchnorm_fwd_raw, _call, _ld, _need_cuda, _on_operand_device, _ptr, _ptr_array, _rows, _sizes, _stream,
-                  _ws, default_precision, split_like)
+from .ops import (PREC_FP32, GraphIndex, _batchnorm_fwd_raw, _call, _fits32, _kan_bwd_input_raw, _kan_bwd_weight_raw, _kan_fwd_raw, _ld,
+                  _need_cuda, _on_operand_device, _ptr, _ptr_array, _rows, _segment_broadcast_raw, _segment_pool_raw, _sizes, _stream,
+                  _weights_key, _ws, default_precision, graph_index, kan_pack_chain, split_like)
 
 
 class _GineKanLayerFn(Function):
@@ -99,120 +100,143 @@ class _GineKanLayerFn(Function):
         return (gx, gea, None, None, None, None, None, None, g_bnw, g_bnb, None, None, None, None, *grads)
 
 
+class _StackState:
+    """what the backward of the GINE stack needs (kept by the tape node that ran the forward)"""
+    __slots__ = ("g", "self_scales", "G", "K", "mode", "nconv", "nl", "H", "fb", "db", "xg", "ea", "acts_all", "h_all", "stats", "packs",
+                 "knots", "bnw", "sws", "scs")
+
+
+def _gine_stack_fwd_raw(x, edge_attr, g, self_scales, knots, grid_size, spline_order, mode, running, momentum, eps, nconv, nl, params):
+    """``kagnn_gine_kan_stack_fwd`` -> (h of the last convolution, _StackState).  ``params``: per convolution ``bn_weight, bn_bias``
+    then per layer ``base_weight, spline_weight, spline_scaler``; ``running``: per convolution ``(running_mean, running_var)`` or
+    ``(None, None)``.  Everything a step allocates comes from a handful of tensors (activations, normalised outputs, statistics)
+    that the per-layer pointers index into."""
+    _need_cuda(x, edge_attr, *params)
+    xg, ea = _rows(x), _rows(edge_attr)
+    n, dev, H = xg.size(0), xg.device, xg.size(1)
+    per = 2 + 3 * nl
+    bnw = [params[i * per].contiguous() for i in range(nconv)]
+    bnb = [params[i * per + 1].contiguous() for i in range(nconv)]
+    bws, sws, scs = [], [], []
+    for i in range(nconv):
+        for l in range(nl):
+            b, w, c = params[i * per + 2 + 3 * l:i * per + 5 + 3 * l]
+            bws.append(b.contiguous()); sws.append(w.contiguous()); scs.append(c.contiguous())
+    if n != g.num_nodes or ea.shape != (g.num_edges, H):
+        raise ValueError("x must be [N, H] and edge_attr [E, H] with N / E those of the graph")
+    f32 = dict(dtype=torch.float32, device=dev)
+    acts_all = torch.empty((nconv, nl + 1, n, H), **f32)
+    h_all = torch.empty((nconv, n, H), **f32)
+    stats = torch.empty((nconv, 2, H), **f32)
+    fb, db = _sizes("kagnn_kan_pack_bytes", H, H, grid_size, spline_order, mode, outputs=2)
+    fb, db = (fb + 255) & ~255, (db + 255) & ~255
+    packs = torch.empty(nconv * nl * (fb + db), dtype=torch.uint8, device=dev)
+    pf_ptr = [packs.data_ptr() + k * fb for k in range(nconv * nl)]
+    pd_ptr = [packs.data_ptr() + nconv * nl * fb + k * db for k in range(nconv * nl)]
+    widths = (H,) * (nl + 1)
+    warr = (ctypes.c_int32 * (nl + 1))(*widths)
+    wf, _ = _sizes("kagnn_gine_kan_stack_workspace_bytes", n, nconv, nl, widths, grid_size, spline_order, mode, outputs=2)
+    ws = _ws(wf, dev)
+    VP, FA = ctypes.c_void_p * (nconv * nl), ctypes.c_float * nconv
+    VC = ctypes.c_void_p * nconv
+    a0, hs = acts_all.data_ptr(), n * H * 4
+    acts_ptr = (ctypes.c_void_p * (nconv * (nl + 1)))(*[a0 + k * hs for k in range(nconv * (nl + 1))])
+    h_ptr = VC(*[h_all.data_ptr() + i * hs for i in range(nconv)])
+    mean_ptr = VC(*[stats.data_ptr() + (2 * i) * H * 4 for i in range(nconv)])
+    rstd_ptr = VC(*[stats.data_ptr() + (2 * i + 1) * H * 4 for i in range(nconv)])
+    scale_arr = FA(*[float(v) for v in self_scales])
+    _call("kagnn_gine_kan_stack_fwd", _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm), scale_arr,
+          nconv, nl, warr, _ptr_array(bws), _ptr_array(sws), _ptr_array(scs), _ptr(knots), grid_size, spline_order, mode, acts_ptr,
+          VP(*pf_ptr), VP(*pd_ptr), _ptr_array(bnw), _ptr_array(bnb), _ptr_array([r[0] for r in running]),
+          _ptr_array([r[1] for r in running]), FA(*[float(v) for v in momentum]), FA(*[float(v) for v in eps]), h_ptr, mean_ptr,
+          rstd_ptr, _ptr(ws), ws.numel(), _stream())
+    st = _StackState()
+    st.g, st.self_scales, st.G, st.K, st.mode, st.nconv, st.nl, st.H, st.fb, st.db = (
+        g, tuple(float(v) for v in self_scales), grid_size, spline_order, mode, nconv, nl, H, fb, db)
+    st.xg, st.ea, st.acts_all, st.h_all, st.stats, st.packs, st.knots, st.bnw, st.sws, st.scs = xg, ea, acts_all, h_all, stats, packs, knots, bnw, sws, scs
+    return h_all[nconv - 1], st
+
+
+def _gine_stack_bwd_raw(gh, st, need_gea):
+    """``kagnn_gine_kan_stack_bwd`` -> (gx, g_edge_attr or None, parameter gradients in the order of ``params``)"""
+    g, self_scales, G, K, mode, nconv, nl, H, fb, db = st.g, st.self_scales, st.G, st.K, st.mode, st.nconv, st.nl, st.H, st.fb, st.db
+    xg, ea, acts_all, h_all, stats, packs, knots, bnw, sws, scs = st.xg, st.ea, st.acts_all, st.h_all, st.stats, st.packs, st.knots, st.bnw, st.sws, st.scs
+    gh = _rows(gh)
+    n, dev = gh.size(0), gh.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    C = G + K
+    gx = torch.empty((n, H), **f32)
+    gea = torch.empty((g.num_edges, H), **f32) if need_gea else None
+    g_bn = torch.empty((nconv, 2, H), **f32)
+    g_bw = torch.empty((nconv * nl, H, H), **f32)
+    g_sw = torch.empty((nconv * nl, H, H, C), **f32)
+    g_sc = torch.empty((nconv * nl, H, H), **f32)
+    widths = (H,) * (nl + 1)
+    warr = (ctypes.c_int32 * (nl + 1))(*widths)
+    _, wb = _sizes("kagnn_gine_kan_stack_workspace_bytes", n, nconv, nl, widths, G, K, mode, outputs=2)
+    ws = _ws(wb, dev)
+    VP, FA, VC = ctypes.c_void_p * (nconv * nl), ctypes.c_float * nconv, ctypes.c_void_p * nconv
+    a0, hs = acts_all.data_ptr(), n * H * 4
+    acts_ptr = (ctypes.c_void_p * (nconv * (nl + 1)))(*[a0 + k * hs for k in range(nconv * (nl + 1))])
+    pd_ptr = VP(*[packs.data_ptr() + nconv * nl * fb + k * db for k in range(nconv * nl)])
+    _call("kagnn_gine_kan_stack_bwd", _ptr(gh), _ld(gh), _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr_t), _ptr(g.col_t),
+          _ptr(g.perm_t), FA(*self_scales), nconv, nl, warr, _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, acts_ptr, pd_ptr,
+          VC(*[h_all.data_ptr() + i * hs for i in range(nconv)]), _ptr_array(bnw),
+          VC(*[stats.data_ptr() + (2 * i) * H * 4 for i in range(nconv)]), VC(*[stats.data_ptr() + (2 * i + 1) * H * 4 for i in range(nconv)]),
+          _ptr(gx), H, _ptr(gea), H, VC(*[g_bn.data_ptr() + (2 * i) * H * 4 for i in range(nconv)]),
+          VC(*[g_bn.data_ptr() + (2 * i + 1) * H * 4 for i in range(nconv)]),
+          VP(*[g_bw.data_ptr() + k * H * H * 4 for k in range(nconv * nl)]), VP(*[g_sw.data_ptr() + k * H * H * C * 4 for k in range(nconv * nl)]),
+          VP(*[g_sc.data_ptr() + k * H * H * 4 for k in range(nconv * nl)]), _ptr(ws), ws.numel(), _stream())
+    grads = []
+    for i in range(nconv):
+        grads += [g_bn[i, 0], g_bn[i, 1]]
+        for l in range(nl):
+            k = i * nl + l
+            grads += [g_bw[k], g_sw[k], g_sc[k]]
+    return gx, gea, grads
+
+
 class _GineKanStackFn(Function):
     """The whole message-passing stack of a graph-level model -- ``nconv x {GINE convolution around a KAN chain -> training-mode
     BatchNorm1d}``, all chains hidden -> ... -> hidden (reference ``graph_regression/models.py:107-119``) -- as ONE tape node over
     ``kagnn_gine_kan_stack_fwd / _bwd`` (round 5; see include/kagnn_hip.h: on a 256-molecule batch the per-convolution nodes cost the
-    host as much as the device).  Everything a step allocates comes from a handful of tensors (activations, normalised outputs,
-    statistics, gradients) that the per-layer pointers index into."""
+    host as much as the device)."""
 
     @staticmethod
     @_on_operand_device
     def forward(ctx, x, edge_attr, g, self_scales, knots, grid_size, spline_order, mode, running, momentum, eps, nconv, nl, *params):
-        """``params``: per convolution ``bn_weight, bn_bias`` then per layer ``base_weight, spline_weight, spline_scaler``;
-        ``running``: per convolution ``(running_mean, running_var)`` or ``(None, None)``"""
-        _need_cuda(x, edge_attr, *params)
-        xg, ea = _rows(x), _rows(edge_attr)
-        n, dev, H = xg.size(0), xg.device, xg.size(1)
-        per = 2 + 3 * nl
-        bnw = [params[i * per].contiguous() for i in range(nconv)]
-        bnb = [params[i * per + 1].contiguous() for i in range(nconv)]
-        bws, sws, scs = [], [], []
-        for i in range(nconv):
-            for l in range(nl):
-                b, w, c = params[i * per + 2 + 3 * l:i * per + 5 + 3 * l]
-                bws.append(b.contiguous()); sws.append(w.contiguous()); scs.append(c.contiguous())
-        if n != g.num_nodes or ea.shape != (g.num_edges, H):
-            raise ValueError("x must be [N, H] and edge_attr [E, H] with N / E those of the graph")
-        f32 = dict(dtype=torch.float32, device=dev)
-        acts_all = torch.empty((nconv, nl + 1, n, H), **f32)
-        h_all = torch.empty((nconv, n, H), **f32)
-        stats = torch.empty((nconv, 2, H), **f32)
-        fb, db = _sizes("kagnn_kan_pack_bytes", H, H, grid_size, spline_order, mode, outputs=2)
-        fb, db = (fb + 255) & ~255, (db + 255) & ~255
-        packs = torch.empty(nconv * nl * (fb + db), dtype=torch.uint8, device=dev)
-        pf_ptr = [packs.data_ptr() + k * fb for k in range(nconv * nl)]
-        pd_ptr = [packs.data_ptr() + nconv * nl * fb + k * db for k in range(nconv * nl)]
-        widths = (H,) * (nl + 1)
-        warr = (ctypes.c_int32 * (nl + 1))(*widths)
-        wf, _ = _sizes("kagnn_gine_kan_stack_workspace_bytes", n, nconv, nl, widths, grid_size, spline_order, mode, outputs=2)
-        ws = _ws(wf, dev)
-        VP, FA = ctypes.c_void_p * (nconv * nl), ctypes.c_float * nconv
-        VC = ctypes.c_void_p * nconv
-        a0, hs = acts_all.data_ptr(), n * H * 4
-        acts_ptr = (ctypes.c_void_p * (nconv * (nl + 1)))(*[a0 + k * hs for k in range(nconv * (nl + 1))])
-        h_ptr = VC(*[h_all.data_ptr() + i * hs for i in range(nconv)])
-        mean_ptr = VC(*[stats.data_ptr() + (2 * i) * H * 4 for i in range(nconv)])
-        rstd_ptr = VC(*[stats.data_ptr() + (2 * i + 1) * H * 4 for i in range(nconv)])
-        scale_arr = FA(*[float(v) for v in self_scales])
-        _call("kagnn_gine_kan_stack_fwd", _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm), scale_arr,
-              nconv, nl, warr, _ptr_array(bws), _ptr_array(sws), _ptr_array(scs), _ptr(knots), grid_size, spline_order, mode, acts_ptr,
-              VP(*pf_ptr), VP(*pd_ptr), _ptr_array(bnw), _ptr_array(bnb), _ptr_array([r[0] for r in running]),
-              _ptr_array([r[1] for r in running]), FA(*[float(v) for v in momentum]), FA(*[float(v) for v in eps]), h_ptr, mean_ptr,
-              rstd_ptr, _ptr(ws), ws.numel(), _stream())
-        ctx.meta = (g, tuple(float(v) for v in self_scales), grid_size, spline_order, mode, nconv, nl, H, fb, db)
-        ctx.save_for_backward(xg, ea, acts_all, h_all, stats, packs, knots, *bnw, *sws, *scs)
-        return h_all[nconv - 1]
+        h, st = _gine_stack_fwd_raw(x, edge_attr, g, self_scales, knots, grid_size, spline_order, mode, running, momentum, eps, nconv, nl, params)
+        ctx.meta = (st.g, st.self_scales, st.G, st.K, st.mode, st.nconv, st.nl, st.H, st.fb, st.db)
+        ctx.save_for_backward(st.xg, st.ea, st.acts_all, st.h_all, st.stats, st.packs, st.knots, *st.bnw, *st.sws, *st.scs)
+        return h
 
     @staticmethod
     @once_differentiable
     @_on_operand_device
     def backward(ctx, gh):
-        g, self_scales, G, K, mode, nconv, nl, H, fb, db = ctx.meta
+        st = _StackState()
+        st.g, st.self_scales, st.G, st.K, st.mode, st.nconv, st.nl, st.H, st.fb, st.db = ctx.meta
         t = ctx.saved_tensors
-        xg, ea, acts_all, h_all, stats, packs, knots = t[:7]
-        bnw = t[7:7 + nconv]
-        sws = t[7 + nconv:7 + nconv + nconv * nl]
-        scs = t[7 + nconv + nconv * nl:7 + nconv + 2 * nconv * nl]
-        gh = _rows(gh)
-        n, dev = gh.size(0), gh.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        C = G + K
-        gx = torch.empty((n, H), **f32)
-        gea = torch.empty((g.num_edges, H), **f32) if ctx.needs_input_grad[1] else None
-        g_bn = torch.empty((nconv, 2, H), **f32)
-        g_bw = torch.empty((nconv * nl, H, H), **f32)
-        g_sw = torch.empty((nconv * nl, H, H, C), **f32)
-        g_sc = torch.empty((nconv * nl, H, H), **f32)
-        widths = (H,) * (nl + 1)
-        warr = (ctypes.c_int32 * (nl + 1))(*widths)
-        _, wb = _sizes("kagnn_gine_kan_stack_workspace_bytes", n, nconv, nl, widths, G, K, mode, outputs=2)
-        ws = _ws(wb, dev)
-        VP, FA, VC = ctypes.c_void_p * (nconv * nl), ctypes.c_float * nconv, ctypes.c_void_p * nconv
-        a0, hs = acts_all.data_ptr(), n * H * 4
-        acts_ptr = (ctypes.c_void_p * (nconv * (nl + 1)))(*[a0 + k * hs for k in range(nconv * (nl + 1))])
-        pd_ptr = VP(*[packs.data_ptr() + nconv * nl * fb + k * db for k in range(nconv * nl)])
-        _call("kagnn_gine_kan_stack_bwd", _ptr(gh), _ld(gh), _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr_t), _ptr(g.col_t),
-              _ptr(g.perm_t), FA(*self_scales), nconv, nl, warr, _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, acts_ptr, pd_ptr,
-              VC(*[h_all.data_ptr() + i * hs for i in range(nconv)]), _ptr_array(bnw),
-              VC(*[stats.data_ptr() + (2 * i) * H * 4 for i in range(nconv)]), VC(*[stats.data_ptr() + (2 * i + 1) * H * 4 for i in range(nconv)]),
-              _ptr(gx), H, _ptr(gea), H, VC(*[g_bn.data_ptr() + (2 * i) * H * 4 for i in range(nconv)]),
-              VC(*[g_bn.data_ptr() + (2 * i + 1) * H * 4 for i in range(nconv)]),
-              VP(*[g_bw.data_ptr() + k * H * H * 4 for k in range(nconv * nl)]), VP(*[g_sw.data_ptr() + k * H * H * C * 4 for k in range(nconv * nl)]),
-              VP(*[g_sc.data_ptr() + k * H * H * 4 for k in range(nconv * nl)]), _ptr(ws), ws.numel(), _stream())
-        grads = []
-        for i in range(nconv):
-            grads += [g_bn[i, 0], g_bn[i, 1]]
-            for l in range(nl):
-                k = i * nl + l
-                grads += [g_bw[k], g_sw[k], g_sc[k]]
+        st.xg, st.ea, st.acts_all, st.h_all, st.stats, st.packs, st.knots = t[:7]
+        nconv, nl = st.nconv, st.nl
+        st.bnw = t[7:7 + nconv]
+        st.sws = t[7 + nconv:7 + nconv + nconv * nl]
+        st.scs = t[7 + nconv + nconv * nl:7 + nconv + 2 * nconv * nl]
+        gx, gea, grads = _gine_stack_bwd_raw(gh, st, ctx.needs_input_grad[1])
         return (gx, gea, None, None, None, None, None, None, None, None, None, None, None, *grads)
 
 
 _GINE_STACK_ABI = True      # False: one tape node per convolution (bit-identical)
 
 
-def gine_kan_stack(x, edge_attr, g: "GraphIndex", convs, bns):
-    """``for conv, bn in zip(convs, bns): x = bn(conv(x, g, edge_attr))`` as ONE tape node (``_GineKanStackFn``), or ``None`` when the
-    stack is outside what the node covers (the caller then runs the loop): GINE convolutions around KAN chains of identical
-    hidden -> ... -> hidden widths (<= 64: one pack launch for the stack), one uniform grid and precision for all of them, a
-    split-like mode, training-mode affine BatchNorm1d modules, fp32 CUDA rows, at most 16 KANLinears in all, not under torch.compile."""
+def _gine_stack_plan(x, convs, bns):
+    """Is ``for conv, bn in zip(convs, bns): x = bn(conv(x, g, edge_attr))`` within what ``_GineKanStackFn`` covers?  -> ``(first
+    layer, layers per chain, mode)`` or ``None``.  No side effects (the norms' batch counters move in ``_gine_stack_args``)."""
     if (not _GINE_STACK_ABI or not _GINE_LAYER_ABI or torch.compiler.is_compiling() or not x.is_cuda or x.dtype != torch.float32
             or x.size(0) < 2 or len(convs) < 2):
         return None
     H = x.size(1)
     first = None
-    params, scales, running, momentum, eps = [], [], [], [], []
     nl = None
     for conv, bn in zip(convs, bns):
         layers = list(getattr(conv.nn, "layers", []))
@@ -231,6 +255,12 @@ def gine_kan_stack(x, edge_attr, g: "GraphIndex", convs, bns):
     mode = first.precision if first.precision is not None else default_precision()
     if not split_like(mode) or first.spline_order != 3 or first.grid_size + first.spline_order > 8 or H > 64 or len(convs) * nl > 16:
         return None
+    return first, nl, mode
+
+
+def _gine_stack_args(convs, bns):
+    """the per-convolution arguments of the stack node; counts the batch in every norm (``BatchNorm1d.step``)"""
+    params, scales, running, momentum, eps = [], [], [], [], []
     for conv, bn in zip(convs, bns):
         factor, use_running = bn.step()
         params += [bn.weight, bn.bias]
@@ -239,8 +269,21 @@ def gine_kan_stack(x, edge_attr, g: "GraphIndex", convs, bns):
         scales.append(1.0 + conv._eps())
         running.append((bn.running_mean, bn.running_var) if use_running else (None, None))
         momentum.append(factor); eps.append(bn.eps)
-    return _GineKanStackFn.apply(x, edge_attr, g, tuple(scales), first._knots(), first.grid_size, first.spline_order, mode, tuple(running),
-                                 tuple(momentum), tuple(eps), len(convs), nl, *params)
+    return params, tuple(scales), tuple(running), tuple(momentum), tuple(eps)
+
+
+def gine_kan_stack(x, edge_attr, g: "GraphIndex", convs, bns):
+    """``for conv, bn in zip(convs, bns): x = bn(conv(x, g, edge_attr))`` as ONE tape node (``_GineKanStackFn``), or ``None`` when the
+    stack is outside what the node covers (the caller then runs the loop): GINE convolutions around KAN chains of identical
+    hidden -> ... -> hidden widths (<= 64: one pack launch for the stack), one uniform grid and precision for all of them, a
+    split-like mode, training-mode affine BatchNorm1d modules, fp32 CUDA rows, at most 16 KANLinears in all, not under torch.compile."""
+    plan = _gine_stack_plan(x, convs, bns)
+    if plan is None:
+        return None
+    first, nl, mode = plan
+    params, scales, running, momentum, eps = _gine_stack_args(convs, bns)
+    return _GineKanStackFn.apply(x, edge_attr, g, scales, first._knots(), first.grid_size, first.spline_order, mode, running,
+                                 momentum, eps, len(convs), nl, *params)
 
 
 _GINE_LAYER_ABI = True      # False: the per-operation composition (module attributes for the A/B tests, not environment switches)
@@ -277,6 +320,38 @@ def gine_kan_layer(x, edge_attr, g: "GraphIndex", self_scale: float, net, batch_
 
 
 
+def _embedding_sum_fwd_raw(x, tables):
+    """-> (sum_c tables[c][x[:, c]], the contiguous index matrix, the tables' shapes)"""
+    _need_cuda(x, *tables)
+    if x.dtype != torch.int64 or x.dim() != 2 or x.size(1) != len(tables):
+        raise ValueError("x must be an int64 [N, columns] matrix with one table per column")
+    x = x.contiguous()
+    n, cols, f = x.size(0), x.size(1), tables[0].size(1)
+    out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    tabs = [t.contiguous() for t in tables]
+    for c, t in enumerate(tabs):
+        if t.dtype != torch.float32 or t.size(1) != f:
+            raise ValueError("embedding tables must be fp32 [V, F] with one F")
+        _call("kagnn_embedding_fwd", x.data_ptr() + 8 * c, cols, n, _ptr(t), t.size(0), f, _ptr(out), f, int(c > 0), _stream())
+    return out, x, [tuple(t.shape) for t in tabs]
+
+
+def _embedding_sum_bwd_raw(x, g, shapes, wanted=None):
+    """table gradients of ``_embedding_sum_fwd_raw`` (``None`` where ``wanted[c]`` is false)"""
+    g = _rows(g)
+    n, cols = x.shape
+    grads = []
+    for c, (v, f) in enumerate(shapes):
+        if wanted is not None and not wanted[c]:
+            grads.append(None)
+            continue
+        gt = torch.empty((v, f), dtype=torch.float32, device=g.device)
+        ws = _ws(_sizes("kagnn_embedding_bwd_workspace_bytes", n, v, f), g.device)
+        _call("kagnn_embedding_bwd", x.data_ptr() + 8 * c, cols, n, _ptr(g), _ld(g), v, f, _ptr(gt), _ptr(ws), ws.numel(), _stream())
+        grads.append(gt)
+    return grads
+
+
 class _EmbeddingSumFn(Function):
     """``sum_c tables[c][x[:, c]]`` (the OGB-style Atom / BondEncoder of the graph-level models, reference
     ``graph_regression/models.py:244-281``): one launch per feature column each way (``kagnn_embedding_fwd / _bwd``) instead of a
@@ -285,19 +360,9 @@ class _EmbeddingSumFn(Function):
     @staticmethod
     @_on_operand_device
     def forward(ctx, x, *tables):
-        _need_cuda(x, *tables)
-        if x.dtype != torch.int64 or x.dim() != 2 or x.size(1) != len(tables):
-            raise ValueError("x must be an int64 [N, columns] matrix with one table per column")
-        x = x.contiguous()
-        n, cols, f = x.size(0), x.size(1), tables[0].size(1)
-        out = torch.empty((n, f), dtype=torch.float32, device=x.device)
-        tabs = [t.contiguous() for t in tables]
-        for c, t in enumerate(tabs):
-            if t.dtype != torch.float32 or t.size(1) != f:
-                raise ValueError("embedding tables must be fp32 [V, F] with one F")
-            _call("kagnn_embedding_fwd", x.data_ptr() + 8 * c, cols, n, _ptr(t), t.size(0), f, _ptr(out), f, int(c > 0), _stream())
-        ctx.save_for_backward(x)
-        ctx.shapes = [tuple(t.shape) for t in tabs]
+        out, xc, shapes = _embedding_sum_fwd_raw(x, tables)
+        ctx.save_for_backward(xc)
+        ctx.shapes = shapes
         return out
 
     @staticmethod
@@ -305,21 +370,155 @@ class _EmbeddingSumFn(Function):
     @_on_operand_device
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        g = _rows(g)
-        n, cols = x.shape
-        grads = []
-        for c, (v, f) in enumerate(ctx.shapes):
-            if not ctx.needs_input_grad[1 + c]:
-                grads.append(None)
-                continue
-            gt = torch.empty((v, f), dtype=torch.float32, device=g.device)
-            ws = _ws(_sizes("kagnn_embedding_bwd_workspace_bytes", n, v, f), g.device)
-            _call("kagnn_embedding_bwd", x.data_ptr() + 8 * c, cols, n, _ptr(g), _ld(g), v, f, _ptr(gt), _ptr(ws), ws.numel(), _stream())
-            grads.append(gt)
-        return (None, *grads)
+        return (None, *_embedding_sum_bwd_raw(x, g, ctx.shapes, ctx.needs_input_grad[1:]))
 
 
 def embedding_sum(x: torch.Tensor, tables) -> torch.Tensor:
     return _EmbeddingSumFn.apply(x, *tables)
 
+
+# ======================================================================== the whole regression model as one tape node
+class _ModelPlan:
+    """the non-tensor arguments of ``_KaginModelFn`` (one object instead of ~20 positional Python values)"""
+    __slots__ = ("n_atom", "n_bond", "n_stack", "n_readout", "scales", "running", "momentum", "eps", "nconv", "nl", "knots", "G", "K", "mode",
+                 "ro_knots", "ro_G", "ro_K", "ro_modes")
+
+
+class _KaginModelFn(Function):
+    """``KAGIN.forward`` of the graph-regression models (reference ``graph_regression/models.py:107-119``: Atom / BondEncoder ->
+    ``n_layers x {GINEConv(KAN) -> BatchNorm1d}`` -> ``global_add_pool`` -> KAN read-out) as ONE tape node.  No new kernels and no new
+    library entry points: the node runs the calls of its five constituents (``_EmbeddingSumFn`` x 2, ``_GineKanStackFn``,
+    ``_SegmentPoolFn``, ``_KANLinearFn`` per read-out layer) back to back -- same kernels, same order per tensor, same bits.  What
+    it removes is Python: on a 256-molecule mini-batch the device needs ~0.8 ms per training step and the host ~1.2 ms, a third of
+    it ``Function.apply`` / ``nn.Module.__call__`` / autograd-engine overhead of those nodes (``profiles/r05_experiments.md`` 9)."""
+
+    @staticmethod
+    @_on_operand_device
+    def forward(ctx, x_int, e_int, g, seg, plan, *params):
+        a, b, c = plan.n_atom, plan.n_atom + plan.n_bond, plan.n_atom + plan.n_bond + plan.n_stack
+        x0, xi, ashapes = _embedding_sum_fwd_raw(x_int, params[:a])
+        ea, ei, bshapes = _embedding_sum_fwd_raw(e_int, params[a:b])
+        h, st = _gine_stack_fwd_raw(x0, ea, g, plan.scales, plan.knots, plan.G, plan.K, plan.mode, plan.running, plan.momentum, plan.eps,
+                                    plan.nconv, plan.nl, params[b:c])
+        pooled = _segment_pool_raw(h, seg, False)
+        ro = params[c:]
+        layers = [(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]) for i in range(plan.n_readout)]
+        packs = None
+        if plan.n_readout > 1 and len(set(plan.ro_modes)) == 1 and split_like(plan.ro_modes[0]):
+            packs = kan_pack_chain(layers, plan.ro_G, plan.ro_K, plan.ro_modes[0])         # one pack launch (None: each layer packs itself)
+        acts, pds, kept = [pooled], [], []
+        for i, (bw, sw, sc) in enumerate(layers):
+            bw_c, sw_c, sc_c = bw.contiguous(), sw.contiguous(), None if sc is None else sc.contiguous()
+            y, pd = _kan_fwd_raw(acts[-1], bw_c, sw_c, sc_c, plan.ro_knots[i], plan.ro_G, plan.ro_K, plan.ro_modes[i],
+                                 None if packs is None else packs[i], _weights_key(bw, sw, sc) if packs is not None else None)
+            acts.append(y); pds.append(pd); kept.append((sw_c, sc_c))
+        ctx.state = (plan, g, seg, xi, ashapes, ei, bshapes, st, acts, pds, kept, h.size(0))
+        return acts[-1]
+
+    @staticmethod
+    @once_differentiable
+    @_on_operand_device
+    def backward(ctx, gout):
+        plan, g, seg, xi, ashapes, ei, bshapes, st, acts, pds, kept, n = ctx.state
+        gy = _rows(gout)
+        ro_grads = [None] * (3 * plan.n_readout)
+        for i in reversed(range(plan.n_readout)):
+            x_i, (sw_c, sc_c) = acts[i], kept[i]
+            fin, fout, G, K, mode = x_i.size(1), sw_c.size(0), plan.ro_G, plan.ro_K, plan.ro_modes[i]
+            gx = _kan_bwd_input_raw(x_i, gy, plan.ro_knots[i], pds[i], fin, fout, G, K, mode)
+            ro_grads[3 * i:3 * i + 3] = _kan_bwd_weight_raw(x_i, gy, plan.ro_knots[i], sw_c, sc_c, fin, fout, G, K, mode, True)
+            gy = gx
+        gh = _segment_broadcast_raw(gy, seg, n, False)
+        gx0, gea, sgrads = _gine_stack_bwd_raw(gh, st, True)
+        agrads = _embedding_sum_bwd_raw(xi, gx0, ashapes)
+        bgrads = _embedding_sum_bwd_raw(ei, gea, bshapes)
+        ctx.state = None
+        return (None, None, None, None, None, *agrads, *bgrads, *sgrads, *ro_grads)
+
+
+_GINE_MODEL_NODE = True      # False: the model runs as its five kinds of tape nodes (bit-identical; module attribute for the A/B test)
+
+
+def _hook_free(mods) -> bool:
+    mod = torch.nn.modules.module
+    if (mod._global_forward_hooks or mod._global_forward_pre_hooks or mod._global_backward_hooks
+            or getattr(mod, "_global_backward_pre_hooks", None)):
+        return False
+    for m in mods:
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+            return False
+    return True
+
+
+def kagin_regression_forward(model, data):
+    """``KAGINRegression.forward(data)`` as ONE tape node (``_KaginModelFn``), or ``None`` when the model or the batch is outside
+    what the node covers (the caller then runs its modules one by one): training mode, no dropout, embedding-table encoders on
+    int64 features, a GINE stack that ``_GineKanStackFn`` takes, a read-out ``KAN`` of uniform-grid ``KANLinear`` layers with at
+    most 16 coefficients, no hooks anywhere, not under torch.compile."""
+    if not _GINE_MODEL_NODE or not model.training or model.dropout.p > 0.0 or torch.compiler.is_compiling():
+        return None
+    x, e = data.x, data.edge_attr
+    if e.dim() == 1:
+        e = e.unsqueeze(1)
+    atom, bond = model.atom_encoder, model.bond_encoder
+    fast = getattr(atom, "_fast_tables", None), getattr(bond, "_fast_tables", None)
+    if fast[0] is None or fast[1] is None:
+        return None
+    atabs, btabs = fast[0](x), fast[1](e)
+    if atabs is None or btabs is None:
+        return None
+    convs, bns, ro = list(model.conv), list(model.bn), list(getattr(model.kan, "layers", []))
+    if not ro or any(type(l).__name__ != "KANLinear" for l in ro) or type(model.kan).__name__ != "KAN":
+        return None
+    if any(type(c).__name__ != "GINEKANLayer" for c in convs) or any(type(b).__name__ != "BatchNorm1d" or not hasattr(b, "step") for b in bns):
+        return None
+    H = atabs[0].size(1)
+    if btabs[0].size(1) != H or x.size(0) < 2:
+        return None
+    mods = [model, atom, bond, model.kan, *convs, *bns, *ro]
+    for cv in convs:
+        mods.append(cv.nn); mods += list(getattr(cv.nn, "layers", []))
+    if not _hook_free(mods):
+        return None
+    plan_s = _gine_stack_plan(_ShapeOnly(x.size(0), H, x.device), convs, bns)
+    if plan_s is None:
+        return None
+    first, nl, mode = plan_s
+    G_r, K_r = ro[0].grid_size, ro[0].spline_order
+    ro_knots, ro_modes = [], []
+    for l in ro:
+        k = l._knots()
+        if k.dim() != 1 or l.grid_size != G_r or l.spline_order != K_r or G_r + K_r > 16:
+            return None
+        m = l.precision if l.precision is not None else default_precision()
+        if split_like(m) and max(l.in_features, l.out_features) > 7680:
+            m = PREC_FP32
+        ro_knots.append(k); ro_modes.append(int(m))
+    if ro[0].in_features != H:
+        return None
+    from .graph_models import _segment_ptr
+    g = graph_index(data.edge_index, x.size(0), cache=False)
+    seg = _segment_ptr(data)
+    sparams, scales, running, momentum, eps = _gine_stack_args(convs, bns)
+    plan = _ModelPlan()
+    plan.n_atom, plan.n_bond, plan.n_stack, plan.n_readout = len(atabs), len(btabs), len(sparams), len(ro)
+    plan.scales, plan.running, plan.momentum, plan.eps, plan.nconv, plan.nl = scales, running, momentum, eps, len(convs), nl
+    plan.knots, plan.G, plan.K, plan.mode = first._knots(), first.grid_size, first.spline_order, mode
+    plan.ro_knots, plan.ro_G, plan.ro_K, plan.ro_modes = ro_knots, G_r, K_r, ro_modes
+    rparams = []
+    for l in ro:
+        rparams += [l.base_weight, l.spline_weight, l.spline_scaler if l.enable_standalone_scale_spline else None]
+    return _KaginModelFn.apply(x, e, g, seg, plan, *atabs, *btabs, *sparams, *rparams)
+
+
+class _ShapeOnly:
+    """what ``_gine_stack_plan`` asks of its input before the input exists (the atom encoder's output: fp32 [N, H] on the device)"""
+    __slots__ = ("_n", "_h", "device")
+    is_cuda, dtype = True, torch.float32
+
+    def __init__(self, n, h, device):
+        self._n, self._h, self.device = n, h, device
+
+    def size(self, d):
+        return (self._n, self._h)[d]
 

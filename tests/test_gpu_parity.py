@@ -745,8 +745,9 @@ def test_gine_conv_one_library_call_each_way_matches_the_composition(golden, mon
     pre = "kan.state."
     state = {k[len(pre):]: T(z[k], DEV) for k in z.files if k.startswith(pre)}
     res = {}
-    for how in ("stack", "layer", "ops"):
-        monkeypatch.setattr(graph_ops, "_GINE_STACK_ABI", how == "stack")
+    for how in ("model", "stack", "layer", "ops"):
+        monkeypatch.setattr(graph_ops, "_GINE_MODEL_NODE", how == "model")
+        monkeypatch.setattr(graph_ops, "_GINE_STACK_ABI", how in ("model", "stack"))
         monkeypatch.setattr(graph_ops, "_GINE_LAYER_ABI", how != "ops")
         m.load_state_dict(state, strict=True)
         m = m.to(DEV).train()
@@ -761,7 +762,19 @@ def test_gine_conv_one_library_call_each_way_matches_the_composition(golden, mon
             ops.set_timer(None)
         names = [r[0] for r in timer.records]
         res[how] = (pred.detach().clone(), float(loss), {k: p.grad.clone() for k, p in m.named_parameters()},
-                    {k: v.clone() for k, v in m.state_dict().items() if "running" in k}, names)
+                    {k: v.clone() for k, v in m.state_dict().items() if "running" in k}, names, pred.grad_fn,
+                    {k: int(v) for k, v in m.state_dict().items() if "num_batches" in k})
+    # the whole forward as ONE tape node (graph_ops._KaginModelFn): the same library calls as the stack form, the same bits everywhere
+    assert type(res["model"][5]).__name__ == "_KaginModelFnBackward" and type(res["stack"][5]).__name__ != "_KaginModelFnBackward"
+    work_ = lambda names_: [n_ for n_ in names_ if not n_.endswith("_bytes")]
+    assert sorted(work_(res["model"][4])) == sorted(work_(res["stack"][4])), (work_(res["model"][4]), work_(res["stack"][4]))
+    assert torch.equal(res["model"][0], res["stack"][0]) and res["model"][1] == res["stack"][1]
+    assert set(res["model"][2]) == set(res["stack"][2])
+    for k, gref in res["stack"][2].items():
+        assert torch.equal(res["model"][2][k], gref), k
+    for k, v in res["stack"][3].items():
+        assert torch.equal(res["model"][3][k], v), k
+    assert res["model"][6] == res["stack"][6] and len(res["model"][6]) == 3
     sn, fn, cn = res["stack"][4], res["layer"][4], res["ops"][4]
     assert sn.count("kagnn_gine_kan_stack_fwd") == 1 and sn.count("kagnn_gine_kan_stack_bwd") == 1 and "kagnn_gine_kan_layer_fwd" not in sn, sn
     assert fn.count("kagnn_gine_kan_layer_fwd") == 3 and fn.count("kagnn_gine_kan_layer_bwd") == 3, fn
@@ -782,6 +795,46 @@ def test_gine_conv_one_library_call_each_way_matches_the_composition(golden, mon
         assert_close(res["layer"][2][k], gref, 1e-4, what=f"gine one-call grad.{k}", noise=prenorm_bias_noise(k, res["ops"][2]), elementwise=False)
     for k, v in res["ops"][3].items():
         assert_close(res["layer"][3][k], v, 1e-5, what=f"gine one-call {k}")
+
+
+def test_model_node_steps_aside_when_it_does_not_cover_the_call(golden):
+    """graph_ops.kagin_regression_forward returns None -- and the modules run one by one, with the same result where both apply --
+    in eval mode, with dropout, with a hook on any sub-module, with Linear encoders, under the FastKAN flavour"""
+    z = golden("g8b_zinc_batch")
+
+    class Data:
+        pass
+    d = Data()
+    d.x, d.edge_index, d.batch = T(z["x"], DEV), T(z["edge_index"], DEV), T(z["batch"], DEV)
+    d.edge_attr, d.num_graphs = T(z["edge_attr"], DEV), 256
+
+    def make(p=0.0):
+        torch.manual_seed(0)
+        m = kagnn_amd.KAGINRegression(1, 1, 3, 32, 2, 4, 3, 1, p, True)
+        m.atom_encoder = kagnn_amd.graph_models.AtomEncoder(32, [21])
+        m.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, 32)])
+        return m.to(DEV)
+    node = lambda out: type(out.grad_fn).__name__ == "_KaginModelFnBackward"
+    m = make().train()
+    ref = m(d)
+    assert node(ref)
+    assert not node(m.eval()(d))                                             # eval: running statistics, the composed path
+    m.train()
+    h = m.conv[1].nn.layers[0].register_forward_hook(lambda *a: None)
+    assert graph_ops.kagin_regression_forward(m, d) is None and not node(m(d))
+    h.remove()
+    assert node(m(d))
+    assert graph_ops.kagin_regression_forward(make(0.2).train(), d) is None      # dropout between the convolutions
+    lin = kagnn_amd.KAGINRegression(21, 4, 2, 32, 2, 4, 3, 1, 0.0).to(DEV).train()
+    dl = Data()
+    dl.x, dl.edge_attr = torch.randn(d.x.size(0), 21, device=DEV), torch.randn(d.edge_attr.size(0), 4, device=DEV)
+    dl.edge_index, dl.batch, dl.num_graphs = d.edge_index, d.batch, 256
+    assert graph_ops.kagin_regression_forward(lin, dl) is None and lin(dl).shape == (256, 1)
+    fk = kagnn_amd.FASTKAGINRegression(1, 1, 2, 32, 2, 4, 1, 0.0, True).to(DEV).train()
+    fk.atom_encoder = kagnn_amd.graph_models.AtomEncoder(32, [21]).to(DEV)
+    fk.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, 32)]).to(DEV)
+    out = fk(d)
+    assert not node(out) and out.shape == (256, 1)
 
 
 def test_p2p_exchange_kernels_on_local_buffers():
