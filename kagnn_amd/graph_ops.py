@@ -261,8 +261,14 @@ def _gine_stack_plan(x, convs, bns):
 def _gine_stack_args(convs, bns):
     """the per-convolution arguments of the stack node; counts the batch in every norm (``BatchNorm1d.step``)"""
     params, scales, running, momentum, eps = [], [], [], [], []
+    # the norms' batch counters: one multi-tensor increment for all of them where BatchNorm1d.step would do `counter.add_(1)` each
+    # (training, tracked statistics, a fixed momentum -- with momentum=None the factor is read back from the counter: left to step())
+    together = len(bns) > 1 and all(bn.training and bn.track_running_stats and bn.num_batches_tracked is not None and bn.momentum is not None
+                                    for bn in bns)
+    if together:
+        torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
     for conv, bn in zip(convs, bns):
-        factor, use_running = bn.step()
+        factor, use_running = (bn.momentum, True) if together else bn.step()
         params += [bn.weight, bn.bias]
         for l in conv.nn.layers:
             params += [l.base_weight, l.spline_weight, l.spline_scaler]
