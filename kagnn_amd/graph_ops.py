@@ -125,6 +125,8 @@ def _gine_stack_fwd_raw(x, edge_attr, g, self_scales, knots, grid_size, spline_o
     if n != g.num_nodes or ea.shape != (g.num_edges, H):
         raise ValueError("x must be [N, H] and edge_attr [E, H] with N / E those of the graph")
     f32 = dict(dtype=torch.float32, device=dev)
+    if ea.numel() == 0:                  # a batch without edges (single atoms): the library wants a non-null pointer; it reads no row
+        ea = torch.zeros((1, H), **f32)
     acts_all = torch.empty((nconv, nl + 1, n, H), **f32)
     h_all = torch.empty((nconv, n, H), **f32)
     stats = torch.empty((nconv, 2, H), **f32)

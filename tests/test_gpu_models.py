@@ -1113,6 +1113,19 @@ def test_fuzz_models_folds_on_vs_off():
     assert m and int(m.group(1)) >= 20 and int(m.group(2)) >= 20, tail       # the folds really ran
 
 
+def test_fuzz_graph_models_one_node_vs_five_nodes_vs_oracle():
+    """tools/fuzz_graph_models.py inside the suite: 30 random graph-regression models / mini-batches (hidden 8..64, 2..5 convolutions,
+    1..300 graphs, edgeless batches, tables of 2..300 rows): the whole forward as one tape node is bit-identical to its five-node
+    form and as close to the fp64 oracle as the per-operation composition (or 1e-4)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_graph_models.py"), "30", "0"], cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "failures: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    m = re.search(r"ran as one tape node: (\d+) of 30", r.stdout)
+    assert m and int(m.group(1)) >= 25, r.stdout[-1000:]
+
+
 # ------------------------------------------------------------------ the harness optimiser (optuna_zinc.py:49,62: torch.optim.Adam)
 @pytest.mark.parametrize("weight_decay", [0.0, 0.01])
 def test_harness_adam_is_torch_adam(weight_decay):
