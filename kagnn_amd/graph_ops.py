@@ -47,7 +47,10 @@ class _GineKanLayerFn(Function):
         wf, _ = _sizes("kagnn_gin_kan_layer_workspace_bytes", n, nl, tuple(widths), grid_size, spline_order, mode, 0, 0, outputs=2)
         ws = _ws(wf, dev)
         mom = torch.empty((2, widths[nl]), dtype=torch.float32, device=dev) if bn is not None else None
-        _call("kagnn_gine_kan_layer_fwd", _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm),
+        if ea.numel() == 0:              # a batch without edges: the library wants non-null edge arrays; it reads no element of them
+            ea = torch.zeros((1, widths[0]), dtype=torch.float32, device=dev)
+        perm = g.perm if g.num_edges else torch.zeros(1, dtype=torch.int32, device=dev)
+        _call("kagnn_gine_kan_layer_fwd", _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr), _ptr(g.col), _ptr(perm),
               float(self_scale), nl, warr, _ptr_array([l[0] for l in layers]), _ptr_array([l[1] for l in layers]),
               _ptr_array([l[2] for l in layers]), _ptr(knots), grid_size, spline_order, mode, _ptr_array(acts), _ptr_array(pfs),
               _ptr_array(pds), _ptr(mom[0]) if mom is not None else None, _ptr(mom[1]) if mom is not None else None,
@@ -90,8 +93,9 @@ class _GineKanLayerFn(Function):
             g_bnw, g_bnb = torch.empty(widths[nl], **f32), torch.empty(widths[nl], **f32)
         ws = _ws(wb, dev)
         warr = (ctypes.c_int32 * (nl + 1))(*widths)
+        perm_t = g.perm_t if g.num_edges else torch.zeros(1, dtype=torch.int32, device=dev)
         _call("kagnn_gine_kan_layer_bwd", _ptr(gh), _ld(gh), _ptr(y), _ld(y) if y is not None else 0, _ptr(bn_w), _ptr(mean), _ptr(rstd),
-              _ptr(g_bnw), _ptr(g_bnb), _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(g.perm_t),
+              _ptr(g_bnw), _ptr(g_bnb), _ptr(xg), _ld(xg), _ptr(ea), _ld(ea), n, _ptr(g.rowptr_t), _ptr(g.col_t), _ptr(perm_t),
               float(self_scale), nl, warr, _ptr_array(sws), _ptr_array(scs), _ptr(knots), G, K, mode, _ptr_array(acts), _ptr_array(pds),
               _ptr(gx), widths[0], _ptr(gea), widths[0], _ptr_array(gbw), _ptr_array(gsw), _ptr_array(gsc), _ptr(ws), ws.numel(), _stream())
         grads = []

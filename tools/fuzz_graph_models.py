@@ -3,7 +3,8 @@
 1..300 graphs of 1..40 nodes with 0..3x as many edges incl. self loops / duplicates / isolated nodes, 1..3 atom and 1..2 bond feature
 columns with tables of 2..300 rows, 1 or 3 targets): KAGINRegression's default path -- the whole forward as ONE tape node
 (graph_ops._KaginModelFn: stack call, embedding / pool / read-out calls, deferred slab reductions, merged norm kernels) -- against
-(a) the same model run as its five kinds of nodes (bit for bit: prediction, loss, every gradient, running statistics) and (b) the
+(a) the same model run as its five kinds of nodes, and with one node per convolution instead of the stack node (all bit for bit:
+prediction, loss, every gradient, running statistics) and (b) the
 fp64 oracle, with the per-operation composition (aggregate_gine -> pack -> KANLinear -> BatchNorm ...) as the yardstick, through
 ops.l1_loss.  usage: python tools/fuzz_graph_models.py [cases] [seed]"""
 import copy, os, random, sys
@@ -53,9 +54,10 @@ for case in range(cases):
     label = f"case {case}: hidden {H} convs {nconv} chain {hl} grid {G} graphs {B} nodes {n} edges {e} atom tables {adims} bond tables {bdims} targets {targets}"
     try:
         res = {}
-        for how in ("model", "nodes", "ops"):
+        for how in ("model", "nodes", "layer", "ops"):
             graph_ops._GINE_MODEL_NODE = how == "model"
-            graph_ops._GINE_STACK_ABI = graph_ops._GINE_LAYER_ABI = how != "ops"
+            graph_ops._GINE_STACK_ABI = how in ("model", "nodes")
+            graph_ops._GINE_LAYER_ABI = how != "ops"
             m = copy.deepcopy(m0)
             pred = m(d)
             nodes_run += how == "model" and type(pred.grad_fn).__name__ == "_KaginModelFnBackward"
@@ -63,9 +65,11 @@ for case in range(cases):
             loss.backward()
             res[how] = ([pred.detach().clone(), loss.detach().clone()] + [p.grad.clone() for p in m.parameters()]
                         + [b_.clone() for b_ in m.buffers() if b_.dtype.is_floating_point])
-        for k, (a, b) in enumerate(zip(res["model"], res["nodes"])):
+        for k, (a, b, c) in enumerate(zip(res["model"], res["nodes"], res["layer"])):
             if not torch.equal(a, b):
                 raise AssertionError(f"tensor {k}: the one-node form differs from the five-node form by {float((a - b).abs().max()):.3e}")
+            if not torch.equal(b, c):
+                raise AssertionError(f"tensor {k}: the stack node differs from one node per convolution by {float((b - c).abs().max()):.3e}")
         # referee: the fp64 oracle restatement of the model (oracle/kan_oracle.py::graph_regression_forward); yardstick: the error of
         # the per-operation composition against it.  relu(x_j + e_ij) has a kink -- a message element within rounding of zero flips
         # the upstream gradient by ~1e-3 of its scale, and which side an fp32 pipeline lands on is arithmetic-order luck (the
