@@ -837,6 +837,77 @@ def test_model_node_steps_aside_when_it_does_not_cover_the_call(golden):
     assert not node(out) and out.shape == (256, 1)
 
 
+def test_library_calls_follow_the_current_stream():
+    """every launch goes to torch's CURRENT stream (forward and, through autograd, backward): on a side stream the results are the
+    default stream's bit for bit, and the side stream finishes while the default stream is still busy with something else --
+    nothing was enqueued behind it.  Layers, a node-model step (CSR build included) and the graph-level step (deferred CSR
+    validation: an event on the current stream)."""
+    from types import SimpleNamespace
+    gen = torch.Generator().manual_seed(12)
+    n, f = 20_000, 64
+    ei = orc.powerlaw_graph(n, 120_000, seed=2).to(DEV)
+    x = (torch.randn(n, f, generator=gen) * 0.5).to(DEV)
+    ycls = torch.randint(0, 7, (n,), generator=gen).to(DEV)
+    torch.manual_seed(1)
+    layer = kagnn_amd.KANLinear(f, 48, grid_size=5, spline_order=3).to(DEV)
+    conv = kagnn_amd.GIFASTKANLayer(f, 32, grid_size=4, hidden_dim=32, nb_layers=2).to(DEV)
+    model = kagnn_amd.GKAN_Nodes("gin", 2, f, 32, 7, grid_size=5, spline_order=3).to(DEV)
+    B, H = 64, 32
+    sizes = torch.randint(5, 30, (B,), generator=gen)
+    nn_ = int(sizes.sum()); off = torch.cumsum(sizes, 0) - sizes
+    src = torch.cat([torch.randint(0, int(sizes[b]), (2 * int(sizes[b]),), generator=gen) + off[b] for b in range(B)])
+    dst = torch.cat([torch.randint(0, int(sizes[b]), (2 * int(sizes[b]),), generator=gen) + off[b] for b in range(B)])
+    d = SimpleNamespace(x=torch.randint(0, 21, (nn_, 1), generator=gen).to(DEV), edge_index=torch.stack([src, dst]).to(DEV),
+                        edge_attr=torch.randint(0, 4, (src.numel(),), generator=gen).to(DEV),
+                        batch=torch.cat([torch.full((int(sizes[b]),), b) for b in range(B)]).to(DEV), num_graphs=B)
+    yreg = torch.randn(B, generator=gen).to(DEV)
+    gm = kagnn_amd.KAGINRegression(1, 1, 3, H, 2, 4, 3, 1, 0.0, True)
+    gm.atom_encoder = kagnn_amd.graph_models.AtomEncoder(H, [21])
+    gm.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, H)])
+    gm = gm.to(DEV).train()
+    gm_state = {k: v.clone() for k, v in gm.state_dict().items()}
+    model_state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run():
+        out = []
+        for m in (layer, conv, model, gm):
+            m.zero_grad()
+        model.load_state_dict(model_state); gm.load_state_dict(gm_state)
+        xr = x.clone().requires_grad_(True)
+        y1 = layer(xr); y1.square().sum().backward()
+        out += [y1.detach(), xr.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        g = ops.GraphIndex(ei, n)
+        y2 = conv(x, g); y2.sum().backward()
+        out += [y2.detach()] + [p.grad.clone() for p in conv.parameters() if p.grad is not None]
+        loss = ops.softmax_cross_entropy(model(x, ei), ycls); loss.backward()
+        out += [loss.detach()] + [p.grad.clone() for p in model.parameters() if p.grad is not None]
+        l2 = ops.l1_loss(gm(d).squeeze(), yreg); l2.backward()
+        out += [l2.detach()] + [p.grad.clone() for p in gm.parameters() if p.grad is not None]
+        return out
+
+    ops.clear_graph_cache()
+    want = run()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    ops.clear_graph_cache()
+    busy = torch.cuda.Event()
+    torch.cuda._sleep(2_000_000_000)                 # ~1 s of the DEFAULT stream
+    busy.record()
+    with torch.cuda.stream(side):
+        got = run()
+        done = torch.cuda.Event()
+        done.record()
+    side.synchronize()
+    still_busy = not busy.query()
+    torch.cuda.synchronize()
+    assert done.query()
+    assert still_busy, "the side stream's work waited for the default stream: a launch went to the wrong stream"
+    assert len(got) == len(want)
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), k
+
+
 def test_p2p_exchange_kernels_on_local_buffers():
     """kagnn_p2p_reduce_scatter / kagnn_p2p_all_gather (csrc/p2p.hip) through the C ABI with the "peers" being buffers of this
     process: the column block of the rank-ordered sum, and the shards side by side (the two-process, hipIpc-mapped form runs in
