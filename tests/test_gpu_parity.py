@@ -908,6 +908,56 @@ def test_library_calls_follow_the_current_stream():
         assert torch.equal(a, b), k
 
 
+def test_two_host_threads_with_different_precision_modes_do_not_interfere():
+    """the library keeps its per-call state (precision mode of the call, error text, deferred reductions) in thread-local storage
+    and autograd runs every backward on its own thread: two host threads, each on its own stream, one in the three-product mode and
+    one in KAGNN_PREC_HALF, 30 forward + backward passes each at different shapes -- every pass gives the bits of the same pass
+    run alone"""
+    import threading
+    gen = torch.Generator().manual_seed(4)
+    jobs = []
+    for k, (n, fin, fout, mode) in enumerate([(3000, 64, 64, ops.PREC_SPLIT), (2500, 40, 70, ops.PREC_HALF)]):
+        torch.manual_seed(k)
+        layer = kagnn_amd.KANLinear(fin, fout, grid_size=5, spline_order=3).to(DEV)
+        layer.precision = mode
+        x = (torch.randn(n, fin, generator=gen) * 0.6).to(DEV)
+        gy = torch.randn(n, fout, generator=gen).to(DEV)
+        jobs.append((layer, x, gy))
+
+    def one_pass(layer, x, gy):
+        layer.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        y = layer(xr)
+        y.backward(gy)
+        return [y.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    alone = [one_pass(*j) for j in jobs]
+    torch.cuda.synchronize()
+    errors, results = [], [None, None]
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                outs = [one_pass(*jobs[k]) for _ in range(30)]
+            s.synchronize()
+            results[k] = outs
+        except Exception as ex:                       # noqa: BLE001
+            errors.append((k, repr(ex)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        for it, out in enumerate(results[k]):
+            for a, b in zip(out, alone[k]):
+                assert torch.equal(a, b), (k, it)
+    # and the half-mode thread really ran another arithmetic than the split mode would have
+    jobs[1][0].precision = ops.PREC_SPLIT
+    assert not torch.equal(one_pass(*jobs[1])[0], alone[1][0])
+
+
 def test_p2p_exchange_kernels_on_local_buffers():
     """kagnn_p2p_reduce_scatter / kagnn_p2p_all_gather (csrc/p2p.hip) through the C ABI with the "peers" being buffers of this
     process: the column block of the rank-ordered sum, and the shards side by side (the two-process, hipIpc-mapped form runs in
