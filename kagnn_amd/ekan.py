@@ -112,7 +112,7 @@ class KANLinear(nn.Module):
             # call cached, else assume the (uniform) grid the constructor made -- adaptive grids need one eager call first
             return self._knots_row if self._knots_row is not None else self.grid[0].contiguous()
         g = self.grid
-        key = (g.data_ptr(), g._version, str(g.device))
+        key = (g.data_ptr(), g._version, g.device)          # (the device object itself: str() of it was 1.5 us x 13 calls per graph-level step)
         if key != self._knots_key:
             row = g[0].detach().to(torch.float32)
             steps = row[1:] - row[:-1]

@@ -32,7 +32,12 @@ print(f"host issue time {host * 1e3:.3f} ms/step, wall {wall * 1e3:.3f} ms/step 
 # host issue time per phase (no synchronisation inside the loop: what the Python side costs when the device keeps up)
 from kagnn_amd import ops
 from kagnn_amd.harness import Adam
-for label, opt in (("torch.optim.Adam(fused=True)", opt), ("kagnn_amd.harness.Adam", Adam(m.parameters(), lr=1e-3)), ("torch.optim.Adam(fused=True) again", opt)):
+own = Adam(m.parameters(), lr=1e-3)
+for label, opt, mt in (("torch.optim.Adam(fused=True)", opt, True), ("kagnn_amd.harness.Adam", own, True),
+                       ("kagnn_amd.harness.Adam, backward on the calling thread (autograd multithreading off)", own, False),
+                       ("kagnn_amd.harness.Adam again", own, True),
+                       ("kagnn_amd.harness.Adam, backward on the calling thread, again", own, False)):
+  torch.autograd.set_multithreading_enabled(mt)
   ph = {"zero_grad": 0.0, "forward": 0.0, "loss": 0.0, "backward": 0.0, "optimizer": 0.0}
   for _ in range(10):
       for d in batches:
@@ -46,6 +51,7 @@ for label, opt in (("torch.optim.Adam(fused=True)", opt), ("kagnn_amd.harness.Ad
               ph[k] += b - a
   torch.cuda.synchronize()
   print(label, "-- host issue time per phase, us/step:", {k: round(v / 80 * 1e6, 1) for k, v in ph.items()}, "sum", round(sum(ph.values()) / 80 * 1e6, 1))
+torch.autograd.set_multithreading_enabled(True)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10):
     for d in batches: step(d)
