@@ -444,7 +444,6 @@ class _KaginModelFn(Function):
         gx0, gea, sgrads = _gine_stack_bwd_raw(gh, st, True)
         agrads = _embedding_sum_bwd_raw(xi, gx0, ashapes)
         bgrads = _embedding_sum_bwd_raw(ei, gea, bshapes)
-        ctx.state = None
         return (None, None, None, None, None, *agrads, *bgrads, *sgrads, *ro_grads)
 
 

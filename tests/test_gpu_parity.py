@@ -825,6 +825,15 @@ def test_model_node_steps_aside_when_it_does_not_cover_the_call(golden):
     h.remove()
     assert node(m(d))
     assert graph_ops.kagin_regression_forward(make(0.2).train(), d) is None      # dropout between the convolutions
+    # the node keeps what its backward needs for as long as the graph lives: a second backward over a retained graph accumulates
+    m.zero_grad()
+    out = m(d)
+    assert node(out)
+    out.sum().backward(retain_graph=True)
+    once = {k: p.grad.clone() for k, p in m.named_parameters()}
+    out.sum().backward()
+    for k, p in m.named_parameters():
+        assert torch.equal(p.grad, once[k] + once[k]), k
     lin = kagnn_amd.KAGINRegression(21, 4, 2, 32, 2, 4, 3, 1, 0.0).to(DEV).train()
     dl = Data()
     dl.x, dl.edge_attr = torch.randn(d.x.size(0), 21, device=DEV), torch.randn(d.edge_attr.size(0), 4, device=DEV)
