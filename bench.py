@@ -270,6 +270,40 @@ def secondary_figures(dev, conv, graph, x, n, e, f, grid, order):
     return out
 
 
+def graph_level_step_figures(dev, epochs=4):
+    """BASELINE config 4 (the latency-bound regime): the ZINC-shaped mini-batch training step of the reference's
+    graph-regression script (graph_regression/optuna_zinc.py:56-66: KAGIN(1, 1, 4 GINE convolutions, hidden 64, embedding encoders),
+    256 molecules of 23 +- 5 atoms per batch, L1 loss, Adam) through kagnn_amd.harness.train_graph_batches over 8 distinct batches
+    (a CSR per batch): wall ms per step (the step is host-bound: ~0.8 ms of device time)."""
+    import kagnn_amd
+    from types import SimpleNamespace
+    from kagnn_amd import harness
+    B, H = 256, 64
+    batches = []
+    for k in range(8):
+        g = torch.Generator().manual_seed(100 + k)
+        sizes = torch.randint(18, 29, (B,), generator=g)
+        n = int(sizes.sum()); off = torch.cumsum(sizes, 0) - sizes
+        src, dst, batch = [], [], []
+        for b in range(B):
+            nb = int(sizes[b]); eb = 2 * nb + 4
+            src.append(torch.randint(0, nb, (eb,), generator=g) + off[b]); dst.append(torch.randint(0, nb, (eb,), generator=g) + off[b])
+            batch.append(torch.full((nb,), b))
+        e = sum(len(s_) for s_ in src)
+        batches.append(SimpleNamespace(x=torch.randint(0, 21, (n, 1), generator=g).to(dev), edge_index=torch.stack([torch.cat(src), torch.cat(dst)]).to(dev),
+                                       edge_attr=torch.randint(0, 4, (e,), generator=g).to(dev), batch=torch.cat(batch).to(dev), num_graphs=B,
+                                       y=torch.randn(B, generator=g).to(dev)))
+    torch.manual_seed(0)
+    m = kagnn_amd.KAGINRegression(1, 1, 4, H, 2, 4, 3, 1, 0.0, True)
+    m.atom_encoder = kagnn_amd.graph_models.AtomEncoder(H, [21])
+    m.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, H)])
+    m = m.to(dev)
+    t, means = harness.train_graph_batches(m, batches, nb_epochs=epochs, warmup=2)
+    return {"what": "KAGIN graph-regression training step, 256-molecule mini-batch (~5.9k nodes / ~12.7k edges), 4 GINE(KAN) convolutions, "
+                    "hidden 64, grid 4, embedding encoders, L1 loss, Adam; 8 distinct batches, CSR rebuilt per batch (optuna_zinc.py:56-66)",
+            "ms_per_step": t * 1e3, "graphs_per_s": B / t, "edges_per_s": 12700 / t, "final_epoch_mean_loss": means[-1]}
+
+
 def other_layer_figures(dev, graph, n, e, steps=10):
     """The two other layer workloads of this script (`--workload config3`, `--workload fastkan`) timed in the same process,
     after the headline's timed region, on the same graph: ms per fwd+bwd step and the same roofline arithmetic."""
@@ -792,6 +826,7 @@ def main():
             out["secondary"]["model_step"]["conv_layers_share"] = conv_ms / out["secondary"]["model_step"]["ms_per_step"]
             if args.workload == "headline" and args.act == "fp32" and not fp32_mode:
                 out["secondary"]["other_layers"] = other_layer_figures(dev, graph, n, e)
+                out["secondary"]["graph_level_step"] = graph_level_step_figures(dev)
         if not args.no_traffic and world == 1:
             torch.cuda.synchronize()
             prefix = {"kagnn_aggregate_sum": "agg_rows", "kagnn_kan_linear_fwd": "kan_sparse_fwd",
