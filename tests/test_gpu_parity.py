@@ -899,6 +899,9 @@ def test_library_calls_follow_the_current_stream():
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                    # (once untimed: the caching allocator keeps a pool per stream, and the hipMalloc
+        run()                                        # calls that fill a new pool synchronise the whole device -- not our launches)
+    side.synchronize()
     ops.clear_graph_cache()
     busy = torch.cuda.Event()
     torch.cuda._sleep(2_000_000_000)                 # ~1 s of the DEFAULT stream
