@@ -543,6 +543,52 @@ int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy
                       size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Feature-sharded FastKAN layer (no counterpart in the reference, which is single-device: this is
+ * FastKANLayer.forward, fastkan.py:76-85, when a rank holds `in_features` of the row's P * in_features input columns and the
+ * matching slices of layernorm.weight / .bias, spline_linear.weight[:, columns * num_grids], base_linear.weight[:, columns]).
+ * LayerNorm (fastkan.py:77-78) is the one operation of the layer that reduces over the sharded axis; the exchange is
+ * 2 floats per row each way:
+ *   forward : kagnn_fastkan_row_moments  -> moments[n] = (mean, sum of squared deviations from it) over the local columns;
+ *             the caller gathers the P arrays ([P][N][2], rank order);  kagnn_fastkan_merge_moments merges a row's P pairs
+ *             in rank order (Chan's update: no cancellation, same bits on every rank) -> row_stats[n] = (mean, rstd) over all
+ *             P * in_features columns;  kagnn_fastkan_shard_fwd = kagnn_fastkan_fwd with row_stats GIVEN: y = this rank's
+ *             partial sums over its columns for ALL outputs (base_bias on one rank only); the caller reduce-scatters them.
+ *   backward: kagnn_fastkan_shard_bwd (gy = the gathered [N, out] gradient) = everything but the LayerNorm backward:
+ *             g_spline_weight / g_base_weight / g_base_bias (may be NULL) of the local slices, gx = the base-branch part,
+ *             d loss / dz kept in `workspace`, row_sums[n] = (sum_f gz*gamma, sum_f gz*gamma*zhat) over the local columns;
+ *             the caller sums row_sums over the ranks (all-reduce);  kagnn_fastkan_shard_bwd_finish completes gx and writes
+ *             g_ln_weight / g_ln_bias -- SAME shape arguments and SAME workspace (kagnn_fastkan_bwd_workspace_bytes), not
+ *             touched between the two calls.  Without layernorm (ln_weight NULL) shard_bwd alone is the whole backward.
+ * ------------------------------------------------------------------------------------------ */
+int kagnn_fastkan_row_moments(const float* x, int64_t ldx, int64_t num_rows, int32_t in_features,
+                              float* moments /* [N,2] */, void* stream);
+int kagnn_fastkan_merge_moments(const float* gathered /* [P][N][2] */, int32_t num_ranks, int64_t num_rows,
+                                int32_t in_features /* per rank */, float ln_eps, float* row_stats /* [N,2] */,
+                                void* stream);
+int kagnn_fastkan_shard_fwd(const float* x, int64_t ldx, int64_t num_rows, int32_t in_features,
+                            int32_t out_features, int32_t num_grids, const float* centers,
+                            float denominator, const float* ln_weight, const float* ln_bias,
+                            const float* row_stats, const float* spline_weight, const float* base_weight,
+                            const float* base_bias, float* y, int64_t ldy, int32_t precision,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int kagnn_fastkan_shard_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy,
+                            int64_t num_rows, int32_t in_features, int32_t out_features,
+                            int32_t num_grids, const float* centers, float denominator,
+                            const float* ln_weight, const float* ln_bias, const float* spline_weight,
+                            const float* base_weight, const float* row_stats, float* gx, int64_t ldgx,
+                            float* row_sums /* [N,2] */, float* g_spline_weight, float* g_base_weight,
+                            float* g_base_bias,
+                            int32_t parts /* 1 = input-gradient half (gx, dz, row_sums), 2 = weight-gradient half, 3 = both:
+                                             two calls (1 then 2) let the all-reduce of row_sums run beside the weight gradient */,
+                            int32_t precision, void* workspace, size_t workspace_bytes, void* stream);
+int kagnn_fastkan_shard_bwd_finish(const float* x, int64_t ldx, int64_t num_rows, int32_t in_features,
+                                   int32_t in_features_total, int32_t out_features, int32_t num_grids,
+                                   const float* ln_weight, const float* ln_bias, const float* row_stats,
+                                   const float* row_sums, float* gx, int64_t ldgx, float* g_ln_weight,
+                                   float* g_ln_bias, int32_t precision, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * BatchNorm1d over node rows (the epilogue after every convolution of the node / graph models:
  * node_classification_clean/models.py:195-202, torch.nn.BatchNorm1d semantics).  x, y, gy, gx are
  * [num_rows, num_features] row-major with leading dimensions in elements; statistics per column.

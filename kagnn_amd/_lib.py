@@ -127,6 +127,15 @@ _SIGNATURES = {
     "kagnn_fastkan_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, _P,
                                     c_float, _P, _P, c_float, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
                                     _P, c_int32, _P, c_size_t, _P]),
+    "kagnn_fastkan_row_moments": (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P]),
+    "kagnn_fastkan_merge_moments": (c_int32, [_P, c_int32, c_int64, c_int32, c_float, _P, _P]),
+    "kagnn_fastkan_shard_fwd": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, c_int32, _P, c_float, _P, _P,
+                                          _P, _P, _P, _P, _P, c_int64, c_int32, _P, c_size_t, _P]),
+    "kagnn_fastkan_shard_bwd": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, _P,
+                                          c_float, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P,
+                                          _P, c_int32, c_int32, _P, c_size_t, _P]),
+    "kagnn_fastkan_shard_bwd_finish": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P,
+                                                 _P, _P, c_int64, _P, _P, c_int32, _P, c_size_t, _P]),
     "kagnn_gat_att_grad_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, POINTER(c_size_t)]),
     "kagnn_gat_att_grad": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "kagnn_softmax_xent_workspace_bytes": (c_int32, [c_int64, POINTER(c_size_t)]),

@@ -79,10 +79,12 @@ int kan_split_dx_stats(const float*, long, const float*, long, long, const float
                        const float*, const float*, const float*, float*);
 bool kan_split_dw_ok(int in, int out, int G, int K);
 
-int fastkan_fwd(const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, void*, size_t, int, hipStream_t);
+int fastkan_fwd(const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, void*, size_t, int, hipStream_t, bool stats_given = false);
+int fastkan_row_moments(const float*, long, long, int, float*, hipStream_t);
+int fastkan_merge_moments(const float*, int, long, int, float, float*, hipStream_t);
 size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng, int mode);
 size_t fastkan_bwd_ws_bytes(long N, int in, int out, int ng, int mode);
-int fastkan_bwd(const float*, long, const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, float*, float*, float*, float*, void*, size_t, int, hipStream_t);
+int fastkan_bwd(const float*, long, const float*, long, long, int, int, int, const float*, float, const float*, const float*, float, const float*, const float*, const float*, float*, long, float*, float*, float*, float*, float*, void*, size_t, int, hipStream_t, int phase = 0, float* row_sums = nullptr, int in_total = 0);
 int gat_logits(const float*, long, long, int, int, const float*, const float*, float*, float*, hipStream_t);
 int gat_fwd(const float*, long, const float*, const float*, const int*, const int*, long, int, int, const float*, float*, long, float*, float*, const int*, long, int, hipStream_t);
 int gat_bwd(const float*, long, const float*, long, const float*, long, const float*, const float*, const float*, const float*, const float*, const int*, const int*, const int*, const int*, const int*, const int*, const float*, const float*, long, int, int, float*, float*, float*, float*, float*, long, const int*, long, int, hipStream_t);
@@ -197,7 +199,7 @@ static bool use_split_dw(int in, int out, int G, int K, int mode) { return mode 
 #pragma GCC visibility push(default)
 extern "C" {
 
-int kagnn_version(void) { return 252; }
+int kagnn_version(void) { return 260; }
 const char* kagnn_last_error(void) { return g_err; }
 
 int kagnn_stage_timer_enable(const char* only) {
@@ -769,6 +771,83 @@ int kagnn_fastkan_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy
     return fastkan_bwd(x, ldx, gy, ldgy, N, in, out, ng, centers, denominator, ln_w, ln_b, ln_eps, spline_w,
                        base_w, row_stats, gx, ldgx, g_ln_w, g_ln_b, g_spline_w, g_base_w, g_base_b, ws,
                        ws_bytes, mode, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- feature-sharded FastKAN layer
+int kagnn_fastkan_row_moments(const float* x, int64_t ldx, int64_t N, int32_t in, float* moments, void* stream) {
+    KAGNN_STAGE(stream);
+    KAGNN_CHECK_ARG(N >= 0 && in >= 1 && ldx >= in, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (x && moments), "null array");
+    return fastkan_row_moments(x, ldx, N, in, moments, as_stream(stream));
+}
+
+int kagnn_fastkan_merge_moments(const float* gathered, int32_t P, int64_t N, int32_t in, float ln_eps, float* row_stats,
+                                void* stream) {
+    KAGNN_STAGE(stream);
+    KAGNN_CHECK_ARG(N >= 0 && in >= 1 && P >= 1, "bad shape");
+    KAGNN_CHECK_ARG(N == 0 || (gathered && row_stats), "null array");
+    return fastkan_merge_moments(gathered, P, N, in, ln_eps, row_stats, as_stream(stream));
+}
+
+int kagnn_fastkan_shard_fwd(const float* x, int64_t ldx, int64_t N, int32_t in, int32_t out, int32_t ng,
+                            const float* centers, float denominator, const float* ln_w, const float* ln_b,
+                            const float* row_stats, const float* spline_w, const float* base_w, const float* base_b,
+                            float* y, int64_t ldy, int32_t mode, void* ws, size_t ws_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
+    KAGNN_STAGE(stream);
+    int rc = check_fk(__func__, in, out, ng, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldy >= out, "bad shape");
+    if (N == 0) return KAGNN_OK;
+    KAGNN_CHECK_ARG(x && centers && spline_w && y && ws, "null array");
+    KAGNN_CHECK_ARG(denominator != 0.0f, "denominator is zero");
+    KAGNN_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "layernorm weight and bias must both be given or both be null");
+    KAGNN_CHECK_ARG(ln_w == nullptr || row_stats, "layernorm on a column shard needs the merged row statistics");
+    if (mode == KAGNN_PREC_SPLIT && !(fits32(N, ldx) && fits32(N, ldy)))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
+    return fastkan_fwd(x, ldx, N, in, out, ng, centers, denominator, ln_w, ln_b, 0.0f, spline_w, base_w, base_b, y, ldy,
+                       const_cast<float*>(row_stats), ws, ws_bytes, mode, as_stream(stream), ln_w != nullptr);
+}
+
+int kagnn_fastkan_shard_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy, int64_t N, int32_t in,
+                            int32_t out, int32_t ng, const float* centers, float denominator,
+                            const float* ln_w, const float* ln_b, const float* spline_w,
+                            const float* base_w, const float* row_stats, float* gx, int64_t ldgx,
+                            float* row_sums, float* g_spline_w, float* g_base_w,
+                            float* g_base_b, int32_t parts, int32_t mode, void* ws, size_t ws_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
+    KAGNN_STAGE(stream);
+    int rc = check_fk(__func__, in, out, ng, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgy >= out && ldgx >= in, "bad shape");
+    KAGNN_CHECK_ARG(parts >= 1 && parts <= 3, "parts: 1 = input-gradient half, 2 = weight-gradient half, 3 = both");
+    KAGNN_CHECK_ARG(centers && spline_w && ws, "null array");
+    KAGNN_CHECK_ARG(N == 0 || (x && gy), "null array");
+    KAGNN_CHECK_ARG(!(parts & 1) || N == 0 || gx, "null array");
+    KAGNN_CHECK_ARG(!(parts & 1) || ln_w == nullptr || (ln_b && row_stats && (N == 0 || row_sums)), "layernorm needs bias, row_stats and row_sums");
+    KAGNN_CHECK_ARG(!(parts & 2) || (g_spline_w && (base_w == nullptr || g_base_w)), "the weight-gradient half needs its outputs");
+    KAGNN_CHECK_ARG(ln_w == nullptr || (ln_b && row_stats), "layernorm needs bias and row_stats");
+    if (mode == KAGNN_PREC_SPLIT && !(fits32(N, ldx) && fits32(N, ldgy) && fits32(N, ldgx)))
+        return fail(KAGNN_ERR_UNSUPPORTED, "%s: leading dimension > 7680 floats; call with KAGNN_PREC_FP32", __func__);
+    return fastkan_bwd(x, ldx, gy, ldgy, N, in, out, ng, centers, denominator, ln_w, ln_b, 0.0f, spline_w,
+                       base_w, row_stats, gx, ldgx, nullptr, nullptr, g_spline_w, g_base_w, g_base_b, ws,
+                       ws_bytes, mode, as_stream(stream), parts == 3 ? 1 : parts == 1 ? 3 : 4, row_sums, 0);
+}
+
+int kagnn_fastkan_shard_bwd_finish(const float* x, int64_t ldx, int64_t N, int32_t in, int32_t in_total, int32_t out,
+                                   int32_t ng, const float* ln_w, const float* ln_b, const float* row_stats,
+                                   const float* row_sums, float* gx, int64_t ldgx, float* g_ln_w, float* g_ln_b,
+                                   int32_t mode, void* ws, size_t ws_bytes, void* stream) {
+    ModeScope mode_scope_(mode);
+    KAGNN_STAGE(stream);
+    int rc = check_fk(__func__, in, out, ng, mode);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(N >= 0 && ldx >= in && ldgx >= in && in_total >= in, "bad shape");
+    KAGNN_CHECK_ARG(ln_w && ln_b && g_ln_w && g_ln_b && ws, "null array");
+    KAGNN_CHECK_ARG(N == 0 || (x && gx && row_stats && row_sums), "null array");
+    return fastkan_bwd(x, ldx, nullptr, out, N, in, out, ng, nullptr, 1.0f, ln_w, ln_b, 0.0f, nullptr,
+                       nullptr, row_stats, gx, ldgx, g_ln_w, g_ln_b, nullptr, nullptr, nullptr, ws,
+                       ws_bytes, mode, as_stream(stream), 2, const_cast<float*>(row_sums), in_total);
 }
 
 // ---------------------------------------------------------------- BatchNorm1d

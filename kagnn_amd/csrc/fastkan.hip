@@ -32,6 +32,11 @@ void dw_plan(long N, int in, int out, int* NBx, long* rpw);
 
 struct LnArgs {
     const float* w; const float* b; float eps;   // w == nullptr: no layernorm
+    const float* stats_in = nullptr;             // forward (exact-fp32 kernel): row statistics GIVEN by the caller (feature-sharded
+                                                 // layer: they cover all ranks' columns) instead of taken from the rows loaded here
+    // LayerNorm backward, feature-sharded layer: the two row sums  sum_f gz*gamma,  sum_f gz*gamma*zhat  over ALL ranks' columns
+    // (already summed over the ranks) and 1 / (total column count); nullptr: the kernel's own sums over its `in` columns
+    const float* row_sums = nullptr; float inv_total = 0.0f;
 };
 
 __device__ __forceinline__ float rbf_val(float z, float c, float inv_den) {
@@ -110,6 +115,81 @@ static int launch_stats(const float* x, long ldx, long N, int in, float eps, flo
     return KAGNN_OK;
 }
 
+// ------------------------------------------------------------------ feature-sharded layer: the LayerNorm exchange
+// a rank holds `in` of the row's `P * in` columns; "LayerNorm statistics -> all-reduce of 2 floats / row".
+// Each rank leaves (mean, M2 = sum of squared deviations from ITS mean) of its columns -- two-pass, like torch's LayerNorm and
+// the kernels above --, the P pairs of a row are gathered and merged in RANK ORDER by Chan's update.  (Summing (sum x, sum x^2)
+// over the ranks instead would lose the variance's digits whenever |mean| >> std, and its bits would depend on the collective's
+// reduction order; the gathered form moves the same 2 floats per row and rank.)  16 lanes per row.
+__global__ __launch_bounds__(256) void fastkan_row_moments_kernel(const float* __restrict__ x, long ldx, long N, int in,
+                                                                  float* __restrict__ moments) {
+    const long row = (blockIdx.x * 256L + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    const float* xr = x + min(row, N - 1) * ldx;
+    float s = 0.0f;
+    for (int f = l; f < in; f += 16) s += xr[f];
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)in;
+    float v = 0.0f;
+    for (int f = l; f < in; f += 16) { const float d = xr[f] - mean; v = fmaf(d, d, v); }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (l == 0 && row < N) { moments[2 * row] = mean; moments[2 * row + 1] = v; }
+}
+
+// gathered[p][n] = (mean_p, M2_p) over `in` columns each -> stats[n] = (mean, 1 / sqrt(M2 / (P * in) + eps)); one thread per row
+__global__ __launch_bounds__(256) void fastkan_merge_moments_kernel(const float* __restrict__ gathered, int P, long N, int in,
+                                                                    float eps, float* __restrict__ stats) {
+    const long row = blockIdx.x * 256L + threadIdx.x;
+    if (row >= N) return;
+    float mean = gathered[2 * row], m2 = gathered[2 * row + 1];
+    const float nb = (float)in;
+    for (int p = 1; p < P; ++p) {
+        const float mb = gathered[((long)p * N + row) * 2], qb = gathered[((long)p * N + row) * 2 + 1];
+        const float na = nb * (float)p, n = na + nb, d = mb - mean;
+        mean = fmaf(d, nb / n, mean);
+        m2 = m2 + qb + d * d * (na * nb / n);
+    }
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rsqrtf(m2 / (nb * (float)P) + eps);
+}
+
+// the two row sums of the LayerNorm backward over this rank's columns:  sums[n] = (sum_f gz*gamma, sum_f gz*gamma*zhat),
+// zhat = (x - mean) * rstd with the MERGED statistics; summed over the ranks by the caller (all-reduce of 2 floats / row),
+// then fastkan_ln_bwd_kernel finishes with them (LnArgs::row_sums).  16 lanes per row, fixed order.
+__global__ __launch_bounds__(256) void fastkan_ln_row_sums_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gz,
+                                                                  long N, int in, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ stats, float* __restrict__ sums) {
+    const long row = (blockIdx.x * 256L + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    const long rc = min(row, N - 1);
+    const float mean = stats[2 * rc], rstd = stats[2 * rc + 1];
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int f = l; f < in; f += 16) {
+        const float h = gz[rc * (long)in + f] * gamma[f];
+        s1 += h;
+        s2 = fmaf(h, (x[rc * ldx + f] - mean) * rstd, s2);
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (l == 0 && row < N) { sums[2 * row] = s1; sums[2 * row + 1] = s2; }
+}
+
+int fastkan_row_moments(const float* x, long ldx, long N, int in, float* moments, hipStream_t st) {
+    if (N == 0) return KAGNN_OK;
+    fastkan_row_moments_kernel<<<cdiv(N, 16), 256, 0, st>>>(x, ldx, N, in, moments);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
+int fastkan_merge_moments(const float* gathered, int P, long N, int in, float eps, float* stats, hipStream_t st) {
+    if (N == 0) return KAGNN_OK;
+    fastkan_merge_moments_kernel<<<cdiv(N, 256), 256, 0, st>>>(gathered, P, N, in, eps, stats);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 static bool fk_stats_in_fwd() {                       // KAGNN_FASTKAN_STATS_IN_FWD=0: the separate statistics pass (A/B)
     static const bool on = [] { const char* e = getenv("KAGNN_FASTKAN_STATS_IN_FWD"); return e == nullptr || atoi(e) != 0; }();
     return on;
@@ -147,7 +227,10 @@ __global__ __launch_bounds__(256) void fastkan_fwd_kernel(
     const float* xr = x + (rv ? row : 0) * ldx;
 
     float mean = 0.0f, rstd = 1.0f;
-    if (ln.w) {                                   // two-pass mean / biased variance, eps inside the sqrt
+    if (ln.w && ln.stats_in) {                    // (wave-uniform) the caller's statistics: the row is a column shard of a wider one
+        const long rc = rv ? row : 0;
+        mean = ln.stats_in[2 * rc]; rstd = ln.stats_in[2 * rc + 1];
+    } else if (ln.w) {                            // two-pass mean / biased variance, eps inside the sqrt
         float s = 0.0f;
         for (int p = 0; p < P; ++p) {               // unconditional clamped loads, masked by a 0/1 factor
             const int f = p + kh * P;
@@ -341,7 +424,8 @@ __global__ __launch_bounds__(256) void fastkan_ln_bwd_kernel(
         for (int r = 0; r < R; ++r) {
             if (row0 + r >= N) break;
             const long row = row0 + r;
-            const float m1 = s1[r] * inv_n, m2 = s2[r] * inv_n;
+            const float m1 = ln.row_sums ? ln.row_sums[2 * row] * ln.inv_total : s1[r] * inv_n;
+            const float m2 = ln.row_sums ? ln.row_sums[2 * row + 1] * ln.inv_total : s2[r] * inv_n;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int f = lane + 64 * t;
@@ -424,7 +508,8 @@ __global__ __launch_bounds__(256) void fastkan_ln_bwd_v4_kernel(
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+        const float m1 = ln.row_sums ? ln.row_sums[2 * row] * ln.inv_total : s1 * inv_n;
+        const float m2 = ln.row_sums ? ln.row_sums[2 * row + 1] * ln.inv_total : s2 * inv_n;
 #pragma unroll
         for (int t = 0; t < T4; ++t) {
             const int c4 = lane + 64 * t;
@@ -650,15 +735,16 @@ size_t fastkan_fwd_ws_bytes(long N, int in, int out, int ng, int mode) {
 int fastkan_fwd(const float* x, long ldx, long N, int in, int out, int ng, const float* centers,
                 float den, const float* lnw, const float* lnb, float eps, const float* sw,
                 const float* bw, const float* bb, float* y, long ldy, float* stats, void* ws,
-                size_t ws_bytes, int mode, hipStream_t st) {
+                size_t ws_bytes, int mode, hipStream_t st, bool stats_given) {
+    // stats_given: `stats` is an INPUT -- the row statistics over all ranks' columns of the feature-sharded layer
     if (ws_bytes < fastkan_fwd_ws_bytes(N, in, out, ng, mode)) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "fastkan_fwd");
     if (lnw && !stats) return fail(KAGNN_ERR_ARG, "%s: row_stats is required with layernorm", "fastkan_fwd");
     if (fk_split(in, out, ng, mode)) {
         // one-chunk layers (<= 8 centres, in <= 64 with <= 64 outputs / in <= 32 with <= 128, one output block): the forward
         // kernel takes the row statistics from the rows it loads and stores them; anything else runs the statistics pass first
         const int cf = cdiv(min(out, 128), 32) <= 2 ? 64 : 32;
-        const bool own_stats = lnw && ng <= 8 && in <= cf && out <= 128 && N > 0 && fk_stats_in_fwd();
-        if (lnw && !own_stats) { int rc = launch_stats(x, ldx, N, in, eps, stats, st); if (rc) return rc; }
+        const bool own_stats = lnw && !stats_given && ng <= 8 && in <= cf && out <= 128 && N > 0 && fk_stats_in_fwd();
+        if (lnw && !own_stats && !stats_given) { int rc = launch_stats(x, ldx, N, in, eps, stats, st); if (rc) return rc; }
         { int rc = kan_split_pack_fwd_noscale(bw, sw, nullptr, in, out, ng, ws, st); if (rc) return rc; }
         char* part = static_cast<char*>(ws) + al256(kan_split_pack_fwd_bytes(in, out, ng));
         RbfArgs rb = fk_rbf(centers, ng, den, lnw, lnb, stats, bb, nullptr);
@@ -670,6 +756,7 @@ int fastkan_fwd(const float* x, long ldx, long N, int in, int out, int ng, const
     float* pd = (float*)((char*)ws + al256(kan_f32_pack_fwd_bytes(in, out, ng)));
     { int rc = kan_f32_pack(bw, sw, nullptr, in, out, ng, pf, pd, st); if (rc) return rc; }
     LnArgs ln{lnw, lnb, eps};
+    if (stats_given) ln.stats_in = stats;
     const int OTt = cdiv(out, 32);
     dim3 grid(cdiv(N, 128));
     for (int ot0 = 0; ot0 < OTt; ot0 += 4) {
@@ -727,7 +814,14 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
                 const float* centers, float den, const float* lnw, const float* lnb, float eps,
                 const float* sw, const float* bw, const float* stats, float* gx, long ldgx,
                 float* g_lnw, float* g_lnb, float* g_sw, float* g_bw, float* g_bb, void* ws,
-                size_t ws_bytes, int mode, hipStream_t st) {
+                size_t ws_bytes, int mode, hipStream_t st, int phase, float* row_sums, int in_total) {
+    // phase 0: the whole backward.  Feature-sharded layer (the row is P column shards, `stats` covers all of them): phase 1 = all
+    // of it EXCEPT the LayerNorm backward -- d loss / dz stays in the workspace, gx holds the base-branch part, row_sums[n] receives
+    // the two row sums over this rank's columns; the caller sums them over the ranks; phase 2 (same shape arguments, same
+    // workspace, untouched in between) = the LayerNorm backward with those sums: gx completed, g_lnw / g_lnb written.
+    // phase 3 / 4: phase 1 in two halves -- 3 = the input-gradient half (gx, d loss / dz, row_sums), 4 = the weight-gradient half --
+    // so that the caller's all-reduce of row_sums can run beside the weight gradient.
+    const bool do_dx = phase != 4, do_dw = phase != 3, shard = phase == 1 || phase == 3 || phase == 4;
     const FkBwdPlan p = fk_plan(N, in, out, ng, mode);
     if (ws_bytes < p.total) return fail(KAGNN_ERR_ARG, "%s: workspace too small", "fastkan_bwd");
     if (lnw && in > 64 * kLnMaxT) return fail(KAGNN_ERR_UNSUPPORTED, "%s: layernorm backward supports input_dim <= 4096", "fastkan_bwd");
@@ -739,21 +833,34 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
     float* slab = (float*)q; q += p.slab;
     float* lnpart = (float*)q; q += p.lnpart;
     float* colpart = (float*)q;
+    if (phase == 2) {
+        if (!lnw) return KAGNN_OK;
+        LnArgs ln{lnw, lnb, eps};
+        ln.row_sums = row_sums; ln.inv_total = 1.0f / (float)in_total;
+        if (N > 0) { int rc = launch_ln_bwd(p.ln_blocks, x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart, st); if (rc) return rc; }
+        else KAGNN_HIP(hipMemsetAsync(lnpart, 0, (size_t)p.ln_blocks * 2 * in * sizeof(float), st));
+        sum_partials_kernel<<<cdiv(2L * in, 32), 32 * kSumGroups, 0, st>>>(lnpart, p.ln_blocks, 2L * in, 2L * in, g_lnw, g_lnb, in);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
     if (p.split) {
         // same split-precision kernels as the B-spline layer, K == 0 selecting the RBF basis
         const RbfArgs rb = fk_rbf(centers, ng, den, lnw, lnb, stats, nullptr, gz);
-        if (N > 0) {
+        if (N > 0 && do_dx) {
             int rc = kan_split_pack_dx_noscale(bw, sw, nullptr, in, out, ng, 0, pd, st);
             if (rc) return rc;
             rc = kan_split_dx_any(x, ldx, gy, ldgy, N, nullptr, in, out, ng, 0, pd, gx, ldgx, rb, st, 0);
             if (rc) return rc;
         }
-        if (lnw) {
+        if (lnw && shard) {
+            if (N > 0 && do_dx) { fastkan_ln_row_sums_kernel<<<cdiv(N, 16), 256, 0, st>>>(x, ldx, gz, N, in, lnw, stats, row_sums); KAGNN_LAUNCH_CHECK(); }
+        } else if (lnw) {
             LnArgs ln{lnw, lnb, eps};
             { int rc = launch_ln_bwd(p.ln_blocks, x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart, st); if (rc) return rc; }
             sum_partials_kernel<<<cdiv(2L * in, 32), 32 * kSumGroups, 0, st>>>(lnpart, p.ln_blocks, 2L * in, 2L * in, g_lnw, g_lnb, in);
             KAGNN_LAUNCH_CHECK();
         }
+        if (!do_dw) return KAGNN_OK;
         // the base bias gradient (column sums of gy) rides in the weight-gradient kernel, which reads gy anyway: one row of
         // sums per row slab, folded in slab order (deterministic).  (A pass of its own over gy cost 0.08 ms per layer at 1M x 64.)
         RbfArgs rbw = rb;
@@ -775,7 +882,7 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
     const float inv_den = 1.0f / den;
     LnArgs ln{lnw, lnb, eps};
     const int OTt = cdiv(out, 32), FT = cdiv(in, 32);
-    if (N > 0) {
+    if (N > 0 && do_dx) {
         int rc = kan_f32_pack(bw, sw, nullptr, in, out, ng, pf, pd, st);
         if (rc) return rc;
         int W = 4;                                    // waves per workgroup: as many as the gy tiles leave LDS for
@@ -787,11 +894,14 @@ int fastkan_bwd(const float* x, long ldx, const float* gy, long ldgy, long N, in
         fastkan_dx_kernel<<<cdiv(N, 32 * W), 64 * W, lds, st>>>(x, ldx, gy, ldgy, N, in, out, ng, centers, inv_den, ln, stats, pd, OTt, gx, ldgx, gz);
         KAGNN_LAUNCH_CHECK();
     }
-    if (lnw) {
+    if (lnw && shard) {
+        if (N > 0 && do_dx) { fastkan_ln_row_sums_kernel<<<cdiv(N, 16), 256, 0, st>>>(x, ldx, gz, N, in, lnw, stats, row_sums); KAGNN_LAUNCH_CHECK(); }
+    } else if (lnw) {
         { int rc = launch_ln_bwd(p.ln_blocks, x, ldx, gz, N, in, ln, stats, gx, ldgx, lnpart, st); if (rc) return rc; }
         sum_partials_kernel<<<cdiv(2L * in, 32), 32 * kSumGroups, 0, st>>>(lnpart, p.ln_blocks, 2L * in, 2L * in, g_lnw, g_lnb, in);
         KAGNN_LAUNCH_CHECK();
     }
+    if (!do_dw) return KAGNN_OK;
     dim3 grid(p.nb, FT * OTt);
     fastkan_dw_kernel<<<grid, 256, 0, st>>>(x, ldx, gy, ldgy, N, in, out, ng, centers, inv_den, ln, stats, OTt, p.rpw, slab);
     KAGNN_LAUNCH_CHECK();

@@ -1573,6 +1573,130 @@ class _FastKANFn(Function):
         return gx, glw, glb, gsw, gbw, (gbb if has_bb else None), None, None, None, None
 
 
+# ------------------------------------------------------------------------ feature-sharded FastKAN layer (SURVEY.md 8(e))
+# The local-compute half of kagnn_amd.sharded.ShardedFastKANLayer: a rank holds `w` of the row's P*w input columns.  LayerNorm
+# (fastkan.py:77-78) is the only reduction over the sharded axis -- 2 floats per row each way; the collectives themselves are the
+# caller's (torch.distributed), these are the library calls around them (include/kagnn_hip.h: kagnn_fastkan_row_moments ...).
+def fastkan_row_moments(x: torch.Tensor) -> torch.Tensor:
+    """[N, 2] = (mean, sum of squared deviations from it) of every row over the LOCAL columns"""
+    _need_cuda(x)
+    x = _rows(x)
+    mom = torch.empty((x.size(0), 2), dtype=torch.float32, device=x.device)
+    with _device_of(x):
+        _call("kagnn_fastkan_row_moments", _ptr(x), _ld(x), x.size(0), x.size(1), _ptr(mom), _stream())
+    return mom
+
+
+def fastkan_merge_moments(gathered: torch.Tensor, width: int, ln_eps: float) -> torch.Tensor:
+    """``gathered`` [P, N, 2]: every rank's ``fastkan_row_moments`` (``width`` columns each), merged per row in rank order ->
+    [N, 2] = (mean, 1 / sqrt(biased variance + eps)) over all P * width columns: torch.nn.LayerNorm's statistics"""
+    _need_cuda(gathered)
+    gathered = gathered.contiguous()
+    p, n = gathered.size(0), gathered.size(1)
+    stats = torch.empty((n, 2), dtype=torch.float32, device=gathered.device)
+    with _device_of(gathered):
+        _call("kagnn_fastkan_merge_moments", _ptr(gathered), p, n, int(width), float(ln_eps), _ptr(stats), _stream())
+    return stats
+
+
+def _fastkan_shard_mode(x, spline_w, ng, mode):
+    if mode is None:
+        mode = default_precision()
+    if split_like(mode) and (ng > 16 or not _fits32(x, spline_w.size(0))):
+        mode = PREC_FP32                    # (more than 16 centres / very wide rows: the exact-fp32 kernels)
+    return int(mode)
+
+
+def fastkan_shard_fwd(x, stats, ln_w, ln_b, spline_w, base_w, base_b, centers, denominator: float, mode=None, out=None):
+    """this rank's partial sums ``[N, out]`` of FastKANLayer.forward over its input columns, LayerNorm on the MERGED row
+    statistics ``stats`` (``None`` with ``ln_w is None``); ``base_b``: on one rank only"""
+    _need_cuda(x, spline_w, centers)
+    x = _rows(x)
+    n, fin = x.shape
+    fout, ng = spline_w.size(0), centers.numel()
+    if spline_w.size(1) != fin * ng:
+        raise AssertionError("spline_linear.weight slice must be [out, in_local*num_grids]")
+    mode = _fastkan_shard_mode(x, spline_w, ng, mode)
+    sw = spline_w.contiguous()
+    lw, lb = (None, None) if ln_w is None else (ln_w.contiguous(), ln_b.contiguous())
+    bw = None if base_w is None else base_w.contiguous()
+    bb = None if base_b is None else base_b.contiguous()
+    ws = _ws(_sizes("kagnn_fastkan_fwd_workspace_bytes", n, fin, fout, ng, mode), x.device)
+    y = torch.empty((n, fout), dtype=torch.float32, device=x.device) if out is None else out
+    with _device_of(x):
+        _call("kagnn_fastkan_shard_fwd", _ptr(x), _ld(x), n, fin, fout, ng, _ptr(centers), float(denominator), _ptr(lw), _ptr(lb),
+              _ptr(stats), _ptr(sw), _ptr(bw), _ptr(bb), _ptr(y), _ld(y), mode, _ptr(ws), ws.numel(), _stream())
+    return y
+
+
+class FastKANShardBackward:
+    """the state between ``fastkan_shard_bwd`` and ``fastkan_shard_bwd_finish``: the library workspace holding d loss / dz, the
+    partially written input gradient, and the shape the second call has to repeat"""
+    __slots__ = ("x", "stats", "lw", "lb", "gx", "ws", "dims", "mode", "wgrads")
+
+
+def fastkan_shard_bwd(x, gy, stats, ln_w, ln_b, spline_w, base_w, centers, denominator: float, mode=None, want_bias=False):
+    """everything of the layer's backward but the LayerNorm backward, from the gathered gradient ``gy`` [N, out]:
+    ``(state, row_sums [N, 2] or None, g_spline_weight, g_base_weight, g_base_bias)``.  ``row_sums`` = (sum_f gz*gamma,
+    sum_f gz*gamma*zhat) over the local columns: to be summed over the ranks, then ``fastkan_shard_bwd_finish``."""
+    st, sums = fastkan_shard_bwd_halves(x, gy, stats, ln_w, ln_b, spline_w, base_w, centers, denominator, mode, part="both",
+                                        want_bias=want_bias)
+    return (st, sums) + st.wgrads
+
+
+def fastkan_shard_bwd_halves(x, gy, stats, ln_w, ln_b, spline_w, base_w, centers, denominator: float, mode=None, part="input",
+                             state=None, want_bias=False):
+    """``kagnn_fastkan_shard_bwd`` in its two halves: ``part="input"`` -> ``(state, row_sums)`` (gx's base-branch part and
+    d loss / dz are in ``state``); ``part="weight", state=...`` -> ``(g_spline_weight, g_base_weight, g_base_bias)`` -- the
+    caller's all-reduce of ``row_sums`` runs between / beside them.  ``part="both"``: one call, ``state.wgrads`` holds the three."""
+    _need_cuda(x, gy, spline_w, centers)
+    x, gy = _rows(x), _rows(gy)
+    n, fin = x.shape
+    fout, ng = spline_w.size(0), centers.numel()
+    mode = _fastkan_shard_mode(x, spline_w, ng, mode)
+    dev = x.device
+    sw = spline_w.contiguous()
+    lw, lb = (None, None) if ln_w is None else (ln_w.contiguous(), ln_b.contiguous())
+    bw = None if base_w is None else base_w.contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    st = state
+    if st is None:
+        st = FastKANShardBackward()
+        st.x, st.stats, st.lw, st.lb, st.mode, st.dims = x, stats, lw, lb, mode, (n, fin, fout, ng)
+        st.ws = _ws(_sizes("kagnn_fastkan_bwd_workspace_bytes", n, fin, fout, ng, mode), dev)
+        st.gx = torch.empty((n, fin), **f32)
+        st.wgrads = None
+    parts = {"input": 1, "weight": 2, "both": 3}[part]
+    sums = gsw = gbw = gbb = None
+    if parts & 1:
+        sums = torch.empty((n, 2), **f32) if lw is not None else None
+    if parts & 2:
+        gsw = torch.empty((fout, fin * ng), **f32)
+        gbw = torch.empty((fout, fin), **f32) if bw is not None else None
+        gbb = torch.empty(fout, **f32) if (want_bias and bw is not None) else None
+    with _device_of(x):
+        _call("kagnn_fastkan_shard_bwd", _ptr(x), _ld(x), _ptr(gy), _ld(gy), n, fin, fout, ng, _ptr(centers), float(denominator),
+              _ptr(lw), _ptr(lb), _ptr(sw), _ptr(bw), _ptr(stats), _ptr(st.gx), fin, _ptr(sums), _ptr(gsw), _ptr(gbw), _ptr(gbb),
+              parts, mode, _ptr(st.ws), st.ws.numel(), _stream())
+    if parts == 2:
+        return gsw, gbw, gbb
+    st.wgrads = (gsw, gbw, gbb)
+    return st, sums
+
+
+def fastkan_shard_bwd_finish(st: FastKANShardBackward, row_sums: Optional[torch.Tensor], width_total: int):
+    """-> ``(gx, g_ln_weight, g_ln_bias)`` with ``row_sums`` summed over the ranks (``None``: the layer has no LayerNorm)"""
+    if st.lw is None:
+        return st.gx, None, None
+    n, fin, fout, ng = st.dims
+    glw = torch.empty(fin, dtype=torch.float32, device=st.gx.device)
+    glb = torch.empty_like(glw)
+    with _device_of(st.gx):
+        _call("kagnn_fastkan_shard_bwd_finish", _ptr(st.x), _ld(st.x), n, fin, int(width_total), fout, ng, _ptr(st.lw), _ptr(st.lb),
+              _ptr(st.stats), _ptr(row_sums), _ptr(st.gx), fin, _ptr(glw), _ptr(glb), st.mode, _ptr(st.ws), st.ws.numel(), _stream())
+    return st.gx, glw, glb
+
+
 # ======================================================================== harness loss
 class _SoftmaxXentFn(Function):
     @staticmethod

@@ -243,22 +243,32 @@ def _chunk_bounds(n: int, chunks: int):
 
 
 class ShardedKANLinear(nn.Module):
-    """Input-feature slice ``[lo, hi)`` of a KANLinear: ``forward`` returns this rank's partial
-    sums over its features for ALL outputs."""
+    """Input-feature slice of a KANLinear: ``forward`` returns this rank's partial sums over its features for ALL outputs.
+    ``columns`` (a LongTensor; default: the contiguous block ``[rank*w, (rank+1)*w)``) names the input features this rank
+    holds -- the skip read-out of a sharded node model owns one block of every part of ``[x | h1 | ... | hL]``.
+    ``scatter_out=False``: the partial sums are closed by an all-reduce instead of a reduce-scatter, so ``out_features`` need
+    not be divisible by the world size (40 classes over 8 ranks)."""
 
-    def __init__(self, full: KANLinear, rank: int, world: int):
+    def __init__(self, full: KANLinear, rank: int, world: int, columns: Optional[torch.Tensor] = None, scatter_out: bool = True):
         super().__init__()
-        if full.in_features % world or full.out_features % world:
+        if columns is None and full.in_features % world:
+            raise ValueError("in_features and out_features must be divisible by the world size")
+        if scatter_out and full.out_features % world:
             raise ValueError("in_features and out_features must be divisible by the world size")
         self.grid_size, self.spline_order = full.grid_size, full.spline_order
         self.out_features = full.out_features
-        w = full.in_features // world
-        self.lo, self.hi = rank * w, (rank + 1) * w
-        ow = full.out_features // world
-        self.out_lo, self.out_hi = rank * ow, (rank + 1) * ow
-        self.base_weight = nn.Parameter(full.base_weight.detach()[:, self.lo:self.hi].clone())
-        self.spline_weight = nn.Parameter(full.spline_weight.detach()[:, self.lo:self.hi].clone())
-        self.spline_scaler = (nn.Parameter(full.spline_scaler.detach()[:, self.lo:self.hi].clone())
+        if columns is None:
+            w = full.in_features // world
+            self.lo, self.hi = rank * w, (rank + 1) * w
+            columns = torch.arange(self.lo, self.hi)
+        columns = columns.to(full.base_weight.device)
+        self.register_buffer("columns", columns.clone(), persistent=False)
+        if scatter_out:
+            ow = full.out_features // world
+            self.out_lo, self.out_hi = rank * ow, (rank + 1) * ow
+        self.base_weight = nn.Parameter(full.base_weight.detach()[:, columns].clone())
+        self.spline_weight = nn.Parameter(full.spline_weight.detach()[:, columns].clone())
+        self.spline_scaler = (nn.Parameter(full.spline_scaler.detach()[:, columns].clone())
                               if full.enable_standalone_scale_spline else None)
         self.register_buffer("knots", full.grid[0].detach().clone())
         self.precision = full.precision
@@ -373,6 +383,242 @@ class ShardedGIKANLayer(nn.Module):
                      for i, (r0, r1) in enumerate(bounds)]
             h = _Finish.apply(comm, bounds, *parts)
         return h
+
+
+# ----------------------------------------------------------------------------------------------------------
+# feature-sharded FastKAN ("LayerNorm statistics -> all-reduce of 2 floats/row")
+class _ShardedFastKANFn(Function):
+    """rows [r0, r1) of one feature-sharded FastKANLayer (reference ``fastkan.py:76-85`` on a column shard): forward = this rank's
+    partial sums over its input columns, LayerNorm on the row statistics of ALL ranks' columns (``stats``: merged by the layer
+    before the row chunks start).  Backward, from the gathered gradient rows: the input-gradient half leaves d loss / dz and the
+    two row sums of the LayerNorm backward over the local columns; their all-reduce (2 floats per row) runs on the layer's side
+    stream BESIDE the weight-gradient half; the finish completes gx and the LayerNorm parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, stats, ln_w, ln_b, spline_w, base_w, base_b, layer):
+        ops = layer.local_ops
+        y = ops.fastkan_shard_fwd(x.detach(), stats, ln_w, ln_b, spline_w, base_w, base_b, layer.centers, layer.denominator, layer.precision)
+        ctx.save_for_backward(x, stats, ln_w, ln_b, spline_w, base_w)
+        ctx.layer, ctx.has_bias = layer, base_b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, ln_w, ln_b, spline_w, base_w = ctx.saved_tensors
+        layer = ctx.layer
+        ops, group = layer.local_ops, layer.group
+        gy = gy.contiguous()
+        halves = getattr(ops, "fastkan_shard_bwd_halves", None)
+        if halves is not None and ln_w is not None and x.is_cuda:
+            # input-gradient half -> all-reduce of the row sums on the side stream || weight-gradient half -> finish
+            st, sums = halves(x, gy, stats, ln_w, ln_b, spline_w, base_w, layer.centers, layer.denominator, layer.precision, part="input")
+            work = layer.comm.launch(lambda: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group, async_op=True), sums)
+            gsw, gbw, gbb = halves(x, gy, stats, ln_w, ln_b, spline_w, base_w, layer.centers, layer.denominator, layer.precision,
+                                   part="weight", state=st, want_bias=ctx.has_bias)
+            work.wait()
+        else:
+            st, sums, gsw, gbw, gbb = ops.fastkan_shard_bwd(x, gy, stats, ln_w, ln_b, spline_w, base_w, layer.centers, layer.denominator,
+                                                            layer.precision, want_bias=ctx.has_bias)
+            if sums is not None:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        gx, glw, glb = ops.fastkan_shard_bwd_finish(st, sums, layer.in_total)
+        return gx, None, glw, glb, gsw, gbw, gbb, None
+
+
+class ShardedFastKANLayer(nn.Module):
+    """Input-column slice of a ``FastKANLayer`` (reference ``fastkan.py:49-85``): ``layernorm.weight / .bias`` and
+    ``base_linear.weight`` on this rank's columns, ``spline_linear.weight`` on their ``num_grids`` RBF columns each;
+    ``base_linear.bias`` lives on ``bias_rank`` only (it enters the summed partial sums once).  ``forward`` returns the partial
+    sums ``[N, out]`` -- one tensor per row chunk of ``bounds`` -- for the caller to reduce-scatter (a convolution's chain) or
+    all-reduce (a read-out).  ``columns`` as in ``ShardedKANLinear``."""
+
+    def __init__(self, full, rank: int, world: int, group=None, local_ops=None, columns: Optional[torch.Tensor] = None,
+                 bias_rank: int = 0):
+        super().__init__()
+        if columns is None:
+            if full.input_dim % world:
+                raise ValueError("input_dim must be divisible by the world size")
+            w = full.input_dim // world
+            self.lo, self.hi = rank * w, (rank + 1) * w
+            columns = torch.arange(self.lo, self.hi)
+        self.group, self.world, self.rank = group, world, rank
+        self.local_ops = _hip_ops if local_ops is None else local_ops
+        self.in_total, self.out_features = full.input_dim, full.output_dim
+        ng = full.rbf.num_grids
+        dev = full.spline_linear.weight.device
+        columns = columns.to(dev)
+        self.register_buffer("columns", columns.clone(), persistent=False)
+        if full.layernorm is not None:
+            self.ln_weight = nn.Parameter(full.layernorm.weight.detach()[columns].clone())
+            self.ln_bias = nn.Parameter(full.layernorm.bias.detach()[columns].clone())
+            self.ln_eps = float(full.layernorm.eps)
+        else:
+            self.ln_weight = self.ln_bias = None
+            self.ln_eps = 1e-5
+        sw = full.spline_linear.weight.detach().view(full.output_dim, full.input_dim, ng)
+        self.spline_weight = nn.Parameter(sw[:, columns, :].reshape(full.output_dim, columns.numel() * ng).clone())
+        if full.use_base_update:
+            self.base_weight = nn.Parameter(full.base_linear.weight.detach()[:, columns].clone())
+            self.base_bias = nn.Parameter(full.base_linear.bias.detach().clone()) if rank == bias_rank else None
+        else:
+            self.base_weight = self.base_bias = None
+        self.register_buffer("centers", full.rbf.grid.detach().clone())
+        self.denominator = float(full.rbf.denominator)
+        self.precision = full.precision
+        self.comm = _Comm(group)               # the side stream of the backward's row-sum all-reduce
+
+    def row_stats(self, x_shard: torch.Tensor) -> Optional[torch.Tensor]:
+        """LayerNorm statistics of every row over ALL ranks' columns: local (mean, M2) -> all-gather (2 floats per row and
+        rank) -> merged in rank order on every rank (the same bits everywhere).  Not differentiated: the LayerNorm backward's
+        two row sums carry the dependence of the statistics on x."""
+        if self.ln_weight is None:
+            return None
+        ops = self.local_ops
+        with torch.no_grad():
+            mom = ops.fastkan_row_moments(x_shard.detach())
+            gathered = torch.empty((self.world,) + tuple(mom.shape), dtype=mom.dtype, device=mom.device)
+            dist.all_gather_into_tensor(gathered.view(-1, 2), mom, group=self.group)
+            return ops.fastkan_merge_moments(gathered, x_shard.size(1), self.ln_eps)
+
+    def forward(self, x_shard: torch.Tensor, bounds=None):
+        stats = self.row_stats(x_shard)
+        if bounds is None:
+            bounds = [(0, x_shard.size(0))]
+        return [_ShardedFastKANFn.apply(x_shard[r0:r1], None if stats is None else stats[r0:r1], self.ln_weight, self.ln_bias,
+                                        self.spline_weight, self.base_weight, self.base_bias, self) for r0, r1 in bounds]
+
+
+class ShardedGIFASTKANLayer(nn.Module):
+    """``GIFASTKANLayer`` (reference ``models.py:85-92``: sum-aggregate + FastKAN chain) on 1/P of the feature columns per rank:
+    column-sharded aggregation, then per FastKANLayer the LayerNorm exchange (2 floats per row each way), the local RBF
+    expansion + contraction over this rank's input columns, and the SAME reduce-scatter (forward) / all-gather (backward) of
+    the partial sums as ``ShardedGIKANLayer`` -- row-chunked and overlapped the same way."""
+
+    def __init__(self, conv, group=None, local_ops=None, chunks: Optional[int] = None):
+        super().__init__()
+        self.group, self.chunks = group, chunks
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.local_ops = _hip_ops if local_ops is None else local_ops
+        self.eps = float(conv.eps)
+        for l in conv.nn.layers:
+            if l.input_dim % self.world or l.output_dim % self.world:
+                raise ValueError("layer widths must be divisible by the world size")
+        self.layers = nn.ModuleList(ShardedFastKANLayer(l, self.rank, self.world, group, self.local_ops) for l in conv.nn.layers)
+
+    def shard_columns(self, t: torch.Tensor) -> torch.Tensor:
+        w = t.size(1) // self.world
+        return t[:, self.rank * w:(self.rank + 1) * w].contiguous()
+
+    def forward(self, x_shard: torch.Tensor, graph) -> torch.Tensor:
+        h = self.local_ops.aggregate_sum(x_shard, graph, self_scale=1.0 + self.eps)
+        n = h.size(0)
+        bounds = _chunk_bounds(n, self.chunks if self.chunks is not None else (4 if n >= 262144 else 1))
+        for layer in self.layers:
+            comm = _Comm(self.group)
+            parts = [_ReduceScatterChunk.apply(p, comm, i) for i, p in enumerate(layer(h, bounds))]
+            h = _Finish.apply(comm, bounds, *parts)
+        return h
+
+
+# ----------------------------------------------------------------------------------------------------------
+# a whole node model on column shards
+class _AllReduceSum(Function):
+    """partial sums -> their sum on every rank.  Backward: identity -- every rank evaluates the same loss on the same summed
+    tensor, so the gradient it holds already IS the gradient of its partial sums (no communication)."""
+
+    @staticmethod
+    def forward(ctx, partial, group):
+        y = partial.detach().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class ShardedNodeModel(nn.Module):
+    """``GKAN_Nodes`` / ``GFASTKAN_Nodes`` with GIN convolutions (reference ``models.py:150-257``) on column shards:
+    ``mp_layers x {sharded conv -> BatchNorm1d on the LOCAL columns (per-feature statistics: no communication) -> dropout}``,
+    the skip read-out as an INPUT-sharded KANLinear / FastKANLayer over this rank's columns of ``[x | h1 | ... | hL]``
+    (``models.py:200-203``) closed by ONE all-reduce of the ``[N, classes]`` partial sums (classes need not divide by P), so every
+    rank holds the full logits and evaluates the loss itself.  Parameters are sharded (gradients are local); only the FastKAN
+    base biases live on rank 0.  ``forward(x_shard, graph)``: ``x_shard = shard_columns(x)``."""
+
+    def __init__(self, model, group=None, local_ops=None, chunks: Optional[int] = None, comm: str = "rccl"):
+        super().__init__()
+        from .models import GIFASTKANLayer
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.local_ops = _hip_ops if local_ops is None else local_ops
+        self.skip = bool(model.skip)
+        convs = []
+        for c in model.convs:
+            if isinstance(c, GIFASTKANLayer):
+                convs.append(ShardedGIFASTKANLayer(c, group, local_ops, chunks))
+            elif isinstance(c, GIKANLayer):
+                convs.append(ShardedGIKANLayer(c, group, local_ops, chunks, comm))
+            else:
+                raise ValueError("ShardedNodeModel shards the GIN convolutions (GIKANLayer / GIFASTKANLayer); "
+                                 f"got {type(c).__name__}")
+        self.convs = nn.ModuleList(convs)
+        bn_cls = getattr(self.local_ops, "BatchNorm1d", None)
+        if bn_cls is None:
+            from .norm import BatchNorm1d as bn_cls
+        widths = []
+        self.bns = nn.ModuleList()
+        for bn in model.bns:
+            if bn.num_features % self.world:
+                raise ValueError("hidden_channels must be divisible by the world size")
+            w = bn.num_features // self.world
+            sl = slice(self.rank * w, (self.rank + 1) * w)
+            b = bn_cls(w, eps=bn.eps, momentum=bn.momentum, affine=bn.affine, track_running_stats=bn.track_running_stats)
+            with torch.no_grad():
+                if bn.affine:
+                    b.weight.copy_(bn.weight[sl]); b.bias.copy_(bn.bias[sl])
+                if bn.track_running_stats:
+                    b.running_mean.copy_(bn.running_mean[sl]); b.running_var.copy_(bn.running_var[sl])
+                    b.num_batches_tracked.copy_(bn.num_batches_tracked)
+            self.bns.append(b.to(bn.weight.device if bn.affine else bn.running_mean.device))
+            widths.append(bn.num_features)
+        self.dropout = nn.Dropout(model.dropout.p)
+        # this rank's input columns of the read-out: its block of every concatenated part
+        first = model.convs[0].nn.layers[0]
+        fin = first.in_features if hasattr(first, "in_features") else first.input_dim
+        if fin % self.world:
+            raise ValueError("num_features must be divisible by the world size")
+        parts = ([fin] + widths) if self.skip else [widths[-1]]
+        cols, off = [], 0
+        for wd in parts:
+            w = wd // self.world
+            cols.append(torch.arange(off + self.rank * w, off + (self.rank + 1) * w))
+            off += wd
+        cols = torch.cat(cols)
+        self.num_features = fin
+        if isinstance(model.lay_out, KANLinear):
+            self.lay_out = ShardedKANLinear(model.lay_out, self.rank, self.world, columns=cols, scatter_out=False)
+        else:
+            self.lay_out = ShardedFastKANLayer(model.lay_out, self.rank, self.world, group, self.local_ops, columns=cols)
+
+    def shard_columns(self, t: torch.Tensor) -> torch.Tensor:
+        w = t.size(1) // self.world
+        return t[:, self.rank * w:(self.rank + 1) * w].contiguous()
+
+    def forward(self, x_shard: torch.Tensor, graph) -> torch.Tensor:
+        if self.local_ops is _hip_ops and not isinstance(graph, _hip_ops.GraphIndex):
+            graph = _hip_ops.graph_index(graph, x_shard.size(0))
+        cat = getattr(self.local_ops, "concat_columns", None) or (lambda parts: torch.cat(parts, dim=1))
+        outs = [x_shard]
+        x = x_shard
+        for conv, bn in zip(self.convs, self.bns):
+            x = self.dropout(bn(conv(x, graph)))
+            outs.append(x)
+        h = cat(outs) if self.skip else x
+        if isinstance(self.lay_out, ShardedKANLinear):
+            partial = self.lay_out(h, self.local_ops)
+        else:
+            partial = self.lay_out(h)[0]
+        return _AllReduceSum.apply(partial, self.group)
 
 
 # ----------------------------------------------------------------------------------------------------------

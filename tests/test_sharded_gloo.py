@@ -28,6 +28,74 @@ class OracleOps:
         from oracle import kan_oracle as orc
         return orc.kan_linear_forward(x, bw, sw, sc, knots.expand(x.size(1), -1), K)
 
+    # ---- the local halves of the feature-sharded FastKAN layer (kagnn_amd.ops.fastkan_row_moments ... _shard_bwd_finish),
+    # restated with torch ops in fp64: what is under test is the exchange algebra of kagnn_amd.sharded around them
+    BatchNorm1d = torch.nn.BatchNorm1d
+
+    @staticmethod
+    def fastkan_row_moments(x):
+        xd = x.double()
+        mean = xd.mean(1)
+        return torch.stack([mean, ((xd - mean[:, None]) ** 2).sum(1)], 1).to(x.dtype)
+
+    @staticmethod
+    def fastkan_merge_moments(gathered, width, eps):
+        g = gathered.double()
+        mean, m2 = g[0, :, 0].clone(), g[0, :, 1].clone()
+        for p in range(1, g.size(0)):                       # Chan's update, rank order
+            na, nb = float(p * width), float(width)
+            d = g[p, :, 0] - mean
+            mean = mean + d * (nb / (na + nb))
+            m2 = m2 + g[p, :, 1] + d * d * (na * nb / (na + nb))
+        return torch.stack([mean, torch.rsqrt(m2 / (g.size(0) * width) + eps)], 1).to(gathered.dtype)
+
+    @staticmethod
+    def _fk_partial(z, x, sw, bw, bb, centers, den):
+        from oracle import kan_oracle as orc
+        phi = orc.rbf_bases(z, centers.double(), den)
+        y = torch.nn.functional.linear(phi.view(z.size(0), -1), sw.double())
+        if bw is not None:
+            y = y + torch.nn.functional.linear(torch.nn.functional.silu(x), bw.double(), None if bb is None else bb.double())
+        return y
+
+    @staticmethod
+    def fastkan_shard_fwd(x, stats, ln_w, ln_b, sw, bw, bb, centers, den, mode=None):
+        xd = x.double()
+        with torch.no_grad():
+            z = xd if ln_w is None else (xd - stats[:, :1].double()) * stats[:, 1:].double() * ln_w.double() + ln_b.double()
+            return OracleOps._fk_partial(z, xd, sw, bw, bb, centers, den).to(x.dtype)
+
+    @staticmethod
+    def fastkan_shard_bwd(x, gy, stats, ln_w, ln_b, sw, bw, centers, den, mode=None, want_bias=False):
+        xd = x.detach().double()
+        zhat = None if ln_w is None else (xd - stats[:, :1].double()) * stats[:, 1:].double()
+        with torch.enable_grad():
+            xb = xd.clone().requires_grad_(True)                     # the base branch's (and, without LayerNorm, the RBF's) input
+            z = xb if ln_w is None else (zhat * ln_w.detach().double() + ln_b.detach().double()).requires_grad_(True)
+            swd = sw.detach().double().requires_grad_(True)
+            bwd = None if bw is None else bw.detach().double().requires_grad_(True)
+            bbd = torch.zeros(sw.size(0), dtype=torch.float64, requires_grad=True) if (want_bias and bw is not None) else None
+            y = OracleOps._fk_partial(z, xb, swd, bwd, bbd, centers, den)
+            y.backward(gy.double())
+        st = dict(gx=xb.grad, gz=None if ln_w is None else z.grad, zhat=zhat, rstd=None if ln_w is None else stats[:, 1:].double(),
+                  lw=ln_w, dtype=x.dtype)
+        sums = None
+        if ln_w is not None:
+            h = z.grad * ln_w.detach().double()
+            sums = torch.stack([h.sum(1), (h * zhat).sum(1)], 1).to(x.dtype)
+        f = x.dtype
+        return st, sums, swd.grad.to(f), None if bwd is None else bwd.grad.to(f), None if bbd is None else bbd.grad.to(f)
+
+    @staticmethod
+    def fastkan_shard_bwd_finish(st, sums, width_total):
+        f = st["dtype"]
+        if st["lw"] is None:
+            return st["gx"].to(f), None, None
+        h = st["gz"] * st["lw"].detach().double()
+        s = sums.double() / width_total
+        gx = st["gx"] + st["rstd"] * (h - s[:, :1] - st["zhat"] * s[:, 1:])
+        return gx.to(f), (st["gz"] * st["zhat"]).sum(0).to(f), st["gz"].sum(0).to(f)
+
 
 def _worker(rank, world, port, out_dir, f=8, hid=12, grid=5, full=True):
     """``f`` / ``hid`` / ``grid``: layer widths and grid size -- world 8 at 64 / 64 / 5 and 128 / 128 / 8 gives every rank the 8 and 16
@@ -133,6 +201,137 @@ def _worker(rank, world, port, out_dir, f=8, hid=12, grid=5, full=True):
         dist.destroy_process_group()
 
 
+def _worker_e2(rank, world, port, out_dir, f=16, hid=24, classes=10):
+    """SURVEY 8(e)'s other exchanges: the feature-sharded FastKAN-GIN layer (LayerNorm statistics: 2 floats
+    per row each way), and whole node models on column shards (shard-local BatchNorm1d, input-sharded skip read-out closed by
+    one all-reduce of the [N, classes] partial sums) -- against the unsharded oracle, every gradient."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kagnn_amd
+        import helpers
+        from kagnn_amd.sharded import ShardedGIFASTKANLayer, ShardedNodeModel
+        from oracle import kan_oracle as orc
+        n, e = 300, 2500
+        ei = orc.powerlaw_graph(n, e, seed=21)
+        gen = torch.Generator().manual_seed(21)
+        x = torch.randn(n, f, generator=gen) * 0.3 + 0.7          # (a non-zero row mean: the statistics merge has something to do)
+        gy = torch.randn(n, f, generator=gen)
+        tol = 2e-5
+        w = f // world
+        sl = slice(rank * w, (rank + 1) * w)
+
+        def close(a, b, what, t=tol):
+            err = float((a.double() - b.double()).abs().max()) / max(1e-30, float(b.abs().max()))
+            assert err <= t, (what, err)
+
+        # ---- (a) ShardedGIFASTKANLayer
+        torch.manual_seed(6)
+        conv = kagnn_amd.GIFASTKANLayer(f, f, grid_size=5, hidden_dim=hid, nb_layers=2)
+        with torch.no_grad():                                     # (default init: LayerNorm weight 1 / bias 0, base bias ~0: make them matter)
+            for l in conv.nn.layers:
+                l.layernorm.weight.uniform_(0.5, 1.5); l.layernorm.bias.uniform_(-0.3, 0.3); l.base_linear.bias.uniform_(-0.5, 0.5)
+        layers = [{k: v.detach().clone().double() for k, v in l.state_dict().items()} for l in conv.nn.layers]
+        leaves = [{k: (v.requires_grad_(True) if k != "rbf.grid" else v) for k, v in p.items()} for p in layers]
+        xr = x.double().requires_grad_(True)
+        y_ref = orc.gin_conv(xr, ei, lambda h: orc.fastkan_forward(h, leaves))
+        y_ref.backward(gy.double())
+        for chunks in (1, 3):
+            sconv = ShardedGIFASTKANLayer(conv, None, local_ops=OracleOps, chunks=chunks)
+            xs = sconv.shard_columns(x).requires_grad_(True)
+            y = sconv(xs, ei)
+            y.backward(sconv.shard_columns(gy))
+            close(y, y_ref[:, sl], "fastkan y")
+            close(xs.grad, xr.grad[:, sl], "fastkan gx")
+            for li, (layer, p) in enumerate(zip(sconv.layers, leaves)):
+                cols = layer.columns
+                ng = layer.centers.numel()
+                fin, fout = p["base_linear.weight"].size(1), p["base_linear.weight"].size(0)
+                close(layer.ln_weight.grad, p["layernorm.weight"].grad[cols], f"L{li} g_ln_weight")
+                close(layer.ln_bias.grad, p["layernorm.bias"].grad[cols], f"L{li} g_ln_bias")
+                close(layer.spline_weight.grad, p["spline_linear.weight"].grad.view(fout, fin, ng)[:, cols].reshape(fout, -1), f"L{li} g_spline")
+                close(layer.base_weight.grad, p["base_linear.weight"].grad[:, cols], f"L{li} g_base_weight")
+                assert (layer.base_bias is not None) == (rank == 0)
+                if rank == 0:
+                    close(layer.base_bias.grad, p["base_linear.bias"].grad, f"L{li} g_base_bias")
+
+        # ---- (b) whole node models on column shards: GKAN_Nodes and GFASTKAN_Nodes, gin, skip read-out
+        labels = torch.randint(0, classes, (n,), generator=gen)
+        for arch in ("kan", "fastkan"):
+            torch.manual_seed(7)
+            if arch == "kan":
+                model = kagnn_amd.GKAN_Nodes("gin", 2, f, hid, classes, grid_size=4, spline_order=3, hidden_layers=2)
+            else:
+                model = kagnn_amd.GFASTKAN_Nodes("gin", 2, f, hid, classes, grid_size=4, hidden_layers=2)
+            with torch.no_grad():
+                for bn in model.bns:
+                    bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+            state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            # the loss every rank evaluates on the full logits (harness loss: softmax -> CrossEntropy, time_model.py:43-44)
+            logits_ref = None
+
+            def loss_grad(lg):
+                lg = lg.detach().double().requires_grad_(True)
+                orc.harness_loss(lg, labels).backward()
+                return lg.grad
+            xr = x.double()
+            out_ref, gx_ref, g_ref = None, None, None
+            lg0 = orc.node_model_forward(xr, ei, {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}, arch, "gin", 2)
+            gout = loss_grad(lg0)
+            out_ref, gx_ref, g_ref = helpers.oracle_node_model_fwd_bwd(x, ei, state, gout, arch, "gin", 2)
+            sm = ShardedNodeModel(model, None, local_ops=OracleOps, chunks=2)
+            sm.train()
+            xs = sm.shard_columns(x).requires_grad_(True)
+            logits = sm(xs, ei)
+            assert logits.shape == (n, classes)
+            close(logits, out_ref, f"{arch} logits")
+            logits.backward(loss_grad(logits).to(logits.dtype))                   # every rank: its own loss on the full logits
+            close(xs.grad, gx_ref[:, sl], f"{arch} gx", 5e-5)
+            # parameter gradients: every sharded tensor against its slice of the unsharded model's
+            checked = 0
+            for ci, sc in enumerate(sm.convs):
+                for li, layer in enumerate(sc.layers):
+                    pre = f"convs.{ci}.nn.layers.{li}."
+                    cols = layer.columns
+                    if arch == "kan":
+                        for name in ("base_weight", "spline_weight", "spline_scaler"):
+                            close(getattr(layer, name).grad, g_ref[pre + name][:, cols], pre + name, 5e-5)
+                            checked += 1
+                    else:
+                        ng = layer.centers.numel()
+                        gsw = g_ref[pre + "spline_linear.weight"]
+                        fout = gsw.size(0)
+                        close(layer.spline_weight.grad, gsw.view(fout, -1, ng)[:, cols].reshape(fout, -1), pre + "spline", 5e-5)
+                        close(layer.base_weight.grad, g_ref[pre + "base_linear.weight"][:, cols], pre + "base_weight", 5e-5)
+                        close(layer.ln_weight.grad, g_ref[pre + "layernorm.weight"][cols], pre + "ln_w", 5e-5)
+                        close(layer.ln_bias.grad, g_ref[pre + "layernorm.bias"][cols], pre + "ln_b", 5e-5)
+                        checked += 4
+            hw = hid // world
+            for bi, bn in enumerate(sm.bns):
+                close(bn.weight.grad, g_ref[f"bns.{bi}.weight"][rank * hw:(rank + 1) * hw], f"bns.{bi}.weight", 5e-5)
+                close(bn.bias.grad, g_ref[f"bns.{bi}.bias"][rank * hw:(rank + 1) * hw], f"bns.{bi}.bias", 5e-5)
+            cols = sm.lay_out.columns
+            assert cols.numel() == (f + 2 * hid) // world
+            if arch == "kan":
+                for name in ("base_weight", "spline_weight", "spline_scaler"):
+                    close(getattr(sm.lay_out, name).grad, g_ref["lay_out." + name][:, cols], "lay_out." + name, 5e-5)
+            else:
+                ng = sm.lay_out.centers.numel()
+                gsw = g_ref["lay_out.spline_linear.weight"]
+                close(sm.lay_out.spline_weight.grad, gsw.view(classes, -1, ng)[:, cols].reshape(classes, -1), "lay_out.spline", 5e-5)
+                close(sm.lay_out.ln_weight.grad, g_ref["lay_out.layernorm.weight"][cols], "lay_out.ln_w", 5e-5)
+                if rank == 0:
+                    close(sm.lay_out.base_bias.grad, g_ref["lay_out.base_linear.bias"], "lay_out.base_bias", 5e-5)
+            assert checked >= 6
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -151,6 +350,15 @@ def test_sharded_layer_world4_and_world8_gloo(tmp_path, world, f, hid, grid):
     reduce-scatter / all-gather algebra, uneven row chunks (400 rows in 3 and 7 chunks) and the transposed variant's all-to-all with
     401 rows over P ranks -- at the widths the P = 8 shards have (8 columns per rank at F = 64, 16 at F = 128 / grid 8)."""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), f, hid, grid, False), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.parametrize("world,f,hid", [(2, 16, 24), (4, 16, 24), (8, 64, 64)], ids=["P2", "P4", "P8-F64"])
+def test_sharded_fastkan_layer_and_node_models_gloo(tmp_path, world, f, hid):
+    """SURVEY 8(e) beyond the KAN-GIN conv (VERDICT r05 row e2 a + b): feature-sharded FastKAN-GIN layer and the sharded
+    GKAN_Nodes / GFASTKAN_Nodes step at world 2 / 4 / 8 against the unsharded oracle (reference ``fastkan.py:76-85``,
+    ``models.py:195-203,246-257``)."""
+    mp.spawn(_worker_e2, args=(world, _free_port(), str(tmp_path), f, hid), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
