@@ -3,7 +3,7 @@
 (sum-aggregate + KAN([F,F,F])) forward AND backward on the synthetic power-law graph of
 SURVEY.md 8(d) (1M nodes / 10M edges, fp32 I/O).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|config3|fastkan]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|config3|fastkan|model]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One JSON line on stdout (rank 0).  Besides the contract's fields it carries
@@ -27,6 +27,9 @@ The line survives a transport that hangs or kills a rank (none of the N > 1 path
 rank 0's line travels through a forked reporter process that prints the LAST line it was handed when rank 0 ends -- the
 complete one, or the interim one written after the last combination that finished -- and every phase runs under a
 watchdog (KAGNN_BENCH_PHASE_TIMEOUT seconds, default 90; 300 for the first, which includes RCCL's start-up).
+`--workload fastkan` / `--workload model` at N > 1 (round 6): the feature-sharded FastKAN-GIN layer (LayerNorm exchange of 2 floats
+per row each way) and the whole GKAN_Nodes training step on column shards (kagnn_amd.sharded.ShardedGIFASTKANLayer /
+ShardedNodeModel), north_star's scheme over RCCL only; same contract, reporter and watchdog.
 """
 from __future__ import annotations
 
@@ -58,6 +61,9 @@ WORKLOADS = {
     "config3": (128, 8),       # BASELINE.json configs[2]: hidden=128 grid=8 (the 8-GPU config)
     "fastkan": (64, 8),        # the RBF-basis twin of the headline layer (BASELINE.json configs[4]'s kernel path): FastKAN-GIN,
                                # hidden 64, 8 grids -- BASELINE.md section 2 holds the reference CPU time of this very layer
+    "model": (64, 5),          # SURVEY 8(d)'s secondary figure as a workload of its own: the full GKAN_Nodes(gin, 3 conv layers, hidden
+                               # 64, 40 classes, skip, BatchNorm) TRAINING step (forward, softmax + CE, backward, Adam), value = 3E / t;
+                               # N > 1: kagnn_amd.sharded.ShardedNodeModel (column shards, shard-local BatchNorm, sharded read-out)
 }
 
 
@@ -310,7 +316,7 @@ def other_layer_figures(dev, graph, n, e, steps=10):
     import kagnn_amd
     out = {}
     for name, (f, grid) in WORKLOADS.items():
-        if name == "headline":
+        if name in ("headline", "model"):
             continue
         torch.manual_seed(0)
         if name == "fastkan":
@@ -453,8 +459,6 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1 and args.workload == "fastkan":
-        raise SystemExit("--workload fastkan is a single-GPU figure (the sharded layers of kagnn_amd/sharded.py wrap the KAN-GIN layer)")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -472,6 +476,7 @@ def main():
     ops._LAYER_ABI = os.environ.get("KAGNN_BENCH_LAYER_ABI", "1") == "1"
 
     n, e = args.nodes, args.edges
+    units = (3 * e) if args.workload == "model" else e           # edges processed per step (the model has 3 conv layers)
     fp32_mode = args.precision in ("fp32", "exact", "0")
     half_mode = args.precision in ("half", "fp16", "3")
     ei = powerlaw_graph(n, e, seed=0).to(dev)
@@ -480,7 +485,13 @@ def main():
     gy_full = torch.randn(n, f, generator=torch.Generator().manual_seed(1))
     torch.manual_seed(0)
     fastkan = args.workload == "fastkan"
-    if fastkan:
+    model_wl = args.workload == "model"
+    net = labels = None
+    if model_wl:
+        net = kagnn_amd.GKAN_Nodes("gin", 3, f, f, 40, skip=True, grid_size=grid, spline_order=args.order, hidden_layers=2)
+        labels = torch.randint(0, 40, (n,), generator=torch.Generator().manual_seed(2)).to(dev)
+        conv = net.convs[0]
+    elif fastkan:
         conv = kagnn_amd.GIFASTKANLayer(f, f, grid_size=grid, hidden_dim=f, nb_layers=2)
     else:
         conv = kagnn_amd.GIKANLayer(f, f, grid_size=grid, spline_order=args.order, hidden_dim=f, nb_layers=2)
@@ -523,7 +534,10 @@ def main():
                                           if half_mode else "f32 (fp16 hi/lo split operands, fp32 accumulate)") +
                                           (" + bf16 gather operands (KAGNN_ACT=bf16, build-defined config-2 mode)" if args.act == "bf16" else ""),
             "data": "synthetic",
-            "config": {"workload": (f"{args.workload}: FastKAN-GIN conv layer fwd+bwd (aggregate + FastKAN([{f},{f},{f}]) num_grids={grid}), "
+            "config": {"workload": (f"{args.workload}: GKAN_Nodes(gin, 3 x KAN-GIN conv hidden {f} grid {grid} order {args.order}, BatchNorm, skip read-out, "
+                                    "40 classes) TRAINING step = forward, softmax + cross-entropy, backward, Adam (time_model.py:35-48); value = 3E / t_step, "
+                                    if model_wl else
+                                    f"{args.workload}: FastKAN-GIN conv layer fwd+bwd (aggregate + FastKAN([{f},{f},{f}]) num_grids={grid}), "
                                     if fastkan else
                                     f"{args.workload}: KAN-GIN conv layer fwd+bwd (aggregate + KAN([{f},{f},{f}]) grid={grid} order={args.order}), ")
                                    + f"power-law graph N={n} E={e} seed 0 (SURVEY 8(d))",
@@ -531,8 +545,27 @@ def main():
                        "precision": args.precision, "activation_storage": args.act, "parallelism": parallelism_},
         }
 
+    def model_step_fn(module, xin):
+        """one epoch of the reference's timing loop (time_model.py:35-48) on `module` (the node model, or its column-sharded form)"""
+        try:
+            opt = torch.optim.Adam(module.parameters(), lr=0.001, fused=True)
+        except (TypeError, RuntimeError):
+            opt = torch.optim.Adam(module.parameters(), lr=0.001)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = ops.softmax_cross_entropy(module(xin, graph), labels, None, pre_softmax=True)
+            loss.backward()
+            opt.step()
+        return step
+
     alt = None
-    if world == 1:
+    if world == 1 and model_wl:
+        net = net.to(dev).train()
+        x = x_full.to(dev)
+        step = model_step_fn(net, x)
+        parallelism = "single GPU"
+    elif world == 1:
         conv = conv.to(dev)
         x = x_full.to(dev)
         if args.act == "bf16":
@@ -549,10 +582,18 @@ def main():
             y.backward(gy)
         parallelism = "single GPU"
     else:
-        from kagnn_amd.sharded import ShardedGIKANLayer, TransposedShardedGIKANLayer
+        from kagnn_amd.sharded import ShardedGIFASTKANLayer, ShardedGIKANLayer, ShardedNodeModel, TransposedShardedGIKANLayer
         classes = {"feature": ShardedGIKANLayer, "transposed": TransposedShardedGIKANLayer}
 
         def describe(scheme, comm):
+            if model_wl:
+                return (f"ShardedNodeModel x{world}: every activation as a column shard, 3 x feature-sharded KAN-GIN conv (RCCL reduce-scatter "
+                        "fwd / all-gather bwd per KANLinear), shard-local BatchNorm1d, input-sharded skip read-out closed by ONE all-reduce of "
+                        "the [N, 40] partial sums, loss on every rank, sharded parameters (local Adam)")
+            if fastkan:
+                return (f"feature-sharded x{world}: FastKAN coefficients split by input feature; per FastKANLayer the LayerNorm exchange (2 floats "
+                        "per row: all-gather of the local moments fwd, all-reduce of the two row sums bwd) + RCCL reduce-scatter (fwd) / "
+                        "all-gather (bwd) of the partial sums, row-chunked and overlapped")
             if scheme == "feature":
                 return (f"feature-sharded x{world}: spline coefficients split by input feature, " +
                         ("RCCL reduce-scatter (fwd) / all-gather (bwd) per KANLinear, row-chunked and overlapped (north_star's scheme)"
@@ -577,8 +618,13 @@ def main():
                     if how == "kill":
                         os.kill(os.getpid(), 9)
                     time.sleep(1e6)
+            if model_wl:
+                torch.manual_seed(0)
+                sm = ShardedNodeModel(net, dist.group.WORLD, comm=comm).to(dev).train()
+                return model_step_fn(sm, sm.shard_columns(x_full.to(dev)))
             cls = classes[scheme]
-            sconv = (cls(conv, dist.group.WORLD, sync_in_backward=False, comm=comm) if cls is TransposedShardedGIKANLayer
+            sconv = (ShardedGIFASTKANLayer(conv, dist.group.WORLD) if fastkan else
+                     cls(conv, dist.group.WORLD, sync_in_backward=False, comm=comm) if cls is TransposedShardedGIKANLayer
                      else cls(conv, dist.group.WORLD, comm=comm)).to(dev)
             xs = sconv.shard_columns(x_full.to(dev)).requires_grad_(True)
             gs = sconv.shard_columns(gy_full.to(dev))
@@ -602,6 +648,8 @@ def main():
         # listed with its error and skipped (setup errors are symmetric across ranks; an asymmetric one ends in the watchdog).
         pin_s, pin_c = os.environ.get("KAGNN_SHARDING"), os.environ.get("KAGNN_COMM")
         order = [("feature", "rccl"), ("transposed", "rccl"), ("feature", "p2p"), ("transposed", "p2p"), ("feature", "rccl_c")]
+        if fastkan or model_wl:      # (the FastKAN layer and the whole node model exist in north_star's scheme over torch.distributed / RCCL)
+            order = [("feature", "rccl")]
         combos = [(sc, cm) for sc, cm in order if (pin_s is None or sc == pin_s) and (pin_c is None or cm == pin_c)]
         if not combos:
             raise SystemExit("KAGNN_SHARDING must be 'feature' or 'transposed', KAGNN_COMM 'rccl', 'rccl_c' (feature only) or 'p2p'")
@@ -628,7 +676,7 @@ def main():
                 for _ in range(args.warmup):
                     st()
                 dtp = timed(st, args.steps)
-                entry.update(ms_per_step=dtp / args.steps * 1e3, value=e / (dtp / args.steps), steps=args.steps, warmup=args.warmup)
+                entry.update(ms_per_step=dtp / args.steps * 1e3, value=units / (dtp / args.steps), steps=args.steps, warmup=args.warmup)
                 del st
             except Exception as ex:                       # noqa: BLE001 -- reported in the line, not swallowed
                 entry["error"] = f"{type(ex).__name__}: {ex}"[:300]
@@ -675,7 +723,10 @@ def main():
     # the dominant COMPUTE stage (the exchange kernels of the sharded layers -- kagnn_p2p_* -- are wire-bound and have no HBM / MFMA
     # roofline: they stay in entry_points_ms_per_step, the roofline block describes the largest stage that has one)
     ROOFLINE_STAGES = ("kagnn_aggregate_sum", "kagnn_aggregate_sum_bf16", "kagnn_kan_linear_fwd", "kagnn_kan_linear_fwd_moments",
-                       "kagnn_kan_linear_bwd_input", "kagnn_kan_linear_bwd_weight", "kagnn_fastkan_fwd", "kagnn_fastkan_bwd")
+                       "kagnn_kan_linear_bwd_input", "kagnn_kan_linear_bwd_weight", "kagnn_fastkan_fwd", "kagnn_fastkan_bwd",
+                       "kagnn_fastkan_shard_fwd", "kagnn_fastkan_shard_bwd")
+    if model_wl:     # (the model's KAN launches have several shapes -- conv layers and the 256 -> 40 read-out --: the roofline block is its aggregation)
+        ROOFLINE_STAGES = ("kagnn_aggregate_sum",)
     cand = {k: v for k, v in warm.items() if k in ROOFLINE_STAGES}
     only = max(cand, key=lambda k: cand[k]["total_ms"]) if cand else None
     with ops.LibraryStageTimer(only):
@@ -684,7 +735,7 @@ def main():
     if dog is not None:
         dog.phase("per-rank gather", 60.0)
     ms = dt / args.steps * 1e3
-    value = e / (dt / args.steps)
+    value = units / (dt / args.steps)
 
     # N > 1: what each rank's device spent INSIDE the library (kernels, summed over the entry points of the profile steps) vs the
     # step time -- the rest is exposed waiting on the collectives (+ launch gaps): explains the driver's scaling curve
@@ -698,7 +749,7 @@ def main():
         dog.clear()
 
     fp32_ms = None
-    if not args.no_fp32 and not fp32_mode and world == 1:
+    if not args.no_fp32 and not fp32_mode and world == 1 and not model_wl:
         for l in conv.nn.layers:
             l.precision = ops.PREC_FP32
         for _ in range(2):
@@ -710,7 +761,7 @@ def main():
     # the build-defined reduced-precision mode of BASELINE config 2 (KAGNN_PRECISION=half: one fp16 product per fp32 product) on
     # the same layer, measured after the timed region like the exact-fp32 figure -- reported beside the headline, never as it
     half_ms = None
-    if not args.no_fp32 and not fp32_mode and not half_mode and world == 1 and not fastkan:
+    if not args.no_fp32 and not fp32_mode and not half_mode and world == 1 and not fastkan and not model_wl:
         for l in conv.nn.layers:
             l.precision = ops.PREC_HALF
         for _ in range(2):
@@ -741,8 +792,14 @@ def main():
                                   4.0 * nrows * (fl + f) + 8.0 * nrows, kan),
             "kagnn_fastkan_bwd": ("FastKANLayer backward (input gradient through the LayerNorm, LayerNorm / spline / base weight and "
                                   "bias gradients)", 4.0 * nrows * (3 * fl + 2 * f), 2.0 * kan),
+            "kagnn_fastkan_shard_fwd": ("feature-sharded FastKANLayer forward on this rank's input columns (merged LayerNorm statistics given): "
+                                        "partial sums for all outputs", 4.0 * nrows * (fl + f) + 8.0 * nrows, kan),
+            "kagnn_fastkan_shard_bwd": ("feature-sharded FastKANLayer backward without the LayerNorm finish (two launches per layer: input-gradient "
+                                        "half, weight-gradient half)", 4.0 * nrows * (1.5 * fl + f) + 8.0 * nrows, kan),
         }
         spec["kagnn_kan_linear_fwd_moments"] = spec["kagnn_kan_linear_fwd"]
+        if model_wl:
+            spec = {"kagnn_aggregate_sum": spec["kagnn_aggregate_sum"]}
         kernels = []
         for name, (what, nbytes, flops) in spec.items():
             if name not in warm:
@@ -775,16 +832,17 @@ def main():
             raise RuntimeError(f"bench.py: the dominant entry point {dom!r} has no roofline specification (spec table above)")
         roof["frac"] = roof["achieved"] / roof["peak"]
         # the honest whole-layer figure next to the dominant kernel's: all of B_layer over the step time
-        roof["layer_frac"] = layer_bytes(n, e, f) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        lbytes = layer_bytes(n, e, f) * (3 if model_wl else 1)          # (model: the three conv layers' B_layer; read-out / norms / loss not counted)
+        roof["layer_frac"] = lbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         roof["avg_launch_ms"] = d["avg_launch_ms"] if d else None
         roof["traffic"] = None
         roof["note"] = ("dominant = largest device time per step; it is the kernel closest to its roofline and its bytes are "
                         "mostly served by the Infinity Cache (served_from) -- the limiting kernels are in roofline_kernels, and "
                         "the honest headline figure is layer_hbm_frac")
-        layer_gbs = layer_bytes(n, e, f) / (ms * 1e-3) / 1e9
+        layer_gbs = lbytes / (ms * 1e-3) / 1e9
         out = contract_fields(value, ms, parallelism)
         out.update({
-            "layer_algorithmic_bytes": layer_bytes(n, e, f),
+            "layer_algorithmic_bytes": lbytes,
             "layer_hbm_GBs": layer_gbs, "layer_hbm_frac": layer_gbs / HBM_PEAK_GBS,
             "fp32_mode_ms_per_step": fp32_ms,
             "half_mode_ms_per_step": half_ms,      # KAGNN_PRECISION=half on the same layer (build-defined config-2 mode; ~3e-4 from fp32)
@@ -795,7 +853,8 @@ def main():
             "entry_points_measured_in": "3 extra untimed steps after the warm-up; kagnn_stage_timer_* (HIP events on the launch stream "
                                         "around every stage inside the library calls)",
             "timed_path": ("product default: one library call per convolution each way (kagnn_gin_kan_layer_fwd / _bwd)" if ops._LAYER_ABI
-                           else "composed from the per-operation entry points (KAGNN_BENCH_LAYER_ABI=0)") if world == 1 and not fastkan
+                           else "composed from the per-operation entry points (KAGNN_BENCH_LAYER_ABI=0)") if world == 1 and not fastkan and not model_wl
+                          else "the node model's default path (fused conv + norm nodes, lazy norms, one-launch skip read-out)" if world == 1 and model_wl
                           else "per-operation entry points (sharded / FastKAN layers)",
             # one-time per edge_index (cached on its identity); outside the timed region
             "graph_index_build_ms": {"steady": graph_build_ms, "first_call": graph_build_first_ms,
@@ -820,14 +879,14 @@ def main():
             roof["frac_of_copy_bw"] = (roof["achieved"] / copy_gbs) if roof["unit"] == "GB/s" else None
             for k in kernels:
                 k["hbm_frac_of_copy_bw"] = k["hbm_GBs"] / copy_gbs
-        if not args.no_extras and world == 1 and not fastkan:
+        if not args.no_extras and world == 1 and not fastkan and not model_wl:
             out["secondary"] = secondary_figures(dev, conv, graph, x.detach().float(), n, e, f, grid, args.order)
             conv_ms = 3 * ms
             out["secondary"]["model_step"]["conv_layers_share"] = conv_ms / out["secondary"]["model_step"]["ms_per_step"]
             if args.workload == "headline" and args.act == "fp32" and not fp32_mode:
                 out["secondary"]["other_layers"] = other_layer_figures(dev, graph, n, e)
                 out["secondary"]["graph_level_step"] = graph_level_step_figures(dev)
-        if not args.no_traffic and world == 1:
+        if not args.no_traffic and world == 1 and not model_wl:
             torch.cuda.synchronize()
             prefix = {"kagnn_aggregate_sum": "agg_rows", "kagnn_kan_linear_fwd": "kan_sparse_fwd",
                       "kagnn_kan_linear_bwd_input": "kan_split_dx", "kagnn_kan_linear_bwd_weight": "kan_split_dw",
@@ -839,7 +898,7 @@ def main():
                                    "fabric-side bytes, Infinity-Cache hits included") if traffic else str(detail)
             if isinstance(detail, dict):
                 out["traffic_per_kernel_bytes"] = detail
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not model_wl:
             # the FULL workload when the host has the memory for the reference algorithm's ~46 GB of dense
             # bases (1 warm-up + 1 timed pass at 32 threads, ~75 s on the GPU boxes' 2 x 64-core hosts), else the 1/10 sample
             mem = _mem_available_gb()

@@ -478,7 +478,7 @@ int embedding_bwd(const int64_t* idx, long stride, long N, const float* g, long 
     const size_t lds = waves * tbl;
     if (lds > 64 * 1024) {
         static unsigned long long configured = 0;
-        if (first_use_on_this_device(configured)) {
+        if (auto first_use_ = first_use_on_this_device(configured)) {
             KAGNN_HIP(hipFuncSetAttribute((const void*)embedding_bwd_partial_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 1024));
             KAGNN_HIP(hipFuncSetAttribute((const void*)embedding_bwd_partial_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 1024));
         }

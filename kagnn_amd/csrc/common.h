@@ -48,14 +48,24 @@ extern thread_local DwDefer* g_dw_defer;
 int dw_defer_flush(hipStream_t st);                 // launches what g_dw_defer holds (no-op when empty) and empties it
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a process-wide "configured" flag leaves the kernel
-// at the 64 KB default on the second GPU a process drives and its launch fails there.  One bit per device ordinal;
-// true the first time the calling thread's current device (the one the launch goes to) meets this call site.
-inline bool first_use_on_this_device(unsigned long long& seen) {
+// at the 64 KB default on the second GPU a process drives and its launch fails there.  One bit per device ordinal.
+// Use:  `if (auto first = first_use_on_this_device(seen)) { hipFuncSetAttribute(...); }` -- true until the calling thread's current
+// device (the one the launch goes to) has been configured at this call site.  The bit is set when the guard LEAVES the if
+// statement, i.e. after the attribute calls: a second host thread on the same device that arrives meanwhile configures again
+// (idempotent) instead of launching a > 64 KB kernel before the first thread's call has completed.
+struct FirstUseGuard {
+    unsigned long long* seen; unsigned long long bit; bool go;
+    explicit operator bool() const { return go; }
+    FirstUseGuard(unsigned long long* s, unsigned long long b, bool g) : seen(s), bit(b), go(g) {}
+    FirstUseGuard(const FirstUseGuard&) = delete;
+    FirstUseGuard& operator=(const FirstUseGuard&) = delete;
+    ~FirstUseGuard() { if (go && bit) __atomic_fetch_or(seen, bit, __ATOMIC_RELEASE); }
+};
+inline FirstUseGuard first_use_on_this_device(unsigned long long& seen) {
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;      // unknown: configure again (idempotent)
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return FirstUseGuard(&seen, 0, true);      // unknown: configure again
     const unsigned long long bit = 1ull << d;
-    const unsigned long long before = __atomic_fetch_or(&seen, bit, __ATOMIC_RELAXED);
-    return !(before & bit);
+    return FirstUseGuard(&seen, bit, !(__atomic_load_n(&seen, __ATOMIC_ACQUIRE) & bit));
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

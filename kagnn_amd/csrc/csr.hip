@@ -176,7 +176,7 @@ int csr_build_small(const int64_t* src, const int64_t* dst, long E, long N, int*
     if (E <= kSmallLdsMax) {
         const size_t lds = lds_base + 2 * (size_t)E * 4;
         static unsigned long long configured = 0;          // (per device: common.h)
-        if (first_use_on_this_device(configured))
+        if (auto first_use_ = first_use_on_this_device(configured))
             KAGNN_HIP(hipFuncSetAttribute((const void*)csr_small_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         csr_small_pair_kernel<true><<<2, kSmallThreads, lds, st>>>(src, dst, (int)E, (int)N, bits, rowptr, col, perm, rowptr_t, col_t, perm_t,
                                                                   flags, static_cast<int*>(ws), 4 * arr, arr);

@@ -938,7 +938,7 @@ static int launch_sparse(const float* x, long ldx, long N, int in, const float* 
     // (wide, OT = 4: two LDS buffers of a QUARTER chunk each)
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT) / (OT == 4 ? 2 : 1) + (MOM ? 8 * OT * 64 * sizeof(float) : 0);
     static unsigned long long configured = 0;          // (per device: common.h)
-    if (first_use_on_this_device(configured)) {
+    if (auto first_use_ = first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, SH, MOM, NARROW, -1, false, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int nchunks = cdiv(in << (SH ? 1 : 0), kSpCF);
@@ -1002,7 +1002,7 @@ static int launch_sparse_agg(const float* x, long ldx, long N, int in, const flo
                              float* y, long ldy, int out, const SpAgg& ag, hipStream_t st) {
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
     static unsigned long long configured = 0;          // (per device: common.h)
-    if (first_use_on_this_device(configured)) {
+    if (auto first_use_ = first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, false, false, true, AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     kan_sparse_fwd_kernel<OT, false, false, true, AGG><<<sp_grid(N), 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, 1, y, ldy, out, 1, 0L,
@@ -1108,7 +1108,7 @@ static int launch_sparse_parts(const SpParts& xp, long N, int in, const float* k
     }
     const size_t lds = kLdsHdr + sparse_fwd_chunk_bytes(OT);
     static unsigned long long configured = 0;          // (per device: common.h)
-    if (first_use_on_this_device(configured)) {
+    if (auto first_use_ = first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_sparse_fwd_kernel<OT, false, false, false, -1, true, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int nchunks = in / kSpCF, gx = sp_grid(N);

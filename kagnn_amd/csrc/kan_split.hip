@@ -437,7 +437,7 @@ static int launch_fwd(const float* x, long ldx, long N, int in, const float* kno
                       int sh, float* ws, size_t ws_bytes, hipStream_t st) {
     const size_t lds = kLdsHdr + split_fwd_chunk_bytes(OT);
     static unsigned long long configured = 0;          // (per device: common.h)
-    if (first_use_on_this_device(configured)) {
+    if (auto first_use_ = first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_fwd_kernel<K, OT, NT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }

@@ -520,7 +520,7 @@ static int launch_dx_pp(const float* x, long ldx, const float* gy, long ldgy, lo
         return fail(KAGNN_ERR_UNSUPPORTED, "%s: column statistics need <= 64 input features, resident weights and >= 32768 rows", "kan_split_dx");
     const size_t lds = kLdsHdr + (resident ? fpb : 1) * ft_bytes + (XST ? 8 * 128 * sizeof(float) : 0);
     static unsigned long long configured = 0;          // (per device: common.h)
-    if (first_use_on_this_device(configured)) {
+    if (auto first_use_ = first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_kernel<K, Q2, GEN, PP, GX16, BNB, XAFF, XST, HALF>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     }
@@ -785,7 +785,7 @@ static int launch_dx_w2(const float* x, long ldx, const float* gy, long ldgy, lo
                         const float* knots, int nknots, const unsigned char* pack, float* gx, long ldgx, hipStream_t st) {
     const size_t lds = kLdsHdr + (size_t)(kCTmax + NS1) * Q2 * 2 * 1024;       // window 0's 9 slots + window 1's NS1 (two regions)
     static unsigned long long configured = 0;          // (per device: common.h)
-    if (first_use_on_this_device(configured)) {
+    if (auto first_use_ = first_use_on_this_device(configured)) {
         KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dx_w2_kernel<Q2, NS1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     }
     kan_split_dx_w2_kernel<Q2, NS1><<<(unsigned)min((long)cdiv(N, 256), 256L), 512, lds, st>>>(x, ldx, gy, ldgy, N, in, out, C, knots, nknots,
@@ -1890,7 +1890,7 @@ int kan_split_dw_any(const float* x, long ldx, const float* gy, long ldgy, long 
         const int SHn = p.OC % 4 == 0 ? 4 : 2;
 #define LS(KK, SS) do { \
             static unsigned long long seen_##KK##_##SS = 0; \
-            if (first_use_on_this_device(seen_##KK##_##SS)) \
+            if (auto first_use_ = first_use_on_this_device(seen_##KK##_##SS)) \
                 KAGNN_HIP(hipFuncSetAttribute((const void*)kan_split_dw_shared_kernel<KK, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwShLds)); \
             kan_split_dw_shared_kernel<KK, SS><<<grid, 256, kDwShLds, st>>>(x, ldx, gy, ldgy, N, in, out, Ck, knots, nk, p.OC, p.rpw, p.inP, p.outP, slab, rb); } while (0)
         if (K == 0) { if (SHn == 4) LS(0, 4); else LS(0, 2); }

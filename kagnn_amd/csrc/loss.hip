@@ -303,7 +303,7 @@ int xent_fwd(const float* z, long ld, long N, int C, const long* y, const unsign
     if (C <= 64 && N > 0) {
         nb = (int)min((long)cdiv(N, 256), 4096L);
         static unsigned long long big_lds = 0;                     // 256 rows x 65 floats is just over the 64 KB default
-        if (first_use_on_this_device(big_lds)) {
+        if (auto first_use_ = first_use_on_this_device(big_lds)) {
             KAGNN_HIP(hipFuncSetAttribute((const void*)xent_fwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
             KAGNN_HIP(hipFuncSetAttribute((const void*)xent_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
         }

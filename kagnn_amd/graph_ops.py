@@ -11,7 +11,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from .ops import (PREC_FP32, GraphIndex, _batchnorm_fwd_raw, _call, _fits32, _kan_bwd_input_raw, _kan_bwd_weight_raw, _kan_fwd_raw, _ld,
+from .ops import (PREC_FP32, GraphIndex, _same_knots, _batchnorm_fwd_raw, _call, _fits32, _kan_bwd_input_raw, _kan_bwd_weight_raw, _kan_fwd_raw, _ld,
                   _need_cuda, _on_operand_device, _ptr, _ptr_array, _rows, _segment_broadcast_raw, _segment_pool_raw, _sizes, _stream,
                   _weights_key, _ws, default_precision, graph_index, kan_pack_chain, split_like)
 
@@ -244,6 +244,7 @@ def _gine_stack_plan(x, convs, bns):
     H = x.size(1)
     first = None
     nl = None
+    all_layers = []
     for conv, bn in zip(convs, bns):
         layers = list(getattr(conv.nn, "layers", []))
         if nl is None:
@@ -254,10 +255,15 @@ def _gine_stack_plan(x, convs, bns):
             first = layers[0]
         for l in layers:
             if (l.in_features != H or l.out_features != H or l.precision != first.precision or l.grid_size != first.grid_size
-                    or l.spline_order != first.spline_order or l._knots().dim() != 1):
+                    or l.spline_order != first.spline_order or not l.enable_standalone_scale_spline):
                 return None
+        all_layers += layers
         if not (bn.training and bn.affine and bn.num_features == H):
             return None
+    #  ONE knot vector for every layer of every convolution, verified -- not assumed from the first layer
+    knots = [l._knots() for l in all_layers]
+    if any(k.dim() != 1 or k.numel() != knots[0].numel() for k in knots) or not _same_knots(all_layers, knots):
+        return None
     mode = first.precision if first.precision is not None else default_precision()
     if not split_like(mode) or first.spline_order != 3 or first.grid_size + first.spline_order > 8 or H > 64 or len(convs) * nl > 16:
         return None
@@ -316,7 +322,12 @@ def gine_kan_layer(x, edge_attr, g: "GraphIndex", self_scale: float, net, batch_
     if not split_like(mode) or first.grid_size + first.spline_order > 16:
         return None
     if any(l.precision != first.precision or l.grid_size != first.grid_size or l.spline_order != first.spline_order
-           or l._knots().dim() != 1 for l in layers):
+           or not l.enable_standalone_scale_spline for l in layers):
+        return None
+    #  the library evaluates the whole chain on ONE knot vector: layers with uniform but different grids (another
+    # grid_range, update_grid with grid_eps = 1) must not be folded onto the first layer's -- the guards of ops.gin_kan_layer
+    knots = [l._knots() for l in layers]
+    if any(k.dim() != 1 or k.numel() != knots[0].numel() for k in knots) or not _same_knots(layers, knots):
         return None
     if max(max(l.in_features, l.out_features) for l in layers) > 7680:
         return None
@@ -328,7 +339,7 @@ def gine_kan_layer(x, edge_attr, g: "GraphIndex", self_scale: float, net, batch_
         factor, use_running = batch_norm.step()
         bn = (batch_norm.weight, batch_norm.bias, batch_norm.running_mean if use_running else None,
               batch_norm.running_var if use_running else None, factor, batch_norm.eps)
-    return _GineKanLayerFn.apply(x, edge_attr, g, float(self_scale), first._knots(), first.grid_size, first.spline_order, mode, *bn, *params)
+    return _GineKanLayerFn.apply(x, edge_attr, g, float(self_scale), knots[0], first.grid_size, first.spline_order, mode, *bn, *params)
 
 
 
@@ -424,14 +435,36 @@ class _KaginModelFn(Function):
             y, pd = _kan_fwd_raw(acts[-1], bw_c, sw_c, sc_c, plan.ro_knots[i], plan.ro_G, plan.ro_K, plan.ro_modes[i],
                                  None if packs is None else packs[i], _weights_key(bw, sw, sc) if packs is not None else None)
             acts.append(y); pds.append(pd); kept.append((sw_c, sc_c))
-        ctx.state = (plan, g, seg, xi, ashapes, ei, bshapes, st, acts, pds, kept, h.size(0))
+        #  everything the backward reads goes through save_for_backward (autograd's in-place checks on weights and
+        # activations apply, a retained graph can run twice) and the OUTPUT is not among it: acts[-1] in the state made an
+        # output -> grad_fn -> state -> output cycle that kept a step's whole activation set alive until the cyclic collector ran
+        flat_kept = []
+        for sw_c, sc_c in kept:
+            flat_kept += [sw_c, sc_c]
+        tensors = [xi, ei, st.xg, st.ea, st.acts_all, st.h_all, st.stats, st.packs, st.knots, *st.bnw, *st.sws, *st.scs,
+                   *acts[:-1], *pds, *flat_kept]
+        ctx.save_for_backward(*tensors)
+        ctx.meta = (plan, g, seg, ashapes, bshapes, h.size(0), len(st.bnw), len(st.sws),
+                    (st.g, st.self_scales, st.G, st.K, st.mode, st.nconv, st.nl, st.H, st.fb, st.db))
         return acts[-1]
 
     @staticmethod
     @once_differentiable
     @_on_operand_device
     def backward(ctx, gout):
-        plan, g, seg, xi, ashapes, ei, bshapes, st, acts, pds, kept, n = ctx.state
+        plan, g, seg, ashapes, bshapes, n, nbn, nsw, stmeta = ctx.meta
+        t = ctx.saved_tensors
+        st = _StackState()
+        st.g, st.self_scales, st.G, st.K, st.mode, st.nconv, st.nl, st.H, st.fb, st.db = stmeta
+        xi, ei, st.xg, st.ea, st.acts_all, st.h_all, st.stats, st.packs, st.knots = t[:9]
+        o = 9
+        st.bnw = t[o:o + nbn]; o += nbn
+        st.sws = t[o:o + nsw]; o += nsw
+        st.scs = t[o:o + nsw]; o += nsw
+        nr = plan.n_readout
+        acts = t[o:o + nr]; o += nr
+        pds = t[o:o + nr]; o += nr
+        kept = [(t[o + 2 * i], t[o + 2 * i + 1]) for i in range(nr)]
         gy = _rows(gout)
         ro_grads = [None] * (3 * plan.n_readout)
         for i in reversed(range(plan.n_readout)):

@@ -165,7 +165,48 @@ def _ctypes_arrays(n: int):
     return ctypes.c_void_p * n, ctypes.c_int64 * n
 
 
-def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr: float = 1e-3, optimizer=None):
+class GradientReplicas:
+    """Data-parallel replicas of a mini-batch training loop ("replicas only ... a gradient all-reduce of <= a few
+    MB" -- BASELINE config 4: every rank trains the same model on its own mini-batches; the reference loop is
+    ``graph_regression/optuna_zinc.py:56-66`` on one device).  ONE flat all-reduce per step, between ``backward()`` and
+    ``optimizer.step()``: the ranks' gradients are concatenated into one buffer, summed (RCCL), and ``p.grad`` of every parameter
+    becomes a view of the result.  The 1/P of the mean over the global batch is folded into the upstream gradient of the loss
+    (``scale()``), so the all-reduce is a plain sum and no extra pass touches the gradients.  Parameters are broadcast from
+    rank 0 at construction; equal updates keep them equal (the optimiser state is replicated, not communicated)."""
+
+    def __init__(self, params, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.params = [p for p in params if p.requires_grad]
+        for p in self.params:
+            dist.broadcast(p.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self._flat = None
+        self._scale = None
+
+    def scale(self, like: torch.Tensor) -> torch.Tensor:
+        """the upstream gradient ``1 / world`` of this rank's loss (``loss.backward(replicas.scale(loss))``)"""
+        if self._scale is None or self._scale.device != like.device or self._scale.dtype != like.dtype:
+            self._scale = torch.full((), 1.0 / self.world, dtype=like.dtype, device=like.device)
+        return self._scale
+
+    def sync(self) -> None:
+        """sum the gradients of this step over the ranks: one ``torch.cat``, one all-reduce, views back"""
+        import torch.distributed as dist
+        live = [p for p in self.params if p.grad is not None]
+        if not live:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in live])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for p in live:
+            n = p.numel()
+            p.grad = flat[off:off + n].view_as(p)
+            off += n
+
+
+def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr: float = 1e-3, optimizer=None, group=None,
+                        loss_fn=None):
     """The mini-batch training loop of the reference's graph-regression scripts (``graph_regression/optuna_zinc.py:56-66``: Adam,
     L1 loss, ``{zero_grad, loss(model(data).squeeze(), data.y), backward, step}`` per batch) over ``batches`` -- objects with
     ``x, edge_index, edge_attr, batch, y`` (``num_graphs`` / ``ptr`` when the loader supplies them) already on the device.
@@ -176,12 +217,21 @@ def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr:
     * the loss is ``ops.l1_loss`` (the same mean absolute error, the same gradient bits; its forward sum runs in another order);
     * the running loss is accumulated ON THE DEVICE and read once per epoch -- the script's ``loss.item()`` per batch drains the
       stream every step, which on a step of ~1 ms of device work is the difference between the host running ahead of the GPU
-      and waiting for it."""
+      and waiting for it.
+    ``group`` (a torch.distributed process group, or ``True`` for the default one): data-parallel REPLICAS -- ``batches`` are this
+    rank's own; every step ends in ONE flat gradient all-reduce (``GradientReplicas``), i.e. the step of the script on the
+    P-times larger batch that the ranks' batches form together (except that BatchNorm statistics stay per replica, as in
+    torch's DistributedDataParallel).  The returned loss is this rank's."""
+    replicas = None
+    if group is not None:
+        replicas = GradientReplicas(model.parameters(), None if group is True else group)
     if optimizer is None:
         optimizer = Adam(model.parameters(), lr=lr)            # torch.optim.Adam's rule, one library call per step
-    from . import ops
-    loss_fn = ops.l1_loss              # = torch.nn.L1Loss() (mean |p - t|), one launch each way instead of six
+    from . import ops as ops_mod
+    if loss_fn is None:
+        loss_fn = ops_mod.l1_loss      # = torch.nn.L1Loss() (mean |p - t|), one launch each way instead of six
     model.train()
+    on_gpu = any(p.is_cuda for p in model.parameters())
 
     def epoch():
         total = None
@@ -189,7 +239,11 @@ def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr:
         for data in batches:
             optimizer.zero_grad(set_to_none=True)
             loss = loss_fn(model(data).squeeze(), data.y.squeeze())
-            loss.backward()
+            if replicas is None:
+                loss.backward()
+            else:
+                loss.backward(replicas.scale(loss))
+                replicas.sync()
             optimizer.step()
             ng = int(getattr(data, "num_graphs", 0) or data.y.size(0))
             if total is None:
@@ -197,14 +251,18 @@ def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr:
             else:
                 total.add_(loss.detach(), alpha=ng)
             graphs += ng
+        if on_gpu:
+            ops_mod.flush_graph_checks()       # the epoch's deferred node-id range checks (incl. the LAST batch's): one wait per epoch
         return total / max(graphs, 1)
 
     for _ in range(warmup):
         epoch()
-    torch.cuda.synchronize()
+    if on_gpu:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     means = [epoch() for _ in range(nb_epochs)]
-    torch.cuda.synchronize()
+    if on_gpu:
+        torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / max(1, nb_epochs * len(batches))
     return float(dt), [float(m) for m in means]
 

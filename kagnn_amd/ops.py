@@ -352,6 +352,25 @@ def _validate_pending(dev) -> None:
             raise RuntimeError("kagnn_csr_build_small: an edge_index indexed earlier held node ids outside [0, num_nodes)")
 
 
+def flush_graph_checks(device=None) -> None:
+    """WAIT for the deferred node-id range checks of every small graph indexed so far (``graph_index(cache=False)``:
+    ``kagnn_csr_build_small`` clamps out-of-range ids and raises a flag that is otherwise only looked at when a LATER graph is
+    indexed) and raise if any failed.  Call it at a natural synchronisation point -- the end of an epoch or an evaluation loop,
+    before reading outputs back on the host (the last batch of a loop, or a single inference call, was never
+    validated).  ``harness.train_graph_batches`` does so at the end of every epoch."""
+    devs = list(_pending_checks) if device is None else [torch.device(device).index]
+    bad = False
+    for d in devs:
+        for en in _pending_checks.get(d) or []:
+            try:
+                _check_flags(en, True)
+            except RuntimeError:
+                bad = True
+        _pending_checks[d] = []
+    if bad:
+        raise RuntimeError("kagnn_csr_build_small: an edge_index indexed earlier held node ids outside [0, num_nodes)")
+
+
 _graph_cache: "dict[tuple, GraphIndex]" = {}
 _GRAPH_CACHE_MAX = 8
 

@@ -362,6 +362,107 @@ def test_sharded_fastkan_layer_and_node_models_gloo(tmp_path, world, f, hid):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
+def _small_graph_batches(seed, nb, B=6, n_atom=21, n_bond=4):
+    """ZINC-shaped mini-batches (categorical atom / bond features, a few small graphs each), as types.SimpleNamespace"""
+    from types import SimpleNamespace
+    out = []
+    for k in range(nb):
+        g = torch.Generator().manual_seed(seed + k)
+        sizes = torch.randint(5, 12, (B,), generator=g)
+        n = int(sizes.sum()); off = torch.cumsum(sizes, 0) - sizes
+        src, dst, batch = [], [], []
+        for b in range(B):
+            m = int(sizes[b]); eb = 2 * m + 2
+            src.append(torch.randint(0, m, (eb,), generator=g) + off[b]); dst.append(torch.randint(0, m, (eb,), generator=g) + off[b])
+            batch.append(torch.full((m,), b))
+        e = sum(len(t) for t in src)
+        x = torch.randint(0, n_atom, (n, 1), generator=g)
+        out.append(SimpleNamespace(x=x, edge_index=torch.stack([torch.cat(src), torch.cat(dst)]), edge_attr=torch.randint(0, n_bond, (e,), generator=g),
+                                   batch=torch.cat(batch), num_graphs=B, y=x.float().mean() + torch.randn(B, generator=g) * 0.1))
+    return out
+
+
+class _OracleKAGIN(torch.nn.Module):
+    """test stand-in for kagnn_amd.KAGINRegression on CPU: the same parameters (a reference-keyed state dict), forward through
+    ``oracle.graph_regression_forward`` + stock autograd.  What is under test is harness.train_graph_batches(group=)."""
+
+    def __init__(self, state, gnn_layers):
+        super().__init__()
+        self.names = [k for k, v in state.items() if v.is_floating_point() and not k.endswith(("grid", "running_mean", "running_var", "eps"))]
+        self.params = torch.nn.ParameterList([torch.nn.Parameter(state[k].clone()) for k in self.names])
+        self.fixed = {k: v.clone() for k, v in state.items() if k not in self.names}
+        self.gnn_layers = gnn_layers
+
+    def forward(self, d):
+        from oracle import kan_oracle as orc
+        st = dict(self.fixed)
+        st.update({k: p for k, p in zip(self.names, self.params)})
+        ea = d.edge_attr if d.edge_attr.dim() == 2 else d.edge_attr.view(-1, 1)
+        return orc.graph_regression_forward(d.x, d.edge_index, ea, d.batch, d.num_graphs, st, "kan", self.gnn_layers)
+
+
+def _worker_replicas(rank, world, port, out_dir):
+    """SURVEY 8(e) "replicas only" (BASELINE config 4): every rank its own mini-batches, ONE flat gradient all-reduce per step
+    (VERDICT r05 row e2 c; reference loop graph_regression/optuna_zinc.py:56-66) -- against the same loop written out on one
+    process with the gradients of all ranks' batches averaged by hand."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kagnn_amd
+        from kagnn_amd.harness import train_graph_batches
+        H, L, steps = 8, 2, 3
+        torch.manual_seed(4)
+        proto = kagnn_amd.KAGINRegression(1, 1, L, H, 2, 4, 3, 1, 0.0, True)
+        proto.atom_encoder = kagnn_amd.graph_models.AtomEncoder(H, [21])
+        proto.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, H)])
+        state = {k: v.detach().clone() for k, v in proto.state_dict().items()}
+        all_batches = [_small_graph_batches(100 * r, steps) for r in range(world)]
+        # this rank starts from DIFFERENT parameters: the constructor's broadcast from rank 0 has to repair that
+        mine = _OracleKAGIN(state, L)
+        with torch.no_grad():
+            for p_ in mine.parameters():
+                p_.add_(0.01 * rank)
+        opt = torch.optim.Adam(mine.parameters(), lr=5e-3)
+        _, means = train_graph_batches(mine, all_batches[rank], nb_epochs=2, lr=5e-3, optimizer=opt, group=True, loss_fn=torch.nn.L1Loss())
+        # the same loop by hand on one process: per step the mean of the ranks' gradients
+        ref = _OracleKAGIN(state, L)
+        ropt = torch.optim.Adam(ref.parameters(), lr=5e-3)
+        ref.train()
+        for _ in range(2):
+            for k in range(steps):
+                grads = None
+                for r in range(world):
+                    ropt.zero_grad(set_to_none=True)
+                    d = all_batches[r][k]
+                    torch.nn.L1Loss()(ref(d).squeeze(), d.y.squeeze()).backward()
+                    g = [p.grad.clone() for p in ref.parameters()]
+                    grads = g if grads is None else [a + b for a, b in zip(grads, g)]
+                for p, g in zip(ref.parameters(), grads):
+                    p.grad = g / world
+                ropt.step()
+        for (name, a), b in zip(zip(mine.names, mine.params), ref.params):
+            err = float((a - b).abs().max()) / max(1e-12, float(b.abs().max()))
+            assert err < 2e-5, (name, err)
+        # replicas stay bit-identical: same reduced gradients, same optimiser state
+        flat = torch.cat([p.detach().reshape(-1) for p in mine.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], t) for t in gathered[1:])
+        assert all(m == m for m in means)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_graph_level_replicas_one_flat_gradient_all_reduce_gloo(tmp_path, world):
+    mp.spawn(_worker_replicas, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
 # ---------------------------------------------------------------------------------------------------------
 # the same two sharded layers with the PRODUCT's local ops (HIP kernels): two ranks share cuda:0, collectives
 # over gloo -- checks the sharding algebra end to end against the unsharded layer on the same device
@@ -471,6 +572,177 @@ def _gpu_worker(rank, world, port, out_dir, backend="gloo", f=16, big=True):
         dist.destroy_process_group()
 
 
+def _gpu_worker_e2(rank, world, port, out_dir, f=32, hid=32, classes=10):
+    """the exchanges of _worker_e2 / _worker_replicas with the PRODUCT's local ops: `world` processes sharing cuda:0 (collectives
+    over gloo), HIP kernels as local compute, against the unsharded modules on the same device"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kagnn_amd
+        from kagnn_amd import ops
+        from kagnn_amd.sharded import ShardedGIFASTKANLayer, ShardedNodeModel
+        from oracle import kan_oracle as orc
+        n, e = 3001, 30000
+        ei = orc.powerlaw_graph(n, e, seed=5).to(dev)
+        gen = torch.Generator().manual_seed(5)
+        x = (torch.randn(n, f, generator=gen) * 0.3 + 0.5).to(dev)
+        gy = torch.randn(n, f, generator=gen).to(dev)
+        graph = ops.GraphIndex(ei, n)
+        w = f // world
+        sl = slice(rank * w, (rank + 1) * w)
+
+        def close(a, b, what, tol=1e-4):
+            err = float((a - b).abs().max()) / max(1e-300, float(b.abs().max()))
+            assert err <= tol, (what, err)
+
+        # ---- (a) the feature-sharded FastKAN-GIN layer, both precision modes, 1 and 3 row chunks
+        for mode in (ops.PREC_SPLIT, ops.PREC_FP32):
+            torch.manual_seed(11)
+            conv = kagnn_amd.GIFASTKANLayer(f, f, grid_size=5, hidden_dim=hid, nb_layers=2)
+            with torch.no_grad():
+                for l in conv.nn.layers:
+                    l.layernorm.weight.uniform_(0.5, 1.5); l.layernorm.bias.uniform_(-0.3, 0.3); l.base_linear.bias.uniform_(-0.5, 0.5)
+                    l.precision = mode
+            conv = conv.to(dev)
+            xr = x.clone().requires_grad_(True)
+            y_ref = conv(xr, graph)
+            y_ref.backward(gy)
+            for chunks in (1, 3):
+                sconv = ShardedGIFASTKANLayer(conv, None, chunks=chunks).to(dev)
+                for step in range(2):                      # twice: the side stream / workspace reuse across steps
+                    xs = sconv.shard_columns(x).requires_grad_(True)
+                    sconv.zero_grad()
+                    y = sconv(xs, graph)
+                    y.backward(sconv.shard_columns(gy))
+                tag = f"fastkan mode {mode} chunks {chunks}"
+                close(y, y_ref[:, sl], tag + " y")
+                close(xs.grad, xr.grad[:, sl], tag + " gx")
+                for li, (layer, full) in enumerate(zip(sconv.layers, conv.nn.layers)):
+                    cols, ng = layer.columns, layer.centers.numel()
+                    close(layer.ln_weight.grad, full.layernorm.weight.grad[cols], f"{tag} L{li} ln_w")
+                    close(layer.ln_bias.grad, full.layernorm.bias.grad[cols], f"{tag} L{li} ln_b")
+                    fo = full.output_dim
+                    close(layer.spline_weight.grad, full.spline_linear.weight.grad.view(fo, -1, ng)[:, cols].reshape(fo, -1), f"{tag} L{li} spline")
+                    close(layer.base_weight.grad, full.base_linear.weight.grad[:, cols], f"{tag} L{li} base_w")
+                    if rank == 0:
+                        close(layer.base_bias.grad, full.base_linear.bias.grad, f"{tag} L{li} base_b")
+
+        # ---- (b) whole node models on column shards against the unsharded models (fused epilogue paths and all)
+        labels = torch.randint(0, classes, (n,), generator=gen).to(dev)
+        for arch in ("kan", "fastkan"):
+            torch.manual_seed(12)
+            if arch == "kan":
+                model = kagnn_amd.GKAN_Nodes("gin", 2, f, hid, classes, grid_size=4, spline_order=3, hidden_layers=2)
+            else:
+                model = kagnn_amd.GFASTKAN_Nodes("gin", 2, f, hid, classes, grid_size=4, hidden_layers=2)
+            with torch.no_grad():
+                for bn in model.bns:
+                    bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+            model = model.to(dev).train()
+            sm = ShardedNodeModel(model, None, chunks=2).to(dev).train()       # (built BEFORE the reference step: same running statistics)
+            xr = x.clone().requires_grad_(True)
+            out = model(xr, graph)
+            ops.softmax_cross_entropy(out, labels, None, pre_softmax=True).backward()
+            xs = sm.shard_columns(x).requires_grad_(True)
+            logits = sm(xs, graph)
+            close(logits, out, f"{arch} logits")
+            ops.softmax_cross_entropy(logits, labels, None, pre_softmax=True).backward()   # every rank: the loss on the full logits
+            close(xs.grad, xr.grad[:, sl], f"{arch} gx", 2e-4)
+            for ci, (sc, fc) in enumerate(zip(sm.convs, model.convs)):
+                for li, (layer, full) in enumerate(zip(sc.layers, fc.nn.layers)):
+                    cols = layer.columns
+                    if arch == "kan":
+                        for name in ("base_weight", "spline_weight", "spline_scaler"):
+                            close(getattr(layer, name).grad, getattr(full, name).grad[:, cols], f"{arch} convs.{ci}.{li}.{name}", 2e-4)
+                    else:
+                        ng, fo = layer.centers.numel(), full.output_dim
+                        close(layer.spline_weight.grad, full.spline_linear.weight.grad.view(fo, -1, ng)[:, cols].reshape(fo, -1), f"{arch} convs.{ci}.{li}.spline", 2e-4)
+                        close(layer.ln_weight.grad, full.layernorm.weight.grad[cols], f"{arch} convs.{ci}.{li}.ln_w", 2e-4)
+            hw = hid // world
+            for bi, (sb, fb) in enumerate(zip(sm.bns, model.bns)):
+                close(sb.weight.grad, fb.weight.grad[rank * hw:(rank + 1) * hw], f"{arch} bns.{bi}.weight", 2e-4)
+                close(sb.bias.grad, fb.bias.grad[rank * hw:(rank + 1) * hw], f"{arch} bns.{bi}.bias", 2e-4)
+                close(sb.running_mean, fb.running_mean[rank * hw:(rank + 1) * hw], f"{arch} bns.{bi}.running_mean")
+                close(sb.running_var, fb.running_var[rank * hw:(rank + 1) * hw], f"{arch} bns.{bi}.running_var")
+            cols = sm.lay_out.columns
+            if arch == "kan":
+                for name in ("base_weight", "spline_weight", "spline_scaler"):
+                    close(getattr(sm.lay_out, name).grad, getattr(model.lay_out, name).grad[:, cols], f"{arch} lay_out.{name}", 2e-4)
+            else:
+                ng = sm.lay_out.centers.numel()
+                close(sm.lay_out.spline_weight.grad, model.lay_out.spline_linear.weight.grad.view(classes, -1, ng)[:, cols].reshape(classes, -1),
+                      f"{arch} lay_out.spline", 2e-4)
+                close(sm.lay_out.ln_weight.grad, model.lay_out.layernorm.weight.grad[cols], f"{arch} lay_out.ln_w", 2e-4)
+
+        # ---- (c) BASELINE config 4 as data-parallel replicas: every rank its own ZINC-shaped mini-batches, ONE flat gradient
+        # all-reduce per step, harness.Adam -- against the same steps on one process with the ranks' gradients averaged by hand
+        from kagnn_amd.harness import Adam, train_graph_batches
+        H, L, steps = 32, 2, 3
+
+        def make():
+            torch.manual_seed(13)
+            m = kagnn_amd.KAGINRegression(1, 1, L, H, 2, 4, 3, 1, 0.0, True)
+            m.atom_encoder = kagnn_amd.graph_models.AtomEncoder(H, [21])
+            m.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, H)])
+            return m.to(dev)
+        all_batches = []
+        for r in range(world):
+            bs = _small_graph_batches(200 * r + 7, steps, B=24)
+            for b in bs:
+                for k in ("x", "edge_index", "edge_attr", "batch", "y"):
+                    setattr(b, k, getattr(b, k).to(dev))
+            all_batches.append(bs)
+        mine = make()
+        with torch.no_grad():
+            for p_ in mine.parameters():
+                p_.add_(0.01 * rank)                       # (the constructor's broadcast from rank 0 has to repair this)
+        _, means = train_graph_batches(mine, all_batches[rank], nb_epochs=2, lr=5e-3, group=True)
+        ref = make()
+        # (rank 0's construction is THE model: the spline-weight init is a CPU lstsq whose last bit is not reproducible)
+        for p_ in ref.parameters():
+            dist.broadcast(p_.data, src=0)
+        ropt = Adam(ref.parameters(), lr=5e-3)
+        ref.train()
+        for _ in range(2):
+            for k in range(steps):
+                grads = None
+                for r in range(world):
+                    ropt.zero_grad()
+                    d = all_batches[r][k]
+                    ops.l1_loss(ref(d).squeeze(), d.y.squeeze()).backward()
+                    g = [p_.grad.clone() for p_ in ref.parameters()]
+                    grads = g if grads is None else [a + b for a, b in zip(grads, g)]
+                for p_, g in zip(ref.parameters(), grads):
+                    p_.grad = g / world
+                ropt.step()
+        for (name, a), b in zip(mine.named_parameters(), ref.parameters()):
+            # (the all-reduce sums g_r / P in another association than the hand average, and Adam divides by sqrt(v): on elements whose
+            # gradient is tiny a rounding-level difference becomes a visible fraction of an lr-sized update; first-step gradients are
+            # compared to the bit by the CPU test)
+            close(a, b, f"replicas {name}", 3e-3)
+        flat = torch.cat([p_.detach().reshape(-1) for p_ in mine.parameters()]).cpu()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], t) for t in gathered[1:]), "replicas diverged"
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_fastkan_node_models_and_replicas_ranks_on_one_gpu(tmp_path, world):
+    """VERDICT r05 row e2 on the HIP kernels: feature-sharded FastKAN-GIN layer (kagnn_fastkan_row_moments / _merge_moments /
+    _shard_fwd / _shard_bwd / _shard_bwd_finish), sharded GKAN_Nodes / GFASTKAN_Nodes steps, and config 4's replicas with one flat
+    gradient all-reduce -- 2 and 4 processes sharing cuda:0"""
+    mp.spawn(_gpu_worker_e2, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
 @pytest.mark.gpu
 def test_sharded_layers_two_ranks_one_gpu(tmp_path):
     with socket.socket() as s:
@@ -515,7 +787,7 @@ def test_sharded_layers_two_ranks_two_gpus_rccl(tmp_path):
 # the collectives on gloo (KAGNN_BENCH_BACKEND=gloo: numbers meaningless, control flow real): the combination loop, the
 # reporter process that owns THE line, and the watchdog -- none of the N > 1 transports has ever run on two devices, so
 # the line must survive one that hangs and one that takes a rank down (KAGNN_BENCH_FAULT)
-def _run_bench_two_ranks(extra_env, timeout=420, nproc=2):
+def _run_bench_two_ranks(extra_env, timeout=420, nproc=2, workload=None):
     import json
     import subprocess
     with socket.socket() as s:
@@ -524,7 +796,7 @@ def _run_bench_two_ranks(extra_env, timeout=420, nproc=2):
     env = dict(os.environ, KAGNN_BENCH_BACKEND="gloo", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
-           "--nodes", "20000", "--edges", "200000"]
+           "--nodes", "20000", "--edges", "200000"] + (["--workload", workload] if workload else [])
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
@@ -577,3 +849,19 @@ def test_bench_four_ranks_one_gpu_runs_every_combination():
     for k in (("feature", "rccl"), ("transposed", "rccl"), ("feature", "p2p"), ("transposed", "p2p")):
         assert "error" not in combos[k] and combos[k]["ms_per_step"] > 0, combos[k]
     assert line["n_gpus"] == 4 and line["complete"] is True and line["value_scheme_is_north_star"] is True and len(line["per_rank"]) == 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["fastkan", "model"])
+def test_bench_two_ranks_fastkan_and_model_workloads(workload):
+    """`bench.py --gpus N --workload fastkan|model` produce a complete line under the watchdog (two ranks on
+    cuda:0, collectives on gloo): the feature-sharded FastKAN-GIN layer and the whole GKAN_Nodes training step on column shards"""
+    rc, line, err = _run_bench_two_ranks({}, workload=workload)
+    assert rc == 0, err[-3000:]
+    assert line["complete"] is True and line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["config"]["workload"].startswith(workload) and line["value_scheme_is_north_star"] is True
+    combos = line["multi_gpu_probe"]["combinations"]
+    assert len(combos) == 1 and "error" not in combos[0], combos
+    assert line["roofline"]["frac"] > 0 and len(line["per_rank"]) == 2
+    if workload == "model":
+        assert abs(line["value"] - 3 * 200000 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]

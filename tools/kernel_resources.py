@@ -52,7 +52,10 @@ def _run(*cmd: str) -> str:
 def _device_code_object(obj: str, tmp: str) -> str:
     fat = os.path.join(tmp, os.path.basename(obj) + ".fatbin")
     co = os.path.join(tmp, os.path.basename(obj) + ".co")
-    r = subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj], capture_output=True)
+    # (an explicit output operand: without one llvm-objcopy re-emits `obj` IN PLACE -- a test then bumped the mtime of every
+    # build object and the next build() relinked both libraries)
+    r = subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj, os.path.join(tmp, "discard.o")],
+                       capture_output=True)
     if r.returncode != 0:            # a translation unit without device code (the C-ABI dispatcher)
         return ""
     subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
