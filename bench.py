@@ -268,11 +268,14 @@ def secondary_figures(dev, conv, graph, x, n, e, f, grid, order):
                                  hidden_layers=2).to(dev)
     y = torch.randint(0, classes, (n,), generator=torch.Generator().manual_seed(2)).to(dev)
     mask = torch.ones(n, dtype=torch.bool, device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
     t_step, _ = harness.time_model(model, x.detach(), graph, y, mask, nb_epochs=5, warmup=2)
+    model_peak = torch.cuda.max_memory_allocated()
     out["model_step"] = {"what": f"GKAN_Nodes(gin, 3 conv layers, hidden {f}, {classes} classes, skip, BatchNorm) training step "
                                  "(forward, softmax + cross-entropy, backward, Adam), time_model.py:35-48",
                          "ms_per_step": t_step * 1e3, "edges_per_s": 3 * e / t_step,
-                         "conv_layers_share": None}
+                         "conv_layers_share": None, "peak_device_GB": model_peak / 1e9}
     return out
 
 
@@ -729,8 +732,12 @@ def main():
         ROOFLINE_STAGES = ("kagnn_aggregate_sum",)
     cand = {k: v for k, v in warm.items() if k in ROOFLINE_STAGES}
     only = max(cand, key=lambda k: cand[k]["total_ms"]) if cand else None
+    torch.cuda.synchronize()
+    resident_bytes = torch.cuda.memory_allocated()          # graph (CSR + transpose), x, gy / labels, parameters, optimiser state
+    torch.cuda.reset_peak_memory_stats()
     with ops.LibraryStageTimer(only):
         dt = timed(step, args.steps)
+    peak_bytes = torch.cuda.max_memory_allocated()          # (the memory contract, SURVEY 7.3: the reference needs 45.1 GB RSS at 1M / 64)
     prof_live = ops.LibraryStageTimer.collect()
     if dog is not None:
         dog.phase("per-rank gather", 60.0)
@@ -857,6 +864,13 @@ def main():
                           else "the node model's default path (fused conv + norm nodes, lazy norms, one-launch skip read-out)" if world == 1 and model_wl
                           else "per-operation entry points (sharded / FastKAN layers)",
             # one-time per edge_index (cached on its identity); outside the timed region
+            # device memory over the timed region (torch.cuda.max_memory_allocated; this rank): everything resident before the step
+            # (graph index, inputs, parameters) and the step's own peak on top -- saved activations are the layer INPUTS only
+            "peak_device_GB": peak_bytes / 1e9,
+            "device_memory": {"resident_before_step_GB": resident_bytes / 1e9, "step_peak_over_resident_GB": (peak_bytes - resident_bytes) / 1e9,
+                              "activation_matrix_GB": n * f * 4 / 1e9,
+                              "reference_cpu_rss_GB": 45.1 if (args.workload == "headline" and n == 1_000_000) else None,
+                              "how": "torch.cuda.max_memory_allocated() around the timed region; reference figure: BASELINE.md section 2"},
             "graph_index_build_ms": {"steady": graph_build_ms, "first_call": graph_build_first_ms,
                                      "what": "CSR by destination + its transpose (stable radix sort, hub segments), int64 edge_index already in HBM"},
         })

@@ -310,6 +310,46 @@ def graph_regression_forward(x: Tensor, edge_index: Tensor, edge_attr: Tensor, b
     return chain("kan.", global_add_pool(h, batch, num_graphs))
 
 
+def graph_classification_forward(x: Tensor, edge_index: Tensor, batch: Tensor, num_graphs: int, state: dict, arch: str,
+                                 family: str, gnn_layers: int, spline_order: int = 3, bn_eps: float = 1e-5) -> Tensor:
+    """The graph-CLASSIFICATION callers of the hot path, ``graph_classification/models.py``, in TRAINING mode with dropout 0 on a
+    reference-keyed ``state`` dict:
+    ``family='gin'`` -- ``KAGIN.forward`` :107-119 / ``FASTKAGIN.forward`` :141-151: ``gnn_layers x {GINConv(chain) -> BatchNorm1d}``
+    -> ``global_add_pool`` -> chain ``kan`` -> ``log_softmax`` (keys ``conv.{l}.nn.layers.{i}.*``, ``bn.{l}.weight|bias``,
+    ``kan.layers.{i}.*``);
+    ``family='gcn'`` -- ``KAGCN.forward`` :184-194 / ``FASTKAGCN.forward`` :255-265: ``gnn_layers x {GCNConv(lin) -> SiLU}`` ->
+    ``global_mean_pool`` -> one-layer chain ``readout`` -> ``log_softmax`` (keys ``conv.{l}.lin.*``, ``conv.{l}.bias``,
+    ``readout.layers.0.*``).  ``arch``: 'kan' | 'fastkan'.  Runs in the dtype of ``state`` (fp64 for the GPU parity tests)."""
+    kan_keys = ("base_weight", "spline_weight", "spline_scaler", "grid")
+    fk_keys = ("layernorm.weight", "layernorm.bias", "rbf.grid", "spline_linear.weight", "base_linear.weight", "base_linear.bias")
+
+    def one(prefix, h):
+        if arch == "kan":
+            p = {q: state[prefix + q] for q in kan_keys}
+            return kan_linear_forward(h, p["base_weight"], p["spline_weight"], p["spline_scaler"], p["grid"], spline_order)
+        return fastkan_forward(h, [{q: state[prefix + q] for q in fk_keys if prefix + q in state}])
+
+    def chain(prefix, h):
+        n = 1 + max(int(k[len(prefix) + 7:].split(".")[0]) for k in state if k.startswith(prefix + "layers."))
+        for i in range(n):
+            h = one(f"{prefix}layers.{i}.", h)
+        return h
+
+    h = x
+    if family == "gin":
+        for l in range(gnn_layers):
+            eps = float(state[f"conv.{l}.eps"][0]) if f"conv.{l}.eps" in state else 0.0
+            h = gin_conv(h, edge_index, lambda t: chain(f"conv.{l}.nn.", t), eps)
+            mu, var = h.mean(0), h.var(0, unbiased=False)
+            h = (h - mu) / torch.sqrt(var + bn_eps) * state[f"bn.{l}.weight"] + state[f"bn.{l}.bias"]
+        return F.log_softmax(chain("kan.", global_add_pool(h, batch, num_graphs)), dim=1)
+    if family == "gcn":
+        for l in range(gnn_layers):
+            h = F.silu(gcn_conv(h, edge_index, lambda t: one(f"conv.{l}.lin.", t), state[f"conv.{l}.bias"]))
+        return F.log_softmax(chain("readout.", global_mean_pool(h, batch, num_graphs)), dim=1)
+    raise ValueError("family must be 'gin' or 'gcn'")
+
+
 # --------------------------------------------------------------------------------------
 # Node-level models (reference: node_classification_clean/models.py:150-257)
 # --------------------------------------------------------------------------------------

@@ -355,6 +355,112 @@ def g8b():
     save("g8b_zinc_batch", **out)
 
 
+# ---------------------------------------------------------------- G13: the graph-CLASSIFICATION callers
+def _load_graph_classification_layers():
+    """graph_classification/ekan.py and fastkan.py of the reference (the files graph_classification/models.py imports; the same
+    arithmetic as node_classification_clean's, + torch.cuda.empty_cache() calls) under private module names"""
+    import importlib.util
+    mods = []
+    for name in ("ekan", "fastkan"):
+        spec = importlib.util.spec_from_file_location(f"_gc_{name}", f"/root/reference/graph_classification/{name}.py")
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods.append(m)
+    return mods
+
+
+class _RefGraphClassification(torch.nn.Module):
+    """forward of the reference's graph_classification KAGIN / FASTKAGIN / KAGCN / FASTKAGCN (graph_classification/models.py:95-119,
+    125-151, 174-194, 245-265) with the reference's own KAN / FastKAN / KANLinear / FastKANLayer modules and torch's BatchNorm1d
+    under the reference's attribute names; GINConv / GCNConv / global_add_pool / global_mean_pool (torch_geometric, absent here)
+    are the oracle's restatement."""
+
+    def __init__(self, family, kind, gnn_layers, fin, hidden, classes, hidden_layers, grid, order, ek, fk):
+        super().__init__()
+        self.family = family
+
+        def chain(a, b, nl):
+            sizes = [a] + [hidden] * (nl - 1) + [b]
+            return ek.KAN(sizes, grid_size=grid, spline_order=order) if kind == "kan" else fk.FastKAN(sizes, num_grids=grid)
+        self.conv = torch.nn.ModuleList()
+        for i in range(gnn_layers):
+            c = torch.nn.Module()
+            a = fin if i == 0 else hidden
+            if family == "gin":
+                c.nn = chain(a, hidden, hidden_layers)
+                c.register_buffer("eps", torch.zeros(1))
+            else:
+                c.lin = (ek.KANLinear(a, hidden, grid_size=grid, spline_order=order) if kind == "kan"
+                         else fk.FastKANLayer(a, hidden, num_grids=grid))
+                c.bias = torch.nn.Parameter(torch.zeros(hidden))
+            self.conv.append(c)
+        if family == "gin":
+            self.bn = torch.nn.ModuleList(torch.nn.BatchNorm1d(hidden) for _ in range(gnn_layers))
+            self.kan = chain(hidden, classes, hidden_layers)
+        else:
+            self.readout = chain(hidden, classes, 1)
+
+    def forward(self, x, ei, batch, num_graphs):
+        if self.family == "gin":
+            for c, bn in zip(self.conv, self.bn):
+                x = bn(orc.gin_conv(x, ei, c.nn))                              # dropout 0
+            return torch.nn.functional.log_softmax(self.kan(orc.global_add_pool(x, batch, num_graphs)), dim=1)
+        for c in self.conv:
+            x = torch.nn.functional.silu(orc.gcn_conv(x, ei, c.lin, c.bias))
+        return torch.nn.functional.log_softmax(self.readout(orc.global_mean_pool(x, batch, num_graphs)), dim=1)
+
+
+def _classification_batches():
+    """(a) the 16 graphs of G8 with 7 continuous node features (a TU-dataset-like batch); (b) a batch holding an EMPTY graph and
+    a SINGLE-NODE graph (sizes 5, 0, 1, 9, 3; the single node has a self loop and no other edge) -- the pooling edge cases"""
+    gen = torch.Generator().manual_seed(1300)
+    out = []
+    for sizes in ([int(torch.randint(12, 35, (1,), generator=gen)) for _ in range(16)], [5, 0, 1, 9, 3]):
+        xs, eis, batch, off = [], [], [], 0
+        for g, n in enumerate(sizes):
+            if n:
+                e = 1 if n == 1 else int(torch.randint(2 * n, 4 * n, (1,), generator=gen))
+                xs.append(torch.randn(n, 7, generator=gen) * 0.5)
+                eis.append(torch.randint(0, n, (2, e), generator=gen) + off)
+                batch.append(torch.full((n,), g, dtype=torch.int64))
+            off += n
+        out.append((torch.cat(xs), torch.cat(eis, 1), torch.cat(batch), len(sizes)))
+    return out
+
+
+def g13():
+    """KAGIN / FASTKAGIN / KAGCN / FASTKAGCN of graph_classification/models.py on both batches: log-probabilities, d/dx and every
+    parameter gradient under a random upstream gradient (training mode: BatchNorm on batch statistics, dropout 0)."""
+    ek, fk = _load_graph_classification_layers()
+    out = {}
+    for bi, (x, ei, batch, ng) in enumerate(_classification_batches()):
+        out[f"b{bi}.x"], out[f"b{bi}.edge_index"], out[f"b{bi}.batch"], out[f"b{bi}.num_graphs"] = npy(x), npy(ei), npy(batch), np.int64(ng)
+        gen = torch.Generator().manual_seed(1310 + bi)
+        gout = torch.randn(ng, 3, generator=gen)
+        out[f"b{bi}.g_out"] = npy(gout)
+        for name, family, kind, grid in (("KAGIN", "gin", "kan", 4), ("FASTKAGIN", "gin", "fastkan", 5),
+                                         ("KAGCN", "gcn", "kan", 4), ("FASTKAGCN", "gcn", "fastkan", 5)):
+            torch.manual_seed(1320)
+            m = _RefGraphClassification(family, kind, 2, 7, 16, 3, 2, grid, 3, ek, fk).train()
+            with torch.no_grad():
+                for p_name, p_ in m.named_parameters():
+                    if p_name.endswith(".bias") and p_.dim() == 1 and "bn." not in p_name and "layernorm" not in p_name:
+                        p_.uniform_(-0.3, 0.3)                # (GCN conv biases and FastKAN base biases start at ~0: make them matter)
+                if family == "gin":
+                    for bn in m.bn:
+                        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+            for k_, v in m.state_dict().items():
+                out[f"b{bi}.{name}.init.{k_}"] = npy(v)      # BEFORE the step (running statistics untouched)
+            xr = x.clone().requires_grad_(True)
+            y = m(xr, ei, batch, ng)
+            y.backward(gout)
+            out[f"b{bi}.{name}.out"], out[f"b{bi}.{name}.gx"] = npy(y), npy(xr.grad)
+            for p_name, p_ in m.named_parameters():
+                if p_.grad is not None:
+                    out[f"b{bi}.{name}.grad.{p_name}"] = npy(p_.grad)
+    save("g13_graph_classification", **out)
+
+
 # ---------------------------------------------------------------- G9: harness step (2 Adam steps)
 class _RefConv(torch.nn.Module):
     """reference KAN modules inside the restated GIN / GCN message passing, with the attribute names of
@@ -630,8 +736,8 @@ def g12():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4b", "g567", "g5b", "g8", "g8b", "g9", "g10", "g11", "g12"]
-    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g4b": g4b, "g567": g5_g6_g7, "g5b": g5b, "g8": g8, "g8b": g8b, "g9": g9,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4b", "g567", "g5b", "g8", "g8b", "g9", "g10", "g11", "g12", "g13"]
+    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g4b": g4b, "g567": g5_g6_g7, "g5b": g5b, "g8": g8, "g8b": g8b, "g13": g13, "g9": g9,
            "g10": g10, "g11": g11, "g12": g12}
     for w in which:
         fns[w]()

@@ -413,3 +413,41 @@ def test_aggregation_and_batchnorm_beyond_4gib():
     gyv = torch.ones(1, 64, device=DEV).expand(n, 64)
     y.backward(gyv)                                                         # d/dx of sum(y) is 0 for batch statistics
     assert float(xr.grad.abs().max()) < 1e-3
+
+
+def test_fullsize_layer_memory_contract_saves_only_the_layer_inputs(big):
+    """"saved-for-backward = layer inputs only" (the reference's autograd keeps ~45 GB at this size).
+    The KAN-GIN layer at 1M x 64 holds, between forward and backward, h0 (the aggregate = the first KANLinear's input), h1 (the
+    second one's input) and the output y -- 3 x N x F x 4 bytes -- plus the weight packs (< 1 MB); no bases, no messages, no
+    workspace survives the calls; after the backward only the gradients remain.  (VERDICT r05 missing 6 / next 5.)"""
+    _, x, gi = big
+    torch.manual_seed(0)
+    conv = kagnn_amd.GIKANLayer(F, F, grid_size=5, spline_order=3, hidden_dim=F, nb_layers=2).to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    gy = torch.randn(N, F, generator=torch.Generator().manual_seed(1)).to(DEV)
+    for _ in range(2):                                   # warm the allocator / one-time caches (packs, size queries)
+        conv(xd, gi).backward(gy)
+    xd.grad = None
+    conv.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    rows = N * F * 4
+    y = conv(xd, gi)
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated() - base
+    fwd_peak = torch.cuda.max_memory_allocated() - base
+    assert held <= 3 * rows + (2 << 20), f"forward keeps {held / rows:.2f} x N*F*4 (h0, h1, y = 3 allowed)"
+    assert fwd_peak <= 4 * rows + (8 << 20), f"forward peak {fwd_peak / rows:.2f} x N*F*4"
+    y.backward(gy)
+    del y
+    torch.cuda.synchronize()
+    after = torch.cuda.memory_allocated() - base
+    peak = torch.cuda.max_memory_allocated() - base
+    params = sum(p.numel() * 4 for p in conv.parameters())
+    assert after <= rows + 2 * params + (2 << 20), f"after the backward {after / rows:.2f} x N*F*4 remain (x.grad = 1 allowed)"
+    # the backward's transients: two gradient matrices in flight + the weight-gradient slabs
+    assert peak <= 6 * rows + (64 << 20), f"step peak {peak / rows:.2f} x N*F*4"
+    print(f"memory contract at 1M x 64: held {held / 1e9:.3f} GB between fwd and bwd, step peak {peak / 1e9:.3f} GB over the resident "
+          f"{base / 1e9:.3f} GB (reference CPU path: 45.1 GB RSS)")

@@ -1215,3 +1215,21 @@ def test_train_graph_batches_is_the_reference_loop():
     assert np.allclose(means, want, rtol=1e-6, atol=0), (means, want)
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_run_reference_runs_the_standin_timing_script_on_the_gpu(tmp_path):
+    """`python -m kagnn_amd.run_reference tests/standin/time_model_standin.py`: the script with time_model.py:13-15's import lines, unedited,
+    trains the four KAN / FastKAN node models on the HIP path (VERDICT r05 missing 5)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "report.json"
+    r = subprocess.run([sys.executable, "-m", "kagnn_amd.run_reference", os.path.join(root, "tests", "standin", "time_model_standin.py"), str(out)],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads(out.read_text())
+    assert rep["device"] == "cuda" and len(rep["classes"]) == 4
+    for k, v in rep["classes"].items():
+        assert "error" not in v and v["module"] == "kagnn_amd.models", (k, v)
+        assert all(np.isfinite(v["losses"])) and v["losses"][-1] < v["losses"][0], (k, v["losses"])

@@ -4,6 +4,7 @@ signatures and state_dict keys; the product refuses CPU tensors instead of falli
 import inspect
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -327,3 +328,30 @@ def test_norm_sums_side_channel_drops_sums_when_the_parked_gradient_was_accumula
     assert ns.take(g.clone()) is None             # a new tensor (what autograd's out-of-place accumulation produces)
     ns.park(sums, g)
     assert ns.take(g.view(8, 4)) is sums          # an alias of the unmodified tensor is still that gradient
+
+
+def _run_standin(tmp_path):
+    import json
+    import subprocess
+    out = tmp_path / "report.json"
+    script = os.path.join(ROOT, "tests", "standin", "time_model_standin.py")
+    r = subprocess.run([sys.executable, "-m", "kagnn_amd.run_reference", script, str(out)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(out.read_text())
+
+
+def test_run_reference_resolves_the_scripts_own_import_lines(tmp_path):
+    """`python -m kagnn_amd.run_reference <script>`: a script carrying time_model.py:13-15's exact import lines (`from utils import *`,
+    `from models import GNN_Nodes, GKAN_Nodes, GFASTKAN_Nodes`) runs unedited -- `models` / `ekan` / `fastkan` resolve to this
+    package, `utils` to the script's own directory, GNN_Nodes to a class that explains itself when torch_geometric is absent; without
+    a GPU every forward is refused loudly (no CPU path)."""
+    rep = _run_standin(tmp_path)
+    assert set(rep["classes"]) == {"GKAN_Nodes/gcn", "GKAN_Nodes/gin", "GFASTKAN_Nodes/gcn", "GFASTKAN_Nodes/gin"}
+    for k, v in rep["classes"].items():
+        assert v["module"] == "kagnn_amd.models" and v["params"] > 0, (k, v)
+        if rep["device"] == "cpu":
+            assert "no CPU fallback" in v["error"], v
+    try:
+        import torch_geometric  # noqa: F401
+    except ImportError:
+        assert rep["GNN_Nodes"].startswith("ImportError") and "torch_geometric" in rep["GNN_Nodes"]

@@ -335,3 +335,48 @@ def test_g8b_zinc_batch_whole_model_restatement(golden, kind):
         close(g64, z[k], 5e-3)
         checked += 1
     assert checked >= 20 and zero <= 4, (checked, zero)
+
+
+G13_MODELS = [("KAGIN", "gin", "kan"), ("FASTKAGIN", "gin", "fastkan"), ("KAGCN", "gcn", "kan"), ("FASTKAGCN", "gcn", "fastkan")]
+
+
+@pytest.mark.parametrize("name,family,arch", G13_MODELS, ids=[m[0] for m in G13_MODELS])
+@pytest.mark.parametrize("bi", [0, 1], ids=["16graphs", "empty+single-node"])
+def test_g13_graph_classification_restatement(golden, name, family, arch, bi):
+    """the graph-CLASSIFICATION callers (graph_classification/models.py:95-119,125-151,174-194,245-265): ``oracle.
+    graph_classification_forward`` reproduces the log-probabilities, d/dx and every parameter gradient of fixture G13, which was made
+    with the reference's own graph_classification/ekan.py / fastkan.py modules inside the restated GIN / GCN convolutions, torch's
+    BatchNorm1d, global_add_pool / global_mean_pool and log_softmax -- on the G8-sized 16-graph batch and on a batch with an empty
+    and a single-node graph (VERDICT r05 missing 4)."""
+    z = golden("g13_graph_classification")
+    b = f"b{bi}."
+    x, ei, batch, ng, gout = T(z[b + "x"]), T(z[b + "edge_index"]), T(z[b + "batch"]), int(z[b + "num_graphs"]), T(z[b + "g_out"])
+    pre = f"{b}{name}.init."
+    st32 = {k[len(pre):]: T(z[k]) for k in z.files if k.startswith(pre)}
+    out32 = orc.graph_classification_forward(x, ei, batch, ng, st32, arch, family, 2)
+    close(out32, z[f"{b}{name}.out"], 2e-5)
+    frozen = ("grid", "rbf.grid", "eps", "running_mean", "running_var", "num_batches_tracked")
+    st = {k: (v.double().requires_grad_(True) if v.is_floating_point() and not k.endswith(frozen) else v.double() if v.is_floating_point() else v)
+          for k, v in st32.items()}
+    xr = x.double().requires_grad_(True)
+    out = orc.graph_classification_forward(xr, ei, batch, ng, st, arch, family, 2)
+    assert out.shape == (ng, 3)
+    close(out.detach(), z[f"{b}{name}.out"], 2e-5)
+    out.backward(gout.double())
+    close(xr.grad, z[f"{b}{name}.gx"], 2e-4)
+    names = [k for k in z.files if k.startswith(f"{b}{name}.grad.")]
+    gmax = max(float(np.abs(z[k]).max()) for k in names)
+    checked = 0
+    for k in names:
+        g64 = st[k[len(f"{b}{name}.grad."):]].grad
+        if float(g64.abs().max()) <= 1e-12 * gmax:          # a bias right in front of a training-mode BatchNorm: identically zero
+            assert float(np.abs(z[k]).max()) <= 1e-5 * gmax, k
+            continue
+        close(g64, z[k], 2e-4)
+        checked += 1
+    assert checked >= 8, checked
+    if bi == 1:                                              # the empty graph: zero pooled row -> the read-out of a zero vector
+        empty = out.detach()[1]
+        zero_in = orc.graph_classification_forward(torch.zeros(1, 16, dtype=torch.float64), torch.zeros(2, 0, dtype=torch.int64),
+                                                   torch.zeros(1, dtype=torch.int64), 1, {k: v.detach() for k, v in st.items()}, arch, family, 0)
+        close(empty, zero_in[0], 1e-12)
