@@ -299,8 +299,10 @@ def graph_level_step_figures(dev, epochs=4):
             src.append(torch.randint(0, nb, (eb,), generator=g) + off[b]); dst.append(torch.randint(0, nb, (eb,), generator=g) + off[b])
             batch.append(torch.full((nb,), b))
         e = sum(len(s_) for s_ in src)
+        # (the attributes of a torch_geometric Batch: `ptr` -- the node offsets of the graphs -- is part of what its DataLoader collates)
         batches.append(SimpleNamespace(x=torch.randint(0, 21, (n, 1), generator=g).to(dev), edge_index=torch.stack([torch.cat(src), torch.cat(dst)]).to(dev),
                                        edge_attr=torch.randint(0, 4, (e,), generator=g).to(dev), batch=torch.cat(batch).to(dev), num_graphs=B,
+                                       ptr=torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)]).to(dev),
                                        y=torch.randn(B, generator=g).to(dev)))
     torch.manual_seed(0)
     m = kagnn_amd.KAGINRegression(1, 1, 4, H, 2, 4, 3, 1, 0.0, True)

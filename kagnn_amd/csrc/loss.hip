@@ -397,7 +397,7 @@ int l1_loss_bwd(const float* p, const float* t, long n, const float* g_loss, flo
 // (state bookkeeping, tensor grouping, step counters as tensors); this is the same rule as one launch over all parameter tensors,
 // driven by pointer tables in the kernel arguments.  fp32, no amsgrad, L2 weight decay as torch's (grad += wd * param):
 //   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-constexpr int kAdamBatch = 32;
+constexpr int kAdamBatch = 64;      // (2.6 KB of kernel arguments; the ZINC model's 40 parameter tensors are ONE launch -- round 6: was 32 = two)
 struct AdamBatch {
     float* p[kAdamBatch]; const float* g[kAdamBatch]; float* m[kAdamBatch]; float* v[kAdamBatch]; long n[kAdamBatch];
 };

@@ -234,8 +234,7 @@ def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr:
     on_gpu = any(p.is_cuda for p in model.parameters())
 
     def epoch():
-        total = None
-        graphs = 0
+        losses, weights = [], []
         for data in batches:
             optimizer.zero_grad(set_to_none=True)
             loss = loss_fn(model(data).squeeze(), data.y.squeeze())
@@ -245,25 +244,35 @@ def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr:
                 loss.backward(replicas.scale(loss))
                 replicas.sync()
             optimizer.step()
-            ng = int(getattr(data, "num_graphs", 0) or data.y.size(0))
-            if total is None:
-                total = loss.detach() * ng
-            else:
-                total.add_(loss.detach(), alpha=ng)
-            graphs += ng
+            losses.append(loss.detach())           # (kept on the device: no kernel and no read-back per step)
+            weights.append(float(int(getattr(data, "num_graphs", 0) or data.y.size(0))))
         if on_gpu:
             ops_mod.flush_graph_checks()       # the epoch's deferred node-id range checks (incl. the LAST batch's): one wait per epoch
-        return total / max(graphs, 1)
+        if not losses:
+            return torch.zeros(())
+        # the epoch's mean training loss, weighted by graphs per batch: three small launches per EPOCH, still no read-back
+        # (the caller converts after the final synchronisation)
+        w = torch.tensor(weights, dtype=losses[0].dtype).to(losses[0].device, non_blocking=True)
+        return (torch.stack(losses) * w).sum() / max(sum(weights), 1.0)
 
-    for _ in range(warmup):
-        epoch()
-    if on_gpu:
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    means = [epoch() for _ in range(nb_epochs)]
-    if on_gpu:
-        torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / max(1, nb_epochs * len(batches))
+    # The backward of a ~1 ms step is ~80 kernel launches from ~10 library calls: handing every tape node to autograd's per-device
+    # worker thread costs more than running it (host issue time of the ZINC-shaped step on the round-6 boxes: 1.41-1.50 ms per
+    # step with the engine's threads, 0.85-0.90 ms on the calling thread -- tools/host_profile_cfg4.py, profiles/r06_experiments.md).
+    # One device, one stream: nothing runs concurrently in that backward anyway.
+    mt_was = torch.autograd.is_multithreading_enabled()
+    torch.autograd.set_multithreading_enabled(False)
+    try:
+        for _ in range(warmup):
+            epoch()
+        if on_gpu:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        means = [epoch() for _ in range(nb_epochs)]
+        if on_gpu:
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / max(1, nb_epochs * len(batches))
+    finally:
+        torch.autograd.set_multithreading_enabled(mt_was)
     return float(dt), [float(m) for m in means]
 
 
