@@ -233,9 +233,28 @@ def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr:
     model.train()
     on_gpu = any(p.is_cuda for p in model.parameters())
 
+    import os
+    # (opt-in: on the round-6 boxes the step is HOST-bound, and the prefetch's stream switch + events cost the host more than the
+    # 55 us of device time they hide -- same-box A/B in profiles/r06_experiments.md; a device-bound loop can turn it on)
+    prefetch = on_gpu and os.environ.get("KAGNN_PREFETCH_CSR", "0") == "1"
+
+    def lookahead(it):
+        it = iter(it)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        for nxt in it:
+            yield cur, nxt
+            cur = nxt
+        yield cur, None
+
     def epoch():
         losses, weights = [], []
-        for data in batches:
+        for data, upcoming in lookahead(batches):
+            if prefetch and upcoming is not None and hasattr(upcoming, "edge_index") and torch.is_tensor(getattr(upcoming, "x", None)):
+                # the NEXT batch's CSR is built on a side stream beside this step's kernels (a loader worker's job; ops.prefetch_graph_index)
+                ops_mod.prefetch_graph_index(upcoming.edge_index, upcoming.x.size(0))
             optimizer.zero_grad(set_to_none=True)
             loss = loss_fn(model(data).squeeze(), data.y.squeeze())
             if replicas is None:

@@ -1233,3 +1233,26 @@ def test_run_reference_runs_the_standin_timing_script_on_the_gpu(tmp_path):
     for k, v in rep["classes"].items():
         assert "error" not in v and v["module"] == "kagnn_amd.models", (k, v)
         assert all(np.isfinite(v["losses"])) and v["losses"][-1] < v["losses"][0], (k, v["losses"])
+
+
+def test_prefetched_graph_index_is_the_same_index():
+    """ops.prefetch_graph_index builds a later mini-batch's CSR + transpose on a side stream; graph_index(cache=False) adopts it: the same six
+    arrays, bit for bit, as the direct build; an edge list that is never consumed does not pile up; a big graph is not prefetched."""
+    g = torch.Generator().manual_seed(9)
+    n, e = 5000, 12000
+    ei = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    want = ops.GraphIndex(ei, n)
+    assert ops.prefetch_graph_index(ei, n) and len(ops._prefetched) == 1
+    got = ops.graph_index(ei, n, cache=False)
+    assert len(ops._prefetched) == 0
+    for name in ("rowptr", "col", "perm", "rowptr_t", "col_t", "perm_t"):
+        assert torch.equal(getattr(got, name), getattr(want, name)), name
+    x = torch.randn(n, 16, generator=g).to(DEV)
+    assert torch.equal(ops.aggregate_sum(x, got), ops.aggregate_sum(x, want))
+    for k in range(7):                                       # never consumed: bounded
+        ops.prefetch_graph_index(torch.randint(0, n, (2, e + k), generator=g).to(DEV), n)
+    assert len(ops._prefetched) <= 4
+    ops.clear_graph_cache()
+    big = torch.randint(0, 100000, (2, 200000), generator=g).to(DEV)
+    assert not ops.prefetch_graph_index(big, 100000) and len(ops._prefetched) == 0
+    ops.flush_graph_checks()

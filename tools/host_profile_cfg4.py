@@ -51,11 +51,12 @@ for label, opt, mt in (("torch.optim.Adam(fused=True)", opt, True), ("kagnn_amd.
               ph[k] += b - a
   torch.cuda.synchronize()
   print(label, "-- host issue time per phase, us/step:", {k: round(v / 80 * 1e6, 1) for k, v in ph.items()}, "sum", round(sum(ph.values()) / 80 * 1e6, 1))
-torch.autograd.set_multithreading_enabled(True)
+torch.autograd.set_multithreading_enabled(os.environ.get("KAGNN_PROFILE_MT", "0") == "1")     # (default: as harness.train_graph_batches runs it)
+opt = own
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10):
     for d in batches: step(d)
 pr.disable(); torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
-st.sort_stats("cumulative").print_stats(45)
+st.sort_stats("tottime").print_stats(45)
+st.sort_stats("cumulative").print_stats(70)
