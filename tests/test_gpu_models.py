@@ -915,7 +915,7 @@ BF16_TOL = {"logits": 1e-2, "gx": 2.5e-2, "params": 1.2e-1}
 # gradients 1e-5, input gradient 1e-4 in L2).  At MODEL level it cannot be: where fp32 and fp64 arithmetic land on different
 # sides of a bf16 tie (~6e-4 of the elements after a KAN chain + BatchNorm) the two paths differ by ONE bf16 ulp = 3.9e-3
 # of that element; measured: logits 1e-4 in L2 -- 17x below the unrounded oracle -- while gradients, sums of mixed-sign terms
-# over 170 000 rows, amplify the same flips to 1e-3 .. 2e-3 (tools/debug/bf16_model_dbg.py lists them per parameter).
+# over 170 000 rows, amplify the same flips to 1e-3 .. 2e-3 (tools/archive/debug/bf16_model_dbg.py lists them per parameter).
 BF16_ROUNDED_TOL = {"logits": 1e-3, "gx": 8e-3, "params": 8e-3}
 BF16_ROUNDED_L2 = {"logits": 5e-4, "gx": 5e-3, "params": 1e-2}
 
@@ -1189,7 +1189,7 @@ def test_train_graph_batches_is_the_reference_loop():
         return m.to(DEV)
     m1 = make()
     # (a second seeded construction is NOT the same model to the bit: the spline-weight init is a CPU lstsq, as in the reference's
-    # curve2coeff, whose last bit depends on buffer alignment -- tools/experiments/train_determinism.py; the copy below is)
+    # curve2coeff, whose last bit depends on buffer alignment -- tools/archive/experiments/train_determinism.py; the copy below is)
     initial = {k: v.clone() for k, v in m1.state_dict().items()}
     t, means = train_graph_batches(m1, batches, nb_epochs=6, warmup=0, lr=2e-3, optimizer=torch.optim.Adam(m1.parameters(), lr=2e-3, fused=True))
     assert t > 0 and all(np.isfinite(means)) and means[-1] < means[0], means
