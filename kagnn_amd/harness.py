@@ -98,21 +98,29 @@ def time_model(model, x, edge_index, y, mask, nb_epochs: int = 20, warmup: int =
 
 class Adam:
     """``torch.optim.Adam(params, lr, betas, eps, weight_decay)`` (no amsgrad) for fp32 device parameters as ONE library call per
-    step (``kagnn_adam_step``: one launch per 32 tensors) -- the optimiser of the reference's graph-regression scripts
+    step (``kagnn_adam_step``: one launch per 64 tensors) -- the optimiser of the reference's graph-regression scripts
     (``graph_regression/optuna_zinc.py:49,62``).  Same update rule in fp32; what it removes is torch.optim's per-step Python (state
     dictionaries, tensor grouping, step counters kept as tensors: 0.2-0.3 ms of host time per step, fused or not -- a quarter of a
     256-molecule mini-batch's step).  ``step()`` / ``zero_grad()`` / ``state_dict()``-free by design: a training-loop helper, not a
-    torch.optim subclass (schedulers and checkpoints want the real one: pass it to ``train_graph_batches(optimizer=...)``)."""
+    torch.optim subclass (schedulers and checkpoints want the real one: pass it to ``train_graph_batches(optimizer=...)``).
+    As in torch.optim.Adam the step count of the bias correction is PER PARAMETER TENSOR and advances only when that tensor has a
+    gradient (ADVICE r05: a global counter gave a tensor that skips steps another correction than the reference's optimiser);
+    ``amsgrad`` / ``maximize`` are not implemented and rejected."""
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, amsgrad: bool = False,
+                 maximize: bool = False):
         import ctypes
+        if amsgrad or maximize:
+            raise NotImplementedError("kagnn_amd.harness.Adam implements torch.optim.Adam's default rule only (no amsgrad / maximize); "
+                                      "pass a torch.optim.Adam to train_graph_batches(optimizer=...) for those")
         self.params = [p for p in params if p.requires_grad]
         if not self.params or any((not p.is_cuda) or p.dtype != torch.float32 or not p.is_contiguous() for p in self.params):
             raise TypeError("kagnn_amd.harness.Adam takes contiguous fp32 parameters on the GPU (there is no CPU path)")
         if len({p.device for p in self.params}) != 1:
             raise ValueError("kagnn_amd.harness.Adam: all parameters on one device")
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
-        self.steps = 0
+        self.steps = 0                                               # steps taken by the optimiser
+        self._tensor_steps = None                                    # per-tensor counts; None while every tensor has taken every step
         total = sum(p.numel() for p in self.params)
         self._m = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
         self._v = torch.zeros_like(self._m)
@@ -148,15 +156,44 @@ class Adam:
             # (`None in gs` would compare every TENSOR with None through torch's dispatcher: 10 us each)
             keep = [k for k, g in enumerate(gs) if g is not None]
             if not keep:
+                self.steps -= 1                                       # (no gradient anywhere: not a step, as in torch.optim.Adam)
                 return
-            gs = [gs[k] if gs[k].dtype is f32 and gs[k].is_contiguous() else gs[k].to(f32).contiguous() for k in keep]
-            pp, mp, vp, nn_ = ([a[k] for k in keep] for a in (self._p_ptr, self._m_ptr, self._v_ptr, self._numel))
-            VP, I64 = _ctypes_arrays(len(keep))
-            tables = (VP(*pp), VP(*[g.data_ptr() for g in gs]), VP(*mp), VP(*vp), I64(*nn_))
+            if len(keep) < len(gs) and self._tensor_steps is None:    # first time a tensor sits a step out: counts diverge from here
+                self._tensor_steps = [self.steps - 1] * len(gs)
+            gs = {k: (gs[k] if gs[k].dtype is f32 and gs[k].is_contiguous() else gs[k].to(f32).contiguous()) for k in keep}
+            groups = {}
+            if self._tensor_steps is None:
+                groups[self.steps] = keep
+            else:
+                for k in keep:
+                    self._tensor_steps[k] += 1
+                    groups.setdefault(self._tensor_steps[k], []).append(k)
+            for t, ks in groups.items():                              # one library call per distinct step count (normally one)
+                VP, I64 = _ctypes_arrays(len(ks))
+                with ops._device_of(self.params[0]):
+                    ops._call("kagnn_adam_step", len(ks), VP(*[self._p_ptr[k] for k in ks]), VP(*[gs[k].data_ptr() for k in ks]),
+                              VP(*[self._m_ptr[k] for k in ks]), VP(*[self._v_ptr[k] for k in ks]), I64(*[self._numel[k] for k in ks]),
+                              self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, t, ops._stream())
+            return
+        if self._tensor_steps is not None:                            # all tensors present, but their counts differ
+            groups = {}
+            for k in range(len(gs)):
+                self._tensor_steps[k] += 1
+                groups.setdefault(self._tensor_steps[k], []).append(k)
+            if len(groups) > 1:
+                for t, ks in groups.items():
+                    VP, I64 = _ctypes_arrays(len(ks))
+                    with ops._device_of(self.params[0]):
+                        ops._call("kagnn_adam_step", len(ks), VP(*[self._p_ptr[k] for k in ks]), VP(*[gs[k].data_ptr() for k in ks]),
+                                  VP(*[self._m_ptr[k] for k in ks]), VP(*[self._v_ptr[k] for k in ks]), I64(*[self._numel[k] for k in ks]),
+                                  self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, t, ops._stream())
+                return
+            step_t = next(iter(groups))
         else:
-            tables = (self._p_tab, self._VP(*[g.data_ptr() for g in gs]), self._m_tab, self._v_tab, self._n_tab)
+            step_t = self.steps
+        tables = (self._p_tab, self._VP(*[g.data_ptr() for g in gs]), self._m_tab, self._v_tab, self._n_tab)
         with ops._device_of(self.params[0]):
-            ops._call("kagnn_adam_step", len(gs), *tables, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps,
+            ops._call("kagnn_adam_step", len(gs), *tables, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, step_t,
                       ops._stream())
 
 
@@ -238,6 +275,13 @@ def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr:
     # 55 us of device time they hide -- same-box A/B in profiles/r06_experiments.md; a device-bound loop can turn it on)
     prefetch = on_gpu and os.environ.get("KAGNN_PREFETCH_CSR", "0") == "1"
 
+    root = []
+
+    def one(like):
+        if not root or root[0].device != like.device or root[0].dtype != like.dtype or root[0].shape != like.shape:
+            root[:] = [torch.ones(like.shape, dtype=like.dtype, device=like.device)]
+        return root[0]
+
     def lookahead(it):
         it = iter(it)
         try:
@@ -258,7 +302,7 @@ def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr:
             optimizer.zero_grad(set_to_none=True)
             loss = loss_fn(model(data).squeeze(), data.y.squeeze())
             if replicas is None:
-                loss.backward()
+                loss.backward(one(loss))           # (the implicit root gradient would be a torch.ones_like: one fill launch per step)
             else:
                 loss.backward(replicas.scale(loss))
                 replicas.sync()

@@ -1129,8 +1129,8 @@ def test_fuzz_graph_models_one_node_vs_five_nodes_vs_oracle():
 # ------------------------------------------------------------------ the harness optimiser (optuna_zinc.py:49,62: torch.optim.Adam)
 @pytest.mark.parametrize("weight_decay", [0.0, 0.01])
 def test_harness_adam_is_torch_adam(weight_decay):
-    """kagnn_amd.harness.Adam (kagnn_adam_step: one launch per 32 tensors) against torch.optim.Adam run in float64 on the same
-    gradients: 40 tensors of 1 .. 100 003 elements (two launches), 6 steps, a tensor without a gradient is left alone"""
+    """kagnn_amd.harness.Adam (kagnn_adam_step: one launch per 64 tensors) against torch.optim.Adam run in float64 on the same
+    gradients: 40 tensors of 1 .. 100 003 elements, 6 steps, a tensor without a gradient is left alone"""
     from kagnn_amd.harness import Adam
     gen = torch.Generator().manual_seed(9)
     sizes = [1, 2, 63, 64, 65, 4096, 100_003] + [int(v) for v in torch.randint(1, 5000, (33,), generator=gen)]
@@ -1154,6 +1154,32 @@ def test_harness_adam_is_torch_adam(weight_decay):
     assert torch.equal(ps[frozen].detach().double(), ref[frozen].detach())
     with pytest.raises(TypeError, match="no CPU path"):
         Adam([torch.nn.Parameter(torch.zeros(3))])
+    with pytest.raises(NotImplementedError, match="amsgrad"):
+        Adam(ps, amsgrad=True)
+
+
+def test_harness_adam_counts_steps_per_tensor_like_torch():
+    """ torch.optim.Adam keeps one step count PER PARAMETER and does not advance it while that parameter has no gradient:
+    a tensor that sits out steps 2-3 gets the bias correction of ITS third step at the optimiser's fifth.  A step with no gradient
+    anywhere is not a step."""
+    from kagnn_amd.harness import Adam
+    gen = torch.Generator().manual_seed(10)
+    ps = [torch.nn.Parameter(torch.randn(n, generator=gen).to(DEV)) for n in (5, 300, 4097)]
+    ref = [torch.nn.Parameter(p.detach().double().clone()) for p in ps]
+    mine = Adam(ps, lr=1e-2)
+    theirs = torch.optim.Adam(ref, lr=1e-2)
+    mine.zero_grad(); theirs.zero_grad()
+    mine.step(); theirs.step()                               # nothing has a gradient: neither optimiser moves or counts
+    for step in range(7):
+        mine.zero_grad(); theirs.zero_grad()
+        for k, (p, r) in enumerate(zip(ps, ref)):
+            if (k == 1 and step in (2, 3)) or (k == 2 and step == 5):
+                continue
+            g = torch.randn(p.shape, generator=gen).to(DEV)
+            p.grad, r.grad = g, g.double()
+        mine.step(); theirs.step()
+        for k, (p, r) in enumerate(zip(ps, ref)):
+            assert_close(p.detach(), r.detach(), 2e-6, what=f"adam step {step} tensor {k}", elementwise=False)
 
 
 # ------------------------------------------------------------------ the graph-level training loop (optuna_zinc.py:56-66)
