@@ -6,6 +6,7 @@ namespace kagnn {
 thread_local char g_err[512] = "";
 thread_local bool g_half_products = false;      // KAGNN_PREC_HALF for the duration of an entry-point call (split_common.h)
 thread_local DwDefer* g_dw_defer = nullptr;       // deferred weight-gradient slab reductions of a stack call (common.h)
+thread_local MomDefer* g_mom_defer = nullptr;     // column moments whose finish is folded into the norm's apply kernel (common.h)
 
 size_t aggregate_ws_bytes(long num_hub_seg, int F);
 size_t aggregate_bf16_ws_bytes(long num_hub_seg, int F);
@@ -104,6 +105,7 @@ size_t bn_ws_bytes(long N, int F);
 int bn_fwd(const float*, long, long, int, const float*, const float*, float*, float*, float, float, int, const float*, const float*, float, unsigned long long, float*, long, float*, float*, void*, size_t, hipStream_t);
 int bn_bwd(const float*, long, const float*, long, long, int, const float*, const float*, const float*, int, float, unsigned long long, float*, long, float*, float*, void*, size_t, hipStream_t);
 int bn_bwd_stats(const float*, long, const float*, long, long, int, const float*, const float*, const float*, float*, float*, float*, int, void*, size_t, hipStream_t);
+int bn_fwd_partial_moments(const float*, long, long, int, const float*, const float*, float*, float*, float, float, const float*, int, float*, long, float*, float*, hipStream_t);
 int bn_stats_affine(const float*, const float*, long, int, const float*, const float*, float*, float*, float, float, float*, float*, float*, hipStream_t);
 bool kan_split_dx_bn_ok(long, int, int, int, int, const BnBack&, const void*);
 int kan_split_dx_bn(const float*, long, const float*, long, long, const float*, int, int, int, int, const void*, float*, long, const BnBack&, hipStream_t);
@@ -1511,6 +1513,11 @@ int kagnn_gine_kan_stack_workspace_bytes(int64_t N, int32_t nconv, int32_t L, co
     return KAGNN_OK;
 }
 
+static bool mom_defer_enabled() {             // (read per call: the bit-identity test flips it inside one process)
+    const char* e = getenv("KAGNN_MOM_DEFER");
+    return e == nullptr || atoi(e) != 0;
+}
+
 int kagnn_gine_kan_stack_fwd(const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int64_t N, const int32_t* rowptr,
                              const int32_t* col, const int32_t* perm, const float* self_scale, int32_t nconv,
                              int32_t L, const int32_t* widths, const float* const* bw, const float* const* sw,
@@ -1547,13 +1554,30 @@ int kagnn_gine_kan_stack_fwd(const float* x, int64_t ldx, const float* edge_attr
     for (int i = 0; i < nconv; ++i) {
         GineStage gs{in, ldin, edge_attr, lde, perm, nullptr, 0};
         gs.prepacked = batch ? 1 : 0;
-        rc = layer_fwd_impl(in, KAGNN_DTYPE_F32, ldin, N, rowptr, col, nullptr, 0, 0, self_scale[i], nullptr, nullptr, L, widths, bw + i * L,
-                            sw + i * L, sc ? sc + i * L : nullptr, knots, G, K, mode, acts + i * (L + 1), pack_fwd + i * L, pack_dx + i * L,
-                            mom, mom + H, ws, al256z(lf), stream, __func__, &gs);
+        // (round 6) the last forward kernel leaves its <= 32 per-workgroup moment rows where they are and the norm's apply kernel folds
+        // them: no moments_finish launch (same merge order, same bits; KAGNN_MOM_DEFER=0 restores the finish launch)
+        kagnn::MomDefer md{nullptr, 0};
+        {
+            struct MomScope {
+                kagnn::MomDefer* prev;
+                explicit MomScope(kagnn::MomDefer* d) : prev(kagnn::g_mom_defer) { kagnn::g_mom_defer = d; }
+                ~MomScope() { kagnn::g_mom_defer = prev; }
+            } mom_scope_(mom_defer_enabled() ? &md : nullptr);
+            rc = layer_fwd_impl(in, KAGNN_DTYPE_F32, ldin, N, rowptr, col, nullptr, 0, 0, self_scale[i], nullptr, nullptr, L, widths, bw + i * L,
+                                sw + i * L, sc ? sc + i * L : nullptr, knots, G, K, mode, acts + i * (L + 1), pack_fwd + i * L, pack_dx + i * L,
+                                mom, mom + H, ws, al256z(lf), stream, __func__, &gs);
+        }
         if (rc) return rc;
-        rc = kagnn_batchnorm_fwd(acts[i * (L + 1) + L], H, N, H, bn_weight[i], bn_bias[i], running_mean ? running_mean[i] : nullptr,
-                                 running_var ? running_var[i] : nullptr, momentum[i], eps[i], 1, mom, mom + H, 0.0f, 0ULL, h[i], H,
-                                 save_mean[i], save_rstd[i], ws_bn, bnb, stream);
+        if (md.P > 0) {
+            KAGNN_STAGE_AS("kagnn_batchnorm_fwd", stream);
+            rc = bn_fwd_partial_moments(acts[i * (L + 1) + L], H, N, H, bn_weight[i], bn_bias[i], running_mean ? running_mean[i] : nullptr,
+                                        running_var ? running_var[i] : nullptr, momentum[i], eps[i], md.partial, md.P, h[i], H,
+                                        save_mean[i], save_rstd[i], as_stream(stream));
+        } else {
+            rc = kagnn_batchnorm_fwd(acts[i * (L + 1) + L], H, N, H, bn_weight[i], bn_bias[i], running_mean ? running_mean[i] : nullptr,
+                                     running_var ? running_var[i] : nullptr, momentum[i], eps[i], 1, mom, mom + H, 0.0f, 0ULL, h[i], H,
+                                     save_mean[i], save_rstd[i], ws_bn, bnb, stream);
+        }
         if (rc) return rc;
         in = h[i]; ldin = H;
     }

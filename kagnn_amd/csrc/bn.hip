@@ -11,6 +11,7 @@
 //   * dropout (reference models.py:201, F.dropout after the norm) is applied by the normalising kernel itself and
 //     regenerated from (seed, row, column) in the backward: no mask tensor, no extra pass.  Counter-based hash, so the
 //     mask is a pure function of the seed; it is NOT torch's Philox stream (same distribution, different bits).
+#include <atomic>
 #include "common.h"
 
 namespace kagnn {
@@ -57,6 +58,15 @@ static DropArgs drop_args(float p, unsigned long long seed) {
     return d;
 }
 
+// bn_colsum_kernel<1>'s optional tail (see its end): ticket = slot of g_bn_tickets (-1: no tail, the caller launches bn_finish_*)
+struct BnTail { int ticket = -1; const float* gamma = nullptr; float* sum_gy = nullptr; float* sum_gyx = nullptr; float* tab = nullptr; int ldt = 0; };
+constexpr int kBnTickets = 64;
+__device__ unsigned g_bn_tickets[kBnTickets];           // zero at module load; every user leaves its slot at zero
+static int bn_next_ticket() {                            // launches in flight at once on different streams draw different slots
+    static std::atomic<unsigned> next{0};
+    return (int)(next.fetch_add(1u, std::memory_order_relaxed) % kBnTickets);
+}
+
 // partial[b][0][f] = sum_n a(n,f), partial[b][1][f] = sum_n b(n,f) over the rows of workgroup b, where
 //   MODE 0 (forward statistics):  a = x - shift_f,  b = (x - shift_f)^2      (shift_f = x[0][f]: no cancellation)
 //   MODE 1 (backward sums):       a = gy,           b = gy * (x - mean_f) * rstd_f
@@ -65,7 +75,8 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict_
                                                         const float* __restrict__ gy, long ldgy, long N, int F,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, int cl, int rs,
-                                                        long rows_per_block, float* __restrict__ partial, DropArgs dr) {
+                                                        long rows_per_block, float* __restrict__ partial, DropArgs dr,
+                                                        BnTail tail = BnTail{}) {
     extern __shared__ float s_red[];                    // [rs][2][4*cl]
     const int cg = threadIdx.x % cl, slot = threadIdx.x / cl;
     const bool vec = ((F & 3) == 0) && ((ldx & 3) == 0) && (MODE == 0 || (ldgy & 3) == 0) &&
@@ -116,6 +127,50 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict_
                 if (c + i < F) { partial[(blockIdx.x * 2L + 0) * F + c + i] = ta; partial[(blockIdx.x * 2L + 1) * F + c + i] = tb; }
             }
         }
+    }
+    if constexpr (MODE == 1) {
+        // round 6 (the graph-level mini-batches are launch-bound): the workgroup that finishes LAST folds all partial rows and writes
+        // the sums + the per-column table -- bn_finish_table_kernel's work, in ITS order (32 row groups: group rg adds rows rg, rg + 32, ..,
+        // then the groups are added 0 .. 31), so the same bits whichever workgroup it is -- instead of a second launch.
+        if (tail.ticket < 0) return;
+        __shared__ int s_last;
+        __shared__ float s_p[32][2][33];
+        __threadfence();                                 // this workgroup's partial row is visible device-wide before its ticket
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&g_bn_tickets[tail.ticket], 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        const volatile float* vp = partial;             // (written by other workgroups of this launch: never through a stale cache line)
+        const long B = gridDim.x;
+        const int c = threadIdx.x & 31, rq = threadIdx.x >> 5;        // 32 columns x 8 threads, each standing for 4 of the 32 row groups
+        for (int cb = 0; cb < cdiv(tail.ldt, 32); ++cb) {
+            const int f = cb * 32 + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rg = 4 * rq + j;
+                float a = 0.0f, b = 0.0f;
+                if (f < F)
+                    for (long w = rg; w < B; w += 32) { a += vp[(w * 2 + 0) * F + f]; b += vp[(w * 2 + 1) * F + f]; }
+                s_p[rg][0][c] = a; s_p[rg][1][c] = b;
+            }
+            __syncthreads();
+            if (rq == 0 && f < tail.ldt) {
+                float A = 0.0f, Bc = 0.0f, C = 0.0f, m = 0.0f;
+                if (f < F) {
+                    float ta = 0.f, tb = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 32; ++g) { ta += s_p[g][0][c]; tb += s_p[g][1][c]; }
+                    tail.sum_gy[f] = ta;        // g_bias
+                    tail.sum_gyx[f] = tb;       // g_weight
+                    m = mean[f];
+                    bn_bwd_consts(rstd[f], tail.gamma ? tail.gamma[f] : 1.0f, ta, tb, 1.0f / (float)N, A, Bc, C);
+                }
+                tail.tab[f] = m; tail.tab[tail.ldt + f] = A; tail.tab[2 * tail.ldt + f] = Bc; tail.tab[3 * tail.ldt + f] = C;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) g_bn_tickets[tail.ticket] = 0u;      // ready for the next launch that draws this slot
     }
 }
 
@@ -248,6 +303,68 @@ __global__ __launch_bounds__(256) void bn_apply_from_moments_kernel(const float*
     }
 }
 
+// (count, mean, M2) of two disjoint row sets -> of their union (Chan et al.); b is folded into a
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+    if (nb <= 0.0f) return;
+    const float n = na + nb, d = mb - ma, w = nb / n;
+    ma = fmaf(d, w, ma);
+    qa += qb + d * d * na * w;
+    na = n;
+}
+
+// bn_apply_from_moments_kernel whose moments arrive as the producer's P <= 32 per-workgroup partial rows [P][{mean, M2, count}][F]
+// (common.h: MomDefer): every workgroup folds them first -- for P <= 32 moments_finish_kernel's two-level order IS the sequential
+// merge over the rows (each of its 32 row groups holds one row, and merging a row into the empty set copies it exactly), so the
+// column statistics carry the same bits -- then the same expressions as above.  Saves the finish launch; round 6.
+__global__ __launch_bounds__(256) void bn_apply_from_partial_moments_kernel(const float* __restrict__ x, long ldx, long N, int F,
+                                                                            const float* __restrict__ partial, int P,
+                                                                            float eps, float momentum, float* __restrict__ save_mean,
+                                                                            float* __restrict__ save_rstd, float* __restrict__ running_mean,
+                                                                            float* __restrict__ running_var,
+                                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                            float* __restrict__ y, long ldy, int cl, int rs) {
+    extern __shared__ float s_mom[];                    // [2][F]: mean, M2
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float n = 0.0f, m = 0.0f, q = 0.0f;
+        for (int w = 0; w < P; ++w)
+            chan_merge(n, m, q, partial[((long)w * 3 + 2) * F + f], partial[((long)w * 3 + 0) * F + f], partial[((long)w * 3 + 1) * F + f]);
+        s_mom[f] = m; s_mom[F + f] = q;
+    }
+    __syncthreads();
+    const int cg = threadIdx.x % cl, slot = threadIdx.x / cl;
+    if (slot >= rs) return;
+    const bool vec = ((F & 3) == 0) && ((ldx & 3) == 0) && ((ldy & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    const bool writer = blockIdx.x == 0 && slot == 0;
+    for (int c = 4 * cg; c < F; c += 4 * cl) {
+        float sc[4], sh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = min(c + i, F - 1);
+            const float mean = s_mom[ci], var = fmaxf(s_mom[F + ci] / (float)N, 0.0f);
+            const float rstd = rsqrtf(var + eps);
+            if (writer && c + i < F) {
+                save_mean[ci] = mean;
+                save_rstd[ci] = rstd;
+                if (running_mean) {
+                    const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+                    running_mean[ci] = fmaf(momentum, mean - running_mean[ci], running_mean[ci]);
+                    running_var[ci] = fmaf(momentum, unb - running_var[ci], running_var[ci]);
+                }
+            }
+            sc[i] = rstd * (gamma ? gamma[ci] : 1.0f);
+            sh[i] = fmaf(-mean, sc[i], beta ? beta[ci] : 0.0f);
+        }
+        for (long n = blockIdx.x * (long)rs + slot; n < N; n += (long)gridDim.x * rs) {
+            float v[4];
+            ld4c(x + n * ldx, c, F, vec, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+            st4c(y + n * ldy, c, F, vec, v);
+        }
+    }
+}
+
 // training: gx = gamma*rstd * (gy - sum_gy/N - xhat * sum_gy_xhat/N);   eval: gx = gamma*rstd*gy
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, long ldx,
                                                            const float* __restrict__ gy, long ldgy, long N, int F,
@@ -359,15 +476,6 @@ __global__ void bn_from_moments_affine_kernel(const float* __restrict__ col_mean
     affine[F + f] = fmaf(-mean, sc, beta ? beta[f] : 0.0f);
 }
 
-// (count, mean, M2) of two disjoint row sets -> of their union (Chan et al.); b is folded into a
-__device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
-    if (nb <= 0.0f) return;
-    const float n = na + nb, d = mb - ma, w = nb / n;
-    ma = fmaf(d, w, ma);
-    qa += qb + d * d * na * w;
-    na = n;
-}
-
 // partial[p][{mean, M2, count}][F] of P producer workgroups, merged in a fixed order: 32 row groups x 32 columns
 __global__ __launch_bounds__(1024) void moments_finish_kernel(const float* __restrict__ partial, int P, int F,
                                                              float* __restrict__ col_mean, float* __restrict__ col_m2) {
@@ -457,6 +565,20 @@ int bn_fwd(const float* x, long ldx, long N, int F, const float* gamma, const fl
     return KAGNN_OK;
 }
 
+// training-mode forward whose statistics are the producer's deferred partial moments (common.h: MomDefer): ONE launch
+int bn_fwd_partial_moments(const float* x, long ldx, long N, int F, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, const float* partial, int P, float* y, long ldy,
+                           float* save_mean, float* save_rstd, hipStream_t st) {
+    if (P < 1 || P > kMomDeferMaxP) return fail(KAGNN_ERR_ARG, "%s: 1 .. 32 partial rows", "bn_fwd_partial_moments");
+    const BnShape s = bn_shape(F);
+    const int grid = (int)min(4096L, max(1L, (long)cdiv(N, s.rs)));
+    bn_apply_from_partial_moments_kernel<<<grid, 256, 2 * (size_t)F * sizeof(float), st>>>(x, ldx, N, F, partial, P, eps, momentum, save_mean,
+                                                                                          save_rstd, running_mean, running_var, gamma, beta,
+                                                                                          y, ldy, s.cl, s.rs);
+    KAGNN_LAUNCH_CHECK();
+    return KAGNN_OK;
+}
+
 int bn_stats_affine(const float* col_mean, const float* col_m2, long N, int F, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* save_mean, float* save_rstd,
                     float* affine, hipStream_t st) {
@@ -465,6 +587,12 @@ int bn_stats_affine(const float* col_mean, const float* col_m2, long N, int F, c
                                                                 running_var, gamma, beta, affine);
     KAGNN_LAUNCH_CHECK();
     return KAGNN_OK;
+}
+
+constexpr int kBnTailMaxBlocks = 128;        // (more partial rows: the 1024-thread finish launch folds them faster than one workgroup would)
+static bool bn_tail_enabled() {              // KAGNN_BN_TAIL=0: always the two launches (A/B; bit-identical; read per call for the test)
+    const char* e = getenv("KAGNN_BN_TAIL");
+    return e == nullptr || atoi(e) != 0;
 }
 
 // the statistics half of the training backward: g_beta = sum g, g_gamma = sum g xhat, and the per-column table for a kernel
@@ -480,6 +608,13 @@ int bn_bwd_stats(const float* x, long ldx, const float* gy, long ldgy, long N, i
     float* sg = g_beta ? g_beta : sums;
     float* sgx = g_gamma ? g_gamma : sums + F;
     const size_t lds = (size_t)s.rs * 2 * 4 * s.cl * sizeof(float);
+    if (p.blocks <= kBnTailMaxBlocks && bn_tail_enabled()) {      // few partial rows (mini-batches): the last workgroup finishes -- one launch
+        BnTail tail;
+        tail.ticket = bn_next_ticket(); tail.gamma = gamma; tail.sum_gy = sg; tail.sum_gyx = sgx; tail.tab = tab; tail.ldt = ldt;
+        bn_colsum_kernel<1><<<p.blocks, 256, lds, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, s.cl, s.rs, p.rpb, partial, dr, tail);
+        KAGNN_LAUNCH_CHECK();
+        return KAGNN_OK;
+    }
     bn_colsum_kernel<1><<<p.blocks, 256, lds, st>>>(x, ldx, gy, ldgy, N, F, save_mean, save_rstd, s.cl, s.rs, p.rpb, partial, dr);
     KAGNN_LAUNCH_CHECK();
     bn_finish_table_kernel<<<cdiv(ldt, 32), 1024, 0, st>>>(partial, p.blocks, F, N, save_mean, save_rstd, gamma, sg, sgx, tab, ldt);

@@ -47,6 +47,15 @@ struct DwDefer {
 extern thread_local DwDefer* g_dw_defer;
 int dw_defer_flush(hipStream_t st);                 // launches what g_dw_defer holds (no-op when empty) and empties it
 
+// Column moments whose finish is left to the consumer (round 6: the graph-level mini-batches are launch-bound).  A caller that runs
+// forward-with-moments and the BatchNorm1d right behind it (kagnn_gine_kan_stack_fwd) sets g_mom_defer for the forward call: the
+// forward kernel then leaves its <= kMomDeferMaxP per-workgroup partial rows where they are, skips moments_finish_kernel, and
+// records them here; the norm's apply kernel folds them itself (bn_apply_from_partial_moments_kernel: the same merge order, the
+// same bits, one launch fewer per convolution).
+constexpr int kMomDeferMaxP = 32;
+struct MomDefer { const float* partial; int P; };
+extern thread_local MomDefer* g_mom_defer;
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a process-wide "configured" flag leaves the kernel
 // at the 64 KB default on the second GPU a process drives and its launch fails there.  One bit per device ordinal.
 // Use:  `if (auto first = first_use_on_this_device(seen)) { hipFuncSetAttribute(...); }` -- true until the calling thread's current

@@ -950,6 +950,10 @@ static int launch_sparse(const float* x, long ldx, long N, int in, const float* 
             return fail(KAGNN_ERR_ARG, "%s: workspace too small for the column moments", "kan_sparse_fwd");
         kan_sparse_fwd_kernel<OT, SH, true, NARROW, -1, false, HALF><<<gx, 512, lds, st>>>(x, ldx, N, in, knots, nknots, pack, nchunks, y, ldy, out, nchunks, 0L, ws, SpAgg{}, SpParts{});
         KAGNN_LAUNCH_CHECK();
+        if (g_mom_defer && gx <= kMomDeferMaxP) {        // the consumer (the norm's apply kernel) folds the partial rows itself
+            g_mom_defer->partial = ws; g_mom_defer->P = gx;
+            return KAGNN_OK;
+        }
         return moments_finish(ws, gx, out, col_mean, col_m2, st);
     }
     if (p.splits > 1) {

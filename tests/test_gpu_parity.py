@@ -862,6 +862,56 @@ def test_gine_conv_one_library_call_each_way_matches_the_composition(golden, mon
         assert_close(res["layer"][3][k], v, 1e-5, what=f"gine one-call {k}")
 
 
+def test_norm_launch_merges_of_the_graph_level_step_are_bit_identical(golden, monkeypatch):
+    """Round 6 (config 4 is launch-bound): (i) the convolution's column moments are folded by the norm's apply kernel itself
+    (``bn_apply_from_partial_moments_kernel``: no ``moments_finish`` launch), (ii) the last workgroup of the norm's backward
+    statistics pass writes the sums and the table (no ``bn_finish_table`` launch).  Both in the fold order of the launches they
+    replace: prediction, loss, every gradient and the running statistics are the SAME BITS with ``KAGNN_MOM_DEFER=0`` /
+    ``KAGNN_BN_TAIL=0`` (the two-launch forms), on the ZINC-shaped fixture batch and on a batch of 40 000 rows (> 32 moment rows and
+    > 128 statistics rows: the merged forms step aside there)."""
+    z = golden("g8b_zinc_batch")
+
+    class Data:
+        pass
+    small = Data()
+    small.x, small.edge_index, small.batch = T(z["x"], DEV), T(z["edge_index"], DEV), T(z["batch"], DEV)
+    small.edge_attr, small.num_graphs = T(z["edge_attr"], DEV), 256
+    g = torch.Generator().manual_seed(3)
+    big = Data()
+    nb, eb, gb = 40000, 60000, 1000
+    big.x = torch.randint(0, 21, (nb, 1), generator=g).to(DEV)
+    big.edge_index = torch.randint(0, nb, (2, eb), generator=g).to(DEV)
+    big.edge_attr = torch.randint(0, 4, (eb, 1), generator=g).to(DEV)
+    big.batch = torch.sort(torch.randint(0, gb, (nb,), generator=g)).values.to(DEV)
+    big.num_graphs = gb
+    pre = "kan.state."
+    state = {k[len(pre):]: T(z[k], DEV) for k in z.files if k.startswith(pre)}
+    m = kagnn_amd.KAGINRegression(1, 1, 3, 32, 2, 4, 3, 1, 0.0, True)
+    m.atom_encoder = kagnn_amd.graph_models.AtomEncoder(32, [21])
+    m.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, 32)])
+    for d in (small, big):
+        res = {}
+        for how, env in (("merged", {}), ("two-launch", {"KAGNN_MOM_DEFER": "0", "KAGNN_BN_TAIL": "0"}), ("merged again", {})):
+            for k in ("KAGNN_MOM_DEFER", "KAGNN_BN_TAIL"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            m.load_state_dict(state, strict=True)
+            m = m.to(DEV).train()
+            m.zero_grad()
+            pred = m(d)
+            pred.abs().mean().backward()
+            res[how] = (pred.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                        {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+        for other in ("two-launch", "merged again"):
+            assert torch.equal(res["merged"][0], res[other][0]), other
+            for k, gref in res[other][1].items():
+                assert torch.equal(res["merged"][1][k], gref), (other, k)
+            for k, v in res[other][2].items():
+                assert torch.equal(res["merged"][2][k], v), (other, k)
+    ops.flush_graph_checks()
+
+
 def test_model_node_steps_aside_when_it_does_not_cover_the_call(golden):
     """graph_ops.kagin_regression_forward returns None -- and the modules run one by one, with the same result where both apply --
     in eval mode, with dropout, with a hook on any sub-module, with Linear encoders, under the FastKAN flavour"""
