@@ -323,7 +323,7 @@ def train_graph_batches(model, batches, nb_epochs: int = 1, warmup: int = 0, lr:
     # step with the engine's threads, 0.85-0.90 ms on the calling thread -- tools/host_profile_cfg4.py, profiles/r06_experiments.md).
     # One device, one stream: nothing runs concurrently in that backward anyway.
     mt_was = torch.autograd.is_multithreading_enabled()
-    torch.autograd.set_multithreading_enabled(False)
+    torch.autograd.set_multithreading_enabled(os.environ.get("KAGNN_CFG4_MT", "0") == "1")     # (=1: the engine's worker threads, for A/B)
     try:
         for _ in range(warmup):
             epoch()

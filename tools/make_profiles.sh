@@ -37,6 +37,11 @@ python bench.py --workload config3 --no-cpu-baseline --no-extras --no-traffic 2>
 python bench.py --workload fastkan 2>/dev/null | tail -1 > $OUT/${TAG}_bench_fastkan.json
 tools/prof_fastkan.sh ${TAG}_fk 40 > $OUT/${TAG}_fastkan_layer_kernel_trace.txt 2>&1
 python tools/shard_plan_probe.py --link-gbs=50 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_shard_plan.txt; cp gpurun_out/shard_plan.json $OUT/${TAG}_shard_plan.json
+# round 6: the other sharded paths (FastKAN-GIN layer, GKAN_Nodes step), the model workload as a bench line, config 4's step repeated
+python tools/shard_plan_probe_e2.py --link-gbs=50 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_shard_plan_e2.txt; cp gpurun_out/shard_plan_e2.json $OUT/${TAG}_shard_plan_e2.json
+python bench.py --workload model 2>/dev/null | tail -1 > $OUT/${TAG}_bench_model.json
+python tools/cfg4_step.py 2>/dev/null | tail -1 > $OUT/${TAG}_config4_step.json
+KAGNN_CFG4_MT=1 python tools/cfg4_step.py 2>/dev/null | tail -1 > $OUT/${TAG}_config4_step_autograd_threads.json
 python tools/kernel_resources.py > $OUT/${TAG}_kernel_resources.txt 2>&1
 rm -rf $R/gpurun_out/prof_${TAG}* 
 ls -la $OUT
