@@ -279,7 +279,7 @@ def secondary_figures(dev, conv, graph, x, n, e, f, grid, order):
     return out
 
 
-def graph_level_step_figures(dev, epochs=4):
+def graph_level_step_figures(dev, epochs=10):
     """BASELINE config 4 (the latency-bound regime): the ZINC-shaped mini-batch training step of the reference's
     graph-regression script (graph_regression/optuna_zinc.py:56-66: KAGIN(1, 1, 4 GINE convolutions, hidden 64, embedding encoders),
     256 molecules of 23 +- 5 atoms per batch, L1 loss, Adam) through kagnn_amd.harness.train_graph_batches over 8 distinct batches
@@ -309,10 +309,18 @@ def graph_level_step_figures(dev, epochs=4):
     m.atom_encoder = kagnn_amd.graph_models.AtomEncoder(H, [21])
     m.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, H)])
     m = m.to(dev)
-    t, means = harness.train_graph_batches(m, batches, nb_epochs=epochs, warmup=2)
+    # three repeats of `epochs` epochs (8 steps each; the model keeps training across them): a single 32-step region is ~27 ms of wall
+    # clock and one scheduler hiccup moves it by 10 % -- the MEDIAN repeat is the figure, all three are listed
+    reps = []
+    for _ in range(3):
+        t, means = harness.train_graph_batches(m, batches, nb_epochs=epochs, warmup=1)
+        reps.append(t)
+    t = sorted(reps)[1]
     return {"what": "KAGIN graph-regression training step, 256-molecule mini-batch (~5.9k nodes / ~12.7k edges), 4 GINE(KAN) convolutions, "
-                    "hidden 64, grid 4, embedding encoders, L1 loss, Adam; 8 distinct batches, CSR rebuilt per batch (optuna_zinc.py:56-66)",
-            "ms_per_step": t * 1e3, "graphs_per_s": B / t, "edges_per_s": 12700 / t, "final_epoch_mean_loss": means[-1]}
+                    "hidden 64, grid 4, embedding encoders, L1 loss, Adam; 8 distinct batches, CSR rebuilt per batch (optuna_zinc.py:56-66); "
+                    f"median of 3 repeats of {epochs} epochs",
+            "ms_per_step": t * 1e3, "repeats_ms_per_step": [r * 1e3 for r in reps], "graphs_per_s": B / t, "edges_per_s": 12700 / t,
+            "final_epoch_mean_loss": means[-1]}
 
 
 def other_layer_figures(dev, graph, n, e, steps=10):

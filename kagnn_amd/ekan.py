@@ -162,11 +162,6 @@ class KANLinear(nn.Module):
         ``kagnn_kan_grid_refit`` -- no [N, in, out] intermediate.  The layer then runs on per-feature knots."""
         assert x.dim() == 2 and x.size(1) == self.in_features
         n, g, k, dev = x.size(0), self.grid_size, self.spline_order, x.device
-        if g + k > 16:
-            # the refit kernel solves per-feature normal equations for <= 16 coefficients (csrc/kan_grid.hip); the
-            # forward / backward handle more (coefficient groups), the reference's search space reaches grid_size 32
-            raise NotImplementedError(f"update_grid supports grid_size + spline_order <= 16 (got {g + k}); "
-                                      "KAGNN itself never calls update_grid (SURVEY.md 8(f) rank 4)")
         ranked = torch.sort(x, dim=0).values
         quantiles = ranked[torch.linspace(0, n - 1, g + 1, dtype=torch.int64, device=dev)]       # [G+1, in]
         step = (ranked[-1] - ranked[0] + 2 * margin) / g
@@ -176,9 +171,40 @@ class KANLinear(nn.Module):
         above = inner[-1:] + step * torch.arange(1, k + 1, device=dev).unsqueeze(1)
         new_grid = torch.cat([below, inner, above], dim=0).T.contiguous()
         scaler = self.spline_scaler if self.enable_standalone_scale_spline else None
-        fitted = ops.kan_grid_refit(x, self.grid, new_grid, self.spline_weight, scaler, g, k)
+        if g + k <= 16:
+            fitted = ops.kan_grid_refit(x, self.grid, new_grid, self.spline_weight, scaler, g, k)
+        else:
+            fitted = self._refit_wide(x, new_grid, scaler)
         self.grid.copy_(new_grid)
         self.spline_weight.data.copy_(fitted)
+
+    @torch.no_grad()
+    def _refit_wide(self, x: torch.Tensor, new_grid: torch.Tensor, scaler) -> torch.Tensor:
+        """``update_grid``'s refit for MORE than 16 coefficients (the reference's searches reach grid_size 32; ``ekan.py:164-211``
+        has no limit).  The fp64-MFMA refit kernel (``kagnn_kan_grid_refit``) holds a feature's C x C Gram matrices in one wave's
+        accumulators, C <= 16; beyond that the same normal equations are accumulated here from the dense bases of
+        ``kagnn_kan_bsplines`` (device, 8192 rows at a time, fp64 einsum) -- ``G1 = A_new^T A_new``, ``G2 = A_new^T A_old`` per input
+        feature, never the reference's ``[N, in, out]`` curves -- and the ``in`` small systems ``G1 X = G2 W^T`` are solved in fp64
+        by a minimum-norm least-squares solve on the host (a basis no sample touches gets coefficient 0, as in the kernel).  Off
+        the hot path twice over: KAGNN never calls ``update_grid`` (VERDICT r05 missing 8)."""
+        n, g, k = x.size(0), self.grid_size, self.spline_order
+        c = g + k
+        dev = x.device
+        g1 = torch.zeros((self.in_features, c, c), dtype=torch.float64, device=dev)
+        g2 = torch.zeros_like(g1)
+        old_grid = self.grid.contiguous()
+        for r0 in range(0, n, 8192):
+            rows = x[r0:r0 + 8192].contiguous()
+            a_new = ops.kan_bsplines(rows, new_grid, g, k).double()
+            a_old = ops.kan_bsplines(rows, old_grid, g, k).double()
+            g1 += torch.einsum("nfc,nfd->fcd", a_new, a_new)
+            g2 += torch.einsum("nfc,nfd->fcd", a_new, a_old)
+        w = self.spline_weight.detach().double()
+        if scaler is not None:
+            w = w * scaler.detach().double().unsqueeze(-1)                       # the curves the layer evaluates (scaled_spline_weight)
+        rhs = torch.einsum("fcd,ofd->fco", g2, w)                                # [in, C, out]
+        sol = torch.linalg.lstsq(g1.cpu(), rhs.cpu(), driver="gelsd").solution     # [in, C, out], minimum norm per feature
+        return sol.permute(2, 0, 1).to(dtype=self.spline_weight.dtype, device=dev).contiguous()
 
     def regularization_loss(self, regularize_activation=1.0, regularize_entropy=1.0):
         mag = self.spline_weight.abs().mean(-1)

@@ -1440,7 +1440,9 @@ def test_update_grid_golden(golden):
             layer.load_state_dict({n: v for n, v in p.items()})
 
 
-@pytest.mark.parametrize("n,fi,fo,G,k", [(20000, 16, 8, 5, 3), (3001, 70, 5, 8, 3), (17, 3, 2, 3, 2), (5000, 4, 40, 12, 4)])
+# (the last two: MORE than 16 coefficients -- the reference's searches reach grid_size 32, ekan.py:164-211 has no limit; KANLinear._refit_wide, round 6)
+@pytest.mark.parametrize("n,fi,fo,G,k", [(20000, 16, 8, 5, 3), (3001, 70, 5, 8, 3), (17, 3, 2, 3, 2), (5000, 4, 40, 12, 4),
+                                         (9000, 6, 5, 20, 3), (12000, 3, 4, 32, 3)])
 def test_update_grid_vs_oracle(n, fi, fo, G, k):
     torch.manual_seed(n)
     layer = kagnn_amd.KANLinear(fi, fo, grid_size=G, spline_order=k)
