@@ -1513,9 +1513,9 @@ int kagnn_gine_kan_stack_workspace_bytes(int64_t N, int32_t nconv, int32_t L, co
     return KAGNN_OK;
 }
 
-static bool mom_defer_enabled() {             // (read per call: the bit-identity test flips it inside one process)
+static bool mom_defer_enabled() {             // OPT-IN (KAGNN_MOM_DEFER=1): measured slower on the device, see below; read per call for the test
     const char* e = getenv("KAGNN_MOM_DEFER");
-    return e == nullptr || atoi(e) != 0;
+    return e != nullptr && atoi(e) != 0;
 }
 
 int kagnn_gine_kan_stack_fwd(const float* x, int64_t ldx, const float* edge_attr, int64_t lde, int64_t N, const int32_t* rowptr,
@@ -1554,8 +1554,10 @@ int kagnn_gine_kan_stack_fwd(const float* x, int64_t ldx, const float* edge_attr
     for (int i = 0; i < nconv; ++i) {
         GineStage gs{in, ldin, edge_attr, lde, perm, nullptr, 0};
         gs.prepacked = batch ? 1 : 0;
-        // (round 6) the last forward kernel leaves its <= 32 per-workgroup moment rows where they are and the norm's apply kernel folds
-        // them: no moments_finish launch (same merge order, same bits; KAGNN_MOM_DEFER=0 restores the finish launch)
+        // (round 6, opt-in: KAGNN_MOM_DEFER=1) the last forward kernel leaves its <= 32 per-workgroup moment rows where they are and the
+        // norm's apply kernel folds them: no moments_finish launch, same merge order, same bits.  One launch fewer per convolution, but
+        // every one of the apply kernel's ~370 workgroups repeats the 24-row merge chain: 15.7 us against 5.0 + 5.1 for the two
+        // launches (profiles/r06_experiments.md 3) -- and a launch costs the host ~1 us.  Off by default.
         kagnn::MomDefer md{nullptr, 0};
         {
             struct MomScope {

@@ -590,9 +590,9 @@ int bn_stats_affine(const float* col_mean, const float* col_m2, long N, int F, c
 }
 
 constexpr int kBnTailMaxBlocks = 128;        // (more partial rows: the 1024-thread finish launch folds them faster than one workgroup would)
-static bool bn_tail_enabled() {              // KAGNN_BN_TAIL=0: always the two launches (A/B; bit-identical; read per call for the test)
-    const char* e = getenv("KAGNN_BN_TAIL");
-    return e == nullptr || atoi(e) != 0;
+static bool bn_tail_enabled() {              // OPT-IN (KAGNN_BN_TAIL=1; bit-identical; read per call for the test): the ticket's device-wide
+    const char* e = getenv("KAGNN_BN_TAIL");  // fence + atomic in EVERY workgroup and the 256-thread fold made the pass 26 us against
+    return e != nullptr && atoi(e) != 0;      // 6.4 + 4.7 for the two launches (profiles/r06_experiments.md 3)
 }
 
 // the statistics half of the training backward: g_beta = sum g, g_gamma = sum g xhat, and the per-column table for a kernel

@@ -866,8 +866,9 @@ def test_norm_launch_merges_of_the_graph_level_step_are_bit_identical(golden, mo
     """Round 6 (config 4 is launch-bound): (i) the convolution's column moments are folded by the norm's apply kernel itself
     (``bn_apply_from_partial_moments_kernel``: no ``moments_finish`` launch), (ii) the last workgroup of the norm's backward
     statistics pass writes the sums and the table (no ``bn_finish_table`` launch).  Both in the fold order of the launches they
-    replace: prediction, loss, every gradient and the running statistics are the SAME BITS with ``KAGNN_MOM_DEFER=0`` /
-    ``KAGNN_BN_TAIL=0`` (the two-launch forms), on the ZINC-shaped fixture batch and on a batch of 40 000 rows (> 32 moment rows and
+    replace: prediction, loss, every gradient and the running statistics are the SAME BITS with ``KAGNN_MOM_DEFER=1`` /
+    ``KAGNN_BN_TAIL=1`` as with the two-launch forms (the default: the merged kernels measured SLOWER on the device,
+    profiles/r06_experiments.md 3), on the ZINC-shaped fixture batch and on a batch of 40 000 rows (> 32 moment rows and
     > 128 statistics rows: the merged forms step aside there)."""
     z = golden("g8b_zinc_batch")
 
@@ -891,7 +892,8 @@ def test_norm_launch_merges_of_the_graph_level_step_are_bit_identical(golden, mo
     m.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, 32)])
     for d in (small, big):
         res = {}
-        for how, env in (("merged", {}), ("two-launch", {"KAGNN_MOM_DEFER": "0", "KAGNN_BN_TAIL": "0"}), ("merged again", {})):
+        on = {"KAGNN_MOM_DEFER": "1", "KAGNN_BN_TAIL": "1"}
+        for how, env in (("merged", on), ("two-launch", {}), ("merged again", on)):
             for k in ("KAGNN_MOM_DEFER", "KAGNN_BN_TAIL"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
