@@ -666,6 +666,9 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
                     u32x4 e0, e1, nbw[MERGED ? 1 : 4 * OT]; float u0, u1;
                     if constexpr (MERGED) { if (s < 3) prep_reads(s + 1, e0, e1, u0, u1, bw); }      // (index + table reads only)
                     else if (s < 3) prep_reads(s + 1, e0, e1, u0, u1, reinterpret_cast<u32x4 (&)[4 * OT]>(nbw));
+#ifdef KAGNN_ABLATE_FWD_12SLOT               // TIMING-ONLY ablation (wrong results; profiles/r06_experiments.md 4): the two-window layers with three
+                    if (!(SH && s == 3)) {           // of every four sparse steps -- the matrix-core work a 12-slot 2:4 layout would leave, with the
+#endif                                               // expansion, weight reads and everything else as they are: the upper bound of that layout's gain
 #pragma unroll
                     for (int t = 0; t < OT; ++t) acc[t] = smfmac(ahi, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
                     if constexpr (!HALF) {
@@ -674,6 +677,9 @@ __global__ __launch_bounds__(512) void kan_sparse_fwd_kernel(
 #pragma unroll
                         for (int t = 0; t < OT; ++t) acc[t] = smfmac(alo, bw[4 * t], bw[4 * t + 1], acc[t], aidx);
                     }
+#ifdef KAGNN_ABLATE_FWD_12SLOT
+                    }
+#endif
                     if (s < 3) {
                         u32x4 nhi, nlo; int nidx;
                         build(s + 1, e0, e1, u0, u1, nhi, nlo, nidx);
