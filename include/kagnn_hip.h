@@ -754,6 +754,61 @@ int kagnn_kan_linear_bwd_weight_affine(const float* x, int64_t ldx, const float*
                                        const float* spline_scaler, float* g_base_weight, float* g_spline_weight,
                                        float* g_spline_scaler, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The WHOLE graph-regression model per call (round 6; BASELINE config 4).  Replaces, per mini-batch, `KAGIN.forward`
+ * of the reference's graph_regression/models.py:107-119 -- `AtomEncoder` / `BondEncoder` embedding sums (:244-281),
+ * `n_layers x {GINEConv(KAN) -> BatchNorm1d}` (:98,108-114), `global_add_pool` (:117), the KAN read-out (:118) -- and its
+ * autograd backward, called from graph_regression/optuna_zinc.py:56-66.  No new kernels: the call sequences this header's own
+ * entry points (kagnn_embedding_fwd, kagnn_gine_kan_stack_fwd, kagnn_segment_pool, kagnn_kan_pack_batch / kagnn_kan_pack,
+ * kagnn_kan_linear_fwd; on the way back kagnn_kan_linear_bwd_input / _bwd_weight, kagnn_segment_broadcast,
+ * kagnn_gine_kan_stack_bwd, kagnn_embedding_bwd) on `stream` in exactly the order and with exactly the arguments the
+ * per-operation host code uses -- same bits.  What it removes is the HOST: a 256-molecule step is ~0.75 ms of device work and
+ * the per-operation binding spent as long again in ~19 calls, ~45 allocations and their pointer tables.  Everything the backward
+ * needs lives in ONE caller-owned `saved` buffer whose layout only the library knows (kagnn_kagin_model_sizes); all parameter
+ * gradients land in ONE flat fp32 buffer `grads`, in the order: atom tables, bond tables, then per convolution bn_weight, bn_bias
+ * and per layer base_weight, spline_weight, spline_scaler, then per read-out layer base_weight, spline_weight, spline_scaler
+ * (absent scalers take no room).  All fields are 8 bytes wide except the three float arrays at the end.
+ * Limits: num_convs * num_layers <= 16, hidden -> hidden chains of width <= 64 on the split path (kagnn_gine_kan_stack_*),
+ * <= 8 read-out layers, <= 16 tables per encoder with <= 512 rows, training-mode affine BatchNorm1d, >= 2 nodes.          */
+#define KAGNN_MODEL_MAX_LAYERS 16
+#define KAGNN_MODEL_MAX_CONVS 16
+#define KAGNN_MODEL_MAX_TABLES 16
+#define KAGNN_MODEL_MAX_READOUT 8
+typedef struct kagnn_kagin_model {
+    int64_t num_nodes, num_edges, num_graphs, hidden;
+    int64_t num_atom_tables, num_bond_tables, x_stride, e_stride;     /* index matrices: int64 [N, x_stride] / [E, e_stride]; table t reads column t */
+    int64_t num_convs, num_layers, grid_size, spline_order, mode;
+    int64_t num_readout, readout_grid_size, readout_spline_order;
+    int64_t readout_widths[KAGNN_MODEL_MAX_READOUT + 1];               /* hidden, ..., outputs */
+    int64_t readout_modes[KAGNN_MODEL_MAX_READOUT];
+    int64_t atom_rows[KAGNN_MODEL_MAX_TABLES], bond_rows[KAGNN_MODEL_MAX_TABLES];
+    const int64_t* x_index; const int64_t* e_index;
+    const float* atom_table[KAGNN_MODEL_MAX_TABLES]; const float* bond_table[KAGNN_MODEL_MAX_TABLES];
+    const int32_t* rowptr; const int32_t* col; const int32_t* perm;        /* CSR by destination (kagnn_csr_build_small) */
+    const int32_t* rowptr_t; const int32_t* col_t; const int32_t* perm_t;  /* ... and its transpose */
+    const int32_t* seg_ptr;                                                /* [num_graphs + 1] node offsets */
+    const float* knots;
+    const float* base_weight[KAGNN_MODEL_MAX_LAYERS]; const float* spline_weight[KAGNN_MODEL_MAX_LAYERS];
+    const float* spline_scaler[KAGNN_MODEL_MAX_LAYERS];
+    const float* bn_weight[KAGNN_MODEL_MAX_CONVS]; const float* bn_bias[KAGNN_MODEL_MAX_CONVS];
+    float* running_mean[KAGNN_MODEL_MAX_CONVS]; float* running_var[KAGNN_MODEL_MAX_CONVS];      /* NULL: not tracked */
+    const float* readout_knots[KAGNN_MODEL_MAX_READOUT];
+    const float* readout_base_weight[KAGNN_MODEL_MAX_READOUT]; const float* readout_spline_weight[KAGNN_MODEL_MAX_READOUT];
+    const float* readout_spline_scaler[KAGNN_MODEL_MAX_READOUT];      /* NULL entries: no scaler */
+    void* saved; int64_t saved_bytes;                                 /* forward writes, backward reads */
+    void* workspace; int64_t workspace_bytes;                         /* scratch of the call (forward / backward sizes differ) */
+    float* out;                                                       /* forward: [num_graphs, readout_widths[num_readout]] */
+    const float* g_out; int64_t ld_g_out;                             /* backward: gradient of `out` */
+    float* grads;                                                     /* backward: all parameter gradients, flat */
+    float self_scale[KAGNN_MODEL_MAX_CONVS];                          /* 1 + eps of every GINE convolution */
+    float momentum[KAGNN_MODEL_MAX_CONVS]; float eps[KAGNN_MODEL_MAX_CONVS];
+} kagnn_kagin_model_t;
+int kagnn_kagin_model_struct_bytes(void);                             /* sizeof(kagnn_kagin_model_t): a binding checks its mirror */
+int kagnn_kagin_model_sizes(const kagnn_kagin_model_t* model, size_t* saved_bytes_host, size_t* fwd_workspace_bytes_host,
+                            size_t* bwd_workspace_bytes_host, size_t* grads_floats_host);
+int kagnn_kagin_model_fwd(const kagnn_kagin_model_t* model, void* stream);
+int kagnn_kagin_model_bwd(const kagnn_kagin_model_t* model, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,10 @@ _SIGNATURES = {
                                           _P, c_int32, c_int32, _P, c_size_t, _P]),
     "kagnn_fastkan_shard_bwd_finish": (c_int32, [_P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P,
                                                  _P, _P, c_int64, _P, _P, c_int32, _P, c_size_t, _P]),
+    "kagnn_kagin_model_struct_bytes": (c_int32, []),
+    "kagnn_kagin_model_sizes": (c_int32, [_P, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t)]),
+    "kagnn_kagin_model_fwd": (c_int32, [_P, _P]),
+    "kagnn_kagin_model_bwd": (c_int32, [_P, _P]),
     "kagnn_gat_att_grad_workspace_bytes": (c_int32, [c_int64, c_int32, c_int32, POINTER(c_size_t)]),
     "kagnn_gat_att_grad": (c_int32, [_P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "kagnn_softmax_xent_workspace_bytes": (c_int32, [c_int64, POINTER(c_size_t)]),
@@ -167,6 +171,33 @@ _SIGNATURES = {
                                       _P, c_int64, _P, _P, _P, c_size_t, _P]),
 }
 
+MODEL_MAX_LAYERS, MODEL_MAX_CONVS, MODEL_MAX_TABLES, MODEL_MAX_READOUT = 16, 16, 16, 8
+
+
+class KaginModel(ctypes.Structure):
+    """mirror of ``kagnn_kagin_model_t`` (include/kagnn_hip.h); ``load()`` checks its size against the library's"""
+    _fields_ = [
+        ("num_nodes", c_int64), ("num_edges", c_int64), ("num_graphs", c_int64), ("hidden", c_int64),
+        ("num_atom_tables", c_int64), ("num_bond_tables", c_int64), ("x_stride", c_int64), ("e_stride", c_int64),
+        ("num_convs", c_int64), ("num_layers", c_int64), ("grid_size", c_int64), ("spline_order", c_int64), ("mode", c_int64),
+        ("num_readout", c_int64), ("readout_grid_size", c_int64), ("readout_spline_order", c_int64),
+        ("readout_widths", c_int64 * (MODEL_MAX_READOUT + 1)), ("readout_modes", c_int64 * MODEL_MAX_READOUT),
+        ("atom_rows", c_int64 * MODEL_MAX_TABLES), ("bond_rows", c_int64 * MODEL_MAX_TABLES),
+        ("x_index", c_void_p), ("e_index", c_void_p),
+        ("atom_table", c_void_p * MODEL_MAX_TABLES), ("bond_table", c_void_p * MODEL_MAX_TABLES),
+        ("rowptr", c_void_p), ("col", c_void_p), ("perm", c_void_p), ("rowptr_t", c_void_p), ("col_t", c_void_p), ("perm_t", c_void_p),
+        ("seg_ptr", c_void_p), ("knots", c_void_p),
+        ("base_weight", c_void_p * MODEL_MAX_LAYERS), ("spline_weight", c_void_p * MODEL_MAX_LAYERS), ("spline_scaler", c_void_p * MODEL_MAX_LAYERS),
+        ("bn_weight", c_void_p * MODEL_MAX_CONVS), ("bn_bias", c_void_p * MODEL_MAX_CONVS),
+        ("running_mean", c_void_p * MODEL_MAX_CONVS), ("running_var", c_void_p * MODEL_MAX_CONVS),
+        ("readout_knots", c_void_p * MODEL_MAX_READOUT), ("readout_base_weight", c_void_p * MODEL_MAX_READOUT),
+        ("readout_spline_weight", c_void_p * MODEL_MAX_READOUT), ("readout_spline_scaler", c_void_p * MODEL_MAX_READOUT),
+        ("saved", c_void_p), ("saved_bytes", c_int64), ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("out", c_void_p), ("g_out", c_void_p), ("ld_g_out", c_int64), ("grads", c_void_p),
+        ("self_scale", c_float * MODEL_MAX_CONVS), ("momentum", c_float * MODEL_MAX_CONVS), ("eps", c_float * MODEL_MAX_CONVS),
+    ]
+
+
 EXPORTED = tuple(_SIGNATURES)
 _lib = None
 
@@ -184,6 +215,9 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
             fn.restype = res
             fn.argtypes = args
+        if lib.kagnn_kagin_model_struct_bytes() != ctypes.sizeof(KaginModel):
+            raise RuntimeError(f"kagnn_kagin_model_t is {lib.kagnn_kagin_model_struct_bytes()} bytes in {LIB_PATH}, its ctypes mirror "
+                               f"{ctypes.sizeof(KaginModel)}: header and kagnn_amd/_lib.py disagree")
         _lib = lib
     return _lib
 

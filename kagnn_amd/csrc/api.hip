@@ -1641,5 +1641,282 @@ int kagnn_gine_kan_stack_bwd(const float* g, int64_t ldg, const float* x, int64_
     }
 }
 
+// ---------------------------------------------------------------- the whole graph-regression model per call (round 6)
+// KAGIN.forward of the reference's graph_regression/models.py:107-119 and its backward as ONE library call each way: the sequence of
+// this file's own entry points that kagnn_amd/graph_ops.py::_KaginModelFn runs from Python, with the same arguments in the same
+// order -- the same kernels, the same bits -- minus ~17 ctypes round trips, ~45 tensor allocations and their pointer tables.
+namespace {
+struct KmLayout {
+    // `saved`: byte offsets
+    size_t x0, ea, acts, h, stats, packs, pooled, ro_act[KAGNN_MODEL_MAX_READOUT], ro_pf[KAGNN_MODEL_MAX_READOUT], ro_pd[KAGNN_MODEL_MAX_READOUT], saved_total;
+    size_t fb, db;                       // one stack layer's forward / input-gradient pack, 256-aligned
+    // workspaces: byte offsets of the fixed parts, then the shared scratch of the sub-calls
+    size_t fwd_scratch, fwd_total;
+    size_t bwd_gy[2], bwd_gh, bwd_gx0, bwd_gea, bwd_scratch, bwd_total;
+    size_t grads_floats;
+    size_t g_atom[KAGNN_MODEL_MAX_TABLES], g_bond[KAGNN_MODEL_MAX_TABLES], g_bn_w[KAGNN_MODEL_MAX_CONVS], g_bn_b[KAGNN_MODEL_MAX_CONVS];
+    size_t g_bw[KAGNN_MODEL_MAX_LAYERS], g_sw[KAGNN_MODEL_MAX_LAYERS], g_sc[KAGNN_MODEL_MAX_LAYERS];
+    size_t g_ro_bw[KAGNN_MODEL_MAX_READOUT], g_ro_sw[KAGNN_MODEL_MAX_READOUT], g_ro_sc[KAGNN_MODEL_MAX_READOUT];   // float offsets into grads
+    bool ro_batch;                       // the read-out's packs in one launch (kagnn_kan_pack_batch)
+};
+
+int km_check(const kagnn_kagin_model_t* m, const char* fn) {
+    if (!m) return fail(KAGNN_ERR_ARG, "%s: null model", fn);
+    const bool ok = m->num_nodes >= 2 && m->num_edges >= 0 && m->num_graphs >= 1 && m->hidden >= 1 && m->hidden <= 64 &&
+                    m->num_atom_tables >= 1 && m->num_atom_tables <= KAGNN_MODEL_MAX_TABLES && m->num_bond_tables >= 1 &&
+                    m->num_bond_tables <= KAGNN_MODEL_MAX_TABLES && m->x_stride >= m->num_atom_tables && m->e_stride >= m->num_bond_tables &&
+                    m->num_convs >= 1 && m->num_convs <= KAGNN_MODEL_MAX_CONVS && m->num_layers >= 1 && m->num_layers <= 8 &&
+                    m->num_convs * m->num_layers <= KAGNN_MODEL_MAX_LAYERS && m->num_readout >= 1 && m->num_readout <= KAGNN_MODEL_MAX_READOUT &&
+                    m->readout_widths[0] == m->hidden;
+    if (!ok) return fail(KAGNN_ERR_ARG, "%s: sizes outside the limits of kagnn_kagin_model_t (include/kagnn_hip.h)", fn);
+    return KAGNN_OK;
+}
+
+int km_layout(const kagnn_kagin_model_t* m, KmLayout& L, const char* fn) {
+    int rc = km_check(m, fn);
+    if (rc) return rc;
+    const size_t N = (size_t)m->num_nodes, E = (size_t)m->num_edges, B = (size_t)m->num_graphs, H = (size_t)m->hidden;
+    const int nconv = (int)m->num_convs, nl = (int)m->num_layers, G = (int)m->grid_size, K = (int)m->spline_order, mode = (int)m->mode;
+    const int C = G + K;
+    size_t fb = 0, db = 0;
+    rc = kagnn_kan_pack_bytes((int)H, (int)H, G, K, mode, &fb, &db); if (rc) return rc;
+    L.fb = al256z(fb); L.db = al256z(db);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += al256z(bytes); return at; };
+    L.x0 = take(N * H * 4);
+    L.ea = take((E ? E : 1) * H * 4);
+    L.acts = take((size_t)nconv * (nl + 1) * N * H * 4);
+    L.h = take((size_t)nconv * N * H * 4);
+    L.stats = take((size_t)nconv * 2 * H * 4);
+    L.packs = take((size_t)nconv * nl * (L.fb + L.db));
+    L.pooled = take(B * H * 4);
+    const int nr = (int)m->num_readout;
+    bool batch = nr >= 2 && (int)m->readout_spline_order == 3 && (int)m->readout_grid_size + 3 <= 8;
+    for (int i = 0; i < nr; ++i) {
+        const int fin = (int)m->readout_widths[i], fout = (int)m->readout_widths[i + 1], rm = (int)m->readout_modes[i];
+        if (fin < 1 || fout < 1) return fail(KAGNN_ERR_ARG, "%s: read-out widths", fn);
+        L.ro_act[i] = i == 0 ? L.pooled : take(B * (size_t)fin * 4);          // input of read-out layer i
+        size_t pf = 0, pd = 0;
+        rc = kagnn_kan_pack_bytes(fin, fout, (int)m->readout_grid_size, (int)m->readout_spline_order, rm, &pf, &pd); if (rc) return rc;
+        L.ro_pf[i] = take(pf); L.ro_pd[i] = take(pd);
+        batch = batch && rm == (int)m->readout_modes[0] && (rm == KAGNN_PREC_SPLIT || rm == KAGNN_PREC_HALF) && fout <= 64;
+    }
+    L.ro_batch = batch;
+    L.saved_total = o + 256;
+    // forward workspace: the stack's, the read-out forwards' split-K scratch
+    int32_t widths[9];
+    for (int l = 0; l <= nl; ++l) widths[l] = (int32_t)H;
+    size_t sf = 0, sb = 0;
+    rc = kagnn_gine_kan_stack_workspace_bytes((int64_t)N, nconv, nl, widths, G, K, mode, &sf, &sb); if (rc) return rc;
+    size_t scratch_f = sf, scratch_b = sb;
+    for (int i = 0; i < nr; ++i) {
+        const int fin = (int)m->readout_widths[i], fout = (int)m->readout_widths[i + 1], rm = (int)m->readout_modes[i];
+        size_t a = 0, b = 0;
+        rc = kagnn_kan_fwd_workspace_bytes((int64_t)B, fin, fout, (int)m->readout_grid_size, (int)m->readout_spline_order, rm, &a); if (rc) return rc;
+        rc = kagnn_kan_bwd_weight_workspace_bytes((int64_t)B, fin, fout, (int)m->readout_grid_size, (int)m->readout_spline_order, rm, &b); if (rc) return rc;
+        scratch_f = scratch_f > a ? scratch_f : a;
+        scratch_b = scratch_b > b ? scratch_b : b;
+    }
+    for (int t = 0; t < (int)m->num_atom_tables; ++t) {
+        size_t a = 0;
+        rc = kagnn_embedding_bwd_workspace_bytes((int64_t)N, (int)m->atom_rows[t], (int)H, &a); if (rc) return rc;
+        scratch_b = scratch_b > a ? scratch_b : a;
+    }
+    for (int t = 0; t < (int)m->num_bond_tables; ++t) {
+        size_t a = 0;
+        rc = kagnn_embedding_bwd_workspace_bytes((int64_t)E, (int)m->bond_rows[t], (int)H, &a); if (rc) return rc;
+        scratch_b = scratch_b > a ? scratch_b : a;
+    }
+    L.fwd_scratch = 0; L.fwd_total = al256z(scratch_f) + 256;
+    size_t wmax = 1;
+    for (int i = 0; i <= nr; ++i) wmax = wmax > (size_t)m->readout_widths[i] ? wmax : (size_t)m->readout_widths[i];
+    o = 0;
+    L.bwd_gy[0] = take(B * wmax * 4); L.bwd_gy[1] = take(B * wmax * 4);
+    L.bwd_gh = take(N * H * 4); L.bwd_gx0 = take(N * H * 4); L.bwd_gea = take((E ? E : 1) * H * 4);
+    L.bwd_scratch = o; L.bwd_total = o + al256z(scratch_b) + 256;
+    // the flat gradient buffer (floats)
+    size_t g = 0;
+    for (int t = 0; t < (int)m->num_atom_tables; ++t) { L.g_atom[t] = g; g += (size_t)m->atom_rows[t] * H; }
+    for (int t = 0; t < (int)m->num_bond_tables; ++t) { L.g_bond[t] = g; g += (size_t)m->bond_rows[t] * H; }
+    for (int i = 0; i < nconv; ++i) {
+        L.g_bn_w[i] = g; g += H; L.g_bn_b[i] = g; g += H;
+        for (int l = 0; l < nl; ++l) {
+            const int k = i * nl + l;
+            L.g_bw[k] = g; g += H * H; L.g_sw[k] = g; g += H * H * C; L.g_sc[k] = g; g += H * H;
+        }
+    }
+    for (int i = 0; i < nr; ++i) {
+        const size_t fin = (size_t)m->readout_widths[i], fout = (size_t)m->readout_widths[i + 1];
+        const size_t Cr = (size_t)(m->readout_grid_size + m->readout_spline_order);
+        L.g_ro_bw[i] = g; g += fout * fin; L.g_ro_sw[i] = g; g += fout * fin * Cr;
+        L.g_ro_sc[i] = g; if (m->readout_spline_scaler[i]) g += fout * fin;
+    }
+    L.grads_floats = g;
+    return KAGNN_OK;
+}
+}  // namespace
+
+int kagnn_kagin_model_struct_bytes(void) { return (int)sizeof(kagnn_kagin_model_t); }
+
+int kagnn_kagin_model_sizes(const kagnn_kagin_model_t* m, size_t* saved_bytes, size_t* fwd_ws, size_t* bwd_ws, size_t* grads_floats) {
+    KAGNN_CHECK_ARG(saved_bytes && fwd_ws && bwd_ws && grads_floats, "null output");
+    KmLayout L;
+    int rc = km_layout(m, L, __func__);
+    if (rc) return rc;
+    *saved_bytes = L.saved_total; *fwd_ws = L.fwd_total; *bwd_ws = L.bwd_total; *grads_floats = L.grads_floats;
+    return KAGNN_OK;
+}
+
+int kagnn_kagin_model_fwd(const kagnn_kagin_model_t* m, void* stream) {
+    KmLayout L;
+    int rc = km_layout(m, L, __func__);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(m->saved && m->workspace && m->out && m->x_index && m->rowptr && m->seg_ptr && m->knots, "null array");
+    KAGNN_CHECK_ARG(m->num_edges == 0 || (m->e_index && m->col && m->perm), "null edge array");       // (a batch of single atoms has none)
+    KAGNN_CHECK_ARG((size_t)m->saved_bytes >= L.saved_total && (size_t)m->workspace_bytes >= L.fwd_total,
+                    "saved / workspace too small (kagnn_kagin_model_sizes)");
+    const int64_t N = m->num_nodes, E = m->num_edges, B = m->num_graphs;
+    const int H = (int)m->hidden, nconv = (int)m->num_convs, nl = (int)m->num_layers, G = (int)m->grid_size, K = (int)m->spline_order, mode = (int)m->mode;
+    unsigned char* sv = static_cast<unsigned char*>(m->saved);
+    unsigned char* ws = static_cast<unsigned char*>(m->workspace);
+    float* x0 = reinterpret_cast<float*>(sv + L.x0);
+    float* ea = reinterpret_cast<float*>(sv + L.ea);
+    // encoders: sum over the feature columns of one table each (models.py:244-281)
+    for (int t = 0; t < (int)m->num_atom_tables; ++t) {
+        rc = kagnn_embedding_fwd(m->x_index + t, m->x_stride, N, m->atom_table[t], (int32_t)m->atom_rows[t], H, x0, H, t > 0, stream);
+        if (rc) return rc;
+    }
+    if (E == 0) { KAGNN_HIP(hipMemsetAsync(ea, 0, (size_t)H * sizeof(float), as_stream(stream))); }   // (a batch of single atoms: a row nothing reads)
+    for (int t = 0; t < (int)m->num_bond_tables; ++t) {
+        rc = kagnn_embedding_fwd(m->e_index + t, m->e_stride, E, m->bond_table[t], (int32_t)m->bond_rows[t], H, ea, H, t > 0, stream);
+        if (rc) return rc;
+    }
+    // the GINE stack
+    int32_t widths[9];
+    for (int l = 0; l <= nl; ++l) widths[l] = H;
+    float* acts[KAGNN_MODEL_MAX_CONVS * 9];
+    void* pf[KAGNN_MODEL_MAX_LAYERS]; void* pd[KAGNN_MODEL_MAX_LAYERS];
+    float* h[KAGNN_MODEL_MAX_CONVS]; float* mean[KAGNN_MODEL_MAX_CONVS]; float* rstd[KAGNN_MODEL_MAX_CONVS];
+    const size_t hs = (size_t)N * H * sizeof(float);
+    for (int k = 0; k < nconv * (nl + 1); ++k) acts[k] = reinterpret_cast<float*>(sv + L.acts + (size_t)k * hs);
+    for (int k = 0; k < nconv * nl; ++k) { pf[k] = sv + L.packs + (size_t)k * L.fb; pd[k] = sv + L.packs + (size_t)nconv * nl * L.fb + (size_t)k * L.db; }
+    for (int i = 0; i < nconv; ++i) {
+        h[i] = reinterpret_cast<float*>(sv + L.h + (size_t)i * hs);
+        mean[i] = reinterpret_cast<float*>(sv + L.stats) + (size_t)(2 * i) * H;
+        rstd[i] = reinterpret_cast<float*>(sv + L.stats) + (size_t)(2 * i + 1) * H;
+    }
+    rc = kagnn_gine_kan_stack_fwd(x0, H, ea, H, N, m->rowptr, m->col, m->perm, m->self_scale, nconv, nl, widths, m->base_weight, m->spline_weight,
+                                  m->spline_scaler, m->knots, G, K, mode, acts, pf, pd, m->bn_weight, m->bn_bias,
+                                  const_cast<float* const*>(m->running_mean), const_cast<float* const*>(m->running_var), m->momentum, m->eps, h, mean, rstd,
+                                  ws + L.fwd_scratch, (size_t)m->workspace_bytes - L.fwd_scratch, stream);
+    if (rc) return rc;
+    // global_add_pool, then the read-out chain
+    float* pooled = reinterpret_cast<float*>(sv + L.pooled);
+    rc = kagnn_segment_pool(h[nconv - 1], H, pooled, H, m->seg_ptr, B, H, 0, stream);
+    if (rc) return rc;
+    const int nr = (int)m->num_readout, rG = (int)m->readout_grid_size, rK = (int)m->readout_spline_order;
+    void* rpf[KAGNN_MODEL_MAX_READOUT]; void* rpd[KAGNN_MODEL_MAX_READOUT];
+    int32_t rin[KAGNN_MODEL_MAX_READOUT], rout[KAGNN_MODEL_MAX_READOUT];
+    for (int i = 0; i < nr; ++i) { rpf[i] = sv + L.ro_pf[i]; rpd[i] = sv + L.ro_pd[i]; rin[i] = (int32_t)m->readout_widths[i]; rout[i] = (int32_t)m->readout_widths[i + 1]; }
+    if (L.ro_batch) {
+        rc = kagnn_kan_pack_batch(nr, m->readout_base_weight, m->readout_spline_weight, m->readout_spline_scaler, rin, rout, rG, rK,
+                                  (int32_t)m->readout_modes[0], rpf, rpd, stream);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < nr; ++i) {
+        const int rm = (int)m->readout_modes[i];
+        if (!L.ro_batch) {
+            rc = kagnn_kan_pack(m->readout_base_weight[i], m->readout_spline_weight[i], m->readout_spline_scaler[i], rin[i], rout[i], rG, rK, rm, rpf[i], rpd[i], stream);
+            if (rc) return rc;
+        }
+        const float* xin = reinterpret_cast<const float*>(sv + L.ro_act[i]);
+        float* y = i + 1 < nr ? reinterpret_cast<float*>(sv + L.ro_act[i + 1]) : m->out;
+        size_t wb = 0;
+        rc = kagnn_kan_fwd_workspace_bytes(B, rin[i], rout[i], rG, rK, rm, &wb); if (rc) return rc;
+        rc = kagnn_kan_linear_fwd(xin, rin[i], B, m->readout_knots[i], rin[i], rout[i], rG, rK, rm, rpf[i], y, rout[i],
+                                  wb ? ws + L.fwd_scratch : nullptr, wb, stream);
+        if (rc) return rc;
+    }
+    return KAGNN_OK;
+}
+
+int kagnn_kagin_model_bwd(const kagnn_kagin_model_t* m, void* stream) {
+    KmLayout L;
+    int rc = km_layout(m, L, __func__);
+    if (rc) return rc;
+    KAGNN_CHECK_ARG(m->saved && m->workspace && m->g_out && m->grads && m->x_index && m->rowptr_t && m->seg_ptr && m->knots, "null array");
+    KAGNN_CHECK_ARG(m->num_edges == 0 || (m->e_index && m->col_t && m->perm_t), "null edge array");
+    KAGNN_CHECK_ARG((size_t)m->saved_bytes >= L.saved_total && (size_t)m->workspace_bytes >= L.bwd_total,
+                    "saved / workspace too small (kagnn_kagin_model_sizes)");
+    const int64_t N = m->num_nodes, E = m->num_edges, B = m->num_graphs;
+    const int H = (int)m->hidden, nconv = (int)m->num_convs, nl = (int)m->num_layers, G = (int)m->grid_size, K = (int)m->spline_order, mode = (int)m->mode;
+    unsigned char* sv = static_cast<unsigned char*>(m->saved);
+    unsigned char* ws = static_cast<unsigned char*>(m->workspace);
+    float* gr = m->grads;
+    const int nr = (int)m->num_readout, rG = (int)m->readout_grid_size, rK = (int)m->readout_spline_order;
+    KAGNN_CHECK_ARG(m->ld_g_out >= m->readout_widths[nr], "ld_g_out smaller than the model's output width");
+    // read-out, last layer first: input gradient, then weight gradient (the order of graph_ops._KaginModelFn.backward)
+    const float* gy = m->g_out;
+    int64_t ldgy = m->ld_g_out;
+    for (int i = nr - 1; i >= 0; --i) {
+        const int fin = (int)m->readout_widths[i], fout = (int)m->readout_widths[i + 1], rm = (int)m->readout_modes[i];
+        const float* xin = reinterpret_cast<const float*>(sv + L.ro_act[i]);
+        float* gx = reinterpret_cast<float*>(ws + L.bwd_gy[i & 1]);
+        rc = kagnn_kan_linear_bwd_input(xin, fin, gy, ldgy, B, m->readout_knots[i], fin, fout, rG, rK, rm, sv + L.ro_pd[i], gx, fin, KAGNN_DTYPE_F32, stream);
+        if (rc) return rc;
+        size_t wb = 0;
+        rc = kagnn_kan_bwd_weight_workspace_bytes(B, fin, fout, rG, rK, rm, &wb); if (rc) return rc;
+        rc = kagnn_kan_linear_bwd_weight(xin, fin, gy, ldgy, B, m->readout_knots[i], fin, fout, rG, rK, rm, m->readout_spline_weight[i],
+                                         m->readout_spline_scaler[i], gr + L.g_ro_bw[i], gr + L.g_ro_sw[i],
+                                         m->readout_spline_scaler[i] ? gr + L.g_ro_sc[i] : nullptr, ws + L.bwd_scratch, wb, stream);
+        if (rc) return rc;
+        gy = gx; ldgy = fin;
+    }
+    // pool backward, the stack, the encoders
+    float* gh = reinterpret_cast<float*>(ws + L.bwd_gh);
+    rc = kagnn_segment_broadcast(gy, ldgy, gh, H, m->seg_ptr, B, H, 0, stream);
+    if (rc) return rc;
+    int32_t widths[9];
+    for (int l = 0; l <= nl; ++l) widths[l] = H;
+    const float* acts[KAGNN_MODEL_MAX_CONVS * 9];
+    const void* pd[KAGNN_MODEL_MAX_LAYERS];
+    const float* h[KAGNN_MODEL_MAX_CONVS]; const float* mean[KAGNN_MODEL_MAX_CONVS]; const float* rstd[KAGNN_MODEL_MAX_CONVS];
+    float* g_bn_w[KAGNN_MODEL_MAX_CONVS]; float* g_bn_b[KAGNN_MODEL_MAX_CONVS];
+    float* g_bw[KAGNN_MODEL_MAX_LAYERS]; float* g_sw[KAGNN_MODEL_MAX_LAYERS]; float* g_sc[KAGNN_MODEL_MAX_LAYERS];
+    const size_t hs = (size_t)N * H * sizeof(float);
+    for (int k = 0; k < nconv * (nl + 1); ++k) acts[k] = reinterpret_cast<const float*>(sv + L.acts + (size_t)k * hs);
+    for (int k = 0; k < nconv * nl; ++k) {
+        pd[k] = sv + L.packs + (size_t)nconv * nl * L.fb + (size_t)k * L.db;
+        g_bw[k] = gr + L.g_bw[k]; g_sw[k] = gr + L.g_sw[k]; g_sc[k] = gr + L.g_sc[k];
+    }
+    for (int i = 0; i < nconv; ++i) {
+        h[i] = reinterpret_cast<const float*>(sv + L.h + (size_t)i * hs);
+        mean[i] = reinterpret_cast<const float*>(sv + L.stats) + (size_t)(2 * i) * H;
+        rstd[i] = reinterpret_cast<const float*>(sv + L.stats) + (size_t)(2 * i + 1) * H;
+        g_bn_w[i] = gr + L.g_bn_w[i]; g_bn_b[i] = gr + L.g_bn_b[i];
+    }
+    const float* x0 = reinterpret_cast<const float*>(sv + L.x0);
+    const float* ea = reinterpret_cast<const float*>(sv + L.ea);
+    float* gx0 = reinterpret_cast<float*>(ws + L.bwd_gx0);
+    float* gea = reinterpret_cast<float*>(ws + L.bwd_gea);
+    rc = kagnn_gine_kan_stack_bwd(gh, H, x0, H, ea, H, N, m->rowptr_t, m->col_t, m->perm_t, m->self_scale, nconv, nl, widths, m->spline_weight,
+                                  m->spline_scaler, m->knots, G, K, mode, acts, pd, h, m->bn_weight, mean, rstd, gx0, H, gea, H, g_bn_w, g_bn_b, g_bw, g_sw,
+                                  g_sc, ws + L.bwd_scratch, (size_t)m->workspace_bytes - L.bwd_scratch, stream);
+    if (rc) return rc;
+    for (int t = 0; t < (int)m->num_atom_tables; ++t) {
+        size_t wb = 0;
+        rc = kagnn_embedding_bwd_workspace_bytes(N, (int32_t)m->atom_rows[t], H, &wb); if (rc) return rc;
+        rc = kagnn_embedding_bwd(m->x_index + t, m->x_stride, N, gx0, H, (int32_t)m->atom_rows[t], H, gr + L.g_atom[t], ws + L.bwd_scratch, wb, stream);
+        if (rc) return rc;
+    }
+    for (int t = 0; t < (int)m->num_bond_tables; ++t) {
+        size_t wb = 0;
+        rc = kagnn_embedding_bwd_workspace_bytes(E, (int32_t)m->bond_rows[t], H, &wb); if (rc) return rc;
+        rc = kagnn_embedding_bwd(m->e_index + t, m->e_stride, E, gea, H, (int32_t)m->bond_rows[t], H, gr + L.g_bond[t], ws + L.bwd_scratch, wb, stream);
+        if (rc) return rc;
+    }
+    return KAGNN_OK;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

@@ -480,6 +480,123 @@ class _KaginModelFn(Function):
         return (None, None, None, None, None, *agrads, *bgrads, *sgrads, *ro_grads)
 
 
+# ======================================================================== ... and as ONE library call each way (round 6)
+_MODEL_SIZES: dict = {}
+
+
+def _model_struct(plan, params, cache_owner):
+    """a ``kagnn_kagin_model_t`` with everything that does not change from step to step filled in -- parameter pointers, table
+    shapes, layer configuration -- copied from a per-model template as long as the parameters still live where they did"""
+    from . import _lib
+    ptrs = [0 if t is None else t.data_ptr() for t in params]
+    key = (tuple(ptrs), plan.n_atom, plan.n_bond, plan.nconv, plan.nl, plan.G, plan.K, plan.mode, plan.ro_G, plan.ro_K, tuple(plan.ro_modes),
+           plan.scales, plan.momentum, plan.eps, tuple(0 if r[0] is None else r[0].data_ptr() for r in plan.running), plan.knots.data_ptr(),
+           tuple(k.data_ptr() for k in plan.ro_knots))
+    hit = cache_owner.__dict__.get("_kagnn_model_call_template")
+    if hit is None or hit[0] != key:
+        m = _lib.KaginModel()
+        a, b, c = plan.n_atom, plan.n_atom + plan.n_bond, plan.n_atom + plan.n_bond + plan.n_stack
+        H = params[0].size(1)
+        m.hidden, m.num_atom_tables, m.num_bond_tables = H, plan.n_atom, plan.n_bond
+        for t in range(plan.n_atom):
+            m.atom_table[t], m.atom_rows[t] = ptrs[t], params[t].size(0)
+        for t in range(plan.n_bond):
+            m.bond_table[t], m.bond_rows[t] = ptrs[a + t], params[a + t].size(0)
+        m.num_convs, m.num_layers, m.grid_size, m.spline_order, m.mode = plan.nconv, plan.nl, plan.G, plan.K, plan.mode
+        per = 2 + 3 * plan.nl
+        for i in range(plan.nconv):
+            m.bn_weight[i], m.bn_bias[i] = ptrs[b + i * per], ptrs[b + i * per + 1]
+            rm, rv = plan.running[i]
+            m.running_mean[i] = None if rm is None else rm.data_ptr()
+            m.running_var[i] = None if rv is None else rv.data_ptr()
+            m.self_scale[i], m.momentum[i], m.eps[i] = float(plan.scales[i]), float(plan.momentum[i]), float(plan.eps[i])
+            for l in range(plan.nl):
+                k = i * plan.nl + l
+                m.base_weight[k], m.spline_weight[k], m.spline_scaler[k] = ptrs[b + i * per + 2 + 3 * l: b + i * per + 5 + 3 * l]
+        m.knots = plan.knots.data_ptr()
+        m.num_readout, m.readout_grid_size, m.readout_spline_order = plan.n_readout, plan.ro_G, plan.ro_K
+        m.readout_widths[0] = H
+        for i in range(plan.n_readout):
+            bw, sw, sc = params[c + 3 * i: c + 3 * i + 3]
+            m.readout_widths[i + 1] = sw.size(0)
+            m.readout_modes[i] = plan.ro_modes[i]
+            m.readout_knots[i] = plan.ro_knots[i].data_ptr()
+            m.readout_base_weight[i], m.readout_spline_weight[i] = bw.data_ptr(), sw.data_ptr()
+            m.readout_spline_scaler[i] = None if sc is None else sc.data_ptr()
+        hit = (key, bytes(m))                     # (plain bytes: the module stays deep-copyable / picklable; a stale copy fails the key)
+        cache_owner.__dict__["_kagnn_model_call_template"] = hit
+    return _lib.KaginModel.from_buffer_copy(hit[1])
+
+
+class _KaginModelCallFn(Function):
+    """``_KaginModelFn`` with its library calls folded into ONE per direction (``kagnn_kagin_model_fwd / _bwd``, include/kagnn_hip.h):
+    the same entry points in the same order with the same arguments, sequenced inside the library -- same bits --, the activations
+    the backward needs in ONE ``saved`` buffer, all parameter gradients in ONE flat buffer handed back as views.  What is left on the
+    host per direction: two or three allocations, ~25 field assignments, one ctypes call."""
+
+    @staticmethod
+    @_on_operand_device
+    def forward(ctx, x_int, e_int, g, seg, plan, owner, *params):
+        from . import _lib
+        params = tuple(None if t is None else t.contiguous() for t in params)
+        xi, ei = x_int.contiguous(), e_int.contiguous()
+        m = _model_struct(plan, params, owner)
+        n, e, nb = xi.size(0), ei.size(0), seg.numel() - 1
+        if n != g.num_nodes or e != g.num_edges:
+            raise ValueError("x must have one row per node and edge_attr one per edge of the graph")
+        m.num_nodes, m.num_edges, m.num_graphs, m.x_stride, m.e_stride = n, e, nb, xi.size(1), ei.size(1)
+        m.x_index, m.e_index = xi.data_ptr(), ei.data_ptr()
+        m.rowptr, m.col, m.perm = g.rowptr.data_ptr(), g.col.data_ptr(), g.perm.data_ptr()
+        m.rowptr_t, m.col_t, m.perm_t = g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.perm_t.data_ptr()
+        m.seg_ptr = seg.data_ptr()
+        skey = (n, e, nb, int(m.hidden), plan.n_atom, plan.n_bond, plan.nconv, plan.nl, plan.G, plan.K, plan.mode, plan.ro_G, plan.ro_K,
+                tuple(plan.ro_modes), tuple(int(m.readout_widths[i]) for i in range(plan.n_readout + 1)),
+                tuple(int(m.atom_rows[t]) for t in range(plan.n_atom)), tuple(int(m.bond_rows[t]) for t in range(plan.n_bond)),
+                tuple(params[-3 * plan.n_readout + 3 * i + 2] is not None for i in range(plan.n_readout)))
+        sizes = _MODEL_SIZES.get(skey)
+        if sizes is None:
+            outs = [ctypes.c_size_t(0) for _ in range(4)]
+            _call("kagnn_kagin_model_sizes", ctypes.byref(m), *[ctypes.byref(o) for o in outs])
+            if len(_MODEL_SIZES) > 512:
+                _MODEL_SIZES.clear()
+            sizes = _MODEL_SIZES[skey] = tuple(o.value for o in outs)
+        dev = xi.device
+        saved = torch.empty(sizes[0], dtype=torch.uint8, device=dev)
+        ws = torch.empty(sizes[1], dtype=torch.uint8, device=dev)
+        out = torch.empty((nb, int(m.readout_widths[plan.n_readout])), dtype=torch.float32, device=dev)
+        m.saved, m.saved_bytes, m.workspace, m.workspace_bytes, m.out = saved.data_ptr(), sizes[0], ws.data_ptr(), sizes[1], out.data_ptr()
+        _call("kagnn_kagin_model_fwd", ctypes.byref(m), _stream())
+        ctx.save_for_backward(saved, xi, ei, seg, g.rowptr_t, g.col_t, g.perm_t, plan.knots, *plan.ro_knots, *params)
+        ctx.model, ctx.sizes, ctx.graph = m, sizes, g
+        ctx.shapes = [None if t is None else tuple(t.shape) for t in params]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @_on_operand_device
+    def backward(ctx, gout):
+        m, sizes = ctx.model, ctx.sizes
+        _ = ctx.saved_tensors                       # (autograd's in-place checks on everything the library is about to read)
+        gy = _rows(gout)
+        dev = gy.device
+        ws = torch.empty(sizes[2], dtype=torch.uint8, device=dev)
+        flat = torch.empty(sizes[3], dtype=torch.float32, device=dev)
+        m.workspace, m.workspace_bytes, m.g_out, m.ld_g_out, m.grads = ws.data_ptr(), sizes[2], gy.data_ptr(), _ld(gy), flat.data_ptr()
+        _call("kagnn_kagin_model_bwd", ctypes.byref(m), _stream())
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            if shp is None:
+                grads.append(None)
+                continue
+            cnt = 1
+            for d in shp:
+                cnt *= d
+            grads.append(flat[off:off + cnt].view(shp))
+            off += cnt
+        return (None, None, None, None, None, None, *grads)
+
+
+_GINE_MODEL_CALL = True      # False: _KaginModelFn's per-operation library calls (bit-identical; module attribute for the A/B test)
 _GINE_MODEL_NODE = True      # False: the model runs as its five kinds of tape nodes (bit-identical; module attribute for the A/B test)
 
 
@@ -552,6 +669,8 @@ def kagin_regression_forward(model, data):
     rparams = []
     for l in ro:
         rparams += [l.base_weight, l.spline_weight, l.spline_scaler if l.enable_standalone_scale_spline else None]
+    if _GINE_MODEL_CALL and H <= 64 and len(atabs) <= 16 and len(btabs) <= 16 and len(ro) <= 8:
+        return _KaginModelCallFn.apply(x, e, g, seg, plan, model, *atabs, *btabs, *sparams, *rparams)
     return _KaginModelFn.apply(x, e, g, seg, plan, *atabs, *btabs, *sparams, *rparams)
 
 

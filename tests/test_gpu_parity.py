@@ -810,9 +810,10 @@ def test_gine_conv_one_library_call_each_way_matches_the_composition(golden, mon
     pre = "kan.state."
     state = {k[len(pre):]: T(z[k], DEV) for k in z.files if k.startswith(pre)}
     res = {}
-    for how in ("model", "stack", "layer", "ops"):
-        monkeypatch.setattr(graph_ops, "_GINE_MODEL_NODE", how == "model")
-        monkeypatch.setattr(graph_ops, "_GINE_STACK_ABI", how in ("model", "stack"))
+    for how in ("call", "model", "stack", "layer", "ops"):
+        monkeypatch.setattr(graph_ops, "_GINE_MODEL_CALL", how == "call")
+        monkeypatch.setattr(graph_ops, "_GINE_MODEL_NODE", how in ("call", "model"))
+        monkeypatch.setattr(graph_ops, "_GINE_STACK_ABI", how in ("call", "model", "stack"))
         monkeypatch.setattr(graph_ops, "_GINE_LAYER_ABI", how != "ops")
         m.load_state_dict(state, strict=True)
         m = m.to(DEV).train()
@@ -829,6 +830,19 @@ def test_gine_conv_one_library_call_each_way_matches_the_composition(golden, mon
         res[how] = (pred.detach().clone(), float(loss), {k: p.grad.clone() for k, p in m.named_parameters()},
                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k}, names, pred.grad_fn,
                     {k: int(v) for k, v in m.state_dict().items() if "num_batches" in k})
+    # (round 6) the whole model as ONE library call each way (kagnn_kagin_model_fwd / _bwd, graph_ops._KaginModelCallFn): the library
+    # sequences the same entry points itself -- the same bits as the per-operation calls of _KaginModelFn, everywhere
+    cn_ = [n_ for n_ in res["call"][4] if not n_.endswith(("_bytes", "_sizes"))]
+    assert type(res["call"][5]).__name__ == "_KaginModelCallFnBackward", type(res["call"][5]).__name__
+    assert cn_.count("kagnn_kagin_model_fwd") == 1 and cn_.count("kagnn_kagin_model_bwd") == 1 and "kagnn_gine_kan_stack_fwd" not in cn_, cn_
+    assert len(cn_) <= 6, cn_                    # + the CSR build, the loss's two calls
+    assert torch.equal(res["call"][0], res["model"][0]) and res["call"][1] == res["model"][1]
+    assert set(res["call"][2]) == set(res["model"][2])
+    for k, gref in res["model"][2].items():
+        assert torch.equal(res["call"][2][k], gref), k
+    for k, v in res["model"][3].items():
+        assert torch.equal(res["call"][3][k], v), k
+    assert res["call"][6] == res["model"][6]
     # the whole forward as ONE tape node (graph_ops._KaginModelFn): the same library calls as the stack form, the same bits everywhere
     assert type(res["model"][5]).__name__ == "_KaginModelFnBackward" and type(res["stack"][5]).__name__ != "_KaginModelFnBackward"
     work_ = lambda names_: [n_ for n_ in names_ if not n_.endswith("_bytes")]
@@ -931,7 +945,7 @@ def test_model_node_steps_aside_when_it_does_not_cover_the_call(golden):
         m.atom_encoder = kagnn_amd.graph_models.AtomEncoder(32, [21])
         m.bond_encoder.bond_embedding_list = torch.nn.ModuleList([torch.nn.Embedding(4, 32)])
         return m.to(DEV)
-    node = lambda out: type(out.grad_fn).__name__ == "_KaginModelFnBackward"
+    node = lambda out: type(out.grad_fn).__name__ in ("_KaginModelFnBackward", "_KaginModelCallFnBackward")      # (round 6: the default is the one-call form)
     m = make().train()
     ref = m(d)
     assert node(ref)

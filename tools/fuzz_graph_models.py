@@ -19,7 +19,7 @@ from oracle import kan_oracle as orc
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 DEV = "cuda:0"
-bad = nodes_run = kinks = 0
+bad = nodes_run = calls_run = kinks = 0
 for case in range(cases):
     H = rng.choice([8, 16, 24, 32, 40, 48, 64])
     nconv, hl, G = rng.choice([2, 3, 4, 5]), rng.choice([1, 2, 3]), rng.choice([3, 4, 5])
@@ -54,17 +54,23 @@ for case in range(cases):
     label = f"case {case}: hidden {H} convs {nconv} chain {hl} grid {G} graphs {B} nodes {n} edges {e} atom tables {adims} bond tables {bdims} targets {targets}"
     try:
         res = {}
-        for how in ("model", "nodes", "layer", "ops"):
-            graph_ops._GINE_MODEL_NODE = how == "model"
-            graph_ops._GINE_STACK_ABI = how in ("model", "nodes")
+        for how in ("call", "model", "nodes", "layer", "ops"):
+            graph_ops._GINE_MODEL_CALL = how == "call"            # (round 6) the whole model as ONE library call each way
+            graph_ops._GINE_MODEL_NODE = how in ("call", "model")
+            graph_ops._GINE_STACK_ABI = how in ("call", "model", "nodes")
             graph_ops._GINE_LAYER_ABI = how != "ops"
             m = copy.deepcopy(m0)
             pred = m(d)
             nodes_run += how == "model" and type(pred.grad_fn).__name__ == "_KaginModelFnBackward"
+            calls_run += how == "call" and type(pred.grad_fn).__name__ == "_KaginModelCallFnBackward"
             loss = ops.l1_loss(pred, y)
             loss.backward()
             res[how] = ([pred.detach().clone(), loss.detach().clone()] + [p.grad.clone() for p in m.parameters()]
                         + [b_.clone() for b_ in m.buffers() if b_.dtype.is_floating_point])
+        for k, (a, b) in enumerate(zip(res["call"], res["model"])):
+            if not torch.equal(a, b):
+                raise AssertionError(f"tensor {k}: the one-call form differs from the one-node form by {float((a - b).abs().max()):.3e}")
+        copy.deepcopy(m)                                 # (a model that has run stays deep-copyable: its call template is plain bytes)
         for k, (a, b, c) in enumerate(zip(res["model"], res["nodes"], res["layer"])):
             if not torch.equal(a, b):
                 raise AssertionError(f"tensor {k}: the one-node form differs from the five-node form by {float((a - b).abs().max()):.3e}")
@@ -118,9 +124,9 @@ for case in range(cases):
         bad += 1
         print("FAIL", label, "->", str(ex)[:300], flush=True)
     finally:
-        graph_ops._GINE_MODEL_NODE = graph_ops._GINE_STACK_ABI = graph_ops._GINE_LAYER_ABI = True
+        graph_ops._GINE_MODEL_CALL = graph_ops._GINE_MODEL_NODE = graph_ops._GINE_STACK_ABI = graph_ops._GINE_LAYER_ABI = True
 if kinks > max(1, cases // 20):
     bad += 1
     print(f"FAIL {kinks} of {cases} cases needed the relu-kink allowance: that is not chance any more")
-print(f"failures: {bad}   (cases that ran as one tape node: {nodes_run} of {cases}; relu-kink allowance used by {kinks})")
+print(f"failures: {bad}   (cases that ran as one tape node: {nodes_run} of {cases}, as one library call each way: {calls_run}; relu-kink allowance used by {kinks})")
 sys.exit(1 if bad else 0)
