@@ -49,7 +49,7 @@ extern "C" {
 #define KAGNN_DTYPE_F32 0
 #define KAGNN_DTYPE_BF16 1
 
-int kagnn_version(void);          /* 250 = this header (240 + KAGNN_PREC_HALF; 240 = 230 + kagnn_gin_kan_layer_bwd_bn_sums; 230 = 220 + the *_affine entry points of a folded BatchNorm1d; 220 = 210 + the stage timer) */
+int kagnn_version(void);          /* 260 = this header (round 6: + the feature-sharded FastKAN entry points kagnn_fastkan_row_moments .. _shard_bwd_finish, + kagnn_kagin_model_*; 250 = 240 + KAGNN_PREC_HALF; 240 = 230 + kagnn_gin_kan_layer_bwd_bn_sums; 230 = 220 + the *_affine entry points of a folded BatchNorm1d; 220 = 210 + the stage timer) */
 const char* kagnn_last_error(void);
 
 /* Stage timer -- a measurement aid, off by default (no reference counterpart: the reference times whole epochs with
