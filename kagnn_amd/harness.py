@@ -83,16 +83,24 @@ def time_model(model, x, edge_index, y, mask, nb_epochs: int = 20, warmup: int =
         optimizer.step()
         return loss
 
-    for _ in range(warmup):
-        epoch()
-    if x.is_cuda:
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(nb_epochs):
-        losses.append(epoch())
-    if x.is_cuda:
-        torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / nb_epochs
+    # (round 6) the backward on the calling thread: on small graphs an epoch is ~1 ms of ~100 short kernels and handing its tape nodes
+    # to autograd's per-device worker thread costs more than running them (see train_graph_batches; KAGNN_CFG4_MT=1 for the A/B)
+    import os
+    mt_was = torch.autograd.is_multithreading_enabled()
+    torch.autograd.set_multithreading_enabled(os.environ.get("KAGNN_CFG4_MT", "0") == "1")
+    try:
+        for _ in range(warmup):
+            epoch()
+        if x.is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nb_epochs):
+            losses.append(epoch())
+        if x.is_cuda:
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / nb_epochs
+    finally:
+        torch.autograd.set_multithreading_enabled(mt_was)
     return float(np.round(dt, 6)), [float(l.detach()) for l in losses]
 
 
