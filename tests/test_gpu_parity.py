@@ -1050,7 +1050,7 @@ def test_library_calls_follow_the_current_stream():
         _lib.call = real_call
     torch.cuda.synchronize()
     # every library call of the pass -- forward on this thread, backward on autograd's -- was handed the side stream's handle
-    assert len(seen) > 40 and {n for n, _ in seen} >= {"kagnn_csr_build", "kagnn_csr_build_small", "kagnn_gine_kan_stack_bwd"}
+    assert len(seen) >= 25 and {n for n, _ in seen} >= {"kagnn_csr_build", "kagnn_csr_build_small", "kagnn_kagin_model_fwd", "kagnn_kagin_model_bwd"}      # (round 6: the graph-level model is one call each way)
     wrong = [(n, hex(h)) for n, h in seen if h != side.cuda_stream]
     assert not wrong and side.cuda_stream != torch.cuda.current_stream().cuda_stream, wrong[:5]
     assert len(got) == len(want)
