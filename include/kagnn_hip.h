@@ -787,6 +787,10 @@ typedef struct kagnn_kagin_model {
     const int32_t* rowptr; const int32_t* col; const int32_t* perm;        /* CSR by destination (kagnn_csr_build_small) */
     const int32_t* rowptr_t; const int32_t* col_t; const int32_t* perm_t;  /* ... and its transpose */
     const int32_t* seg_ptr;                                                /* [num_graphs + 1] node offsets */
+    /* edge_src != NULL: the library builds the CSR + transpose of THIS batch itself (kagnn_csr_build_small: num_edges, num_nodes
+     * <= 65 536) into `saved`, on a stream of its own beside the encoders and the weight packs, and ignores the six arrays above;
+     * csr_flags (2 ints, device) receives the out-of-range-id flags of that build for the caller's validation                    */
+    const int64_t* edge_src; const int64_t* edge_dst; int32_t* csr_flags;
     const float* knots;
     const float* base_weight[KAGNN_MODEL_MAX_LAYERS]; const float* spline_weight[KAGNN_MODEL_MAX_LAYERS];
     const float* spline_scaler[KAGNN_MODEL_MAX_LAYERS];

@@ -186,7 +186,7 @@ class KaginModel(ctypes.Structure):
         ("x_index", c_void_p), ("e_index", c_void_p),
         ("atom_table", c_void_p * MODEL_MAX_TABLES), ("bond_table", c_void_p * MODEL_MAX_TABLES),
         ("rowptr", c_void_p), ("col", c_void_p), ("perm", c_void_p), ("rowptr_t", c_void_p), ("col_t", c_void_p), ("perm_t", c_void_p),
-        ("seg_ptr", c_void_p), ("knots", c_void_p),
+        ("seg_ptr", c_void_p), ("edge_src", c_void_p), ("edge_dst", c_void_p), ("csr_flags", c_void_p), ("knots", c_void_p),
         ("base_weight", c_void_p * MODEL_MAX_LAYERS), ("spline_weight", c_void_p * MODEL_MAX_LAYERS), ("spline_scaler", c_void_p * MODEL_MAX_LAYERS),
         ("bn_weight", c_void_p * MODEL_MAX_CONVS), ("bn_bias", c_void_p * MODEL_MAX_CONVS),
         ("running_mean", c_void_p * MODEL_MAX_CONVS), ("running_var", c_void_p * MODEL_MAX_CONVS),

@@ -7,6 +7,7 @@ thread_local char g_err[512] = "";
 thread_local bool g_half_products = false;      // KAGNN_PREC_HALF for the duration of an entry-point call (split_common.h)
 thread_local DwDefer* g_dw_defer = nullptr;       // deferred weight-gradient slab reductions of a stack call (common.h)
 thread_local MomDefer* g_mom_defer = nullptr;     // column moments whose finish is folded into the norm's apply kernel (common.h)
+thread_local bool g_stack_prepacked = false;      // kagnn_kagin_model_fwd has packed the stack's layers together with the read-out's (one launch)
 
 size_t aggregate_ws_bytes(long num_hub_seg, int F);
 size_t aggregate_bf16_ws_bytes(long num_hub_seg, int F);
@@ -1548,7 +1549,7 @@ int kagnn_gine_kan_stack_fwd(const float* x, int64_t ldx, const float* edge_attr
         in_[k] = widths[k % L]; out_[k] = widths[k % L + 1];
         batch = use_split_dx(in_[k], out_[k], G, K, mode) && use_sparse_fwd(in_[k], out_[k], G, K, mode) && kan_fused_pack_ok(in_[k], out_[k], G + K);
     }
-    if (batch) { rc = kagnn_kan_pack_batch(nconv * L, bw, sw, sc, in_, out_, G, K, mode, pack_fwd, pack_dx, stream); if (rc) return rc; }
+    if (batch && !kagnn::g_stack_prepacked) { rc = kagnn_kan_pack_batch(nconv * L, bw, sw, sc, in_, out_, G, K, mode, pack_fwd, pack_dx, stream); if (rc) return rc; }
     const float* in = x;
     int64_t ldin = ldx;
     for (int i = 0; i < nconv; ++i) {
@@ -1650,6 +1651,8 @@ struct KmLayout {
     // `saved`: byte offsets
     size_t x0, ea, acts, h, stats, packs, pooled, ro_act[KAGNN_MODEL_MAX_READOUT], ro_pf[KAGNN_MODEL_MAX_READOUT], ro_pd[KAGNN_MODEL_MAX_READOUT], saved_total;
     size_t fb, db;                       // one stack layer's forward / input-gradient pack, 256-aligned
+    size_t csr[6];                       // rowptr, col, perm, rowptr_t, col_t, perm_t (int32) when the library builds the CSR itself
+    size_t fwd_csr_ws, csr_ws_bytes;     // ... and that build's scratch inside the forward workspace
     // workspaces: byte offsets of the fixed parts, then the shared scratch of the sub-calls
     size_t fwd_scratch, fwd_total;
     size_t bwd_gy[2], bwd_gh, bwd_gx0, bwd_gea, bwd_scratch, bwd_total;
@@ -1659,6 +1662,22 @@ struct KmLayout {
     size_t g_ro_bw[KAGNN_MODEL_MAX_READOUT], g_ro_sw[KAGNN_MODEL_MAX_READOUT], g_ro_sc[KAGNN_MODEL_MAX_READOUT];   // float offsets into grads
     bool ro_batch;                       // the read-out's packs in one launch (kagnn_kan_pack_batch)
 };
+
+// a stream + two events of the library's own, per host thread and device (created on first use, never destroyed: process lifetime)
+struct SideStream { hipStream_t st; hipEvent_t fork, join; };
+SideStream* side_stream() {
+    thread_local SideStream pool[64];
+    thread_local bool made[64] = {};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return nullptr;
+    if (!made[d]) {
+        if (hipStreamCreateWithFlags(&pool[d].st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&pool[d].fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&pool[d].join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        made[d] = true;
+    }
+    return &pool[d];
+}
 
 int km_check(const kagnn_kagin_model_t* m, const char* fn) {
     if (!m) return fail(KAGNN_ERR_ARG, "%s: null model", fn);
@@ -1702,6 +1721,14 @@ int km_layout(const kagnn_kagin_model_t* m, KmLayout& L, const char* fn) {
         batch = batch && rm == (int)m->readout_modes[0] && (rm == KAGNN_PREC_SPLIT || rm == KAGNN_PREC_HALF) && fout <= 64;
     }
     L.ro_batch = batch;
+    for (int k = 0; k < 6; ++k) L.csr[k] = 0;
+    L.csr_ws_bytes = 0;
+    if (m->edge_src) {
+        if (!m->edge_dst || !m->csr_flags || !kagnn_csr_small_ok((int64_t)E, (int64_t)N))
+            return fail(KAGNN_ERR_ARG, "%s: edge_src needs edge_dst, csr_flags and a graph kagnn_csr_build_small covers", fn);
+        for (int k = 0; k < 6; ++k) L.csr[k] = take(((k % 3 == 0) ? N + 1 : (E ? E : 1)) * sizeof(int32_t));
+        rc = kagnn_csr_small_workspace_bytes((int64_t)E, &L.csr_ws_bytes); if (rc) return rc;
+    }
     L.saved_total = o + 256;
     // forward workspace: the stack's, the read-out forwards' split-K scratch
     int32_t widths[9];
@@ -1727,7 +1754,7 @@ int km_layout(const kagnn_kagin_model_t* m, KmLayout& L, const char* fn) {
         rc = kagnn_embedding_bwd_workspace_bytes((int64_t)E, (int)m->bond_rows[t], (int)H, &a); if (rc) return rc;
         scratch_b = scratch_b > a ? scratch_b : a;
     }
-    L.fwd_scratch = 0; L.fwd_total = al256z(scratch_f) + 256;
+    L.fwd_scratch = 0; L.fwd_csr_ws = al256z(scratch_f); L.fwd_total = al256z(scratch_f) + al256z(L.csr_ws_bytes) + 256;
     size_t wmax = 1;
     for (int i = 0; i <= nr; ++i) wmax = wmax > (size_t)m->readout_widths[i] ? wmax : (size_t)m->readout_widths[i];
     o = 0;
@@ -1771,8 +1798,8 @@ int kagnn_kagin_model_fwd(const kagnn_kagin_model_t* m, void* stream) {
     KmLayout L;
     int rc = km_layout(m, L, __func__);
     if (rc) return rc;
-    KAGNN_CHECK_ARG(m->saved && m->workspace && m->out && m->x_index && m->rowptr && m->seg_ptr && m->knots, "null array");
-    KAGNN_CHECK_ARG(m->num_edges == 0 || (m->e_index && m->col && m->perm), "null edge array");       // (a batch of single atoms has none)
+    KAGNN_CHECK_ARG(m->saved && m->workspace && m->out && m->x_index && (m->rowptr || m->edge_src) && m->seg_ptr && m->knots, "null array");
+    KAGNN_CHECK_ARG(m->num_edges == 0 || (m->e_index && (m->edge_src || (m->col && m->perm))), "null edge array");       // (a batch of single atoms has none)
     KAGNN_CHECK_ARG((size_t)m->saved_bytes >= L.saved_total && (size_t)m->workspace_bytes >= L.fwd_total,
                     "saved / workspace too small (kagnn_kagin_model_sizes)");
     const int64_t N = m->num_nodes, E = m->num_edges, B = m->num_graphs;
@@ -1781,6 +1808,23 @@ int kagnn_kagin_model_fwd(const kagnn_kagin_model_t* m, void* stream) {
     unsigned char* ws = static_cast<unsigned char*>(m->workspace);
     float* x0 = reinterpret_cast<float*>(sv + L.x0);
     float* ea = reinterpret_cast<float*>(sv + L.ea);
+    // the batch's CSR + transpose, built by the library on a stream of its own: nothing before the first GINE aggregation depends on
+    // it, so the one-workgroup-per-direction sort (55 us for a 256-molecule batch) runs beside the encoders and the weight packs
+    const int32_t* rowptr = m->rowptr; const int32_t* col = m->col; const int32_t* perm = m->perm;
+    SideStream* side = nullptr;
+    if (m->edge_src) {
+        int32_t* a[6];
+        for (int k = 0; k < 6; ++k) a[k] = reinterpret_cast<int32_t*>(sv + L.csr[k]);
+        rowptr = a[0]; col = a[1]; perm = a[2];
+        side = side_stream();
+        if (side == nullptr) return fail(KAGNN_ERR_HIP, "%s: no side stream", __func__);
+        KAGNN_HIP(hipEventRecord(side->fork, as_stream(stream)));
+        KAGNN_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+        rc = kagnn_csr_build_small(m->edge_src, m->edge_dst, E, N, a[0], a[1], a[2], a[3], a[4], a[5], m->csr_flags, ws + L.fwd_csr_ws,
+                                   L.csr_ws_bytes, side->st);
+        if (rc) return rc;
+        KAGNN_HIP(hipEventRecord(side->join, side->st));
+    }
     // encoders: sum over the feature columns of one table each (models.py:244-281)
     for (int t = 0; t < (int)m->num_atom_tables; ++t) {
         rc = kagnn_embedding_fwd(m->x_index + t, m->x_stride, N, m->atom_table[t], (int32_t)m->atom_rows[t], H, x0, H, t > 0, stream);
@@ -1805,27 +1849,56 @@ int kagnn_kagin_model_fwd(const kagnn_kagin_model_t* m, void* stream) {
         mean[i] = reinterpret_cast<float*>(sv + L.stats) + (size_t)(2 * i) * H;
         rstd[i] = reinterpret_cast<float*>(sv + L.stats) + (size_t)(2 * i + 1) * H;
     }
-    rc = kagnn_gine_kan_stack_fwd(x0, H, ea, H, N, m->rowptr, m->col, m->perm, m->self_scale, nconv, nl, widths, m->base_weight, m->spline_weight,
+    // ONE pack launch for the stack's layers AND the read-out's where they share grid, order and mode (each layer's pack depends on
+    // its own weights only: the same bits as the two launches of the per-operation path)
+    const int nr = (int)m->num_readout, rG = (int)m->readout_grid_size, rK = (int)m->readout_spline_order;
+    void* rpf[KAGNN_MODEL_MAX_READOUT]; void* rpd[KAGNN_MODEL_MAX_READOUT];
+    int32_t rin[KAGNN_MODEL_MAX_READOUT], rout[KAGNN_MODEL_MAX_READOUT];
+    for (int i = 0; i < nr; ++i) { rpf[i] = sv + L.ro_pf[i]; rpd[i] = sv + L.ro_pd[i]; rin[i] = (int32_t)m->readout_widths[i]; rout[i] = (int32_t)m->readout_widths[i + 1]; }
+    bool packed_all = false;
+    {
+        int32_t md = mode;
+        ModeScope mode_scope_(md);
+        bool ok = nconv * nl + nr <= 16 && L.ro_batch && rG == G && rK == K && (int)m->readout_modes[0] == mode &&
+                  use_split_dx(H, H, G, K, md) && use_sparse_fwd(H, H, G, K, md) && kan_fused_pack_ok(H, H, G + K);
+        for (int i = 0; i < nr && ok; ++i)
+            ok = use_split_dx(rin[i], rout[i], G, K, md) && use_sparse_fwd(rin[i], rout[i], G, K, md) && kan_fused_pack_ok(rin[i], rout[i], G + K);
+        if (ok) {
+            const float* abw[16]; const float* asw[16]; const float* asc[16]; int32_t ain[16], aout[16]; void* apf[16]; void* apd[16];
+            int n = 0;
+            for (int k = 0; k < nconv * nl; ++k, ++n) { abw[n] = m->base_weight[k]; asw[n] = m->spline_weight[k]; asc[n] = m->spline_scaler[k]; ain[n] = H; aout[n] = H; apf[n] = pf[k]; apd[n] = pd[k]; }
+            for (int i = 0; i < nr; ++i, ++n) { abw[n] = m->readout_base_weight[i]; asw[n] = m->readout_spline_weight[i]; asc[n] = m->readout_spline_scaler[i]; ain[n] = rin[i]; aout[n] = rout[i]; apf[n] = rpf[i]; apd[n] = rpd[i]; }
+            rc = kagnn_kan_pack_batch(n, abw, asw, asc, ain, aout, G, K, mode, apf, apd, stream);
+            if (rc) return rc;
+            packed_all = true;
+        }
+    }
+    struct PrepackedScope {
+        bool prev;
+        explicit PrepackedScope(bool on) : prev(kagnn::g_stack_prepacked) { kagnn::g_stack_prepacked = on; }
+        ~PrepackedScope() { kagnn::g_stack_prepacked = prev; }
+    };
+    if (side) KAGNN_HIP(hipStreamWaitEvent(as_stream(stream), side->join, 0));
+    {
+    PrepackedScope prepacked_scope_(packed_all);
+    rc = kagnn_gine_kan_stack_fwd(x0, H, ea, H, N, rowptr, col, perm, m->self_scale, nconv, nl, widths, m->base_weight, m->spline_weight,
                                   m->spline_scaler, m->knots, G, K, mode, acts, pf, pd, m->bn_weight, m->bn_bias,
                                   const_cast<float* const*>(m->running_mean), const_cast<float* const*>(m->running_var), m->momentum, m->eps, h, mean, rstd,
                                   ws + L.fwd_scratch, (size_t)m->workspace_bytes - L.fwd_scratch, stream);
+    }
     if (rc) return rc;
     // global_add_pool, then the read-out chain
     float* pooled = reinterpret_cast<float*>(sv + L.pooled);
     rc = kagnn_segment_pool(h[nconv - 1], H, pooled, H, m->seg_ptr, B, H, 0, stream);
     if (rc) return rc;
-    const int nr = (int)m->num_readout, rG = (int)m->readout_grid_size, rK = (int)m->readout_spline_order;
-    void* rpf[KAGNN_MODEL_MAX_READOUT]; void* rpd[KAGNN_MODEL_MAX_READOUT];
-    int32_t rin[KAGNN_MODEL_MAX_READOUT], rout[KAGNN_MODEL_MAX_READOUT];
-    for (int i = 0; i < nr; ++i) { rpf[i] = sv + L.ro_pf[i]; rpd[i] = sv + L.ro_pd[i]; rin[i] = (int32_t)m->readout_widths[i]; rout[i] = (int32_t)m->readout_widths[i + 1]; }
-    if (L.ro_batch) {
+    if (L.ro_batch && !packed_all) {
         rc = kagnn_kan_pack_batch(nr, m->readout_base_weight, m->readout_spline_weight, m->readout_spline_scaler, rin, rout, rG, rK,
                                   (int32_t)m->readout_modes[0], rpf, rpd, stream);
         if (rc) return rc;
     }
     for (int i = 0; i < nr; ++i) {
         const int rm = (int)m->readout_modes[i];
-        if (!L.ro_batch) {
+        if (!L.ro_batch && !packed_all) {
             rc = kagnn_kan_pack(m->readout_base_weight[i], m->readout_spline_weight[i], m->readout_spline_scaler[i], rin[i], rout[i], rG, rK, rm, rpf[i], rpd[i], stream);
             if (rc) return rc;
         }
@@ -1844,8 +1917,8 @@ int kagnn_kagin_model_bwd(const kagnn_kagin_model_t* m, void* stream) {
     KmLayout L;
     int rc = km_layout(m, L, __func__);
     if (rc) return rc;
-    KAGNN_CHECK_ARG(m->saved && m->workspace && m->g_out && m->grads && m->x_index && m->rowptr_t && m->seg_ptr && m->knots, "null array");
-    KAGNN_CHECK_ARG(m->num_edges == 0 || (m->e_index && m->col_t && m->perm_t), "null edge array");
+    KAGNN_CHECK_ARG(m->saved && m->workspace && m->g_out && m->grads && m->x_index && (m->rowptr_t || m->edge_src) && m->seg_ptr && m->knots, "null array");
+    KAGNN_CHECK_ARG(m->num_edges == 0 || (m->e_index && (m->edge_src || (m->col_t && m->perm_t))), "null edge array");
     KAGNN_CHECK_ARG((size_t)m->saved_bytes >= L.saved_total && (size_t)m->workspace_bytes >= L.bwd_total,
                     "saved / workspace too small (kagnn_kagin_model_sizes)");
     const int64_t N = m->num_nodes, E = m->num_edges, B = m->num_graphs;
@@ -1899,7 +1972,13 @@ int kagnn_kagin_model_bwd(const kagnn_kagin_model_t* m, void* stream) {
     const float* ea = reinterpret_cast<const float*>(sv + L.ea);
     float* gx0 = reinterpret_cast<float*>(ws + L.bwd_gx0);
     float* gea = reinterpret_cast<float*>(ws + L.bwd_gea);
-    rc = kagnn_gine_kan_stack_bwd(gh, H, x0, H, ea, H, N, m->rowptr_t, m->col_t, m->perm_t, m->self_scale, nconv, nl, widths, m->spline_weight,
+    const int32_t* rowptr_t = m->rowptr_t; const int32_t* col_t = m->col_t; const int32_t* perm_t = m->perm_t;
+    if (m->edge_src) {                      // (built by the forward into `saved`)
+        rowptr_t = reinterpret_cast<const int32_t*>(static_cast<unsigned char*>(m->saved) + L.csr[3]);
+        col_t = reinterpret_cast<const int32_t*>(static_cast<unsigned char*>(m->saved) + L.csr[4]);
+        perm_t = reinterpret_cast<const int32_t*>(static_cast<unsigned char*>(m->saved) + L.csr[5]);
+    }
+    rc = kagnn_gine_kan_stack_bwd(gh, H, x0, H, ea, H, N, rowptr_t, col_t, perm_t, m->self_scale, nconv, nl, widths, m->spline_weight,
                                   m->spline_scaler, m->knots, G, K, mode, acts, pd, h, m->bn_weight, mean, rstd, gx0, H, gea, H, g_bn_w, g_bn_b, g_bw, g_sw,
                                   g_sc, ws + L.bwd_scratch, (size_t)m->workspace_bytes - L.bwd_scratch, stream);
     if (rc) return rc;

@@ -11,7 +11,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from .ops import (PREC_FP32, GraphIndex, _same_knots, _batchnorm_fwd_raw, _call, _fits32, _kan_bwd_input_raw, _kan_bwd_weight_raw, _kan_fwd_raw, _ld,
+from .ops import (PREC_FP32, GraphIndex, _defer_flag_check, _same_knots, _validate_pending, _batchnorm_fwd_raw, _call, _fits32, _kan_bwd_input_raw, _kan_bwd_weight_raw, _kan_fwd_raw, _ld,
                   _need_cuda, _on_operand_device, _ptr, _ptr_array, _rows, _segment_broadcast_raw, _segment_pool_raw, _sizes, _stream,
                   _weights_key, _ws, default_precision, graph_index, kan_pack_chain, split_like)
 
@@ -542,17 +542,26 @@ class _KaginModelCallFn(Function):
         xi, ei = x_int.contiguous(), e_int.contiguous()
         m = _model_struct(plan, params, owner)
         n, e, nb = xi.size(0), ei.size(0), seg.numel() - 1
-        if n != g.num_nodes or e != g.num_edges:
-            raise ValueError("x must have one row per node and edge_attr one per edge of the graph")
+        flags = edges = None
+        if isinstance(g, torch.Tensor):                # the raw edge_index: the library builds this batch's CSR inside the call
+            if g.size(1) != e:
+                raise ValueError("edge_attr must have one row per edge of edge_index")
+            edges = g if g.is_contiguous() else g.contiguous()
+            flags = torch.empty(2, dtype=torch.int32, device=xi.device)
+            m.edge_src, m.edge_dst, m.csr_flags = edges.data_ptr(), edges.data_ptr() + 8 * e, flags.data_ptr()
+            _validate_pending(xi.device)
+        else:
+            if n != g.num_nodes or e != g.num_edges:
+                raise ValueError("x must have one row per node and edge_attr one per edge of the graph")
+            m.rowptr, m.col, m.perm = g.rowptr.data_ptr(), g.col.data_ptr(), g.perm.data_ptr()
+            m.rowptr_t, m.col_t, m.perm_t = g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.perm_t.data_ptr()
         m.num_nodes, m.num_edges, m.num_graphs, m.x_stride, m.e_stride = n, e, nb, xi.size(1), ei.size(1)
         m.x_index, m.e_index = xi.data_ptr(), ei.data_ptr()
-        m.rowptr, m.col, m.perm = g.rowptr.data_ptr(), g.col.data_ptr(), g.perm.data_ptr()
-        m.rowptr_t, m.col_t, m.perm_t = g.rowptr_t.data_ptr(), g.col_t.data_ptr(), g.perm_t.data_ptr()
         m.seg_ptr = seg.data_ptr()
         skey = (n, e, nb, int(m.hidden), plan.n_atom, plan.n_bond, plan.nconv, plan.nl, plan.G, plan.K, plan.mode, plan.ro_G, plan.ro_K,
                 tuple(plan.ro_modes), tuple(int(m.readout_widths[i]) for i in range(plan.n_readout + 1)),
                 tuple(int(m.atom_rows[t]) for t in range(plan.n_atom)), tuple(int(m.bond_rows[t]) for t in range(plan.n_bond)),
-                tuple(params[-3 * plan.n_readout + 3 * i + 2] is not None for i in range(plan.n_readout)))
+                tuple(params[-3 * plan.n_readout + 3 * i + 2] is not None for i in range(plan.n_readout)), edges is not None)
         sizes = _MODEL_SIZES.get(skey)
         if sizes is None:
             outs = [ctypes.c_size_t(0) for _ in range(4)]
@@ -566,7 +575,11 @@ class _KaginModelCallFn(Function):
         out = torch.empty((nb, int(m.readout_widths[plan.n_readout])), dtype=torch.float32, device=dev)
         m.saved, m.saved_bytes, m.workspace, m.workspace_bytes, m.out = saved.data_ptr(), sizes[0], ws.data_ptr(), sizes[1], out.data_ptr()
         _call("kagnn_kagin_model_fwd", ctypes.byref(m), _stream())
-        ctx.save_for_backward(saved, xi, ei, seg, g.rowptr_t, g.col_t, g.perm_t, plan.knots, *plan.ro_knots, *params)
+        if flags is not None:
+            _defer_flag_check(flags)                   # (ids are clamped on the device; the flags are read without blocking later)
+            ctx.save_for_backward(saved, xi, ei, seg, plan.knots, *plan.ro_knots, *params)
+        else:
+            ctx.save_for_backward(saved, xi, ei, seg, g.rowptr_t, g.col_t, g.perm_t, plan.knots, *plan.ro_knots, *params)
         ctx.model, ctx.sizes, ctx.graph = m, sizes, g
         ctx.shapes = [None if t is None else tuple(t.shape) for t in params]
         return out
@@ -597,6 +610,27 @@ class _KaginModelCallFn(Function):
 
 
 _GINE_MODEL_CALL = True      # False: _KaginModelFn's per-operation library calls (bit-identical; module attribute for the A/B test)
+import os as _os
+# True (KAGNN_MODEL_CSR=1): the library builds the batch's CSR inside kagnn_kagin_model_fwd, on a stream of its own beside the encoders and
+# the weight packs (identical arrays).  Measured, NOT a gain: the two cross-stream waits cost the device about what the overlap hides
+# (same-box A/B 0.71-0.77 ms per step without, 0.77-0.82 with; profiles/r06_experiments.md 2) -- opt-in.
+_GINE_MODEL_CSR = _os.environ.get("KAGNN_MODEL_CSR", "0") == "1"
+
+
+def ops_small_csr() -> bool:
+    from . import ops
+    return ops._SMALL_CSR
+
+
+def ops_has_prefetched() -> bool:
+    from . import ops
+    return bool(ops._prefetched)
+
+
+def _lib_csr_small_ok(e: int, n: int) -> bool:
+    from . import _lib
+    return bool(_lib.load().kagnn_csr_small_ok(e, n))
+
 _GINE_MODEL_NODE = True      # False: the model runs as its five kinds of tape nodes (bit-identical; module attribute for the A/B test)
 
 
@@ -658,7 +692,12 @@ def kagin_regression_forward(model, data):
     if ro[0].in_features != H:
         return None
     from .graph_models import _segment_ptr
-    g = graph_index(data.edge_index, x.size(0), cache=False)
+    ei_raw = data.edge_index
+    in_call = (_GINE_MODEL_CALL and _GINE_MODEL_CSR and H <= 64 and len(atabs) <= 16 and len(btabs) <= 16 and len(ro) <= 8
+               and torch.is_tensor(ei_raw) and ei_raw.is_cuda and ei_raw.dtype == torch.int64 and ei_raw.dim() == 2 and ei_raw.size(0) == 2
+               and ops_small_csr() and _lib_csr_small_ok(int(ei_raw.size(1)), int(x.size(0))) and not ops_has_prefetched())
+    # (in_call: the library builds this batch's CSR itself, on its own stream beside the encoders and the weight packs)
+    g = ei_raw if in_call else graph_index(ei_raw, x.size(0), cache=False)
     seg = _segment_ptr(data)
     sparams, scales, running, momentum, eps = _gine_stack_args(convs, bns)
     plan = _ModelPlan()

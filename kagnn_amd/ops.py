@@ -273,12 +273,7 @@ class GraphIndex:
         flags = torch.empty(2, **i32)
         _call("kagnn_csr_build_small", _ptr(src), _ptr(dst), e, n, _ptr(self.rowptr), _ptr(self.col), _ptr(self.perm),
               _ptr(self.rowptr_t), _ptr(self.col_t), _ptr(self.perm_t), _ptr(flags), _ptr(ws), ws.numel(), _stream())
-        host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-        host.copy_(flags, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        self._flags = [host, ev, flags, False]
-        _pending_checks.setdefault(dev.index, []).append(self._flags)
+        self._flags = _defer_flag_check(flags)
 
     def validate(self, wait: bool = True) -> None:
         """raise if the edge list named node ids outside [0, num_nodes) (small-graph path; the rocPRIM path has already raised)"""
@@ -316,6 +311,20 @@ class GraphIndex:
         if transposed:
             return self.rowptr_t, self.col_t, self.perm_t, self.hub_seg_t, self.num_hub_seg_t
         return self.rowptr, self.col, self.perm, self.hub_seg, self.num_hub_seg
+
+
+def _defer_flag_check(flags: torch.Tensor):
+    """the out-of-range-id flags of a small-graph CSR build (2 ints on the device) travel to pinned host memory behind the launches
+    queued so far; the entry joins ``_pending_checks`` and is looked at -- without waiting -- when a later small graph is indexed, or
+    by ``flush_graph_checks()`` / ``GraphIndex.validate()``"""
+    dev = flags.device
+    host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+    host.copy_(flags, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    entry = [host, ev, flags, False]
+    _pending_checks.setdefault(dev.index, []).append(entry)
+    return entry
 
 
 _SMALL_CSR = True      # False: always the rocPRIM build (a module attribute for the bitwise tests; identical arrays)

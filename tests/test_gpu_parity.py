@@ -810,10 +810,11 @@ def test_gine_conv_one_library_call_each_way_matches_the_composition(golden, mon
     pre = "kan.state."
     state = {k[len(pre):]: T(z[k], DEV) for k in z.files if k.startswith(pre)}
     res = {}
-    for how in ("call", "model", "stack", "layer", "ops"):
-        monkeypatch.setattr(graph_ops, "_GINE_MODEL_CALL", how == "call")
-        monkeypatch.setattr(graph_ops, "_GINE_MODEL_NODE", how in ("call", "model"))
-        monkeypatch.setattr(graph_ops, "_GINE_STACK_ABI", how in ("call", "model", "stack"))
+    for how in ("call", "call_own_csr", "model", "stack", "layer", "ops"):
+        monkeypatch.setattr(graph_ops, "_GINE_MODEL_CALL", how.startswith("call"))
+        monkeypatch.setattr(graph_ops, "_GINE_MODEL_CSR", how == "call")       # the batch's CSR built inside the call / by ops.graph_index before it
+        monkeypatch.setattr(graph_ops, "_GINE_MODEL_NODE", how.startswith("call") or how == "model")
+        monkeypatch.setattr(graph_ops, "_GINE_STACK_ABI", how.startswith("call") or how in ("model", "stack"))
         monkeypatch.setattr(graph_ops, "_GINE_LAYER_ABI", how != "ops")
         m.load_state_dict(state, strict=True)
         m = m.to(DEV).train()
@@ -835,7 +836,12 @@ def test_gine_conv_one_library_call_each_way_matches_the_composition(golden, mon
     cn_ = [n_ for n_ in res["call"][4] if not n_.endswith(("_bytes", "_sizes"))]
     assert type(res["call"][5]).__name__ == "_KaginModelCallFnBackward", type(res["call"][5]).__name__
     assert cn_.count("kagnn_kagin_model_fwd") == 1 and cn_.count("kagnn_kagin_model_bwd") == 1 and "kagnn_gine_kan_stack_fwd" not in cn_, cn_
-    assert len(cn_) <= 6, cn_                    # + the CSR build, the loss's two calls
+    assert len(cn_) <= 5 and "kagnn_csr_build_small" not in cn_, cn_        # + the loss's two calls; the CSR build is inside the forward call
+    on_ = [n_ for n_ in res["call_own_csr"][4] if not n_.endswith(("_bytes", "_sizes"))]
+    assert on_.count("kagnn_csr_build_small") == 1 and on_.count("kagnn_kagin_model_fwd") == 1, on_
+    assert torch.equal(res["call"][0], res["call_own_csr"][0]) and res["call"][1] == res["call_own_csr"][1]
+    for k, gref in res["call_own_csr"][2].items():
+        assert torch.equal(res["call"][2][k], gref), k
     assert torch.equal(res["call"][0], res["model"][0]) and res["call"][1] == res["model"][1]
     assert set(res["call"][2]) == set(res["model"][2])
     for k, gref in res["model"][2].items():
@@ -1050,7 +1056,7 @@ def test_library_calls_follow_the_current_stream():
         _lib.call = real_call
     torch.cuda.synchronize()
     # every library call of the pass -- forward on this thread, backward on autograd's -- was handed the side stream's handle
-    assert len(seen) >= 25 and {n for n, _ in seen} >= {"kagnn_csr_build", "kagnn_csr_build_small", "kagnn_kagin_model_fwd", "kagnn_kagin_model_bwd"}      # (round 6: the graph-level model is one call each way)
+    assert len(seen) >= 25 and {n for n, _ in seen} >= {"kagnn_csr_build", "kagnn_kagin_model_fwd", "kagnn_kagin_model_bwd"}      # (round 6: the graph-level model is one call each way, its CSR build inside)
     wrong = [(n, hex(h)) for n, h in seen if h != side.cuda_stream]
     assert not wrong and side.cuda_stream != torch.cuda.current_stream().cuda_stream, wrong[:5]
     assert len(got) == len(want)
