@@ -445,7 +445,10 @@ def _worker_replicas(rank, world, port, out_dir):
                 ropt.step()
         for (name, a), b in zip(zip(mine.names, mine.params), ref.params):
             err = float((a - b).abs().max()) / max(1e-12, float(b.abs().max()))
-            assert err < 2e-5, (name, err)
+            # (six Adam steps: the all-reduce adds g_r / P in another association than the hand average, and Adam divides by sqrt(v) --
+            # on elements with tiny gradients a last-bit difference becomes a visible fraction of an lr-sized update; seen up to
+            # 2.6e-5 over runs whose lstsq-made initial weights differ in the last bit.  A dropped or doubled all-reduce is O(1).)
+            assert err < 5e-4, (name, err)
         # replicas stay bit-identical: same reduced gradients, same optimiser state
         flat = torch.cat([p.detach().reshape(-1) for p in mine.parameters()])
         gathered = [torch.empty_like(flat) for _ in range(world)]
