@@ -1282,3 +1282,36 @@ def test_prefetched_graph_index_is_the_same_index():
     big = torch.randint(0, 100000, (2, 200000), generator=g).to(DEV)
     assert not ops.prefetch_graph_index(big, 100000) and len(ops._prefetched) == 0
     ops.flush_graph_checks()
+
+
+@pytest.mark.parametrize("workload", ["headline", "config3", "fastkan", "model"])
+def test_bench_single_gpu_line_carries_the_contract(workload):
+    """`python bench.py --workload X` at a small size: ONE JSON line with the driver's contract fields, the roofline block, the memory
+    contract, and -- for the headline -- the cpu_baseline block and the secondary figures (model step, other layers, graph-level step)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--nodes", "30000", "--edges", "300000", "--steps", "3",
+           "--warmup", "1", "--no-traffic", "--cpu-sample", "3000", "--cpu-sample-only"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "peak_device_GB", "device_memory"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "edges/s" and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith(workload) and d["value"] > 0 and d["complete"] is True
+    units = 3 * 300000 if workload == "model" else 300000
+    assert abs(d["value"] - units / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and 0 < roof["frac"] < 1.5 and roof["peak"] > 0 and "traffic" in roof
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert d["peak_device_GB"] > 0 and d["device_memory"]["step_peak_over_resident_GB"] >= 0
+    if workload == "headline":
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+        sec = d["secondary"]
+        assert sec["model_step"]["ms_per_step"] > 0 and sec["graph_level_step"]["ms_per_step"] > 0 and len(sec["graph_level_step"]["repeats_ms_per_step"]) == 3
+        assert set(sec["other_layers"]) == {"config3", "fastkan"} and d["fp32_mode_ms_per_step"] > d["ms_per_step"]
