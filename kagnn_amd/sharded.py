@@ -21,6 +21,12 @@ the whole KAN chain runs on the row shard with replicated weights, one all-to-al
 column shards for the next convolution / BatchNorm.  Backward mirrors it; parameter gradients (a few hundred
 KB) are summed with an all-reduce.  8x less wire traffic and no partial-sum buffers.
 
+Round 6 -- SURVEY.md 8(e)'s other exchanges: ``ShardedGIFASTKANLayer`` (the FastKAN flavour: LayerNorm is the one reduction over the
+sharded axis, exchanged as 2 floats per row each way -- local (mean, M2) gathered and merged in rank order on the way forward, the two
+row sums of its backward all-reduced beside the weight gradient), ``ShardedNodeModel`` (``GKAN_Nodes`` / ``GFASTKAN_Nodes`` on column
+shards: shard-local BatchNorm1d, the skip read-out as an input-sharded layer closed by ONE all-reduce of the ``[N, classes]`` partial
+sums); config 4's replicas with one flat gradient all-reduce live in ``kagnn_amd.harness`` (``GradientReplicas``).
+
 ``local_ops`` exists so the communication
 logic can be exercised on CPU with gloo by the test-suite (which injects the oracle there); the
 default -- and the only thing the product uses -- is ``kagnn_amd.ops`` (HIP kernels, no fallback).
