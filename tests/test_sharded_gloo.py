@@ -736,6 +736,91 @@ def _gpu_worker_e2(rank, world, port, out_dir, f=32, hid=32, classes=10):
         dist.destroy_process_group()
 
 
+def _gpu_worker_e2_big(rank, world, port, out_dir):
+    """the round-6 sharded paths at REAL sizes, two processes on cuda:0: the FastKAN-GIN layer at 262 221 rows (the default 4 row
+    chunks: reduce-scatter / all-gather chunked and overlapped, LayerNorm exchange over all rows at once) and BASELINE config 2's
+    model shape -- GKAN_Nodes(gin, 3 layers, 128 features, hidden 64, 40 classes) on an arxiv-sized graph -- as a ShardedNodeModel
+    against the unsharded model's fused default path"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kagnn_amd
+        from kagnn_amd import ops
+        from kagnn_amd.sharded import ShardedGIFASTKANLayer, ShardedNodeModel
+        from oracle import kan_oracle as orc
+
+        def close(a, b, what, tol=1e-4):
+            err = float((a - b).abs().max()) / max(1e-300, float(b.abs().max()))
+            assert err <= tol, (what, err)
+
+        # ---- FastKAN-GIN layer, 4 row chunks by default
+        n, e, f = 262144 + 77, 1_500_000, 64
+        ei = orc.powerlaw_graph(n, e, seed=6).to(dev)
+        graph = ops.GraphIndex(ei, n)
+        gen = torch.Generator().manual_seed(6)
+        x = (torch.randn(n, f, generator=gen) * 0.3 + 0.2).to(dev)
+        gy = torch.randn(n, f, generator=gen).to(dev)
+        torch.manual_seed(21)
+        conv = kagnn_amd.GIFASTKANLayer(f, f, grid_size=8, hidden_dim=f, nb_layers=2).to(dev)
+        xr = x.clone().requires_grad_(True)
+        y_ref = conv(xr, graph)
+        y_ref.backward(gy)
+        w = f // world
+        sl = slice(rank * w, (rank + 1) * w)
+        sconv = ShardedGIFASTKANLayer(conv, None).to(dev)
+        xs = sconv.shard_columns(x).requires_grad_(True)
+        y = sconv(xs, graph)
+        y.backward(sconv.shard_columns(gy))
+        close(y, y_ref[:, sl], "big fastkan y")
+        close(xs.grad, xr.grad[:, sl], "big fastkan gx")
+        for li, (layer, full) in enumerate(zip(sconv.layers, conv.nn.layers)):
+            cols, ng, fo = layer.columns, layer.centers.numel(), full.output_dim
+            close(layer.spline_weight.grad, full.spline_linear.weight.grad.view(fo, -1, ng)[:, cols].reshape(fo, -1), f"big fastkan L{li} spline")
+            close(layer.ln_weight.grad, full.layernorm.weight.grad[cols], f"big fastkan L{li} ln_w")
+            close(layer.ln_bias.grad, full.layernorm.bias.grad[cols], f"big fastkan L{li} ln_b")
+        del conv, sconv, xr, xs, y, y_ref, x, gy, graph, ei
+        torch.cuda.empty_cache()
+
+        # ---- config 2's model shape on column shards
+        n, e, fin, hid, classes = 169_343, 1_166_243, 128, 64, 40
+        ei = orc.powerlaw_graph(n, e, seed=7).to(dev)
+        graph = ops.GraphIndex(ei, n)
+        gen = torch.Generator().manual_seed(7)
+        x = (torch.randn(n, fin, generator=gen) * 0.4).to(dev)
+        labels = torch.randint(0, classes, (n,), generator=gen).to(dev)
+        torch.manual_seed(22)
+        model = kagnn_amd.GKAN_Nodes("gin", 3, fin, hid, classes, grid_size=5, spline_order=3, hidden_layers=2).to(dev).train()
+        sm = ShardedNodeModel(model, None).to(dev).train()
+        xr = x.clone().requires_grad_(True)
+        out = model(xr, graph)
+        ops.softmax_cross_entropy(out, labels, None, pre_softmax=True).backward()
+        xs = sm.shard_columns(x).requires_grad_(True)
+        logits = sm(xs, graph)
+        close(logits, out, "arxiv-shaped logits", 2e-4)
+        ops.softmax_cross_entropy(logits, labels, None, pre_softmax=True).backward()
+        wi = fin // world
+        close(xs.grad, xr.grad[:, rank * wi:(rank + 1) * wi], "arxiv-shaped gx", 1e-3)      # (three norms deep, a mean-type loss: tiny gradients)
+        for ci, (sc, fc) in enumerate(zip(sm.convs, model.convs)):
+            for li, (layer, full) in enumerate(zip(sc.layers, fc.nn.layers)):
+                for name in ("base_weight", "spline_weight", "spline_scaler"):
+                    close(getattr(layer, name).grad, getattr(full, name).grad[:, layer.columns], f"arxiv-shaped convs.{ci}.{li}.{name}", 1e-3)
+        for name in ("base_weight", "spline_weight", "spline_scaler"):
+            close(getattr(sm.lay_out, name).grad, getattr(model.lay_out, name).grad[:, sm.lay_out.columns], f"arxiv-shaped lay_out.{name}", 1e-3)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_fastkan_layer_and_arxiv_shaped_node_model_two_ranks_one_gpu_real_sizes(tmp_path):
+    mp.spawn(_gpu_worker_e2_big, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_fastkan_node_models_and_replicas_ranks_on_one_gpu(tmp_path, world):
