@@ -355,3 +355,31 @@ def test_run_reference_resolves_the_scripts_own_import_lines(tmp_path):
         import torch_geometric  # noqa: F401
     except ImportError:
         assert rep["GNN_Nodes"].startswith("ImportError") and "torch_geometric" in rep["GNN_Nodes"]
+
+
+def test_kagin_model_struct_mirror_matches_the_header():
+    """kagnn_kagin_model_t (include/kagnn_hip.h) against its ctypes mirror kagnn_amd._lib.KaginModel: same size as the built library's
+    struct, and the same field names in the same order (every field is 8 bytes wide or a float array at the end, so name order + size
+    pin the layout)"""
+    import ctypes
+    src = open(os.path.join(ROOT, "include", "kagnn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef struct kagnn_kagin_model \{(.*?)\} kagnn_kagin_model_t;", src, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        # "const float* a[N]" / "int64_t a, b, c" / "const int32_t* rowptr" / "float* x[N]"
+        first, *rest = [p.strip() for p in decl.split(",")]
+        names.append(re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])?$", first).group(1))
+        names += [re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])?$", p).group(1) for p in rest]
+    mirror = [f[0] for f in _lib.KaginModel._fields_]
+    assert names == mirror, [(a, b) for a, b in zip(names, mirror) if a != b][:5]
+    lib = _lib.load()
+    assert lib.kagnn_kagin_model_struct_bytes() == ctypes.sizeof(_lib.KaginModel)
+    # size query on an out-of-range description: an error code and a message, not a crash
+    m = _lib.KaginModel()
+    outs = [ctypes.c_size_t(0) for _ in range(4)]
+    assert lib.kagnn_kagin_model_sizes(ctypes.byref(m), *[ctypes.byref(o) for o in outs]) != 0
+    assert b"kagnn_kagin_model" in lib.kagnn_last_error()
