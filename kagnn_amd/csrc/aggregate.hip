@@ -32,11 +32,16 @@ __device__ __forceinline__ void stats_products(const AggArgs& a, long row, int c
 }
 
 // STATS: also leave the workgroup's column sums of the rows it stores (and of their products with xhat) in
-// a.st_partial[blockIdx.x][2][F] -- rows of one workgroup meet in LDS and are added in row order (deterministic); hub rows
+// a.st_partial[row group][2][F] -- rows of one workgroup meet in LDS and are added in row order (deterministic); hub rows
 // contribute nothing here (their final value exists only in agg_hub_merge_kernel, which adds their share)
 template <int LPR, bool STATS = false>
 __global__ __launch_bounds__(256) void agg_rows_v4_kernel(AggArgs a) {
-    const long gid = (blockIdx.x * 256L + threadIdx.x) / LPR;
+    // XCD placement (speed only -- nothing depends on it): workgroups reach the 8 XCDs round-robin (block b runs on XCD b % 8:
+    // observed, not promised).  Each XCD takes ONE contiguous eighth of the row groups instead of every 8th one, so the rowptr / col
+    // lines two neighbouring row groups share land in one L2 instead of two: -0.012 ms of 0.868 per step at the headline graph
+    // (profiles/r06_experiments.md 6).  The launch rounds the grid up to whole eighths; `wg` is the row group, as blockIdx.x was.
+    const unsigned wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long gid = (wg * 256L + threadIdx.x) / LPR;
     const int c4 = (threadIdx.x % LPR) * 4;
     const bool live = gid < a.N && c4 < a.F;
     if (!STATS && !live) return;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void agg_rows_v4_kernel(AggArgs a) {
         __shared__ float4 s_a[256], s_b[256];
         s_a[threadIdx.x] = pa; s_b[threadIdx.x] = pb;
         __syncthreads();
-        if (threadIdx.x < LPR && c4 < a.F) {
+        if (threadIdx.x < LPR && c4 < a.F && wg * 256L < a.N * LPR) {      // (the grid's round-up row groups own no partial slot)
             constexpr int R = 256 / LPR;
 #pragma unroll 4
             for (int k = 1; k < R; ++k) {          // rows of the workgroup, in order
@@ -95,8 +100,8 @@ __global__ __launch_bounds__(256) void agg_rows_v4_kernel(AggArgs a) {
                 pa.x += u.x; pa.y += u.y; pa.z += u.z; pa.w += u.w;
                 pb.x += v.x; pb.y += v.y; pb.z += v.z; pb.w += v.w;
             }
-            *reinterpret_cast<float4*>(a.st_partial + (blockIdx.x * 2L + 0) * a.F + c4) = pa;
-            *reinterpret_cast<float4*>(a.st_partial + (blockIdx.x * 2L + 1) * a.F + c4) = pb;
+            *reinterpret_cast<float4*>(a.st_partial + (wg * 2L + 0) * a.F + c4) = pa;
+            *reinterpret_cast<float4*>(a.st_partial + (wg * 2L + 1) * a.F + c4) = pb;
         }
     }
 }
@@ -556,14 +561,15 @@ int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, float*
         agg_hub_merge_kernel<LPR, ST><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg, num_hub_seg, ws, ldp, (long)cdiv(a.N * LPR, 256)); \
         KAGNN_LAUNCH_CHECK();                                                                       \
     }
+#define AGG_ROWS_GRID(threads) (cdiv(cdiv((threads), 256), 8) * 8)        // whole eighths: one per XCD (see the kernel)
 #define ROWS(LPR)                                                                     \
     {                                                                                 \
         if (stats) {                                                                  \
-            agg_rows_v4_kernel<LPR, true><<<cdiv(a.N * LPR, 256), 256, 0, st>>>(b);   \
+            agg_rows_v4_kernel<LPR, true><<<AGG_ROWS_GRID(a.N * LPR), 256, 0, st>>>(b);   \
             KAGNN_LAUNCH_CHECK();                                                     \
             HUBS(LPR, true)                                                           \
         } else {                                                                      \
-            agg_rows_v4_kernel<LPR><<<cdiv(a.N * LPR, 256), 256, 0, st>>>(b);         \
+            agg_rows_v4_kernel<LPR><<<AGG_ROWS_GRID(a.N * LPR), 256, 0, st>>>(b);       \
             KAGNN_LAUNCH_CHECK();                                                     \
             HUBS(LPR, false)                                                          \
         }                                                                             \
@@ -579,6 +585,7 @@ int aggregate_sum(const AggArgs& a, const int* hub_seg, long num_hub_seg, float*
     else if (a.F <= 64) ROWS(16)
     else if (a.F <= 128) ROWS(32) else ROWS(64)
 #undef ROWS
+#undef AGG_ROWS_GRID
 #undef ROWS_EP
 #undef HUBS
     return KAGNN_OK;

@@ -80,7 +80,9 @@ __device__ __forceinline__ void finish_row(const Agg16Args& a, long row, int c8,
 
 template <int LPR, bool OUT16>
 __global__ __launch_bounds__(256) void agg16_rows_kernel(Agg16Args a) {
-    const long gid = (blockIdx.x * 256L + threadIdx.x) / LPR;
+    // one contiguous eighth of the row groups per XCD, as agg_rows_v4_kernel (aggregate.hip); the grid is whole eighths
+    const unsigned wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long gid = (wg * 256L + threadIdx.x) / LPR;
     const int c8 = (threadIdx.x % LPR) * 8;
     if (gid >= a.N || c8 >= a.F) return;
     const int s = a.rowptr[gid], t = a.rowptr[gid + 1];
@@ -192,7 +194,7 @@ static int run16(const Agg16Args& a, const int* hub_seg, long num_hub_seg, float
     const int ldp = (a.F + 7) & ~7;
 #define GO(LPR)                                                                                                   \
     {                                                                                                             \
-        agg16_rows_kernel<LPR, OUT16><<<cdiv(a.N * LPR, 256), 256, 0, st>>>(b);                                    \
+        agg16_rows_kernel<LPR, OUT16><<<cdiv(cdiv(a.N * LPR, 256), 8) * 8, 256, 0, st>>>(b);                       \
         KAGNN_LAUNCH_CHECK();                                                                                     \
         if (hubs) {                                                                                               \
             agg16_hub_kernel<LPR><<<(unsigned)num_hub_seg, 256, 0, st>>>(b, hub_seg, ws, ldp);                     \
