@@ -73,7 +73,7 @@ int kagnn_stage_timer_collect(char* names, int64_t* launches, double* total_ms, 
  *   perm[E]      = argsort(key, stable)                (bit-exact contract)
  *   col[E]       = val[perm]
  * (key=dst,val=src) gives the forward structure, (key=src,val=dst) its transpose for backward.
- * Rows whose degree exceeds `hub_threshold` are split into segments of L = max(hub_threshold/4, 32)
+ * Rows whose degree exceeds `hub_threshold` are split into segments of L = max(hub_threshold/4, 64)
  * edges, listed in hub_seg[3*i+{0,1,2}] = {row, e_begin, e_end} (a row's segments are contiguous
  * in e and its first one starts at rowptr[row]); *num_hub_seg_host receives their count (never
  * more than E/L + E/hub_threshold + 1, so size hub_seg for 3x that many int32).  This call

@@ -176,7 +176,19 @@ __global__ __launch_bounds__(256) void agg_hub_v4_kernel(AggArgs a, const int* _
     const int g = threadIdx.x / LPR, lg = threadIdx.x % LPR, c4 = lg * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < a.F) {
-        for (int e = e0 + g; e < e1; e += G) {
+        int e = e0 + g;
+        for (; e + 3 * G < e1; e += 4 * G) {   // four gathers of a lane group in flight; the sums keep the edge order
+            const int j0 = a.col[e], j1 = a.col[e + G], j2 = a.col[e + 2 * G], j3 = a.col[e + 3 * G];
+            const float4 v0 = ld4(a.x + (long)j0 * a.ldx + c4);
+            const float4 v1 = ld4(a.x + (long)j1 * a.ldx + c4);
+            const float4 v2 = ld4(a.x + (long)j2 * a.ldx + c4);
+            const float4 v3 = ld4(a.x + (long)j3 * a.ldx + c4);
+            fma4(acc, edge_w(a, e, j0, row), v0);
+            fma4(acc, edge_w(a, e + G, j1, row), v1);
+            fma4(acc, edge_w(a, e + 2 * G, j2, row), v2);
+            fma4(acc, edge_w(a, e + 3 * G, j3, row), v3);
+        }
+        for (; e < e1; e += G) {
             const int j = a.col[e];
             fma4(acc, edge_w(a, e, j, row), ld4(a.x + (long)j * a.ldx + c4));
         }

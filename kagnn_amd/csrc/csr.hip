@@ -40,8 +40,10 @@ __global__ void csr_hub_kernel(const int* __restrict__ rowptr, long N, int T, in
     if (i >= N) return;
     const int s = rowptr[i], t = rowptr[i + 1];
     if (t - s <= T) return;
-    const int L = max(T / 4, 32);                      // segment length: short segments = more workgroups per hub,
-    const int nseg = (t - s + L - 1) / L;             // a hub kernel is pure latency otherwise (<= T edges each, as documented)
+    // segment length: short segments = more workgroups per hub (a hub kernel is pure latency otherwise); 64, not 32, at the default
+    // threshold of 96: half the workgroups with four gathers per lane group in flight, -0.014 ms per step (profiles/r06_experiments.md 8)
+    const int L = max(T / 4, 64);
+    const int nseg = (t - s + L - 1) / L;
     const int base = atomicAdd(counter, nseg);
     for (int k = 0; k < nseg; ++k) {
         if (base + k < cap) {
